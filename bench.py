@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- atom-steps/s of the Martini MD inner loop on synthetic water.
+
+    python bench.py --gpus N --steps K --warmup W [--n LATTICE] [--no-cpu]
+
+One "step" is one NGLF velocity-Verlet step of the whole box (half kick, drift,
+image refresh, nonbonded + bonded forces with energy and virial, half kick +
+kinetic terms; neighbour-list rebuild every 20 steps inside the timed region).
+Workload at N=1: BASELINE.json's headline config, the 4.096M-bead Martini water
+box (n=160 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM.
+Prints ONE JSON line (rank 0).  `roofline` prices the nonbonded kernel with the
+ALGORITHMIC bytes of SURVEY 8(d): (36 + 24 + 4*L) B per atom-step, L = stored
+full-list entries per atom, over the HIP-event time of that kernel measured on
+the library's own stream.  `cpu_baseline` times the CPU oracle (a port of the
+reference's serial per-rank path; the reference itself cannot be built) on one
+host core on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DT_FS = 20.0
+
+
+def cpu_baseline(n_lattice, seconds_budget=20.0):
+    """Oracle (port of bioMartini.c/pairlist.c/nglf.c) on one core, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    import ddcmd_amd
+    import tempfile
+    native = os.path.join(tempfile.gettempdir(), "libddc_oracle_native_%d.so" % os.getpid())
+    try:
+        pyoracle.build(native=True, out=native)
+        libpath = native
+    except Exception:
+        libpath = None
+    s = ddcmd_amd.make_water_setup(n_lattice)
+    o = pyoracle.Oracle(s, libpath)
+    o.forces()
+    t0 = time.time()
+    o.step(1)
+    per = max(time.time() - t0, 1e-4)
+    steps = int(max(20, min(200, seconds_budget / per)))
+    steps = (steps // 20) * 20           # whole rebuild periods
+    o.step(20)                           # warm-up incl. one rebuild
+    t0 = time.time()
+    o.step(steps)
+    el = time.time() - t0
+    try:
+        os.remove(native)
+    except OSError:
+        pass
+    return {"value": s.natoms * steps / el, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+            "host_cores": os.cpu_count(),
+            "sample": "%d-bead Martini water (n=%d lattice), %d NGLF steps incl. %d list rebuilds, gcc -O3 -march=native, 1 thread"
+                      % (s.natoms, n_lattice, steps, steps // 20)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=160, help="lattice edge: n^3 beads (160 -> 4.096M)")
+    ap.add_argument("--cpu-n", type=int, default=40, help="lattice edge of the CPU-baseline sample (40 -> 64k beads)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import ddcmd_amd
+    from ddcmd_amd.martini import MartiniHIP
+    s = ddcmd_amd.make_water_setup(args.n)
+    m = MartiniHIP(s, device=local_rank)
+    m.eval_forces()                       # firstEnergyCall (masters.c:579)
+    st = m.list_stats()
+    m.step(args.warmup)
+    m.sync()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        m.sync()
+
+    m.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    m.step(args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    launches, kernel_ms = m.timing_read()
+    m.timing(False)
+    e, vir, rk, tion = m.energies()
+    st = m.list_stats()
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    natoms_total = s.natoms * world        # replicas until the RCCL decomposition lands
+    value = natoms_total * args.steps / el
+    L = st["entries"] / float(s.natoms)
+    bytes_per_atom = 36.0 + 24.0 + 4.0 * L
+    t_kernel = kernel_ms * 1e-3 / max(1, launches)
+    achieved = bytes_per_atom * s.natoms / t_kernel / 1e9
+    out = {
+        "metric": "atom_steps_per_sec", "value": value, "unit": "atom-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "ns_per_day": (args.steps / el) * DT_FS * 1e-6 * 86400.0,
+        "config": {"workload": "martini_water_%dk_beads" % (s.natoms // 1000), "beads_per_gpu": s.natoms, "lattice_n": args.n,
+                   "rcut_A": 12.0, "skin_A": 4.0, "dt_fs": DT_FS, "list_rebuild_every": int(s.updateRate),
+                   "energy_virial_every_step": True, "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                   "list_entries_per_atom": L, "image_atoms": st["images"], "rebuilds_in_timed_region": None},
+        "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches},
+        "check": {"epot": e["total"], "ekin": rk},
+    }
+    if rank == 0 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+    if rank == 0:
+        print(json.dumps(out))
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

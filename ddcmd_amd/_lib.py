@@ -1,0 +1,100 @@
+"""ctypes loader for libddcmi.so (the product).  Fails loudly when absent."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libddcmi.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Return the ctypes handle of libddcmi.so; raise LibraryMissing if it is not built.
+
+    There is deliberately no fallback: the HIP library *is* the implementation.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ddcmd_amd/csrc`)" % LIB_PATH)
+    _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    _declare(_lib)
+    return _lib
+
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_u64_p = ctypes.POINTER(ctypes.c_uint64)
+c_char_pp = ctypes.POINTER(ctypes.c_char_p)
+
+
+class CSetup(ctypes.Structure):
+    """Mirror of struct ddcmi_setup (ddcmd_amd/csrc/host/deck.h)."""
+    _fields_ = [
+        ("loop", ctypes.c_int64), ("maxloop", ctypes.c_int64), ("deltaloop", ctypes.c_int64),
+        ("time", ctypes.c_double), ("dt", ctypes.c_double),
+        ("printrate", ctypes.c_int), ("snapshotrate", ctypes.c_int), ("checkpointrate", ctypes.c_int),
+        ("h", ctypes.c_double * 9),
+        ("pbc", ctypes.c_int),
+        ("deltaR", ctypes.c_double),
+        ("updateRate", ctypes.c_int),
+        ("lx", ctypes.c_int), ("ly", ctypes.c_int), ("lz", ctypes.c_int),
+        ("rmax", ctypes.c_double), ("rcoulomb", ctypes.c_double), ("epsilon_r", ctypes.c_double),
+        ("epsilon_rf", ctypes.c_double), ("krf", ctypes.c_double), ("crf", ctypes.c_double), ("keR", ctypes.c_double),
+        ("excludePotentialTerm", ctypes.c_int), ("potentialShift", ctypes.c_int),
+        ("nlj", ctypes.c_int),
+        ("sigma", c_double_p), ("eps", c_double_p), ("shift", c_double_p),
+        ("nspecies", ctypes.c_int),
+        ("species_name", c_char_pp),
+        ("mass", c_double_p), ("charge", c_double_p),
+        ("ljtype", c_int_p), ("moltype", c_int_p), ("resitype", c_int_p), ("atomoffset", c_int_p),
+        ("nmoltype", ctypes.c_int),
+        ("mol_nspecies", c_int_p), ("bpair_off", c_int_p), ("bpairI", c_int_p), ("bpairJ", c_int_p),
+        ("nresi", ctypes.c_int),
+        ("resi_natoms", c_int_p),
+        ("bond_off", c_int_p), ("bondI", c_int_p), ("bondJ", c_int_p),
+        ("bond_kb", c_double_p), ("bond_b0", c_double_p),
+        ("angle_off", c_int_p), ("angleI", c_int_p), ("angleJ", c_int_p), ("angleK", c_int_p), ("angle_func", c_int_p),
+        ("angle_k", c_double_p), ("angle_t0", c_double_p),
+        ("tors_off", c_int_p), ("torsI", c_int_p), ("torsJ", c_int_p), ("torsK", c_int_p), ("torsL", c_int_p),
+        ("tors_func", c_int_p), ("tors_n", c_int_p),
+        ("tors_k", c_double_p), ("tors_delta", c_double_p),
+        ("ngroup", ctypes.c_int),
+        ("group_name", c_char_pp),
+        ("group_type", c_int_p),
+        ("group_Teq", c_double_p), ("group_tau", c_double_p),
+        ("group_interval", c_int_p),
+        ("natoms", ctypes.c_int),
+        ("rx", c_double_p), ("ry", c_double_p), ("rz", c_double_p),
+        ("vx", c_double_p), ("vy", c_double_p), ("vz", c_double_p),
+        ("gid", c_u64_p),
+        ("species", c_int_p), ("group", c_int_p),
+        ("nConstraints", ctypes.c_int),
+        ("integrator_type", ctypes.c_char_p),
+        ("has_accelerator", ctypes.c_int),
+        ("accelerator_type", ctypes.c_char_p),
+        ("u_pressure", ctypes.c_char_p), ("u_volume", ctypes.c_char_p), ("u_temperature", ctypes.c_char_p),
+        ("u_energy", ctypes.c_char_p), ("u_time", ctypes.c_char_p), ("u_length", ctypes.c_char_p),
+    ]
+
+
+def _declare(lib):
+    lib.ddcmi_deck_load_with.restype = ctypes.POINTER(CSetup)
+    lib.ddcmi_deck_load_with.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    lib.ddcmi_setup_free.restype = None
+    lib.ddcmi_setup_free.argtypes = [ctypes.POINTER(CSetup)]
+    lib.ddcmi_setup_sizeof.restype = ctypes.c_int
+    lib.units_convert.restype = ctypes.c_double
+    lib.units_convert.argtypes = [ctypes.c_double, ctypes.c_char_p, ctypes.c_char_p]
+    lib.units_ke.restype = ctypes.c_double
+    lib.units_kB.restype = ctypes.c_double
+    lib.units_ddcmd_defaults.restype = None
+    assert lib.ddcmi_setup_sizeof() == ctypes.sizeof(CSetup), "struct ddcmi_setup layout mismatch"

@@ -1,0 +1,329 @@
+/*
+ * bonded.hip -- Martini bonded terms on the device: one thread per TERM
+ * (the reference CUDA path uses one thread per atom looping its terms,
+ * bondedGPU.cu:1267-2672).  Formulas follow the CPU reference:
+ *   resBondSorted            bioCharmmCovalentEnergiesSorted.c:18-116
+ *   resAngleSorted           :118-242   (func 1)
+ *   resAngleCosineSorted     :244-363   (func 2)
+ *   resAngleRestrainSorted   :365-487   (func 10)
+ *   resTorsionSorted         :577-721   (func 1) via bioDihedralFast
+ *   resImproperSorted        :723-848   (func 2)   (bioCharmmCovalentEnergies.c:266-351)
+ * Term atoms are caller-order indices translated through slot_of_orig each
+ * launch (atoms are re-sorted at every rebuild).  Separations use the rint-based
+ * nearestImage (Preduce, preduce.c:282-338) like bioVec.  Forces go to the
+ * member atoms with FP64 hardware atomics (a handful per atom); energies and
+ * virial use per-block partials + a fixed-order second stage.
+ */
+#include "ddcmi_internal.h"
+#include <math.h>
+
+#define FLOAT_EPS 1e-08
+#define NEAR_ZERO_ANGLE 0.017453292519943295
+#define NEAR_180_ANGLE 3.12413936106985
+
+struct BoxArgs { double L[3]; double Linv[3]; int pbc; };
+
+__device__ __forceinline__ void bioVec(const BoxArgs &b, const double4 &p1, const double4 &p2, double &x, double &y, double &z)
+{
+   x = p1.x - p2.x; y = p1.y - p2.y; z = p1.z - p2.z;
+   if (b.pbc & 1) { double da = -rint(b.Linv[0] * x); x += b.L[0] * da; }
+   if (b.pbc & 2) { double db = -rint(b.Linv[1] * y); y += b.L[1] * db; }
+   if (b.pbc & 4) { double dc = -rint(b.Linv[2] * z); z += b.L[2] * dc; }
+}
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+   return v;
+}
+template <int NV>
+__device__ __forceinline__ void block_store(double (&v)[NV], double *out)
+{
+   __shared__ double s_red[4][NV];
+   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+   for (int k = 0; k < NV; k++)
+   {
+      double s = wsum(v[k]);
+      if (lane == 0) s_red[w][k] = s;
+   }
+   __syncthreads();
+   if (threadIdx.x < NV) out[threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+__device__ __forceinline__ void addf(double *fx, double *fy, double *fz, int i, double x, double y, double z)
+{
+   atomicAdd(&fx[i], x); atomicAdd(&fy[i], y); atomicAdd(&fz[i], z);
+}
+
+__global__ __launch_bounds__(256) void k_bond(int nbond, BoxArgs box, const int *__restrict__ ij, const double *__restrict__ kb, const double *__restrict__ b0,
+                                              const int *__restrict__ slot, const double4 *__restrict__ pos,
+                                              double *fx, double *fy, double *fz, double *partials)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* e, xx,yy,zz,xy,xz,yz */
+   if (t < nbond)
+   {
+      int I = slot[ij[2 * t]], J = slot[ij[2 * t + 1]];
+      double x, y, z;
+      bioVec(box, pos[I], pos[J], x, y, z);
+      double b = sqrt(x * x + y * y + z * z);
+      double bDelta = b - b0[t];
+      acc[0] = kb[t] * bDelta * bDelta;
+      double ux = x / b, uy = y / b, uz = z / b;
+      double kforce = -2 * kb[t] * bDelta;
+      double fxD = kforce * ux, fyD = kforce * uy, fzD = kforce * uz;
+      addf(fx, fy, fz, I, fxD, fyD, fzD);
+      addf(fx, fy, fz, J, -fxD, -fyD, -fzD);
+      acc[1] = fxD * x; acc[2] = fyD * y; acc[3] = fzD * z;
+      acc[4] = fxD * y; acc[5] = fxD * z; acc[6] = fyD * z;
+   }
+   block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
+}
+
+__global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, const int *__restrict__ ijk, const int *__restrict__ func,
+                                               const double *__restrict__ kt_, const double *__restrict__ t0_, int excl_mask,
+                                               const int *__restrict__ slot, const double4 *__restrict__ pos,
+                                               double *fx, double *fy, double *fz, double *partials)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   if (t < nangle)
+   {
+      int f = func[t];
+      bool skip = (f == 1 && (excl_mask & 2)) || (f == 2 && (excl_mask & 4)) || (f == 10 && (excl_mask & 256));
+      if (!skip)
+      {
+         int I = slot[ijk[3 * t]], J = slot[ijk[3 * t + 1]], K = slot[ijk[3 * t + 2]];
+         double4 pj = pos[J];
+         double ax, ay, az, cx, cy, cz;
+         bioVec(box, pos[I], pj, ax, ay, az);
+         bioVec(box, pos[K], pj, cx, cy, cz);
+         double b_ij = sqrt(ax * ax + ay * ay + az * az), b_kj = sqrt(cx * cx + cy * cy + cz * cz);
+         double uix = ax / b_ij, uiy = ay / b_ij, uiz = az / b_ij;
+         double ukx = cx / b_kj, uky = cy / b_kj, ukz = cz / b_kj;
+         double cosT = uix * ukx + uiy * uky + uiz * ukz;
+         double kt = kt_[t], t0 = t0_[t];
+         double coef_i, coef_k;
+         if (f == 1)
+         {
+            double a = acos(cosT);
+            double aDelta = a - t0;
+            acc[0] = kt * aDelta * aDelta;
+            double sinabs = sin(a);
+            coef_i = 2 * kt * aDelta / (b_ij * sinabs);
+            coef_k = 2 * kt * aDelta / (b_kj * sinabs);
+         }
+         else if (f == 2)
+         {
+            double aDelta = cosT - t0;
+            acc[0] = kt * aDelta * aDelta;
+            coef_i = -2 * kt * aDelta / b_ij;
+            coef_k = -2 * kt * aDelta / b_kj;
+         }
+         else
+         {
+            double sinAsq = 1 - cosT * cosT;
+            double aDelta = cosT - t0;
+            acc[0] = kt * aDelta * aDelta / sinAsq;
+            double coef_reb = -2 * kt * aDelta * (1 - cosT * t0) / (sinAsq * sinAsq);
+            coef_i = coef_reb / b_ij;
+            coef_k = coef_reb / b_kj;
+         }
+         double fxI = coef_i * (ukx - uix * cosT), fyI = coef_i * (uky - uiy * cosT), fzI = coef_i * (ukz - uiz * cosT);
+         double fxK = coef_k * (uix - ukx * cosT), fyK = coef_k * (uiy - uky * cosT), fzK = coef_k * (uiz - ukz * cosT);
+         addf(fx, fy, fz, I, fxI, fyI, fzI);
+         addf(fx, fy, fz, K, fxK, fyK, fzK);
+         addf(fx, fy, fz, J, -(fxI + fxK), -(fyI + fyK), -(fzI + fzK));
+         acc[1] = fxI * ax + fxK * cx; acc[2] = fyI * ay + fyK * cy; acc[3] = fzI * az + fzK * cz;
+         acc[4] = fxI * ay + fxK * cy; acc[5] = fxI * az + fxK * cz; acc[6] = fyI * az + fyK * cz;
+      }
+   }
+   block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
+}
+
+__global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, const int *__restrict__ ijkl, const int *__restrict__ func, const int *__restrict__ nn_,
+                                                 const double *__restrict__ kk_, const double *__restrict__ delta_, int excl_mask,
+                                                 const int *__restrict__ slot, const double4 *__restrict__ pos,
+                                                 double *fx, double *fy, double *fz, double *partials)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* e_tors, e_impr, xx,yy,zz,xy,xz,yz */
+   if (t < ntors)
+   {
+      int f = func[t];
+      bool skip = (f == 1 && (excl_mask & 16)) || (f == 2 && (excl_mask & 32));
+      if (!skip)
+      {
+         int I = slot[ijkl[4 * t]], J = slot[ijkl[4 * t + 1]], K = slot[ijkl[4 * t + 2]], L = slot[ijkl[4 * t + 3]];
+         double4 pI = pos[I], pJ = pos[J], pK = pos[K], pL = pos[L];
+         /* bioDihedralFast, bioCharmmCovalentEnergies.c:266-351 */
+         const double eps = 1e-12;
+         double ax, ay, az, bx, by, bz, cx, cy, cz;
+         bioVec(box, pI, pJ, ax, ay, az);
+         bioVec(box, pJ, pK, bx, by, bz);
+         bioVec(box, pK, pL, cx, cy, cz);
+         double a2 = ax * ax + ay * ay + az * az, b2 = bx * bx + by * by + bz * bz, c2 = cx * cx + cy * cy + cz * cz;
+         double ab = ax * bx + ay * by + az * bz, bc = bx * cx + by * cy + bz * cz, ac = ax * cx + ay * cy + az * cz;
+         double ff = ab * bc - ac * b2;
+         double g1 = a2 * b2 - ab * ab + eps;
+         double g2 = b2 * c2 - bc * bc + eps;
+         double yy = 1.0 / sqrt(g1 * g2);
+         double xx = yy * ff;
+         double xab = yy * bc + xx / g1 * ab;
+         double xbc = yy * ab + xx / g2 * bc;
+         double xac = -yy * b2;
+         double xaa = -0.5 * xx * b2 / g1;
+         double xcc = -0.5 * xx * b2 / g2;
+         double xbb = -yy * ac - 0.5 * xx * (a2 / g1 + c2 / g2);
+         double cax = xab * bx + xac * cx + (2 * xaa) * ax, cay = xab * by + xac * cy + (2 * xaa) * ay, caz = xab * bz + xac * cz + (2 * xaa) * az;
+         double cbx = xab * ax + xbc * cx + (2 * xbb) * bx, cby = xab * ay + xbc * cy + (2 * xbb) * by, cbz = xab * az + xbc * cz + (2 * xbb) * bz;
+         double ccx = xbc * bx + xac * ax + (2 * xcc) * cx, ccy = xbc * by + xac * ay + (2 * xcc) * cy, ccz = xbc * bz + xac * az + (2 * xcc) * cz;
+         double mx = ay * bz - az * by, my = az * bx - ax * bz, mz = ax * by - ay * bx;
+         double nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
+         double qx = my * nz - mz * ny, qy = mz * nx - mx * nz, qz = mx * ny - my * nx;
+         double signnum = bx * qx + by * qy + bz * qz;
+         double sign = (signnum < 0.0) ? -1.0 : 1.0;
+         xx = fmax(fmin(xx, 1.0), -1.0);
+         double ang = sign * acos(xx);
+         double sinX = sin(ang);
+         double v0 = -(cax * ax + cbx * bx + ccx * cx), v3 = -(cax * ay + cbx * by + ccx * cy), v4 = -(cax * az + cbx * bz + ccx * cz);
+         double v1 = -(cay * ay + cby * by + ccy * cy), v5 = -(cay * az + cby * bz + ccy * cz), v2 = -(caz * az + cbz * bz + ccz * cz);
+         double kk;
+         if (f == 1)
+         {
+            double kchi = kk_[t], delta = delta_[t];
+            int n = nn_[t];
+            acc[0] = kchi * (1 + cos(n * ang - delta));
+            if (fabs(sinX) > FLOAT_EPS) kk = kchi * n * sin(n * ang - delta) / sinX;
+            else
+            {
+               double nX = n * ang, nX2 = nX * nX, nX4 = nX2 * nX2, nX6 = nX4 * nX2, nX8 = nX4 * nX4, nX10 = nX8 * nX2;
+               double X2 = ang * ang, X4 = X2 * X2, X6 = X4 * X2, X8 = X4 * X4, X10 = X8 * X2;
+               double ratio = n * (1 - nX2 / 6 + nX4 / 120 - nX6 / 5040 + nX8 / 362880 - nX10 / 39916800) /
+                              (1 - X2 / 6 + X4 / 120 - X6 / 5040 + X8 / 362880 - X10 / 39916800);
+               if (delta < NEAR_ZERO_ANGLE) kk = kchi * n * ratio;
+               else if (delta > NEAR_180_ANGLE) kk = -kchi * n * ratio;
+               else kk = kchi * n * ratio;
+            }
+         }
+         else
+         {
+            double kpsi = kk_[t], psi0 = delta_[t];
+            double d = ang - psi0;
+            if (d < -M_PI) d += 2 * M_PI; else if (d > M_PI) d -= 2 * M_PI;
+            acc[1] = kpsi * d * d;
+            double absX = sinX < 0 ? -sinX : sinX;
+            if (absX > FLOAT_EPS) kk = -2 * kpsi * d / sinX;
+            else
+            {
+               double i2 = ang * ang, i4 = i2 * i2, i6 = i4 * i2, i8 = i4 * i4, i10 = i8 * i2;
+               kk = -2 * kpsi / (1 - i2 / 6 + i4 / 120 - i6 / 5040 + i8 / 362880 - i10 / 39916800);
+            }
+         }
+         addf(fx, fy, fz, I, -cax * kk, -cay * kk, -caz * kk);
+         addf(fx, fy, fz, J, -(cbx - cax) * kk, -(cby - cay) * kk, -(cbz - caz) * kk);
+         addf(fx, fy, fz, K, -(ccx - cbx) * kk, -(ccy - cby) * kk, -(ccz - cbz) * kk);
+         addf(fx, fy, fz, L, ccx * kk, ccy * kk, ccz * kk);
+         acc[2] = v0 * kk; acc[3] = v1 * kk; acc[4] = v2 * kk; acc[5] = v3 * kk; acc[6] = v4 * kk; acc[7] = v5 * kk;
+      }
+   }
+   block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_b(const double *partials, int nblocks, int nv, double *out)
+{
+   __shared__ double s[256];
+   for (int k = 0; k < nv; k++)
+   {
+      double a = 0.0;
+      for (int b = threadIdx.x; b < nblocks; b += 256) a += partials[(size_t)b * 8 + k];
+      s[threadIdx.x] = a;
+      __syncthreads();
+      for (int off = 128; off > 0; off >>= 1)
+      {
+         if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+         __syncthreads();
+      }
+      if (threadIdx.x == 0) out[k] = s[0];
+      __syncthreads();
+   }
+}
+
+template <class T>
+static int up(ddcmi_ctx *ctx, dbuf<T> &buf, const T *src, size_t n)
+{
+   if (n == 0) return DDCMI_OK;
+   ENSURE(ctx, buf, n);
+   HIPCHK(ctx, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
+                                int nbond, const int *bond_ij, const double *bond_kb, const double *bond_b0,
+                                int nangle, const int *angle_ijk, const int *angle_func, const double *angle_k, const double *angle_t0,
+                                int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
+                                int excludePotentialTerm)
+{
+   if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   ctx->excludePotentialTerm = excludePotentialTerm;
+   ctx->nbond = (excludePotentialTerm & 1) ? 0 : nbond;
+   ctx->nangle = nangle; ctx->ntors = ntors;
+   int rc;
+   if (ctx->nbond > 0)
+   {
+      if (!bond_ij || !bond_kb || !bond_b0) return DDCMI_EINVAL;
+      if ((rc = up(ctx, ctx->bond_ij, bond_ij, 2 * (size_t)nbond)) || (rc = up(ctx, ctx->bond_kb, bond_kb, nbond)) || (rc = up(ctx, ctx->bond_b0, bond_b0, nbond))) return rc;
+   }
+   if (nangle > 0)
+   {
+      if (!angle_ijk || !angle_func || !angle_k || !angle_t0) return DDCMI_EINVAL;
+      for (int t = 0; t < nangle; t++)
+         if (angle_func[t] != 1 && angle_func[t] != 2 && angle_func[t] != 10) SETERR(ctx, DDCMI_EINVAL, "angle %d: func %d is not 1, 2 or 10", t, angle_func[t]);
+      if ((rc = up(ctx, ctx->angle_ijk, angle_ijk, 3 * (size_t)nangle)) || (rc = up(ctx, ctx->angle_func, angle_func, nangle)) ||
+          (rc = up(ctx, ctx->angle_k, angle_k, nangle)) || (rc = up(ctx, ctx->angle_t0, angle_t0, nangle))) return rc;
+   }
+   if (ntors > 0)
+   {
+      if (!tors_ijkl || !tors_func || !tors_n || !tors_k || !tors_delta) return DDCMI_EINVAL;
+      for (int t = 0; t < ntors; t++)
+         if (tors_func[t] != 1 && tors_func[t] != 2) SETERR(ctx, DDCMI_EINVAL, "dihedral %d: func %d is not 1 or 2", t, tors_func[t]);
+      if ((rc = up(ctx, ctx->tors_ijkl, tors_ijkl, 4 * (size_t)ntors)) || (rc = up(ctx, ctx->tors_func, tors_func, ntors)) || (rc = up(ctx, ctx->tors_n, tors_n, ntors)) ||
+          (rc = up(ctx, ctx->tors_k, tors_k, ntors)) || (rc = up(ctx, ctx->tors_delta, tors_delta, ntors))) return rc;
+   }
+   ctx->forces_valid = false;
+   return DDCMI_OK;
+}
+
+int ddcmi_launch_bonded(ddcmi_ctx *ctx)
+{
+   if (ctx->nbond + ctx->nangle + ctx->ntors == 0) return DDCMI_OK;
+   hipStream_t st = ctx->stream;
+   BoxArgs box;
+   box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
+   for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
+   box.pbc = ctx->pbc;
+   int nbb = cdiv(ctx->nbond, 256), nab = cdiv(ctx->nangle, 256), ntb = cdiv(ctx->ntors, 256);
+   ENSURE(ctx, ctx->bpartials, (size_t)(nbb + nab + ntb + 3) * 8);
+   double *pb = ctx->bpartials.p, *pa = pb + (size_t)nbb * 8, *pt = pa + (size_t)nab * 8;
+   if (ctx->nbond > 0)
+   {
+      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, ctx->bond_ij.p, ctx->bond_kb.p, ctx->bond_b0.p, ctx->slot_of_orig.p, ctx->pos.p,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
+      hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pb, nbb, 7, ctx->d_results + R_SCR_BOND);
+   }
+   if (ctx->nangle > 0)
+   {
+      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, ctx->angle_ijk.p, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
+                         ctx->excludePotentialTerm, ctx->slot_of_orig.p, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
+      hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pa, nab, 7, ctx->d_results + R_SCR_ANGLE);
+   }
+   if (ctx->ntors > 0)
+   {
+      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, ctx->tors_ijkl.p, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
+                         ctx->excludePotentialTerm, ctx->slot_of_orig.p, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
+      hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pt, ntb, 8, ctx->d_results + R_SCR_TORS);
+   }
+   return DDCMI_OK;
+}

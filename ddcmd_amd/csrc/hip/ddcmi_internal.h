@@ -1,0 +1,129 @@
+/* ddcmi_internal.h -- private declarations shared by the .hip translation units. */
+#ifndef DDCMI_INTERNAL_H
+#define DDCMI_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "ddcmi.h"
+
+#define DDCMI_BLOCK 256
+
+/* cell grid over the local domain plus a margin of image/halo cells.
+ * Cells are numbered tile-major (4x4x4 cells per tile) so that 256 consecutive
+ * sorted atoms form a compact region instead of a long row. */
+struct GridParams
+{
+   double lo[3];     /* lower corner of the owned domain */
+   double L[3];      /* global box lengths */
+   double cinv[3];   /* 1/cell size */
+   double rlist;
+   int n[3];         /* interior cells */
+   int m[3];         /* margin cells per side (0 on non-periodic, undivided axes) */
+   int g[3];         /* n + 2m */
+   int T[3];         /* tiles = ceil(g/4) */
+   int pbc;
+   int ncell;        /* T0*T1*T2*64 */
+};
+
+template <class T> struct dbuf
+{
+   T *p = nullptr;
+   size_t cap = 0;
+   int ensure(size_t n, bool keep = false, hipStream_t s = 0)
+   {
+      if (n <= cap) return 0;
+      size_t ncap = n + n / 8 + 64;
+      T *q = nullptr;
+      if (hipMalloc((void **)&q, ncap * sizeof(T)) != hipSuccess) return -1;
+      if (keep && p && cap) { if (hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1; (void)hipStreamSynchronize(s); }
+      if (p) (void)hipFree(p);
+      p = q; cap = ncap;
+      return 0;
+   }
+   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+/* results block on the device / pinned host mirror */
+enum
+{
+   R_NB_LJ = 0, R_NB_ELE = 1, R_NB_VIR = 2,        /* raw full-list sums (x2) */
+   R_SCR_BOND = 8,                                 /* bonded kernels' reduced sums: {e, vir6} */
+   R_SCR_ANGLE = 16,                               /* {e, vir6} */
+   R_SCR_TORS = 24,                                /* {e_tors, e_impr, vir6} */
+   R_RK = 56, R_TION = 57,
+   R_E = 64,                                       /* final energies[DDCMI_NE] */
+   R_VIR = 72,                                     /* final virial[6] */
+   R_GROUP = 80,                                   /* per-group rk, count pairs */
+   R_FLAGS = 150,                                  /* ELL overflow etc (as doubles) */
+   R_SIZE = 160
+};
+
+struct ddcmi_ctx
+{
+   int device = 0;
+   hipStream_t stream = 0;
+   std::string err;
+   /* parameters */
+   double h[9] = {0}; int pbc = 7; bool have_box = false;
+   int nspecies = 0; std::vector<double> mass, charge; std::vector<int> ljtype, moltype;
+   int nlj = 0; std::vector<double> sigma, eps, shift; double rmax = 0, keR = 0, krf = 0, crf = 0;
+   int nmoltype = 0; std::vector<int> mol_nspecies, bpair_off, bpairI, bpairJ;
+   double deltaR = 0; int updateRate = 0;
+   int ngroup = 1; std::vector<int> gtype, ginterval; std::vector<double> gTeq, gtau;
+   std::vector<double> glambda, gTsum, gT; std::vector<int> gnT, gdoScaling;
+   int64_t loop = 0; double time = 0;
+   int excludePotentialTerm = 0;
+   bool has_charge = false;
+   /* device tables */
+   dbuf<double> d_invmass, d_mass, d_charge_sp; dbuf<int> d_ljtype_sp, d_moltype_sp;
+   dbuf<double4> d_ljtab;          /* nlj*nlj {sigma^2, 4eps, shift, 24eps} */
+   dbuf<int> d_mol_nspecies, d_bpair_off, d_bpairI, d_bpairJ;
+   /* particle state: [0,nloc) owned, [nloc,nloc+nhalo) images/halo */
+   int nloc = 0, nhalo = 0, npad = 0;
+   dbuf<double4> pos, pos2;
+   dbuf<double> vx, vy, vz, vx2, vy2, vz2, fx, fy, fz, qatom;
+   dbuf<int> species, species2, group, group2, orig, orig2, slot_of_orig;
+   dbuf<uint64_t> gid, gid2;
+   /* sort / cells */
+   GridParams gp;
+   dbuf<int> cid, crank, order, cell_cnt_o, cell_start_o, cell_cnt_h, cell_start_h, cell_start, cell_cnt;
+   dbuf<int> nimg, img_off, hsrc_t, hshift_t, hcid, hrank, horder, halo_src, halo_shift;
+   dbuf<int> scan_tmp;
+   /* lists */
+   int maxnbr = 0, maxexcl = 0;
+   dbuf<int> nbr, nbr_cnt, excl, excl_cnt;
+   bool list_valid = false;
+   int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
+   /* bonded */
+   int nbond = 0, nangle = 0, ntors = 0;
+   dbuf<int> bond_ij, angle_ijk, angle_func, tors_ijkl, tors_func, tors_n;
+   dbuf<double> bond_kb, bond_b0, angle_k, angle_t0, tors_k, tors_delta;
+   /* reductions */
+   dbuf<double> partials, bpartials; int npartial_blocks = 0;
+   double *d_results = nullptr; double *h_results = nullptr;
+   int *d_flags = nullptr; int *h_flags = nullptr;
+   double self_ele = 0.0;
+   bool forces_valid = false;
+   /* timing */
+   bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
+   /* comm */
+   int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1};
+};
+
+#define SETERR(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
+#define HIPCHK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { SETERR(ctx, DDCMI_ENODEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+#define ENSURE(ctx, buf, n) do { if ((buf).ensure((n)) != 0) SETERR(ctx, DDCMI_ENOMEM, "device allocation of %zu elements failed (%s:%d)", (size_t)(n), __FILE__, __LINE__); } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+/* scan.hip */
+int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
+/* bonded.hip */
+int ddcmi_launch_bonded(ddcmi_ctx *ctx);
+/* comm.hip */
+void ddcmi_comm_destroy(ddcmi_ctx *ctx);
+
+#endif

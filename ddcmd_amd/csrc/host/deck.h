@@ -1,0 +1,93 @@
+/*
+ * deck.h -- load a ddcMD input deck (object.data + restart + parmfile + atoms
+ * file) into one flat, plain-C description of the Martini hot path.
+ *
+ * Replaces, for this path only, what simulate_init / system_init /
+ * martini_parms / mmff_init / collection_read build as pointer graphs
+ * (simulate.c:104-297, system.c:79-214, bioMartini.c:1210-1353, bioMMFF.c,
+ * collection_read.c:86-200).  Every key and default follows those call sites.
+ */
+#ifndef DDCMI_DECK_H
+#define DDCMI_DECK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DDCMI_GROUP_FREE = 0, DDCMI_GROUP_BERENDSEN = 1, DDCMI_GROUP_LANGEVIN = 2, DDCMI_GROUP_OTHER = 3 };
+
+typedef struct ddcmi_setup
+{
+   /* SIMULATE (simulate.c:141-169,239-244) */
+   int64_t loop, maxloop, deltaloop;
+   double time, dt;
+   int printrate, snapshotrate, checkpointrate;
+   /* BOX (box.c:56-67) */
+   double h[9];
+   int pbc;
+   /* NEIGHBOR (neighbor.c:49-54), DDC (ddc.c:49-107) */
+   double deltaR;
+   int updateRate;
+   int lx, ly, lz;
+   /* POTENTIAL type=MARTINI (bioMartini.c:1210-1245, :876-879) */
+   double rmax, rcoulomb, epsilon_r, epsilon_rf, krf, crf, keR;
+   int excludePotentialTerm;
+   int potentialShift;
+   /* LJ atom types (mmff->nAtomType) */
+   int nlj;
+   double *sigma, *eps, *shift;     /* [nlj*nlj]; unset pairs are NaN */
+   /* SPECIES in ddcMD index order (molecule order, species.c:30) */
+   int nspecies;
+   char **species_name;
+   double *mass, *charge;
+   int *ljtype;       /* getCGLJindexbySpecie (bioMartini.c:952-987) */
+   int *moltype;      /* speciesIndexToMoleculeIndex (molecule.c:56) */
+   int *resitype;     /* index of the RESIPARMS the species belongs to */
+   int *atomoffset;   /* position of the atom inside its residue's atomList */
+   /* MOLECULE types + reOrgPairs exclusion lists (bioMartini.c:135-282,1416-1423) */
+   int nmoltype;
+   int *mol_nspecies, *bpair_off, *bpairI, *bpairJ;
+   /* RESIDUE types: bonded terms (genMartiniConn bioMartini.c:571-838) */
+   int nresi;
+   int *resi_natoms;
+   int *bond_off, *bondI, *bondJ;
+   double *bond_kb, *bond_b0;
+   int *angle_off, *angleI, *angleJ, *angleK, *angle_func;
+   double *angle_k, *angle_t0;
+   int *tors_off, *torsI, *torsJ, *torsK, *torsL, *tors_func, *tors_n;
+   double *tors_k, *tors_delta;
+   /* GROUPs (group.c:48-90, berendsen.c:91-113) */
+   int ngroup;
+   char **group_name;
+   int *group_type;
+   double *group_Teq, *group_tau;
+   int *group_interval;
+   /* atoms (collection_read.c:86-200), internal units */
+   int natoms;
+   double *rx, *ry, *rz, *vx, *vy, *vz;
+   uint64_t *gid;
+   int *species, *group;
+   int nConstraints;
+   /* INTEGRATOR / ACCELERATOR */
+   char *integrator_type;
+   int has_accelerator;
+   char *accelerator_type;
+   /* PRINTINFO unit strings (printinfo.c:51-64) */
+   char *u_pressure, *u_volume, *u_temperature, *u_energy, *u_time, *u_length;
+} ddcmi_setup;
+
+/* Load a deck.  object_file is required; restart_file may be NULL (then
+ * "restart" next to object_file is tried, as run_ddcMD_CPU.sh does).  Relative
+ * file names inside the deck (parmfile, atoms files) resolve against the
+ * directory of object_file.  Returns NULL and fills err on failure. */
+ddcmi_setup *ddcmi_deck_load(const char *object_file, const char *restart_file, char *err, int errlen);
+/* Same, but additional object text (e.g. overriding the integrator/group
+ * objects as SURVEY 8c prescribes) is compiled after the files. */
+ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_file, const char *extra_objects, char *err, int errlen);
+void ddcmi_setup_free(ddcmi_setup *s);
+int ddcmi_setup_sizeof(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,264 @@
+"""Python driver of the C-ABI (include/ddcmi.h) used by tests and bench.py.
+
+Mirrors the call order of ddcMD's own plugin glue: accelerator_init ->
+martini_parms (set_* calls) -> sendGPUState (upload) -> firstEnergyCall
+(eval_forces) -> eval_integrator (step_nglf).  No computation happens in Python.
+"""
+import ctypes
+import numpy as np
+from . import _lib
+
+E_NAMES = ("lj", "ele", "bond", "angle", "tors", "impr", "total")
+POS, VEL, FORCE = 1, 2, 4
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_up = ctypes.POINTER(ctypes.c_uint64)
+_MOLRES = np.uint64(0xFFFFFFFFFFFF0000)
+
+
+class DdcmiError(RuntimeError):
+    pass
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def _declare(lib):
+    if getattr(lib, "_ddcmi_declared", False):
+        return
+    vp = ctypes.c_void_p
+    lib.ddcmi_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.ddcmi_destroy.argtypes = [vp]
+    lib.ddcmi_destroy.restype = None
+    lib.ddcmi_last_error.argtypes = [vp]
+    lib.ddcmi_last_error.restype = ctypes.c_char_p
+    lib.ddcmi_version.restype = ctypes.c_char_p
+    lib.ddcmi_set_box.argtypes = [vp, _dp, ctypes.c_int]
+    lib.ddcmi_set_species.argtypes = [vp, ctypes.c_int, _dp, _dp, _ip, _ip]
+    lib.ddcmi_set_nonbonded.argtypes = [vp, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.ddcmi_set_molecules.argtypes = [vp, ctypes.c_int, _ip, _ip, _ip, _ip]
+    lib.ddcmi_set_bonded.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, ctypes.c_int, _ip, _ip, _dp, _dp,
+                                     ctypes.c_int, _ip, _ip, _ip, _dp, _dp, ctypes.c_int]
+    lib.ddcmi_set_neighbor.argtypes = [vp, ctypes.c_double, ctypes.c_int]
+    lib.ddcmi_set_groups.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, _ip]
+    lib.ddcmi_set_clock.argtypes = [vp, ctypes.c_int64, ctypes.c_double]
+    lib.ddcmi_get_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp]
+    lib.ddcmi_upload_state.argtypes = [vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up, _ip, _ip]
+    lib.ddcmi_download_state.argtypes = [vp, ctypes.c_int] + [_dp] * 9
+    lib.ddcmi_nlocal.argtypes = [vp]
+    lib.ddcmi_build_list.argtypes = [vp]
+    lib.ddcmi_eval_forces.argtypes = [vp, _dp, _dp]
+    lib.ddcmi_step_nglf.argtypes = [vp, ctypes.c_double, ctypes.c_int]
+    lib.ddcmi_get_energies.argtypes = [vp, _dp, _dp, _dp, _dp]
+    lib.ddcmi_kinetic.argtypes = [vp, _dp, _dp]
+    lib.ddcmi_group_temperatures.argtypes = [vp, _dp]
+    lib.ddcmi_sync.argtypes = [vp]
+    lib.ddcmi_list_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
+    lib.ddcmi_get_list.argtypes = [vp, ctypes.c_int, _ip, _ip, ctypes.POINTER(ctypes.c_int64)]
+    lib.ddcmi_timing_enable.argtypes = [vp, ctypes.c_int]
+    lib.ddcmi_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp, ctypes.c_int]
+    lib.ddcmi_stream.argtypes = [vp]
+    lib.ddcmi_stream.restype = vp
+    lib.ddcmi_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.ddcmi_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.ddcmi_comm_allreduce_sum.argtypes = [vp, _dp, ctypes.c_int]
+    lib._ddcmi_declared = True
+
+
+def expand_bonded_terms(s):
+    """Residue-relative bonded tables -> term lists over caller-order atom indices.
+
+    Follows charmmResidues (bioCharmmCovalent.c:48-93): sort atoms by gid, cut
+    residue runs at changes of gid & molResMask; term atoms are offsets into the run.
+    """
+    n = s.natoms
+    empty_i = np.zeros(0, np.int32)
+    out = {"bond_ij": empty_i, "bond_kb": np.zeros(0), "bond_b0": np.zeros(0),
+           "angle_ijk": empty_i, "angle_func": empty_i, "angle_k": np.zeros(0), "angle_t0": np.zeros(0),
+           "tors_ijkl": empty_i, "tors_func": empty_i, "tors_n": empty_i, "tors_k": np.zeros(0), "tors_delta": np.zeros(0)}
+    if s.nresi == 0 or (s.bond_off[-1] == 0 and s.angle_off[-1] == 0 and s.tors_off[-1] == 0):
+        return out
+    order = np.argsort(s.gid, kind="stable")
+    key = s.gid[order] & _MOLRES
+    first = np.flatnonzero(np.concatenate(([True], key[1:] != key[:-1])))
+    cnt = np.diff(np.concatenate((first, [n])))
+    rt = s.resitype[s.species[order[first]]]
+    if np.any(cnt != s.resi_natoms[rt]):
+        raise DdcmiError("incomplete residue in the particle set")
+    bi, bk, b0 = [], [], []
+    ai, af, ak, a0 = [], [], [], []
+    ti, tf, tn, tk, td = [], [], [], [], []
+    for r in range(s.nresi):
+        starts = first[rt == r]
+        if starts.size == 0:
+            continue
+        b = slice(s.bond_off[r], s.bond_off[r + 1])
+        if b.stop > b.start:
+            I = order[starts[:, None] + s.bondI[b][None, :]]
+            J = order[starts[:, None] + s.bondJ[b][None, :]]
+            bi.append(np.stack((I, J), axis=-1).reshape(-1, 2))
+            bk.append(np.tile(s.bond_kb[b], starts.size))
+            b0.append(np.tile(s.bond_b0[b], starts.size))
+        a = slice(s.angle_off[r], s.angle_off[r + 1])
+        if a.stop > a.start:
+            idx = [order[starts[:, None] + getattr(s, k)[a][None, :]] for k in ("angleI", "angleJ", "angleK")]
+            ai.append(np.stack(idx, axis=-1).reshape(-1, 3))
+            af.append(np.tile(s.angle_func[a], starts.size))
+            ak.append(np.tile(s.angle_k[a], starts.size))
+            a0.append(np.tile(s.angle_t0[a], starts.size))
+        t = slice(s.tors_off[r], s.tors_off[r + 1])
+        if t.stop > t.start:
+            idx = [order[starts[:, None] + getattr(s, k)[t][None, :]] for k in ("torsI", "torsJ", "torsK", "torsL")]
+            ti.append(np.stack(idx, axis=-1).reshape(-1, 4))
+            tf.append(np.tile(s.tors_func[t], starts.size))
+            tn.append(np.tile(s.tors_n[t], starts.size))
+            tk.append(np.tile(s.tors_k[t], starts.size))
+            td.append(np.tile(s.tors_delta[t], starts.size))
+
+    def cat(lst, dt):
+        return np.ascontiguousarray(np.concatenate(lst), dtype=dt) if lst else np.zeros(0, dt)
+
+    out.update(bond_ij=cat(bi, np.int32).ravel(), bond_kb=cat(bk, np.float64), bond_b0=cat(b0, np.float64),
+               angle_ijk=cat(ai, np.int32).ravel(), angle_func=cat(af, np.int32), angle_k=cat(ak, np.float64), angle_t0=cat(a0, np.float64),
+               tors_ijkl=cat(ti, np.int32).ravel(), tors_func=cat(tf, np.int32), tors_n=cat(tn, np.int32),
+               tors_k=cat(tk, np.float64), tors_delta=cat(td, np.float64))
+    return out
+
+
+class MartiniHIP(object):
+    """One device context running the Martini hot path for a Setup."""
+
+    def __init__(self, setup, device=0, upload=True):
+        self.lib = _lib.load_library()
+        _declare(self.lib)
+        self.s = setup
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.ddcmi_create(ctypes.byref(self.ctx), int(device))
+        if rc != 0:
+            raise DdcmiError("ddcmi_create failed (%d): %s" % (rc, self.lib.ddcmi_last_error(None).decode()))
+        s = setup
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self._chk(self.lib.ddcmi_set_box(self.ctx, _d(f64(s.h)), int(s.pbc)))
+        self._chk(self.lib.ddcmi_set_species(self.ctx, s.nspecies, _d(f64(s.mass)), _d(f64(s.charge)), _i(i32(s.ljtype)), _i(i32(s.moltype))))
+        self._chk(self.lib.ddcmi_set_nonbonded(self.ctx, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)),
+                                               s.rmax, s.keR, s.krf, s.crf))
+        if s.nmoltype > 0:
+            bi, bj = i32(s.bpairI), i32(s.bpairJ)
+            if bi.size == 0:
+                bi = bj = np.zeros(1, np.int32)
+            self._chk(self.lib.ddcmi_set_molecules(self.ctx, s.nmoltype, _i(i32(s.mol_nspecies)), _i(i32(s.bpair_off)), _i(bi), _i(bj)))
+        else:
+            self._chk(self.lib.ddcmi_set_molecules(self.ctx, 0, None, None, None, None))
+        t = self.terms = expand_bonded_terms(s)
+        nb, na, nt = t["bond_kb"].size, t["angle_k"].size, t["tors_k"].size
+        self._chk(self.lib.ddcmi_set_bonded(self.ctx, nb, _i(t["bond_ij"]), _d(t["bond_kb"]), _d(t["bond_b0"]),
+                                            na, _i(t["angle_ijk"]), _i(t["angle_func"]), _d(t["angle_k"]), _d(t["angle_t0"]),
+                                            nt, _i(t["tors_ijkl"]), _i(t["tors_func"]), _i(t["tors_n"]), _d(t["tors_k"]), _d(t["tors_delta"]),
+                                            int(s.excludePotentialTerm)))
+        self._chk(self.lib.ddcmi_set_neighbor(self.ctx, s.deltaR, int(s.updateRate)))
+        gt = i32(np.where(np.asarray(s.group_type) == 1, 1, 0))
+        self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
+        self._chk(self.lib.ddcmi_set_clock(self.ctx, int(s.loop), float(s.time)))
+        self.n = s.natoms
+        if upload:
+            self.upload(s.rx, s.ry, s.rz, s.vx, s.vy, s.vz)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DdcmiError("ddcmi error %d: %s" % (rc, self.lib.ddcmi_last_error(self.ctx).decode()))
+
+    def close(self):
+        if self.ctx:
+            self.lib.ddcmi_destroy(self.ctx)
+            self.ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, rx, rz_or_ry, rz=None, vx=None, vy=None, vz=None):
+        s = self.s
+        ry = rz_or_ry
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        a = [f64(x) for x in (rx, ry, rz)]
+        v = [f64(x) for x in (vx, vy, vz)] if vx is not None else [None, None, None]
+        gid = np.ascontiguousarray(s.gid, dtype=np.uint64)
+        sp = np.ascontiguousarray(s.species, dtype=np.int32)
+        gr = np.ascontiguousarray(s.group, dtype=np.int32)
+        self._chk(self.lib.ddcmi_upload_state(self.ctx, self.n, _d(a[0]), _d(a[1]), _d(a[2]), _d(v[0]), _d(v[1]), _d(v[2]),
+                                              gid.ctypes.data_as(_up), _i(sp), _i(gr)))
+
+    def build_list(self):
+        self._chk(self.lib.ddcmi_build_list(self.ctx))
+
+    def eval_forces(self):
+        e = np.zeros(7)
+        v = np.zeros(6)
+        self._chk(self.lib.ddcmi_eval_forces(self.ctx, _d(e), _d(v)))
+        return dict(zip(E_NAMES, e.tolist())), v
+
+    def step(self, nsteps=1, dt=None):
+        self._chk(self.lib.ddcmi_step_nglf(self.ctx, float(self.s.dt if dt is None else dt), int(nsteps)))
+
+    def energies(self):
+        e, v, t = np.zeros(7), np.zeros(6), np.zeros(6)
+        rk = ctypes.c_double(0)
+        self._chk(self.lib.ddcmi_get_energies(self.ctx, _d(e), _d(v), ctypes.byref(rk), _d(t)))
+        return dict(zip(E_NAMES, e.tolist())), v, rk.value, t
+
+    def kinetic(self):
+        t = np.zeros(6)
+        rk = ctypes.c_double(0)
+        self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
+        return rk.value, t
+
+    def group_temperatures(self):
+        T = np.zeros(max(1, self.s.ngroup))
+        self._chk(self.lib.ddcmi_group_temperatures(self.ctx, _d(T)))
+        return T
+
+    def download(self, mask=POS | VEL | FORCE):
+        n = self.n
+        out = [np.zeros(n) for _ in range(9)]
+        self._chk(self.lib.ddcmi_download_state(self.ctx, int(mask), *[_d(a) for a in out]))
+        return {"r": out[0:3], "v": out[3:6], "f": out[6:9]}
+
+    def sync(self):
+        self._chk(self.lib.ddcmi_sync(self.ctx))
+
+    def clock(self):
+        loop = ctypes.c_int64(0)
+        t = ctypes.c_double(0)
+        self._chk(self.lib.ddcmi_get_clock(self.ctx, ctypes.byref(loop), ctypes.byref(t)))
+        return loop.value, t.value
+
+    def list_stats(self):
+        st = (ctypes.c_int64 * 8)()
+        self._chk(self.lib.ddcmi_list_stats(self.ctx, st))
+        return {"entries": st[0], "excluded": st[1], "ell_width": st[2], "images": st[3], "cells": st[4], "rebuilds": st[5], "npad": st[6]}
+
+    def get_list(self, which=0):
+        n = self.n
+        tot = ctypes.c_int64(0)
+        start = np.zeros(n + 1, np.int32)
+        self._chk(self.lib.ddcmi_get_list(self.ctx, which, _i(start), None, ctypes.byref(tot)))
+        j = np.zeros(max(1, tot.value), np.int32)
+        self._chk(self.lib.ddcmi_get_list(self.ctx, which, _i(start), _i(j), ctypes.byref(tot)))
+        return start, j[:tot.value]
+
+    def timing(self, on=True):
+        self._chk(self.lib.ddcmi_timing_enable(self.ctx, 1 if on else 0))
+
+    def timing_read(self, reset=True):
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0)
+        self._chk(self.lib.ddcmi_timing_read(self.ctx, ctypes.byref(n), ctypes.byref(ms), 1 if reset else 0))
+        return n.value, ms.value

@@ -1,0 +1,129 @@
+"""Synthetic Martini water boxes: the bench / parity-test workload.
+
+Simple-cubic lattice of n^3 sites at the example deck's density
+(6173 beads / 93.858^3 A^3), uniform jitter +-0.5 A per axis, 10 % antifreeze beads
+(BP4, species WFxWF) chosen by splitmix64(seed ^ i) % 10 == 0, gid = i << 32 (one
+bead per molecule, like examples/waterbox), Maxwell-Boltzmann velocities at 310 K
+with the centre-of-mass velocity removed.  Force-field numbers are those of
+examples/waterbox/martini.data:45-47.  Everything is generated from splitmix64
+hashes so the same (n, seed) gives bit-identical inputs on every machine.
+"""
+import numpy as np
+from .deck import Setup, units_convert, GROUP_FREE, GROUP_BERENDSEN
+
+SEED = 20261002
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _uniform(seed, idx, stream):
+    """uniform in [0,1) from hash(seed, stream, idx)"""
+    with np.errstate(over="ignore"):
+        key = splitmix64(np.uint64(seed) ^ (np.uint64(stream) * np.uint64(0xD1342543DE82EF95))) ^ idx.astype(np.uint64)
+    bits = splitmix64(key) >> np.uint64(11)
+    return bits.astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def lj_shift(sigma, eps, rcut):
+    s6 = (sigma / rcut) ** 6
+    return -4.0 * eps * (s6 * s6 - s6)
+
+
+def water_forcefield(s, rcut_A=12.0, skin_A=4.0, dt_fs=20.0, update_rate=20):
+    """Fill the force-field/run-control part of a Setup like examples/waterbox does."""
+    s.dt = units_convert(dt_fs, "fs")
+    s.deltaR = units_convert(skin_A, "Angstrom")
+    s.updateRate = update_rate
+    s.rmax = units_convert(rcut_A, "Angstrom")
+    s.rcoulomb = s.rmax
+    s.epsilon_r, s.epsilon_rf = 15.0, -1.0
+    irc = 1.0 / s.rcoulomb
+    s.krf, s.crf = 0.5 * irc ** 3, 1.5 * irc
+    from . import _lib
+    s.keR = _lib.load_library().units_ke() / s.epsilon_r
+    s.nlj = 2                      # 0 = BP4, 1 = P4 (martini.data:8-9)
+    sig = np.zeros((2, 2))
+    eps = np.zeros((2, 2))
+    nm, kj = units_convert(1.0, "nm"), units_convert(1.0, "kJ*mol^-1")
+    sig[1, 1], eps[1, 1] = 0.47 * nm, 5.0 * kj
+    sig[0, 1] = sig[1, 0] = 0.57 * nm
+    eps[0, 1] = eps[1, 0] = 5.6 * kj
+    sig[0, 0], eps[0, 0] = 0.47 * nm, 5.0 * kj
+    s.sigma, s.eps = sig.ravel().copy(), eps.ravel().copy()
+    s.shift = lj_shift(s.sigma, s.eps, s.rmax)
+    s.nspecies = 2
+    s.species_name = ["WxW", "WFxWF"]
+    mass = units_convert(72.0, "M_p")
+    s.mass = np.array([mass, mass])
+    s.charge = np.zeros(2)
+    s.ljtype = np.array([1, 0], np.int32)
+    s.moltype = np.array([0, 1], np.int32)
+    s.resitype = np.array([0, 1], np.int32)
+    s.atomoffset = np.zeros(2, np.int32)
+    s.nmoltype = 2
+    s.mol_nspecies = np.array([1, 1], np.int32)
+    s.bpair_off = np.zeros(3, np.int32)
+    s.nresi = 2
+    s.resi_natoms = np.array([1, 1], np.int32)
+    s.bond_off = np.zeros(3, np.int32)
+    s.angle_off = np.zeros(3, np.int32)
+    s.tors_off = np.zeros(3, np.int32)
+    s.ngroup = 1
+    s.group_name = ["group"]
+    s.group_type = np.array([GROUP_FREE], np.int32)
+    s.group_Teq = np.zeros(1)
+    s.group_tau = np.zeros(1)
+    s.group_interval = np.ones(1, np.int32)
+    return s
+
+
+def make_water_setup(n, seed=SEED, temperature_K=310.0, rcut_A=12.0, skin_A=4.0, dt_fs=20.0,
+                     update_rate=20, thermostat=None):
+    """n^3-bead Martini water box (n=40: 64k, n=100: 1M, n=160: 4.096M)."""
+    s = Setup()
+    water_forcefield(s, rcut_A, skin_A, dt_fs, update_rate)
+    N = n * n * n
+    a_A = (93.858 ** 3 / 6173.0) ** (1.0 / 3.0)
+    ang = units_convert(1.0, "Angstrom")
+    L = n * a_A * ang
+    s.h = np.array([L, 0, 0, 0, L, 0, 0, 0, L], dtype=np.float64)
+    s.pbc = 7
+    idx = np.arange(N, dtype=np.uint64)
+    ix = (idx % np.uint64(n)).astype(np.float64)
+    iy = ((idx // np.uint64(n)) % np.uint64(n)).astype(np.float64)
+    iz = (idx // np.uint64(n * n)).astype(np.float64)
+    a = a_A * ang
+    jit = 0.5 * ang
+    s.rx = (ix + 0.5) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 1) - 1.0)
+    s.ry = (iy + 0.5) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 2) - 1.0)
+    s.rz = (iz + 0.5) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 3) - 1.0)
+    is_bp4 = (splitmix64(np.uint64(seed) ^ idx) % np.uint64(10)) == np.uint64(0)
+    s.species = is_bp4.astype(np.int32)          # 0 = WxW (P4), 1 = WFxWF (BP4)
+    s.group = np.zeros(N, np.int32)
+    s.gid = idx << np.uint64(32)
+    kT = units_convert(temperature_K, "K")       # kB = 1 in internal units
+    sig_v = np.sqrt(kT / s.mass[s.species])
+    vel = []
+    for c in range(3):
+        u1 = 1.0 - _uniform(seed + 1, idx, 10 + 2 * c)      # (0,1]
+        u2 = _uniform(seed + 1, idx, 11 + 2 * c)
+        vel.append(sig_v * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2))
+    m = s.mass[s.species]
+    for c in range(3):
+        vel[c] -= np.sum(m * vel[c]) / np.sum(m)
+    s.vx, s.vy, s.vz = vel
+    s.natoms = N
+    if thermostat == "berendsen":
+        s.group_type = np.array([GROUP_BERENDSEN], np.int32)
+        s.group_Teq = np.array([kT])
+        s.group_tau = np.array([units_convert(1.0, "ps")])
+    return s

@@ -1,0 +1,154 @@
+/*
+ * ddcmi.h -- C-ABI of libddcmi.so: the MI355X (gfx950) device side of ddcMD's
+ * Martini MD inner loop.  Plain pointers and sizes only; the caller owns host
+ * arrays, the library owns device memory.  Every call returns 0 on success or a
+ * negative DDCMI_E* code; ddcmi_last_error() gives the message.  No exceptions,
+ * no callbacks.  One host thread per context; all work is queued on the
+ * context's HIP stream and only the calls marked [sync] wait for it.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference/src).  All quantities are in ddcMD internal units (bohr, fs,
+ * Rydberg, e; kB = 1: ddcMD.c:71-73).  Particle arrays are in the CALLER's order
+ * on both upload and download; the library keeps its own cell-sorted order
+ * internally.
+ */
+#ifndef DDCMI_H
+#define DDCMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ddcmi_ctx ddcmi_ctx;
+
+enum
+{
+   DDCMI_OK = 0,
+   DDCMI_ENODEVICE = -1,    /* no HIP device / HIP runtime error */
+   DDCMI_EINVAL = -2,       /* bad argument or call order */
+   DDCMI_ENOMEM = -3,
+   DDCMI_EUNSUPPORTED = -4, /* e.g. non-orthorhombic box, box < 2*(rmax+deltaR) */
+   DDCMI_ECOMM = -5         /* RCCL error */
+};
+
+/* energies[] slots of ddcmi_eval_forces / ddcmi_get_energies (BIOENERGIES,
+ * bioCharmmParms.h; e->eion is slot DDCMI_E_TOTAL) */
+enum { DDCMI_E_LJ = 0, DDCMI_E_ELE, DDCMI_E_BOND, DDCMI_E_ANGLE, DDCMI_E_TORS, DDCMI_E_IMPR, DDCMI_E_TOTAL, DDCMI_NE };
+/* virial / tion component order (THREE_SMATRIX as summed in bioMartini.c:1098-1103) */
+enum { DDCMI_XX = 0, DDCMI_YY, DDCMI_ZZ, DDCMI_XY, DDCMI_XZ, DDCMI_YZ };
+/* download mask */
+enum { DDCMI_POS = 1, DDCMI_VEL = 2, DDCMI_FORCE = 4 };
+/* group (thermostat) kinds: free.c, berendsen.c */
+enum { DDCMI_FREE = 0, DDCMI_BERENDSEN = 1 };
+
+/* ---- context -------------------------------------------------------------
+ * replaces accelerator_init / accelerator_getAccelerator (accelerator.c:10-56)
+ * and the allocation half of allocSendGPUState / allocGPUBoxInfo
+ * (gpuMemUtils.cu).  device = HIP device ordinal. */
+int ddcmi_create(ddcmi_ctx **ctx, int device);
+void ddcmi_destroy(ddcmi_ctx *ctx);
+const char *ddcmi_last_error(const ddcmi_ctx *ctx);   /* ctx may be NULL: last create error */
+int ddcmi_device_count(void);                          /* hipGetDeviceCount; 0 without a GPU */
+const char *ddcmi_version(void);
+
+/* ---- parameters ------------------------------------------------------------ */
+/* BOX h (row-major 3x3, orthorhombic) and pbc bitmask: allocGPUBoxInfo */
+int ddcmi_set_box(ddcmi_ctx *ctx, const double h[9], int pbc);
+/* SPECIES tables: mass, charge (ddcenergy.c:210), LJ type (getCGLJindexbySpecie
+ * bioMartini.c:952), molecule type (molecule.c:56) */
+int ddcmi_set_species(ddcmi_ctx *ctx, int nspecies, const double *mass, const double *charge,
+                      const int *ljtype, const int *moltype);
+/* martiniNonBondGPUParms (bioMartiniGPU.h:8): LJ table [nlj*nlj] {sigma,eps,shift},
+ * rmax ("cutoff"), keR = ke/epsilon_r, krf, crf (bioMartini.c:1234-1245) */
+int ddcmi_set_nonbonded(ddcmi_ctx *ctx, int nlj, const double *sigma, const double *eps, const double *shift,
+                        double rmax, double keR, double krf, double crf);
+/* reOrgPairs inputs (bioMartini.c:1392-1485): per molecule type nSpecies and the
+ * bpairList (atmgrp codes) of its ownership residue.  nmoltype = 0: no MOLECULECLASS */
+int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_nspecies, const int *bpair_off,
+                        const int *bpairI, const int *bpairJ);
+/* martiniBondGPUParms (bioMartiniGPU.h:9): bonded terms as lists over CALLER-order
+ * atom indices.  angle func 1/2/10 = resAngleSorted/resAngleCosineSorted/
+ * resAngleRestrainSorted; tors func 1/2 = resTorsionSorted/resImproperSorted
+ * (bioCharmmCovalentEnergiesSorted.c).  excludePotentialTerm: bioCharmmParms.h:25-28 */
+int ddcmi_set_bonded(ddcmi_ctx *ctx,
+                     int nbond, const int *bond_ij, const double *bond_kb, const double *bond_b0,
+                     int nangle, const int *angle_ijk, const int *angle_func, const double *angle_k, const double *angle_t0,
+                     int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
+                     int excludePotentialTerm);
+/* NEIGHBOR deltaR (neighbor.c:49) and DDC updateRate (ddc.c:96; >0 required) */
+int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);
+/* GROUP objects (group.c:48-90): type DDCMI_FREE / DDCMI_BERENDSEN{Teq,tau,interval} */
+int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval);
+/* SIMULATE loop/time (simulate.c:146,155) */
+int ddcmi_set_clock(ddcmi_ctx *ctx, int64_t loop, double time);
+
+/* ---- state ----------------------------------------------------------------- */
+/* allocSendGPUState + sendGPUState + sendForceVelocityToGPU (gpuMemUtils.h):
+ * nlocal particles in caller order.  v may be NULL (zero). [sync] */
+int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal,
+                       const double *rx, const double *ry, const double *rz,
+                       const double *vx, const double *vy, const double *vz,
+                       const uint64_t *gid, const int *species, const int *group);
+/* sendHostState / sendForceVelocityToHost / sendPosnToHost: any pointer may be
+ * NULL; positions come back wrapped into the box like backInBox_fast
+ * (nglf.c:90). [sync] */
+int ddcmi_download_state(ddcmi_ctx *ctx, int mask,
+                         double *rx, double *ry, double *rz,
+                         double *vx, double *vy, double *vz,
+                         double *fx, double *fy, double *fz);
+int ddcmi_nlocal(const ddcmi_ctx *ctx);
+
+/* ---- hot path -------------------------------------------------------------- */
+/* constructList (nlistGPU.cu:1459; hook ddcUpdateAll.c:136-139): wrap, bin-sort,
+ * image atoms, full neighbour list within rmax+deltaR, exclusion split. [sync] */
+int ddcmi_build_list(ddcmi_ctx *ctx);
+/* martiniGPU1 (bioMartini.cu:146-171) = zeroGPUForceEnergyBuffers + charmmPairGPU
+ * + charmmConvalentGPU: forces on the device, energies[DDCMI_NE], virial[6].
+ * Builds the list first when none exists.  [sync] */
+int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *virial);
+/* nglfGPU (nglfGPU.cu:511; CPU contract nglf.c:67-112): nsteps velocity-Verlet
+ * steps fully on the device incl. rebuild every updateRate loops and
+ * kinetic_terms each step.  Not synchronising except at rebuilds. */
+int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps);
+/* sendForceEnergyToHost + kineticGPU: energies/virial of the last force
+ * evaluation, rk and tion[6] of the last kinetic_terms. [sync] */
+int ddcmi_get_energies(ddcmi_ctx *ctx, double *energies, double *virial, double *rk, double *tion);
+/* kinetic_terms (energy.c:48-163) on the current velocities. [sync] */
+int ddcmi_kinetic(ddcmi_ctx *ctx, double *rk, double *tion);
+/* eval_energyInfo group branch (energyInfo.c:118-141): refresh the per-group
+ * temperatures Berendsen reads; returns them in Tgroup[ngroup] if not NULL. [sync] */
+int ddcmi_group_temperatures(ddcmi_ctx *ctx, double *Tgroup);
+int ddcmi_get_clock(const ddcmi_ctx *ctx, int64_t *loop, double *time);
+int ddcmi_sync(ddcmi_ctx *ctx);
+
+/* ---- introspection / measurement ------------------------------------------- */
+/* list statistics of the last build: stats[0]=stored full-list entries,
+ * [1]=excluded-list entries, [2]=ELL width, [3]=image (halo) atoms, [4]=cells,
+ * [5]=rebuild count */
+int ddcmi_list_stats(const ddcmi_ctx *ctx, int64_t stats[8]);
+/* Copy the full neighbour list out as CSR over caller-order indices (image atoms
+ * are mapped back to their source atom). start[nlocal+1]; j may be NULL to query
+ * the size (returned through *nentries).  which: 0 kept, 1 excluded. [sync] */
+int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int64_t *nentries);
+/* HIP-event timing of the nonbonded kernel on the context's stream:
+ * enable, run, then read {launch count, total ms}.  [sync] on read */
+int ddcmi_timing_enable(ddcmi_ctx *ctx, int on);
+int ddcmi_timing_read(ddcmi_ctx *ctx, int64_t *launches, double *total_ms, int reset);
+/* native stream handle (hipStream_t) for callers that time with their own events */
+void *ddcmi_stream(ddcmi_ctx *ctx);
+
+/* ---- multi-GPU: spatial decomposition over RCCL ----------------------------
+ * replaces ddc_init / ddcAssignment / ddcSendRecvTables / ddcUpdate (ddc.c,
+ * ddcAssignment.c, ddcSendRecv.c, ddcUpdate.c).  The caller distributes the
+ * 128-byte id produced on rank 0 (MPI_Bcast in ddcMD, torch.distributed in
+ * bench.py).  With a full list no force return (ddcUpdateForce) is needed. */
+int ddcmi_comm_unique_id(char id[128]);
+int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char id[128], int px, int py, int pz);
+/* energyInfo.c:9-63 allreduce(): sum the 24-double ETYPE block across ranks */
+int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

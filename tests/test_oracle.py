@@ -1,0 +1,167 @@
+"""CPU tests: the oracle against the golden vectors and against its independent
+checks (O(N^2), finite differences, Newton's third law, NVE), the host deck
+loader, units.  No GPU needed."""
+import os
+import numpy as np
+import pytest
+
+import pyoracle
+import ddcmd_amd
+from ddcmd_amd.deck import units_convert, load_deck
+from ddcmd_amd.synth import make_water_setup
+
+REF_DECK = "/root/reference/examples/waterbox/object.data"
+
+
+def test_units_ddcmd_internal():
+    # ddcMD.c:71-73: bohr, fs, Rydberg; kB = 1; ke = e^2/(4 pi eps0) = 2 Ry*bohr
+    assert abs(units_convert(1.0, "Angstrom") - 1.0 / 0.52917721067) < 1e-12
+    assert abs(units_convert(1.0, "nm") - 10.0 / 0.52917721067) < 1e-11
+    assert abs(units_convert(1.0, "Ry") - 1.0) < 1e-14
+    assert abs(units_convert(2625.499638, "kJ*mol^-1") - 2.0) < 1e-6     # 1 Hartree
+    assert abs(units_convert(1.0, "ps") - 1000.0) < 1e-12
+    lib = ddcmd_amd.load_library()
+    assert abs(lib.units_ke() - 2.0) < 1e-8
+    assert abs(lib.units_kB() - 1.0) < 1e-7
+    # temperature unit: Ry/kB kelvin
+    assert abs(units_convert(157887.5, "K") - 1.0) < 1e-5
+    # "i*t" charge in e, "l" external length = Angstrom
+    assert abs(units_convert(1.0, "i*t") - 1.0) < 1e-14
+    assert abs(units_convert(1.0, "l") - units_convert(1.0, "Angstrom")) < 1e-15
+    # energy = mass * length^2 / time^2 closes in internal units
+    m = units_convert(1.0, "amu")
+    assert abs(m * units_convert(1.0, "Angstrom") ** 2 / units_convert(1.0, "fs") ** 2 - units_convert(1.0, "amu*Angstrom^2*fs^-2")) < 1e-12
+
+
+def test_golden_waterbox_oracle(waterbox):
+    """oracle reproduces the committed golden vectors bit-for-bit-ish (same code, same inputs)"""
+    s, g = waterbox
+    o = pyoracle.Oracle(s)
+    npairs = o.build_list()
+    assert npairs[0] == int(g["gold_npairs_list"])
+    e, vir = o.forces()
+    assert np.allclose([e[k] for k in pyoracle.E_NAMES], g["gold_e"], rtol=1e-13, atol=0)
+    assert np.allclose(vir, g["gold_virial"], rtol=1e-12)
+    for k, a in (("gold_fx", o.fx), ("gold_fy", o.fy), ("gold_fz", o.fz)):
+        assert np.abs(a - g[k]).max() <= 1e-15
+    # Newton's third law: total force vanishes
+    assert abs(o.fx.sum()) < 1e-13 and abs(o.fy.sum()) < 1e-13 and abs(o.fz.sum()) < 1e-13
+
+
+def test_oracle_vs_brute_force(waterbox):
+    """cell list + half list == O(N^2) with rint minimum image (independent path)"""
+    s, g = waterbox
+    o = pyoracle.Oracle(s)
+    e, vir = o.forces()
+    fx, fy, fz, vlj, vele, bvir, nin = o.brute_force()
+    assert nin == int(g["gold_npairs_cut"])
+    fmax = np.abs(o.fx).max()
+    assert max(np.abs(fx - o.fx).max(), np.abs(fy - o.fy).max(), np.abs(fz - o.fz).max()) < 1e-13 * fmax
+    assert abs(vlj - e["lj"]) < 1e-12 * abs(vlj)
+    assert np.allclose(bvir, vir, rtol=1e-11)
+
+
+def test_oracle_finite_difference_forces():
+    """forcetest.c:10-88 method: central differences of eion against analytic forces"""
+    s = make_water_setup(6)          # 216 beads, box 30.7 A: needs rlist < L/2
+    s.rmax = units_convert(9.0, "Angstrom")
+    s.deltaR = units_convert(2.0, "Angstrom")
+    s.shift = ddcmd_amd.synth.lj_shift(s.sigma, s.eps, s.rmax)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    f0 = np.stack([o.fx.copy(), o.fy.copy(), o.fz.copy()])
+    rng = np.random.RandomState(1)
+    delta = 1e-4
+    worst = 0.0
+    for i in rng.choice(s.natoms, 10, replace=False):
+        for c, arr in enumerate((o.rx, o.ry, o.rz)):
+            x0 = arr[i]
+            arr[i] = x0 + delta
+            o.build_list()
+            ep = o.forces()[0]["total"]
+            arr[i] = x0 - delta
+            o.build_list()
+            em = o.forces()[0]["total"]
+            arr[i] = x0
+            fd = -(ep - em) / (2 * delta)
+            worst = max(worst, abs(fd - f0[c, i]) / np.abs(f0).max())
+    assert worst < 1e-6
+
+
+def test_oracle_virial_vs_volume_derivative():
+    """testPressure method (masters.c:134-202): tr(virial) = -3V dE/dV under uniform scaling"""
+    s = make_water_setup(6)
+    s.rmax = units_convert(9.0, "Angstrom")
+    s.deltaR = units_convert(2.0, "Angstrom")
+    s.shift = 0.0 * s.shift          # un-shifted so E depends on V only through r
+    o = pyoracle.Oracle(s)
+    e0, vir = o.forces()
+
+    def energy_scaled(lam):
+        s2 = make_water_setup(6)
+        s2.rmax, s2.deltaR, s2.shift = s.rmax, s.deltaR, s.shift
+        s2.h = s.h * lam
+        s2.rx, s2.ry, s2.rz = s.rx * lam, s.ry * lam, s.rz * lam
+        o2 = pyoracle.Oracle(s2)
+        return o2.forces()[0]["total"]
+    d = 1e-5
+    dEdlam = (energy_scaled(1 + d) - energy_scaled(1 - d)) / (2 * d)
+    # E(lam r): dE/dlam = sum_pairs dV/dr * r = -sum f.d = -tr(virial); truncation at rmax
+    # adds a surface term for pairs crossing the cutoff, small for d -> 0
+    assert abs(dEdlam + (vir[0] + vir[1] + vir[2])) < 2e-3 * abs(vir[0] + vir[1] + vir[2])
+
+
+def test_oracle_nve_energy_conservation():
+    """velocity-Verlet: the energy error is O(dt^2) (shadow Hamiltonian) and does not drift"""
+    errs = {}
+    for dt, nsteps in ((2.0, 60), (1.0, 120)):
+        s = make_water_setup(8, dt_fs=dt)
+        s.rmax = units_convert(11.0, "Angstrom")
+        s.deltaR = units_convert(4.0, "Angstrom")
+        s.shift = ddcmd_amd.synth.lj_shift(s.sigma, s.eps, s.rmax)
+        o = pyoracle.Oracle(s)
+        e, _ = o.forces()
+        rk, _ = o.kinetic()
+        e0 = e["total"] + rk
+        tr = []
+        for _ in range(nsteps // 20):
+            e, _, rk, _ = o.step(20)
+            tr.append(e["total"] + rk - e0)
+        errs[dt] = tr
+        assert abs(tr[-1] - tr[-2]) < 0.1 * abs(tr[-1])        # plateau, no drift
+        assert abs(tr[-1]) < 2e-3 * rk
+    ratio = errs[2.0][-1] / errs[1.0][-1]
+    assert 3.0 < ratio < 5.0
+
+
+def test_synth_generator_is_deterministic():
+    a, b = make_water_setup(5), make_water_setup(5)
+    assert np.array_equal(a.rx, b.rx) and np.array_equal(a.vz, b.vz) and np.array_equal(a.species, b.species)
+    assert a.natoms == 125
+    assert abs(np.sum(a.mass[a.species] * a.vx)) < 1e-12
+    frac = a.species.mean()
+    big = make_water_setup(20)
+    assert 0.08 < big.species.mean() < 0.12
+    # kinetic temperature close to 310 K (kB = 1)
+    T = np.sum(big.mass[big.species] * (big.vx ** 2 + big.vy ** 2 + big.vz ** 2)) / (3 * big.natoms)
+    assert abs(T / units_convert(310.0, "K") - 1) < 0.03
+    # gid convention of the deck: one bead per molecule, gid = i << 32
+    assert int(big.gid[3]) == 3 << 32
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DECK), reason="reference deck only exists in the build container")
+def test_deck_loader_on_reference_waterbox(waterbox):
+    """host C loader on the real deck == the committed fixture"""
+    s0, g = waterbox
+    extra = "nglf INTEGRATOR {type = NGLF;}\n group GROUP { type = FREE; }\n free GROUP { type = FREE; }\n"
+    s = load_deck(REF_DECK, None, extra)
+    assert s.natoms == 6173 and s.nspecies == 2 and s.species_name == ["WxW", "WFxWF"]
+    assert np.array_equal(s.gid, s0.gid) and np.array_equal(s.species, s0.species)
+    assert np.array_equal(s.rx, s0.rx) and np.allclose(s.sigma, s0.sigma, rtol=0, atol=0)
+    assert s.integrator_type == "NGLF" and s.updateRate == 20 and s.maxloop == 10
+    assert abs(s.rmax - units_convert(11.0, "Angstrom")) < 1e-13
+    assert abs(s.h[0] - units_convert(93.858, "Angstrom")) < 1e-12
+    assert abs(s.dt - 20.0) < 1e-15
+    # the shipped selection (no override) is NGLFCONSTRAINT + LANGEVIN groups
+    raw = load_deck(REF_DECK)
+    assert raw.integrator_type == "NGLFCONSTRAINT" and list(raw.group_type) == [2, 2]
