@@ -6,8 +6,8 @@
 One "step" is one NGLF velocity-Verlet step of the whole box (half kick, drift,
 image refresh, nonbonded + bonded forces with energy and virial, half kick +
 kinetic terms; neighbour-list rebuild every 20 steps inside the timed region).
-Workload at N=1: BASELINE.json's headline config, the 4.096M-bead Martini water
-box (n=160 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM.
+Workload at N=1: BASELINE.json's headline config, the 4.0M-bead Martini water
+box (FCC n=100 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM.
 Prints ONE JSON line (rank 0).  `roofline` prices the nonbonded kernel with the
 ALGORITHMIC bytes of SURVEY 8(d): (36 + 24 + 4*L) B per atom-step, L = stored
 full-list entries per atom, over the HIP-event time of that kernel measured on
@@ -68,8 +68,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=160, help="lattice edge: n^3 beads (160 -> 4.096M)")
-    ap.add_argument("--cpu-n", type=int, default=40, help="lattice edge of the CPU-baseline sample (40 -> 64k beads)")
+    ap.add_argument("--n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 64 -> 1.05M, 25 -> 62.5k)")
+    ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -1,12 +1,21 @@
 """Synthetic Martini water boxes: the bench / parity-test workload.
 
-Simple-cubic lattice of n^3 sites at the example deck's density
-(6173 beads / 93.858^3 A^3), uniform jitter +-0.5 A per axis, 10 % antifreeze beads
-(BP4, species WFxWF) chosen by splitmix64(seed ^ i) % 10 == 0, gid = i << 32 (one
-bead per molecule, like examples/waterbox), Maxwell-Boltzmann velocities at 310 K
-with the centre-of-mass velocity removed.  Force-field numbers are those of
-examples/waterbox/martini.data:45-47.  Everything is generated from splitmix64
-hashes so the same (n, seed) gives bit-identical inputs on every machine.
+FCC lattice of 4*n^3 sites at the example deck's density (6173 beads /
+93.858^3 A^3; nearest-neighbour distance 5.74 A), uniform jitter +-0.2 A per axis,
+10 % antifreeze beads (BP4, species WFxWF) chosen by splitmix64(seed ^ i) % 10 == 0,
+gid = i << 32 (one bead per molecule, like examples/waterbox), Maxwell-Boltzmann
+velocities with the centre-of-mass velocity removed.  The initial temperature is
+50 K: relaxing the jittered mixed-bead lattice releases ~260 K, so the run settles
+at the deck's 310 K within ~100 steps.  Force-field numbers are those of examples/waterbox/martini.data:45-47.
+Everything is generated from splitmix64 hashes so the same (n, seed) gives
+bit-identical inputs on every machine.
+
+SURVEY 8(d) proposed a simple-cubic lattice (a = 5.12 A, jitter +-0.5 A).  That
+start puts P4-BP4 pairs (sigma = 5.7 A) at 4.1-5.1 A, i.e. tens of kJ/mol up the
+repulsive wall, and the box explodes within ~6 steps at dt = 20 fs -- in the CPU
+oracle and on the GPU alike (lattice="sc" keeps it available for that
+demonstration).  FCC at the same density is the nearest stable equivalent:
+same bead count per volume, hence the same neighbour-list sizes and traffic.
 """
 import numpy as np
 from .deck import Setup, units_convert, GROUP_FREE, GROUP_BERENDSEN
@@ -86,26 +95,42 @@ def water_forcefield(s, rcut_A=12.0, skin_A=4.0, dt_fs=20.0, update_rate=20):
     return s
 
 
-def make_water_setup(n, seed=SEED, temperature_K=310.0, rcut_A=12.0, skin_A=4.0, dt_fs=20.0,
-                     update_rate=20, thermostat=None):
-    """n^3-bead Martini water box (n=40: 64k, n=100: 1M, n=160: 4.096M)."""
+def make_water_setup(n, seed=SEED, temperature_K=50.0, rcut_A=12.0, skin_A=4.0, dt_fs=20.0,
+                     update_rate=20, thermostat=None, lattice="fcc", jitter_A=None):
+    """Martini water box: 4*n^3 beads on FCC (n=25: 62.5k, n=64: 1.05M, n=100: 4.0M);
+    lattice="sc" gives SURVEY's n^3 simple-cubic start (unstable at 20 fs)."""
     s = Setup()
     water_forcefield(s, rcut_A, skin_A, dt_fs, update_rate)
-    N = n * n * n
-    a_A = (93.858 ** 3 / 6173.0) ** (1.0 / 3.0)
     ang = units_convert(1.0, "Angstrom")
+    vol_per_bead_A3 = 93.858 ** 3 / 6173.0
+    if lattice == "fcc":
+        N = 4 * n * n * n
+        a_A = (4.0 * vol_per_bead_A3) ** (1.0 / 3.0)
+        basis = np.array([[0.0, 0.0, 0.0], [0.5, 0.5, 0.0], [0.5, 0.0, 0.5], [0.0, 0.5, 0.5]])
+        jit_A = 0.2 if jitter_A is None else jitter_A
+        nb = 4
+    elif lattice == "sc":
+        N = n * n * n
+        a_A = vol_per_bead_A3 ** (1.0 / 3.0)
+        basis = np.array([[0.25, 0.25, 0.25]])
+        jit_A = 0.5 if jitter_A is None else jitter_A
+        nb = 1
+    else:
+        raise ValueError("lattice must be 'fcc' or 'sc'")
     L = n * a_A * ang
     s.h = np.array([L, 0, 0, 0, L, 0, 0, 0, L], dtype=np.float64)
     s.pbc = 7
     idx = np.arange(N, dtype=np.uint64)
-    ix = (idx % np.uint64(n)).astype(np.float64)
-    iy = ((idx // np.uint64(n)) % np.uint64(n)).astype(np.float64)
-    iz = (idx // np.uint64(n * n)).astype(np.float64)
+    b = (idx % np.uint64(nb)).astype(np.int64)
+    cell = idx // np.uint64(nb)
+    ix = (cell % np.uint64(n)).astype(np.float64)
+    iy = ((cell // np.uint64(n)) % np.uint64(n)).astype(np.float64)
+    iz = (cell // np.uint64(n * n)).astype(np.float64)
     a = a_A * ang
-    jit = 0.5 * ang
-    s.rx = (ix + 0.5) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 1) - 1.0)
-    s.ry = (iy + 0.5) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 2) - 1.0)
-    s.rz = (iz + 0.5) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 3) - 1.0)
+    jit = jit_A * ang
+    s.rx = (ix + basis[b, 0] + 0.25) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 1) - 1.0)
+    s.ry = (iy + basis[b, 1] + 0.25) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 2) - 1.0)
+    s.rz = (iz + basis[b, 2] + 0.25) * a - 0.5 * L + jit * (2.0 * _uniform(seed, idx, 3) - 1.0)
     is_bp4 = (splitmix64(np.uint64(seed) ^ idx) % np.uint64(10)) == np.uint64(0)
     s.species = is_bp4.astype(np.int32)          # 0 = WxW (P4), 1 = WFxWF (BP4)
     s.group = np.zeros(N, np.int32)
@@ -124,6 +149,6 @@ def make_water_setup(n, seed=SEED, temperature_K=310.0, rcut_A=12.0, skin_A=4.0,
     s.natoms = N
     if thermostat == "berendsen":
         s.group_type = np.array([GROUP_BERENDSEN], np.int32)
-        s.group_Teq = np.array([kT])
+        s.group_Teq = np.array([units_convert(310.0, "K")])
         s.group_tau = np.array([units_convert(1.0, "ps")])
     return s

@@ -94,9 +94,9 @@ def test_waterbox_10_step_nve_trajectory(waterbox):
     m.close()
 
 
-@pytest.mark.parametrize("n", [24, 40])
+@pytest.mark.parametrize("n", [15, 25])
 def test_synthetic_water_forces(n):
-    """synthetic Martini water, rcut 12 A + 4 A skin (64k-bead config at n=40): F/E/virial vs oracle"""
+    """synthetic Martini water, rcut 12 A + 4 A skin (62.5k-bead config at n=25): F/E/virial vs oracle"""
     from ddcmd_amd.martini import MartiniHIP
     s = make_water_setup(n)
     o = pyoracle.Oracle(s)
@@ -115,7 +115,7 @@ def test_synthetic_water_forces(n):
 def test_synthetic_water_25_steps_with_rebuild():
     """every-step diff over a rebuild boundary (updateRate=20): energies each step, state at the end"""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(24)
+    s = make_water_setup(15)
     o = pyoracle.Oracle(s)
     o.forces()
     m = MartiniHIP(s)
@@ -141,7 +141,7 @@ def test_synthetic_water_25_steps_with_rebuild():
 def test_charged_beads_reaction_field():
     """HAS_Q kernel variant: random +-1 charges on water beads exercise LJ + RF Coulomb + self term"""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(16)
+    s = make_water_setup(10)
     # four species: neutral/charged variants with the two LJ types
     s.nspecies = 4
     s.species_name = ["WxW", "WFxWF", "QPxQP", "QMxQM"]
@@ -173,7 +173,7 @@ def test_charged_beads_reaction_field():
 def test_rsqrt_accuracy_through_energy():
     """the kernel's rsq-seed + Newton 1/sqrt is FP64-accurate: a 2-bead system's E equals the closed form"""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(8)
+    s = make_water_setup(5)
     s.natoms = 2
     L = s.h[0]
     for k in ("rx", "ry", "rz", "vx", "vy", "vz"):
@@ -199,7 +199,7 @@ def test_rsqrt_accuracy_through_energy():
 def test_berendsen_thermostat_matches_oracle():
     """BERENDSEN group (berendsen.c): lambda from the group temperature refreshed per batch"""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(16, thermostat="berendsen")
+    s = make_water_setup(10, thermostat="berendsen")
     s.group_Teq = np.array([units_convert(350.0, "K")])
     s.group_tau = np.array([units_convert(0.1, "ps")])
     o = pyoracle.Oracle(s)
@@ -224,14 +224,14 @@ def test_berendsen_thermostat_matches_oracle():
 def test_error_paths():
     """error behaviour of the boundary: bad call order and unsupported input return codes, not crashes"""
     from ddcmd_amd.martini import MartiniHIP, DdcmiError
-    s = make_water_setup(4)      # box 20.5 A < 2*(12+4) A: nearest-image convention breaks
+    s = make_water_setup(3)      # box 24.4 A < 2*(12+4) A: nearest-image convention breaks
     m = MartiniHIP(s)
     with pytest.raises(DdcmiError):
         m.eval_forces()
     with pytest.raises(DdcmiError):
         m.step(1)                # no forces yet
     m.close()
-    s = make_water_setup(8)
+    s = make_water_setup(5)
     s.h = s.h.copy()
     s.h[1] = 0.3                 # triclinic
     with pytest.raises(DdcmiError):
