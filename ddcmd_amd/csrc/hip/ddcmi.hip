@@ -214,91 +214,230 @@ __global__ void k_merge_cells(int ncell, int nloc, const int *cnt_o, const int *
 /* ------------------------------------------------------------------------- */
 /* neighbour list: pairlist1 semantics (pairlist.c:205-314) as a FULL list --
  * every j != i with |r_ij| < rmax+deltaR -- plus the reOrgPairs split
- * (bioMartini.c:1392-1485) done at build time. */
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_build_list(GridParams gp, int nloc, int npad, const double4 *pos, const uint64_t *gid, const int *species,
-                                                            const int *cell_start, const int *cell_cnt,
+ * (bioMartini.c:1392-1485) done at build time.
+ *
+ * One workgroup per TILE (4x4x4 cells, ~250 beads, a compact ~32 A cube).  The
+ * tile's neighbourhood -- the 8x8x8 cells within two cells of it, ~2000 beads --
+ * is written once as a staging list (global indices, raster order) and loaded
+ * into LDS; every owned bead of the tile then scans the 5x5x5 cells around its
+ * own cell out of LDS.  List entries are 16-bit indices into the tile's staged
+ * set, stored slot-major per tile (ELL) and ordered by distance shell at build
+ * time so that late slots are rejected by whole waves. */
+__device__ __forceinline__ int block_excl_scan256(int v, int *tot, int *s_w)
+{
+   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   int inc = v;
+#pragma unroll
+   for (int off = 1; off < 64; off <<= 1)
+   {
+      int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+   }
+   if (lane == 63) s_w[w] = inc;
+   __syncthreads();
+   int base = 0;
+   for (int k = 0; k < w; k++) base += s_w[k];
+   *tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+   __syncthreads();
+   return base + inc - v;
+}
+
+struct TileArgs
+{
+   int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
+   const int *cell_start_o;             /* owned beads per cell: exclusive scan, [ncell+1] */
+   const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges */
+   int *stage_idx, *tile_nstage;
+   long long *tile_base; int *tile_width, *tile_rows;
+   unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
+   int *nbr_cnt, *shellpk;
+};
+
+struct NbTileArgs
+{
+   int ntile, stage_stride, cap, nlj;
+   const int *cell_start_o;
+   const int *stage_idx, *tile_nstage;
+   const long long *tile_base; const int *tile_width, *tile_rows;
+   const unsigned short *nbr16;
+   const int *nbr_cnt;
+};
+
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
+                                                            const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ,
-                                                            int maxnbr, int *nbr, int *nbr_cnt, int maxexcl, int *excl, int *excl_cnt, int *flags)
+                                                            double sh0, double sh1, double sh2,
+                                                            int maxexcl, int *excl, int *excl_cnt, int *flags, unsigned long long *totals)
 {
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= nloc) return;
-   double4 pi = pos[i];
-   int cx, cy, cz;
-   cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
-   double rl2 = gp.rlist * gp.rlist;
-   uint64_t gi = 0;
-   int mt = 0, mns = 1;
-   if (nmoltype > 0) { gi = gid[i]; mt = moltype_sp[species[i]]; mns = mol_nspecies[mt]; }
-   int cnt = 0, ecnt = 0;
-   for (int dz = -2; dz <= 2; dz++)
+   extern __shared__ double2 smem[];
+   double2 *A_s = smem, *B_s = smem + ta.cap;
+   int *ofs_s = (int *)(smem + 2 * (size_t)ta.cap);      /* [513] staged offset of each region cell */
+   int *gst_s = ofs_s + 520;                               /* [512] global start of each region cell */
+   __shared__ int s_w[4];
+   __shared__ long long s_base;
+   int t = blockIdx.x;
+   int ts = ta.cell_start_o[64 * t], te = ta.cell_start_o[64 * t + 64];
+   int nown = te - ts;
+   if (nown <= 0)
    {
-      int jz = cz + dz;
-      if (jz < 0 || jz >= gp.g[2]) continue;
-      for (int dy = -2; dy <= 2; dy++)
+      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
+      return;
+   }
+   int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
+   /* phase 0: the 512 region cells (raster order), their counts and staged offsets */
+   int v[2], g[2];
+#pragma unroll
+   for (int h = 0; h < 2; h++)
+   {
+      int c = 2 * threadIdx.x + h;
+      int cx = 4 * tx - 2 + (c & 7), cy = 4 * ty - 2 + ((c >> 3) & 7), cz = 4 * tz - 2 + (c >> 6);
+      v[h] = 0; g[h] = 0;
+      if (cx >= 0 && cy >= 0 && cz >= 0 && cx < gp.g[0] && cy < gp.g[1] && cz < gp.g[2])
       {
-         int jy = cy + dy;
-         if (jy < 0 || jy >= gp.g[1]) continue;
-         for (int dx = -2; dx <= 2; dx++)
+         int id = cell_linear(gp, cx, cy, cz);
+         v[h] = ta.cell_cnt[id]; g[h] = ta.cell_start[id];
+      }
+   }
+   int tot;
+   int ex = block_excl_scan256(v[0] + v[1], &tot, s_w);
+   ofs_s[2 * threadIdx.x] = ex; ofs_s[2 * threadIdx.x + 1] = ex + v[0];
+   gst_s[2 * threadIdx.x] = g[0]; gst_s[2 * threadIdx.x + 1] = g[1];
+   if (threadIdx.x == 0) { ofs_s[512] = tot; ta.tile_nstage[t] = tot; }
+   if (tot > ta.cap || tot > 65535)
+   {
+      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
+      return;      /* LDS capacity too small: the host retries with a larger cap */
+   }
+   __syncthreads();
+   /* phase 1: staging list (global indices) + positions into LDS */
+   int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
+#pragma unroll
+   for (int h = 0; h < 2; h++)
+   {
+      int o = ofs_s[2 * threadIdx.x + h];
+      for (int k = 0; k < v[h]; k++)
+      {
+         int gj = g[h] + k;
+         sidx[o + k] = gj;
+         double4 p = pos[gj];
+         A_s[o + k] = make_double2(p.x, p.y);
+         B_s[o + k] = make_double2(p.z, p.w);
+      }
+   }
+   __syncthreads();
+   const double rl2 = gp.rlist * gp.rlist;
+   const int rows = (nown + 63) & ~63;
+   int mymax = 0;
+   /* pass 0 counts (per distance shell), pass 1 fills */
+   for (int pass = 0; pass < 2; pass++)
+   {
+      long long base = (pass == 1) ? s_base : 0;
+      if (pass == 1 && base < 0) break;            /* arena overflow: host grows it and rebuilds */
+      for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK)
+      {
+         int a = ts + al;
+         double4 pi = pos[a];
+         int cx, cy, cz;
+         cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
+         int lx = cx - 4 * tx, ly = cy - 4 * ty, lz = cz - 4 * tz;       /* 0..3 */
+         int rc_own = (lz + 2) * 64 + (ly + 2) * 8 + (lx + 2);
+         int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
+         uint64_t gi = 0;
+         int mt = 0, mns = 1;
+         if (nmoltype > 0) { gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt]; }
+         int c0 = 0, c1 = 0, c2 = 0, c3 = 0, ecnt = 0;
+         int o1 = 0, o2 = 0, o3 = 0;
+         if (pass == 1)
          {
-            int jx = cx + dx;
-            if (jx < 0 || jx >= gp.g[0]) continue;
-            int c = cell_linear(gp, jx, jy, jz);
-            int s = cell_start[c], n = cell_cnt[c];
-            for (int j = s; j < s + n; j++)
+            int pk = ta.shellpk[a];
+            o1 = pk & 1023; o2 = o1 + ((pk >> 10) & 1023); o3 = o2 + ((pk >> 20) & 1023);
+         }
+         for (int dz = 0; dz < 5; dz++)
+            for (int dy = 0; dy < 5; dy++)
             {
-               if (j == i) continue;
-               double4 pj = pos[j];
-               double x = pi.x - pj.x, y = pi.y - pj.y, z = pi.z - pj.z;
-               double r2 = x * x + y * y + z * z;
-               if (r2 < rl2)
+               int rc0 = (lz + dz) * 64 + (ly + dy) * 8 + lx;      /* 5 consecutive cells in x are contiguous */
+               int s0 = ofs_s[rc0], s1 = ofs_s[rc0 + 5];
+               for (int sj = s0; sj < s1; sj++)
                {
-                  bool pruned = false;
-                  if (nmoltype > 0)
+                  if (sj == self) continue;
+                  double2 pa = A_s[sj], pb = B_s[sj];
+                  double x = pi.x - pa.x, y = pi.y - pa.y, z = pi.z - pb.x;
+                  double r2 = x * x + y * y + z * z;
+                  if (r2 < rl2)
                   {
-                     uint64_t gj = gid[j];
-                     if ((gi >> 32) == (gj >> 32))
+                     bool pruned = false;
+                     if (nmoltype > 0)
                      {
-                        if (mns > 1)
+                        uint64_t gj = gid[sidx[sj]];
+                        if ((gi >> 32) == (gj >> 32))
                         {
-                           unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
-                           for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
+                           if (mns > 1)
                            {
-                              unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
-                              if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
+                              unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
+                              for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
+                              {
+                                 unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
+                                 if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
+                              }
                            }
+                           else pruned = true;
                         }
-                        else pruned = true;
                      }
-                  }
-                  if (!pruned)
-                  {
-                     if (cnt < maxnbr) nbr[(size_t)cnt * npad + i] = j;
-                     cnt++;
-                  }
-                  else
-                  {
-                     if (ecnt < maxexcl) excl[(size_t)ecnt * npad + i] = j;
-                     ecnt++;
+                     if (pruned)
+                     {
+                        if (pass == 1 && ecnt < maxexcl) excl[(size_t)ecnt * npad + a] = sidx[sj];
+                        ecnt++;
+                        continue;
+                     }
+                     int sh = (r2 >= sh0) + (r2 >= sh1) + (r2 >= sh2);
+                     int slot;
+                     if (sh == 0) slot = c0++;
+                     else if (sh == 1) slot = o1 + c1++;
+                     else if (sh == 2) slot = o2 + c2++;
+                     else slot = o3 + c3++;
+                     if (pass == 1) ta.nbr16[base + (size_t)slot * rows + al] = (unsigned short)sj;
                   }
                }
             }
+         if (pass == 0)
+         {
+            int cnt = c0 + c1 + c2 + c3;
+            mymax = max(mymax, cnt);
+            ta.nbr_cnt[a] = cnt;
+            ta.shellpk[a] = min(c0, 1023) | (min(c1, 1023) << 10) | (min(c2, 1023) << 20);
+            excl_cnt[a] = min(ecnt, maxexcl);
+            if (ecnt > maxexcl) atomicMax(&flags[1], ecnt);
          }
       }
+      if (pass == 0)
+      {
+         /* block max -> ELL width of this tile; one thread takes the arena slice */
+         int m = mymax;
+#pragma unroll
+         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+         if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+         __syncthreads();
+         if (threadIdx.x == 0)
+         {
+            int width = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+            width = max(width, 1);
+            unsigned long long need = (unsigned long long)rows * width;
+            unsigned long long b0 = atomicAdd(ta.arena_used, need);
+            if (b0 + need > ta.arena_cap) { s_base = -1; atomicMax(&flags[0], 1); }
+            else s_base = (long long)b0;
+            ta.tile_base[t] = s_base < 0 ? 0 : s_base;
+            ta.tile_width[t] = width; ta.tile_rows[t] = s_base < 0 ? 0 : rows;
+            atomicMax(&flags[2], width);
+         }
+         __syncthreads();
+      }
    }
-   nbr_cnt[i] = min(cnt, maxnbr);
-   excl_cnt[i] = min(ecnt, maxexcl);
-   if (cnt > maxnbr) atomicMax(&flags[0], cnt);
-   if (ecnt > maxexcl) atomicMax(&flags[1], ecnt);
-   atomicMax(&flags[2], cnt);
-   atomicMax(&flags[3], ecnt);
-}
-__global__ void k_sum_counts(int n, const int *a, const int *b, unsigned long long *out)
-{
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
-   unsigned long long va = (i < n) ? (unsigned long long)a[i] : 0ull, vb = (i < n) ? (unsigned long long)b[i] : 0ull;
-   for (int off = 32; off > 0; off >>= 1) { va += __shfl_down(va, off, 64); vb += __shfl_down(vb, off, 64); }
-   if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], va); atomicAdd(&out[1], vb); }
+   /* statistics: entries of this tile */
+   unsigned long long mine = 0, mex = 0;
+   for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK) { mine += ta.nbr_cnt[ts + al]; mex += excl_cnt[ts + al]; }
+   for (int off = 32; off > 0; off >>= 1) { mine += __shfl_down(mine, off, 64); mex += __shfl_down(mex, off, 64); }
+   if ((threadIdx.x & 63) == 0) { atomicAdd(&totals[0], mine); atomicAdd(&totals[1], mex); }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -326,92 +465,141 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 }
 
 template <bool HAS_Q>
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(int nloc, int npad, int nblocks_logical,
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ qatom,
-                                                         const int *__restrict__ nbr, const int *__restrict__ nbr_cnt,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
-                                                         const double4 *__restrict__ ljtab, int nlj,
+                                                         const double4 *__restrict__ ljtab,
                                                          double rc2, double krf, double crf, double keR,
                                                          double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz,
                                                          double *__restrict__ partials)
 {
-   extern __shared__ double4 s_lj[];
-   /* XCD-aware mapping: hardware deals blocks round-robin over the 8 XCDs, so
+   extern __shared__ double2 smem[];
+   double2 *A_s = smem, *B_s = smem + ta.cap;
+   double4 *s_lj = (double4 *)(smem + 2 * (size_t)ta.cap);
+   double *q_s = (double *)(s_lj + ta.nlj * ta.nlj);
+   /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
     * give XCD x the contiguous tile range [x*per, (x+1)*per): neighbouring tiles
-    * then share one L2 (speed only, never correctness). */
-   int per = (nblocks_logical + 7) >> 3;
-   int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-   for (int t = threadIdx.x; t < nlj * nlj; t += blockDim.x) s_lj[t] = ljtab[t];
-   __syncthreads();
+    * (which stage overlapping neighbourhoods) then share one L2. Speed only. */
+   int per = (ta.ntile + 7) >> 3;
+   int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* vLJ, vEle, xx,yy,zz,xy,xz,yz */
-   if (lb < nblocks_logical)
+   int nown = 0, ts = 0;
+   if (t < ta.ntile)
    {
-      int i = lb * DDCMI_BLOCK + threadIdx.x;
-      bool active = i < nloc;
-      int ii = active ? i : nloc - 1;
-      double4 pi = pos[ii];
-      int ti = (int)(__double_as_longlong(pi.w) & 0xffffffffll);
-      double kqi = 0.0;
-      if (HAS_Q) kqi = keR * qatom[ii];
-      int cnt = active ? nbr_cnt[i] : 0;
-      double fxi = 0, fyi = 0, fzi = 0;
-      const int *col = nbr + ii;
-      for (int k = 0; k < cnt; k++)
-      {
-         int j = col[(size_t)k * npad];
-         double4 pj = pos[j];
-         double x = pi.x - pj.x, y = pi.y - pj.y, z = pi.z - pj.z;
-         double r2 = x * x + y * y + z * z;
-         if (r2 < rc2)
-         {
-            int tj = (int)(__double_as_longlong(pj.w) & 0xffffffffll);
-            double4 lj = s_lj[ti * nlj + tj];          /* {sigma^2, 4eps, shift, 24eps} */
-            double ir = rsqrt_f64(r2);
-            double ir2 = ir * ir;
-            double s2 = lj.x * ir2;
-            double s4 = s2 * s2;
-            double s6 = s4 * s2;
-            double s12 = s6 * s6;
-            acc[0] += lj.y * (s12 - s6) + lj.z;
-            double dvdr = lj.w * (s6 - 2.0 * s12) * ir2;
-            if (HAS_Q)
-            {
-               double kqij = kqi * qatom[j];
-               acc[1] += kqij * (ir + krf * r2 - crf);
-               dvdr += kqij * (2.0 * krf - ir2 * ir);
-            }
-            double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
-            fxi += fxij; fyi += fyij; fzi += fzij;
-            acc[2] += fxij * x; acc[3] += fyij * y; acc[4] += fzij * z;
-            acc[5] += fxij * y; acc[6] += fxij * z; acc[7] += fyij * z;
-         }
-      }
-      if (HAS_Q)
-      {
-         /* excluded (same-molecule bonded) pairs: reaction-field correction only */
-         int ecnt = active ? excl_cnt[i] : 0;
-         const int *ecol = excl + ii;
-         for (int k = 0; k < ecnt; k++)
-         {
-            int j = ecol[(size_t)k * npad];
-            double4 pj = pos[j];
-            double x = pi.x - pj.x, y = pi.y - pj.y, z = pi.z - pj.z;
-            double r2 = x * x + y * y + z * z;
-            if (r2 < rc2)
-            {
-               double kqij = kqi * qatom[j];
-               acc[1] += kqij * (krf * r2 - crf);
-               double dvdr = kqij * (2.0 * krf);
-               double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
-               fxi += fxij; fyi += fyij; fzi += fzij;
-               acc[2] += fxij * x; acc[3] += fyij * y; acc[4] += fzij * z;
-               acc[5] += fxij * y; acc[6] += fxij * z; acc[7] += fyij * z;
-            }
-         }
-      }
-      if (active) { fx[i] = fxi; fy[i] = fyi; fz[i] = fzi; }
+      ts = ta.cell_start_o[64 * t];
+      nown = ta.cell_start_o[64 * t + 64] - ts;
    }
-   if (lb < nblocks_logical) block_reduce_store<8>(acc, partials + (size_t)lb * 8);
+   if (nown > 0)
+   {
+      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += DDCMI_BLOCK) s_lj[k] = ljtab[k];
+      int ns = ta.tile_nstage[t];
+      const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
+      for (int k = threadIdx.x; k < ns; k += DDCMI_BLOCK)
+      {
+         int gj = sidx[k];
+         double4 p = pos[gj];
+         A_s[k] = make_double2(p.x, p.y);
+         B_s[k] = make_double2(p.z, p.w);
+         if (HAS_Q) q_s[k] = qatom[gj];
+      }
+      __syncthreads();
+      long long base = ta.tile_base[t];
+      int rows = ta.tile_rows[t];
+      const int nlj = ta.nlj;
+      for (int al = threadIdx.x; al < rows; al += DDCMI_BLOCK)
+      {
+         bool active = al < nown;
+         int a = ts + (active ? al : 0);
+         double4 pi = pos[a];
+         int ti = (int)(__double_as_longlong(pi.w) & 0xffffffffll);
+         double kqi = 0.0;
+         if (HAS_Q) kqi = keR * qatom[a];
+         int cnt = active ? ta.nbr_cnt[a] : 0;
+         double fxi = 0, fyi = 0, fzi = 0;
+         const unsigned short *col = ta.nbr16 + base + al;
+         /* wave-uniform trip count; the list is read CH slots ahead so the HBM/L2
+          * latency of the (coalesced, slot-major) list stream overlaps the pair math,
+          * and the CH distance tests of a chunk are independent (ILP at low occupancy) */
+         int wmax = cnt;
+#pragma unroll
+         for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+         constexpr int CH = 8;
+         unsigned short e[CH], en[CH];
+#pragma unroll
+         for (int u = 0; u < CH; u++) e[u] = (u < wmax) ? col[(size_t)u * rows] : (unsigned short)0;
+         for (int k0 = 0; k0 < wmax; k0 += CH)
+         {
+#pragma unroll
+            for (int u = 0; u < CH; u++) en[u] = (k0 + CH + u < wmax) ? col[(size_t)(k0 + CH + u) * rows] : (unsigned short)0;
+            double x[CH], y[CH], z[CH], r2[CH];
+            int tj[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+            {
+               int sj = (k0 + u < cnt) ? (int)e[u] : 0;
+               double2 pa = A_s[sj], pb = B_s[sj];
+               x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pb.x;
+               tj[u] = (int)(__double_as_longlong(pb.y) & 0xffffffffll);
+               double rr = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
+               r2[u] = (k0 + u < cnt) ? rr : rc2;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+            {
+               if (r2[u] < rc2)
+               {
+                  double4 lj = s_lj[ti * nlj + tj[u]];          /* {sigma^2, 4eps, shift, 24eps} */
+                  double ir = rsqrt_f64(r2[u]);
+                  double ir2 = ir * ir;
+                  double s2 = lj.x * ir2;
+                  double s4 = s2 * s2;
+                  double s6 = s4 * s2;
+                  double s12 = s6 * s6;
+                  acc[0] += lj.y * (s12 - s6) + lj.z;
+                  double dvdr = lj.w * (s6 - 2.0 * s12) * ir2;
+                  if (HAS_Q)
+                  {
+                     int sj = (int)e[u];
+                     double kqij = kqi * q_s[sj];
+                     acc[1] += kqij * (ir + krf * r2[u] - crf);
+                     dvdr += kqij * (2.0 * krf - ir2 * ir);
+                  }
+                  double fxij = -dvdr * x[u], fyij = -dvdr * y[u], fzij = -dvdr * z[u];
+                  fxi += fxij; fyi += fyij; fzi += fzij;
+                  acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u];
+                  acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u];
+               }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) e[u] = en[u];
+         }
+         if (HAS_Q)
+         {
+            /* excluded (same-molecule bonded) pairs: reaction-field correction only
+             * (martiniIntraMoleReaction); few per bead, gathered from global memory */
+            int ecnt = active ? excl_cnt[a] : 0;
+            for (int k = 0; k < ecnt; k++)
+            {
+               int j = excl[(size_t)k * npad + a];
+               double4 pj = pos[j];
+               double x = pi.x - pj.x, y = pi.y - pj.y, z = pi.z - pj.z;
+               double r2 = x * x + y * y + z * z;
+               if (r2 < rc2)
+               {
+                  double kqij = kqi * qatom[j];
+                  acc[1] += kqij * (krf * r2 - crf);
+                  double dvdr = kqij * (2.0 * krf);
+                  double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
+                  fxi += fxij; fyi += fyij; fzi += fzij;
+                  acc[2] += fxij * x; acc[3] += fyij * y; acc[4] += fzij * z;
+                  acc[5] += fxij * y; acc[6] += fxij * z; acc[7] += fyij * z;
+               }
+            }
+         }
+         if (active) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; }
+      }
+   }
+   if (t < ta.ntile) block_reduce_store<8>(acc, partials + (size_t)t * 8);
 }
 
 /* zero forces (nonbonded excluded via excludePotentialTerm) */
@@ -421,14 +609,17 @@ __global__ void k_zero3(int n, double *a, double *b, double *c)
    if (i < n) { a[i] = 0; b[i] = 0; c[i] = 0; }
 }
 
-/* fixed-order second stage: out[k] = sum_b partials[b*stride+k] */
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_reduce_partials(const double *partials, int nblocks, int stride, int nv, double *out)
+/* fixed-order reduction of per-workgroup partials: stage A, RED_BLOCKS
+ * workgroups each sum a strided subset; stage B, one workgroup sums those.
+ * Same order every run => bitwise reproducible. */
+#define RED_BLOCKS 64
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_reduce_stageA(const double *partials, int nblocks, int stride, int nv, double *tmp)
 {
    __shared__ double s[DDCMI_BLOCK];
    for (int k = 0; k < nv; k++)
    {
       double a = 0.0;
-      for (int b = threadIdx.x; b < nblocks; b += DDCMI_BLOCK) a += partials[(size_t)b * stride + k];
+      for (int b = blockIdx.x * DDCMI_BLOCK + threadIdx.x; b < nblocks; b += RED_BLOCKS * DDCMI_BLOCK) a += partials[(size_t)b * stride + k];
       s[threadIdx.x] = a;
       __syncthreads();
       for (int off = DDCMI_BLOCK / 2; off > 0; off >>= 1)
@@ -436,9 +627,18 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_reduce_partials(const double *p
          if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
          __syncthreads();
       }
-      if (threadIdx.x == 0) out[k] = s[0];
+      if (threadIdx.x == 0) tmp[blockIdx.x * 8 + k] = s[0];
       __syncthreads();
    }
+}
+__global__ __launch_bounds__(64) void k_reduce_stageB(const double *tmp, int nv, double *out)
+{
+   int k = threadIdx.x >> 3, l = threadIdx.x & 7;     /* 8 values x 8 lanes */
+   if (k >= nv) return;
+   double a = 0.0;
+   for (int b = l; b < RED_BLOCKS; b += 8) a += tmp[b * 8 + k];
+   a += __shfl_down(a, 4, 8); a += __shfl_down(a, 2, 8); a += __shfl_down(a, 1, 8);
+   if (l == 0) out[k] = a;
 }
 /* final energies / virial: full list counts every pair twice */
 __global__ void k_finish_energy(double *r, double self_ele)
@@ -568,6 +768,30 @@ __global__ void k_fill_q(int n, const double4 *pos, const double *charge_sp, dou
    int sp = (int)(__double_as_longlong(pos[i].w) >> 32);
    qatom[i] = charge_sp[sp];
 }
+/* test/inspection export: decode the tile ELL (16-bit staged indices) into CSR
+ * over caller-order indices; image atoms map back to their source bead */
+__global__ void k_tilelist_to_csr(NbTileArgs ta, int nloc, const int *orig, const int *halo_src, const int *start, int *jout)
+{
+   int t = blockIdx.x;
+   int ts = ta.cell_start_o[64 * t];
+   int nown = ta.cell_start_o[64 * t + 64] - ts;
+   if (nown <= 0) return;
+   const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
+   long long base = ta.tile_base[t];
+   int rows = ta.tile_rows[t];
+   for (int al = threadIdx.x; al < nown; al += blockDim.x)
+   {
+      int a = ts + al;
+      int s = start[orig[a]];
+      int cnt = ta.nbr_cnt[a];
+      for (int k = 0; k < cnt; k++)
+      {
+         int j = sidx[ta.nbr16[base + (size_t)k * rows + al]];
+         if (j >= nloc) j = halo_src[j - nloc];
+         jout[s + k] = orig[j];
+      }
+   }
+}
 __global__ void k_list_to_csr(int nloc, int npad, const int *lst, const int *cnt, const int *orig, const int *halo_src, const int *start, int *jout)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,10 +869,12 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    dbuf<int> *ib[] = {&ctx->d_ljtype_sp, &ctx->d_moltype_sp, &ctx->d_mol_nspecies, &ctx->d_bpair_off, &ctx->d_bpairI, &ctx->d_bpairJ, &ctx->species, &ctx->species2,
                       &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->cell_cnt_o, &ctx->cell_start_o,
                       &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt, &ctx->nimg, &ctx->img_off, &ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank,
-                      &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt,
+                      &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt, &ctx->shellpk,
+                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows,
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -916,7 +1142,7 @@ static int setup_grid(ddcmi_ctx *ctx)
       if (n < 1) n = 1;
       gp.n[a] = n;
       gp.cinv[a] = (double)n / L[a];
-      gp.m[a] = periodic ? 2 : 0;
+      gp.m[a] = periodic ? 4 : 0;      /* one whole tile of margin: interior tiles hold owned beads only */
       gp.g[a] = n + 2 * gp.m[a];
       gp.T[a] = (gp.g[a] + 3) / 4;
       ncell *= gp.T[a] * 4;
@@ -938,13 +1164,13 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nb = cdiv(n, 256), ncell = gp.ncell, ncb = cdiv(ncell, 256);
    dbuf<int> *cb[] = {&ctx->cell_cnt_o, &ctx->cell_start_o, &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt};
-   for (auto b : cb) ENSURE(ctx, *b, ncell + 1);
+   for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
    /* 1. wrap + cell ids + counting sort of the owned atoms */
-   HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_o.p, 0, ncell * sizeof(int), st));
+   HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_o.p, 0, (ncell + 1) * sizeof(int), st));
    HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p);
-   HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_o.p, ctx->cell_cnt_o.p, ncell * sizeof(int), hipMemcpyDeviceToDevice, st));
-   if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_o.p, ncell, nullptr))) return rc;
+   HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_o.p, ctx->cell_cnt_o.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
+   if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
    hipLaunchKernelGGL(k_scatter_order, dim3(nb), dim3(256), 0, st, n, ctx->cid.p, ctx->crank.p, ctx->cell_start_o.p, ctx->order.p);
    hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
    hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
@@ -981,46 +1207,70 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
    hipLaunchKernelGGL(k_fill_q, dim3(cdiv(n + nh, 256)), dim3(256), 0, st, n + nh, ctx->pos.p, ctx->d_charge_sp.p, ctx->qatom.p);
-   /* 3. full neighbour list (ELL, slot-major) */
+   /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
    ctx->npad = cdiv(n, DDCMI_BLOCK) * DDCMI_BLOCK;
-   if (ctx->maxnbr == 0)
+   int ntile = gp.T[0] * gp.T[1] * gp.T[2];
+   ctx->ntile = ntile;
+   double vol = gp.L[0] * gp.L[1] * gp.L[2];
+   double dens = (double)n / vol;
+   if (ctx->stage_cap == 0)
    {
-      double vol = gp.L[0] * gp.L[1] * gp.L[2];
-      double expect = 4.0 / 3.0 * M_PI * gp.rlist * gp.rlist * gp.rlist * (double)n / vol;
-      ctx->maxnbr = ((int)(expect * 1.25) + 24 + 7) & ~7;
-      ctx->maxexcl = ctx->nmoltype > 0 ? 8 : 1;
-      bool multi = false;
-      for (int m = 0; m < ctx->nmoltype; m++) if (ctx->mol_nspecies[m] > 1) multi = true;
-      if (multi) ctx->maxexcl = 16;
+      double per_cell = dens / (gp.cinv[0] * gp.cinv[1] * gp.cinv[2]);
+      ctx->stage_cap = (((int)(512.0 * per_cell * 1.12) + 96) + 63) & ~63;
+      if (ctx->stage_cap < 256) ctx->stage_cap = 256;
+      ctx->maxexcl = 1;
+      for (int m = 0; m < ctx->nmoltype; m++) if (ctx->mol_nspecies[m] > 1) ctx->maxexcl = 16;
    }
-   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
-   for (int attempt = 0; attempt < 8; attempt++)
+   if (ctx->arena_cap == 0)
    {
-      ENSURE(ctx, ctx->nbr, (size_t)ctx->maxnbr * ctx->npad);
+      double expect = 4.0 / 3.0 * M_PI * gp.rlist * gp.rlist * gp.rlist * dens;
+      ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
+   }
+   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad); ENSURE(ctx, ctx->shellpk, ctx->npad);
+   ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
+   if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
+   double rcut = ctx->rmax, dR = ctx->deltaR;
+   double sh0 = (rcut - 0.25 * dR) * (rcut - 0.25 * dR), sh1 = (rcut + 0.125 * dR) * (rcut + 0.125 * dR), sh2 = (rcut + 0.5 * dR) * (rcut + 0.5 * dR);
+   unsigned long long *d_tot = (unsigned long long *)(ctx->d_results + R_FLAGS);    /* [0]=entries [1]=excluded [2]=arena used */
+   for (int attempt = 0;; attempt++)
+   {
+      if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
+      size_t lds = (size_t)ctx->stage_cap * 32 + (520 + 512) * sizeof(int);
+      if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
+      ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
+      if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
-      hipLaunchKernelGGL(k_build_list, dim3(nb), dim3(DDCMI_BLOCK), 0, st, gp, n, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
-                         ctx->cell_start.p, ctx->cell_cnt.p, ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p,
-                         ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->maxnbr, ctx->nbr.p, ctx->nbr_cnt.p, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags);
+      HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
+      TileArgs ta;
+      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap;
+      ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
+      ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
+      ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p;
+      ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_tot + 2;
+      ta.nbr_cnt = ctx->nbr_cnt.p; ta.shellpk = ctx->shellpk.p;
+      HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(DDCMI_BLOCK), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
+                         ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,
+                         sh0, sh1, sh2, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+      HIPCHK(ctx, hipGetLastError());
+      unsigned long long tot[3];
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      if (ctx->h_flags[0] == 0 && ctx->h_flags[1] == 0) break;
-      if (ctx->h_flags[0]) ctx->maxnbr = ((int)(ctx->h_flags[0] * 1.15) + 8 + 7) & ~7;
-      if (ctx->h_flags[1]) ctx->maxexcl = ctx->h_flags[1] + 4;
-      if (attempt == 7) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
-   }
-   /* statistics */
-   {
-      unsigned long long *d_tot = (unsigned long long *)(ctx->d_results + R_FLAGS);
-      HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 2 * sizeof(unsigned long long), st));
-      hipLaunchKernelGGL(k_sum_counts, dim3(nb), dim3(256), 0, st, n, ctx->nbr_cnt.p, ctx->excl_cnt.p, d_tot);
-      unsigned long long tot[2];
       HIPCHK(ctx, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
-      ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
+      bool again = false;
+      if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.05) + 32) + 63) & ~63; again = true; }
+      if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }
+      if (ctx->h_flags[1] > 0) { ctx->maxexcl = ctx->h_flags[1] + 4; again = true; }
+      if (!again)
+      {
+         ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
+         ctx->maxnbr = ctx->h_flags[2];
+         break;
+      }
    }
-   int nblk = cdiv(n, DDCMI_BLOCK);
-   ENSURE(ctx, ctx->partials, (size_t)(nblk + 8) * 8);
+   ENSURE(ctx, ctx->partials, (size_t)(std::max(ntile, cdiv(n, DDCMI_BLOCK)) + 8) * 8);
+   ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
    ctx->list_valid = true;
    ctx->nrebuild++;
    return DDCMI_OK;
@@ -1031,15 +1281,22 @@ static int launch_forces(ddcmi_ctx *ctx)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
-   int nblk = cdiv(n, DDCMI_BLOCK);
    if (nh > 0)
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false);
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, R_RK * sizeof(double), st));
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
-      int grid = ((nblk + 7) / 8) * 8;
-      size_t lds = (size_t)ctx->nlj * ctx->nlj * sizeof(double4);
+      int ntile = ctx->ntile;
+      int grid = ((ntile + 7) / 8) * 8;
+      bool useq = ctx->has_charge;
+      size_t lds = (size_t)ctx->stage_cap * 32 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? (size_t)ctx->stage_cap * 8 : 0);
+      if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
+      NbTileArgs na;
+      na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
+      na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
+      na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
+      na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (ctx->timing)
       {
@@ -1052,17 +1309,23 @@ static int launch_forces(ddcmi_ctx *ctx)
          e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
          HIPCHK(ctx, hipEventRecord(e0, st));
       }
-      bool useq = ctx->has_charge;
       if (useq)
-         hipLaunchKernelGGL(k_nonbond<true>, dim3(grid), dim3(DDCMI_BLOCK), lds, st, n, ctx->npad, nblk, ctx->pos.p, ctx->qatom.p, ctx->nbr.p, ctx->nbr_cnt.p,
-                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->nlj, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR,
+      {
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         hipLaunchKernelGGL(k_nonbond<true>, dim3(grid), dim3(DDCMI_BLOCK), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p,
+                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR,
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p);
+      }
       else
-         hipLaunchKernelGGL(k_nonbond<false>, dim3(grid), dim3(DDCMI_BLOCK), lds, st, n, ctx->npad, nblk, ctx->pos.p, ctx->qatom.p, ctx->nbr.p, ctx->nbr_cnt.p,
-                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->nlj, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR,
+      {
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         hipLaunchKernelGGL(k_nonbond<false>, dim3(grid), dim3(DDCMI_BLOCK), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p,
+                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR,
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p);
+      }
       if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
-      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, nblk, 8, 8, ctx->d_results + R_NB_LJ);
+      hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);
+      hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ);
    }
    else
       hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
@@ -1097,10 +1360,12 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
 static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick)
 {
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK);
-   ENSURE(ctx, ctx->partials, (size_t)(nblk + 8) * 8);
+   ENSURE(ctx, ctx->partials, (size_t)(std::max(ctx->ntile, nblk) + 8) * 8);
+   ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
    hipLaunchKernelGGL(k_kick_ke, dim3(nblk), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
                       ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->partials.p, do_kick);
-   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->d_results + R_RK);
+   hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->red_tmp.p + RED_BLOCKS * 8);
+   hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK);
    return DDCMI_OK;
 }
 
@@ -1208,7 +1473,6 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
    (void)hipSetDevice(ctx->device);
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nb = cdiv(n, 256);
-   const int *lst = which ? ctx->excl.p : ctx->nbr.p;
    const int *cnt = which ? ctx->excl_cnt.p : ctx->nbr_cnt.p;
    int64_t tot = which ? ctx->excl_entries : ctx->list_entries;
    if (nentries) *nentries = tot;
@@ -1225,7 +1489,17 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
    {
       if (d_j.ensure(tot)) { d_start.release(); SETERR(ctx, DDCMI_ENOMEM, "get_list alloc"); }
       HIPCHK(ctx, hipMemcpyAsync(d_start.p, start, (n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_list_to_csr, dim3(nb), dim3(256), 0, st, n, ctx->npad, lst, cnt, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
+      if (which == 0)
+      {
+         NbTileArgs na;
+         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
+         na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
+         na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
+         na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
+         hipLaunchKernelGGL(k_tilelist_to_csr, dim3(ctx->ntile), dim3(256), 0, st, na, n, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
+      }
+      else
+         hipLaunchKernelGGL(k_list_to_csr, dim3(nb), dim3(256), 0, st, n, ctx->npad, ctx->excl.p, cnt, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
       HIPCHK(ctx, hipMemcpyAsync(j, d_j.p, tot * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
    }

@@ -94,7 +94,14 @@ struct ddcmi_ctx
    dbuf<int> scan_tmp;
    /* lists */
    int maxnbr = 0, maxexcl = 0;
-   dbuf<int> nbr, nbr_cnt, excl, excl_cnt;
+   dbuf<int> nbr_cnt, excl, excl_cnt, shellpk;
+   /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
+   int ntile = 0, stage_cap = 0;
+   dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
+   dbuf<long long> tile_base;
+   dbuf<unsigned short> nbr16;
+   unsigned long long arena_cap = 0;
+   dbuf<double> red_tmp;
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
    /* bonded */
