@@ -245,6 +245,7 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *tot, int *s_w)
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
+   int pack_type;                       /* entries carry the LJ type in bits 15:12 (nlj <= 16, cap <= 4096) */
    const int *cell_start_o;             /* owned beads per cell: exclusive scan, [ncell+1] */
    const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges */
    int *stage_idx, *tile_nstage;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    ofs_s[2 * threadIdx.x] = ex; ofs_s[2 * threadIdx.x + 1] = ex + v[0];
    gst_s[2 * threadIdx.x] = g[0]; gst_s[2 * threadIdx.x + 1] = g[1];
    if (threadIdx.x == 0) { ofs_s[512] = tot; ta.tile_nstage[t] = tot; }
-   if (tot > ta.cap || tot > 65535)
+   if (tot > ta.cap || tot > (ta.pack_type ? 4096 : 65535))
    {
       if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
       return;      /* LDS capacity too small: the host retries with a larger cap */
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
                   if (r2 < rl2)
                   {
                      bool pruned = false;
-                     if (nmoltype > 0)
+                     long long wj = __double_as_longlong(pb.y);
+                     if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
                      {
                         uint64_t gj = gid[sidx[sj]];
                         if ((gi >> 32) == (gj >> 32))
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
                      else if (sh == 1) slot = o1 + c1++;
                      else if (sh == 2) slot = o2 + c2++;
                      else slot = o3 + c3++;
-                     if (pass == 1) ta.nbr16[base + (size_t)slot * rows + al] = (unsigned short)sj;
+                     if (pass == 1) ta.nbr16[base + (size_t)slot * rows + al] = (unsigned short)(ta.pack_type ? (sj | ((int)(wj & 0xf) << 12)) : sj);
                   }
                }
             }
@@ -464,7 +466,7 @@ __device__ __forceinline__ double rsqrt_f64(double x)
    return y;
 }
 
-template <bool HAS_Q>
+template <bool HAS_Q, bool PACKED>
 __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ qatom,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
@@ -473,10 +475,14 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
                                                          double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz,
                                                          double *__restrict__ partials)
 {
+   /* LDS: staged neighbourhood as {x,y} pairs + z (24 B per bead), LJ table, and --
+    * only when needed -- per-bead LJ types (nlj > 16) and charges */
    extern __shared__ double2 smem[];
-   double2 *A_s = smem, *B_s = smem + ta.cap;
-   double4 *s_lj = (double4 *)(smem + 2 * (size_t)ta.cap);
+   double2 *XY_s = smem;
+   double *Z_s = (double *)(smem + ta.cap);
+   double4 *s_lj = (double4 *)(Z_s + ta.cap);
    double *q_s = (double *)(s_lj + ta.nlj * ta.nlj);
+   unsigned char *T_s = (unsigned char *)(q_s + (HAS_Q ? ta.cap : 0));
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
     * give XCD x the contiguous tile range [x*per, (x+1)*per): neighbouring tiles
     * (which stage overlapping neighbourhoods) then share one L2. Speed only. */
@@ -498,8 +504,9 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
       {
          int gj = sidx[k];
          double4 p = pos[gj];
-         A_s[k] = make_double2(p.x, p.y);
-         B_s[k] = make_double2(p.z, p.w);
+         XY_s[k] = make_double2(p.x, p.y);
+         Z_s[k] = p.z;
+         if (!PACKED) T_s[k] = (unsigned char)(__double_as_longlong(p.w) & 0xff);
          if (HAS_Q) q_s[k] = qatom[gj];
       }
       __syncthreads();
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
          bool active = al < nown;
          int a = ts + (active ? al : 0);
          double4 pi = pos[a];
-         int ti = (int)(__double_as_longlong(pi.w) & 0xffffffffll);
+         int ti = (int)(__double_as_longlong(pi.w) & 0xffffll);
          double kqi = 0.0;
          if (HAS_Q) kqi = keR * qatom[a];
          int cnt = active ? ta.nbr_cnt[a] : 0;
@@ -536,10 +543,12 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
 #pragma unroll
             for (int u = 0; u < CH; u++)
             {
-               int sj = (k0 + u < cnt) ? (int)e[u] : 0;
-               double2 pa = A_s[sj], pb = B_s[sj];
-               x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pb.x;
-               tj[u] = (int)(__double_as_longlong(pb.y) & 0xffffffffll);
+               int ee = (k0 + u < cnt) ? (int)e[u] : 0;
+               int sj = PACKED ? (ee & 0xfff) : ee;
+               double2 pa = XY_s[sj];
+               double pz = Z_s[sj];
+               x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
+               tj[u] = PACKED ? (ee >> 12) : sj;
                double rr = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                r2[u] = (k0 + u < cnt) ? rr : rc2;
             }
@@ -548,7 +557,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
             {
                if (r2[u] < rc2)
                {
-                  double4 lj = s_lj[ti * nlj + tj[u]];          /* {sigma^2, 4eps, shift, 24eps} */
+                  int tjj = PACKED ? tj[u] : (int)T_s[tj[u]];
+                  double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */
                   double ir = rsqrt_f64(r2[u]);
                   double ir2 = ir * ir;
                   double s2 = lj.x * ir2;
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
                   double dvdr = lj.w * (s6 - 2.0 * s12) * ir2;
                   if (HAS_Q)
                   {
-                     int sj = (int)e[u];
+                     int sj = PACKED ? ((int)e[u] & 0xfff) : (int)e[u];
                      double kqij = kqi * q_s[sj];
                      acc[1] += kqij * (ir + krf * r2[u] - crf);
                      dvdr += kqij * (2.0 * krf - ir2 * ir);
@@ -749,13 +759,14 @@ __global__ void k_export3(int nloc, const double *a, const double *b, const doub
    int o = orig[i];
    oa[o] = a[i]; ob[o] = b[i]; oc[o] = c[i];
 }
+/* record tag w (bit-cast into pos.w): [63:32] molecule id (gid>>32, bioGid.h) [31:16] species [15:0] LJ type */
 __global__ void k_init_state(int n, const double *rx, const double *ry, const double *rz, const int *species, const int *ljtype_sp,
-                             const double *charge_sp, double4 *pos, double *qatom, int *orig, int *slot)
+                             const double *charge_sp, const uint64_t *gid, double4 *pos, double *qatom, int *orig, int *slot)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
    int sp = species[i];
-   long long w = ((long long)sp << 32) | (long long)(unsigned)ljtype_sp[sp];
+   long long w = (long long)((gid[i] >> 32) << 32) | ((long long)(sp & 0xffff) << 16) | (long long)(ljtype_sp[sp] & 0xffff);
    pos[i] = make_double4(rx[i], ry[i], rz[i], __longlong_as_double(w));
    qatom[i] = charge_sp[sp];
    orig[i] = i;
@@ -765,12 +776,12 @@ __global__ void k_fill_q(int n, const double4 *pos, const double *charge_sp, dou
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
-   int sp = (int)(__double_as_longlong(pos[i].w) >> 32);
+   int sp = (int)((__double_as_longlong(pos[i].w) >> 16) & 0xffff);
    qatom[i] = charge_sp[sp];
 }
 /* test/inspection export: decode the tile ELL (16-bit staged indices) into CSR
  * over caller-order indices; image atoms map back to their source bead */
-__global__ void k_tilelist_to_csr(NbTileArgs ta, int nloc, const int *orig, const int *halo_src, const int *start, int *jout)
+__global__ void k_tilelist_to_csr(NbTileArgs ta, int pack_type, int nloc, const int *orig, const int *halo_src, const int *start, int *jout)
 {
    int t = blockIdx.x;
    int ts = ta.cell_start_o[64 * t];
@@ -786,7 +797,8 @@ __global__ void k_tilelist_to_csr(NbTileArgs ta, int nloc, const int *orig, cons
       int cnt = ta.nbr_cnt[a];
       for (int k = 0; k < cnt; k++)
       {
-         int j = sidx[ta.nbr16[base + (size_t)k * rows + al]];
+         int ee = ta.nbr16[base + (size_t)k * rows + al];
+         int j = sidx[pack_type ? (ee & 0xfff) : ee];
          if (j >= nloc) j = halo_src[j - nloc];
          jout[s + k] = orig[j];
       }
@@ -1057,7 +1069,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    }
    hipLaunchKernelGGL(k_init_state, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species.p,
-                      ctx->d_ljtype_sp.p, ctx->d_charge_sp.p, ctx->pos.p, ctx->qatom.p, ctx->orig.p, ctx->slot_of_orig.p);
+                      ctx->d_ljtype_sp.p, ctx->d_charge_sp.p, ctx->gid.p, ctx->pos.p, ctx->qatom.p, ctx->orig.p, ctx->slot_of_orig.p);
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    if (vx && vy && vz)
    {
@@ -1216,7 +1228,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    if (ctx->stage_cap == 0)
    {
       double per_cell = dens / (gp.cinv[0] * gp.cinv[1] * gp.cinv[2]);
-      ctx->stage_cap = (((int)(512.0 * per_cell * 1.12) + 96) + 63) & ~63;
+      ctx->stage_cap = (((int)(512.0 * per_cell * 1.05) + 48) + 63) & ~63;
       if (ctx->stage_cap < 256) ctx->stage_cap = 256;
       ctx->maxexcl = 1;
       for (int m = 0; m < ctx->nmoltype; m++) if (ctx->mol_nspecies[m] > 1) ctx->maxexcl = 16;
@@ -1242,8 +1254,9 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
+      ctx->pack_type = (ctx->nlj <= 16 && ctx->stage_cap <= 4096);
       TileArgs ta;
-      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap;
+      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type ? 1 : 0;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
       ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p;
@@ -1290,7 +1303,8 @@ static int launch_forces(ddcmi_ctx *ctx)
       int ntile = ctx->ntile;
       int grid = ((ntile + 7) / 8) * 8;
       bool useq = ctx->has_charge;
-      size_t lds = (size_t)ctx->stage_cap * 32 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? (size_t)ctx->stage_cap * 8 : 0);
+      bool packed = ctx->pack_type;
+      size_t lds = (size_t)ctx->stage_cap * 24 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? (size_t)ctx->stage_cap * 8 : 0) + (packed ? 0 : (size_t)ctx->stage_cap);
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
@@ -1309,20 +1323,16 @@ static int launch_forces(ddcmi_ctx *ctx)
          e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
          HIPCHK(ctx, hipEventRecord(e0, st));
       }
-      if (useq)
-      {
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         hipLaunchKernelGGL(k_nonbond<true>, dim3(grid), dim3(DDCMI_BLOCK), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p,
-                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR,
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p);
-      }
-      else
-      {
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         hipLaunchKernelGGL(k_nonbond<false>, dim3(grid), dim3(DDCMI_BLOCK), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p,
-                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR,
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p);
-      }
+#define LAUNCH_NB(Q, P) do { \
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P>), dim3(grid), dim3(DDCMI_BLOCK), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
+                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
+      if (useq && packed) LAUNCH_NB(true, true);
+      else if (useq) LAUNCH_NB(true, false);
+      else if (packed) LAUNCH_NB(false, true);
+      else LAUNCH_NB(false, false);
+#undef LAUNCH_NB
       if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
       hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);
       hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ);
@@ -1496,7 +1506,7 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
          na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
          na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
          na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
-         hipLaunchKernelGGL(k_tilelist_to_csr, dim3(ctx->ntile), dim3(256), 0, st, na, n, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
+         hipLaunchKernelGGL(k_tilelist_to_csr, dim3(ctx->ntile), dim3(256), 0, st, na, ctx->pack_type ? 1 : 0, n, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
       }
       else
          hipLaunchKernelGGL(k_list_to_csr, dim3(nb), dim3(256), 0, st, n, ctx->npad, ctx->excl.p, cnt, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);

@@ -96,7 +96,7 @@ struct ddcmi_ctx
    int maxnbr = 0, maxexcl = 0;
    dbuf<int> nbr_cnt, excl, excl_cnt, shellpk;
    /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
-   int ntile = 0, stage_cap = 0;
+   int ntile = 0, stage_cap = 0; bool pack_type = false;
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
    dbuf<long long> tile_base;
    dbuf<unsigned short> nbr16;
