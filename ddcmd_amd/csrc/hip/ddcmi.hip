@@ -252,6 +252,7 @@ struct TileArgs
    long long *tile_base; int *tile_width, *tile_rows;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt, *shellpk;
+   unsigned short *tmp16; unsigned char *tmp8; int tmpw;     /* row-major scratch list + shell tags, tmpw entries per bead */
 };
 
 struct NbTileArgs
@@ -330,116 +331,192 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    const double rl2 = gp.rlist * gp.rlist;
    const int rows = (nown + 63) & ~63;
    int mymax = 0;
-   /* pass 0 counts (per distance shell), pass 1 fills */
-   for (int pass = 0; pass < 2; pass++)
+   /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go
+    * to the bead's own row of a row-major scratch list (sequential 2-byte appends,
+    * write-combined in L2) tagged with their distance shell; k_tile_transpose then
+    * lays them out slot-major in shell order. */
+   for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK)
    {
-      long long base = (pass == 1) ? s_base : 0;
-      if (pass == 1 && base < 0) break;            /* arena overflow: host grows it and rebuilds */
-      for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK)
-      {
-         int a = ts + al;
-         double4 pi = pos[a];
-         int cx, cy, cz;
-         cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
-         int lx = cx - 4 * tx, ly = cy - 4 * ty, lz = cz - 4 * tz;       /* 0..3 */
-         int rc_own = (lz + 2) * 64 + (ly + 2) * 8 + (lx + 2);
-         int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
-         uint64_t gi = 0;
-         int mt = 0, mns = 1;
-         if (nmoltype > 0) { gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt]; }
-         int c0 = 0, c1 = 0, c2 = 0, c3 = 0, ecnt = 0;
-         int o1 = 0, o2 = 0, o3 = 0;
-         if (pass == 1)
+      int a = ts + al;
+      double4 pi = pos[a];
+      int cx, cy, cz;
+      cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
+      int lx = cx - 4 * tx, ly = cy - 4 * ty, lz = cz - 4 * tz;       /* 0..3 */
+      int rc_own = (lz + 2) * 64 + (ly + 2) * 8 + (lx + 2);
+      int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
+      uint64_t gi = 0;
+      int mt = 0, mns = 1;
+      if (nmoltype > 0) { gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt]; }
+      int c0 = 0, c1 = 0, c2 = 0, cnt = 0, ecnt = 0;
+      unsigned short *row = ta.tmp16 + (size_t)a * ta.tmpw;
+      unsigned char *shrow = ta.tmp8 + (size_t)a * ta.tmpw;
+      for (int dz = 0; dz < 5; dz++)
+         for (int dy = 0; dy < 5; dy++)
          {
-            int pk = ta.shellpk[a];
-            o1 = pk & 1023; o2 = o1 + ((pk >> 10) & 1023); o3 = o2 + ((pk >> 20) & 1023);
-         }
-         for (int dz = 0; dz < 5; dz++)
-            for (int dy = 0; dy < 5; dy++)
+            int rc0 = (lz + dz) * 64 + (ly + dy) * 8 + lx;      /* 5 consecutive cells in x are contiguous */
+            int s0 = ofs_s[rc0], s1 = ofs_s[rc0 + 5];
+            for (int sj = s0; sj < s1; sj++)
             {
-               int rc0 = (lz + dz) * 64 + (ly + dy) * 8 + lx;      /* 5 consecutive cells in x are contiguous */
-               int s0 = ofs_s[rc0], s1 = ofs_s[rc0 + 5];
-               for (int sj = s0; sj < s1; sj++)
+               if (sj == self) continue;
+               double2 pa = A_s[sj], pb = B_s[sj];
+               double x = pi.x - pa.x, y = pi.y - pa.y, z = pi.z - pb.x;
+               double r2 = x * x + y * y + z * z;
+               if (r2 < rl2)
                {
-                  if (sj == self) continue;
-                  double2 pa = A_s[sj], pb = B_s[sj];
-                  double x = pi.x - pa.x, y = pi.y - pa.y, z = pi.z - pb.x;
-                  double r2 = x * x + y * y + z * z;
-                  if (r2 < rl2)
+                  bool pruned = false;
+                  long long wj = __double_as_longlong(pb.y);
+                  if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
                   {
-                     bool pruned = false;
-                     long long wj = __double_as_longlong(pb.y);
-                     if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
+                     uint64_t gj = gid[sidx[sj]];
+                     if ((gi >> 32) == (gj >> 32))
                      {
-                        uint64_t gj = gid[sidx[sj]];
-                        if ((gi >> 32) == (gj >> 32))
+                        if (mns > 1)
                         {
-                           if (mns > 1)
+                           unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
+                           for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
                            {
-                              unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
-                              for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
-                              {
-                                 unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
-                                 if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
-                              }
+                              unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
+                              if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
                            }
-                           else pruned = true;
                         }
+                        else pruned = true;
                      }
-                     if (pruned)
-                     {
-                        if (pass == 1 && ecnt < maxexcl) excl[(size_t)ecnt * npad + a] = sidx[sj];
-                        ecnt++;
-                        continue;
-                     }
-                     int sh = (r2 >= sh0) + (r2 >= sh1) + (r2 >= sh2);
-                     int slot;
-                     if (sh == 0) slot = c0++;
-                     else if (sh == 1) slot = o1 + c1++;
-                     else if (sh == 2) slot = o2 + c2++;
-                     else slot = o3 + c3++;
-                     if (pass == 1) ta.nbr16[base + (size_t)slot * rows + al] = (unsigned short)(ta.pack_type ? (sj | ((int)(wj & 0xf) << 12)) : sj);
                   }
+                  if (pruned)
+                  {
+                     if (ecnt < maxexcl) excl[(size_t)ecnt * npad + a] = sidx[sj];
+                     ecnt++;
+                     continue;
+                  }
+                  int sh = (r2 >= sh0) + (r2 >= sh1) + (r2 >= sh2);
+                  c0 += (sh == 0); c1 += (sh == 1); c2 += (sh == 2);
+                  /* scratch: final-format entry + its shell tag in a parallel byte stream */
+                  if (cnt < ta.tmpw)
+                  {
+                     row[cnt] = (unsigned short)(ta.pack_type ? (sj | ((int)(wj & 0xf) << 12)) : sj);
+                     shrow[cnt] = (unsigned char)sh;
+                  }
+                  cnt++;
                }
             }
-         if (pass == 0)
-         {
-            int cnt = c0 + c1 + c2 + c3;
-            mymax = max(mymax, cnt);
-            ta.nbr_cnt[a] = cnt;
-            ta.shellpk[a] = min(c0, 1023) | (min(c1, 1023) << 10) | (min(c2, 1023) << 20);
-            excl_cnt[a] = min(ecnt, maxexcl);
-            if (ecnt > maxexcl) atomicMax(&flags[1], ecnt);
          }
-      }
-      if (pass == 0)
-      {
-         /* block max -> ELL width of this tile; one thread takes the arena slice */
-         int m = mymax;
+      mymax = max(mymax, cnt);
+      ta.nbr_cnt[a] = min(cnt, ta.tmpw);
+      ta.shellpk[a] = min(c0, 1023) | (min(c1, 1023) << 10) | (min(c2, 1023) << 20);
+      excl_cnt[a] = min(ecnt, maxexcl);
+      if (ecnt > maxexcl) atomicMax(&flags[1], ecnt);
+      if (cnt > ta.tmpw) atomicMax(&flags[5], cnt);
+   }
+   /* block max -> ELL width of this tile; one thread takes the arena slice */
+   int m = mymax;
 #pragma unroll
-         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
-         if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
-         __syncthreads();
-         if (threadIdx.x == 0)
-         {
-            int width = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
-            width = max(width, 1);
-            unsigned long long need = (unsigned long long)rows * width;
-            unsigned long long b0 = atomicAdd(ta.arena_used, need);
-            if (b0 + need > ta.arena_cap) { s_base = -1; atomicMax(&flags[0], 1); }
-            else s_base = (long long)b0;
-            ta.tile_base[t] = s_base < 0 ? 0 : s_base;
-            ta.tile_width[t] = width; ta.tile_rows[t] = s_base < 0 ? 0 : rows;
-            atomicMax(&flags[2], width);
-         }
-         __syncthreads();
-      }
+   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      int width = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+      width = max(min(width, ta.tmpw), 1);
+      unsigned long long need = (unsigned long long)rows * width;
+      unsigned long long b0 = atomicAdd(ta.arena_used, need);
+      long long sb;
+      if (b0 + need > ta.arena_cap) { sb = -1; atomicMax(&flags[0], 1); }
+      else sb = (long long)b0;
+      ta.tile_base[t] = sb < 0 ? 0 : sb;
+      ta.tile_width[t] = width; ta.tile_rows[t] = sb < 0 ? 0 : rows;
+      atomicMax(&flags[2], width);
    }
    /* statistics: entries of this tile */
    unsigned long long mine = 0, mex = 0;
    for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK) { mine += ta.nbr_cnt[ts + al]; mex += excl_cnt[ts + al]; }
    for (int off = 32; off > 0; off >>= 1) { mine += __shfl_down(mine, off, 64); mex += __shfl_down(mex, off, 64); }
    if ((threadIdx.x & 63) == 0) { atomicAdd(&totals[0], mine); atomicAdd(&totals[1], mex); }
+}
+
+/* second half of the build: row-major scratch -> the tile's slot-major ELL slice
+ * with entries ordered by distance shell.  One wave per bead reads the bead's row
+ * coalesced, ranks the entries of each shell with ballot/popcount, and drops them
+ * into an LDS image of the slice, which is then written out with coalesced stores. */
+#define IMG_ROWS 128
+#define IMG_STRIDE (IMG_ROWS + 2)         /* +2 entries: slot rows land on different LDS banks */
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
+{
+   extern __shared__ unsigned int img32[];          /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for fill/copy */
+   unsigned short *img = (unsigned short *)img32;
+   int t = blockIdx.x;
+   int ts = ta.cell_start_o[64 * t];
+   int nown = ta.cell_start_o[64 * t + 64] - ts;
+   int rows = ta.tile_rows[t];
+   if (nown <= 0 || rows <= 0) return;
+   int width = ta.tile_width[t];
+   long long base = ta.tile_base[t];
+   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+   const int npass = (ta.tmpw + 63) >> 6;
+   for (int c0 = 0; c0 < rows; c0 += IMG_ROWS)
+   {
+      for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += DDCMI_BLOCK) img32[idx] = 0;
+      __syncthreads();
+      /* wave w owns rows [32w, 32w+32) of this chunk; their counts are fetched with one load */
+      int r_lane = c0 + 32 * w + (lane & 31);
+      int my_cnt = 0, my_pk = 0;
+      if (r_lane < nown) { my_cnt = ta.nbr_cnt[ts + r_lane]; my_pk = ta.shellpk[ts + r_lane]; }
+      int e_nx[3], s_nx[3];
+      {
+         int a0 = ts + min(c0 + 32 * w, nown - 1);
+         const unsigned short *row = ta.tmp16 + (size_t)a0 * ta.tmpw;
+         const unsigned char *shrow = ta.tmp8 + (size_t)a0 * ta.tmpw;
+#pragma unroll
+         for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : 4; }
+      }
+      for (int rr = 0; rr < 32; rr++)
+      {
+         int r = 32 * w + rr;                      /* row inside the chunk */
+         int cnt = __shfl(my_cnt, rr, 64), pk = __shfl(my_pk, rr, 64);
+         int e_cu[3], s_cu[3];
+#pragma unroll
+         for (int q = 0; q < 3; q++) { e_cu[q] = e_nx[q]; s_cu[q] = s_nx[q]; }
+         if (rr + 1 < 32)
+         {
+            int a1 = ts + min(c0 + r + 1, nown - 1);
+            const unsigned short *row = ta.tmp16 + (size_t)a1 * ta.tmpw;
+            const unsigned char *shrow = ta.tmp8 + (size_t)a1 * ta.tmpw;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : 4; }
+         }
+         if (c0 + r >= nown) continue;
+         int o0 = 0, o1 = pk & 1023, o2 = o1 + ((pk >> 10) & 1023), o3 = o2 + ((pk >> 20) & 1023);
+#define TR_PASS(E, SH, Q) do { \
+            int k_ = 64 * (Q) + lane; \
+            bool valid_ = k_ < cnt; \
+            int sh_ = valid_ ? (SH) : 4; \
+            unsigned long long b0 = __ballot(sh_ == 0), b1 = __ballot(sh_ == 1), b2 = __ballot(sh_ == 2), b3 = __ballot(sh_ == 3); \
+            int slot_ = (sh_ == 0) ? o0 + __popcll(b0 & ltmask) : (sh_ == 1) ? o1 + __popcll(b1 & ltmask) \
+                      : (sh_ == 2) ? o2 + __popcll(b2 & ltmask) : o3 + __popcll(b3 & ltmask); \
+            if (valid_) img[slot_ * IMG_STRIDE + r] = (unsigned short)(E); \
+            o0 += __popcll(b0); o1 += __popcll(b1); o2 += __popcll(b2); o3 += __popcll(b3); } while (0)
+         if (cnt > 0) TR_PASS(e_cu[0], s_cu[0], 0);
+         if (cnt > 64) TR_PASS(e_cu[1], s_cu[1], 1);
+         if (cnt > 128) TR_PASS(e_cu[2], s_cu[2], 2);
+         for (int q = 3; q < npass && 64 * q < cnt; q++)
+         {
+            int a = ts + c0 + r, k = 64 * q + lane;
+            int e = (k < cnt) ? (int)ta.tmp16[(size_t)a * ta.tmpw + k] : 0;
+            int sh = (k < cnt) ? (int)ta.tmp8[(size_t)a * ta.tmpw + k] : 4;
+            TR_PASS(e, sh, q);
+         }
+#undef TR_PASS
+      }
+      __syncthreads();
+      int nr = min(IMG_ROWS, rows - c0);           /* multiple of 64 */
+      int nr2 = nr >> 1;
+      for (int idx = threadIdx.x; idx < width * nr2; idx += DDCMI_BLOCK)
+      {
+         int slot = idx / nr2, r2 = idx - slot * nr2;
+         *(unsigned int *)(ta.nbr16 + base + (size_t)slot * rows + c0 + 2 * r2) = img32[slot * (IMG_STRIDE / 2) + r2];
+      }
+      __syncthreads();
+   }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -886,7 +963,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
-   ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release(); ctx->tmp16.release(); ctx->tmp8.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -1236,6 +1313,8 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    if (ctx->arena_cap == 0)
    {
       double expect = 4.0 / 3.0 * M_PI * gp.rlist * gp.rlist * gp.rlist * dens;
+      ctx->tmpw = ((int)(expect * 1.25) + 24 + 7) & ~7;
+      if ((size_t)ctx->tmpw * IMG_STRIDE * 2 > 150 * 1024) ctx->tmpw = (150 * 1024 / (IMG_STRIDE * 2)) & ~7;
       ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
    }
    ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad); ENSURE(ctx, ctx->shellpk, ctx->npad);
@@ -1262,10 +1341,18 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p;
       ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_tot + 2;
       ta.nbr_cnt = ctx->nbr_cnt.p; ta.shellpk = ctx->shellpk.p;
+      if (ctx->tmp16.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
+      if (ctx->tmp8.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
+      ta.tmp16 = ctx->tmp16.p; ta.tmp8 = ctx->tmp8.p; ta.tmpw = ctx->tmpw;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(DDCMI_BLOCK), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,
                          sh0, sh1, sh2, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+      {
+         size_t lds2 = (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+         hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(DDCMI_BLOCK), lds2, st, ta);
+      }
       HIPCHK(ctx, hipGetLastError());
       unsigned long long tot[3];
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1275,6 +1362,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
       if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.05) + 32) + 63) & ~63; again = true; }
       if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }
       if (ctx->h_flags[1] > 0) { ctx->maxexcl = ctx->h_flags[1] + 4; again = true; }
+      if (ctx->h_flags[5] > 0) { ctx->tmpw = ((int)(ctx->h_flags[5] * 1.1) + 8 + 7) & ~7; again = true; }
       if (!again)
       {
          ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
