@@ -165,3 +165,71 @@ def test_deck_loader_on_reference_waterbox(waterbox):
     # the shipped selection (no override) is NGLFCONSTRAINT + LANGEVIN groups
     raw = load_deck(REF_DECK)
     assert raw.integrator_type == "NGLFCONSTRAINT" and list(raw.group_type) == [2, 2]
+
+
+LIPID_DECK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck", "object.data")
+
+
+def test_lipid_deck_loader():
+    """host C loader on our own ddcMD-format lipid deck: MMFF tree, exclusion lists, units"""
+    s = load_deck(LIPID_DECK)
+    assert s.natoms == 2363 and s.nspecies == 19 and s.nlj == 6 and s.nmoltype == 4 and s.nresi == 4
+    assert list(s.mol_nspecies) == [1, 1, 12, 5]
+    # genMartiniBondPair: func-1 bonds + valid exclusions (bioMartini.c:135-282)
+    assert list(s.bpair_off) == [0, 0, 0, 11, 16]
+    assert (int(s.bpairI[15]), int(s.bpairJ[15])) == (0, 2)
+    assert list(s.resi_natoms) == [1, 1, 12, 5]
+    assert list(s.bond_off) == [0, 0, 0, 11, 15] and list(s.angle_off) == [0, 0, 0, 8, 11] and list(s.tors_off) == [0, 0, 0, 0, 3]
+    assert sorted(set(s.angle_func.tolist())) == [1, 2, 10] and sorted(set(s.tors_func.tolist())) == [1, 2]
+    assert abs(s.bond_kb[0] - units_convert(1250.0, "kJ*mol^-1*nm^-2")) < 1e-15
+    assert abs(s.bond_b0[2] - units_convert(0.37, "nm")) < 1e-13
+    assert abs(s.charge[s.species_name.index("DPPCxNC3")] - 1.0) < 1e-15
+    assert abs(s.charge[s.species_name.index("DPPCxPO4")] + 1.0) < 1e-15
+    assert s.species_name[s.species[0]] == "DPPCxNC3" and int(s.gid[13]) == (1 << 32) | 1
+    # every species maps to its residue/atom slot (getCGLJindexbySpecie)
+    assert s.ljtype[s.species_name.index("DPPCxC3B")] == 5 and s.atomoffset[s.species_name.index("DPPCxC3B")] == 10
+    assert s.updateRate == 10 and abs(s.dt - 10.0) < 1e-15
+
+
+def test_lipid_oracle_vs_brute_force_and_third_law():
+    """nonbonded part incl. excluded-pair reaction field vs the O(N^2) path; bonded forces sum to zero"""
+    s = load_deck(LIPID_DECK)
+    o = pyoracle.Oracle(s)
+    npairs = o.build_list()
+    assert npairs[1] == 120 * 11 + 8 * 5          # every bonded/excluded pair sits in list 1 (reOrgPairs)
+    e, vir = o.forces()
+    fx, fy, fz, vlj, vele, bvir, nin = o.brute_force()
+    bfx, bfy, bfz, e4, bondvir = o.bonded_only()
+    fmax = np.abs(o.fx).max()
+    assert np.abs((o.fx - bfx) - fx).max() < 1e-12 * fmax
+    assert abs(vlj - e["lj"]) < 1e-12 * abs(vlj) and abs(vele - e["ele"]) < 1e-11 * abs(vele)
+    assert np.allclose(bvir + bondvir, vir, rtol=1e-10, atol=1e-12)
+    for f in (bfx, bfy, bfz):
+        assert abs(f.sum()) < 1e-12 * np.abs(f).max() * 50
+    assert abs(e["total"] - (e["lj"] + e["ele"] + e4.sum())) < 1e-12 * abs(e["total"])
+
+
+def test_lipid_oracle_finite_difference_all_terms():
+    """forcetest.c method on the full potential: bonds, 3 angle kinds, torsion, improper, LJ, RF Coulomb"""
+    s = load_deck(LIPID_DECK)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    f0 = np.stack([o.fx.copy(), o.fy.copy(), o.fz.copy()])
+    # pick beads from the test molecules (all term kinds) and a few lipid beads
+    tst = np.flatnonzero(np.array([s.species_name[k].startswith("TSTM") for k in s.species]))[:10]
+    lip = np.array([0, 1, 2, 3, 7, 11])
+    delta = 1e-4
+    worst = 0.0
+    for i in np.concatenate((tst, lip)):
+        for c, arr in enumerate((o.rx, o.ry, o.rz)):
+            x0 = arr[i]
+            arr[i] = x0 + delta
+            o.build_list()
+            ep = o.forces()[0]["total"]
+            arr[i] = x0 - delta
+            o.build_list()
+            em = o.forces()[0]["total"]
+            arr[i] = x0
+            fd = -(ep - em) / (2 * delta)
+            worst = max(worst, abs(fd - f0[c, i]) / np.abs(f0).max())
+    assert worst < 2e-7
