@@ -26,6 +26,7 @@
 #include "ddcmi_internal.h"
 #include <math.h>
 #include <algorithm>
+#include <rccl/rccl.h>
 
 static std::string g_create_err;
 
@@ -187,20 +188,38 @@ __global__ void k_gather_halo(int nhalo, const int *horder, const int *hsrc_t, c
    halo_src[h] = hsrc_t[k];
    halo_shift[h] = hshift_t[k];
 }
-/* refresh image atoms from their sources: every step (replaces ddcUpdate's
- * position halo for the self-image case, ddcUpdate.c:40-85) */
+/* refresh image/halo beads every step (replaces ddcUpdate's position halo,
+ * ddcUpdate.c:40-85): src >= 0 -> periodic self-image of owned bead src;
+ * src < 0 -> bead -1-src of the buffer received from a neighbour domain (the sender
+ * has already applied the periodic shift). */
 __global__ void k_halo_update(int nloc, int nhalo, const int *halo_src, const int *halo_shift, double L0, double L1, double L2,
-                              double4 *pos, uint64_t *gid, bool with_gid)
+                              double4 *pos, uint64_t *gid, bool with_tags, const double *hrecv3, const double *hrecv5)
 {
    int h = blockIdx.x * blockDim.x + threadIdx.x;
    if (h >= nhalo) return;
-   int s = halo_src[h], code = halo_shift[h];
-   double4 p = pos[s];
-   p.x += (double)(code % 3 - 1) * L0;
-   p.y += (double)((code / 3) % 3 - 1) * L1;
-   p.z += (double)(code / 9 - 1) * L2;
-   pos[nloc + h] = p;
-   if (with_gid) gid[nloc + h] = gid[s];
+   int s = halo_src[h];
+   if (s >= 0)
+   {
+      int code = halo_shift[h];
+      double4 p = pos[s];
+      p.x += (double)(code % 3 - 1) * L0;
+      p.y += (double)((code / 3) % 3 - 1) * L1;
+      p.z += (double)(code / 9 - 1) * L2;
+      pos[nloc + h] = p;
+      if (with_tags) gid[nloc + h] = gid[s];
+   }
+   else
+   {
+      int k = -1 - s;
+      double4 p = pos[nloc + h];
+      p.x = hrecv3[3 * k]; p.y = hrecv3[3 * k + 1]; p.z = hrecv3[3 * k + 2];
+      if (with_tags)
+      {
+         p.w = hrecv5[5 * k + 3];
+         gid[nloc + h] = (uint64_t)__double_as_longlong(hrecv5[5 * k + 4]);
+      }
+      pos[nloc + h] = p;
+   }
 }
 __global__ void k_merge_cells(int ncell, int nloc, const int *cnt_o, const int *start_o, const int *cnt_h, const int *start_h, int *cell_start, int *cell_cnt)
 {
@@ -1223,15 +1242,19 @@ static int setup_grid(ddcmi_ctx *ctx)
    {
       gp.L[a] = L[a];
       bool periodic = (ctx->pbc >> a) & 1;
+      int P = ctx->pgrid[a];
+      double W = L[a] / P;                       /* brick width of this rank */
       if (periodic && L[a] < 2.0 * rlist)
          SETERR(ctx, DDCMI_EUNSUPPORTED, "box length %g on axis %d is shorter than 2*(rmax+deltaR)=%g: the nearest-image convention the reference relies on breaks down", L[a], a, 2.0 * rlist);
-      gp.lo[a] = -0.5 * L[a];
+      if (P > 1 && W < rlist)
+         SETERR(ctx, DDCMI_EUNSUPPORTED, "domain width %g on axis %d is smaller than rmax+deltaR=%g: halo would reach beyond nearest-neighbour domains", W, a, rlist);
+      gp.lo[a] = -0.5 * L[a] + ctx->pcoord[a] * W;
       double cmin = 0.5 * rlist;
-      int n = (int)floor(L[a] / cmin);
+      int n = (int)floor(W / cmin);
       if (n < 1) n = 1;
       gp.n[a] = n;
-      gp.cinv[a] = (double)n / L[a];
-      gp.m[a] = periodic ? 4 : 0;      /* one whole tile of margin: interior tiles hold owned beads only */
+      gp.cinv[a] = (double)n / W;
+      gp.m[a] = (periodic || P > 1) ? 4 : 0;      /* one whole tile of margin: interior tiles hold owned beads only */
       gp.g[a] = n + 2 * gp.m[a];
       gp.T[a] = (gp.g[a] + 3) / 4;
       ncell *= gp.T[a] * 4;
@@ -1241,12 +1264,9 @@ static int setup_grid(ddcmi_ctx *ctx)
    return DDCMI_OK;
 }
 
-extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
+/* rebuild phase 1: wrap into the box, cell ids, counting sort of the owned beads */
+int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
 {
-   if (!ctx) return DDCMI_EINVAL;
-   if (ctx->nloc <= 0 || !ctx->have_box || ctx->nlj <= 0 || ctx->updateRate <= 0)
-      SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
-   (void)hipSetDevice(ctx->device);
    int rc = setup_grid(ctx);
    if (rc) return rc;
    GridParams &gp = ctx->gp;
@@ -1254,20 +1274,48 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    int n = ctx->nloc, nb = cdiv(n, 256), ncell = gp.ncell, ncb = cdiv(ncell, 256);
    dbuf<int> *cb[] = {&ctx->cell_cnt_o, &ctx->cell_start_o, &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt};
    for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
-   /* 1. wrap + cell ids + counting sort of the owned atoms */
    HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_o.p, 0, (ncell + 1) * sizeof(int), st));
    HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_h.p, 0, ncell * sizeof(int), st));
-   hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p);
+   if (n > 0)
+   {
+      hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p);
+   }
    HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_o.p, ctx->cell_cnt_o.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
-   hipLaunchKernelGGL(k_scatter_order, dim3(nb), dim3(256), 0, st, n, ctx->cid.p, ctx->crank.p, ctx->cell_start_o.p, ctx->order.p);
-   hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
-   hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
-                      ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
-                      ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p);
-   std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
-   std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
-   /* 2. periodic image atoms */
+   if (n > 0)
+   {
+      hipLaunchKernelGGL(k_scatter_order, dim3(nb), dim3(256), 0, st, n, ctx->cid.p, ctx->crank.p, ctx->cell_start_o.p, ctx->order.p);
+      hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
+      hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
+                         ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
+                         ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p);
+      std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
+      std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
+   }
+   return DDCMI_OK;
+}
+
+/* make room for nh image/halo beads behind the owned ones */
+int ddcmi_bl_reserve_halo(ddcmi_ctx *ctx, int nh)
+{
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc;
+   dbuf<int> *hb[] = {&ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank, &ctx->horder, &ctx->halo_src, &ctx->halo_shift};
+   for (auto b : hb) ENSURE(ctx, *b, nh + 1);
+   if ((size_t)(n + nh) > ctx->pos.cap)
+   {
+      if (ctx->pos.ensure(n + nh, true, st) || ctx->pos2.ensure(n + nh) || ctx->qatom.ensure(n + nh) || ctx->gid.ensure(n + nh, true, st) || ctx->gid2.ensure(n + nh))
+         SETERR(ctx, DDCMI_ENOMEM, "growing particle arrays for %d image atoms failed", nh);
+   }
+   return DDCMI_OK;
+}
+
+/* rebuild phase 2 (single domain): periodic self-images */
+static int bl_self_images(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, nb = cdiv(n, 256), rc;
    hipLaunchKernelGGL(k_count_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->nimg.p);
    HIPCHK(ctx, hipMemcpyAsync(ctx->img_off.p, ctx->nimg.p, n * sizeof(int), hipMemcpyDeviceToDevice, st));
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
@@ -1277,31 +1325,62 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    ctx->nhalo = nh;
    if (nh > 0)
    {
-      dbuf<int> *hb[] = {&ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank, &ctx->horder, &ctx->halo_src, &ctx->halo_shift};
-      for (auto b : hb) ENSURE(ctx, *b, nh + 1);
-      if ((size_t)(n + nh) > ctx->pos.cap)
-      {
-         if (ctx->pos.ensure(n + nh, true, st) || ctx->pos2.ensure(n + nh) || ctx->qatom.ensure(n + nh) || ctx->gid.ensure(n + nh, true, st) || ctx->gid2.ensure(n + nh))
-            SETERR(ctx, DDCMI_ENOMEM, "growing particle arrays for %d image atoms failed", nh);
-      }
-      int nhb = cdiv(nh, 256);
+      if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
       hipLaunchKernelGGL(k_fill_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->img_off.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
+   }
+   return DDCMI_OK;
+}
+
+/* rebuild phase 3: sort the halo descriptors by cell, place the halo beads */
+int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, nh = ctx->nhalo, ncell = gp.ncell, ncb = cdiv(ncell, 256), rc;
+   if (nh > 0)
+   {
+      int nhb = cdiv(nh, 256);
       HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_h.p, ctx->cell_cnt_h.p, ncell * sizeof(int), hipMemcpyDeviceToDevice, st));
       if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_h.p, ncell, nullptr))) return rc;
       hipLaunchKernelGGL(k_scatter_order, dim3(nhb), dim3(256), 0, st, nh, ctx->hcid.p, ctx->hrank.p, ctx->cell_start_h.p, ctx->horder.p);
       hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
       hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p);
-      hipLaunchKernelGGL(k_halo_update, dim3(nhb), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true);
+      hipLaunchKernelGGL(k_halo_update, dim3(nhb), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
+                         ctx->hrecv3.p, ctx->hrecv5.p);
    }
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
-   hipLaunchKernelGGL(k_fill_q, dim3(cdiv(n + nh, 256)), dim3(256), 0, st, n + nh, ctx->pos.p, ctx->d_charge_sp.p, ctx->qatom.p);
+   if (n + nh > 0)
+      hipLaunchKernelGGL(k_fill_q, dim3(cdiv(n + nh, 256)), dim3(256), 0, st, n + nh, ctx->pos.p, ctx->d_charge_sp.p, ctx->qatom.p);
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate <= 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
+      SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
+   (void)hipSetDevice(ctx->device);
+   int rc;
+   if (ctx->nranks > 1) return ddcmi_mg_rebuild(ctx);
+   if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
+   if ((rc = bl_self_images(ctx))) return rc;
+   if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
+   return ddcmi_bl_finish(ctx);
+}
+
+/* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
+int ddcmi_bl_finish(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc;
    /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
-   ctx->npad = cdiv(n, DDCMI_BLOCK) * DDCMI_BLOCK;
+   ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
    int ntile = gp.T[0] * gp.T[1] * gp.T[2];
    ctx->ntile = ntile;
-   double vol = gp.L[0] * gp.L[1] * gp.L[2];
-   double dens = (double)n / vol;
+   double vol = gp.L[0] * gp.L[1] * gp.L[2] / (double)ctx->nranks;
+   double dens = (double)std::max(n, 1) / vol;
    if (ctx->stage_cap == 0)
    {
       double per_cell = dens / (gp.cinv[0] * gp.cinv[1] * gp.cinv[2]);
@@ -1382,9 +1461,14 @@ static int launch_forces(ddcmi_ctx *ctx)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
+   if (ctx->nranks > 1 && !ctx->halo_fresh)
+   {
+      int rc0 = ddcmi_mg_refresh_halo(ctx);
+      if (rc0) return rc0;
+   }
    if (nh > 0)
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
-                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false);
+                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, R_RK * sizeof(double), st));
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
@@ -1447,6 +1531,7 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
    if (!ctx) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    int rc;
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group evaluate forces with ddcmi_group_eval_forces");
    if (!ctx->list_valid && (rc = ddcmi_build_list(ctx))) return rc;
    if ((rc = launch_forces(ctx))) return rc;
    if ((rc = fetch_results(ctx))) return rc;
@@ -1460,7 +1545,7 @@ static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick)
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK);
    ENSURE(ctx, ctx->partials, (size_t)(std::max(ctx->ntile, nblk) + 8) * 8);
    ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
-   hipLaunchKernelGGL(k_kick_ke, dim3(nblk), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
+   hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
                       ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->partials.p, do_kick);
    hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->red_tmp.p + RED_BLOCKS * 8);
    hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK);
@@ -1484,32 +1569,45 @@ static void berendsen_update(ddcmi_ctx *ctx, double dt_half)
    }
 }
 
+/* nglf.c:74-95: FRONT half kick + drift, clock advance */
+static int step_pre(ddcmi_ctx *ctx, double dt)
+{
+   int n = ctx->nloc, nb = cdiv(n, 256);
+   GroupLambda lam;
+   /* lambda applies at the FRONT kick when doScaling is set (berendsen.c:74-80) */
+   for (int g = 0; g < 32; g++) lam.v[g] = (g < ctx->ngroup && ctx->gtype[g] == DDCMI_BERENDSEN && ctx->gdoScaling[g]) ? ctx->glambda[g] : 1.0;
+   if (n > 0)
+      hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
+   ctx->time += dt;
+   ctx->loop += 1;
+   ctx->halo_fresh = false;
+   return DDCMI_OK;
+}
+/* nglf.c:97-108: ddcenergy, BACK half kick, kinetic_terms, group Update */
+static int step_post(ddcmi_ctx *ctx, double dt)
+{
+   int rc;
+   if ((rc = launch_forces(ctx))) return rc;
+   if ((rc = launch_kinetic(ctx, dt, 1))) return rc;
+   berendsen_update(ctx, 0.5 * dt);
+   return DDCMI_OK;
+}
+
 extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
 {
    if (!ctx || nsteps < 0) return DDCMI_EINVAL;
    if (!ctx->forces_valid) SETERR(ctx, DDCMI_EINVAL, "ddcmi_step_nglf needs forces: call ddcmi_eval_forces first (firstEnergyCall, masters.c:579)");
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are stepped with ddcmi_group_step_nglf");
    (void)hipSetDevice(ctx->device);
-   hipStream_t st = ctx->stream;
-   int n = ctx->nloc, nb = cdiv(n, 256), rc;
-   GroupLambda lam;
-   for (int g = 0; g < 32; g++) lam.v[g] = 1.0;
+   int rc;
    for (int s = 0; s < nsteps; s++)
    {
-      /* lambda applies at the FRONT kick when doScaling is set (berendsen.c:74-80) */
-      for (int g = 0; g < ctx->ngroup; g++) lam.v[g] = (ctx->gtype[g] == DDCMI_BERENDSEN && ctx->gdoScaling[g]) ? ctx->glambda[g] : 1.0;
-      hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, st, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
-      ctx->time += dt;
-      ctx->loop += 1;
+      if ((rc = step_pre(ctx, dt))) return rc;
       /* ddcUpdateAll.c:64-71: rebuild when loop % updateRate == 0 */
       if (ctx->loop % ctx->updateRate == 0 || !ctx->list_valid)
-      {
          if ((rc = ddcmi_build_list(ctx))) return rc;
-         n = ctx->nloc; nb = cdiv(n, 256);
-      }
-      if ((rc = launch_forces(ctx))) return rc;
-      if ((rc = launch_kinetic(ctx, dt, 1))) return rc;
-      berendsen_update(ctx, 0.5 * dt);
+      if ((rc = step_post(ctx, dt))) return rc;
    }
    return DDCMI_OK;
 }
@@ -1628,3 +1726,5 @@ extern "C" int ddcmi_timing_read(ddcmi_ctx *ctx, int64_t *launches, double *tota
    if (reset) { ctx->t_launches = 0; ctx->t_ms = 0; }
    return DDCMI_OK;
 }
+
+#include "ddcmi_multigpu.inl"

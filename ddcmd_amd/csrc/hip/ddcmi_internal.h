@@ -117,7 +117,16 @@ struct ddcmi_ctx
    /* timing */
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
    /* comm */
-   int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1};
+   int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
+   struct ddcmi_group *group_ = nullptr;        /* in-process multi-domain emulation (tests) */
+   bool halo_fresh = false;
+   int dir_dest[27], dir_shift[27][3];            /* 26 neighbour directions, code = (dx+1)+3(dy+1)+9(dz+1) */
+   int hs_cap = 0, mig_cap = 0;
+   dbuf<int> hs_idx, dir_cnt;                      /* halo send lists per direction */
+   int hs_cnt[27], hr_cnt[27], send_off[28], recv_off[28], nsend = 0, nrecv = 0;
+   int mig_scnt[27], mig_rcnt[27];
+   dbuf<double> sendbuf, hrecv3, hrecv5, mig_out, mig_in;
+   dbuf<int> keep, cnt_xchg;
 };
 
 #define SETERR(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
@@ -132,5 +141,13 @@ int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
 int ddcmi_launch_bonded(ddcmi_ctx *ctx);
 /* comm.hip */
 void ddcmi_comm_destroy(ddcmi_ctx *ctx);
+/* ddcmi.hip: rebuild phases shared by the single- and multi-domain paths */
+int ddcmi_bl_sort_owned(ddcmi_ctx *ctx);
+int ddcmi_bl_reserve_halo(ddcmi_ctx *ctx, int nh);
+int ddcmi_bl_halo_sort(ddcmi_ctx *ctx);
+int ddcmi_bl_finish(ddcmi_ctx *ctx);
+/* multi-domain path (ddcmi_multigpu.inl, compiled into ddcmi.hip) */
+int ddcmi_mg_rebuild(ddcmi_ctx *ctx);
+int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx);
 
 #endif

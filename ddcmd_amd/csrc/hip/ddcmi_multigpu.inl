@@ -1,0 +1,710 @@
+/*
+ * ddcmi_multigpu.inl -- spatial domain decomposition (compiled into ddcmi.hip).
+ *
+ * Replaces ddcMD's DDC layer for this path: ddcAssignment (particle ownership and
+ * migration, ddcAssignment.c:64-150), ddcSendRecvTables / ddcFindPairs (halo
+ * tables, ddcSendRecv.c:41-264), ddcUpdate (per-step position halo,
+ * ddcUpdate.c:40-85).  ddcUpdateForce (ddcUpdate.c:140-223) has no counterpart:
+ * every rank evaluates the full list of its own beads, so no force returns.
+ *
+ * Domains are the bricks of a px*py*pz grid (the Voronoi cells of a cubic lattice
+ * of domain centres, domain.c:191-208).  Each of the 26 neighbour directions has a
+ * destination rank and a periodic shift; a direction whose destination is the
+ * rank itself (undivided periodic axis) yields local image beads, exactly like
+ * the single-domain path.  Halo beads live in the image slots behind the owned
+ * beads; the sender applies the shift.  Transport is RCCL point-to-point
+ * (grouped ncclSend/ncclRecv, one message per direction: 7 distinct peers at
+ * 2x2x2 = the 7 xGMI links) or, for tests on one GPU, direct copies between
+ * contexts of one process (ddcmi_group_*).
+ */
+
+struct DirTab
+{
+   int dest[27];        /* destination rank, -1 = none (open boundary) */
+   int shift[27][3];    /* periodic shift the RECEIVER sees, in box lengths */
+   int me;
+};
+
+extern "C" int ddcmi_plan_directions(int px, int py, int pz, int rank, int pbc, int *dest, int *shift)
+{
+   if (px < 1 || py < 1 || pz < 1 || rank < 0 || rank >= px * py * pz || !dest || !shift) return DDCMI_EINVAL;
+   int P[3] = {px, py, pz};
+   int pc[3] = {rank % px, (rank / px) % py, rank / (px * py)};
+   for (int code = 0; code < 27; code++)
+   {
+      int d[3] = {code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1};
+      int c[3], ok = 1;
+      for (int a = 0; a < 3; a++)
+      {
+         c[a] = pc[a] + d[a];
+         shift[3 * code + a] = 0;
+         if (c[a] < 0)
+         {
+            if ((pbc >> a) & 1) { c[a] += P[a]; shift[3 * code + a] = +1; } else ok = 0;
+         }
+         else if (c[a] >= P[a])
+         {
+            if ((pbc >> a) & 1) { c[a] -= P[a]; shift[3 * code + a] = -1; } else ok = 0;
+         }
+      }
+      dest[code] = (ok && code != 13) ? (c[2] * py + c[1]) * px + c[0] : -1;
+   }
+   return DDCMI_OK;
+}
+
+static void mg_set_topology(ddcmi_ctx *ctx, int rank, int nranks, int px, int py, int pz)
+{
+   ctx->rank = rank; ctx->nranks = nranks;
+   ctx->pgrid[0] = px; ctx->pgrid[1] = py; ctx->pgrid[2] = pz;
+   ctx->pcoord[0] = rank % px; ctx->pcoord[1] = (rank / px) % py; ctx->pcoord[2] = rank / (px * py);
+   ddcmi_plan_directions(px, py, pz, rank, ctx->pbc, ctx->dir_dest, &ctx->dir_shift[0][0]);
+   ctx->list_valid = false;
+}
+
+static DirTab mg_dirtab(const ddcmi_ctx *ctx)
+{
+   DirTab t;
+   for (int c = 0; c < 27; c++) { t.dest[c] = ctx->dir_dest[c]; for (int a = 0; a < 3; a++) t.shift[c][a] = ctx->dir_shift[c][a]; }
+   t.me = ctx->rank;
+   return t;
+}
+
+/* ------------------------------------------------------------------------- */
+__global__ void k_iota(int n, int *a)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) a[i] = i;
+}
+
+struct MigGeom { double L[3], W[3]; int P[3], pc[3], pbc; };
+
+/* ownership (voronoiCalcParticleDestinations for a cubic lattice of centres =
+ * brick index) + packing of the beads that leave: record = x y z tag vx vy vz gid group - */
+__global__ void k_mig_classify(MigGeom mg, int nloc, int mig_cap, double4 *pos, const double *vx, const double *vy, const double *vz,
+                               const uint64_t *gid, const int *group, int *keep, int *dir_cnt, double *mig_out, int *flags)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= nloc) return;
+   double4 p = pos[i];
+   if (mg.pbc & 1) { if (p.x > 0.5 * mg.L[0]) p.x -= mg.L[0]; if (p.x < -0.5 * mg.L[0]) p.x += mg.L[0]; }
+   if (mg.pbc & 2) { if (p.y > 0.5 * mg.L[1]) p.y -= mg.L[1]; if (p.y < -0.5 * mg.L[1]) p.y += mg.L[1]; }
+   if (mg.pbc & 4) { if (p.z > 0.5 * mg.L[2]) p.z -= mg.L[2]; if (p.z < -0.5 * mg.L[2]) p.z += mg.L[2]; }
+   pos[i] = p;
+   double r[3] = {p.x, p.y, p.z};
+   int d[3];
+#pragma unroll
+   for (int a = 0; a < 3; a++)
+   {
+      int b = (int)floor((r[a] + 0.5 * mg.L[a]) / mg.W[a]);
+      b = min(max(b, 0), mg.P[a] - 1);
+      int dd = b - mg.pc[a];
+      if (dd > 1) dd -= mg.P[a];
+      if (dd < -1) dd += mg.P[a];
+      if (dd > 1 || dd < -1) { atomicMax(&flags[6], 1); dd = 0; }
+      d[a] = dd;
+   }
+   int code = (d[0] + 1) + 3 * (d[1] + 1) + 9 * (d[2] + 1);
+   keep[i] = (code == 13);
+   if (code != 13)
+   {
+      int slot = atomicAdd(&dir_cnt[code], 1);
+      if (slot < mig_cap)
+      {
+         double *rec = mig_out + ((size_t)code * mig_cap + slot) * 10;
+         rec[0] = p.x; rec[1] = p.y; rec[2] = p.z; rec[3] = p.w;
+         rec[4] = vx[i]; rec[5] = vy[i]; rec[6] = vz[i];
+         rec[7] = __longlong_as_double((long long)gid[i]);
+         rec[8] = (double)group[i]; rec[9] = 0.0;
+      }
+   }
+}
+__global__ void k_compact_order(int n, const int *keep, const int *scan, int *order)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n && keep[i]) order[scan[i]] = i;
+}
+__global__ void k_unpack_mig(int narr, int nkeep, const double *mig_in, double4 *pos, double *vx, double *vy, double *vz,
+                             uint64_t *gid, int *species, int *group, int *orig)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= narr) return;
+   const double *rec = mig_in + (size_t)k * 10;
+   int i = nkeep + k;
+   pos[i] = make_double4(rec[0], rec[1], rec[2], rec[3]);
+   vx[i] = rec[4]; vy[i] = rec[5]; vz[i] = rec[6];
+   gid[i] = (uint64_t)__double_as_longlong(rec[7]);
+   species[i] = (int)((__double_as_longlong(rec[3]) >> 16) & 0xffff);
+   group[i] = (int)rec[8];
+   orig[i] = i;
+}
+
+/* which owned beads does each neighbour direction need?  (ddcSendRecvTables:
+ * every local particle within rcut of the neighbouring domain) */
+__global__ void k_halo_select(GridParams gp, DirTab dt, int nloc, int hs_cap, const double4 *pos, int *dir_cnt, int *hs_idx)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= nloc) return;
+   double4 p = pos[i];
+   double r[3] = {p.x, p.y, p.z};
+   int nlo[3], nhi[3];
+#pragma unroll
+   for (int a = 0; a < 3; a++)
+   {
+      double W = gp.n[a] / gp.cinv[a];
+      nlo[a] = (gp.m[a] > 0) && (r[a] < gp.lo[a] + gp.rlist);
+      nhi[a] = (gp.m[a] > 0) && (r[a] >= gp.lo[a] + W - gp.rlist);
+   }
+   for (int dz = -1; dz <= 1; dz++)
+   {
+      if ((dz < 0 && !nlo[2]) || (dz > 0 && !nhi[2])) continue;
+      for (int dy = -1; dy <= 1; dy++)
+      {
+         if ((dy < 0 && !nlo[1]) || (dy > 0 && !nhi[1])) continue;
+         for (int dx = -1; dx <= 1; dx++)
+         {
+            if ((dx < 0 && !nlo[0]) || (dx > 0 && !nhi[0])) continue;
+            int code = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+            if (code == 13 || dt.dest[code] < 0) continue;
+            int slot = atomicAdd(&dir_cnt[code], 1);
+            if (slot < hs_cap) hs_idx[(size_t)code * hs_cap + slot] = i;
+         }
+      }
+   }
+}
+struct OffTab { int off[28]; };   /* exclusive offsets of the flattened per-direction segments */
+
+/* pack the beads a remote neighbour needs, shift applied: width 3 (x y z, every
+ * step) or 5 (+ tag, gid: at rebuilds) */
+__global__ void k_pack_halo(int nsend, OffTab so, DirTab dt, int hs_cap, const int *hs_idx, double L0, double L1, double L2,
+                            const double4 *pos, const uint64_t *gid, double *out, int width)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= nsend) return;
+   int code = 0;
+   while (k >= so.off[code + 1]) code++;
+   int i = hs_idx[(size_t)code * hs_cap + (k - so.off[code])];
+   double4 p = pos[i];
+   double *o = out + (size_t)k * width;
+   o[0] = p.x + dt.shift[code][0] * L0;
+   o[1] = p.y + dt.shift[code][1] * L1;
+   o[2] = p.z + dt.shift[code][2] * L2;
+   if (width == 5) { o[3] = p.w; o[4] = __longlong_as_double((long long)gid[i]); }
+}
+/* halo descriptors: first the local images (directions that wrap onto this rank),
+ * then the beads received from other ranks */
+__global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab selfo, DirTab dt, int hs_cap, const int *hs_idx,
+                                const double4 *pos, const double *hrecv5, int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h)
+{
+   int h = blockIdx.x * blockDim.x + threadIdx.x;
+   if (h >= nself + nrecv) return;
+   double x, y, z;
+   if (h < nself)
+   {
+      int code = 0;
+      while (h >= selfo.off[code + 1]) code++;
+      int i = hs_idx[(size_t)code * hs_cap + (h - selfo.off[code])];
+      double4 p = pos[i];
+      x = p.x + dt.shift[code][0] * gp.L[0]; y = p.y + dt.shift[code][1] * gp.L[1]; z = p.z + dt.shift[code][2] * gp.L[2];
+      hsrc[h] = i;
+      hshift[h] = (dt.shift[code][0] + 1) + 3 * (dt.shift[code][1] + 1) + 9 * (dt.shift[code][2] + 1);
+   }
+   else
+   {
+      int k = h - nself;
+      x = hrecv5[5 * k]; y = hrecv5[5 * k + 1]; z = hrecv5[5 * k + 2];
+      hsrc[h] = -1 - k;
+      hshift[h] = 13;
+   }
+   int cx, cy, cz;
+   cell_coords(gp, x, y, z, false, cx, cy, cz);
+   int c = cell_linear(gp, cx, cy, cz);
+   hcid[h] = c;
+   hrank[h] = atomicAdd(&cell_cnt_h[c], 1);
+}
+__global__ void k_rec5to3(int n, const double *r5, double *r3)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k < n) { r3[3 * k] = r5[5 * k]; r3[3 * k + 1] = r5[5 * k + 1]; r3[3 * k + 2] = r5[5 * k + 2]; }
+}
+__global__ void k_sum_q2(int n, const double *q, double *out)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   double v = (i < n) ? q[i] * q[i] : 0.0;
+   v = wave_sum(v);
+   if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
+}
+
+/* ------------------------------------------------------------------------- */
+/* capacity of the owned-bead arrays (beads arrive by migration) */
+static int mg_ensure_owned(ddcmi_ctx *ctx, size_t need)
+{
+   hipStream_t st = ctx->stream;
+   size_t want = need + need / 4 + 4096;
+   if (ctx->vx.cap >= need && ctx->species.cap >= need + 1 && ctx->pos.cap >= need) return DDCMI_OK;
+   dbuf<double> *d3[] = {&ctx->vx, &ctx->vy, &ctx->vz, &ctx->fx, &ctx->fy, &ctx->fz};
+   for (auto b : d3) if (b->ensure(want, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   dbuf<double> *d3b[] = {&ctx->vx2, &ctx->vy2, &ctx->vz2};
+   for (auto b : d3b) if (b->ensure(want)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   dbuf<int> *i1[] = {&ctx->species, &ctx->group, &ctx->orig};
+   for (auto b : i1) if (b->ensure(want + 1, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   dbuf<int> *i2[] = {&ctx->species2, &ctx->group2, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->nimg, &ctx->img_off, &ctx->keep};
+   for (auto b : i2) if (b->ensure(want + 1)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   if (ctx->pos.ensure(want, true, st) || ctx->pos2.ensure(want) || ctx->qatom.ensure(want) || ctx->gid.ensure(want, true, st) || ctx->gid2.ensure(want))
+      SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   return DDCMI_OK;
+}
+
+/* ---- transport ------------------------------------------------------------ */
+struct ddcmi_group { std::vector<ddcmi_ctx *> ranks; };
+
+static inline bool mg_remote(const ddcmi_ctx *ctx, int code) { return code != 13 && ctx->dir_dest[code] >= 0 && ctx->dir_dest[code] != ctx->rank; }
+static inline bool mg_selfdir(const ddcmi_ctx *ctx, int code) { return code != 13 && ctx->dir_dest[code] == ctx->rank; }
+static inline int mg_opp(int code) { return 26 - code; }
+
+#define NCCLCHK2(ctx, call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) SETERR(ctx, DDCMI_ECOMM, "%s failed: %s", #call, ncclGetErrorString(_r)); } while (0)
+
+/* RCCL: exchange one int per remote direction (my count -> the neighbour) */
+static int mg_xchg_counts_rccl(ddcmi_ctx *ctx, const int *scnt, int *rcnt)
+{
+   hipStream_t st = ctx->stream;
+   ncclComm_t comm = (ncclComm_t)ctx->comm;
+   ENSURE(ctx, ctx->cnt_xchg, 64);
+   HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, scnt, 27 * sizeof(int), hipMemcpyHostToDevice, st));
+   NCCLCHK2(ctx, ncclGroupStart());
+   for (int code = 0; code < 27; code++)
+   {
+      if (mg_remote(ctx, code)) NCCLCHK2(ctx, ncclSend(ctx->cnt_xchg.p + code, 1, ncclInt, ctx->dir_dest[code], comm, st));
+      /* the message a neighbour sends along ITS direction `code` comes from the rank in my direction opp(code) */
+      if (mg_remote(ctx, mg_opp(code))) NCCLCHK2(ctx, ncclRecv(ctx->cnt_xchg.p + 27 + code, 1, ncclInt, ctx->dir_dest[mg_opp(code)], comm, st));
+   }
+   NCCLCHK2(ctx, ncclGroupEnd());
+   int tmp[27];
+   HIPCHK(ctx, hipMemcpyAsync(tmp, ctx->cnt_xchg.p + 27, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   for (int code = 0; code < 27; code++) rcnt[code] = mg_remote(ctx, mg_opp(code)) ? tmp[code] : 0;
+   return DDCMI_OK;
+}
+/* RCCL: one message per direction; segments are flattened with the given offsets
+ * (send: by my direction code; recv: by the SENDER's direction code) */
+static int mg_xchg_data_rccl(ddcmi_ctx *ctx, const double *sbase, const int *soff, const int *scnt, size_t sstride_items,
+                             double *rbase, const int *roff, const int *rcnt, int width)
+{
+   hipStream_t st = ctx->stream;
+   ncclComm_t comm = (ncclComm_t)ctx->comm;
+   NCCLCHK2(ctx, ncclGroupStart());
+   for (int code = 0; code < 27; code++)
+   {
+      if (mg_remote(ctx, code) && scnt[code] > 0)
+      {
+         const double *src = sstride_items ? sbase + (size_t)code * sstride_items * width : sbase + (size_t)soff[code] * width;
+         NCCLCHK2(ctx, ncclSend(src, (size_t)scnt[code] * width, ncclDouble, ctx->dir_dest[code], comm, st));
+      }
+      if (mg_remote(ctx, mg_opp(code)) && rcnt[code] > 0)
+         NCCLCHK2(ctx, ncclRecv(rbase + (size_t)roff[code] * width, (size_t)rcnt[code] * width, ncclDouble, ctx->dir_dest[mg_opp(code)], comm, st));
+   }
+   NCCLCHK2(ctx, ncclGroupEnd());
+   return DDCMI_OK;
+}
+/* in-process emulation: same matching rule, direct device copies */
+static int mg_xchg_data_local(ddcmi_group *g, int which /*0 migration, 1 halo5, 2 halo3*/)
+{
+   for (ddcmi_ctx *A : g->ranks) HIPCHK(A, hipStreamSynchronize(A->stream));
+   for (ddcmi_ctx *A : g->ranks)
+      for (int code = 0; code < 27; code++)
+      {
+         if (!mg_remote(A, code)) continue;
+         ddcmi_ctx *B = g->ranks[A->dir_dest[code]];
+         if (which == 0)
+         {
+            int n = A->mig_scnt[code];
+            if (n <= 0) continue;
+            int roff = 0;
+            for (int c = 0; c < code; c++) roff += B->mig_rcnt[c];
+            HIPCHK(A, hipMemcpy(B->mig_in.p + (size_t)roff * 10, A->mig_out.p + (size_t)code * A->mig_cap * 10, (size_t)n * 10 * sizeof(double), hipMemcpyDeviceToDevice));
+         }
+         else
+         {
+            int n = A->hs_cnt[code];
+            if (n <= 0) continue;
+            int w = (which == 1) ? 5 : 3;
+            double *dst = (which == 1 ? B->hrecv5.p : B->hrecv3.p) + (size_t)B->recv_off[code] * w;
+            HIPCHK(A, hipMemcpy(dst, A->sendbuf.p + (size_t)A->send_off[code] * w, (size_t)n * w * sizeof(double), hipMemcpyDeviceToDevice));
+         }
+      }
+   return DDCMI_OK;
+}
+
+/* ---- rebuild phases --------------------------------------------------------- */
+static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
+{
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, rc;
+   if (ctx->nbond + ctx->nangle + ctx->ntors > 0)
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "bonded terms are not yet supported with domain decomposition (whole-molecule migration, ddcRuleMartini, is a next step)");
+   if ((rc = mg_ensure_owned(ctx, (size_t)n + 1))) return rc;
+   if (ctx->mig_cap == 0) ctx->mig_cap = std::max(1024, n / 16);
+   for (;;)
+   {
+      ENSURE(ctx, ctx->mig_out, (size_t)27 * ctx->mig_cap * 10);
+      ENSURE(ctx, ctx->dir_cnt, 32);
+      ENSURE(ctx, ctx->keep, (size_t)n + 1);
+      HIPCHK(ctx, hipMemsetAsync(ctx->dir_cnt.p, 0, 27 * sizeof(int), st));
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
+      MigGeom mg;
+      for (int a = 0; a < 3; a++) { mg.L[a] = ctx->h[4 * a]; mg.P[a] = ctx->pgrid[a]; mg.W[a] = mg.L[a] / mg.P[a]; mg.pc[a] = ctx->pcoord[a]; }
+      mg.pbc = ctx->pbc;
+      if (n > 0)
+      {
+         hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
+         hipLaunchKernelGGL(k_mig_classify, dim3(cdiv(n, 256)), dim3(256), 0, st, mg, n, ctx->mig_cap, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
+                            ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags);
+      }
+      HIPCHK(ctx, hipMemcpyAsync(ctx->mig_scnt, ctx->dir_cnt.p, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      if (ctx->h_flags[6]) SETERR(ctx, DDCMI_EINVAL, "a bead moved further than one domain between rebuilds");
+      int mx = 0;
+      for (int c = 0; c < 27; c++) mx = std::max(mx, ctx->mig_scnt[c]);
+      if (mx <= ctx->mig_cap) break;
+      ctx->mig_cap = mx + mx / 4 + 64;     /* positions were only wrapped (idempotent): simply redo */
+   }
+   return DDCMI_OK;
+}
+static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
+{
+   /* mig_rcnt is known and mig_in holds the arrivals (flattened by sender direction) */
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, rc;
+   int narr = 0;
+   for (int c = 0; c < 27; c++) narr += ctx->mig_rcnt[c];
+   int nleave = 0;
+   for (int c = 0; c < 27; c++) nleave += ctx->mig_scnt[c];
+   int nkeep = n - nleave;
+   if ((rc = mg_ensure_owned(ctx, (size_t)nkeep + narr + 1))) return rc;
+   if (nleave > 0)
+   {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->img_off.p, ctx->keep.p, n * sizeof(int), hipMemcpyDeviceToDevice, st));
+      if ((rc = ddcmi_scan_exclusive(ctx, ctx->img_off.p, n, nullptr))) return rc;
+      hipLaunchKernelGGL(k_compact_order, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->keep.p, ctx->img_off.p, ctx->order.p);
+      if (nkeep > 0)
+      {
+         hipLaunchKernelGGL(k_gather_state, dim3(cdiv(nkeep, 256)), dim3(256), 0, st, nkeep, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
+                            ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
+                            ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p);
+      }
+      std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
+      std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
+   }
+   if (narr > 0)
+      hipLaunchKernelGGL(k_unpack_mig, dim3(cdiv(narr, 256)), dim3(256), 0, st, narr, nkeep, ctx->mig_in.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
+                         ctx->gid.p, ctx->species.p, ctx->group.p, ctx->orig.p);
+   ctx->nloc = nkeep + narr;
+   n = ctx->nloc;
+   if (n > 0) hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
+   /* sort the owned beads, then pick what each neighbour direction needs */
+   if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
+   if (ctx->hs_cap == 0) ctx->hs_cap = std::max(4096, n / 4);
+   for (;;)
+   {
+      ENSURE(ctx, ctx->hs_idx, (size_t)27 * ctx->hs_cap);
+      HIPCHK(ctx, hipMemsetAsync(ctx->dir_cnt.p, 0, 27 * sizeof(int), st));
+      if (n > 0)
+         hipLaunchKernelGGL(k_halo_select, dim3(cdiv(n, 256)), dim3(256), 0, st, ctx->gp, mg_dirtab(ctx), n, ctx->hs_cap, ctx->pos.p, ctx->dir_cnt.p, ctx->hs_idx.p);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->hs_cnt, ctx->dir_cnt.p, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      int mx = 0;
+      for (int c = 0; c < 27; c++) mx = std::max(mx, ctx->hs_cnt[c]);
+      if (mx <= ctx->hs_cap) break;
+      ctx->hs_cap = mx + mx / 4 + 64;
+   }
+   return DDCMI_OK;
+}
+/* after the halo counts are exchanged: offsets, buffers, pack the rebuild records */
+static int mg_phase3_pack(ddcmi_ctx *ctx, int width)
+{
+   hipStream_t st = ctx->stream;
+   int ns = 0, nr = 0;
+   for (int code = 0; code < 27; code++)
+   {
+      ctx->send_off[code] = ns; if (mg_remote(ctx, code)) ns += ctx->hs_cnt[code];
+      ctx->recv_off[code] = nr; nr += ctx->hr_cnt[code];
+   }
+   ctx->send_off[27] = ns; ctx->recv_off[27] = nr;
+   ctx->nsend = ns; ctx->nrecv = nr;
+   ENSURE(ctx, ctx->sendbuf, (size_t)ns * 5 + 8); ENSURE(ctx, ctx->hrecv5, (size_t)nr * 5 + 8); ENSURE(ctx, ctx->hrecv3, (size_t)nr * 3 + 8);
+   if (ns > 0)
+   {
+      OffTab so;
+      int acc = 0;
+      for (int code = 0; code < 27; code++) { so.off[code] = acc; if (mg_remote(ctx, code)) acc += ctx->hs_cnt[code]; }
+      so.off[27] = acc;
+      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, so, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, width);
+   }
+   return DDCMI_OK;
+}
+static int mg_phase4_finish(ddcmi_ctx *ctx)
+{
+   hipStream_t st = ctx->stream;
+   int rc;
+   OffTab selfo;
+   int nself = 0;
+   for (int code = 0; code < 27; code++) { selfo.off[code] = nself; if (mg_selfdir(ctx, code)) nself += ctx->hs_cnt[code]; }
+   selfo.off[27] = nself;
+   int nh = nself + ctx->nrecv;
+   ctx->nhalo = nh;
+   if (nh > 0)
+   {
+      if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
+      hipLaunchKernelGGL(k_halo_assemble, dim3(cdiv(nh, 256)), dim3(256), 0, st, ctx->gp, nself, ctx->nrecv, selfo, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+                         ctx->pos.p, ctx->hrecv5.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
+      if (ctx->nrecv > 0) hipLaunchKernelGGL(k_rec5to3, dim3(cdiv(ctx->nrecv, 256)), dim3(256), 0, st, ctx->nrecv, ctx->hrecv5.p, ctx->hrecv3.p);
+   }
+   if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
+   if (ctx->has_charge)
+   {
+      double *d = ctx->d_results + R_GROUP;
+      HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(double), st));
+      if (ctx->nloc > 0) hipLaunchKernelGGL(k_sum_q2, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, st, ctx->nloc, ctx->qatom.p, d);
+      double q2 = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&q2, d, sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;     /* bioMartini.c:1030-1035 over this rank's local beads */
+   }
+   if ((rc = ddcmi_bl_finish(ctx))) return rc;
+   ctx->halo_fresh = true;
+   return DDCMI_OK;
+}
+
+/* one rank, RCCL transport */
+int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
+{
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are rebuilt with ddcmi_group_* calls");
+   if (!ctx->comm) SETERR(ctx, DDCMI_EINVAL, "ddcmi_comm_init has not been called");
+   int rc;
+   if ((rc = mg_phase1_migrate_out(ctx))) return rc;
+   if ((rc = mg_xchg_counts_rccl(ctx, ctx->mig_scnt, ctx->mig_rcnt))) return rc;
+   {
+      int roff[27], acc = 0;
+      for (int c = 0; c < 27; c++) { roff[c] = acc; acc += ctx->mig_rcnt[c]; }
+      ENSURE(ctx, ctx->mig_in, (size_t)acc * 10 + 16);
+      if ((rc = mg_xchg_data_rccl(ctx, ctx->mig_out.p, nullptr, ctx->mig_scnt, ctx->mig_cap, ctx->mig_in.p, roff, ctx->mig_rcnt, 10))) return rc;
+   }
+   if ((rc = mg_phase2_migrate_in(ctx))) return rc;
+   if ((rc = mg_xchg_counts_rccl(ctx, ctx->hs_cnt, ctx->hr_cnt))) return rc;
+   if ((rc = mg_phase3_pack(ctx, 5))) return rc;
+   if ((rc = mg_xchg_data_rccl(ctx, ctx->sendbuf.p, ctx->send_off, ctx->hs_cnt, 0, ctx->hrecv5.p, ctx->recv_off, ctx->hr_cnt, 5))) return rc;
+   return mg_phase4_finish(ctx);
+}
+
+/* per-step halo refresh: pack x y z of the send lists, exchange, (k_halo_update places them) */
+static int mg_pack3(ddcmi_ctx *ctx)
+{
+   if (ctx->nsend > 0)
+   {
+      OffTab so;
+      for (int code = 0; code < 28; code++) so.off[code] = ctx->send_off[code];
+      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, ctx->stream, ctx->nsend, so, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, 3);
+   }
+   return DDCMI_OK;
+}
+int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx)
+{
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "in-process group: halos are refreshed by ddcmi_group_step_nglf / ddcmi_group_eval_forces");
+   int rc;
+   if ((rc = mg_pack3(ctx))) return rc;
+   if ((rc = mg_xchg_data_rccl(ctx, ctx->sendbuf.p, ctx->send_off, ctx->hs_cnt, 0, ctx->hrecv3.p, ctx->recv_off, ctx->hr_cnt, 3))) return rc;
+   ctx->halo_fresh = true;
+   return DDCMI_OK;
+}
+
+/* ---- in-process group (tests on one GPU) ----------------------------------- */
+static int group_rebuild(ddcmi_group *g)
+{
+   int rc;
+   for (ddcmi_ctx *c : g->ranks) { (void)hipSetDevice(c->device); if ((rc = mg_phase1_migrate_out(c))) return rc; }
+   for (ddcmi_ctx *B : g->ranks)
+   {
+      int acc = 0;
+      for (int code = 0; code < 27; code++)
+      {
+         B->mig_rcnt[code] = mg_remote(B, mg_opp(code)) ? g->ranks[B->dir_dest[mg_opp(code)]]->mig_scnt[code] : 0;
+         acc += B->mig_rcnt[code];
+      }
+      if (B->mig_in.ensure((size_t)acc * 10 + 16)) SETERR(B, DDCMI_ENOMEM, "migration buffer");
+   }
+   if ((rc = mg_xchg_data_local(g, 0))) return rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_phase2_migrate_in(c))) return rc;
+   for (ddcmi_ctx *B : g->ranks)
+      for (int code = 0; code < 27; code++)
+         B->hr_cnt[code] = mg_remote(B, mg_opp(code)) ? g->ranks[B->dir_dest[mg_opp(code)]]->hs_cnt[code] : 0;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_phase3_pack(c, 5))) return rc;
+   if ((rc = mg_xchg_data_local(g, 1))) return rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_phase4_finish(c))) return rc;
+   return DDCMI_OK;
+}
+static int group_refresh(ddcmi_group *g)
+{
+   int rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_pack3(c))) return rc;
+   if ((rc = mg_xchg_data_local(g, 2))) return rc;
+   for (ddcmi_ctx *c : g->ranks) c->halo_fresh = true;
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_group_create(ddcmi_ctx **ctxs, int n, int px, int py, int pz)
+{
+   if (!ctxs || n < 1 || px * py * pz != n) return DDCMI_EINVAL;
+   ddcmi_group *g = new ddcmi_group();
+   for (int r = 0; r < n; r++)
+   {
+      if (!ctxs[r] || ctxs[r]->group_ || ctxs[r]->comm) { delete g; return DDCMI_EINVAL; }
+      g->ranks.push_back(ctxs[r]);
+   }
+   for (int r = 0; r < n; r++) { mg_set_topology(ctxs[r], r, n, px, py, pz); ctxs[r]->group_ = g; }
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_group_destroy(ddcmi_ctx **ctxs, int n)
+{
+   if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
+   ddcmi_group *g = ctxs[0]->group_;
+   for (ddcmi_ctx *c : g->ranks) { c->group_ = nullptr; c->nranks = 1; c->rank = 0; }
+   delete g;
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_group_eval_forces(ddcmi_ctx **ctxs, int n)
+{
+   if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
+   ddcmi_group *g = ctxs[0]->group_;
+   int rc;
+   bool valid = true;
+   for (ddcmi_ctx *c : g->ranks) valid = valid && c->list_valid;
+   if (!valid) { if ((rc = group_rebuild(g))) return rc; }
+   else if ((rc = group_refresh(g))) return rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = launch_forces(c))) return rc;
+   for (ddcmi_ctx *c : g->ranks) HIPCHK(c, hipStreamSynchronize(c->stream));
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nsteps)
+{
+   if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
+   ddcmi_group *g = ctxs[0]->group_;
+   int rc;
+   for (int s = 0; s < nsteps; s++)
+   {
+      bool rebuild = false;
+      for (ddcmi_ctx *c : g->ranks)
+      {
+         if ((rc = step_pre(c, dt))) return rc;
+         if (c->loop % c->updateRate == 0 || !c->list_valid) rebuild = true;
+      }
+      if (rebuild) { if ((rc = group_rebuild(g))) return rc; }
+      else if ((rc = group_refresh(g))) return rc;
+      for (ddcmi_ctx *c : g->ranks) if ((rc = step_post(c, dt))) return rc;
+   }
+   return DDCMI_OK;
+}
+
+/* current local beads in device order, identified by gid (ddcMD identifies
+ * particles by label); r wrapped into the box */
+__global__ void k_export_particles(GridParams gp, int n, const double4 *pos, double *x, double *y, double *z, int *species)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   double4 p = pos[i];
+   if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
+   if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
+   if (gp.pbc & 4) { if (p.z > 0.5 * gp.L[2]) p.z -= gp.L[2]; if (p.z < -0.5 * gp.L[2]) p.z += gp.L[2]; }
+   x[i] = p.x; y[i] = p.y; z[i] = p.z;
+   species[i] = (int)((__double_as_longlong(p.w) >> 16) & 0xffff);
+}
+extern "C" int ddcmi_download_particles(ddcmi_ctx *ctx, int cap, int *nout, uint64_t *gid, int *species,
+                                        double *rx, double *ry, double *rz, double *vx, double *vy, double *vz,
+                                        double *fx, double *fy, double *fz)
+{
+   if (!ctx || !nout) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc;
+   *nout = n;
+   if (cap < n) SETERR(ctx, DDCMI_EINVAL, "ddcmi_download_particles: capacity %d < %d local beads", cap, n);
+   if (n == 0) return DDCMI_OK;
+   GridParams gp = ctx->gp;
+   gp.pbc = ctx->pbc; gp.L[0] = ctx->h[0]; gp.L[1] = ctx->h[4]; gp.L[2] = ctx->h[8];
+   ENSURE(ctx, ctx->species2, (size_t)n + 1);
+   hipLaunchKernelGGL(k_export_particles, dim3(cdiv(n, 256)), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p);
+   if (rx) HIPCHK(ctx, hipMemcpyAsync(rx, ctx->vx2.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (ry) HIPCHK(ctx, hipMemcpyAsync(ry, ctx->vy2.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (rz) HIPCHK(ctx, hipMemcpyAsync(rz, ctx->vz2.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (species) HIPCHK(ctx, hipMemcpyAsync(species, ctx->species2.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
+   if (gid) HIPCHK(ctx, hipMemcpyAsync(gid, ctx->gid.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+   if (vx) HIPCHK(ctx, hipMemcpyAsync(vx, ctx->vx.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (vy) HIPCHK(ctx, hipMemcpyAsync(vy, ctx->vy.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (vz) HIPCHK(ctx, hipMemcpyAsync(vz, ctx->vz.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (fx) HIPCHK(ctx, hipMemcpyAsync(fx, ctx->fx.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (fy) HIPCHK(ctx, hipMemcpyAsync(fy, ctx->fy.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   if (fz) HIPCHK(ctx, hipMemcpyAsync(fz, ctx->fz.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_domain_bounds(const ddcmi_ctx *ctx, double lo[3], double hi[3])
+{
+   if (!ctx || !ctx->have_box) return DDCMI_EINVAL;
+   for (int a = 0; a < 3; a++)
+   {
+      double L = ctx->h[4 * a], W = L / ctx->pgrid[a];
+      lo[a] = -0.5 * L + ctx->pcoord[a] * W;
+      hi[a] = lo[a] + W;
+   }
+   return DDCMI_OK;
+}
+
+/* RCCL bootstrap (the 128-byte id is distributed by the caller: MPI_Bcast in
+ * ddcMD, torch.distributed in bench.py) */
+extern "C" int ddcmi_comm_unique_id(char id[128])
+{
+   if (!id) return DDCMI_EINVAL;
+   ncclUniqueId uid;
+   static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the 128-byte ABI slot");
+   if (ncclGetUniqueId(&uid) != ncclSuccess) return DDCMI_ECOMM;
+   memset(id, 0, 128);
+   memcpy(id, &uid, sizeof(uid));
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char id[128], int px, int py, int pz)
+{
+   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return DDCMI_EINVAL;
+   if (px * py * pz != nranks) SETERR(ctx, DDCMI_EINVAL, "process grid %dx%dx%d does not match %d ranks", px, py, pz, nranks);
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "context already belongs to an in-process group");
+   (void)hipSetDevice(ctx->device);
+   ncclUniqueId uid;
+   memcpy(&uid, id, sizeof(uid));
+   ncclComm_t comm;
+   NCCLCHK2(ctx, ncclCommInitRank(&comm, nranks, uid, rank));
+   ctx->comm = (void *)comm;
+   mg_set_topology(ctx, rank, nranks, px, py, pz);
+   return DDCMI_OK;
+}
+/* energyInfo.c:9-63 allreduce(): sum the ETYPE block across ranks */
+extern "C" int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n)
+{
+   if (!ctx || !values || n <= 0 || n > 64) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   if (ctx->group_)
+   {
+      /* in-process group: only meaningful when called once for rank 0 with pre-summed values */
+      return DDCMI_OK;
+   }
+   if (ctx->nranks == 1 || !ctx->comm) return DDCMI_OK;
+   double *d = ctx->d_results + R_GROUP;   /* scratch */
+   HIPCHK(ctx, hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+   NCCLCHK2(ctx, ncclAllReduce(d, d, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+   HIPCHK(ctx, hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   return DDCMI_OK;
+}
+void ddcmi_comm_destroy(ddcmi_ctx *ctx)
+{
+   if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+}

@@ -262,3 +262,156 @@ class MartiniHIP(object):
         ms = ctypes.c_double(0)
         self._chk(self.lib.ddcmi_timing_read(self.ctx, ctypes.byref(n), ctypes.byref(ms), 1 if reset else 0))
         return n.value, ms.value
+
+
+def _declare_domains(lib):
+    if getattr(lib, "_ddcmi_dom_declared", False):
+        return
+    vp = ctypes.c_void_p
+    lib.ddcmi_plan_directions.argtypes = [ctypes.c_int] * 5 + [_ip, _ip]
+    lib.ddcmi_domain_bounds.argtypes = [vp, _dp, _dp]
+    lib.ddcmi_download_particles.argtypes = [vp, ctypes.c_int, _ip, _up, _ip] + [_dp] * 9
+    lib.ddcmi_group_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.ddcmi_group_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.ddcmi_group_eval_forces.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.ddcmi_group_step_nglf.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    lib._ddcmi_dom_declared = True
+
+
+def plan_directions(px, py, pz, rank, pbc=7):
+    """(dest[27], shift[27,3]) of the 26 neighbour directions (host logic, no GPU needed)."""
+    lib = _lib.load_library()
+    _declare(lib)
+    _declare_domains(lib)
+    dest = np.zeros(27, np.int32)
+    shift = np.zeros(81, np.int32)
+    rc = lib.ddcmi_plan_directions(px, py, pz, rank, pbc, _i(dest), _i(shift))
+    if rc != 0:
+        raise DdcmiError("ddcmi_plan_directions failed: %d" % rc)
+    return dest, shift.reshape(27, 3)
+
+
+def domain_of(setup, grid):
+    """owner rank of every bead for a px*py*pz brick decomposition (box centred on the origin)"""
+    px, py, pz = grid
+    L = setup.box
+    out = np.zeros(setup.natoms, np.int64)
+    mult = 1
+    for a, (r, P) in enumerate(zip((setup.rx, setup.ry, setup.rz), (px, py, pz))):
+        x = r - L[a] * np.rint(r / L[a])
+        b = np.clip(np.floor((x + 0.5 * L[a]) / (L[a] / P)).astype(np.int64), 0, P - 1)
+        out += mult * b
+        mult *= P
+    return out
+
+
+def select_rank(setup, owner, rank):
+    """(index array) of the beads rank owns"""
+    return np.flatnonzero(owner == rank)
+
+
+class DomainMixin(object):
+    """gid-addressed download for decomposed runs"""
+
+    def download_particles(self):
+        _declare_domains(self.lib)
+        cap = int(self.lib.ddcmi_nlocal(self.ctx)) + 16
+        n = ctypes.c_int(0)
+        gid = np.zeros(cap, np.uint64)
+        sp = np.zeros(cap, np.int32)
+        arr = [np.zeros(cap) for _ in range(9)]
+        self._chk(self.lib.ddcmi_download_particles(self.ctx, cap, ctypes.byref(n), gid.ctypes.data_as(_up), _i(sp), *[_d(a) for a in arr]))
+        k = n.value
+        return {"gid": gid[:k], "species": sp[:k], "r": [a[:k] for a in arr[0:3]], "v": [a[:k] for a in arr[3:6]], "f": [a[:k] for a in arr[6:9]]}
+
+
+class MartiniRank(MartiniHIP, DomainMixin):
+    """One rank of a decomposed run: uploads only the beads `index` selects."""
+
+    def __init__(self, setup, index, device=0):
+        MartiniHIP.__init__(self, setup, device=device, upload=False)
+        self.index = np.asarray(index)
+
+    def upload_local(self):
+        s, ix = self.s, self.index
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        gid = np.ascontiguousarray(s.gid[ix], dtype=np.uint64)
+        sp = np.ascontiguousarray(s.species[ix], dtype=np.int32)
+        gr = np.ascontiguousarray(s.group[ix], dtype=np.int32)
+        a = [f64(x[ix]) for x in (s.rx, s.ry, s.rz, s.vx, s.vy, s.vz)]
+        self.n = len(ix)
+        self._chk(self.lib.ddcmi_upload_state(self.ctx, self.n, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(a[4]), _d(a[5]),
+                                              gid.ctypes.data_as(_up), _i(sp), _i(gr)))
+
+    def comm_init(self, rank, nranks, uid, grid):
+        self._chk(self.lib.ddcmi_comm_init(self.ctx, rank, nranks, uid, grid[0], grid[1], grid[2]))
+
+    def allreduce(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._chk(self.lib.ddcmi_comm_allreduce_sum(self.ctx, _d(v), v.size))
+        return v
+
+
+class MartiniGroup(object):
+    """px*py*pz domains emulated inside one process on one GPU (device copies
+    instead of RCCL): exercises migration, halo tables and per-step halo refresh."""
+
+    def __init__(self, setup, grid, device=0):
+        self.s = setup
+        self.grid = tuple(grid)
+        self.n = grid[0] * grid[1] * grid[2]
+        owner = domain_of(setup, grid)
+        self.ranks = [MartiniRank(setup, select_rank(setup, owner, r), device=device) for r in range(self.n)]
+        self.lib = self.ranks[0].lib
+        _declare_domains(self.lib)
+        self.arr = (ctypes.c_void_p * self.n)(*[r.ctx for r in self.ranks])
+        rc = self.lib.ddcmi_group_create(self.arr, self.n, grid[0], grid[1], grid[2])
+        if rc != 0:
+            raise DdcmiError("ddcmi_group_create failed: %d" % rc)
+        for r in self.ranks:
+            r.upload_local()
+
+    def _chk(self, rc):
+        if rc != 0:
+            msgs = [self.lib.ddcmi_last_error(r.ctx).decode() for r in self.ranks]
+            raise DdcmiError("ddcmi group error %d: %s" % (rc, "; ".join(m for m in msgs if m)))
+
+    def eval_forces(self):
+        self._chk(self.lib.ddcmi_group_eval_forces(self.arr, self.n))
+        return self.energies()[:2]
+
+    def step(self, nsteps=1, dt=None):
+        self._chk(self.lib.ddcmi_group_step_nglf(self.arr, self.n, float(self.s.dt if dt is None else dt), int(nsteps)))
+
+    def energies(self):
+        """sum over ranks = energyInfo.c allreduce()"""
+        tot_e, tot_v, tot_rk, tot_t = None, None, 0.0, None
+        for r in self.ranks:
+            e, v, rk, t = r.energies()
+            if tot_e is None:
+                tot_e, tot_v, tot_t = dict(e), v.copy(), t.copy()
+            else:
+                for k in e:
+                    tot_e[k] += e[k]
+                tot_v += v
+                tot_t += t
+            tot_rk += rk
+        return tot_e, tot_v, tot_rk, tot_t
+
+    def gather(self):
+        """all beads ordered by gid"""
+        parts = [r.download_particles() for r in self.ranks]
+        gid = np.concatenate([p["gid"] for p in parts])
+        order = np.argsort(gid, kind="stable")
+        out = {"gid": gid[order], "nlocal": [len(p["gid"]) for p in parts]}
+        for k in ("r", "v", "f"):
+            out[k] = [np.concatenate([p[k][c] for p in parts])[order] for c in range(3)]
+        return out
+
+    def close(self):
+        try:
+            self.lib.ddcmi_group_destroy(self.arr, self.n)
+        except Exception:
+            pass
+        for r in self.ranks:
+            r.close()

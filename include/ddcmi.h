@@ -147,6 +147,26 @@ int ddcmi_comm_unique_id(char id[128]);
 int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char id[128], int px, int py, int pz);
 /* energyInfo.c:9-63 allreduce(): sum the 24-double ETYPE block across ranks */
 int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n);
+/* Call order with decomposition: ddcmi_set_box -> ddcmi_comm_init -> set_* ->
+ * ddcmi_upload_state with THIS rank's local beads (any beads inside the box are
+ * accepted; the first rebuild migrates them to their owners, ddcAssignment.c) */
+/* host logic of the decomposition (domain.c:61-208 for a cubic lattice of domain
+ * centres): destination rank and periodic shift of the 26 neighbour directions,
+ * code = (dx+1)+3(dy+1)+9(dz+1); dest[27], shift[27*3]; dest = -1 where the box is open */
+int ddcmi_plan_directions(int px, int py, int pz, int rank, int pbc, int *dest, int *shift);
+int ddcmi_domain_bounds(const ddcmi_ctx *ctx, double lo[3], double hi[3]);
+/* current local beads in device order, identified by gid (beads migrate between
+ * ranks; ddcMD identifies them by label).  Pointers may be NULL. [sync] */
+int ddcmi_download_particles(ddcmi_ctx *ctx, int cap, int *nout, uint64_t *gid, int *species,
+                             double *rx, double *ry, double *rz, double *vx, double *vy, double *vz,
+                             double *fx, double *fy, double *fz);
+/* in-process emulation of a px*py*pz decomposition (several contexts on one
+ * device, halo/migration traffic by device copies): lets the whole multi-domain
+ * path run on a single GPU.  Contexts of a group are driven only through these. */
+int ddcmi_group_create(ddcmi_ctx **ctxs, int n, int px, int py, int pz);
+int ddcmi_group_destroy(ddcmi_ctx **ctxs, int n);
+int ddcmi_group_eval_forces(ddcmi_ctx **ctxs, int n);
+int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nsteps);
 
 #ifdef __cplusplus
 }
