@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- atom-steps/s of the Martini MD inner loop on synthetic water.
 
-    python bench.py --gpus N --steps K --warmup W [--n LATTICE] [--no-cpu]
+    python bench.py --gpus N --steps K --warmup W [--lattice N] [--no-cpu]
 
 One "step" is one NGLF velocity-Verlet step of the whole box (half kick, drift,
 image refresh, nonbonded + bonded forces with energy and virial, half kick +
@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 64 -> 1.05M, 25 -> 62.5k)")
+    ap.add_argument("--lattice", dest="n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 64 -> 1.05M, 25 -> 62.5k)")
     ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -76,31 +76,52 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("DDCMI_BENCH_SINGLE_DEVICE"):      # debugging aid: all ranks on device 0 (RCCL normally refuses)
+        local_rank = 0
     dist = None
+    torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    import numpy as np
     import ddcmd_amd
-    from ddcmd_amd.martini import MartiniHIP
+    from ddcmd_amd.martini import MartiniHIP, MartiniRank, domain_of
     s = ddcmd_amd.make_water_setup(args.n)
-    m = MartiniHIP(s, device=local_rank)
+    grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+    if grid is None:
+        raise SystemExit("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)")
+    if world == 1:
+        m = MartiniHIP(s, device=local_rank)
+    else:
+        # spatial decomposition: this rank uploads the beads of its brick; halo exchange
+        # and migration run inside libddcmi over RCCL point-to-point (include/ddcmi.h)
+        owner = domain_of(s, grid)
+        m = MartiniRank(s, np.flatnonzero(owner == rank), device=local_rank)
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            assert m.lib.ddcmi_comm_unique_id(buf) == 0
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, src=0)
+        m.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()), grid)
+        m.upload_local()
+    nlocal0 = m.n
     m.eval_forces()                       # firstEnergyCall (masters.c:579)
-    st = m.list_stats()
     m.step(args.warmup)
     m.sync()
 
     def barrier():
         if dist is not None:
-            import torch
             dist.barrier()
             torch.cuda.synchronize()
         m.sync()
 
     m.timing(True)
     barrier()
+    reb0 = m.list_stats()["rebuilds"]
     t0 = time.perf_counter()
     m.step(args.steps)
     barrier()
@@ -109,32 +130,37 @@ def main():
     m.timing(False)
     e, vir, rk, tion = m.energies()
     st = m.list_stats()
+    nlocal = int(m.lib.ddcmi_nlocal(m.ctx))
+    epot, ekin = e["total"], rk
     if dist is not None:
-        import torch
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        tot = m.allreduce([epot, ekin, float(nlocal)])      # energyInfo.c allreduce()
+        epot, ekin = float(tot[0]), float(tot[1])
+        assert int(round(tot[2])) == s.natoms, "beads lost in migration"
 
-    natoms_total = s.natoms * world        # replicas until the RCCL decomposition lands
-    value = natoms_total * args.steps / el
-    L = st["entries"] / float(s.natoms)
+    value = s.natoms * args.steps / el     # whole box, whole job
+    L = st["entries"] / float(max(nlocal, 1))
     bytes_per_atom = 36.0 + 24.0 + 4.0 * L
     t_kernel = kernel_ms * 1e-3 / max(1, launches)
-    achieved = bytes_per_atom * s.natoms / t_kernel / 1e9
+    achieved = bytes_per_atom * nlocal / t_kernel / 1e9
     out = {
         "metric": "atom_steps_per_sec", "value": value, "unit": "atom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "ns_per_day": (args.steps / el) * DT_FS * 1e-6 * 86400.0,
-        "config": {"workload": "martini_water_%dk_beads" % (s.natoms // 1000), "beads_per_gpu": s.natoms, "lattice_n": args.n,
+        "config": {"workload": "martini_water_%dk_beads" % (s.natoms // 1000), "beads_total": s.natoms, "beads_rank0": nlocal, "lattice": "fcc", "lattice_n": args.n,
                    "rcut_A": 12.0, "skin_A": 4.0, "dt_fs": DT_FS, "list_rebuild_every": int(s.updateRate),
-                   "energy_virial_every_step": True, "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
-                   "list_entries_per_atom": L, "image_atoms": st["images"], "rebuilds_in_timed_region": None},
+                   "energy_virial_every_step": True,
+                   "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo" % grid) if world > 1 else "single GPU",
+                   "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
         "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches},
-        "check": {"epot": e["total"], "ekin": rk},
+                     "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches,
+                     "note": "rank 0's kernel on its own beads" if world > 1 else "whole box"},
+        "check": {"epot": epot, "ekin": ekin},
     }
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)

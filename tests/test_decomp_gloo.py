@@ -1,0 +1,170 @@
+"""CPU, world_size=2, gloo: the host logic of the spatial decomposition.
+
+The device path (ddcmi_multigpu.inl) builds, per neighbour direction, the list of
+owned beads within rmax+deltaR of that face, applies the periodic shift on the
+sender and posts one message per direction in increasing direction-code order;
+the receiver posts its receives in the order of the SENDER's codes, from the rank
+in its opposite direction.  This test runs exactly that protocol between two real
+processes over gloo, using ddcmi_plan_directions (the C host function the GPU
+path uses) for the topology, and checks that owned + received halo beads give
+every rank the complete neighbourhood: summed energies and per-bead forces equal
+the single-rank oracle."""
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pair_terms(s, ri, ti, rj, tj, same):
+    """LJ energy/forces of beads i against beads j (no periodic arithmetic: halo beads carry the shift)"""
+    d = ri[:, None, :] - rj[None, :, :]
+    r2 = np.sum(d * d, axis=2)
+    mask = r2 < s.rmax ** 2
+    if same:
+        np.fill_diagonal(mask, False)
+    sij = tj[None, :] + s.nlj * ti[:, None]
+    sig, eps, sh = s.sigma[sij], s.eps[sij], s.shift[sij]
+    r2s = np.where(mask, r2, 1.0)
+    s6 = (sig * sig / r2s) ** 3
+    e = np.where(mask, 4 * eps * (s6 * s6 - s6) + sh, 0.0)
+    dvdr = np.where(mask, 24 * eps * (s6 - 2 * s6 * s6) / r2s, 0.0)
+    f = -(dvdr[:, :, None] * d).sum(axis=1)
+    return 0.5 * e.sum(), f
+
+
+def _worker(rank, world, port, grid, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ddcmd_amd
+    from ddcmd_amd.martini import plan_directions, domain_of
+    s = ddcmd_amd.make_water_setup(6)            # 864 beads, box 48.7 A; 2 bricks of 24.4 A >= rlist 16 A
+    L = s.box
+    rlist = s.rmax + s.deltaR
+    dest, shift = plan_directions(grid[0], grid[1], grid[2], rank, s.pbc)
+    owner = domain_of(s, grid)
+    mine = np.flatnonzero(owner == rank)
+    r = np.stack([s.rx[mine], s.ry[mine], s.rz[mine]], axis=1)
+    typ = s.ljtype[s.species[mine]]
+    pc = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+    lo = np.array([-0.5 * L[a] + pc[a] * L[a] / grid[a] for a in range(3)])
+    W = np.array([L[a] / grid[a] for a in range(3)])
+    near_lo = r < lo + rlist
+    near_hi = r >= lo + W - rlist
+    halo_r, halo_t = [], []
+    reqs, recv_meta = [], []
+    sendbufs = {}
+    # selection per direction (k_halo_select) + sender-side shift (k_pack_halo)
+    for code in range(27):
+        if code == 13 or dest[code] < 0:
+            continue
+        d = (code % 3 - 1, (code // 3) % 3 - 1, code // 9 - 1)
+        sel = np.ones(len(mine), bool)
+        for a in range(3):
+            if d[a] < 0:
+                sel &= near_lo[:, a]
+            elif d[a] > 0:
+                sel &= near_hi[:, a]
+        out = np.concatenate([r[sel] + shift[code] * L, typ[sel, None].astype(np.float64)], axis=1)
+        if dest[code] == rank:
+            halo_r.append(out[:, :3]); halo_t.append(out[:, 3].astype(np.int64))      # local periodic image
+        else:
+            sendbufs[code] = out
+    # counts, then data: sends in increasing code; receives in increasing SENDER code from dest[opp(code)]
+    for phase in ("count", "data"):
+        reqs = []
+        bufs = {}
+        for code in range(27):
+            if code in sendbufs:
+                t = torch.tensor([len(sendbufs[code])], dtype=torch.int64) if phase == "count" else torch.from_numpy(np.ascontiguousarray(sendbufs[code]))
+                if phase == "count" or len(sendbufs[code]) > 0:
+                    reqs.append(dist.isend(t, int(dest[code])))
+            opp = 26 - code
+            if code != 13 and dest[opp] >= 0 and dest[opp] != rank:
+                if phase == "count":
+                    bufs[code] = torch.zeros(1, dtype=torch.int64)
+                    reqs.append(dist.irecv(bufs[code], int(dest[opp])))
+                elif rcnt[code] > 0:
+                    bufs[code] = torch.zeros(rcnt[code], 4, dtype=torch.float64)
+                    reqs.append(dist.irecv(bufs[code], int(dest[opp])))
+        for rq in reqs:
+            rq.wait()
+        if phase == "count":
+            rcnt = {c: int(b.item()) for c, b in bufs.items()}
+        else:
+            for c in sorted(bufs):
+                a = bufs[c].numpy()
+                halo_r.append(a[:, :3]); halo_t.append(a[:, 3].astype(np.int64))
+    hr = np.concatenate(halo_r) if halo_r else np.zeros((0, 3))
+    ht = np.concatenate(halo_t) if halo_t else np.zeros(0, np.int64)
+    e1, f1 = _pair_terms(s, r, typ, r, typ, True)
+    e2, f2 = _pair_terms(s, r, typ, hr, ht, False)
+    etot = torch.tensor([e1 + e2, float(len(mine)), float(len(hr))], dtype=torch.float64)
+    dist.all_reduce(etot)                                           # energyInfo.c allreduce()
+    if rank == 0:
+        import pyoracle
+        o = pyoracle.Oracle(s)
+        e0, _ = o.forces()
+        q.put(("energy", float(etot[0]), e0["lj"], int(etot[1]), s.natoms))
+    import pyoracle
+    o = pyoracle.Oracle(s)
+    o.forces()
+    ref = np.stack([o.fx[mine], o.fy[mine], o.fz[mine]], axis=1)
+    q.put(("force", rank, float(np.abs(f1 + f2 - ref).max() / np.abs(ref).max()), len(hr)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1)])
+def test_world2_gloo_halo_protocol(built, grid):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300) + (7 if grid[0] == 1 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, grid, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for item in res:
+        if item[0] == "energy":
+            _, e, e0, ntot, n = item
+            assert ntot == n
+            assert abs(e - e0) < 1e-10 * abs(e0)
+        else:
+            _, rank, err, nh = item
+            assert err < 1e-10, (rank, err)
+            assert nh > 0
+
+
+def test_plan_directions_topology(built):
+    """ddcmi_plan_directions: destinations are mutual, shifts opposite, 2x2x2 has exactly 7 distinct peers"""
+    from ddcmd_amd.martini import plan_directions
+    for grid in [(2, 2, 2), (2, 2, 1), (2, 1, 1), (3, 2, 1), (1, 1, 1)]:
+        n = grid[0] * grid[1] * grid[2]
+        plans = [plan_directions(grid[0], grid[1], grid[2], r, 7) for r in range(n)]
+        for r in range(n):
+            dest, shift = plans[r]
+            assert dest[13] == -1
+            for code in range(27):
+                if code == 13:
+                    continue
+                b = dest[code]
+                assert 0 <= b < n
+                # the neighbour's opposite direction leads back here with the opposite shift
+                assert plans[b][0][26 - code] == r
+                assert np.array_equal(plans[b][1][26 - code], -shift[code])
+            if grid == (2, 2, 2):
+                assert len(set(dest[dest >= 0].tolist()) - {r}) == 7
+        # open boundaries: no neighbour across a non-periodic face
+        dest, shift = plan_directions(grid[0], grid[1], grid[2], 0, 0)
+        d = np.array([(c % 3 - 1, (c // 3) % 3 - 1, c // 9 - 1) for c in range(27)])
+        assert all(dest[c] == -1 for c in range(27) if (d[c] < 0).any())
