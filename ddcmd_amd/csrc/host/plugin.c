@@ -1,0 +1,386 @@
+/* plugin.c -- see plugin.h: ddcMD's plugin surface for the Martini path, in C, on
+ * top of the C-ABI.  Reference lines are cited per function. */
+#include "plugin.h"
+#include "object.h"
+#include "units.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <inttypes.h>
+
+static ACCELERATOR *the_accelerator = NULL;
+
+static void die(const char *where, const char *msg)
+{
+   /* error_action(msg, ERROR_IN(where, ABORT)) in the reference: print and exit */
+   fprintf(stderr, "%s: %s\n", where, msg);
+   exit(1);
+}
+
+/* accelerator_init, accelerator.c:10-56 */
+ACCELERATOR *accelerator_init(void *parent, const char *name, const char *type)
+{
+   (void)parent;
+   ACCELERATOR *a = calloc(1, sizeof(ACCELERATOR));
+   a->name = strdup(name ? name : "accelerator");
+   a->type = strdup(type ? type : "HIP");
+   if (strcmp(a->type, "CUDA") == 0) a->itype = GPU_CUDA;          /* existing decks say CUDA: accepted, runs on HIP */
+   else if (strcmp(a->type, "HIP") == 0) a->itype = GPU_HIP;
+   else die("accelerator_init", "ACCELERATOR type must be CUDA or HIP");
+   ddcmi_ctx *ctx = NULL;
+   int dev = 0;
+   const char *env = getenv("DDCMI_DEVICE");
+   if (env) dev = atoi(env);
+   if (ddcmi_create(&ctx, dev) != DDCMI_OK) die("accelerator_init", ddcmi_last_error(NULL));
+   a->parms = ctx;
+   the_accelerator = a;
+   return a;
+}
+ACCELERATOR *accelerator_getAccelerator(ACCELERATOR *a) { return a ? a : the_accelerator; }
+
+/* ------------------------------------------------------------------------- */
+/* bonded term lists over particle indices: charmmResidues (bioCharmmCovalent.c:48-93)
+ * sorts by gid and cuts residue runs; term atoms are offsets inside the run */
+typedef struct { uint64_t gid; int id; } gid_order;
+static int cmp_gid(const void *a, const void *b)
+{
+   uint64_t ga = ((const gid_order *)a)->gid, gb = ((const gid_order *)b)->gid;
+   return (ga > gb) - (ga < gb);
+}
+static int martiniBondHIPParms(ddcmi_ctx *ctx, const ddcmi_setup *s)
+{
+   const uint64_t molResMask = 0xffffffffffff0000ull;
+   int n = s->natoms;
+   int nb_tot = s->bond_off[s->nresi], na_tot = s->angle_off[s->nresi], nt_tot = s->tors_off[s->nresi];
+   if (nb_tot + na_tot + nt_tot == 0)
+      return ddcmi_set_bonded(ctx, 0, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, s->excludePotentialTerm);
+   gid_order *ord = malloc(sizeof(gid_order) * n);
+   for (int i = 0; i < n; i++) { ord[i].id = i; ord[i].gid = s->gid[i]; }
+   qsort(ord, n, sizeof(gid_order), cmp_gid);
+   /* count */
+   size_t nb = 0, na = 0, nt = 0;
+   for (int first = 0; first < n;)
+   {
+      uint64_t key = ord[first].gid & molResMask;
+      int last = first;
+      while (last < n && (ord[last].gid & molResMask) == key) last++;
+      int rt = s->resitype[s->species[ord[first].id]];
+      if (last - first != s->resi_natoms[rt]) { free(ord); return DDCMI_EINVAL; }
+      nb += s->bond_off[rt + 1] - s->bond_off[rt]; na += s->angle_off[rt + 1] - s->angle_off[rt]; nt += s->tors_off[rt + 1] - s->tors_off[rt];
+      first = last;
+   }
+   int *bij = malloc(sizeof(int) * (2 * nb + 2)), *aijk = malloc(sizeof(int) * (3 * na + 3)), *af = malloc(sizeof(int) * (na + 1));
+   int *tijkl = malloc(sizeof(int) * (4 * nt + 4)), *tf = malloc(sizeof(int) * (nt + 1)), *tn = malloc(sizeof(int) * (nt + 1));
+   double *kb = malloc(sizeof(double) * (nb + 1)), *b0 = malloc(sizeof(double) * (nb + 1));
+   double *ak = malloc(sizeof(double) * (na + 1)), *a0 = malloc(sizeof(double) * (na + 1));
+   double *tk = malloc(sizeof(double) * (nt + 1)), *td = malloc(sizeof(double) * (nt + 1));
+   nb = na = nt = 0;
+   for (int first = 0; first < n;)
+   {
+      uint64_t key = ord[first].gid & molResMask;
+      int last = first;
+      while (last < n && (ord[last].gid & molResMask) == key) last++;
+      int rt = s->resitype[s->species[ord[first].id]];
+#define AT(off) (ord[first + (off)].id)
+      for (int b = s->bond_off[rt]; b < s->bond_off[rt + 1]; b++, nb++)
+      { bij[2 * nb] = AT(s->bondI[b]); bij[2 * nb + 1] = AT(s->bondJ[b]); kb[nb] = s->bond_kb[b]; b0[nb] = s->bond_b0[b]; }
+      for (int a = s->angle_off[rt]; a < s->angle_off[rt + 1]; a++, na++)
+      { aijk[3 * na] = AT(s->angleI[a]); aijk[3 * na + 1] = AT(s->angleJ[a]); aijk[3 * na + 2] = AT(s->angleK[a]); af[na] = s->angle_func[a]; ak[na] = s->angle_k[a]; a0[na] = s->angle_t0[a]; }
+      for (int t = s->tors_off[rt]; t < s->tors_off[rt + 1]; t++, nt++)
+      { tijkl[4 * nt] = AT(s->torsI[t]); tijkl[4 * nt + 1] = AT(s->torsJ[t]); tijkl[4 * nt + 2] = AT(s->torsK[t]); tijkl[4 * nt + 3] = AT(s->torsL[t]);
+        tf[nt] = s->tors_func[t]; tn[nt] = s->tors_n[t]; tk[nt] = s->tors_k[t]; td[nt] = s->tors_delta[t]; }
+#undef AT
+      first = last;
+   }
+   int rc = ddcmi_set_bonded(ctx, (int)nb, bij, kb, b0, (int)na, aijk, af, ak, a0, (int)nt, tijkl, tf, tn, tk, td, s->excludePotentialTerm);
+   free(ord); free(bij); free(aijk); free(af); free(tijkl); free(tf); free(tn); free(kb); free(b0); free(ak); free(a0); free(tk); free(td);
+   return rc;
+}
+
+/* martini_parms (bioMartini.c:1210-1353): upload what martiniNonBondGPUParms /
+ * martiniBondGPUParms upload in the reference */
+static void martini_parms(POTENTIAL *potential, SIMULATE *simulate)
+{
+   const ddcmi_setup *s = simulate->setup;
+   ACCELERATOR *accelerator = accelerator_getAccelerator(NULL);
+   if (!accelerator) die("martini_parms", "no ACCELERATOR: this library has no CPU force path");
+   ddcmi_ctx *ctx = accelerator->parms;
+   int gtype[32];
+   int rc = 0;
+   rc |= ddcmi_set_box(ctx, s->h, s->pbc);
+   rc |= ddcmi_set_species(ctx, s->nspecies, s->mass, s->charge, s->ljtype, s->moltype);
+   rc |= ddcmi_set_nonbonded(ctx, s->nlj, s->sigma, s->eps, s->shift, s->rmax, s->keR, s->krf, s->crf);
+   rc |= ddcmi_set_molecules(ctx, s->nmoltype, s->mol_nspecies, s->bpair_off, s->bpairI, s->bpairJ);
+   rc |= ddcmi_set_neighbor(ctx, s->deltaR, s->updateRate);
+   for (int g = 0; g < s->ngroup && g < 32; g++)
+   {
+      if (s->group_type[g] == DDCMI_GROUP_FREE) gtype[g] = DDCMI_FREE;
+      else if (s->group_type[g] == DDCMI_GROUP_BERENDSEN) gtype[g] = DDCMI_BERENDSEN;
+      else die("group_init", "only FREE and BERENDSEN groups are supported on this path (LANGEVIN is a next-row item)");
+   }
+   rc |= ddcmi_set_groups(ctx, s->ngroup, gtype, s->group_Teq, s->group_tau, s->group_interval);
+   rc |= martiniBondHIPParms(ctx, s);
+   rc |= ddcmi_set_clock(ctx, s->loop, s->time);
+   if (rc) die("martini_parms", ddcmi_last_error(ctx));
+   printf("using HIP martini parms\n");                 /* bioMartini.c:1339 prints "using gpu martini parms" */
+   potential->use_gpu_list = 1;
+   potential->neighborTableType = NEIGHBORTABLE_GPU;
+   potential->eval_potential = (void (*)(void *, void *, void *))martiniHIP;
+   potential->parms = ctx;
+}
+
+POTENTIAL *potential_init(void *parent, const char *name, const char *type)
+{
+   if (strcmp(type, "MARTINI") != 0) die("potential_init", "only POTENTIAL type=MARTINI is implemented (potential.c:181-188)");
+   POTENTIAL *p = calloc(1, sizeof(POTENTIAL));
+   p->name = strdup(name); p->type = strdup(type); p->parent = parent;
+   martini_parms(p, (SIMULATE *)parent);
+   return p;
+}
+
+/* martiniGPU1 (bioMartini.cu:146-171) / martini (bioMartini.c:1357-1390):
+ * accumulate into e->eion and e->virial */
+void martiniHIP(SYSTEM *sys, void *parms, ETYPE *e)
+{
+   (void)sys;
+   ddcmi_ctx *ctx = parms;
+   double en[DDCMI_NE], vir[6];
+   if (ddcmi_eval_forces(ctx, en, vir) != DDCMI_OK) die("martiniHIP", ddcmi_last_error(ctx));
+   e->eion += en[DDCMI_E_TOTAL];
+   e->virial.xx += vir[DDCMI_XX]; e->virial.yy += vir[DDCMI_YY]; e->virial.zz += vir[DDCMI_ZZ];
+   e->virial.xy += vir[DDCMI_XY]; e->virial.xz += vir[DDCMI_XZ]; e->virial.yz += vir[DDCMI_YZ];
+}
+
+/* integrator_init, integrator.c:37-167 */
+INTEGRATOR *integrator_init(void *parent, const char *name, const char *type)
+{
+   INTEGRATOR *in = calloc(1, sizeof(INTEGRATOR));
+   in->name = strdup(name); in->type = strdup(type); in->parent = parent;
+   if (strcmp(type, "NGLF") == 0 || strcmp(type, "NVTGLF") == 0 || strcmp(type, "NGLFGPU") == 0 || strcmp(type, "NGLFHIP") == 0)
+   {
+      in->eval_integrator = (void (*)(void *, void *, void *))nglfHIP;
+      in->uses_gpu = 1;                                    /* state stays on the device between print steps (masters.c:389-403) */
+   }
+   else
+   {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "INTEGRATOR type %s is not on this path (NGLF, NVTGLF, NGLFGPU, NGLFHIP are)", type);
+      die("integrator_init", msg);
+   }
+   return in;
+}
+
+/* nglfGPU (nglfGPU.cu:511) with the nglf.c:67-112 contract: advance loop/time */
+void nglfHIP(DDC *ddc, SIMULATE *simulate, void *parms)
+{
+   (void)parms;
+   SYSTEM *sys = simulate->system;
+   ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+   if (ddcmi_step_nglf(ctx, simulate->dt, 1) != DDCMI_OK) die("nglfHIP", ddcmi_last_error(ctx));
+   ddc->update = 0;
+   simulate->time += simulate->dt;
+   simulate->loop++;
+   sys->loop = simulate->loop;
+   sys->time = simulate->time;
+}
+
+/* ddcenergy (ddcenergy.c:160-238) for the accelerated path: zero ETYPE, potentials */
+int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag)
+{
+   (void)ddc;
+   ETYPE *e = &sys->energyInfo;
+   e->eion = 0.0;
+   memset(&e->virial, 0, sizeof(e->virial));
+   for (int i = 0; i < sys->npotential; i++) sys->potential[i]->eval_potential(sys, sys->potential[i]->parms, e);
+   if (e_eval_flag) { kinetic_terms(sys, 1); eval_energyInfo(sys); }
+   return 0;
+}
+
+/* kinetic_terms (energy.c:48-163): rk, tion from the device reduction */
+void kinetic_terms(SYSTEM *sys, int flag)
+{
+   (void)flag;
+   ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+   ETYPE *e = &sys->energyInfo;
+   double tion[6];
+   if (ddcmi_kinetic(ctx, &e->rk, tion) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
+   e->tion.xx = tion[DDCMI_XX]; e->tion.yy = tion[DDCMI_YY]; e->tion.zz = tion[DDCMI_ZZ];
+   e->tion.xy = tion[DDCMI_XY]; e->tion.xz = tion[DDCMI_XZ]; e->tion.yz = tion[DDCMI_YZ];
+   e->number = (double)sys->nlocal;
+   e->temperature = 2.0 * e->rk / (3.0 * (double)sys->nglobal);        /* energy.c:151 */
+}
+
+/* eval_energyInfo (energyInfo.c:75-148), one rank */
+void eval_energyInfo(SYSTEM *sys)
+{
+   ETYPE *e = &sys->energyInfo;
+   double vol = sys->box->volume;
+   const double *v = &e->virial.xx, *t = &e->tion.xx;
+   double *s = &e->sion.xx;
+   for (int k = 0; k < 6; k++) s[k] = (v[k] + t[k]) * (1.0 / (-vol));   /* SMATACUM, SMATNORM(-vol) :108-110 */
+   e->pion = -(e->sion.xx + e->sion.yy + e->sion.zz) / 3.0;             /* :114 */
+   e->temperature = 2.0 * e->rk / (3.0 * e->number - sys->nConstraints); /* :115 */
+   sys->energy = e->eion + e->rk;                                       /* :116 */
+   e->energy = sys->energy;
+   /* group branch :118-141: the temperatures BERENDSEN reads */
+   ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+   double Tg[32];
+   if (ddcmi_group_temperatures(ctx, Tg) != DDCMI_OK) die("eval_energyInfo", ddcmi_last_error(ctx));
+   for (int g = 0; g < sys->ngroup && g < 32; g++) sys->group[g]->energyInfo.temperature = Tg[g];
+}
+
+int sendHostState(SYSTEM *sys)
+{
+   ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+   STATE *st = sys->state;
+   return ddcmi_download_state(ctx, DDCMI_POS | DDCMI_VEL | DDCMI_FORCE, st->rx, st->ry, st->rz, st->vx, st->vy, st->vz, st->fx, st->fy, st->fz);
+}
+
+/* ------------------------------------------------------------------------- */
+/* simulate_init (simulate.c:104-297) + system_init (system.c:79-214) from the deck */
+SIMULATE *simulate_init(const char *object_file, const char *restart_file, const char *extra, char *err, int errlen)
+{
+   ddcmi_setup *s = ddcmi_deck_load_with(object_file, restart_file, extra, err, errlen);
+   if (!s) return NULL;
+   SIMULATE *sim = calloc(1, sizeof(SIMULATE));
+   sim->name = strdup("simulate");
+   sim->setup = s;
+   sim->loop = s->loop; sim->maxloop = s->maxloop; sim->time = s->time; sim->dt = s->dt; sim->printrate = s->printrate > 0 ? s->printrate : 1;
+   SYSTEM *sys = sim->system = calloc(1, sizeof(SYSTEM));
+   sys->name = strdup("system");
+   sys->nspecies = s->nspecies;
+   sys->species = calloc(s->nspecies + 1, sizeof(SPECIES *));
+   for (int i = 0; i < s->nspecies; i++)
+   {
+      SPECIES *sp = sys->species[i] = calloc(1, sizeof(SPECIES));
+      sp->name = strdup(s->species_name[i]); sp->index = i; sp->mass = s->mass[i]; sp->charge = s->charge[i];
+   }
+   sys->ngroup = s->ngroup;
+   sys->group = calloc(s->ngroup + 1, sizeof(GROUP *));
+   for (int g = 0; g < s->ngroup; g++)
+   {
+      GROUP *gp = sys->group[g] = calloc(1, sizeof(GROUP));
+      gp->name = strdup(s->group_name[g]); gp->index = g;
+      gp->itype = s->group_type[g] == DDCMI_GROUP_FREE ? FREE : s->group_type[g] == DDCMI_GROUP_BERENDSEN ? BERENDSEN : s->group_type[g] == DDCMI_GROUP_LANGEVIN ? LANGEVIN_GROUP : OTHER_GROUP;
+      gp->Teq = s->group_Teq[g]; gp->tau = s->group_tau[g]; gp->interval = s->group_interval[g];
+   }
+   BOX_STRUCT *box = sys->box = calloc(1, sizeof(BOX_STRUCT));
+   memcpy(box->h0, s->h, sizeof(double) * 9); box->pbc = s->pbc; box->volume = s->h[0] * s->h[4] * s->h[8];
+   int n = s->natoms;
+   STATE *st = sys->state = calloc(1, sizeof(STATE));
+   st->nlocal = st->nion = n;
+   st->rx = s->rx; st->ry = s->ry; st->rz = s->rz; st->vx = s->vx; st->vy = s->vy; st->vz = s->vz;    /* aliases of the deck arrays */
+   st->fx = calloc(n, sizeof(double)); st->fy = calloc(n, sizeof(double)); st->fz = calloc(n, sizeof(double));
+   st->q = calloc(n, sizeof(double));
+   st->label = s->gid;
+   st->species = calloc(n, sizeof(SPECIES *)); st->group = calloc(n, sizeof(GROUP *));
+   for (int i = 0; i < n; i++) { st->species[i] = sys->species[s->species[i]]; st->group[i] = sys->group[s->group[i]]; st->q[i] = st->species[i]->charge; }
+   sys->nlocal = sys->nion = n; sys->nglobal = n; sys->loop = s->loop; sys->time = s->time; sys->nConstraints = s->nConstraints; sys->deltaR = s->deltaR;
+   DDC *ddc = sim->ddc = calloc(1, sizeof(DDC));
+   ddc->updateRate = s->updateRate; ddc->lx = s->lx; ddc->ly = s->ly; ddc->lz = s->lz; ddc->rcut = s->rmax + s->deltaR;   /* ddcenergy.c:43-55 cutoffs() */
+   /* simulate.c:172: accelerator_init when the deck names one; this library always needs one */
+   if (!s->has_accelerator) printf("no ACCELERATOR object in the deck: running on HIP device 0 (this library has no CPU force path)\n");
+   sim->accelerator = accelerator_init(sim, "accelerator", s->has_accelerator ? s->accelerator_type : "HIP");
+   sys->npotential = 1;
+   sys->potential = calloc(2, sizeof(POTENTIAL *));
+   sys->potential[0] = potential_init(sim, "martini", "MARTINI");
+   sim->integrator = integrator_init(sim, "nglf", s->integrator_type);
+   /* sendGPUState + sendForceVelocityToGPU (masters.c:389-393) */
+   ddcmi_ctx *ctx = sim->accelerator->parms;
+   if (ddcmi_upload_state(ctx, n, st->rx, st->ry, st->rz, st->vx, st->vy, st->vz, st->label, s->species, s->group) != DDCMI_OK)
+   {
+      snprintf(err, errlen, "%s", ddcmi_last_error(ctx));
+      return NULL;
+   }
+   return sim;
+}
+
+/* printinfoA, printinfo.c:125-232: one line of the `data` file */
+void printinfo(SIMULATE *simulate, ETYPE *e, int header)
+{
+   const ddcmi_setup *s = simulate->setup;
+   SYSTEM *sys = simulate->system;
+   double cE = units_convert(1.0, NULL, s->u_energy), cT = units_convert(1.0, NULL, s->u_temperature), cP = units_convert(1.0, NULL, s->u_pressure);
+   double cV = units_convert(1.0, NULL, s->u_volume), ct = units_convert(1.0, NULL, s->u_time), cL = units_convert(1.0, NULL, s->u_length);
+   double ng = (double)sys->nglobal;
+   double time = ct * simulate->time;
+   double ekinetic = cE * (e->rk / ng), etot = cE * ((e->eion + e->rk + e->eBath) / ng), epot = cE * (e->eion / ng);
+   double temperature = cT * e->temperature, pressure = cP * e->pion, voln = cV * sys->box->volume / ng;
+   FILE *out[2] = {stdout, simulate->datafile};
+   for (int k = 0; k < 2; k++)
+   {
+      FILE *f = out[k];
+      if (!f) continue;
+      if (header)
+      {
+         char b[6][64];
+         snprintf(b[0], 64, "time(%s)", s->u_time); snprintf(b[1], 64, "Etotal(%s)", s->u_energy); snprintf(b[2], 64, "Ekin(%s)", s->u_energy);
+         snprintf(b[3], 64, "Epot(%s)", s->u_energy); snprintf(b[4], 64, "Temp(%s)", s->u_temperature); snprintf(b[5], 64, "Press(%s)", s->u_pressure);
+         char v[4][64];
+         snprintf(v[0], 64, "Volume(%s)", s->u_volume); snprintf(v[1], 64, "lx(%s)", s->u_length); snprintf(v[2], 64, "ly(%s)", s->u_length); snprintf(v[3], 64, "lz(%s)", s->u_length);
+         fprintf(f, "%-12s %16s %18s %18s %18s %18s %18s %18s %15s %15s %15s\n", "#loop", b[0], b[1], b[2], b[3], b[4], b[5], v[0], v[1], v[2], v[3]);
+      }
+      fprintf(f, "%12" PRId64 " %16.6f %18.12f %18.12f %18.12f %18.8f %18.12f %18.12f %15.8f %15.8f %15.8f\n", simulate->loop, time, etot, ekinetic, epot,
+              temperature, pressure, voln, cL * sys->box->h0[0], cL * sys->box->h0[4], cL * sys->box->h0[8]);
+      fflush(f);
+   }
+}
+
+/* simulateMaster, masters.c:369-559: firstEnergyCall, then batches of steps up to
+ * the next print step (findEndLoop :263-281), energies after each batch */
+int simulateMaster(SIMULATE *simulate, const char *datafile_path)
+{
+   SYSTEM *sys = simulate->system;
+   ddcmi_ctx *ctx = simulate->accelerator->parms;
+   simulate->datafile = datafile_path ? fopen(datafile_path, "a") : NULL;
+   simulate->ddc->update = 3;                                     /* firstEnergyCall :579-620 */
+   ddcenergy(simulate->ddc, sys, 1);
+   printinfo(simulate, &sys->energyInfo, 1);
+   while (simulate->loop < simulate->maxloop)
+   {
+      int64_t endLoop = (simulate->loop / simulate->printrate + 1) * simulate->printrate;
+      if (endLoop > simulate->maxloop) endLoop = simulate->maxloop;
+      while (simulate->loop < endLoop)
+         simulate->integrator->eval_integrator(simulate->ddc, simulate, simulate->integrator->parms);
+      /* uses_gpu: sendForceEnergyToHost (masters.c:448-453), then kinetic_terms + eval_energyInfo (:454-455) */
+      double en[DDCMI_NE], vir[6], rk, tion[6];
+      if (ddcmi_get_energies(ctx, en, vir, &rk, tion) != DDCMI_OK) die("simulateMaster", ddcmi_last_error(ctx));
+      ETYPE *e = &sys->energyInfo;
+      e->eion = en[DDCMI_E_TOTAL];
+      e->virial.xx = vir[DDCMI_XX]; e->virial.yy = vir[DDCMI_YY]; e->virial.zz = vir[DDCMI_ZZ];
+      e->virial.xy = vir[DDCMI_XY]; e->virial.xz = vir[DDCMI_XZ]; e->virial.yz = vir[DDCMI_YZ];
+      kinetic_terms(sys, 1);
+      eval_energyInfo(sys);
+      if (!isfinite(e->eion))                                     /* masters.c:470-475 */
+      {
+         printf("eion = %e is bad. Simulation is being killed at loop = %" PRId64 "\n", e->eion, simulate->loop);
+         break;
+      }
+      if (simulate->loop % simulate->printrate == 0) printinfo(simulate, e, 0);
+   }
+   sendHostState(sys);
+   if (simulate->datafile) fclose(simulate->datafile);
+   simulate->datafile = NULL;
+   return 0;
+}
+
+void simulate_free(SIMULATE *sim)
+{
+   if (!sim) return;
+   if (sim->accelerator) { ddcmi_destroy(sim->accelerator->parms); free(sim->accelerator->name); free(sim->accelerator->type); free(sim->accelerator); the_accelerator = NULL; }
+   SYSTEM *sys = sim->system;
+   if (sys)
+   {
+      STATE *st = sys->state;
+      if (st) { free(st->fx); free(st->fy); free(st->fz); free(st->q); free(st->species); free(st->group); free(st); }
+      for (int i = 0; i < sys->nspecies; i++) { free(sys->species[i]->name); free(sys->species[i]); }
+      for (int g = 0; g < sys->ngroup; g++) { free(sys->group[g]->name); free(sys->group[g]); }
+      if (sys->potential) { free(sys->potential[0]->name); free(sys->potential[0]->type); free(sys->potential[0]); free(sys->potential); }
+      free(sys->species); free(sys->group); free(sys->box); free(sys->name); free(sys);
+   }
+   if (sim->integrator) { free(sim->integrator->name); free(sim->integrator->type); free(sim->integrator); }
+   free(sim->ddc);
+   ddcmi_setup_free(sim->setup);
+   free(sim->name);
+   free(sim);
+}

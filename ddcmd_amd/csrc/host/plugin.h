@@ -1,0 +1,142 @@
+/*
+ * plugin.h -- host-side mirror of the ddcMD plugin surface for the Martini path.
+ *
+ * Same type names, member names and call signatures as the reference for the
+ * members this path touches, so the glue reads like ddcMD's own:
+ *   POTENTIAL   potential.h:42-58      eval_potential(sys, parms, e)
+ *   INTEGRATOR  integrator.h:5-17      eval_integrator(ddc, simulate, parms)
+ *   ACCELERATOR accelerator.h:11-31
+ *   STATE       state.h:7-27           SoA particle store
+ *   ETYPE       energyInfo.h           rk, eion, virial, tion, sion, pion, temperature
+ *   SYSTEM / SIMULATE / DDC            the members nglf.c / ddcenergy.c / masters.c use
+ * The device work behind them is libddcmi's C-ABI (include/ddcmi.h).  There is no
+ * CPU force path in this library: decks without an ACCELERATOR object run on HIP
+ * device 0 and say so.
+ */
+#ifndef DDCMI_PLUGIN_H
+#define DDCMI_PLUGIN_H
+#include <stdint.h>
+#include <stdio.h>
+#include "ddcmi.h"
+#include "deck.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t gid_type;
+typedef struct { double x, y, z; } THREE_VECTOR;
+typedef struct { double xx, yy, zz, xy, xz, yz; } THREE_SMATRIX;
+
+typedef struct etype_st
+{
+   double rk, eion, pion, temperature, number, mass, eBath;
+   THREE_SMATRIX virial, tion, sion;
+   double energy;                       /* sys->energy = eion + rk (energyInfo.c:116) */
+} ETYPE;
+
+typedef struct species_st { char *name; int index; double mass, charge; } SPECIES;
+enum GROUP_CLASS { FREE, BERENDSEN, LANGEVIN_GROUP, OTHER_GROUP };
+typedef struct group_st { char *name; int index; int itype; double Teq, tau; int interval; ETYPE energyInfo; } GROUP;
+
+typedef struct state_st
+{
+   double *rx, *ry, *rz;
+   double *vx, *vy, *vz;
+   double *fx, *fy, *fz;
+   double *q;
+   gid_type *label;
+   SPECIES **species;
+   GROUP **group;
+   int nlocal, nion;
+} STATE;
+
+typedef struct box_st { double h0[9]; int pbc; double volume; } BOX_STRUCT;
+
+enum ACCELERATOR_CLASS { GPU_CUDA = 1, GPU_HIP = 2 };
+typedef struct accelerator_st
+{
+   char *name, *type;
+   enum ACCELERATOR_CLASS itype;
+   void *parms;                         /* ddcmi_ctx* */
+} ACCELERATOR;
+
+enum NEIGHBORTABLETYPE { NEIGHBORTABLE_NONE = 0, NEIGHBORTABLE_SKINNY = 1, NEIGHBORTABLE_FAT = 2, NEIGHBORTABLE_GPU = 4 };
+typedef struct potential_st
+{
+   char *name, *type;
+   void *parent;
+   void (*eval_potential)(void *sys, void *parms, void *e);
+   enum NEIGHBORTABLETYPE neighborTableType;
+   int use_gpu_list;
+   void *parms;
+} POTENTIAL;
+
+typedef struct integrator_st
+{
+   char *name, *type;
+   void *parent;
+   int uses_gpu;
+   void (*eval_integrator)(void *ddc, void *simulate, void *parms);
+   void *parms;
+} INTEGRATOR;
+
+typedef struct ddc_st { int updateRate; int lx, ly, lz; int update; double rcut; } DDC;
+
+typedef struct system_st
+{
+   char *name;
+   int npotential, ngroup, nspecies;
+   POTENTIAL **potential;
+   GROUP **group;
+   SPECIES **species;
+   STATE *state;                        /* sys->collection->state in the reference */
+   BOX_STRUCT *box;
+   ETYPE energyInfo;
+   unsigned nlocal, nion;
+   gid_type nglobal;
+   int64_t loop;
+   double time, energy;
+   int nConstraints;
+   double deltaR;                       /* sys->neighbor->deltaR */
+} SYSTEM;
+
+typedef struct simulate_st
+{
+   char *name;
+   SYSTEM *system;
+   INTEGRATOR *integrator;
+   ACCELERATOR *accelerator;
+   DDC *ddc;
+   int64_t loop, maxloop;
+   double time, dt;
+   int printrate;
+   ddcmi_setup *setup;                  /* the parsed deck */
+   FILE *datafile;
+} SIMULATE;
+
+/* accelerator.c:10-56 */
+ACCELERATOR *accelerator_init(void *parent, const char *name, const char *type);
+ACCELERATOR *accelerator_getAccelerator(ACCELERATOR *a);
+/* potential.c:85-300 (type=MARTINI only) and bioMartini.c:1210-1353 */
+POTENTIAL *potential_init(void *parent, const char *name, const char *type);
+void martiniHIP(SYSTEM *sys, void *parms, ETYPE *e);
+/* integrator.c:37-167 (NGLF, NGLFGPU, NGLFHIP) and nglf.c:67-112 */
+INTEGRATOR *integrator_init(void *parent, const char *name, const char *type);
+void nglfHIP(DDC *ddc, SIMULATE *simulate, void *parms);
+/* ddcenergy.c:160-238, energy.c:48-163, energyInfo.c:75-148 */
+int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag);
+void kinetic_terms(SYSTEM *sys, int flag);
+void eval_energyInfo(SYSTEM *sys);
+/* simulate.c:104-297, masters.c:369-559 (MD loop), printinfo.c:125-232 (data file) */
+SIMULATE *simulate_init(const char *object_file, const char *restart_file, const char *extra_objects, char *err, int errlen);
+int simulateMaster(SIMULATE *simulate, const char *datafile_path);
+void simulate_free(SIMULATE *simulate);
+void printinfo(SIMULATE *simulate, ETYPE *energyInfo, int header);
+/* copy device state back into STATE (sendForceVelocityToHost + sendPosnToHost) */
+int sendHostState(SYSTEM *sys);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
