@@ -1,0 +1,60 @@
+"""CPU tests of the drop-in boundary: libddcmi.so loads without a GPU, exports every
+symbol include/ddcmi.h declares, and fails loudly (error code + message) when no
+device is present -- there is no CPU fallback."""
+import ctypes
+import os
+import re
+
+import ddcmd_amd
+from ddcmd_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddcmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = ddcmd_amd.load_library()
+    names = _declared_functions(os.path.join(ROOT, "include", "ddcmi.h"))
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_layer_symbols(built):
+    lib = ddcmd_amd.load_library()
+    for n in ("object_compilefile", "object_get", "object_getv", "object_find", "units_convert", "units_internal", "units_external",
+              "ddcmi_deck_load", "accelerator_init", "accelerator_getAccelerator", "potential_init", "integrator_init",
+              "martiniHIP", "nglfHIP", "ddcenergy", "kinetic_terms", "eval_energyInfo", "simulate_init", "simulateMaster"):
+        assert hasattr(lib, n), n
+
+
+def test_create_without_gpu_fails_loudly(built):
+    lib = ddcmd_amd.load_library()
+    lib.ddcmi_device_count.restype = ctypes.c_int
+    if lib.ddcmi_device_count() > 0:
+        return          # on a GPU box the positive path is covered by the -m gpu tests
+    ctx = ctypes.c_void_p()
+    lib.ddcmi_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    rc = lib.ddcmi_create(ctypes.byref(ctx), 0)
+    assert rc == -1 and not ctx.value           # DDCMI_ENODEVICE
+    lib.ddcmi_last_error.restype = ctypes.c_char_p
+    lib.ddcmi_last_error.argtypes = [ctypes.c_void_p]
+    assert b"no HIP device" in lib.ddcmi_last_error(None)
+    from ddcmd_amd.martini import MartiniHIP, DdcmiError
+    import pytest
+    with pytest.raises(DdcmiError):
+        MartiniHIP(ddcmd_amd.make_water_setup(3))
+
+
+def test_product_does_not_import_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ddcmd_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".inl")) and "build" not in dirpath:
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "ddc_oracle" not in text, os.path.join(dirpath, f)

@@ -123,8 +123,8 @@ def _worker(rank, world, port, grid, q):
 
 @pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1)])
 def test_world2_gloo_halo_protocol(built, grid):
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
+    import multiprocessing as mp          # plain spawn: the parent never loads torch (its bundled ROCm libs
+    ctx = mp.get_context("spawn")         # must not meet the system ones already loaded through libddcmi.so)
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 300) + (7 if grid[0] == 1 else 0)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, grid, q)) for r in range(2)]
