@@ -57,11 +57,11 @@ __device__ __forceinline__ double wave_sum(double v)
    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
    return v;
 }
-/* block (256 threads) reduction of NV values per thread into out[NV] by thread 0 */
-template <int NV>
+/* block (NW waves) reduction of NV values per thread into out[NV], fixed order */
+template <int NV, int NW = 4>
 __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
 {
-   __shared__ double s_red[4][NV];
+   __shared__ double s_red[NW][NV];
    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
    for (int k = 0; k < NV; k++)
@@ -73,7 +73,10 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
    if (threadIdx.x < NV)
    {
       int k = threadIdx.x;
-      out[k] = ((s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]));
+      double a = s_red[0][k];
+#pragma unroll
+      for (int q = 1; q < NW; q++) a += s_red[q][k];
+      out[k] = a;
    }
 }
 
@@ -562,8 +565,10 @@ __device__ __forceinline__ double rsqrt_f64(double x)
    return y;
 }
 
-template <bool HAS_Q, bool PACKED>
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad,
+/* 5 waves per tile: a tile holds 256 beads on average, so 256-thread workgroups
+ * would make every second tile take a second, mostly idle pass */
+template <bool HAS_Q, bool PACKED, int NB_BLOCK, int WPE = 0>
+__global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ qatom,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
@@ -593,10 +598,10 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
    }
    if (nown > 0)
    {
-      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += DDCMI_BLOCK) s_lj[k] = ljtab[k];
+      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) s_lj[k] = ljtab[k];
       int ns = ta.tile_nstage[t];
       const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
-      for (int k = threadIdx.x; k < ns; k += DDCMI_BLOCK)
+      for (int k = threadIdx.x; k < ns; k += NB_BLOCK)
       {
          int gj = sidx[k];
          double4 p = pos[gj];
@@ -609,17 +614,29 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
       long long base = ta.tile_base[t];
       int rows = ta.tile_rows[t];
       const int nlj = ta.nlj;
-      for (int al = threadIdx.x; al < rows; al += DDCMI_BLOCK)
+      /* one wave per 64-row chunk.  A partial last chunk (k < 64 beads) gives every
+       * bead `parts` lanes that split its list, so a tile with 257..260 beads does
+       * not pay a whole extra pass for four beads. */
+      const int lane = threadIdx.x & 63;
+      for (int chunk = threadIdx.x >> 6; chunk * 64 < rows; chunk += NB_BLOCK / 64)
       {
-         bool active = al < nown;
-         int a = ts + (active ? al : 0);
+         int kb = min(64, nown - chunk * 64);
+         int parts = 1;
+         while (parts * 2 * kb <= 64) parts *= 2;
+         int sub = lane & (parts - 1);
+         int ain = lane / parts;
+         bool active = ain < kb;
+         int al = chunk * 64 + (active ? ain : 0);
+         int a = ts + al;
          double4 pi = pos[a];
          int ti = (int)(__double_as_longlong(pi.w) & 0xffffll);
          double kqi = 0.0;
          if (HAS_Q) kqi = keR * qatom[a];
-         int cnt = active ? ta.nbr_cnt[a] : 0;
+         int cnt_full = active ? ta.nbr_cnt[a] : 0;
+         int cnt = (cnt_full > sub) ? (cnt_full - sub + parts - 1) / parts : 0;     /* slots sub, sub+parts, ... */
          double fxi = 0, fyi = 0, fzi = 0;
-         const unsigned short *col = ta.nbr16 + base + al;
+         const unsigned short *col = ta.nbr16 + base + al + (size_t)sub * rows;
+         const size_t cstride = (size_t)parts * rows;
          /* wave-uniform trip count; the list is read CH slots ahead so the HBM/L2
           * latency of the (coalesced, slot-major) list stream overlaps the pair math,
           * and the CH distance tests of a chunk are independent (ILP at low occupancy) */
@@ -629,11 +646,11 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
          constexpr int CH = 8;
          unsigned short e[CH], en[CH];
 #pragma unroll
-         for (int u = 0; u < CH; u++) e[u] = (u < wmax) ? col[(size_t)u * rows] : (unsigned short)0;
+         for (int u = 0; u < CH; u++) e[u] = (u < wmax) ? col[(size_t)u * cstride] : (unsigned short)0;
          for (int k0 = 0; k0 < wmax; k0 += CH)
          {
 #pragma unroll
-            for (int u = 0; u < CH; u++) en[u] = (k0 + CH + u < wmax) ? col[(size_t)(k0 + CH + u) * rows] : (unsigned short)0;
+            for (int u = 0; u < CH; u++) en[u] = (k0 + CH + u < wmax) ? col[(size_t)(k0 + CH + u) * cstride] : (unsigned short)0;
             double x[CH], y[CH], z[CH], r2[CH];
             int tj[CH];
 #pragma unroll
@@ -683,7 +700,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
          {
             /* excluded (same-molecule bonded) pairs: reaction-field correction only
              * (martiniIntraMoleReaction); few per bead, gathered from global memory */
-            int ecnt = active ? excl_cnt[a] : 0;
+            int ecnt = (active && sub == 0) ? excl_cnt[a] : 0;
             for (int k = 0; k < ecnt; k++)
             {
                int j = excl[(size_t)k * npad + a];
@@ -702,10 +719,14 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_nonbond(NbTileArgs ta, int npad
                }
             }
          }
-         if (active) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; }
+         for (int off = parts >> 1; off > 0; off >>= 1)
+         {
+            fxi += __shfl_xor(fxi, off, 64); fyi += __shfl_xor(fyi, off, 64); fzi += __shfl_xor(fzi, off, 64);
+         }
+         if (active && sub == 0) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; }
       }
    }
-   if (t < ta.ntile) block_reduce_store<8>(acc, partials + (size_t)t * 8);
+   if (t < ta.ntile) block_reduce_store<8, NB_BLOCK / 64>(acc, partials + (size_t)t * 8);
 }
 
 /* zero forces (nonbonded excluded via excludePotentialTerm) */
@@ -959,6 +980,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
+   { const char *nbv = getenv("DDCMI_NB_BLOCK"); if (nbv) ctx->nb_block = atoi(nbv); }
    ctx->gtype.assign(1, DDCMI_FREE); ctx->ginterval.assign(1, 1); ctx->gTeq.assign(1, 0); ctx->gtau.assign(1, 0);
    ctx->glambda.assign(1, 1.0); ctx->gTsum.assign(1, 0); ctx->gT.assign(1, 0); ctx->gnT.assign(1, 0); ctx->gdoScaling.assign(1, 0);
    *out = ctx;
@@ -1495,15 +1517,22 @@ static int launch_forces(ddcmi_ctx *ctx)
          e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
          HIPCHK(ctx, hipEventRecord(e0, st));
       }
-#define LAUNCH_NB(Q, P) do { \
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P>), dim3(grid), dim3(DDCMI_BLOCK), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
+#define LAUNCH_NB(Q, P, NT) do { \
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, NT>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
-      if (useq && packed) LAUNCH_NB(true, true);
-      else if (useq) LAUNCH_NB(true, false);
-      else if (packed) LAUNCH_NB(false, true);
-      else LAUNCH_NB(false, false);
+#define LAUNCH_NB4(Q, P) do { \
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, 256, 4>), dim3(grid), dim3(256), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
+                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
+#define LAUNCH_NB2(Q, P) do { if (ctx->nb_block == 320) LAUNCH_NB(Q, P, 320); else if (ctx->nb_block == 1256) LAUNCH_NB4(Q, P); else LAUNCH_NB(Q, P, 256); } while (0)
+      if (useq && packed) LAUNCH_NB2(true, true);
+      else if (useq) LAUNCH_NB2(true, false);
+      else if (packed) LAUNCH_NB2(false, true);
+      else LAUNCH_NB2(false, false);
+#undef LAUNCH_NB2
 #undef LAUNCH_NB
       if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
       hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);

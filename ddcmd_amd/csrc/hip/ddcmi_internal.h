@@ -114,6 +114,7 @@ struct ddcmi_ctx
    int *d_flags = nullptr; int *h_flags = nullptr;
    double self_ele = 0.0;
    bool forces_valid = false;
+   int nb_block = 256;                 /* threads per tile in k_nonbond (tunable: DDCMI_NB_BLOCK) */
    /* timing */
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
    /* comm */
