@@ -555,13 +555,27 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
  */
 __device__ __forceinline__ double rsqrt_f64(double x)
 {
+   /* v_rsq_f32 seed (23 bits) + two Newton steps y += y*(1/2 - (x/2) y^2): 3 FP64 ops
+    * each, < 2 ulp; checked against the closed form in tests */
    float xf = (float)x;
    double y = (double)__frsqrt_rn(xf);
    double h = 0.5 * x;
-   y = y * (1.5 - h * y * y);
-   y = y * (1.5 - h * y * y);
-   /* third step is free of charge accuracy-wise only when the seed is poor; two
-    * steps from a 23-bit seed give < 2 ulp, checked against sqrt(1/x) in tests */
+   double e = fma(-(h * y), y, 0.5);
+   y = fma(y, e, y);
+   e = fma(-(h * y), y, 0.5);
+   y = fma(y, e, y);
+   return y;
+}
+/* 1/x: v_rcp_f32 seed + two Newton steps y += y*(1 - x y): 2 FP64 ops each.  Used
+ * when no bead carries a charge: Lennard-Jones needs 1/r^2 only, no square root. */
+__device__ __forceinline__ double rcp_f64(double x)
+{
+   float xf = (float)x;
+   double y = (double)__frcp_rn(xf);
+   double e = fma(-x, y, 1.0);
+   y = fma(y, e, y);
+   e = fma(-x, y, 1.0);
+   y = fma(y, e, y);
    return y;
 }
 
@@ -665,34 +679,36 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
                double rr = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                r2[u] = (k0 + u < cnt) ? rr : rc2;
             }
+            /* pair math for slot u of the chunk */
+#define NB_PAIR(u) do { \
+                  int tjj = PACKED ? tj[u] : (int)T_s[tj[u]]; \
+                  double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
+                  double ir = 0.0, ir2; \
+                  if (HAS_Q) { ir = rsqrt_f64(r2[u]); ir2 = ir * ir; } \
+                  else ir2 = rcp_f64(r2[u]); \
+                  double s2 = lj.x * ir2; \
+                  double s4 = s2 * s2; \
+                  double s6 = s4 * s2; \
+                  double s12 = s6 * s6; \
+                  acc[0] += lj.y * (s12 - s6) + lj.z; \
+                  double dvdr = lj.w * (s6 - 2.0 * s12) * ir2; \
+                  if (HAS_Q) \
+                  { \
+                     int sjq = PACKED ? ((int)e[u] & 0xfff) : (int)e[u]; \
+                     double kqij = kqi * q_s[sjq]; \
+                     acc[1] += kqij * (ir + krf * r2[u] - crf); \
+                     dvdr += kqij * (2.0 * krf - ir2 * ir); \
+                  } \
+                  double fxij = -dvdr * x[u], fyij = -dvdr * y[u], fzij = -dvdr * z[u]; \
+                  fxi += fxij; fyi += fyij; fzi += fzij; \
+                  acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u]; \
+                  acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u]; } while (0)
 #pragma unroll
             for (int u = 0; u < CH; u++)
             {
-               if (r2[u] < rc2)
-               {
-                  int tjj = PACKED ? tj[u] : (int)T_s[tj[u]];
-                  double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */
-                  double ir = rsqrt_f64(r2[u]);
-                  double ir2 = ir * ir;
-                  double s2 = lj.x * ir2;
-                  double s4 = s2 * s2;
-                  double s6 = s4 * s2;
-                  double s12 = s6 * s6;
-                  acc[0] += lj.y * (s12 - s6) + lj.z;
-                  double dvdr = lj.w * (s6 - 2.0 * s12) * ir2;
-                  if (HAS_Q)
-                  {
-                     int sj = PACKED ? ((int)e[u] & 0xfff) : (int)e[u];
-                     double kqij = kqi * q_s[sj];
-                     acc[1] += kqij * (ir + krf * r2[u] - crf);
-                     dvdr += kqij * (2.0 * krf - ir2 * ir);
-                  }
-                  double fxij = -dvdr * x[u], fyij = -dvdr * y[u], fzij = -dvdr * z[u];
-                  fxi += fxij; fyi += fyij; fzi += fzij;
-                  acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u];
-                  acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u];
-               }
+               if (r2[u] < rc2) NB_PAIR(u);
             }
+#undef NB_PAIR
 #pragma unroll
             for (int u = 0; u < CH; u++) e[u] = en[u];
          }
