@@ -280,6 +280,7 @@ struct TileArgs
 struct NbTileArgs
 {
    int ntile, stage_stride, cap, nlj;
+   int dbg;                              /* ablation switch for profiling experiments (0 in production) */
    const int *cell_start_o;
    const int *stage_idx, *tile_nstage;
    const long long *tile_base; const int *tile_width, *tile_rows;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    if (threadIdx.x == 0)
    {
       int width = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
-      width = max(min(width, ta.tmpw), 1);
+      width = (max(min(width, ta.tmpw), 1) + 7) & ~7;      /* slots are stored in groups of 8 (one 16-byte load per lane) */
       unsigned long long need = (unsigned long long)rows * width;
       unsigned long long b0 = atomicAdd(ta.arena_used, need);
       long long sb;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
    const int npass = (ta.tmpw + 63) >> 6;
    for (int c0 = 0; c0 < rows; c0 += IMG_ROWS)
    {
-      for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += DDCMI_BLOCK) img32[idx] = 0;
+      for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += DDCMI_BLOCK) img32[idx] = 0;     /* width is a multiple of 8 <= tmpw */
       __syncthreads();
       /* wave w owns rows [32w, 32w+32) of this chunk; their counts are fetched with one load */
       int r_lane = c0 + 32 * w + (lane & 31);
@@ -530,12 +531,15 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
 #undef TR_PASS
       }
       __syncthreads();
+      /* slice layout: [slot group g][row][8 slots] -> a lane reads its 8 slots of a group with one 16-byte load */
       int nr = min(IMG_ROWS, rows - c0);           /* multiple of 64 */
-      int nr2 = nr >> 1;
-      for (int idx = threadIdx.x; idx < width * nr2; idx += DDCMI_BLOCK)
+      int ngrp = width >> 3;
+      for (int idx = threadIdx.x; idx < ngrp * nr * 4; idx += DDCMI_BLOCK)
       {
-         int slot = idx / nr2, r2 = idx - slot * nr2;
-         *(unsigned int *)(ta.nbr16 + base + (size_t)slot * rows + c0 + 2 * r2) = img32[slot * (IMG_STRIDE / 2) + r2];
+         int q = idx & 3, r = (idx >> 2) % nr, g = (idx >> 2) / nr;
+         int k = 8 * g + 2 * q;
+         unsigned int lo = img[k * IMG_STRIDE + r], hi = img[(k + 1) * IMG_STRIDE + r];
+         *(unsigned int *)(ta.nbr16 + base + ((size_t)g * rows + c0 + r) * 8 + 2 * q) = lo | (hi << 16);
       }
       __syncthreads();
    }
@@ -615,14 +619,30 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
       for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) s_lj[k] = ljtab[k];
       int ns = ta.tile_nstage[t];
       const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
-      for (int k = threadIdx.x; k < ns; k += NB_BLOCK)
+      /* stage the neighbourhood: all index loads first, then all record gathers, then the
+       * LDS writes -- a naive loop serialises ~9 dependent HBM/L2 round trips per thread */
+      constexpr int SU = 5;
+      for (int k0 = threadIdx.x; k0 < (ta.dbg == 4 ? 0 : ns); k0 += SU * NB_BLOCK)
       {
-         int gj = sidx[k];
-         double4 p = pos[gj];
-         XY_s[k] = make_double2(p.x, p.y);
-         Z_s[k] = p.z;
-         if (!PACKED) T_s[k] = (unsigned char)(__double_as_longlong(p.w) & 0xff);
-         if (HAS_Q) q_s[k] = qatom[gj];
+         int gj[SU];
+         double4 pp[SU];
+         double qq[SU];
+#pragma unroll
+         for (int u = 0; u < SU; u++) { int k = k0 + u * NB_BLOCK; gj[u] = (k < ns) ? sidx[k] : 0; }
+#pragma unroll
+         for (int u = 0; u < SU; u++) { pp[u] = pos[gj[u]]; if (HAS_Q) qq[u] = qatom[gj[u]]; }
+#pragma unroll
+         for (int u = 0; u < SU; u++)
+         {
+            int k = k0 + u * NB_BLOCK;
+            if (k < ns)
+            {
+               XY_s[k] = make_double2(pp[u].x, pp[u].y);
+               Z_s[k] = pp[u].z;
+               if (!PACKED) T_s[k] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
+               if (HAS_Q) q_s[k] = qq[u];
+            }
+         }
       }
       __syncthreads();
       long long base = ta.tile_base[t];
@@ -647,24 +667,34 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
          double kqi = 0.0;
          if (HAS_Q) kqi = keR * qatom[a];
          int cnt_full = active ? ta.nbr_cnt[a] : 0;
-         int cnt = (cnt_full > sub) ? (cnt_full - sub + parts - 1) / parts : 0;     /* slots sub, sub+parts, ... */
+         /* this lane walks slot groups sub, sub+parts, ... (8 slots each) */
+         int ng_full = (cnt_full + 7) >> 3;
+         int ngl = (ng_full > sub) ? (ng_full - sub + parts - 1) / parts : 0;
          double fxi = 0, fyi = 0, fzi = 0;
-         const unsigned short *col = ta.nbr16 + base + al + (size_t)sub * rows;
+         const uint4 *col = (const uint4 *)(ta.nbr16 + base) + (size_t)sub * rows + al;
          const size_t cstride = (size_t)parts * rows;
-         /* wave-uniform trip count; the list is read CH slots ahead so the HBM/L2
-          * latency of the (coalesced, slot-major) list stream overlaps the pair math,
-          * and the CH distance tests of a chunk are independent (ILP at low occupancy) */
-         int wmax = cnt;
+         /* wave-uniform trip count; the list is read two groups ahead (one 16-byte load per
+          * lane and group, 1 KiB per wave) so the HBM/L2 latency of the list stream overlaps
+          * the pair math; the 8 distance tests of a group are independent (ILP) */
+         int wmax = ngl;
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+         if (ta.dbg == 3) wmax = 0;                       /* ablation: staging only */
          constexpr int CH = 8;
-         unsigned short e[CH], en[CH];
-#pragma unroll
-         for (int u = 0; u < CH; u++) e[u] = (u < wmax) ? col[(size_t)u * cstride] : (unsigned short)0;
-         for (int k0 = 0; k0 < wmax; k0 += CH)
+         const uint4 zero4 = make_uint4(0, 0, 0, 0);
+         uint4 q0 = (0 < wmax) ? col[0] : zero4;
+         uint4 q1 = (1 < wmax) ? col[cstride] : zero4;
+         for (int gi = 0; gi < wmax; gi++)
          {
-#pragma unroll
-            for (int u = 0; u < CH; u++) en[u] = (k0 + CH + u < wmax) ? col[(size_t)(k0 + CH + u) * cstride] : (unsigned short)0;
+            uint4 q2 = (gi + 2 < wmax) ? col[(size_t)(gi + 2) * cstride] : zero4;
+            int kbase = 8 * (sub + parts * gi);          /* first slot of this group */
+            unsigned short e[CH];
+            e[0] = (unsigned short)(q0.x & 0xffff); e[1] = (unsigned short)(q0.x >> 16);
+            e[2] = (unsigned short)(q0.y & 0xffff); e[3] = (unsigned short)(q0.y >> 16);
+            e[4] = (unsigned short)(q0.z & 0xffff); e[5] = (unsigned short)(q0.z >> 16);
+            e[6] = (unsigned short)(q0.w & 0xffff); e[7] = (unsigned short)(q0.w >> 16);
+            const int cnt = cnt_full - kbase;             /* valid slots: u < cnt */
+            const int k0 = 0;
             double x[CH], y[CH], z[CH], r2[CH];
             int tj[CH];
 #pragma unroll
@@ -672,12 +702,15 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
             {
                int ee = (k0 + u < cnt) ? (int)e[u] : 0;
                int sj = PACKED ? (ee & 0xfff) : ee;
+               if (ta.dbg == 2) sj = threadIdx.x;            /* ablation: conflict-free LDS gather */
                double2 pa = XY_s[sj];
                double pz = Z_s[sj];
                x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
                tj[u] = PACKED ? (ee >> 12) : sj;
                double rr = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                r2[u] = (k0 + u < cnt) ? rr : rc2;
+               if (ta.dbg == 1) { acc[7] += rr; r2[u] = rc2; }   /* ablation: distance tests only */
+               if (ta.dbg == 2) r2[u] = (k0 + u < cnt) ? 0.9 * rc2 + 1e-9 * rr : rc2;
             }
             /* pair math for slot u of the chunk */
 #define NB_PAIR(u) do { \
@@ -709,8 +742,7 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
                if (r2[u] < rc2) NB_PAIR(u);
             }
 #undef NB_PAIR
-#pragma unroll
-            for (int u = 0; u < CH; u++) e[u] = en[u];
+            q0 = q1; q1 = q2;
          }
          if (HAS_Q)
          {
@@ -930,7 +962,7 @@ __global__ void k_tilelist_to_csr(NbTileArgs ta, int pack_type, int nloc, const 
       int cnt = ta.nbr_cnt[a];
       for (int k = 0; k < cnt; k++)
       {
-         int ee = ta.nbr16[base + (size_t)k * rows + al];
+         int ee = ta.nbr16[base + ((size_t)(k >> 3) * rows + al) * 8 + (k & 7)];
          int j = sidx[pack_type ? (ee & 0xfff) : ee];
          if (j >= nloc) j = halo_src[j - nloc];
          jout[s + k] = orig[j];
@@ -1521,6 +1553,7 @@ static int launch_forces(ddcmi_ctx *ctx)
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
+      { const char *dv = getenv("DDCMI_DEBUG_MODE"); na.dbg = dv ? atoi(dv) : 0; }
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (ctx->timing)
       {
@@ -1733,7 +1766,7 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
       if (which == 0)
       {
          NbTileArgs na;
-         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
+         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj; na.dbg = 0;
          na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
          na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
          na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
