@@ -145,6 +145,14 @@ def main():
     bytes_per_atom = 36.0 + 24.0 + 4.0 * L
     t_kernel = kernel_ms * 1e-3 / max(1, launches)
     achieved = bytes_per_atom * nlocal / t_kernel / 1e9
+    # HBM bytes of the nonbonded kernel from the PMC passes committed under profiles/ (same workload only)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if world == 1 and args.n == 100:
+            traffic = tj["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "atom_steps_per_sec", "value": value, "unit": "atom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,7 +165,7 @@ def main():
                    "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo" % grid) if world > 1 else "single GPU",
                    "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
         "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches,
                      "note": "rank 0's kernel on its own beads" if world > 1 else "whole box"},
         "check": {"epot": epot, "ekin": ekin},
