@@ -34,8 +34,9 @@ static std::string g_create_err;
 /* small device helpers                                                       */
 __device__ __forceinline__ int cell_linear(const GridParams &gp, int cx, int cy, int cz)
 {
-   int tx = cx >> 2, ty = cy >> 2, tz = cz >> 2;
-   return ((((tz * gp.T[1] + ty) * gp.T[0]) + tx) << 6) | ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3);
+   int tx = cx / TCX, ty = cy / TCY, tz = cz / TCZ;
+   int lx = cx - tx * TCX, ly = cy - ty * TCY, lz = cz - tz * TCZ;
+   return (((tz * gp.T[1] + ty) * gp.T[0]) + tx) * TCELLS + (lz * TCY + ly) * TCX + lx;
 }
 __device__ __forceinline__ void cell_coords(const GridParams &gp, double x, double y, double z, bool owned, int &cx, int &cy, int &cz)
 {
@@ -280,7 +281,6 @@ struct TileArgs
 struct NbTileArgs
 {
    int ntile, stage_stride, cap, nlj;
-   int dbg;                              /* ablation switch for profiling experiments (0 in production) */
    const int *cell_start_o;
    const int *stage_idx, *tile_nstage;
    const long long *tile_base; const int *tile_width, *tile_rows;
@@ -297,12 +297,12 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
 {
    extern __shared__ double2 smem[];
    double2 *A_s = smem, *B_s = smem + ta.cap;
-   int *ofs_s = (int *)(smem + 2 * (size_t)ta.cap);      /* [513] staged offset of each region cell */
-   int *gst_s = ofs_s + 520;                               /* [512] global start of each region cell */
+   int *ofs_s = (int *)(smem + 2 * (size_t)ta.cap);      /* [NRC+1] staged offset of each region cell */
+   int *gst_s = ofs_s + NRC + 8;                           /* [NRC] global start of each region cell */
    __shared__ int s_w[4];
    __shared__ long long s_base;
    int t = blockIdx.x;
-   int ts = ta.cell_start_o[64 * t], te = ta.cell_start_o[64 * t + 64];
+   int ts = ta.cell_start_o[TCELLS * t], te = ta.cell_start_o[TCELLS * t + TCELLS];
    int nown = te - ts;
    if (nown <= 0)
    {
@@ -310,25 +310,34 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
       return;
    }
    int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
-   /* phase 0: the 512 region cells (raster order), their counts and staged offsets */
-   int v[2], g[2];
+   /* phase 0: the NRC region cells (raster order, x fastest), their counts and staged offsets */
+   constexpr int CPT = NRC / DDCMI_BLOCK;                  /* cells per thread */
+   static_assert(CPT * DDCMI_BLOCK == NRC, "region cell count must be a multiple of the block size");
+   int v[CPT], g[CPT];
+   int vsum = 0;
 #pragma unroll
-   for (int h = 0; h < 2; h++)
+   for (int h = 0; h < CPT; h++)
    {
-      int c = 2 * threadIdx.x + h;
-      int cx = 4 * tx - 2 + (c & 7), cy = 4 * ty - 2 + ((c >> 3) & 7), cz = 4 * tz - 2 + (c >> 6);
+      int c = CPT * threadIdx.x + h;
+      int cx = TCX * tx - 2 + (c % RGX), cy = TCY * ty - 2 + ((c / RGX) % RGY), cz = TCZ * tz - 2 + (c / (RGX * RGY));
       v[h] = 0; g[h] = 0;
       if (cx >= 0 && cy >= 0 && cz >= 0 && cx < gp.g[0] && cy < gp.g[1] && cz < gp.g[2])
       {
          int id = cell_linear(gp, cx, cy, cz);
          v[h] = ta.cell_cnt[id]; g[h] = ta.cell_start[id];
       }
+      vsum += v[h];
    }
    int tot;
-   int ex = block_excl_scan256(v[0] + v[1], &tot, s_w);
-   ofs_s[2 * threadIdx.x] = ex; ofs_s[2 * threadIdx.x + 1] = ex + v[0];
-   gst_s[2 * threadIdx.x] = g[0]; gst_s[2 * threadIdx.x + 1] = g[1];
-   if (threadIdx.x == 0) { ofs_s[512] = tot; ta.tile_nstage[t] = tot; }
+   int ex = block_excl_scan256(vsum, &tot, s_w);
+#pragma unroll
+   for (int h = 0; h < CPT; h++)
+   {
+      ofs_s[CPT * threadIdx.x + h] = ex;
+      gst_s[CPT * threadIdx.x + h] = g[h];
+      ex += v[h];
+   }
+   if (threadIdx.x == 0) { ofs_s[NRC] = tot; ta.tile_nstage[t] = tot; }
    if (tot > ta.cap || tot > (ta.pack_type ? 4096 : 65535))
    {
       if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
@@ -338,9 +347,9 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    /* phase 1: staging list (global indices) + positions into LDS */
    int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
 #pragma unroll
-   for (int h = 0; h < 2; h++)
+   for (int h = 0; h < CPT; h++)
    {
-      int o = ofs_s[2 * threadIdx.x + h];
+      int o = ofs_s[CPT * threadIdx.x + h];
       for (int k = 0; k < v[h]; k++)
       {
          int gj = g[h] + k;
@@ -364,8 +373,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
       double4 pi = pos[a];
       int cx, cy, cz;
       cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
-      int lx = cx - 4 * tx, ly = cy - 4 * ty, lz = cz - 4 * tz;       /* 0..3 */
-      int rc_own = (lz + 2) * 64 + (ly + 2) * 8 + (lx + 2);
+      int lx = cx - TCX * tx, ly = cy - TCY * ty, lz = cz - TCZ * tz;
+      int rc_own = (lz + 2) * (RGX * RGY) + (ly + 2) * RGX + (lx + 2);
       int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
       uint64_t gi = 0;
       int mt = 0, mns = 1;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
       for (int dz = 0; dz < 5; dz++)
          for (int dy = 0; dy < 5; dy++)
          {
-            int rc0 = (lz + dz) * 64 + (ly + dy) * 8 + lx;      /* 5 consecutive cells in x are contiguous */
+            int rc0 = (lz + dz) * (RGX * RGY) + (ly + dy) * RGX + lx;      /* 5 consecutive cells in x are contiguous */
             int s0 = ofs_s[rc0], s1 = ofs_s[rc0 + 5];
             for (int sj = s0; sj < s1; sj++)
             {
@@ -467,8 +476,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
    extern __shared__ unsigned int img32[];          /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for fill/copy */
    unsigned short *img = (unsigned short *)img32;
    int t = blockIdx.x;
-   int ts = ta.cell_start_o[64 * t];
-   int nown = ta.cell_start_o[64 * t + 64] - ts;
+   int ts = ta.cell_start_o[TCELLS * t];
+   int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
    int rows = ta.tile_rows[t];
    if (nown <= 0 || rows <= 0) return;
    int width = ta.tile_width[t];
@@ -585,8 +594,8 @@ __device__ __forceinline__ double rcp_f64(double x)
 
 /* 5 waves per tile: a tile holds 256 beads on average, so 256-thread workgroups
  * would make every second tile take a second, mostly idle pass */
-template <bool HAS_Q, bool PACKED, int NB_BLOCK, int WPE = 0>
-__global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArgs ta, int npad,
+template <bool HAS_Q, bool PACKED, int NB_BLOCK>
+__global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ qatom,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
@@ -611,8 +620,8 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
    int nown = 0, ts = 0;
    if (t < ta.ntile)
    {
-      ts = ta.cell_start_o[64 * t];
-      nown = ta.cell_start_o[64 * t + 64] - ts;
+      ts = ta.cell_start_o[TCELLS * t];
+      nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
    }
    if (nown > 0)
    {
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
       /* stage the neighbourhood: all index loads first, then all record gathers, then the
        * LDS writes -- a naive loop serialises ~9 dependent HBM/L2 round trips per thread */
       constexpr int SU = 5;
-      for (int k0 = threadIdx.x; k0 < (ta.dbg == 4 ? 0 : ns); k0 += SU * NB_BLOCK)
+      for (int k0 = threadIdx.x; k0 < ns; k0 += SU * NB_BLOCK)
       {
          int gj[SU];
          double4 pp[SU];
@@ -679,7 +688,6 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
          int wmax = ngl;
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-         if (ta.dbg == 3) wmax = 0;                       /* ablation: staging only */
          constexpr int CH = 8;
          const uint4 zero4 = make_uint4(0, 0, 0, 0);
          uint4 q0 = (0 < wmax) ? col[0] : zero4;
@@ -702,15 +710,12 @@ __global__ __launch_bounds__(NB_BLOCK, (WPE ? WPE : 1)) void k_nonbond(NbTileArg
             {
                int ee = (k0 + u < cnt) ? (int)e[u] : 0;
                int sj = PACKED ? (ee & 0xfff) : ee;
-               if (ta.dbg == 2) sj = threadIdx.x;            /* ablation: conflict-free LDS gather */
                double2 pa = XY_s[sj];
                double pz = Z_s[sj];
                x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
                tj[u] = PACKED ? (ee >> 12) : sj;
                double rr = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                r2[u] = (k0 + u < cnt) ? rr : rc2;
-               if (ta.dbg == 1) { acc[7] += rr; r2[u] = rc2; }   /* ablation: distance tests only */
-               if (ta.dbg == 2) r2[u] = (k0 + u < cnt) ? 0.9 * rc2 + 1e-9 * rr : rc2;
             }
             /* pair math for slot u of the chunk */
 #define NB_PAIR(u) do { \
@@ -949,8 +954,8 @@ __global__ void k_fill_q(int n, const double4 *pos, const double *charge_sp, dou
 __global__ void k_tilelist_to_csr(NbTileArgs ta, int pack_type, int nloc, const int *orig, const int *halo_src, const int *start, int *jout)
 {
    int t = blockIdx.x;
-   int ts = ta.cell_start_o[64 * t];
-   int nown = ta.cell_start_o[64 * t + 64] - ts;
+   int ts = ta.cell_start_o[TCELLS * t];
+   int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
    if (nown <= 0) return;
    const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
    long long base = ta.tile_base[t];
@@ -1324,10 +1329,11 @@ static int setup_grid(ddcmi_ctx *ctx)
       if (n < 1) n = 1;
       gp.n[a] = n;
       gp.cinv[a] = (double)n / W;
-      gp.m[a] = (periodic || P > 1) ? 4 : 0;      /* one whole tile of margin: interior tiles hold owned beads only */
+      const int tdim[3] = {TCX, TCY, TCZ};
+      gp.m[a] = (periodic || P > 1) ? tdim[a] : 0;      /* one whole tile of margin: interior tiles hold owned beads only */
       gp.g[a] = n + 2 * gp.m[a];
-      gp.T[a] = (gp.g[a] + 3) / 4;
-      ncell *= gp.T[a] * 4;
+      gp.T[a] = (gp.g[a] + tdim[a] - 1) / tdim[a];
+      ncell *= gp.T[a] * tdim[a];
    }
    if (ncell > 2000000000L) SETERR(ctx, DDCMI_EUNSUPPORTED, "cell grid too large");
    gp.ncell = (int)ncell;
@@ -1454,7 +1460,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    if (ctx->stage_cap == 0)
    {
       double per_cell = dens / (gp.cinv[0] * gp.cinv[1] * gp.cinv[2]);
-      ctx->stage_cap = (((int)(512.0 * per_cell * 1.05) + 48) + 63) & ~63;
+      ctx->stage_cap = (((int)((double)NRC * per_cell * 1.05) + 48) + 63) & ~63;
       if (ctx->stage_cap < 256) ctx->stage_cap = 256;
       ctx->maxexcl = 1;
       for (int m = 0; m < ctx->nmoltype; m++) if (ctx->mol_nspecies[m] > 1) ctx->maxexcl = 16;
@@ -1475,7 +1481,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    for (int attempt = 0;; attempt++)
    {
       if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
-      size_t lds = (size_t)ctx->stage_cap * 32 + (520 + 512) * sizeof(int);
+      size_t lds = (size_t)ctx->stage_cap * 32 + (2 * NRC + 16) * sizeof(int);
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
@@ -1553,7 +1559,6 @@ static int launch_forces(ddcmi_ctx *ctx)
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
-      { const char *dv = getenv("DDCMI_DEBUG_MODE"); na.dbg = dv ? atoi(dv) : 0; }
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (ctx->timing)
       {
@@ -1571,12 +1576,7 @@ static int launch_forces(ddcmi_ctx *ctx)
          hipLaunchKernelGGL((k_nonbond<Q, P, NT>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
-#define LAUNCH_NB4(Q, P) do { \
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, 256, 4>), dim3(grid), dim3(256), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
-                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
-#define LAUNCH_NB2(Q, P) do { if (ctx->nb_block == 320) LAUNCH_NB(Q, P, 320); else if (ctx->nb_block == 1256) LAUNCH_NB4(Q, P); else LAUNCH_NB(Q, P, 256); } while (0)
+#define LAUNCH_NB2(Q, P) LAUNCH_NB(Q, P, NB_THREADS)
       if (useq && packed) LAUNCH_NB2(true, true);
       else if (useq) LAUNCH_NB2(true, false);
       else if (packed) LAUNCH_NB2(false, true);
@@ -1766,7 +1766,7 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
       if (which == 0)
       {
          NbTileArgs na;
-         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj; na.dbg = 0;
+         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
          na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
          na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
          na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;

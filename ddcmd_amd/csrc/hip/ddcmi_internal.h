@@ -11,6 +11,18 @@
 
 #define DDCMI_BLOCK 256
 
+/* tile = TCX x TCY x TCZ cells (8x4x4 of >= (rmax+deltaR)/2 wide cells: ~500 beads, a
+ * 64 x 32 x 32 A slab); its neighbourhood = the tile plus two cells on every side */
+#define TCX 8
+#define TCY 4
+#define TCZ 4
+#define TCELLS (TCX * TCY * TCZ)
+#define RGX (TCX + 4)
+#define RGY (TCY + 4)
+#define RGZ (TCZ + 4)
+#define NRC (RGX * RGY * RGZ)
+#define NB_THREADS 512       /* k_nonbond workgroup: 8 waves per tile */
+
 /* cell grid over the local domain plus a margin of image/halo cells.
  * Cells are numbered tile-major (4x4x4 cells per tile) so that 256 consecutive
  * sorted atoms form a compact region instead of a long row. */
@@ -23,9 +35,9 @@ struct GridParams
    int n[3];         /* interior cells */
    int m[3];         /* margin cells per side (0 on non-periodic, undivided axes) */
    int g[3];         /* n + 2m */
-   int T[3];         /* tiles = ceil(g/4) */
+   int T[3];         /* tiles per axis */
    int pbc;
-   int ncell;        /* T0*T1*T2*64 */
+   int ncell;        /* T0*T1*T2*TCELLS */
 };
 
 template <class T> struct dbuf
