@@ -246,7 +246,8 @@ __global__ void k_merge_cells(int ncell, int nloc, const int *cnt_o, const int *
  * own cell out of LDS.  List entries are 16-bit indices into the tile's staged
  * set, stored slot-major per tile (ELL) and ordered by distance shell at build
  * time so that late slots are rejected by whole waves. */
-__device__ __forceinline__ int block_excl_scan256(int v, int *tot, int *s_w)
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 {
    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
    int inc = v;
@@ -258,13 +259,15 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *tot, int *s_w)
    }
    if (lane == 63) s_w[w] = inc;
    __syncthreads();
-   int base = 0;
-   for (int k = 0; k < w; k++) base += s_w[k];
-   *tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+   int base = 0, all = 0;
+#pragma unroll
+   for (int k = 0; k < NW; k++) { if (k < w) base += s_w[k]; all += s_w[k]; }
+   *tot = all;
    __syncthreads();
    return base + inc - v;
 }
 
+#define TB_THREADS 512      /* k_tile_build workgroup: one lane per owned bead of the tile */
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
@@ -288,7 +291,7 @@ struct NbTileArgs
    const int *nbr_cnt;
 };
 
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
+__global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ,
@@ -299,8 +302,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    double2 *A_s = smem, *B_s = smem + ta.cap;
    int *ofs_s = (int *)(smem + 2 * (size_t)ta.cap);      /* [NRC+1] staged offset of each region cell */
    int *gst_s = ofs_s + NRC + 8;                           /* [NRC] global start of each region cell */
-   __shared__ int s_w[4];
-   __shared__ long long s_base;
+   __shared__ int s_w[TB_THREADS / 64];
    int t = blockIdx.x;
    int ts = ta.cell_start_o[TCELLS * t], te = ta.cell_start_o[TCELLS * t + TCELLS];
    int nown = te - ts;
@@ -311,16 +313,17 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    }
    int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
    /* phase 0: the NRC region cells (raster order, x fastest), their counts and staged offsets */
-   constexpr int CPT = NRC / DDCMI_BLOCK;                  /* cells per thread */
-   static_assert(CPT * DDCMI_BLOCK == NRC, "region cell count must be a multiple of the block size");
+   constexpr int CPT = 3;                                  /* cells per thread: the first NRC/3 threads carry them */
+   static_assert(CPT * 256 == NRC && TB_THREADS >= 256, "region cell count / block size mismatch");
    int v[CPT], g[CPT];
    int vsum = 0;
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
       int c = CPT * threadIdx.x + h;
-      int cx = TCX * tx - 2 + (c % RGX), cy = TCY * ty - 2 + ((c / RGX) % RGY), cz = TCZ * tz - 2 + (c / (RGX * RGY));
       v[h] = 0; g[h] = 0;
+      if (c >= NRC) continue;
+      int cx = TCX * tx - 2 + (c % RGX), cy = TCY * ty - 2 + ((c / RGX) % RGY), cz = TCZ * tz - 2 + (c / (RGX * RGY));
       if (cx >= 0 && cy >= 0 && cz >= 0 && cx < gp.g[0] && cy < gp.g[1] && cz < gp.g[2])
       {
          int id = cell_linear(gp, cx, cy, cz);
@@ -329,12 +332,15 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
       vsum += v[h];
    }
    int tot;
-   int ex = block_excl_scan256(vsum, &tot, s_w);
+   int ex = block_excl_scan<TB_THREADS / 64>(vsum, &tot, s_w);
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
-      ofs_s[CPT * threadIdx.x + h] = ex;
-      gst_s[CPT * threadIdx.x + h] = g[h];
+      if (CPT * threadIdx.x + h < NRC)
+      {
+         ofs_s[CPT * threadIdx.x + h] = ex;
+         gst_s[CPT * threadIdx.x + h] = g[h];
+      }
       ex += v[h];
    }
    if (threadIdx.x == 0) { ofs_s[NRC] = tot; ta.tile_nstage[t] = tot; }
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
-      int o = ofs_s[CPT * threadIdx.x + h];
+      int o = (CPT * threadIdx.x + h < NRC) ? ofs_s[CPT * threadIdx.x + h] : 0;
       for (int k = 0; k < v[h]; k++)
       {
          int gj = g[h] + k;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
     * to the bead's own row of a row-major scratch list (sequential 2-byte appends,
     * write-combined in L2) tagged with their distance shell; k_tile_transpose then
     * lays them out slot-major in shell order. */
-   for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK)
+   for (int al = threadIdx.x; al < nown; al += TB_THREADS)
    {
       int a = ts + al;
       double4 pi = pos[a];
@@ -387,48 +393,58 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
          {
             int rc0 = (lz + dz) * (RGX * RGY) + (ly + dy) * RGX + lx;      /* 5 consecutive cells in x are contiguous */
             int s0 = ofs_s[rc0], s1 = ofs_s[rc0 + 5];
-            for (int sj = s0; sj < s1; sj++)
+            /* four candidates per trip: the LDS reads of a trip are independent (ILP at low occupancy) */
+            for (int sj0 = s0; sj0 < s1; sj0 += 4)
             {
-               if (sj == self) continue;
-               double2 pa = A_s[sj], pb = B_s[sj];
-               double x = pi.x - pa.x, y = pi.y - pa.y, z = pi.z - pb.x;
-               double r2 = x * x + y * y + z * z;
-               if (r2 < rl2)
+               double2 pa4[4], pb4[4];
+#pragma unroll
+               for (int u = 0; u < 4; u++) { int sq = min(sj0 + u, s1 - 1); pa4[u] = A_s[sq]; pb4[u] = B_s[sq]; }
+#pragma unroll
+               for (int u = 0; u < 4; u++)
                {
-                  bool pruned = false;
-                  long long wj = __double_as_longlong(pb.y);
-                  if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
+                  int sj = sj0 + u;
+                  double2 pa = pa4[u], pb = pb4[u];
+                  double x = pi.x - pa.x, y = pi.y - pa.y, z = pi.z - pb.x;
+                  double r2 = x * x + y * y + z * z;
+                  if (sj < s1 && sj != self && r2 < rl2)
                   {
-                     uint64_t gj = gid[sidx[sj]];
-                     if ((gi >> 32) == (gj >> 32))
+                     bool pruned = false;
+                     long long wj = __double_as_longlong(pb.y);
+                     if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
                      {
-                        if (mns > 1)
+                        uint64_t gj = gid[sidx[sj]];
+                        if ((gi >> 32) == (gj >> 32))
                         {
-                           unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
-                           for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
+                           if (mns > 1)
                            {
-                              unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
-                              if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
+                              unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
+                              for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
+                              {
+                                 unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
+                                 if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
+                              }
                            }
+                           else pruned = true;
                         }
-                        else pruned = true;
+                     }
+                     if (pruned)
+                     {
+                        if (ecnt < maxexcl) excl[(size_t)ecnt * npad + a] = sidx[sj];
+                        ecnt++;
+                     }
+                     else
+                     {
+                        int sh = (r2 >= sh0) + (r2 >= sh1) + (r2 >= sh2);
+                        c0 += (sh == 0); c1 += (sh == 1); c2 += (sh == 2);
+                        /* scratch: final-format entry + its shell tag in a parallel byte stream */
+                        if (cnt < ta.tmpw)
+                        {
+                           row[cnt] = (unsigned short)(ta.pack_type ? (sj | ((int)(wj & 0xf) << 12)) : sj);
+                           shrow[cnt] = (unsigned char)sh;
+                        }
+                        cnt++;
                      }
                   }
-                  if (pruned)
-                  {
-                     if (ecnt < maxexcl) excl[(size_t)ecnt * npad + a] = sidx[sj];
-                     ecnt++;
-                     continue;
-                  }
-                  int sh = (r2 >= sh0) + (r2 >= sh1) + (r2 >= sh2);
-                  c0 += (sh == 0); c1 += (sh == 1); c2 += (sh == 2);
-                  /* scratch: final-format entry + its shell tag in a parallel byte stream */
-                  if (cnt < ta.tmpw)
-                  {
-                     row[cnt] = (unsigned short)(ta.pack_type ? (sj | ((int)(wj & 0xf) << 12)) : sj);
-                     shrow[cnt] = (unsigned char)sh;
-                  }
-                  cnt++;
                }
             }
          }
@@ -447,7 +463,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    __syncthreads();
    if (threadIdx.x == 0)
    {
-      int width = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+      int width = 0;
+      for (int q = 0; q < TB_THREADS / 64; q++) width = max(width, s_w[q]);
       width = (max(min(width, ta.tmpw), 1) + 7) & ~7;      /* slots are stored in groups of 8 (one 16-byte load per lane) */
       unsigned long long need = (unsigned long long)rows * width;
       unsigned long long b0 = atomicAdd(ta.arena_used, need);
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_build(GridParams gp, TileA
    }
    /* statistics: entries of this tile */
    unsigned long long mine = 0, mex = 0;
-   for (int al = threadIdx.x; al < nown; al += DDCMI_BLOCK) { mine += ta.nbr_cnt[ts + al]; mex += excl_cnt[ts + al]; }
+   for (int al = threadIdx.x; al < nown; al += TB_THREADS) { mine += ta.nbr_cnt[ts + al]; mex += excl_cnt[ts + al]; }
    for (int off = 32; off > 0; off >>= 1) { mine += __shfl_down(mine, off, 64); mex += __shfl_down(mex, off, 64); }
    if ((threadIdx.x & 63) == 0) { atomicAdd(&totals[0], mine); atomicAdd(&totals[1], mex); }
 }
@@ -1500,7 +1517,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->tmp8.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp16 = ctx->tmp16.p; ta.tmp8 = ctx->tmp8.p; ta.tmpw = ctx->tmpw;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(DDCMI_BLOCK), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
+      hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,
                          sh0, sh1, sh2, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       {
