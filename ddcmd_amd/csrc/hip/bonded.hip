@@ -292,6 +292,9 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
       if ((rc = up(ctx, ctx->tors_ijkl, tors_ijkl, 4 * (size_t)ntors)) || (rc = up(ctx, ctx->tors_func, tors_func, ntors)) || (rc = up(ctx, ctx->tors_n, tors_n, ntors)) ||
           (rc = up(ctx, ctx->tors_k, tors_k, ntors)) || (rc = up(ctx, ctx->tors_delta, tors_delta, ntors))) return rc;
    }
+   /* the per-kind sums are only written by kernels that run: clear stale ones */
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    ctx->forces_valid = false;
    return DDCMI_OK;
 }

@@ -828,19 +828,28 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_reduce_stageA(const double *par
       __syncthreads();
    }
 }
-__global__ __launch_bounds__(64) void k_reduce_stageB(const double *tmp, int nv, double *out)
+__device__ void finish_energy(double *r, double self_ele);
+/* stage B; with finish != 0 the same launch also forms the final energies/virial
+ * (one launch less per step) */
+__global__ __launch_bounds__(64) void k_reduce_stageB(const double *tmp, int nv, double *out, double *results, double self_ele, int finish)
 {
    int k = threadIdx.x >> 3, l = threadIdx.x & 7;     /* 8 values x 8 lanes */
-   if (k >= nv) return;
-   double a = 0.0;
-   for (int b = l; b < RED_BLOCKS; b += 8) a += tmp[b * 8 + k];
-   a += __shfl_down(a, 4, 8); a += __shfl_down(a, 2, 8); a += __shfl_down(a, 1, 8);
-   if (l == 0) out[k] = a;
+   if (k < nv)
+   {
+      double a = 0.0;
+      for (int b = l; b < RED_BLOCKS; b += 8) a += tmp[b * 8 + k];
+      a += __shfl_down(a, 4, 8); a += __shfl_down(a, 2, 8); a += __shfl_down(a, 1, 8);
+      if (l == 0) out[k] = a;
+   }
+   if (finish)
+   {
+      __syncthreads();          /* one wave: orders the out[] stores before thread 0 reads them */
+      if (threadIdx.x == 0) finish_energy(results, self_ele);
+   }
 }
 /* final energies / virial: full list counts every pair twice */
-__global__ void k_finish_energy(double *r, double self_ele)
+__device__ void finish_energy(double *r, double self_ele)
 {
-   if (threadIdx.x != 0 || blockIdx.x != 0) return;
    double lj = 0.5 * r[R_NB_LJ];
    double ele = 0.5 * r[R_NB_ELE] + self_ele;
    r[R_E + DDCMI_E_LJ] = lj;
@@ -852,6 +861,11 @@ __global__ void k_finish_energy(double *r, double self_ele)
    r[R_E + DDCMI_E_TOTAL] = etot;
    for (int k = 0; k < 6; k++)
       r[R_VIR + k] = 0.5 * r[R_NB_VIR + k] + ((r[R_SCR_BOND + 1 + k] + r[R_SCR_ANGLE + 1 + k]) + r[R_SCR_TORS + 2 + k]);
+}
+
+__global__ void k_finish_energy(double *r, double self_ele)
+{
+   if (threadIdx.x == 0 && blockIdx.x == 0) finish_energy(r, self_ele);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1562,7 +1576,8 @@ static int launch_forces(ddcmi_ctx *ctx)
    if (nh > 0)
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
-   HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, R_RK * sizeof(double), st));
+   const bool has_bonded = (ctx->nbond + ctx->nangle + ctx->ntors) > 0;
+   const double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
       int ntile = ctx->ntile;
@@ -1602,14 +1617,18 @@ static int launch_forces(ddcmi_ctx *ctx)
 #undef LAUNCH_NB
       if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
       hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);
-      hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ);
+      /* without bonded terms the final energies are formed in the same launch */
+      hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ, ctx->d_results, self, has_bonded ? 0 : 1);
    }
    else
+   {
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, 8 * sizeof(double), st));
       hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
+   }
    int rc = ddcmi_launch_bonded(ctx);
    if (rc) return rc;
-   double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
-   hipLaunchKernelGGL(k_finish_energy, dim3(1), dim3(64), 0, st, ctx->d_results, self);
+   if (has_bonded || (ctx->excludePotentialTerm & 128) != 0)
+      hipLaunchKernelGGL(k_finish_energy, dim3(1), dim3(64), 0, st, ctx->d_results, self);
    ctx->forces_valid = true;
    return DDCMI_OK;
 }
@@ -1643,7 +1662,7 @@ static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick)
    hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
                       ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->partials.p, do_kick);
    hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->red_tmp.p + RED_BLOCKS * 8);
-   hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK);
+   hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK, ctx->d_results, 0.0, 0);
    return DDCMI_OK;
 }
 
