@@ -847,6 +847,27 @@ __global__ __launch_bounds__(64) void k_reduce_stageB(const double *tmp, int nv,
       if (threadIdx.x == 0) finish_energy(results, self_ele);
    }
 }
+/* one-launch variant for moderate partial counts: a single 1024-thread workgroup sums
+ * everything in a fixed order and (optionally) forms the final energies */
+__global__ __launch_bounds__(1024) void k_reduce_single(const double *partials, int nblocks, int stride, int nv, double *out, double *results, double self_ele, int finish)
+{
+   __shared__ double s[1024];
+   for (int k = 0; k < nv; k++)
+   {
+      double a = 0.0;
+      for (int b = threadIdx.x; b < nblocks; b += 1024) a += partials[(size_t)b * stride + k];
+      s[threadIdx.x] = a;
+      __syncthreads();
+      for (int off = 512; off > 0; off >>= 1)
+      {
+         if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+         __syncthreads();
+      }
+      if (threadIdx.x == 0) out[k] = s[0];
+      __syncthreads();
+   }
+   if (finish && threadIdx.x == 0) finish_energy(results, self_ele);
+}
 /* final energies / virial: full list counts every pair twice */
 __device__ void finish_energy(double *r, double self_ele)
 {
@@ -1616,9 +1637,14 @@ static int launch_forces(ddcmi_ctx *ctx)
 #undef LAUNCH_NB2
 #undef LAUNCH_NB
       if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
-      hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);
       /* without bonded terms the final energies are formed in the same launch */
-      hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ, ctx->d_results, self, has_bonded ? 0 : 1);
+      if (ntile <= 4096)
+         hipLaunchKernelGGL(k_reduce_single, dim3(1), dim3(1024), 0, st, ctx->partials.p, ntile, 8, 8, ctx->d_results + R_NB_LJ, ctx->d_results, self, has_bonded ? 0 : 1);
+      else
+      {
+         hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);
+         hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ, ctx->d_results, self, has_bonded ? 0 : 1);
+      }
    }
    else
    {
@@ -1661,8 +1687,13 @@ static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick)
    ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
    hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
                       ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->partials.p, do_kick);
-   hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->red_tmp.p + RED_BLOCKS * 8);
-   hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK, ctx->d_results, 0.0, 0);
+   if (nblk <= 4096)
+      hipLaunchKernelGGL(k_reduce_single, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->d_results + R_RK, ctx->d_results, 0.0, 0);
+   else
+   {
+      hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->red_tmp.p + RED_BLOCKS * 8);
+      hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK, ctx->d_results, 0.0, 0);
+   }
    return DDCMI_OK;
 }
 
