@@ -52,6 +52,26 @@ __device__ __forceinline__ void cell_coords(const GridParams &gp, double x, doub
    }
    cx = c[0]; cy = c[1]; cz = c[2];
 }
+/* cell of an image/halo bead.  Computed from the position, then forced onto the correct
+ * side per axis (side[a]: +1 = beyond the hi face, -1 = below the lo face, 0 = inside the
+ * interior range): a bead sitting exactly on a face must never land in an interior cell,
+ * where the owned beads' ranges live. */
+__device__ __forceinline__ int halo_cell(const GridParams &gp, double x, double y, double z, const int side[3])
+{
+   double r[3] = {x, y, z};
+   int c[3];
+#pragma unroll
+   for (int a = 0; a < 3; a++)
+   {
+      int ic = (int)floor((r[a] - gp.lo[a]) * gp.cinv[a]);
+      if (side[a] > 0) ic = max(ic, gp.n[a]);
+      else if (side[a] < 0) ic = min(ic, -1);
+      else ic = min(max(ic, 0), gp.n[a] - 1);
+      ic += gp.m[a];
+      c[a] = min(max(ic, 0), gp.g[a] - 1);
+   }
+   return cell_linear(gp, c[0], c[1], c[2]);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -174,9 +194,8 @@ __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const
             if (!(sx | sy | sz)) continue;
             int ix = sx * d[0], iy = sy * d[1], iz = sz * d[2];
             double x = p.x + ix * gp.L[0], y = p.y + iy * gp.L[1], z = p.z + iz * gp.L[2];
-            int cx, cy, cz;
-            cell_coords(gp, x, y, z, false, cx, cy, cz);
-            int c = cell_linear(gp, cx, cy, cz);
+            int side[3] = {ix, iy, iz};
+            int c = halo_cell(gp, x, y, z, side);
             hsrc[k] = i;
             hshift[k] = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
             hcid[k] = c;

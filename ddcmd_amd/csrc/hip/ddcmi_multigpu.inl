@@ -192,12 +192,13 @@ __global__ void k_pack_halo(int nsend, OffTab so, DirTab dt, int hs_cap, const i
 }
 /* halo descriptors: first the local images (directions that wrap onto this rank),
  * then the beads received from other ranks */
-__global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab selfo, DirTab dt, int hs_cap, const int *hs_idx,
+__global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab selfo, OffTab recvo, DirTab dt, int hs_cap, const int *hs_idx,
                                 const double4 *pos, const double *hrecv5, int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h)
 {
    int h = blockIdx.x * blockDim.x + threadIdx.x;
    if (h >= nself + nrecv) return;
    double x, y, z;
+   int side[3];
    if (h < nself)
    {
       int code = 0;
@@ -207,6 +208,8 @@ __global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab self
       x = p.x + dt.shift[code][0] * gp.L[0]; y = p.y + dt.shift[code][1] * gp.L[1]; z = p.z + dt.shift[code][2] * gp.L[2];
       hsrc[h] = i;
       hshift[h] = (dt.shift[code][0] + 1) + 3 * (dt.shift[code][1] + 1) + 9 * (dt.shift[code][2] + 1);
+      /* an image sent in direction d appears on the opposite side of this (same) domain */
+      side[0] = -(code % 3 - 1); side[1] = -((code / 3) % 3 - 1); side[2] = -(code / 9 - 1);
    }
    else
    {
@@ -214,10 +217,12 @@ __global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab self
       x = hrecv5[5 * k]; y = hrecv5[5 * k + 1]; z = hrecv5[5 * k + 2];
       hsrc[h] = -1 - k;
       hshift[h] = 13;
+      /* received along the SENDER's direction `code`: it lies on my opposite side */
+      int code = 0;
+      while (k >= recvo.off[code + 1]) code++;
+      side[0] = -(code % 3 - 1); side[1] = -((code / 3) % 3 - 1); side[2] = -(code / 9 - 1);
    }
-   int cx, cy, cz;
-   cell_coords(gp, x, y, z, false, cx, cy, cz);
-   int c = cell_linear(gp, cx, cy, cz);
+   int c = halo_cell(gp, x, y, z, side);
    hcid[h] = c;
    hrank[h] = atomicAdd(&cell_cnt_h[c], 1);
 }
@@ -456,7 +461,9 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
    if (nh > 0)
    {
       if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
-      hipLaunchKernelGGL(k_halo_assemble, dim3(cdiv(nh, 256)), dim3(256), 0, st, ctx->gp, nself, ctx->nrecv, selfo, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+      OffTab recvo;
+      for (int code = 0; code < 28; code++) recvo.off[code] = ctx->recv_off[code];
+      hipLaunchKernelGGL(k_halo_assemble, dim3(cdiv(nh, 256)), dim3(256), 0, st, ctx->gp, nself, ctx->nrecv, selfo, recvo, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
                          ctx->pos.p, ctx->hrecv5.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
       if (ctx->nrecv > 0) hipLaunchKernelGGL(k_rec5to3, dim3(cdiv(ctx->nrecv, 256)), dim3(256), 0, st, ctx->nrecv, ctx->hrecv5.p, ctx->hrecv3.p);
    }

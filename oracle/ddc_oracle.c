@@ -135,7 +135,9 @@ orc_nbr *orc_nbr_build(const orc_params *p, int n, const double *rx, const doubl
       for (int a = 0; a < 3; a++)
       {
          double s = r[a] / L[a] + 0.5;       /* reduced coordinate, box centred on origin */
-         s -= floor(s);
+         if ((p->pbc >> a) & 1) s -= floor(s);
+         else { if (s < 0.0) s = 0.0; if (s >= 1.0) s = 0.999999999999; }   /* open axis: beads outside sit in the edge cell;
+                                                                              * only exact while they stay within one cell width of the box */
          ic[a] = (int)(s * nc[a]);
          if (ic[a] >= nc[a]) ic[a] = nc[a] - 1;
          if (ic[a] < 0) ic[a] = 0;
