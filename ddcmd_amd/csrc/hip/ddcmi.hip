@@ -290,7 +290,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
-   int pack_type;                       /* entries carry the LJ type in bits 15:12 (nlj <= 16, cap <= 4096) */
+   int pack_type;                       /* entries are (staged slot << 4) | LJ type (nlj <= 16, cap < 4096); else the bare slot */
    const int *cell_start_o;             /* owned beads per cell: exclusive scan, [ncell+1] */
    const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges */
    int *stage_idx, *tile_nstage;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       ex += v[h];
    }
    if (threadIdx.x == 0) { ofs_s[NRC] = tot; ta.tile_nstage[t] = tot; }
-   if (tot > ta.cap || tot > (ta.pack_type ? 4096 : 65535))
+   if (tot > ta.cap || tot > (ta.pack_type ? 4095 : 65534))     /* staged slot 0 is the sentinel */
    {
       if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
       return;      /* LDS capacity too small: the host retries with a larger cap */
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                         /* scratch: final-format entry + its shell tag in a parallel byte stream */
                         if (cnt < ta.tmpw)
                         {
-                           row[cnt] = (unsigned short)(ta.pack_type ? (sj | ((int)(wj & 0xf) << 12)) : sj);
+                           row[cnt] = (unsigned short)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1);
                            shrow[cnt] = (unsigned char)sh;
                         }
                         cnt++;
@@ -682,12 +682,20 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
             int k = k0 + u * NB_BLOCK;
             if (k < ns)
             {
-               XY_s[k] = make_double2(pp[u].x, pp[u].y);
-               Z_s[k] = pp[u].z;
-               if (!PACKED) T_s[k] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
-               if (HAS_Q) q_s[k] = qq[u];
+               XY_s[k + 1] = make_double2(pp[u].x, pp[u].y);
+               Z_s[k + 1] = pp[u].z;
+               if (!PACKED) T_s[k + 1] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
+               if (HAS_Q) q_s[k + 1] = qq[u];
             }
          }
+      }
+      if (threadIdx.x == 0)
+      {
+         /* staged slot 0: a bead far outside every cutoff.  List padding (entry 0) points
+          * at it, so the walk needs no per-slot validity masks. */
+         XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = 1e30;
+         if (!PACKED) T_s[0] = 0;
+         if (HAS_Q) q_s[0] = 0.0;
       }
       __syncthreads();
       long long base = ta.tile_base[t];
@@ -726,36 +734,41 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
          constexpr int CH = 8;
          const uint4 zero4 = make_uint4(0, 0, 0, 0);
-         uint4 q0 = (0 < wmax) ? col[0] : zero4;
-         uint4 q1 = (1 < wmax) ? col[cstride] : zero4;
+         const char *xy_b = (const char *)XY_s, *z_b = (const char *)Z_s, *q_b = (const char *)q_s;
+         /* lanes past their own last group (sub-lane split) must not read the next tile's slice */
+         uint4 q0 = (0 < ngl) ? col[0] : zero4;
+         uint4 q1 = (1 < ngl) ? col[cstride] : zero4;
          for (int gi = 0; gi < wmax; gi++)
          {
-            uint4 q2 = (gi + 2 < wmax) ? col[(size_t)(gi + 2) * cstride] : zero4;
-            int kbase = 8 * (sub + parts * gi);          /* first slot of this group */
-            unsigned short e[CH];
-            e[0] = (unsigned short)(q0.x & 0xffff); e[1] = (unsigned short)(q0.x >> 16);
-            e[2] = (unsigned short)(q0.y & 0xffff); e[3] = (unsigned short)(q0.y >> 16);
-            e[4] = (unsigned short)(q0.z & 0xffff); e[5] = (unsigned short)(q0.z >> 16);
-            e[6] = (unsigned short)(q0.w & 0xffff); e[7] = (unsigned short)(q0.w >> 16);
-            const int cnt = cnt_full - kbase;             /* valid slots: u < cnt */
-            const int k0 = 0;
+            uint4 q2 = (gi + 2 < ngl) ? col[(size_t)(gi + 2) * cstride] : zero4;
+            /* byte offsets of the 8 neighbours in XY_s (16 B per staged bead) */
+            int o[CH];
+            if (PACKED)
+            {
+               o[0] = (int)(q0.x & 0xfff0u); o[1] = (int)((q0.x >> 16) & 0xfff0u);
+               o[2] = (int)(q0.y & 0xfff0u); o[3] = (int)((q0.y >> 16) & 0xfff0u);
+               o[4] = (int)(q0.z & 0xfff0u); o[5] = (int)((q0.z >> 16) & 0xfff0u);
+               o[6] = (int)(q0.w & 0xfff0u); o[7] = (int)((q0.w >> 16) & 0xfff0u);
+            }
+            else
+            {
+               o[0] = (int)((q0.x & 0xffffu) << 4); o[1] = (int)((q0.x >> 16) << 4);
+               o[2] = (int)((q0.y & 0xffffu) << 4); o[3] = (int)((q0.y >> 16) << 4);
+               o[4] = (int)((q0.z & 0xffffu) << 4); o[5] = (int)((q0.z >> 16) << 4);
+               o[6] = (int)((q0.w & 0xffffu) << 4); o[7] = (int)((q0.w >> 16) << 4);
+            }
             double x[CH], y[CH], z[CH], r2[CH];
-            int tj[CH];
 #pragma unroll
             for (int u = 0; u < CH; u++)
             {
-               int ee = (k0 + u < cnt) ? (int)e[u] : 0;
-               int sj = PACKED ? (ee & 0xfff) : ee;
-               double2 pa = XY_s[sj];
-               double pz = Z_s[sj];
+               double2 pa = *(const double2 *)(xy_b + o[u]);
+               double pz = *(const double *)(z_b + (o[u] >> 1));
                x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
-               tj[u] = PACKED ? (ee >> 12) : sj;
-               double rr = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
-               r2[u] = (k0 + u < cnt) ? rr : rc2;
+               r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
             }
-            /* pair math for slot u of the chunk */
-#define NB_PAIR(u) do { \
-                  int tjj = PACKED ? tj[u] : (int)T_s[tj[u]]; \
+            /* pair math for slot u of the group; w = the dword holding its entry, hi = upper half */
+#define NB_PAIR(u, WD_, HI_) do { \
+                  int tjj = PACKED ? (int)(((WD_) >> ((HI_) ? 16 : 0)) & 0xfu) : (int)T_s[o[u] >> 4]; \
                   double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
                   double ir = 0.0, ir2; \
                   if (HAS_Q) { ir = rsqrt_f64(r2[u]); ir2 = ir * ir; } \
@@ -768,8 +781,7 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
                   double dvdr = lj.w * (s6 - 2.0 * s12) * ir2; \
                   if (HAS_Q) \
                   { \
-                     int sjq = PACKED ? ((int)e[u] & 0xfff) : (int)e[u]; \
-                     double kqij = kqi * q_s[sjq]; \
+                     double kqij = kqi * *(const double *)(q_b + (o[u] >> 1)); \
                      acc[1] += kqij * (ir + krf * r2[u] - crf); \
                      dvdr += kqij * (2.0 * krf - ir2 * ir); \
                   } \
@@ -777,11 +789,14 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
                   fxi += fxij; fyi += fyij; fzi += fzij; \
                   acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u]; \
                   acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u]; } while (0)
-#pragma unroll
-            for (int u = 0; u < CH; u++)
-            {
-               if (r2[u] < rc2) NB_PAIR(u);
-            }
+            if (r2[0] < rc2) NB_PAIR(0, q0.x, 0);
+            if (r2[1] < rc2) NB_PAIR(1, q0.x, 1);
+            if (r2[2] < rc2) NB_PAIR(2, q0.y, 0);
+            if (r2[3] < rc2) NB_PAIR(3, q0.y, 1);
+            if (r2[4] < rc2) NB_PAIR(4, q0.z, 0);
+            if (r2[5] < rc2) NB_PAIR(5, q0.z, 1);
+            if (r2[6] < rc2) NB_PAIR(6, q0.w, 0);
+            if (r2[7] < rc2) NB_PAIR(7, q0.w, 1);
 #undef NB_PAIR
             q0 = q1; q1 = q2;
          }
@@ -1039,7 +1054,7 @@ __global__ void k_tilelist_to_csr(NbTileArgs ta, int pack_type, int nloc, const 
       for (int k = 0; k < cnt; k++)
       {
          int ee = ta.nbr16[base + ((size_t)(k >> 3) * rows + al) * 8 + (k & 7)];
-         int j = sidx[pack_type ? (ee & 0xfff) : ee];
+         int j = sidx[(pack_type ? (ee >> 4) : ee) - 1];
          if (j >= nloc) j = halo_src[j - nloc];
          jout[s + k] = orig[j];
       }
@@ -1559,7 +1574,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
-      ctx->pack_type = (ctx->nlj <= 16 && ctx->stage_cap <= 4096);
+      ctx->pack_type = (ctx->nlj <= 16 && ctx->stage_cap < 4096);
       TileArgs ta;
       ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type ? 1 : 0;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
@@ -1624,10 +1639,11 @@ static int launch_forces(ddcmi_ctx *ctx)
       int grid = ((ntile + 7) / 8) * 8;
       bool useq = ctx->has_charge;
       bool packed = ctx->pack_type;
-      size_t lds = (size_t)ctx->stage_cap * 24 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? (size_t)ctx->stage_cap * 8 : 0) + (packed ? 0 : (size_t)ctx->stage_cap);
+      const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
+      size_t lds = capl * 24 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? capl * 8 : 0) + (packed ? 0 : capl);
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
-      na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
+      na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nlj;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
