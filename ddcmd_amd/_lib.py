@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libddcmi.so")
+# DDCMI_LIB: kernel-tuning builds of the same library (tools/build_variants.sh)
+LIB_PATH = os.environ.get("DDCMI_LIB") or os.path.join(_HERE, "lib", "libddcmi.so")
 
 
 class LibraryMissing(RuntimeError):

@@ -287,6 +287,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 }
 
 #define TB_THREADS 512      /* k_tile_build workgroup: one lane per owned bead of the tile */
+#define NSHELL 8
+struct ShellCuts { double r2[NSHELL - 1]; };
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
@@ -294,9 +296,9 @@ struct TileArgs
    const int *cell_start_o;             /* owned beads per cell: exclusive scan, [ncell+1] */
    const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges */
    int *stage_idx, *tile_nstage;
-   long long *tile_base; int *tile_width, *tile_rows;
+   long long *tile_base; int *tile_width, *tile_rows, *tile_work;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
-   int *nbr_cnt, *shellpk;
+   int *nbr_cnt;
    unsigned short *tmp16; unsigned char *tmp8; int tmpw;     /* row-major scratch list + shell tags, tmpw entries per bead */
 };
 
@@ -308,13 +310,15 @@ struct NbTileArgs
    const long long *tile_base; const int *tile_width, *tile_rows;
    const unsigned short *nbr16;
    const int *nbr_cnt;
+   const int *sched;                    /* [9] tile range of each XCD (k_tile_schedule) */
+   int rot;                             /* tuning builds: rotate the range -> XCD assignment */
 };
 
 __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ,
-                                                            double sh0, double sh1, double sh2,
+                                                            ShellCuts shc,
                                                             int maxexcl, int *excl, int *excl_cnt, int *flags, unsigned long long *totals)
 {
    extern __shared__ double2 smem[];
@@ -327,13 +331,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    int nown = te - ts;
    if (nown <= 0)
    {
-      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
+      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 1; }
       return;
    }
    int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
    /* phase 0: the NRC region cells (raster order, x fastest), their counts and staged offsets */
-   constexpr int CPT = 3;                                  /* cells per thread: the first NRC/3 threads carry them */
-   static_assert(CPT * 256 == NRC && TB_THREADS >= 256, "region cell count / block size mismatch");
+   constexpr int CPT = (NRC + 255) / 256;                  /* cells per thread: the first NRC/CPT threads carry them */
+   static_assert(CPT * TB_THREADS >= NRC && TB_THREADS >= 256, "region cell count / block size mismatch");
    int v[CPT], g[CPT];
    int vsum = 0;
 #pragma unroll
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    if (threadIdx.x == 0) { ofs_s[NRC] = tot; ta.tile_nstage[t] = tot; }
    if (tot > ta.cap || tot > (ta.pack_type ? 4095 : 65534))     /* staged slot 0 is the sentinel */
    {
-      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; }
+      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 1; }
       return;      /* LDS capacity too small: the host retries with a larger cap */
    }
    __syncthreads();
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       uint64_t gi = 0;
       int mt = 0, mns = 1;
       if (nmoltype > 0) { gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt]; }
-      int c0 = 0, c1 = 0, c2 = 0, cnt = 0, ecnt = 0;
+      int cnt = 0, ecnt = 0;
       unsigned short *row = ta.tmp16 + (size_t)a * ta.tmpw;
       unsigned char *shrow = ta.tmp8 + (size_t)a * ta.tmpw;
       for (int dz = 0; dz < 5; dz++)
@@ -453,8 +457,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      }
                      else
                      {
-                        int sh = (r2 >= sh0) + (r2 >= sh1) + (r2 >= sh2);
-                        c0 += (sh == 0); c1 += (sh == 1); c2 += (sh == 2);
+                        int sh = 0;
+#pragma unroll
+                        for (int q = 0; q < NSHELL - 1; q++) sh += (r2 >= shc.r2[q]);
                         /* scratch: final-format entry + its shell tag in a parallel byte stream */
                         if (cnt < ta.tmpw)
                         {
@@ -469,7 +474,6 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          }
       mymax = max(mymax, cnt);
       ta.nbr_cnt[a] = min(cnt, ta.tmpw);
-      ta.shellpk[a] = min(c0, 1023) | (min(c1, 1023) << 10) | (min(c2, 1023) << 20);
       excl_cnt[a] = min(ecnt, maxexcl);
       if (ecnt > maxexcl) atomicMax(&flags[1], ecnt);
       if (cnt > ta.tmpw) atomicMax(&flags[5], cnt);
@@ -499,6 +503,70 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    for (int al = threadIdx.x; al < nown; al += TB_THREADS) { mine += ta.nbr_cnt[ts + al]; mex += excl_cnt[ts + al]; }
    for (int off = 32; off > 0; off >>= 1) { mine += __shfl_down(mine, off, 64); mex += __shfl_down(mex, off, 64); }
    if ((threadIdx.x & 63) == 0) { atomicAdd(&totals[0], mine); atomicAdd(&totals[1], mex); }
+   /* cost estimate of this tile in k_nonbond (list slots + staging), for k_tile_schedule */
+   __syncthreads();
+   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (int)mine;
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      /* residency of the tile's workgroup in k_nonbond: (passes x list groups per lane),
+       * scaled so that a full tile counts its list entries, + staging */
+      constexpr int NWAVES = NB_THREADS / 64;
+      int R = 64;
+      while (R > 1 && (R >> 1) * NWAVES >= nown) R >>= 1;
+      int npass = ((nown + R - 1) / R + NWAVES - 1) / NWAVES;
+      int ngrp = (ta.tile_width[t] + 7) >> 3, parts = 64 / R;
+      ta.tile_work[t] = npass * ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES + (5 * tot) / 2 + 1;
+   }
+}
+
+/* Split the tiles (raster order) into 8 contiguous ranges of equal estimated work,
+ * one per XCD: the hardware deals workgroups round-robin over the XCDs, so k_nonbond
+ * maps workgroup b to the (b>>3)-th tile of range b&7.  Equal COUNTS would leave the
+ * XCDs that own the thin edge tiles idle at the end of the launch.  sched[0..8] =
+ * range starts, flags[6] = longest range. */
+#define SCHED_THREADS 1024
+__global__ __launch_bounds__(SCHED_THREADS) void k_tile_schedule(int ntile, const int *__restrict__ work, int *__restrict__ sched, int *flags)
+{
+   __shared__ unsigned long long s_sum[SCHED_THREADS];
+   __shared__ int s_start[9];
+   int seg = (ntile + SCHED_THREADS - 1) / SCHED_THREADS;
+   int t0 = min(ntile, (int)threadIdx.x * seg), t1 = min(ntile, t0 + seg);
+   unsigned long long mine = 0;
+   for (int t = t0; t < t1; t++) mine += (unsigned long long)work[t];
+   s_sum[threadIdx.x] = mine;
+   if (threadIdx.x < 9) s_start[threadIdx.x] = (threadIdx.x == 8) ? ntile : 0;
+   __syncthreads();
+   /* exclusive prefix of the segment sums: Hillis-Steele over the shared array */
+   for (int off = 1; off < SCHED_THREADS; off <<= 1)
+   {
+      unsigned long long v = (threadIdx.x >= (unsigned)off) ? s_sum[threadIdx.x - off] : 0ull;
+      __syncthreads();
+      s_sum[threadIdx.x] += v;
+      __syncthreads();
+   }
+   unsigned long long W = s_sum[SCHED_THREADS - 1];
+   unsigned long long run = s_sum[threadIdx.x] - mine;          /* work before tile t0 */
+   for (int t = t0; t < t1; t++)
+   {
+      unsigned long long nxt = run + (unsigned long long)work[t];
+      /* range x starts at the first tile whose preceding work reaches x*W/8 */
+      for (int x = 1; x < 8; x++)
+      {
+         unsigned long long target = (W * (unsigned long long)x) >> 3;
+         if (run < target && nxt >= target) s_start[x] = t + 1;
+      }
+      run = nxt;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      int longest = 0;
+      for (int x = 1; x < 9; x++) s_start[x] = max(s_start[x], s_start[x - 1]);     /* ranges may be empty, never reversed */
+      for (int x = 0; x < 9; x++) sched[x] = s_start[x];
+      for (int x = 0; x < 8; x++) longest = max(longest, s_start[x + 1] - s_start[x]);
+      flags[6] = longest;
+   }
 }
 
 /* second half of the build: row-major scratch -> the tile's slot-major ELL slice
@@ -527,20 +595,20 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
       __syncthreads();
       /* wave w owns rows [32w, 32w+32) of this chunk; their counts are fetched with one load */
       int r_lane = c0 + 32 * w + (lane & 31);
-      int my_cnt = 0, my_pk = 0;
-      if (r_lane < nown) { my_cnt = ta.nbr_cnt[ts + r_lane]; my_pk = ta.shellpk[ts + r_lane]; }
+      int my_cnt = 0;
+      if (r_lane < nown) my_cnt = ta.nbr_cnt[ts + r_lane];
       int e_nx[3], s_nx[3];
       {
          int a0 = ts + min(c0 + 32 * w, nown - 1);
          const unsigned short *row = ta.tmp16 + (size_t)a0 * ta.tmpw;
          const unsigned char *shrow = ta.tmp8 + (size_t)a0 * ta.tmpw;
 #pragma unroll
-         for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : 4; }
+         for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : NSHELL; }
       }
       for (int rr = 0; rr < 32; rr++)
       {
          int r = 32 * w + rr;                      /* row inside the chunk */
-         int cnt = __shfl(my_cnt, rr, 64), pk = __shfl(my_pk, rr, 64);
+         int cnt = __shfl(my_cnt, rr, 64);
          int e_cu[3], s_cu[3];
 #pragma unroll
          for (int q = 0; q < 3; q++) { e_cu[q] = e_nx[q]; s_cu[q] = s_nx[q]; }
@@ -550,19 +618,41 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
             const unsigned short *row = ta.tmp16 + (size_t)a1 * ta.tmpw;
             const unsigned char *shrow = ta.tmp8 + (size_t)a1 * ta.tmpw;
 #pragma unroll
-            for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : 4; }
+            for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : NSHELL; }
          }
          if (c0 + r >= nown) continue;
-         int o0 = 0, o1 = pk & 1023, o2 = o1 + ((pk >> 10) & 1023), o3 = o2 + ((pk >> 20) & 1023);
+         /* shell populations of this row (wave-uniform), then exclusive offsets */
+         int o[NSHELL];
+#pragma unroll
+         for (int s = 0; s < NSHELL; s++) o[s] = 0;
+#define TR_COUNT(SH, Q) do { \
+            int sh_ = (64 * (Q) + lane < cnt) ? (SH) : NSHELL; \
+            _Pragma("unroll") for (int s = 0; s < NSHELL; s++) o[s] += __popcll(__ballot(sh_ == s)); } while (0)
+         if (cnt > 0) TR_COUNT(s_cu[0], 0);
+         if (cnt > 64) TR_COUNT(s_cu[1], 1);
+         if (cnt > 128) TR_COUNT(s_cu[2], 2);
+         for (int q = 3; q < npass && 64 * q < cnt; q++)
+         {
+            int a = ts + c0 + r, k = 64 * q + lane;
+            int sh = (k < cnt) ? (int)ta.tmp8[(size_t)a * ta.tmpw + k] : NSHELL;
+            TR_COUNT(sh, q);
+         }
+#undef TR_COUNT
+         {
+            int run = 0;
+#pragma unroll
+            for (int s = 0; s < NSHELL; s++) { int c = o[s]; o[s] = run; run += c; }
+         }
 #define TR_PASS(E, SH, Q) do { \
             int k_ = 64 * (Q) + lane; \
             bool valid_ = k_ < cnt; \
-            int sh_ = valid_ ? (SH) : 4; \
-            unsigned long long b0 = __ballot(sh_ == 0), b1 = __ballot(sh_ == 1), b2 = __ballot(sh_ == 2), b3 = __ballot(sh_ == 3); \
-            int slot_ = (sh_ == 0) ? o0 + __popcll(b0 & ltmask) : (sh_ == 1) ? o1 + __popcll(b1 & ltmask) \
-                      : (sh_ == 2) ? o2 + __popcll(b2 & ltmask) : o3 + __popcll(b3 & ltmask); \
-            if (valid_) img[slot_ * IMG_STRIDE + r] = (unsigned short)(E); \
-            o0 += __popcll(b0); o1 += __popcll(b1); o2 += __popcll(b2); o3 += __popcll(b3); } while (0)
+            int sh_ = valid_ ? (SH) : NSHELL; \
+            int slot_ = 0; \
+            _Pragma("unroll") for (int s = 0; s < NSHELL; s++) { \
+               unsigned long long b_ = __ballot(sh_ == s); \
+               if (sh_ == s) slot_ = o[s] + __popcll(b_ & ltmask); \
+               o[s] += __popcll(b_); } \
+            if (valid_) img[slot_ * IMG_STRIDE + r] = (unsigned short)(E); } while (0)
          if (cnt > 0) TR_PASS(e_cu[0], s_cu[0], 0);
          if (cnt > 64) TR_PASS(e_cu[1], s_cu[1], 1);
          if (cnt > 128) TR_PASS(e_cu[2], s_cu[2], 2);
@@ -570,7 +660,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
          {
             int a = ts + c0 + r, k = 64 * q + lane;
             int e = (k < cnt) ? (int)ta.tmp16[(size_t)a * ta.tmpw + k] : 0;
-            int sh = (k < cnt) ? (int)ta.tmp8[(size_t)a * ta.tmpw + k] : 4;
+            int sh = (k < cnt) ? (int)ta.tmp8[(size_t)a * ta.tmpw + k] : NSHELL;
             TR_PASS(e, sh, q);
          }
 #undef TR_PASS
@@ -630,8 +720,19 @@ __device__ __forceinline__ double rcp_f64(double x)
 
 /* 5 waves per tile: a tile holds 256 beads on average, so 256-thread workgroups
  * would make every second tile take a second, mostly idle pass */
-template <bool HAS_Q, bool PACKED, int NB_BLOCK>
-__global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad,
+#ifdef DDCMI_TRACE_BLOCKS
+/* tuning builds only (tools/build_variants.sh): per-workgroup timeline of k_nonbond */
+__device__ unsigned long long g_trace[8 * 65536];
+#define TRACE_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
+{
+   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#else
+#define TRACE_MARK(slot) do { } while (0)
+#endif
+template <bool HAS_Q, bool PACKED, int NB_BLOCK, int WPE, int CH>
+__global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ qatom,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
@@ -648,13 +749,29 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
    double *q_s = (double *)(s_lj + ta.nlj * ta.nlj);
    unsigned char *T_s = (unsigned char *)(q_s + (HAS_Q ? ta.cap : 0));
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
-    * give XCD x the contiguous tile range [x*per, (x+1)*per): neighbouring tiles
-    * (which stage overlapping neighbourhoods) then share one L2. Speed only. */
-   int per = (ta.ntile + 7) >> 3;
-   int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    * give XCD x one contiguous tile range (k_tile_schedule: equal work per XCD):
+    * neighbouring tiles, which stage overlapping neighbourhoods, then share one L2.
+    * Speed only. */
+   TRACE_MARK(0);
+#ifdef DDCMI_TRACE_BLOCKS
+   if (threadIdx.x == 0 && blockIdx.x < 65536)
+   {
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      g_trace[8 * blockIdx.x + 4] = xcc; g_trace[8 * blockIdx.x + 5] = hw;
+   }
+#endif
+#ifdef DDCMI_TRACE_BLOCKS
+   const int xcd = (blockIdx.x + ta.rot) & 7;
+#else
+   const int xcd = blockIdx.x & 7;
+#endif
+   const int t = ta.sched[xcd] + (int)(blockIdx.x >> 3);
+   const bool mine = t < ta.sched[xcd + 1];
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* vLJ, vEle, xx,yy,zz,xy,xz,yz */
    int nown = 0, ts = 0;
-   if (t < ta.ntile)
+   if (mine)
    {
       ts = ta.cell_start_o[TCELLS * t];
       nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
@@ -698,22 +815,29 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
          if (HAS_Q) q_s[0] = 0.0;
       }
       __syncthreads();
+      TRACE_MARK(1);
       long long base = ta.tile_base[t];
       int rows = ta.tile_rows[t];
       const int nlj = ta.nlj;
-      /* one wave per 64-row chunk.  A partial last chunk (k < 64 beads) gives every
-       * bead `parts` lanes that split its list, so a tile with 257..260 beads does
-       * not pay a whole extra pass for four beads. */
+      /* one wave per chunk of R rows, R = the smallest power of two that spreads the
+       * tile over all waves (64 for a full tile).  With R < 64 -- thin edge tiles, or the
+       * partial last chunk -- every bead gets `parts` lanes that split its list, so a
+       * tile of 120 beads is done in a quarter of a full tile's time instead of
+       * keeping the LDS of the CU busy with two working waves. */
       const int lane = threadIdx.x & 63;
-      for (int chunk = threadIdx.x >> 6; chunk * 64 < rows; chunk += NB_BLOCK / 64)
+      constexpr int NWAVES = NB_BLOCK / 64;
+      int R = 64;
+      while (R > 1 && (R >> 1) * NWAVES >= nown) R >>= 1;
+      const int nchunks = (nown + R - 1) / R;
+      for (int chunk = threadIdx.x >> 6; chunk < nchunks; chunk += NWAVES)
       {
-         int kb = min(64, nown - chunk * 64);
-         int parts = 1;
+         int kb = min(R, nown - chunk * R);
+         int parts = 64 / R;
          while (parts * 2 * kb <= 64) parts *= 2;
          int sub = lane & (parts - 1);
          int ain = lane / parts;
          bool active = ain < kb;
-         int al = chunk * 64 + (active ? ain : 0);
+         int al = chunk * R + (active ? ain : 0);
          int a = ts + al;
          double4 pi = pos[a];
          int ti = (int)(__double_as_longlong(pi.w) & 0xffffll);
@@ -732,7 +856,6 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
          int wmax = ngl;
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-         constexpr int CH = 8;
          const uint4 zero4 = make_uint4(0, 0, 0, 0);
          const char *xy_b = (const char *)XY_s, *z_b = (const char *)Z_s, *q_b = (const char *)q_s;
          /* lanes past their own last group (sub-lane split) must not read the next tile's slice */
@@ -741,32 +864,8 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
          for (int gi = 0; gi < wmax; gi++)
          {
             uint4 q2 = (gi + 2 < ngl) ? col[(size_t)(gi + 2) * cstride] : zero4;
-            /* byte offsets of the 8 neighbours in XY_s (16 B per staged bead) */
-            int o[CH];
-            if (PACKED)
-            {
-               o[0] = (int)(q0.x & 0xfff0u); o[1] = (int)((q0.x >> 16) & 0xfff0u);
-               o[2] = (int)(q0.y & 0xfff0u); o[3] = (int)((q0.y >> 16) & 0xfff0u);
-               o[4] = (int)(q0.z & 0xfff0u); o[5] = (int)((q0.z >> 16) & 0xfff0u);
-               o[6] = (int)(q0.w & 0xfff0u); o[7] = (int)((q0.w >> 16) & 0xfff0u);
-            }
-            else
-            {
-               o[0] = (int)((q0.x & 0xffffu) << 4); o[1] = (int)((q0.x >> 16) << 4);
-               o[2] = (int)((q0.y & 0xffffu) << 4); o[3] = (int)((q0.y >> 16) << 4);
-               o[4] = (int)((q0.z & 0xffffu) << 4); o[5] = (int)((q0.z >> 16) << 4);
-               o[6] = (int)((q0.w & 0xffffu) << 4); o[7] = (int)((q0.w >> 16) << 4);
-            }
-            double x[CH], y[CH], z[CH], r2[CH];
-#pragma unroll
-            for (int u = 0; u < CH; u++)
-            {
-               double2 pa = *(const double2 *)(xy_b + o[u]);
-               double pz = *(const double *)(z_b + (o[u] >> 1));
-               x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
-               r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
-            }
-            /* pair math for slot u of the group; w = the dword holding its entry, hi = upper half */
+            const unsigned qw[4] = {q0.x, q0.y, q0.z, q0.w};
+            /* pair math for slot u of the part; WD_ = the dword holding its entry, HI_ = upper half */
 #define NB_PAIR(u, WD_, HI_) do { \
                   int tjj = PACKED ? (int)(((WD_) >> ((HI_) ? 16 : 0)) & 0xfu) : (int)T_s[o[u] >> 4]; \
                   double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
@@ -789,14 +888,28 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
                   fxi += fxij; fyi += fyij; fzi += fzij; \
                   acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u]; \
                   acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u]; } while (0)
-            if (r2[0] < rc2) NB_PAIR(0, q0.x, 0);
-            if (r2[1] < rc2) NB_PAIR(1, q0.x, 1);
-            if (r2[2] < rc2) NB_PAIR(2, q0.y, 0);
-            if (r2[3] < rc2) NB_PAIR(3, q0.y, 1);
-            if (r2[4] < rc2) NB_PAIR(4, q0.z, 0);
-            if (r2[5] < rc2) NB_PAIR(5, q0.z, 1);
-            if (r2[6] < rc2) NB_PAIR(6, q0.w, 0);
-            if (r2[7] < rc2) NB_PAIR(7, q0.w, 1);
+            /* the group is walked in 8 / CH parts; the CH gathers and tests of a part are independent (ILP) */
+#pragma unroll
+            for (int h = 0; h < 8 / CH; h++)
+            {
+               /* byte offsets of the part's neighbours in XY_s (16 B per staged bead) */
+               int o[CH];
+               double x[CH], y[CH], z[CH], r2[CH];
+#pragma unroll
+               for (int u = 0; u < CH; u++)
+               {
+                  unsigned wd = qw[(h * CH + u) >> 1];
+                  if (PACKED) o[u] = (int)(((u & 1) ? (wd >> 16) : wd) & 0xfff0u);
+                  else o[u] = (int)(((u & 1) ? (wd >> 16) : (wd & 0xffffu)) << 4);
+                  double2 pa = *(const double2 *)(xy_b + o[u]);
+                  double pz = *(const double *)(z_b + (o[u] >> 1));
+                  x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
+                  r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
+               }
+#pragma unroll
+               for (int u = 0; u < CH; u++)
+                  if (r2[u] < rc2) NB_PAIR(u, qw[(h * CH + u) >> 1], u & 1);
+            }
 #undef NB_PAIR
             q0 = q1; q1 = q2;
          }
@@ -830,7 +943,12 @@ __global__ __launch_bounds__(NB_BLOCK, 4) void k_nonbond(NbTileArgs ta, int npad
          if (active && sub == 0) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; }
       }
    }
-   if (t < ta.ntile) block_reduce_store<8, NB_BLOCK / 64>(acc, partials + (size_t)t * 8);
+#ifdef DDCMI_TRACE_BLOCKS
+   __syncthreads();
+   TRACE_MARK(2);
+   if (threadIdx.x == 0 && blockIdx.x < 65536) { g_trace[8 * blockIdx.x + 6] = (unsigned long long)t; g_trace[8 * blockIdx.x + 7] = (unsigned long long)nown; }
+#endif
+   if (mine) block_reduce_store<8, NB_BLOCK / 64>(acc, partials + (size_t)t * 8);
 }
 
 /* zero forces (nonbonded excluded via excludePotentialTerm) */
@@ -1138,8 +1256,8 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    dbuf<int> *ib[] = {&ctx->d_ljtype_sp, &ctx->d_moltype_sp, &ctx->d_mol_nspecies, &ctx->d_bpair_off, &ctx->d_bpairI, &ctx->d_bpairJ, &ctx->species, &ctx->species2,
                       &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->cell_cnt_o, &ctx->cell_start_o,
                       &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt, &ctx->nimg, &ctx->img_off, &ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank,
-                      &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt, &ctx->shellpk,
-                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows,
+                      &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt,
+                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched,
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
@@ -1558,11 +1676,18 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if ((size_t)ctx->tmpw * IMG_STRIDE * 2 > 150 * 1024) ctx->tmpw = (150 * 1024 / (IMG_STRIDE * 2)) & ~7;
       ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
    }
-   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad); ENSURE(ctx, ctx->shellpk, ctx->npad);
+   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
    ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
+   ENSURE(ctx, ctx->tile_work, ntile + 1); ENSURE(ctx, ctx->sched, 16);
    if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
    double rcut = ctx->rmax, dR = ctx->deltaR;
-   double sh0 = (rcut - 0.25 * dR) * (rcut - 0.25 * dR), sh1 = (rcut + 0.125 * dR) * (rcut + 0.125 * dR), sh2 = (rcut + 0.5 * dR) * (rcut + 0.5 * dR);
+   /* distance shells of the list order: fine around the cutoff, where a wave's lanes
+    * disagree about acceptance during the list's lifetime */
+   ShellCuts shc;
+   {
+      const double f[NSHELL - 1] = {-0.375, -0.1875, 0.0, 0.1875, 0.375, 0.5625, 0.78};
+      for (int q = 0; q < NSHELL - 1; q++) { double r = rcut + f[q] * dR; shc.r2[q] = r * r; }
+   }
    unsigned long long *d_tot = (unsigned long long *)(ctx->d_results + R_FLAGS);    /* [0]=entries [1]=excluded [2]=arena used */
    for (int attempt = 0;; attempt++)
    {
@@ -1579,21 +1704,22 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type ? 1 : 0;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
       ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
-      ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p;
+      ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
       ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_tot + 2;
-      ta.nbr_cnt = ctx->nbr_cnt.p; ta.shellpk = ctx->shellpk.p;
+      ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp16.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       if (ctx->tmp8.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp16 = ctx->tmp16.p; ta.tmp8 = ctx->tmp8.p; ta.tmpw = ctx->tmpw;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,
-                         sh0, sh1, sh2, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+                         shc, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       {
          size_t lds2 = (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
          hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(DDCMI_BLOCK), lds2, st, ta);
       }
+      hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(SCHED_THREADS), 0, st, ntile, ctx->tile_work.p, ctx->sched.p, ctx->d_flags);
       HIPCHK(ctx, hipGetLastError());
       unsigned long long tot[3];
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1608,6 +1734,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       {
          ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
          ctx->maxnbr = ctx->h_flags[2];
+         ctx->sched_longest = ctx->h_flags[6];
          break;
       }
    }
@@ -1636,7 +1763,7 @@ static int launch_forces(ddcmi_ctx *ctx)
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
       int ntile = ctx->ntile;
-      int grid = ((ntile + 7) / 8) * 8;
+      int grid = 8 * std::max(ctx->sched_longest, 1);
       bool useq = ctx->has_charge;
       bool packed = ctx->pack_type;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
@@ -1646,7 +1773,8 @@ static int launch_forces(ddcmi_ctx *ctx)
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nlj;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
-      na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
+      na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.sched = ctx->sched.p;
+      { const char *rv = getenv("DDCMI_XCD_ROT"); na.rot = rv ? atoi(rv) : 0; }
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (ctx->timing)
       {
@@ -1660,8 +1788,8 @@ static int launch_forces(ddcmi_ctx *ctx)
          HIPCHK(ctx, hipEventRecord(e0, st));
       }
 #define LAUNCH_NB(Q, P, NT) do { \
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, NT>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
 #define LAUNCH_NB2(Q, P) LAUNCH_NB(Q, P, NB_THREADS)

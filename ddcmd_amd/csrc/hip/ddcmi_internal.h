@@ -13,15 +13,29 @@
 
 /* tile = TCX x TCY x TCZ cells (8x4x4 of >= (rmax+deltaR)/2 wide cells: ~500 beads, a
  * 64 x 32 x 32 A slab); its neighbourhood = the tile plus two cells on every side */
+#ifndef TCX
 #define TCX 8
+#endif
+#ifndef TCY
 #define TCY 4
+#endif
+#ifndef TCZ
 #define TCZ 4
+#endif
 #define TCELLS (TCX * TCY * TCZ)
 #define RGX (TCX + 4)
 #define RGY (TCY + 4)
 #define RGZ (TCZ + 4)
 #define NRC (RGX * RGY * RGZ)
+#ifndef NB_THREADS
 #define NB_THREADS 512       /* k_nonbond workgroup: 8 waves per tile */
+#endif
+#ifndef NB_WPE
+#define NB_WPE 4             /* waves per SIMD the register budget is sized for (2 workgroups per CU) */
+#endif
+#ifndef NB_CH
+#define NB_CH 4              /* list slots gathered and tested together */
+#endif
 
 /* cell grid over the local domain plus a margin of image/halo cells.
  * Cells are numbered tile-major (4x4x4 cells per tile) so that 256 consecutive
@@ -106,7 +120,9 @@ struct ddcmi_ctx
    dbuf<int> scan_tmp;
    /* lists */
    int maxnbr = 0, maxexcl = 0;
-   dbuf<int> nbr_cnt, excl, excl_cnt, shellpk;
+   dbuf<int> nbr_cnt, excl, excl_cnt;
+   dbuf<int> tile_work, sched;         /* per-tile cost estimate; [9] tile range per XCD */
+   int sched_longest = 0;
    /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
    int ntile = 0, stage_cap = 0; bool pack_type = false;
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
