@@ -697,7 +697,7 @@ __device__ __forceinline__ double rsqrt_f64(double x)
    /* v_rsq_f32 seed (23 bits) + two Newton steps y += y*(1/2 - (x/2) y^2): 3 FP64 ops
     * each, < 2 ulp; checked against the closed form in tests */
    float xf = (float)x;
-   double y = (double)__frsqrt_rn(xf);
+   double y = (double)__builtin_amdgcn_rsqf(xf);      /* the bare instruction: __frsqrt_rn expands to a correctly rounded sequence */
    double h = 0.5 * x;
    double e = fma(-(h * y), y, 0.5);
    y = fma(y, e, y);
@@ -710,7 +710,7 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 __device__ __forceinline__ double rcp_f64(double x)
 {
    float xf = (float)x;
-   double y = (double)__frcp_rn(xf);
+   double y = (double)__builtin_amdgcn_rcpf(xf);      /* the bare instruction: __frcp_rn expands to a 10-instruction IEEE division */
    double e = fma(-x, y, 1.0);
    y = fma(y, e, y);
    e = fma(-x, y, 1.0);
@@ -743,11 +743,20 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    /* LDS: staged neighbourhood as {x,y} pairs + z (24 B per bead), LJ table, and --
     * only when needed -- per-bead LJ types (nlj > 16) and charges */
    extern __shared__ double2 smem[];
-   double2 *XY_s = smem;
-   double *Z_s = (double *)(smem + ta.cap);
-   double4 *s_lj = (double4 *)(Z_s + ta.cap);
+   double *Z_s = (double *)smem;                 /* staged positions: z [cap], then {x,y} [cap] -- 24 B per bead */
+   double2 *XY_s = (double2 *)(Z_s + ta.cap);
+   double4 *s_lj = (double4 *)(XY_s + ta.cap);
    double *q_s = (double *)(s_lj + ta.nlj * ta.nlj);
    unsigned char *T_s = (unsigned char *)(q_s + (HAS_Q ? ta.cap : 0));
+   /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
+    * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
+    * starts at LDS address 0 and the z gather needs no base add.  Checked here, not assumed. */
+   typedef __attribute__((address_space(3))) const double lds_cdouble;
+   typedef double xy_t __attribute__((ext_vector_type(2)));
+   typedef __attribute__((address_space(3))) const xy_t lds_cxy;
+   const unsigned xy_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)XY_s;
+   if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)smem != 0u) __builtin_trap();
+   const unsigned q_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)q_s;
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
     * give XCD x one contiguous tile range (k_tile_schedule: equal work per XCD):
     * neighbouring tiles, which stage overlapping neighbourhoods, then share one L2.
@@ -783,7 +792,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
       const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
       /* stage the neighbourhood: all index loads first, then all record gathers, then the
        * LDS writes -- a naive loop serialises ~9 dependent HBM/L2 round trips per thread */
-      constexpr int SU = 5;
+      constexpr int SU = NB_SU;
       for (int k0 = threadIdx.x; k0 < ns; k0 += SU * NB_BLOCK)
       {
          int gj[SU];
@@ -856,14 +865,22 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          int wmax = ngl;
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-         const uint4 zero4 = make_uint4(0, 0, 0, 0);
-         const char *xy_b = (const char *)XY_s, *z_b = (const char *)Z_s, *q_b = (const char *)q_s;
-         /* lanes past their own last group (sub-lane split) must not read the next tile's slice */
-         uint4 q0 = (0 < ngl) ? col[0] : zero4;
-         uint4 q1 = (1 < ngl) ? col[cstride] : zero4;
-         for (int gi = 0; gi < wmax; gi++)
+         /* The list stream: one 16-byte load per lane and group, kept two groups ahead of
+          * the pair loop.  Three named buffers (the loop is unrolled by three) rather
+          * than a rotating one, so each wait covers exactly the oldest load; the loads
+          * are unconditional global loads from a clamped group index and masked
+          * afterwards -- a conditional load here becomes a select of two addresses in
+          * different address spaces, i.e. a flat load that the LDS gathers then wait on. */
+         const int glast = max(ngl - 1, 0);
+         auto load_group = [&](int g) -> uint4
          {
-            uint4 q2 = (gi + 2 < ngl) ? col[(size_t)(gi + 2) * cstride] : zero4;
+            uint4 v = col[(size_t)min(g, glast) * cstride];
+            /* lanes past their own last group (sub-lane split, short rows) get padding */
+            if (g >= ngl) v = make_uint4(0, 0, 0, 0);
+            return v;
+         };
+         auto do_group = [&](const uint4 &q0)
+         {
             const unsigned qw[4] = {q0.x, q0.y, q0.z, q0.w};
             /* pair math for slot u of the part; WD_ = the dword holding its entry, HI_ = upper half */
 #define NB_PAIR(u, WD_, HI_) do { \
@@ -880,7 +897,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                   double dvdr = lj.w * (s6 - 2.0 * s12) * ir2; \
                   if (HAS_Q) \
                   { \
-                     double kqij = kqi * *(const double *)(q_b + (o[u] >> 1)); \
+                     double kqij = kqi * *(lds_cdouble *)(__UINTPTR_TYPE__)(q_off + (o[u] >> 1)); \
                      acc[1] += kqij * (ir + krf * r2[u] - crf); \
                      dvdr += kqij * (2.0 * krf - ir2 * ir); \
                   } \
@@ -892,18 +909,19 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
 #pragma unroll
             for (int h = 0; h < 8 / CH; h++)
             {
-               /* byte offsets of the part's neighbours in XY_s (16 B per staged bead) */
-               int o[CH];
+               /* 16 x staged slot of the part's neighbours */
+               unsigned o[CH];
                double x[CH], y[CH], z[CH], r2[CH];
 #pragma unroll
                for (int u = 0; u < CH; u++)
                {
                   unsigned wd = qw[(h * CH + u) >> 1];
-                  if (PACKED) o[u] = (int)(((u & 1) ? (wd >> 16) : wd) & 0xfff0u);
-                  else o[u] = (int)(((u & 1) ? (wd >> 16) : (wd & 0xffffu)) << 4);
-                  double2 pa = *(const double2 *)(xy_b + o[u]);
-                  double pz = *(const double *)(z_b + (o[u] >> 1));
-                  x[u] = pi.x - pa.x; y[u] = pi.y - pa.y; z[u] = pi.z - pz;
+                  if (PACKED) o[u] = ((u & 1) ? (wd >> 16) : wd) & 0xfff0u;
+                  else o[u] = ((u & 1) ? (wd >> 16) : (wd & 0xffffu)) << 4;
+                  xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + o[u]);
+                  double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(o[u] >> 1);
+                  double px = pxy.x, py = pxy.y;
+                  x[u] = pi.x - px; y[u] = pi.y - py; z[u] = pi.z - pz;
                   r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                }
 #pragma unroll
@@ -911,8 +929,17 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                   if (r2[u] < rc2) NB_PAIR(u, qw[(h * CH + u) >> 1], u & 1);
             }
 #undef NB_PAIR
-            q0 = q1; q1 = q2;
+         };
+         uint4 qa = load_group(0), qb = load_group(1), qc;
+         int gi = 0;
+         for (; gi + 3 <= wmax; gi += 3)
+         {
+            qc = load_group(gi + 2); do_group(qa);
+            qa = load_group(gi + 3); do_group(qb);
+            qb = load_group(gi + 4); do_group(qc);
          }
+         if (gi < wmax) do_group(qa);
+         if (gi + 1 < wmax) do_group(qb);
          if (HAS_Q)
          {
             /* excluded (same-molecule bonded) pairs: reaction-field correction only
@@ -948,7 +975,28 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    TRACE_MARK(2);
    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_trace[8 * blockIdx.x + 6] = (unsigned long long)t; g_trace[8 * blockIdx.x + 7] = (unsigned long long)nown; }
 #endif
-   if (mine) block_reduce_store<8, NB_BLOCK / 64>(acc, partials + (size_t)t * 8);
+   if (mine)
+   {
+      /* the tile's LDS doubles as reduction scratch: no static LDS in this kernel, so the
+       * staged arrays start at LDS address 0 and need no base add per gather */
+      __syncthreads();
+      double *s_red = (double *)smem;
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+      {
+         double sv = wave_sum(acc[k]);
+         if (lane == 0) s_red[w * 8 + k] = sv;
+      }
+      __syncthreads();
+      if (threadIdx.x < 8)
+      {
+         double a = s_red[threadIdx.x];
+#pragma unroll
+         for (int q = 1; q < NB_BLOCK / 64; q++) a += s_red[q * 8 + threadIdx.x];
+         partials[(size_t)t * 8 + threadIdx.x] = a;
+      }
+   }
 }
 
 /* zero forces (nonbonded excluded via excludePotentialTerm) */
