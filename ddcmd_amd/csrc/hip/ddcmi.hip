@@ -857,8 +857,9 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          int ng_full = (cnt_full + 7) >> 3;
          int ngl = (ng_full > sub) ? (ng_full - sub + parts - 1) / parts : 0;
          double fxi = 0, fyi = 0, fzi = 0;
-         const uint4 *col = (const uint4 *)(ta.nbr16 + base) + (size_t)sub * rows + al;
-         const size_t cstride = (size_t)parts * rows;
+         /* 32-bit indexing inside the tile's slice (uniform 64-bit base + lane offset) */
+         const uint4 *slice = (const uint4 *)(ta.nbr16 + base);
+         const unsigned col = (unsigned)(sub * rows + al), cstride = (unsigned)(parts * rows);
          /* wave-uniform trip count; the list is read two groups ahead (one 16-byte load per
           * lane and group, 1 KiB per wave) so the HBM/L2 latency of the list stream overlaps
           * the pair math; the 8 distance tests of a group are independent (ILP) */
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          const int glast = max(ngl - 1, 0);
          auto load_group = [&](int g) -> uint4
          {
-            uint4 v = col[(size_t)min(g, glast) * cstride];
+            uint4 v = slice[col + (unsigned)min(g, glast) * cstride];
             /* lanes past their own last group (sub-lane split, short rows) get padding */
             if (g >= ngl) v = make_uint4(0, 0, 0, 0);
             return v;
