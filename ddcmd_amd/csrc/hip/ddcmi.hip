@@ -287,8 +287,12 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 }
 
 #define TB_THREADS 512      /* k_tile_build workgroup: one lane per owned bead of the tile */
-#define NSHELL 8
-struct ShellCuts { double r2[NSHELL - 1]; };
+#ifndef NSHELL
+#define NSHELL 4            /* distance shells of the list order; the transpose costs ~0.25 ms per shell at 4M beads */
+#endif
+/* shell 0 = r < r0, shells 1.. = equal widths up to the list radius: boundaries only
+ * steer the ORDER of a bead's entries, so single precision is plenty */
+struct ShellCuts { float r0, inv_w; };
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
@@ -299,7 +303,7 @@ struct TileArgs
    long long *tile_base; int *tile_width, *tile_rows, *tile_work;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt;
-   unsigned short *tmp16; unsigned char *tmp8; int tmpw;     /* row-major scratch list + shell tags, tmpw entries per bead */
+   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead: entry | shell << 16 */
 };
 
 struct NbTileArgs
@@ -409,8 +413,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       int mt = 0, mns = 1;
       if (nmoltype > 0) { gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt]; }
       int cnt = 0, ecnt = 0;
-      unsigned short *row = ta.tmp16 + (size_t)a * ta.tmpw;
-      unsigned char *shrow = ta.tmp8 + (size_t)a * ta.tmpw;
+      /* scratch row: two words per 8-byte store (tmpw is even) */
+      uint2 *row2 = (uint2 *)(ta.tmp32 + (size_t)a * ta.tmpw);
+      unsigned wprev = 0;
       for (int dz = 0; dz < 5; dz++)
          for (int dy = 0; dy < 5; dy++)
          {
@@ -457,21 +462,20 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      }
                      else
                      {
-                        int sh = 0;
-#pragma unroll
-                        for (int q = 0; q < NSHELL - 1; q++) sh += (r2 >= shc.r2[q]);
-                        /* scratch: final-format entry + its shell tag in a parallel byte stream */
-                        if (cnt < ta.tmpw)
-                        {
-                           row[cnt] = (unsigned short)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1);
-                           shrow[cnt] = (unsigned char)sh;
-                        }
+                        /* scratch word: final-format entry + its shell tag.  This path runs for
+                         * every candidate of the wave (some lane always accepts), so it is kept short. */
+                        float rf = __builtin_amdgcn_sqrtf((float)r2);
+                        int sh = min(max((int)floorf((rf - shc.r0) * shc.inv_w) + 1, 0), NSHELL - 1);
+                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | ((unsigned)sh << 16);
+                        if (cnt & 1) { if (cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, wcur); }
+                        else wprev = wcur;
                         cnt++;
                      }
                   }
                }
             }
          }
+      if ((cnt & 1) && cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, 0u);
       mymax = max(mymax, cnt);
       ta.nbr_cnt[a] = min(cnt, ta.tmpw);
       excl_cnt[a] = min(ecnt, maxexcl);
@@ -600,10 +604,9 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
       int e_nx[3], s_nx[3];
       {
          int a0 = ts + min(c0 + 32 * w, nown - 1);
-         const unsigned short *row = ta.tmp16 + (size_t)a0 * ta.tmpw;
-         const unsigned char *shrow = ta.tmp8 + (size_t)a0 * ta.tmpw;
+         const unsigned *row = ta.tmp32 + (size_t)a0 * ta.tmpw;
 #pragma unroll
-         for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : NSHELL; }
+         for (int q = 0; q < 3; q++) { int k = 64 * q + lane; unsigned wv = (k < ta.tmpw) ? row[k] : (unsigned)NSHELL << 16; e_nx[q] = (int)(wv & 0xffffu); s_nx[q] = (int)(wv >> 16); }
       }
       for (int rr = 0; rr < 32; rr++)
       {
@@ -615,10 +618,9 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
          if (rr + 1 < 32)
          {
             int a1 = ts + min(c0 + r + 1, nown - 1);
-            const unsigned short *row = ta.tmp16 + (size_t)a1 * ta.tmpw;
-            const unsigned char *shrow = ta.tmp8 + (size_t)a1 * ta.tmpw;
+            const unsigned *row = ta.tmp32 + (size_t)a1 * ta.tmpw;
 #pragma unroll
-            for (int q = 0; q < 3; q++) { int k = 64 * q + lane; bool ok = k < ta.tmpw; e_nx[q] = ok ? (int)row[k] : 0; s_nx[q] = ok ? (int)shrow[k] : NSHELL; }
+            for (int q = 0; q < 3; q++) { int k = 64 * q + lane; unsigned wv = (k < ta.tmpw) ? row[k] : (unsigned)NSHELL << 16; e_nx[q] = (int)(wv & 0xffffu); s_nx[q] = (int)(wv >> 16); }
          }
          if (c0 + r >= nown) continue;
          /* shell populations of this row (wave-uniform), then exclusive offsets */
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
          for (int q = 3; q < npass && 64 * q < cnt; q++)
          {
             int a = ts + c0 + r, k = 64 * q + lane;
-            int sh = (k < cnt) ? (int)ta.tmp8[(size_t)a * ta.tmpw + k] : NSHELL;
+            int sh = (k < cnt) ? (int)(ta.tmp32[(size_t)a * ta.tmpw + k] >> 16) : NSHELL;
             TR_COUNT(sh, q);
          }
 #undef TR_COUNT
@@ -659,9 +661,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
          for (int q = 3; q < npass && 64 * q < cnt; q++)
          {
             int a = ts + c0 + r, k = 64 * q + lane;
-            int e = (k < cnt) ? (int)ta.tmp16[(size_t)a * ta.tmpw + k] : 0;
-            int sh = (k < cnt) ? (int)ta.tmp8[(size_t)a * ta.tmpw + k] : NSHELL;
-            TR_PASS(e, sh, q);
+            unsigned wv = (k < cnt) ? ta.tmp32[(size_t)a * ta.tmpw + k] : (unsigned)NSHELL << 16;
+            TR_PASS((int)(wv & 0xffffu), (int)(wv >> 16), q);
          }
 #undef TR_PASS
       }
@@ -1310,7 +1311,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
-   ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release(); ctx->tmp16.release(); ctx->tmp8.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -1730,13 +1731,10 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    ENSURE(ctx, ctx->tile_work, ntile + 1); ENSURE(ctx, ctx->sched, 16);
    if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
    double rcut = ctx->rmax, dR = ctx->deltaR;
-   /* distance shells of the list order: fine around the cutoff, where a wave's lanes
-    * disagree about acceptance during the list's lifetime */
+   /* distance shells of the list order: entries a wave rejects as a whole come last */
    ShellCuts shc;
-   {
-      const double f[NSHELL - 1] = {-0.375, -0.1875, 0.0, 0.1875, 0.375, 0.5625, 0.78};
-      for (int q = 0; q < NSHELL - 1; q++) { double r = rcut + f[q] * dR; shc.r2[q] = r * r; }
-   }
+   shc.r0 = (float)(rcut - 0.25 * dR);
+   shc.inv_w = (float)((NSHELL - 1) / (rcut + dR - (rcut - 0.25 * dR)));
    unsigned long long *d_tot = (unsigned long long *)(ctx->d_results + R_FLAGS);    /* [0]=entries [1]=excluded [2]=arena used */
    for (int attempt = 0;; attempt++)
    {
@@ -1756,9 +1754,8 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
       ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_tot + 2;
       ta.nbr_cnt = ctx->nbr_cnt.p;
-      if (ctx->tmp16.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
-      if (ctx->tmp8.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
-      ta.tmp16 = ctx->tmp16.p; ta.tmp8 = ctx->tmp8.p; ta.tmpw = ctx->tmpw;
+      if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
+      ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,

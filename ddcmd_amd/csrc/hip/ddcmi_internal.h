@@ -130,7 +130,7 @@ struct ddcmi_ctx
    int ntile = 0, stage_cap = 0; bool pack_type = false;
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
    dbuf<long long> tile_base;
-   dbuf<unsigned short> nbr16, tmp16; dbuf<unsigned char> tmp8; int tmpw = 0;
+   dbuf<unsigned short> nbr16; dbuf<unsigned int> tmp32; int tmpw = 0;
    unsigned long long arena_cap = 0;
    dbuf<double> red_tmp;
    bool list_valid = false;
