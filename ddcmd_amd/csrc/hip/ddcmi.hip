@@ -303,7 +303,7 @@ struct TileArgs
    long long *tile_base; int *tile_width, *tile_rows, *tile_work;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt;
-   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead: entry | shell << 16 */
+   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead: entry | bf16(r^2) << 16 */
 };
 
 struct NbTileArgs
@@ -322,7 +322,6 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ,
-                                                            ShellCuts shc,
                                                             int maxexcl, int *excl, int *excl_cnt, int *flags, unsigned long long *totals)
 {
    extern __shared__ double2 smem[];
@@ -462,11 +461,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      }
                      else
                      {
-                        /* scratch word: final-format entry + its shell tag.  This path runs for
+                        /* scratch word: final-format entry + r^2 as a 16-bit float (enough to pick the
+                         * distance shell in k_tile_transpose).  This path runs for
                          * every candidate of the wave (some lane always accepts), so it is kept short. */
-                        float rf = __builtin_amdgcn_sqrtf((float)r2);
-                        int sh = min(max((int)floorf((rf - shc.r0) * shc.inv_w) + 1, 0), NSHELL - 1);
-                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | ((unsigned)sh << 16);
+                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | (__float_as_uint((float)r2) & 0xffff0000u);
                         if (cnt & 1) { if (cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, wcur); }
                         else wprev = wcur;
                         cnt++;
@@ -574,15 +572,24 @@ __global__ __launch_bounds__(SCHED_THREADS) void k_tile_schedule(int ntile, cons
 }
 
 /* second half of the build: row-major scratch -> the tile's slot-major ELL slice
- * with entries ordered by distance shell.  One wave per bead reads the bead's row
- * coalesced, ranks the entries of each shell with ballot/popcount, and drops them
- * into an LDS image of the slice, which is then written out with coalesced stores. */
-#define IMG_ROWS 128
-#define IMG_STRIDE (IMG_ROWS + 2)         /* +2 entries: slot rows land on different LDS banks */
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
+ * with entries ordered by distance shell.  Rows are brought into LDS in chunks of
+ * TR_ROWS with coalesced loads; TR_TPR threads share a row, each running a
+ * sequential counting sort over its contiguous part (stable, so the result does
+ * not depend on timing); the sorted entries land in an LDS image of the slice,
+ * which is written out with coalesced stores.  No cross-lane ranking: the earlier
+ * wave-per-row version spent its time in ballot/popcount chains. */
+#define TR_THREADS 256
+#define TR_ROWS 32
+#define TR_TPR (TR_THREADS / TR_ROWS)      /* threads per row */
+#define IMG_STRIDE (TR_ROWS + 2)           /* +2 entries: slot rows land on different LDS banks */
+__global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta, ShellCuts shc)
 {
-   extern __shared__ unsigned int img32[];          /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for fill/copy */
+   extern __shared__ unsigned int tr_smem[];
+   const int rs = ta.tmpw | 1;                       /* odd row stride: rows start on different banks */
+   unsigned int *rows_s = tr_smem;                   /* [TR_ROWS][rs] scratch words */
+   unsigned int *img32 = rows_s + TR_ROWS * rs;      /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for fill/copy */
    unsigned short *img = (unsigned short *)img32;
+   __shared__ int cnt_s[TR_ROWS];
    int t = blockIdx.x;
    int ts = ta.cell_start_o[TCELLS * t];
    int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
@@ -590,87 +597,93 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_tile_transpose(TileArgs ta)
    if (nown <= 0 || rows <= 0) return;
    int width = ta.tile_width[t];
    long long base = ta.tile_base[t];
-   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-   const int npass = (ta.tmpw + 63) >> 6;
-   for (int c0 = 0; c0 < rows; c0 += IMG_ROWS)
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int r_own = threadIdx.x / TR_TPR, q_own = threadIdx.x % TR_TPR;
+   for (int c0 = 0; c0 < rows; c0 += TR_ROWS)
    {
-      for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += DDCMI_BLOCK) img32[idx] = 0;     /* width is a multiple of 8 <= tmpw */
+      for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += TR_THREADS) img32[idx] = 0;     /* width is a multiple of 8 <= tmpw */
+      if (threadIdx.x < TR_ROWS) cnt_s[threadIdx.x] = (c0 + threadIdx.x < nown) ? ta.nbr_cnt[ts + c0 + threadIdx.x] : 0;
       __syncthreads();
-      /* wave w owns rows [32w, 32w+32) of this chunk; their counts are fetched with one load */
-      int r_lane = c0 + 32 * w + (lane & 31);
-      int my_cnt = 0;
-      if (r_lane < nown) my_cnt = ta.nbr_cnt[ts + r_lane];
-      int e_nx[3], s_nx[3];
       {
-         int a0 = ts + min(c0 + 32 * w, nown - 1);
-         const unsigned *row = ta.tmp32 + (size_t)a0 * ta.tmpw;
+         /* all loads of the wave's rows are issued before the first LDS write: a plain
+          * row loop pays one memory round trip per row */
+         constexpr int RPW = TR_ROWS / (TR_THREADS / 64);
+         unsigned int v[RPW][3];
 #pragma unroll
-         for (int q = 0; q < 3; q++) { int k = 64 * q + lane; unsigned wv = (k < ta.tmpw) ? row[k] : (unsigned)NSHELL << 16; e_nx[q] = (int)(wv & 0xffffu); s_nx[q] = (int)(wv >> 16); }
-      }
-      for (int rr = 0; rr < 32; rr++)
-      {
-         int r = 32 * w + rr;                      /* row inside the chunk */
-         int cnt = __shfl(my_cnt, rr, 64);
-         int e_cu[3], s_cu[3];
-#pragma unroll
-         for (int q = 0; q < 3; q++) { e_cu[q] = e_nx[q]; s_cu[q] = s_nx[q]; }
-         if (rr + 1 < 32)
+         for (int j = 0; j < RPW; j++)
          {
-            int a1 = ts + min(c0 + r + 1, nown - 1);
-            const unsigned *row = ta.tmp32 + (size_t)a1 * ta.tmpw;
+            int r = w + j * (TR_THREADS / 64);
+            int cnt = cnt_s[r];
+            const unsigned int *src = ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw;
 #pragma unroll
-            for (int q = 0; q < 3; q++) { int k = 64 * q + lane; unsigned wv = (k < ta.tmpw) ? row[k] : (unsigned)NSHELL << 16; e_nx[q] = (int)(wv & 0xffffu); s_nx[q] = (int)(wv >> 16); }
+            for (int q = 0; q < 3; q++) { int k = lane + 64 * q; v[j][q] = (k < cnt) ? src[k] : 0u; }
          }
-         if (c0 + r >= nown) continue;
-         /* shell populations of this row (wave-uniform), then exclusive offsets */
+#pragma unroll
+         for (int j = 0; j < RPW; j++)
+         {
+            int r = w + j * (TR_THREADS / 64);
+            int cnt = cnt_s[r];
+#pragma unroll
+            for (int q = 0; q < 3; q++) { int k = lane + 64 * q; if (k < cnt) rows_s[r * rs + k] = v[j][q]; }
+            if (cnt > 192)
+            {
+               const unsigned int *src = ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw;
+               for (int k = lane + 192; k < cnt; k += 64) rows_s[r * rs + k] = src[k];
+            }
+         }
+      }
+      __syncthreads();
+      {
+         const int cnt = cnt_s[r_own];
+         const int per = (cnt + TR_TPR - 1) / TR_TPR;
+         const int k0 = min(q_own * per, cnt), k1 = min(k0 + per, cnt);
+         const unsigned int *row = rows_s + r_own * rs;
          int o[NSHELL];
 #pragma unroll
          for (int s = 0; s < NSHELL; s++) o[s] = 0;
-#define TR_COUNT(SH, Q) do { \
-            int sh_ = (64 * (Q) + lane < cnt) ? (SH) : NSHELL; \
-            _Pragma("unroll") for (int s = 0; s < NSHELL; s++) o[s] += __popcll(__ballot(sh_ == s)); } while (0)
-         if (cnt > 0) TR_COUNT(s_cu[0], 0);
-         if (cnt > 64) TR_COUNT(s_cu[1], 1);
-         if (cnt > 128) TR_COUNT(s_cu[2], 2);
-         for (int q = 3; q < npass && 64 * q < cnt; q++)
+         auto shell_of = [&](unsigned wv) -> int
          {
-            int a = ts + c0 + r, k = 64 * q + lane;
-            int sh = (k < cnt) ? (int)(ta.tmp32[(size_t)a * ta.tmpw + k] >> 16) : NSHELL;
-            TR_COUNT(sh, q);
-         }
-#undef TR_COUNT
+            float rf = __builtin_amdgcn_sqrtf(__uint_as_float(wv & 0xffff0000u));
+            return min(max((int)floorf((rf - shc.r0) * shc.inv_w) + 1, 0), NSHELL - 1);
+         };
+         for (int k = k0; k < k1; k++)
          {
-            int run = 0;
+            int sh = shell_of(row[k]);
 #pragma unroll
-            for (int s = 0; s < NSHELL; s++) { int c = o[s]; o[s] = run; run += c; }
+            for (int s = 0; s < NSHELL; s++) o[s] += (sh == s);
          }
-#define TR_PASS(E, SH, Q) do { \
-            int k_ = 64 * (Q) + lane; \
-            bool valid_ = k_ < cnt; \
-            int sh_ = valid_ ? (SH) : NSHELL; \
-            int slot_ = 0; \
-            _Pragma("unroll") for (int s = 0; s < NSHELL; s++) { \
-               unsigned long long b_ = __ballot(sh_ == s); \
-               if (sh_ == s) slot_ = o[s] + __popcll(b_ & ltmask); \
-               o[s] += __popcll(b_); } \
-            if (valid_) img[slot_ * IMG_STRIDE + r] = (unsigned short)(E); } while (0)
-         if (cnt > 0) TR_PASS(e_cu[0], s_cu[0], 0);
-         if (cnt > 64) TR_PASS(e_cu[1], s_cu[1], 1);
-         if (cnt > 128) TR_PASS(e_cu[2], s_cu[2], 2);
-         for (int q = 3; q < npass && 64 * q < cnt; q++)
+         /* offsets: shells in order, inside a shell the row's parts in order */
+         int run = 0;
+#pragma unroll
+         for (int s = 0; s < NSHELL; s++)
          {
-            int a = ts + c0 + r, k = 64 * q + lane;
-            unsigned wv = (k < cnt) ? ta.tmp32[(size_t)a * ta.tmpw + k] : (unsigned)NSHELL << 16;
-            TR_PASS((int)(wv & 0xffffu), (int)(wv >> 16), q);
+            int inc = o[s];
+#pragma unroll
+            for (int off = 1; off < TR_TPR; off <<= 1)
+            {
+               int v = __shfl_up(inc, off, TR_TPR);
+               if (q_own >= off) inc += v;
+            }
+            int tot = __shfl(inc, TR_TPR - 1, TR_TPR);
+            int mine = o[s];
+            o[s] = run + inc - mine;
+            run += tot;
          }
-#undef TR_PASS
+         for (int k = k0; k < k1; k++)
+         {
+            unsigned wv = row[k];
+            int sh = shell_of(wv);
+            int slot = 0;
+#pragma unroll
+            for (int s = 0; s < NSHELL; s++) { if (sh == s) slot = o[s]; o[s] += (sh == s); }
+            img[slot * IMG_STRIDE + r_own] = (unsigned short)(wv & 0xffffu);
+         }
       }
       __syncthreads();
       /* slice layout: [slot group g][row][8 slots] -> a lane reads its 8 slots of a group with one 16-byte load */
-      int nr = min(IMG_ROWS, rows - c0);           /* multiple of 64 */
+      int nr = min(TR_ROWS, rows - c0);
       int ngrp = width >> 3;
-      for (int idx = threadIdx.x; idx < ngrp * nr * 4; idx += DDCMI_BLOCK)
+      for (int idx = threadIdx.x; idx < ngrp * nr * 4; idx += TR_THREADS)
       {
          int q = idx & 3, r = (idx >> 2) % nr, g = (idx >> 2) / nr;
          int k = 8 * g + 2 * q;
@@ -1723,7 +1736,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    {
       double expect = 4.0 / 3.0 * M_PI * gp.rlist * gp.rlist * gp.rlist * dens;
       ctx->tmpw = ((int)(expect * 1.25) + 24 + 7) & ~7;
-      if ((size_t)ctx->tmpw * IMG_STRIDE * 2 > 150 * 1024) ctx->tmpw = (150 * 1024 / (IMG_STRIDE * 2)) & ~7;
+      if (ctx->tmpw > 768) ctx->tmpw = 768;          /* k_tile_transpose keeps TR_ROWS rows + their image in LDS */
       ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
    }
    ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
@@ -1759,11 +1772,12 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,
-                         shc, ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+                         ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       {
-         size_t lds2 = (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
+         size_t lds2 = (size_t)TR_ROWS * (ctx->tmpw | 1) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
+         if (lds2 > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "lists of %d entries per bead do not fit the transpose kernel's LDS", ctx->tmpw);
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-         hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(DDCMI_BLOCK), lds2, st, ta);
+         hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta, shc);
       }
       hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(SCHED_THREADS), 0, st, ntile, ctx->tile_work.p, ctx->sched.p, ctx->d_flags);
       HIPCHK(ctx, hipGetLastError());
