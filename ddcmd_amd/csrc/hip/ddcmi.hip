@@ -288,7 +288,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 
 #define TB_THREADS 512      /* k_tile_build workgroup: one lane per owned bead of the tile */
 #ifndef NSHELL
-#define NSHELL 4            /* distance shells of the list order; the transpose costs ~0.25 ms per shell at 4M beads */
+#define NSHELL 8            /* distance shells of the list order */
 #endif
 /* shell 0 = r < r0, shells 1.. = equal widths up to the list radius: boundaries only
  * steer the ORDER of a bead's entries, so single precision is plenty */
