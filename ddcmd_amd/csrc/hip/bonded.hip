@@ -50,50 +50,77 @@ __device__ __forceinline__ void block_store(double (&v)[NV], double *out)
    __syncthreads();
    if (threadIdx.x < NV) out[threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
-__device__ __forceinline__ void addf(double *fx, double *fy, double *fz, int i, double x, double y, double z)
+/* Where a term's atoms and parameters live.
+ *   one domain: atoms[] holds caller-order indices, translated through slot[] each
+ *     launch (atoms are re-sorted at every rebuild); term t uses parameter row t.
+ *   decomposed run: atoms[] holds device slots (owned or halo) of the terms this rank
+ *     touches, rebuilt with the lists (ddcmi_bonded_localize); tmap[t] = parameter row.
+ * A rank adds forces only to the atoms it owns (slot < nloc) and counts a term's
+ * energy and virial with weight (atoms it owns)/(atoms of the term): every term is then
+ * counted exactly once over all ranks, with no force return traffic. */
+struct TermMap { const int *atoms; const int *slot; const int *tmap; int nloc; };
+__device__ __forceinline__ int term_atom(const TermMap &m, int na, int t, int a)
 {
-   atomicAdd(&fx[i], x); atomicAdd(&fy[i], y); atomicAdd(&fz[i], z);
+   int i = m.atoms[na * t + a];
+   return m.slot ? m.slot[i] : i;
+}
+__device__ __forceinline__ int term_row(const TermMap &m, int t) { return m.tmap ? m.tmap[t] : t; }
+__device__ __forceinline__ void addf(const TermMap &m, double *fx, double *fy, double *fz, int i, double x, double y, double z)
+{
+   if (i < m.nloc) { atomicAdd(&fx[i], x); atomicAdd(&fy[i], y); atomicAdd(&fz[i], z); }
+}
+template <int NV>
+__device__ __forceinline__ void weigh(double (&acc)[NV], const TermMap &m, int nown, int na)
+{
+   if (nown == na) return;
+   double w = (double)nown / (double)na;
+#pragma unroll
+   for (int k = 0; k < NV; k++) acc[k] *= w;
 }
 
-__global__ __launch_bounds__(256) void k_bond(int nbond, BoxArgs box, const int *__restrict__ ij, const double *__restrict__ kb, const double *__restrict__ b0,
-                                              const int *__restrict__ slot, const double4 *__restrict__ pos,
+__global__ __launch_bounds__(256) void k_bond(int nbond, BoxArgs box, TermMap tm, const double *__restrict__ kb_, const double *__restrict__ b0_,
+                                              const double4 *__restrict__ pos,
                                               double *fx, double *fy, double *fz, double *partials)
 {
    int t = blockIdx.x * blockDim.x + threadIdx.x;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* e, xx,yy,zz,xy,xz,yz */
    if (t < nbond)
    {
-      int I = slot[ij[2 * t]], J = slot[ij[2 * t + 1]];
+      int I = term_atom(tm, 2, t, 0), J = term_atom(tm, 2, t, 1);
+      const int g = term_row(tm, t);
+      const double kb = kb_[g], b0 = b0_[g];
       double x, y, z;
       bioVec(box, pos[I], pos[J], x, y, z);
       double b = sqrt(x * x + y * y + z * z);
-      double bDelta = b - b0[t];
-      acc[0] = kb[t] * bDelta * bDelta;
+      double bDelta = b - b0;
+      acc[0] = kb * bDelta * bDelta;
       double ux = x / b, uy = y / b, uz = z / b;
-      double kforce = -2 * kb[t] * bDelta;
+      double kforce = -2 * kb * bDelta;
       double fxD = kforce * ux, fyD = kforce * uy, fzD = kforce * uz;
-      addf(fx, fy, fz, I, fxD, fyD, fzD);
-      addf(fx, fy, fz, J, -fxD, -fyD, -fzD);
+      addf(tm, fx, fy, fz, I, fxD, fyD, fzD);
+      addf(tm, fx, fy, fz, J, -fxD, -fyD, -fzD);
       acc[1] = fxD * x; acc[2] = fyD * y; acc[3] = fzD * z;
       acc[4] = fxD * y; acc[5] = fxD * z; acc[6] = fyD * z;
+      weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc), 2);
    }
    block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
 }
 
-__global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, const int *__restrict__ ijk, const int *__restrict__ func,
+__global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, TermMap tm, const int *__restrict__ func,
                                                const double *__restrict__ kt_, const double *__restrict__ t0_, int excl_mask,
-                                               const int *__restrict__ slot, const double4 *__restrict__ pos,
+                                               const double4 *__restrict__ pos,
                                                double *fx, double *fy, double *fz, double *partials)
 {
    int t = blockIdx.x * blockDim.x + threadIdx.x;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
    if (t < nangle)
    {
-      int f = func[t];
+      const int g = term_row(tm, t);
+      int f = func[g];
       bool skip = (f == 1 && (excl_mask & 2)) || (f == 2 && (excl_mask & 4)) || (f == 10 && (excl_mask & 256));
       if (!skip)
       {
-         int I = slot[ijk[3 * t]], J = slot[ijk[3 * t + 1]], K = slot[ijk[3 * t + 2]];
+         int I = term_atom(tm, 3, t, 0), J = term_atom(tm, 3, t, 1), K = term_atom(tm, 3, t, 2);
          double4 pj = pos[J];
          double ax, ay, az, cx, cy, cz;
          bioVec(box, pos[I], pj, ax, ay, az);
@@ -102,7 +129,7 @@ __global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, const in
          double uix = ax / b_ij, uiy = ay / b_ij, uiz = az / b_ij;
          double ukx = cx / b_kj, uky = cy / b_kj, ukz = cz / b_kj;
          double cosT = uix * ukx + uiy * uky + uiz * ukz;
-         double kt = kt_[t], t0 = t0_[t];
+         double kt = kt_[g], t0 = t0_[g];
          double coef_i, coef_k;
          if (f == 1)
          {
@@ -131,30 +158,32 @@ __global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, const in
          }
          double fxI = coef_i * (ukx - uix * cosT), fyI = coef_i * (uky - uiy * cosT), fzI = coef_i * (ukz - uiz * cosT);
          double fxK = coef_k * (uix - ukx * cosT), fyK = coef_k * (uiy - uky * cosT), fzK = coef_k * (uiz - ukz * cosT);
-         addf(fx, fy, fz, I, fxI, fyI, fzI);
-         addf(fx, fy, fz, K, fxK, fyK, fzK);
-         addf(fx, fy, fz, J, -(fxI + fxK), -(fyI + fyK), -(fzI + fzK));
+         addf(tm, fx, fy, fz, I, fxI, fyI, fzI);
+         addf(tm, fx, fy, fz, K, fxK, fyK, fzK);
+         addf(tm, fx, fy, fz, J, -(fxI + fxK), -(fyI + fyK), -(fzI + fzK));
          acc[1] = fxI * ax + fxK * cx; acc[2] = fyI * ay + fyK * cy; acc[3] = fzI * az + fzK * cz;
          acc[4] = fxI * ay + fxK * cy; acc[5] = fxI * az + fxK * cz; acc[6] = fyI * az + fyK * cz;
+         weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc) + (K < tm.nloc), 3);
       }
    }
    block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
 }
 
-__global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, const int *__restrict__ ijkl, const int *__restrict__ func, const int *__restrict__ nn_,
+__global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, TermMap tm, const int *__restrict__ func, const int *__restrict__ nn_,
                                                  const double *__restrict__ kk_, const double *__restrict__ delta_, int excl_mask,
-                                                 const int *__restrict__ slot, const double4 *__restrict__ pos,
+                                                 const double4 *__restrict__ pos,
                                                  double *fx, double *fy, double *fz, double *partials)
 {
    int t = blockIdx.x * blockDim.x + threadIdx.x;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* e_tors, e_impr, xx,yy,zz,xy,xz,yz */
    if (t < ntors)
    {
-      int f = func[t];
+      const int g = term_row(tm, t);
+      int f = func[g];
       bool skip = (f == 1 && (excl_mask & 16)) || (f == 2 && (excl_mask & 32));
       if (!skip)
       {
-         int I = slot[ijkl[4 * t]], J = slot[ijkl[4 * t + 1]], K = slot[ijkl[4 * t + 2]], L = slot[ijkl[4 * t + 3]];
+         int I = term_atom(tm, 4, t, 0), J = term_atom(tm, 4, t, 1), K = term_atom(tm, 4, t, 2), L = term_atom(tm, 4, t, 3);
          double4 pI = pos[I], pJ = pos[J], pK = pos[K], pL = pos[L];
          /* bioDihedralFast, bioCharmmCovalentEnergies.c:266-351 */
          const double eps = 1e-12;
@@ -191,8 +220,8 @@ __global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, const i
          double kk;
          if (f == 1)
          {
-            double kchi = kk_[t], delta = delta_[t];
-            int n = nn_[t];
+            double kchi = kk_[g], delta = delta_[g];
+            int n = nn_[g];
             acc[0] = kchi * (1 + cos(n * ang - delta));
             if (fabs(sinX) > FLOAT_EPS) kk = kchi * n * sin(n * ang - delta) / sinX;
             else
@@ -208,7 +237,7 @@ __global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, const i
          }
          else
          {
-            double kpsi = kk_[t], psi0 = delta_[t];
+            double kpsi = kk_[g], psi0 = delta_[g];
             double d = ang - psi0;
             if (d < -M_PI) d += 2 * M_PI; else if (d > M_PI) d -= 2 * M_PI;
             acc[1] = kpsi * d * d;
@@ -220,11 +249,12 @@ __global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, const i
                kk = -2 * kpsi / (1 - i2 / 6 + i4 / 120 - i6 / 5040 + i8 / 362880 - i10 / 39916800);
             }
          }
-         addf(fx, fy, fz, I, -cax * kk, -cay * kk, -caz * kk);
-         addf(fx, fy, fz, J, -(cbx - cax) * kk, -(cby - cay) * kk, -(cbz - caz) * kk);
-         addf(fx, fy, fz, K, -(ccx - cbx) * kk, -(ccy - cby) * kk, -(ccz - cbz) * kk);
-         addf(fx, fy, fz, L, ccx * kk, ccy * kk, ccz * kk);
+         addf(tm, fx, fy, fz, I, -cax * kk, -cay * kk, -caz * kk);
+         addf(tm, fx, fy, fz, J, -(cbx - cax) * kk, -(cby - cay) * kk, -(cbz - caz) * kk);
+         addf(tm, fx, fy, fz, K, -(ccx - cbx) * kk, -(ccy - cby) * kk, -(ccz - cbz) * kk);
+         addf(tm, fx, fy, fz, L, ccx * kk, ccy * kk, ccz * kk);
          acc[2] = v0 * kk; acc[3] = v1 * kk; acc[4] = v2 * kk; acc[5] = v3 * kk; acc[6] = v4 * kk; acc[7] = v5 * kk;
+         weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc) + (K < tm.nloc) + (L < tm.nloc), 4);
       }
    }
    block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
@@ -249,6 +279,75 @@ __global__ __launch_bounds__(256) void k_reduce_b(const double *partials, int nb
    }
 }
 
+/* ---- decomposed runs: terms are given by gid and located among the owned + halo beads - */
+#define GID_EMPTY 0xffffffffffffffffull
+__device__ __forceinline__ unsigned gid_hash(uint64_t g, unsigned mask)
+{
+   g ^= g >> 33; g *= 0xff51afd7ed558ccdull; g ^= g >> 33; g *= 0xc4ceb9fe1a85ec53ull; g ^= g >> 33;
+   return (unsigned)g & mask;
+}
+/* open-addressing table gid -> lowest device slot holding that gid.  Owned beads have
+ * the lowest slots, so an owned copy wins over halo copies, and among periodic images
+ * the choice does not depend on timing. */
+__global__ void k_gid_insert(int n, const uint64_t *__restrict__ gid, unsigned mask, unsigned long long *keys, int *vals)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   uint64_t g = gid[i];
+   unsigned h = gid_hash(g, mask);
+   for (;;)
+   {
+      unsigned long long old = atomicCAS(&keys[h], (unsigned long long)GID_EMPTY, (unsigned long long)g);
+      if (old == GID_EMPTY || old == g) { atomicMin(&vals[h], i); return; }
+      h = (h + 1) & mask;
+   }
+}
+__device__ __forceinline__ int gid_find(uint64_t g, unsigned mask, const unsigned long long *keys, const int *vals)
+{
+   unsigned h = gid_hash(g, mask);
+   for (;;)
+   {
+      unsigned long long k = keys[h];
+      if (k == g) return vals[h];
+      if (k == GID_EMPTY) return -1;
+      h = (h + 1) & mask;
+   }
+}
+/* pass 1: which of the global terms touch an owned bead; their slots.  flags[0] counts
+ * terms with an owned atom whose partner is neither owned nor in the halo. */
+template <int NA>
+__global__ void k_term_locate(int nterm, const uint64_t *__restrict__ tgid, int nloc, unsigned mask, const unsigned long long *keys, const int *vals,
+                              int *sel, int *slots, int *flags)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= nterm) return;
+   int s[NA], nown = 0, nmiss = 0;
+#pragma unroll
+   for (int a = 0; a < NA; a++)
+   {
+      s[a] = gid_find(tgid[(size_t)NA * t + a], mask, keys, vals);
+      nown += (s[a] >= 0 && s[a] < nloc);
+      nmiss += (s[a] < 0);
+   }
+   int take = nown > 0;
+   if (take && nmiss) { atomicAdd(&flags[0], 1); take = 0; }
+   sel[t] = take;
+#pragma unroll
+   for (int a = 0; a < NA; a++) slots[(size_t)NA * t + a] = s[a];
+}
+/* pass 2: stable compaction (sel has been turned into an exclusive scan) */
+template <int NA>
+__global__ void k_term_compact(int nterm, const int *__restrict__ pre, const int *__restrict__ slots, int total, int *tmap, int *latoms)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= nterm) return;
+   int o = pre[t], nxt = (t + 1 < nterm) ? pre[t + 1] : total;
+   if (nxt == o) return;
+   tmap[o] = t;
+#pragma unroll
+   for (int a = 0; a < NA; a++) latoms[(size_t)NA * o + a] = slots[(size_t)NA * t + a];
+}
+
 template <class T>
 static int up(ddcmi_ctx *ctx, dbuf<T> &buf, const T *src, size_t n)
 {
@@ -268,6 +367,7 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
    if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    ctx->excludePotentialTerm = excludePotentialTerm;
+   ctx->bonded_gid = false;
    ctx->nbond = (excludePotentialTerm & 1) ? 0 : nbond;
    ctx->nangle = nangle; ctx->ntors = ntors;
    int rc;
@@ -299,6 +399,103 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
    return DDCMI_OK;
 }
 
+extern "C" int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
+                                    int nbond, const uint64_t *bond_gid, const double *bond_kb, const double *bond_b0,
+                                    int nangle, const uint64_t *angle_gid, const int *angle_func, const double *angle_k, const double *angle_t0,
+                                    int ntors, const uint64_t *tors_gid, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
+                                    int excludePotentialTerm)
+{
+   if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   ctx->excludePotentialTerm = excludePotentialTerm;
+   ctx->bonded_gid = true;
+   ctx->g_nbond = (excludePotentialTerm & 1) ? 0 : nbond;
+   ctx->g_nangle = nangle; ctx->g_ntors = ntors;
+   ctx->nbond = ctx->nangle = ctx->ntors = 0;           /* local counts: set by ddcmi_bonded_localize at every rebuild */
+   int rc;
+   if (ctx->g_nbond > 0)
+   {
+      if (!bond_gid || !bond_kb || !bond_b0) return DDCMI_EINVAL;
+      if ((rc = up(ctx, ctx->gbond_gid, bond_gid, 2 * (size_t)nbond)) || (rc = up(ctx, ctx->bond_kb, bond_kb, nbond)) || (rc = up(ctx, ctx->bond_b0, bond_b0, nbond))) return rc;
+   }
+   if (nangle > 0)
+   {
+      if (!angle_gid || !angle_func || !angle_k || !angle_t0) return DDCMI_EINVAL;
+      for (int t = 0; t < nangle; t++)
+         if (angle_func[t] != 1 && angle_func[t] != 2 && angle_func[t] != 10) SETERR(ctx, DDCMI_EINVAL, "angle %d: func %d is not 1, 2 or 10", t, angle_func[t]);
+      if ((rc = up(ctx, ctx->gangle_gid, angle_gid, 3 * (size_t)nangle)) || (rc = up(ctx, ctx->angle_func, angle_func, nangle)) ||
+          (rc = up(ctx, ctx->angle_k, angle_k, nangle)) || (rc = up(ctx, ctx->angle_t0, angle_t0, nangle))) return rc;
+   }
+   if (ntors > 0)
+   {
+      if (!tors_gid || !tors_func || !tors_n || !tors_k || !tors_delta) return DDCMI_EINVAL;
+      for (int t = 0; t < ntors; t++)
+         if (tors_func[t] != 1 && tors_func[t] != 2) SETERR(ctx, DDCMI_EINVAL, "dihedral %d: func %d is not 1 or 2", t, tors_func[t]);
+      if ((rc = up(ctx, ctx->gtors_gid, tors_gid, 4 * (size_t)ntors)) || (rc = up(ctx, ctx->tors_func, tors_func, ntors)) || (rc = up(ctx, ctx->tors_n, tors_n, ntors)) ||
+          (rc = up(ctx, ctx->tors_k, tors_k, ntors)) || (rc = up(ctx, ctx->tors_delta, tors_delta, ntors))) return rc;
+   }
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   ctx->forces_valid = false;
+   ctx->list_valid = false;               /* the local term lists are made with the neighbour list */
+   return DDCMI_OK;
+}
+
+template <int NA>
+static int localize_kind(ddcmi_ctx *ctx, int nterm, const uint64_t *tgid, dbuf<int> &tmap, dbuf<int> &latoms, int *nlocal, int *d_total)
+{
+   *nlocal = 0;
+   if (nterm <= 0) return DDCMI_OK;
+   hipStream_t st = ctx->stream;
+   ENSURE(ctx, ctx->term_sel, (size_t)nterm + 1);
+   ENSURE(ctx, ctx->term_slots, (size_t)NA * nterm);
+   hipLaunchKernelGGL(k_term_locate<NA>, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, tgid, ctx->nloc, ctx->hmask, ctx->hkeys.p, ctx->hvals.p,
+                      ctx->term_sel.p, ctx->term_slots.p, ctx->d_flags);
+   int rc = ddcmi_scan_exclusive(ctx, ctx->term_sel.p, nterm, d_total);
+   if (rc) return rc;
+   int total = 0;
+   HIPCHK(ctx, hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   if (total > 0)
+   {
+      ENSURE(ctx, tmap, (size_t)total);
+      ENSURE(ctx, latoms, (size_t)NA * total);
+      hipLaunchKernelGGL(k_term_compact<NA>, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, ctx->term_sel.p, ctx->term_slots.p, total, tmap.p, latoms.p);
+   }
+   *nlocal = total;
+   return DDCMI_OK;
+}
+
+/* decomposed runs, at every list rebuild: find the terms that touch an owned bead and
+ * the device slots (owned or halo) of their atoms */
+int ddcmi_bonded_localize(ddcmi_ctx *ctx)
+{
+   if (!ctx->bonded_gid) return DDCMI_OK;
+   hipStream_t st = ctx->stream;
+   const int nall = ctx->nloc + ctx->nhalo;
+   unsigned cap = 1024;
+   while (cap < 2u * (unsigned)std::max(nall, 1)) cap <<= 1;
+   ctx->hmask = cap - 1;
+   if (ctx->hkeys.ensure(cap) || ctx->hvals.ensure(cap)) SETERR(ctx, DDCMI_ENOMEM, "gid table of %u slots", cap);
+   HIPCHK(ctx, hipMemsetAsync(ctx->hkeys.p, 0xff, (size_t)cap * sizeof(unsigned long long), st));
+   HIPCHK(ctx, hipMemsetAsync(ctx->hvals.p, 0x7f, (size_t)cap * sizeof(int), st));
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
+   if (nall > 0)
+      hipLaunchKernelGGL(k_gid_insert, dim3(cdiv(nall, 256)), dim3(256), 0, st, nall, ctx->gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p);
+   int rc;
+   int *d_total = ctx->d_flags + 8;
+   if ((rc = localize_kind<2>(ctx, ctx->g_nbond, ctx->gbond_gid.p, ctx->l_bond_map, ctx->l_bond_atoms, &ctx->nbond, d_total))) return rc;
+   if ((rc = localize_kind<3>(ctx, ctx->g_nangle, ctx->gangle_gid.p, ctx->l_angle_map, ctx->l_angle_atoms, &ctx->nangle, d_total))) return rc;
+   if ((rc = localize_kind<4>(ctx, ctx->g_ntors, ctx->gtors_gid.p, ctx->l_tors_map, ctx->l_tors_atoms, &ctx->ntors, d_total))) return rc;
+   HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   if (ctx->h_flags[0] > 0)
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "%d bonded terms reach beyond the halo (rmax+deltaR=%g): a partner of an owned bead is on no neighbouring domain's send list",
+             ctx->h_flags[0], ctx->rmax + ctx->deltaR);
+   return DDCMI_OK;
+}
+
 int ddcmi_launch_bonded(ddcmi_ctx *ctx)
 {
    if (ctx->nbond + ctx->nangle + ctx->ntors == 0) return DDCMI_OK;
@@ -307,25 +504,29 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
    for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
    box.pbc = ctx->pbc;
+   const bool gidmode = ctx->bonded_gid;
    int nbb = cdiv(ctx->nbond, 256), nab = cdiv(ctx->nangle, 256), ntb = cdiv(ctx->ntors, 256);
    ENSURE(ctx, ctx->bpartials, (size_t)(nbb + nab + ntb + 3) * 8);
    double *pb = ctx->bpartials.p, *pa = pb + (size_t)nbb * 8, *pt = pa + (size_t)nab * 8;
    if (ctx->nbond > 0)
    {
-      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, ctx->bond_ij.p, ctx->bond_kb.p, ctx->bond_b0.p, ctx->slot_of_orig.p, ctx->pos.p,
+      TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ctx->bond_kb.p, ctx->bond_b0.p, ctx->pos.p,
                          ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
       hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pb, nbb, 7, ctx->d_results + R_SCR_BOND);
    }
    if (ctx->nangle > 0)
    {
-      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, ctx->angle_ijk.p, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
-                         ctx->excludePotentialTerm, ctx->slot_of_orig.p, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
+      TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
+                         ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
       hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pa, nab, 7, ctx->d_results + R_SCR_ANGLE);
    }
    if (ctx->ntors > 0)
    {
-      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, ctx->tors_ijkl.p, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
-                         ctx->excludePotentialTerm, ctx->slot_of_orig.p, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
+      TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
+                         ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
       hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pt, ntb, 8, ctx->d_results + R_SCR_TORS);
    }
    return DDCMI_OK;

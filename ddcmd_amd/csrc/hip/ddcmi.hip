@@ -1324,6 +1324,8 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
+   ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
+   for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->d_results) (void)hipFree(ctx->d_results);
@@ -1802,7 +1804,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
    ctx->list_valid = true;
    ctx->nrebuild++;
-   return DDCMI_OK;
+   return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }
 
 /* ------------------------------------------------------------------------- */

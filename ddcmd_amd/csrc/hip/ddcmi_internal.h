@@ -138,6 +138,13 @@ struct ddcmi_ctx
    /* bonded */
    int nbond = 0, nangle = 0, ntors = 0;
    dbuf<int> bond_ij, angle_ijk, angle_func, tors_ijkl, tors_func, tors_n;
+   /* decomposed runs: global terms by gid (ddcmi_set_bonded_gid) and, rebuilt with the
+    * lists, the terms touching an owned bead with the device slots of their atoms */
+   bool bonded_gid = false;
+   int g_nbond = 0, g_nangle = 0, g_ntors = 0;
+   dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;
+   dbuf<int> l_bond_atoms, l_bond_map, l_angle_atoms, l_angle_map, l_tors_atoms, l_tors_map, term_sel, term_slots;
+   dbuf<unsigned long long> hkeys; dbuf<int> hvals; unsigned hmask = 0;
    dbuf<double> bond_kb, bond_b0, angle_k, angle_t0, tors_k, tors_delta;
    /* reductions */
    dbuf<double> partials, bpartials; int npartial_blocks = 0;
@@ -169,6 +176,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 /* scan.hip */
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
+int ddcmi_bonded_localize(ddcmi_ctx *ctx);
 /* bonded.hip */
 int ddcmi_launch_bonded(ddcmi_ctx *ctx);
 /* comm.hip */

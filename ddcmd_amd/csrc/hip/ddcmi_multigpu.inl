@@ -344,8 +344,8 @@ static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, rc;
-   if (ctx->nbond + ctx->nangle + ctx->ntors > 0)
-      SETERR(ctx, DDCMI_EUNSUPPORTED, "bonded terms are not yet supported with domain decomposition (whole-molecule migration, ddcRuleMartini, is a next step)");
+   if (!ctx->bonded_gid && ctx->nbond + ctx->nangle + ctx->ntors > 0)
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "with domain decomposition bonded terms must be given by gid (ddcmi_set_bonded_gid): caller-order indices do not survive migration");
    if ((rc = mg_ensure_owned(ctx, (size_t)n + 1))) return rc;
    if (ctx->mig_cap == 0) ctx->mig_cap = std::max(1024, n / 16);
    for (;;)

@@ -44,6 +44,8 @@ def _declare(lib):
     lib.ddcmi_set_molecules.argtypes = [vp, ctypes.c_int, _ip, _ip, _ip, _ip]
     lib.ddcmi_set_bonded.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, ctypes.c_int, _ip, _ip, _dp, _dp,
                                      ctypes.c_int, _ip, _ip, _ip, _dp, _dp, ctypes.c_int]
+    lib.ddcmi_set_bonded_gid.argtypes = [vp, ctypes.c_int, _up, _dp, _dp, ctypes.c_int, _up, _ip, _dp, _dp,
+                                         ctypes.c_int, _up, _ip, _ip, _dp, _dp, ctypes.c_int]
     lib.ddcmi_set_neighbor.argtypes = [vp, ctypes.c_double, ctypes.c_int]
     lib.ddcmi_set_groups.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, _ip]
     lib.ddcmi_set_clock.argtypes = [vp, ctypes.c_int64, ctypes.c_double]
@@ -133,7 +135,7 @@ def expand_bonded_terms(s):
 class MartiniHIP(object):
     """One device context running the Martini hot path for a Setup."""
 
-    def __init__(self, setup, device=0, upload=True):
+    def __init__(self, setup, device=0, upload=True, bonded_by_gid=False):
         self.lib = _lib.load_library()
         _declare(self.lib)
         self.s = setup
@@ -157,10 +159,21 @@ class MartiniHIP(object):
             self._chk(self.lib.ddcmi_set_molecules(self.ctx, 0, None, None, None, None))
         t = self.terms = expand_bonded_terms(s)
         nb, na, nt = t["bond_kb"].size, t["angle_k"].size, t["tors_k"].size
-        self._chk(self.lib.ddcmi_set_bonded(self.ctx, nb, _i(t["bond_ij"]), _d(t["bond_kb"]), _d(t["bond_b0"]),
-                                            na, _i(t["angle_ijk"]), _i(t["angle_func"]), _d(t["angle_k"]), _d(t["angle_t0"]),
-                                            nt, _i(t["tors_ijkl"]), _i(t["tors_func"]), _i(t["tors_n"]), _d(t["tors_k"]), _d(t["tors_delta"]),
-                                            int(s.excludePotentialTerm)))
+        if bonded_by_gid:
+            # decomposed runs: every rank holds the global term list, atoms named by gid
+            gids = np.asarray(s.gid, dtype=np.uint64)
+            g = lambda idx: np.ascontiguousarray(gids[np.asarray(idx, dtype=np.int64)], dtype=np.uint64)
+            self._term_gids = (g(t["bond_ij"]), g(t["angle_ijk"]), g(t["tors_ijkl"]))
+            u = lambda a: a.ctypes.data_as(_up)
+            self._chk(self.lib.ddcmi_set_bonded_gid(self.ctx, nb, u(self._term_gids[0]), _d(t["bond_kb"]), _d(t["bond_b0"]),
+                                                    na, u(self._term_gids[1]), _i(t["angle_func"]), _d(t["angle_k"]), _d(t["angle_t0"]),
+                                                    nt, u(self._term_gids[2]), _i(t["tors_func"]), _i(t["tors_n"]), _d(t["tors_k"]), _d(t["tors_delta"]),
+                                                    int(s.excludePotentialTerm)))
+        else:
+            self._chk(self.lib.ddcmi_set_bonded(self.ctx, nb, _i(t["bond_ij"]), _d(t["bond_kb"]), _d(t["bond_b0"]),
+                                                na, _i(t["angle_ijk"]), _i(t["angle_func"]), _d(t["angle_k"]), _d(t["angle_t0"]),
+                                                nt, _i(t["tors_ijkl"]), _i(t["tors_func"]), _i(t["tors_n"]), _d(t["tors_k"]), _d(t["tors_delta"]),
+                                                int(s.excludePotentialTerm)))
         self._chk(self.lib.ddcmi_set_neighbor(self.ctx, s.deltaR, int(s.updateRate)))
         gt = i32(np.where(np.asarray(s.group_type) == 1, 1, 0))
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
@@ -329,7 +342,7 @@ class MartiniRank(MartiniHIP, DomainMixin):
     """One rank of a decomposed run: uploads only the beads `index` selects."""
 
     def __init__(self, setup, index, device=0):
-        MartiniHIP.__init__(self, setup, device=device, upload=False)
+        MartiniHIP.__init__(self, setup, device=device, upload=False, bonded_by_gid=True)
         self.index = np.asarray(index)
 
     def upload_local(self):
