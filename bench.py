@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--lattice", dest="n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 64 -> 1.05M, 25 -> 62.5k)")
     ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=("water", "lipid"), default="water",
+                    help="water: the headline Martini water box; lipid: tests/golden/lipid_deck (DPPC-style bilayer patch in water, "
+                         "all bonded term kinds, charges, Berendsen) tiled --reps times")
+    ap.add_argument("--reps", default="12,12,6", help="lipid workload: copies of the 2363-bead deck along x,y,z (12,12,6 -> 2.04M beads)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +93,18 @@ def main():
     import numpy as np
     import ddcmd_amd
     from ddcmd_amd.martini import MartiniHIP, MartiniRank, domain_of
-    s = ddcmd_amd.make_water_setup(args.n)
+    if args.workload == "water":
+        s = ddcmd_amd.make_water_setup(args.n)
+        wname = "martini_water_%dk_beads" % (s.natoms // 1000)
+    else:
+        from ddcmd_amd.deck import load_deck
+        from ddcmd_amd.synth import replicate_setup
+        reps = tuple(int(x) for x in args.reps.split(","))
+        deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+        # 310 K restart relaxed by tests/golden/make_lipid_relaxed.py, Berendsen group (Teq 310 K, tau 1 ps)
+        s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), reps)
+        wname = "martini_lipid_bilayer_%dk_beads" % (s.natoms // 1000)
+    dt_fs = float(ddcmd_amd.units_convert(s.dt, None, "fs"))
     grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
     if grid is None:
         raise SystemExit("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)")
@@ -110,7 +125,12 @@ def main():
         m.upload_local()
     nlocal0 = m.n
     m.eval_forces()                       # firstEnergyCall (masters.c:579)
+    thermostat = any(int(t) == 1 for t in np.asarray(s.group_type).ravel())
+    if thermostat:
+        m.group_temperatures()            # the temperature Berendsen scales with (published by eval_energyInfo in the reference)
     m.step(args.warmup)
+    if thermostat:
+        m.group_temperatures()
     m.sync()
 
     def barrier():
@@ -149,7 +169,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if world == 1 and args.n == 100:
+        if world == 1 and args.n == 100 and args.workload == "water":
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -158,9 +178,12 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "ns_per_day": (args.steps / el) * DT_FS * 1e-6 * 86400.0,
-        "config": {"workload": "martini_water_%dk_beads" % (s.natoms // 1000), "beads_total": s.natoms, "beads_rank0": nlocal, "lattice": "fcc", "lattice_n": args.n,
-                   "rcut_A": 12.0, "skin_A": 4.0, "dt_fs": DT_FS, "list_rebuild_every": int(s.updateRate),
+        "ns_per_day": (args.steps / el) * dt_fs * 1e-6 * 86400.0,
+        "config": {"workload": wname, "beads_total": s.natoms, "beads_rank0": nlocal,
+                   "lattice": "fcc" if args.workload == "water" else "deck tiled %s" % args.reps, "lattice_n": args.n if args.workload == "water" else None,
+                   "rcut_A": float(ddcmd_amd.units_convert(s.rmax, None, "Angstrom")), "skin_A": float(ddcmd_amd.units_convert(s.deltaR, None, "Angstrom")),
+                   "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
+                   "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
                    "energy_virial_every_step": True,
                    "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo" % grid) if world > 1 else "single GPU",
                    "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},

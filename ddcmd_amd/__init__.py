@@ -6,5 +6,5 @@ loader/driver used by tests and bench.py; it never computes forces itself and
 raises if the HIP library is missing.
 """
 from ._lib import load_library, LibraryMissing  # noqa: F401
-from .deck import Setup, load_deck  # noqa: F401
-from .synth import make_water_setup  # noqa: F401
+from .deck import Setup, load_deck, units_convert  # noqa: F401
+from .synth import make_water_setup, replicate_setup  # noqa: F401

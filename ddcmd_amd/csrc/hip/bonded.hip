@@ -260,9 +260,15 @@ __global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, TermMap
    block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
 }
 
-__global__ __launch_bounds__(256) void k_reduce_b(const double *partials, int nblocks, int nv, double *out)
+/* one launch for the three term kinds: workgroup b sums the partials of kind b in a fixed order */
+struct RedB { const double *partials[3]; int nblocks[3]; int nv[3]; double *out[3]; };
+__global__ __launch_bounds__(256) void k_reduce_b(RedB rb)
 {
    __shared__ double s[256];
+   const double *partials = rb.partials[blockIdx.x];
+   const int nblocks = rb.nblocks[blockIdx.x], nv = rb.nv[blockIdx.x];
+   double *out = rb.out[blockIdx.x];
+   if (nblocks <= 0) return;
    for (int k = 0; k < nv; k++)
    {
       double a = 0.0;
@@ -513,21 +519,23 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
       TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
       hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ctx->bond_kb.p, ctx->bond_b0.p, ctx->pos.p,
                          ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
-      hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pb, nbb, 7, ctx->d_results + R_SCR_BOND);
    }
    if (ctx->nangle > 0)
    {
       TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
       hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
-      hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pa, nab, 7, ctx->d_results + R_SCR_ANGLE);
    }
    if (ctx->ntors > 0)
    {
       TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
       hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
-      hipLaunchKernelGGL(k_reduce_b, dim3(1), dim3(256), 0, st, pt, ntb, 8, ctx->d_results + R_SCR_TORS);
    }
+   RedB rb;
+   rb.partials[0] = pb; rb.nblocks[0] = (ctx->nbond > 0) ? nbb : 0; rb.nv[0] = 7; rb.out[0] = ctx->d_results + R_SCR_BOND;
+   rb.partials[1] = pa; rb.nblocks[1] = (ctx->nangle > 0) ? nab : 0; rb.nv[1] = 7; rb.out[1] = ctx->d_results + R_SCR_ANGLE;
+   rb.partials[2] = pt; rb.nblocks[2] = (ctx->ntors > 0) ? ntb : 0; rb.nv[2] = 8; rb.out[2] = ctx->d_results + R_SCR_TORS;
+   hipLaunchKernelGGL(k_reduce_b, dim3(3), dim3(256), 0, st, rb);
    return DDCMI_OK;
 }

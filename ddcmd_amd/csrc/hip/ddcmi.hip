@@ -321,7 +321,7 @@ struct NbTileArgs
 __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
-                                                            const int *bpairI, const int *bpairJ,
+                                                            const int *bpairI, const int *bpairJ, const unsigned long long *exmask,
                                                             int maxexcl, int *excl, int *excl_cnt, int *flags, unsigned long long *totals)
 {
    extern __shared__ double2 smem[];
@@ -410,7 +410,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
       uint64_t gi = 0;
       int mt = 0, mns = 1;
-      if (nmoltype > 0) { gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt]; }
+      /* exmask[mt*64 + a]: atoms (codes < 64) of molecule type mt bonded to atom a; bit 63 of
+       * entry a = 0 is set when the whole type can be decided by mask */
+      unsigned long long mask_i = 0; bool by_mask = false;
+      if (nmoltype > 0)
+      {
+         gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt];
+         unsigned aI = (unsigned)(gi & 65535ull);
+         if (mns > 1 && aI < 63u && (exmask[(size_t)mt * 64] >> 63)) { by_mask = true; mask_i = exmask[(size_t)mt * 64 + aI]; }
+      }
       int cnt = 0, ecnt = 0;
       /* scratch row: two words per 8-byte store (tmpw is even) */
       uint2 *row2 = (uint2 *)(ta.tmp32 + (size_t)a * ta.tmpw);
@@ -439,20 +447,20 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      long long wj = __double_as_longlong(pb.y);
                      if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
                      {
-                        uint64_t gj = gid[sidx[sj]];
-                        if ((gi >> 32) == (gj >> 32))
+                        /* same molecule id (the tag holds all 32 bits of gid>>32) */
+                        if (mns > 1)
                         {
-                           if (mns > 1)
-                           {
-                              unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)(gj & 65535ull);
+                           unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)((wj >> 8) & 0xff);
+                           if (aJ == 255u) aJ = (unsigned)(gid[sidx[sj]] & 65535ull);
+                           if (by_mask && aJ < 63u) pruned = (mask_i >> aJ) & 1ull;
+                           else
                               for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
                               {
                                  unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
                                  if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
                               }
-                           }
-                           else pruned = true;
                         }
+                        else pruned = true;
                      }
                      if (pruned)
                      {
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          int al = chunk * R + (active ? ain : 0);
          int a = ts + al;
          double4 pi = pos[a];
-         int ti = (int)(__double_as_longlong(pi.w) & 0xffffll);
+         int ti = (int)(__double_as_longlong(pi.w) & 0xffll);
          double kqi = 0.0;
          if (HAS_Q) kqi = keR * qatom[a];
          int cnt_full = active ? ta.nbr_cnt[a] : 0;
@@ -1196,14 +1204,18 @@ __global__ void k_export3(int nloc, const double *a, const double *b, const doub
    int o = orig[i];
    oa[o] = a[i]; ob[o] = b[i]; oc[o] = c[i];
 }
-/* record tag w (bit-cast into pos.w): [63:32] molecule id (gid>>32, bioGid.h) [31:16] species [15:0] LJ type */
+/* record tag w (bit-cast into pos.w): [63:32] molecule id (gid>>32, bioGid.h) [31:16] species
+ * [15:8] atom-in-molecule code (gid & 0xffff when < 255, else 255 = "look at the gid")
+ * [7:0] LJ type.  The atom code lets the list build decide bonded-pair exclusions from
+ * LDS instead of two dependent global loads per same-molecule candidate. */
 __global__ void k_init_state(int n, const double *rx, const double *ry, const double *rz, const int *species, const int *ljtype_sp,
                              const double *charge_sp, const uint64_t *gid, double4 *pos, double *qatom, int *orig, int *slot)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
    int sp = species[i];
-   long long w = (long long)((gid[i] >> 32) << 32) | ((long long)(sp & 0xffff) << 16) | (long long)(ljtype_sp[sp] & 0xffff);
+   unsigned code = (unsigned)(gid[i] & 0xffffull);
+   long long w = (long long)((gid[i] >> 32) << 32) | ((long long)(sp & 0xffff) << 16) | ((long long)min(code, 255u) << 8) | (long long)(ljtype_sp[sp] & 0xff);
    pos[i] = make_double4(rx[i], ry[i], rz[i], __longlong_as_double(w));
    qatom[i] = charge_sp[sp];
    orig[i] = i;
@@ -1324,7 +1336,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
-   ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
+   ctx->d_exmask.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -1421,6 +1433,21 @@ extern "C" int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_
    if ((rc = upload_vec(ctx, ctx->d_bpair_off, ctx->bpair_off.data(), nmoltype + 1))) return rc;
    if ((rc = upload_vec(ctx, ctx->d_bpairI, ctx->bpairI.data(), nb + 1))) return rc;
    if ((rc = upload_vec(ctx, ctx->d_bpairJ, ctx->bpairJ.data(), nb + 1))) return rc;
+   /* bonded-pair masks for the list build: usable for a molecule type whose pair codes are all < 63 */
+   std::vector<unsigned long long> em((size_t)nmoltype * 64, 0ull);
+   for (int m = 0; m < nmoltype; m++)
+   {
+      bool ok = true;
+      for (int k = bpair_off[m]; k < bpair_off[m + 1]; k++) if (bpairI[k] < 0 || bpairJ[k] < 0 || bpairI[k] >= 63 || bpairJ[k] >= 63) ok = false;
+      if (!ok) continue;
+      for (int k = bpair_off[m]; k < bpair_off[m + 1]; k++)
+      {
+         em[(size_t)m * 64 + bpairI[k]] |= 1ull << bpairJ[k];
+         em[(size_t)m * 64 + bpairJ[k]] |= 1ull << bpairI[k];
+      }
+      em[(size_t)m * 64] |= 1ull << 63;
+   }
+   if ((rc = upload_vec(ctx, ctx->d_exmask, em.data(), em.size()))) return rc;
    return DDCMI_OK;
 }
 
@@ -1773,7 +1800,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
-                         ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p,
+                         ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
                          ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       {
          size_t lds2 = (size_t)TR_ROWS * (ctx->tmpw | 1) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
@@ -2004,18 +2031,29 @@ extern "C" int ddcmi_kinetic(ddcmi_ctx *ctx, double *rk, double *tion)
    return ddcmi_get_energies(ctx, nullptr, nullptr, rk, tion);
 }
 
-extern "C" int ddcmi_group_temperatures(ddcmi_ctx *ctx, double *Tgroup)
+/* per-group {kinetic energy, bead count} of this rank's beads -> h_results[R_GROUP..];
+ * over RCCL the sums are all-reduced first (energyInfo.c:75-112 allreduce) */
+int ddcmi_group_ke_sums(ddcmi_ctx *ctx)
 {
-   if (!ctx || ctx->nloc <= 0) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, ng = ctx->ngroup;
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_GROUP, 0, 2 * ng * sizeof(double), st));
-   hipLaunchKernelGGL(k_group_ke, dim3(cdiv(n, DDCMI_BLOCK)), dim3(DDCMI_BLOCK), 0, st, n, ng, ctx->d_mass.p, ctx->species.p, ctx->group.p,
-                      ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->d_results + R_GROUP);
-   int rc = fetch_results(ctx);
+   if (n > 0)
+      hipLaunchKernelGGL(k_group_ke, dim3(cdiv(n, DDCMI_BLOCK)), dim3(DDCMI_BLOCK), 0, st, n, ng, ctx->d_mass.p, ctx->species.p, ctx->group.p,
+                         ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->d_results + R_GROUP);
+   if (ctx->nranks > 1 && ctx->comm && !ctx->group_ && ng > 0)
+      if (ncclAllReduce(ctx->d_results + R_GROUP, ctx->d_results + R_GROUP, 2 * ng, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st) != ncclSuccess)
+         SETERR(ctx, DDCMI_ECOMM, "ncclAllReduce of the group kinetic energies failed");
+   return fetch_results(ctx);
+}
+extern "C" int ddcmi_group_temperatures(ddcmi_ctx *ctx, double *Tgroup)
+{
+   if (!ctx || (ctx->nloc <= 0 && ctx->nranks == 1)) return DDCMI_EINVAL;
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group: use ddcmi_group_temperatures_all");
+   int rc = ddcmi_group_ke_sums(ctx);
    if (rc) return rc;
-   for (int g = 0; g < ng; g++)
+   for (int g = 0; g < ctx->ngroup; g++)
    {
       double rk = ctx->h_results[R_GROUP + 2 * g], num = ctx->h_results[R_GROUP + 2 * g + 1];
       if (num > 0.0) ctx->gT[g] = 2.0 * rk / (3.0 * num);     /* energyInfo.c:139 */

@@ -110,6 +110,7 @@ struct ddcmi_ctx
    dbuf<double> d_invmass, d_mass, d_charge_sp; dbuf<int> d_ljtype_sp, d_moltype_sp;
    dbuf<double4> d_ljtab;          /* nlj*nlj {sigma^2, 4eps, shift, 24eps} */
    dbuf<int> d_mol_nspecies, d_bpair_off, d_bpairI, d_bpairJ;
+   dbuf<unsigned long long> d_exmask;   /* [nmoltype][64] bonded-pair masks by atom code (list build) */
    /* particle state: [0,nloc) owned, [nloc,nloc+nhalo) images/halo */
    int nloc = 0, nhalo = 0, npad = 0;
    dbuf<double4> pos, pos2;
@@ -177,6 +178,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 /* scan.hip */
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
+int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 /* bonded.hip */
 int ddcmi_launch_bonded(ddcmi_ctx *ctx);
 /* comm.hip */

@@ -613,6 +613,27 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
    return DDCMI_OK;
 }
 
+/* group temperatures of an in-process group: the per-rank sums are added on the host */
+extern "C" int ddcmi_group_temperatures_all(ddcmi_ctx **ctxs, int n, double *Tgroup)
+{
+   if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
+   ddcmi_group *g = ctxs[0]->group_;
+   int ng = ctxs[0]->ngroup, rc;
+   std::vector<double> sum(2 * (size_t)std::max(ng, 1), 0.0);
+   for (ddcmi_ctx *c : g->ranks)
+   {
+      if ((rc = ddcmi_group_ke_sums(c))) return rc;
+      for (int k = 0; k < 2 * ng; k++) sum[k] += c->h_results[R_GROUP + k];
+   }
+   for (int q = 0; q < ng; q++)
+   {
+      double T = (sum[2 * q + 1] > 0.0) ? 2.0 * sum[2 * q] / (3.0 * sum[2 * q + 1]) : 0.0;
+      for (ddcmi_ctx *c : g->ranks) if (sum[2 * q + 1] > 0.0) c->gT[q] = T;
+      if (Tgroup) Tgroup[q] = T;
+   }
+   return DDCMI_OK;
+}
+
 /* current local beads in device order, identified by gid (ddcMD identifies
  * particles by label); r wrapped into the box */
 __global__ void k_export_particles(GridParams gp, int n, const double4 *pos, double *x, double *y, double *z, int *species)

@@ -288,6 +288,7 @@ def _declare_domains(lib):
     lib.ddcmi_group_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.ddcmi_group_eval_forces.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.ddcmi_group_step_nglf.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    lib.ddcmi_group_temperatures_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, _dp]
     lib._ddcmi_dom_declared = True
 
 
@@ -395,6 +396,11 @@ class MartiniGroup(object):
 
     def step(self, nsteps=1, dt=None):
         self._chk(self.lib.ddcmi_group_step_nglf(self.arr, self.n, float(self.s.dt if dt is None else dt), int(nsteps)))
+
+    def group_temperatures(self):
+        T = np.zeros(max(1, self.s.ngroup))
+        self._chk(self.lib.ddcmi_group_temperatures_all(self.arr, self.n, _d(T)))
+        return T
 
     def energies(self):
         """sum over ranks = energyInfo.c allreduce()"""

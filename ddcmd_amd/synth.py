@@ -152,3 +152,51 @@ def make_water_setup(n, seed=SEED, temperature_K=50.0, rcut_A=12.0, skin_A=4.0, 
         s.group_Teq = np.array([units_convert(310.0, "K")])
         s.group_tau = np.array([units_convert(1.0, "ps")])
     return s
+
+
+def replicate_setup(s, reps):
+    """Tile a periodic Setup reps=(a,b,c) times along x,y,z: the lipid workload at any size.
+
+    A periodic box repeated is the same system, so every copy of a bead feels the
+    forces of the original -- the size-independent parity property the full-size
+    tests use.  Molecule ids (gid bits 63:32) of copy k are offset by k * (number of
+    molecule ids of the original), everything below the molecule id is kept."""
+    import copy
+    a, b, c = (int(x) for x in reps)
+    out = copy.copy(s)
+    L = np.array([s.h[0], s.h[4], s.h[8]])
+    lo = -0.5 * L
+    ncopy = a * b * c
+    n = s.natoms
+    molid = (np.asarray(s.gid, dtype=np.uint64) >> np.uint64(32)).astype(np.int64)
+    nmol = int(molid.max()) + 1
+    low = np.asarray(s.gid, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    Lnew = L * np.array([a, b, c])
+    rx, ry, rz, gid = [], [], [], []
+    k = 0
+    # Molecules are made whole first (every bead moved to the periodic image nearest its
+    # molecule's first bead): a molecule the original box wraps across its boundary would
+    # otherwise be torn between two copies, L apart in a box where L is no longer a period.
+    r = np.stack([np.asarray(s.rx, dtype=np.float64), np.asarray(s.ry, dtype=np.float64), np.asarray(s.rz, dtype=np.float64)], 1)
+    first = np.zeros(nmol, np.int64)
+    first[molid[::-1]] = np.arange(n - 1, -1, -1)            # index of the first bead of each molecule
+    ref = r[first[molid]]
+    r = r - L * np.rint((r - ref) / L)
+    # positions measured from the original box corner, placed into a box centred on 0 again
+    fx = r[:, 0] - lo[0]; fy = r[:, 1] - lo[1]; fz = r[:, 2] - lo[2]
+    for iz in range(c):
+        for iy in range(b):
+            for ix in range(a):
+                rx.append(fx + ix * L[0] - 0.5 * Lnew[0])
+                ry.append(fy + iy * L[1] - 0.5 * Lnew[1])
+                rz.append(fz + iz * L[2] - 0.5 * Lnew[2])
+                gid.append(((molid + k * nmol).astype(np.uint64) << np.uint64(32)) | low)
+                k += 1
+    out.rx, out.ry, out.rz = np.concatenate(rx), np.concatenate(ry), np.concatenate(rz)
+    out.gid = np.concatenate(gid)
+    for f in ("vx", "vy", "vz", "species", "group"):
+        setattr(out, f, np.tile(np.asarray(getattr(s, f)), ncopy))
+    out.h = np.array(s.h, dtype=np.float64).copy()
+    out.h[0], out.h[4], out.h[8] = Lnew
+    out.natoms = n * ncopy
+    return out

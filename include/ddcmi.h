@@ -130,7 +130,8 @@ int ddcmi_get_energies(ddcmi_ctx *ctx, double *energies, double *virial, double 
 /* kinetic_terms (energy.c:48-163) on the current velocities. [sync] */
 int ddcmi_kinetic(ddcmi_ctx *ctx, double *rk, double *tion);
 /* eval_energyInfo group branch (energyInfo.c:118-141): refresh the per-group
- * temperatures Berendsen reads; returns them in Tgroup[ngroup] if not NULL. [sync] */
+ * temperatures Berendsen reads; returns them in Tgroup[ngroup] if not NULL.  With an
+ * RCCL communicator the sums are all-reduced first (collective call). [sync] */
 int ddcmi_group_temperatures(ddcmi_ctx *ctx, double *Tgroup);
 int ddcmi_get_clock(const ddcmi_ctx *ctx, int64_t *loop, double *time);
 int ddcmi_sync(ddcmi_ctx *ctx);
@@ -180,6 +181,8 @@ int ddcmi_group_create(ddcmi_ctx **ctxs, int n, int px, int py, int pz);
 int ddcmi_group_destroy(ddcmi_ctx **ctxs, int n);
 int ddcmi_group_eval_forces(ddcmi_ctx **ctxs, int n);
 int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nsteps);
+/* ddcmi_group_temperatures for an in-process group (sums over its domains) */
+int ddcmi_group_temperatures_all(ddcmi_ctx **ctxs, int n, double *Tgroup);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,43 @@ def test_decomposition_consistent_at_1M():
     assert np.abs(v8 - v1).max() < 1e-9 * np.abs(v1).max()
     assert sum(int(r.lib.ddcmi_nlocal(r.ctx)) for r in g.ranks) == s.natoms
     g.close()
+
+
+def test_lipid_bilayer_2M_beads_periodic_copies():
+    """BASELINE config 5 size: the lipid deck tiled 12x12x6 (2.04M beads, ~0.9M bonded terms).
+    A periodic box repeated is the same system: every copy of a bead must feel the force the
+    oracle computes for the original 2363-bead deck, and energies scale with the copy count."""
+    import os
+    import pyoracle
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import replicate_setup
+    from ddcmd_amd.martini import MartiniHIP
+    from conftest import rel_force_err
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    # the 310 K restart (make_lipid_relaxed.py): lipids there wrap around the box edges, so the
+    # tiling has to keep molecules whole; Berendsen group as in BASELINE config 5
+    s0 = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    o = pyoracle.Oracle(s0)
+    e0, v0 = o.forces()
+    reps = (12, 12, 6)
+    ncopy = reps[0] * reps[1] * reps[2]
+    s = replicate_setup(s0, reps)
+    assert s.natoms == 2363 * ncopy
+    m = MartiniHIP(s)
+    e, vir = m.eval_forces()
+    d = m.download()
+    f = np.stack(d["f"]).reshape(3, ncopy, s0.natoms)
+    ref = np.stack([o.fx, o.fy, o.fz])[:, None, :]
+    assert np.abs(f - ref).max() < 1e-8 * np.abs(ref).max()
+    for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
+        assert abs(e[k] - ncopy * e0[k]) < 1e-9 * ncopy * max(abs(e0[k]), abs(e0["total"]) * 1e-6), k
+    assert np.abs(vir - ncopy * v0).max() < 1e-9 * ncopy * np.abs(v0).max()
+    # 20 steps (two rebuilds) with the Berendsen group active track the oracle of the small deck
+    o.group_temperature()
+    m.group_temperatures()
+    eo, vo, rko, _ = o.step(20)
+    m.step(20)
+    e2, _, rk, _ = m.energies()
+    assert abs(rk - ncopy * rko) < 1e-6 * ncopy * rko
+    assert abs(e2["total"] - ncopy * eo["total"]) < 1e-6 * ncopy * abs(eo["total"])
+    m.close()
