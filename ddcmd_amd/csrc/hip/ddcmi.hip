@@ -1029,67 +1029,34 @@ __global__ void k_zero3(int n, double *a, double *b, double *c)
    if (i < n) { a[i] = 0; b[i] = 0; c[i] = 0; }
 }
 
-/* fixed-order reduction of per-workgroup partials: stage A, RED_BLOCKS
- * workgroups each sum a strided subset; stage B, one workgroup sums those.
- * Same order every run => bitwise reproducible. */
-#define RED_BLOCKS 64
-__global__ __launch_bounds__(DDCMI_BLOCK) void k_reduce_stageA(const double *partials, int nblocks, int stride, int nv, double *tmp)
-{
-   __shared__ double s[DDCMI_BLOCK];
-   for (int k = 0; k < nv; k++)
-   {
-      double a = 0.0;
-      for (int b = blockIdx.x * DDCMI_BLOCK + threadIdx.x; b < nblocks; b += RED_BLOCKS * DDCMI_BLOCK) a += partials[(size_t)b * stride + k];
-      s[threadIdx.x] = a;
-      __syncthreads();
-      for (int off = DDCMI_BLOCK / 2; off > 0; off >>= 1)
-      {
-         if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
-         __syncthreads();
-      }
-      if (threadIdx.x == 0) tmp[blockIdx.x * 8 + k] = s[0];
-      __syncthreads();
-   }
-}
+/* Fixed-order reductions of per-workgroup partials (8 doubles per row), one workgroup per
+ * job: thread (g = tid/8, k = tid%8) adds column k of rows g, g+128, ...; a tree over the
+ * 128 row groups finishes all columns at once.  Same order every run => bitwise
+ * reproducible.  A step runs its two jobs -- the nonbonded sums (+ the final energies)
+ * and the kinetic terms -- in one launch. */
+struct RedJob { const double *partials; int nblocks; int nv; double *out; int finish; };
 __device__ void finish_energy(double *r, double self_ele);
-/* stage B; with finish != 0 the same launch also forms the final energies/virial
- * (one launch less per step) */
-__global__ __launch_bounds__(64) void k_reduce_stageB(const double *tmp, int nv, double *out, double *results, double self_ele, int finish)
+__global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, double *results, double self_ele)
 {
-   int k = threadIdx.x >> 3, l = threadIdx.x & 7;     /* 8 values x 8 lanes */
-   if (k < nv)
+   const RedJob j = blockIdx.x ? j1 : j0;
+   __shared__ double s[1024];
+   const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
+   double a = 0.0;
+   if (k < j.nv)
+      for (int b = g; b < j.nblocks; b += 128) a += j.partials[(size_t)b * 8 + k];
+   s[threadIdx.x] = a;
+   __syncthreads();
+   for (int off = 512; off >= 8; off >>= 1)
    {
-      double a = 0.0;
-      for (int b = l; b < RED_BLOCKS; b += 8) a += tmp[b * 8 + k];
-      a += __shfl_down(a, 4, 8); a += __shfl_down(a, 2, 8); a += __shfl_down(a, 1, 8);
-      if (l == 0) out[k] = a;
+      if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+      __syncthreads();
    }
-   if (finish)
+   if (threadIdx.x < j.nv) j.out[threadIdx.x] = s[threadIdx.x];
+   if (j.finish)
    {
-      __syncthreads();          /* one wave: orders the out[] stores before thread 0 reads them */
+      __syncthreads();          /* orders the out[] stores before thread 0 reads them */
       if (threadIdx.x == 0) finish_energy(results, self_ele);
    }
-}
-/* one-launch variant for moderate partial counts: a single 1024-thread workgroup sums
- * everything in a fixed order and (optionally) forms the final energies */
-__global__ __launch_bounds__(1024) void k_reduce_single(const double *partials, int nblocks, int stride, int nv, double *out, double *results, double self_ele, int finish)
-{
-   __shared__ double s[1024];
-   for (int k = 0; k < nv; k++)
-   {
-      double a = 0.0;
-      for (int b = threadIdx.x; b < nblocks; b += 1024) a += partials[(size_t)b * stride + k];
-      s[threadIdx.x] = a;
-      __syncthreads();
-      for (int off = 512; off > 0; off >>= 1)
-      {
-         if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
-         __syncthreads();
-      }
-      if (threadIdx.x == 0) out[k] = s[0];
-      __syncthreads();
-   }
-   if (finish && threadIdx.x == 0) finish_energy(results, self_ele);
 }
 /* final energies / virial: full list counts every pair twice */
 __device__ void finish_energy(double *r, double self_ele)
@@ -1338,7 +1305,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
-   ctx->tile_base.release(); ctx->nbr16.release(); ctx->red_tmp.release(); ctx->tmp32.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -1827,15 +1794,16 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
          break;
       }
    }
-   ENSURE(ctx, ctx->partials, (size_t)(std::max(ntile, cdiv(n, DDCMI_BLOCK)) + 8) * 8);
-   ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
+   ENSURE(ctx, ctx->partials, (size_t)(ntile + 8) * 8);
    ctx->list_valid = true;
    ctx->nrebuild++;
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }
 
 /* ------------------------------------------------------------------------- */
-static int launch_forces(ddcmi_ctx *ctx)
+/* defer_reduce: the caller (a time step) folds the nonbonded reduction and the final
+ * energies into the launch that reduces the kinetic terms */
+static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
@@ -1890,22 +1858,20 @@ static int launch_forces(ddcmi_ctx *ctx)
 #undef LAUNCH_NB
       if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
       /* without bonded terms the final energies are formed in the same launch */
-      if (ntile <= 4096)
-         hipLaunchKernelGGL(k_reduce_single, dim3(1), dim3(1024), 0, st, ctx->partials.p, ntile, 8, 8, ctx->d_results + R_NB_LJ, ctx->d_results, self, has_bonded ? 0 : 1);
-      else
+      if (!defer_reduce)
       {
-         hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->partials.p, ntile, 8, 8, ctx->red_tmp.p);
-         hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, st, ctx->red_tmp.p, 8, ctx->d_results + R_NB_LJ, ctx->d_results, self, has_bonded ? 0 : 1);
+         RedJob j0 = {ctx->partials.p, ntile, 8, ctx->d_results + R_NB_LJ, has_bonded ? 0 : 1};
+         hipLaunchKernelGGL(k_reduce_jobs, dim3(1), dim3(1024), 0, st, j0, j0, ctx->d_results, self);
       }
    }
    else
    {
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, 8 * sizeof(double), st));
+      if (!defer_reduce) HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, 8 * sizeof(double), st));
       hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
    }
    int rc = ddcmi_launch_bonded(ctx);
    if (rc) return rc;
-   if (has_bonded || (ctx->excludePotentialTerm & 128) != 0)
+   if (!defer_reduce && (has_bonded || (ctx->excludePotentialTerm & 128) != 0))
       hipLaunchKernelGGL(k_finish_energy, dim3(1), dim3(64), 0, st, ctx->d_results, self);
    ctx->forces_valid = true;
    return DDCMI_OK;
@@ -1932,20 +1898,24 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
    return DDCMI_OK;
 }
 
-static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick)
+/* kinetic_terms (+ the BACK half kick); with_forces: the same launch also reduces the
+ * nonbonded partials of the force evaluation just queued and forms the final energies */
+static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false)
 {
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK);
-   ENSURE(ctx, ctx->partials, (size_t)(std::max(ctx->ntile, nblk) + 8) * 8);
-   ENSURE(ctx, ctx->red_tmp, RED_BLOCKS * 8 * 2);
+   ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
    hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
-                      ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->partials.p, do_kick);
-   if (nblk <= 4096)
-      hipLaunchKernelGGL(k_reduce_single, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->d_results + R_RK, ctx->d_results, 0.0, 0);
-   else
+                      ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, do_kick);
+   RedJob jk = {ctx->kpartials.p, nblk, 7, ctx->d_results + R_RK, 0};
+   if (with_forces)
    {
-      hipLaunchKernelGGL(k_reduce_stageA, dim3(RED_BLOCKS), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->partials.p, nblk, 8, 7, ctx->red_tmp.p + RED_BLOCKS * 8);
-      hipLaunchKernelGGL(k_reduce_stageB, dim3(1), dim3(64), 0, ctx->stream, ctx->red_tmp.p + RED_BLOCKS * 8, 7, ctx->d_results + R_RK, ctx->d_results, 0.0, 0);
+      const bool nb_on = (ctx->excludePotentialTerm & 128) == 0;
+      const double self = nb_on ? ctx->self_ele : 0.0;
+      RedJob jf = {ctx->partials.p, nb_on ? ctx->ntile : 0, 8, ctx->d_results + R_NB_LJ, 1};
+      hipLaunchKernelGGL(k_reduce_jobs, dim3(2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, self);
    }
+   else
+      hipLaunchKernelGGL(k_reduce_jobs, dim3(1), dim3(1024), 0, ctx->stream, jk, jk, ctx->d_results, 0.0);
    return DDCMI_OK;
 }
 
@@ -1985,8 +1955,8 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
 static int step_post(ddcmi_ctx *ctx, double dt)
 {
    int rc;
-   if ((rc = launch_forces(ctx))) return rc;
-   if ((rc = launch_kinetic(ctx, dt, 1))) return rc;
+   if ((rc = launch_forces(ctx, true))) return rc;
+   if ((rc = launch_kinetic(ctx, dt, 1, true))) return rc;
    berendsen_update(ctx, 0.5 * dt);
    return DDCMI_OK;
 }

@@ -133,7 +133,7 @@ struct ddcmi_ctx
    dbuf<long long> tile_base;
    dbuf<unsigned short> nbr16; dbuf<unsigned int> tmp32; int tmpw = 0;
    unsigned long long arena_cap = 0;
-   dbuf<double> red_tmp;
+   dbuf<double> kpartials;             /* per-workgroup kinetic terms (k_kick_ke) */
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
    /* bonded */
