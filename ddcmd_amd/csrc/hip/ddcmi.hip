@@ -1097,10 +1097,11 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
    double lam = glambda.v[group[i] & 31];
    double x = vx[i], y = vy[i], z = vz[i];
    if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
-   x += a * fx[i]; y += a * fy[i]; z += a * fz[i];
+   /* explicit fma: k_kick_ke_drift must produce the same bits as this kernel */
+   x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
    vx[i] = x; vy[i] = y; vz[i] = z;
    double4 p = pos[i];
-   p.x += dt * x; p.y += dt * y; p.z += dt * z;
+   p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
    pos[i] = p;
 }
 /* BACK half kick (nglf.c:100-104) fused with kinetic_terms (energy.c:48-163):
@@ -1120,7 +1121,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
       if (do_kick)
       {
          double a = (0.5 * dt) * invmass[sp];
-         x += a * fx[i]; y += a * fy[i]; z += a * fz[i];
+         x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
          vx[i] = x; vy[i] = y; vz[i] = z;
       }
       double m = massv[sp];
@@ -1128,6 +1129,38 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
       acc[0] = 0.5 * m * (vxx + vyy + vzz);
       acc[1] = m * vxx; acc[2] = m * vyy; acc[3] = m * vzz;
       acc[4] = m * (x * y); acc[5] = m * (x * z); acc[6] = m * (y * z);
+   }
+   block_reduce_store<7>(acc, partials + (size_t)blockIdx.x * 8);
+}
+/* The BACK half kick + kinetic terms of step n and the FRONT half kick + drift of step
+ * n+1 use the same forces: inside a batch of steps they are one pass over v and f
+ * (k_kick_ke followed by k_kick_drift, bit for bit). */
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double dt, const double *__restrict__ invmass, const double *__restrict__ massv,
+                                                               const int *__restrict__ species, const int *__restrict__ group, GroupLambda glambda,
+                                                               const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                                                               double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
+                                                               double4 *__restrict__ pos, double *__restrict__ partials)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+   if (i < nloc)
+   {
+      int sp = species[i];
+      double a = (0.5 * dt) * invmass[sp];
+      double f0 = fx[i], f1 = fy[i], f2 = fz[i];
+      double x = fma(a, f0, vx[i]), y = fma(a, f1, vy[i]), z = fma(a, f2, vz[i]);
+      double m = massv[sp];
+      double vxx = x * x, vyy = y * y, vzz = z * z;
+      acc[0] = 0.5 * m * (vxx + vyy + vzz);
+      acc[1] = m * vxx; acc[2] = m * vyy; acc[3] = m * vzz;
+      acc[4] = m * (x * y); acc[5] = m * (x * z); acc[6] = m * (y * z);
+      double lam = glambda.v[group[i] & 31];
+      if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
+      x = fma(a, f0, x); y = fma(a, f1, y); z = fma(a, f2, z);
+      vx[i] = x; vy[i] = y; vz[i] = z;
+      double4 p = pos[i];
+      p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
+      pos[i] = p;
    }
    block_reduce_store<7>(acc, partials + (size_t)blockIdx.x * 8);
 }
@@ -1900,10 +1933,14 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
 
 /* kinetic_terms (+ the BACK half kick); with_forces: the same launch also reduces the
  * nonbonded partials of the force evaluation just queued and forms the final energies */
-static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false)
+static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false, const GroupLambda *then_drift = nullptr)
 {
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK);
    ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
+   if (then_drift)
+      hipLaunchKernelGGL(k_kick_ke_drift, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p, ctx->group.p, *then_drift,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, ctx->kpartials.p);
+   else
    hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
                       ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, do_kick);
    RedJob jk = {ctx->kpartials.p, nblk, 7, ctx->d_results + R_RK, 0};
@@ -1937,27 +1974,42 @@ static void berendsen_update(ddcmi_ctx *ctx, double dt_half)
 }
 
 /* nglf.c:74-95: FRONT half kick + drift, clock advance */
-static int step_pre(ddcmi_ctx *ctx, double dt)
+static GroupLambda front_lambda(const ddcmi_ctx *ctx)
 {
-   int n = ctx->nloc, nb = cdiv(n, 256);
    GroupLambda lam;
    /* lambda applies at the FRONT kick when doScaling is set (berendsen.c:74-80) */
    for (int g = 0; g < 32; g++) lam.v[g] = (g < ctx->ngroup && ctx->gtype[g] == DDCMI_BERENDSEN && ctx->gdoScaling[g]) ? ctx->glambda[g] : 1.0;
-   if (n > 0)
-      hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
+   return lam;
+}
+static int step_pre(ddcmi_ctx *ctx, double dt)
+{
+   int n = ctx->nloc, nb = cdiv(n, 256);
+   if (!ctx->drift_done)
+   {
+      GroupLambda lam = front_lambda(ctx);
+      if (n > 0)
+         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam,
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
+   }
+   ctx->drift_done = false;             /* else: the previous step's last kernel already did this kick + drift */
    ctx->time += dt;
    ctx->loop += 1;
    ctx->halo_fresh = false;
    return DDCMI_OK;
 }
 /* nglf.c:97-108: ddcenergy, BACK half kick, kinetic_terms, group Update */
-static int step_post(ddcmi_ctx *ctx, double dt)
+static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
 {
    int rc;
    if ((rc = launch_forces(ctx, true))) return rc;
-   if ((rc = launch_kinetic(ctx, dt, 1, true))) return rc;
-   berendsen_update(ctx, 0.5 * dt);
+   berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
+   if (more_steps && ctx->nloc > 0)
+   {
+      GroupLambda lam = front_lambda(ctx);
+      if ((rc = launch_kinetic(ctx, dt, 1, true, &lam))) return rc;
+      ctx->drift_done = true;
+   }
+   else if ((rc = launch_kinetic(ctx, dt, 1, true))) return rc;
    return DDCMI_OK;
 }
 
@@ -1974,7 +2026,7 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
       /* ddcUpdateAll.c:64-71: rebuild when loop % updateRate == 0 */
       if (ctx->loop % ctx->updateRate == 0 || !ctx->list_valid)
          if ((rc = ddcmi_build_list(ctx))) return rc;
-      if ((rc = step_post(ctx, dt))) return rc;
+      if ((rc = step_post(ctx, dt, s + 1 < nsteps))) return rc;
    }
    return DDCMI_OK;
 }

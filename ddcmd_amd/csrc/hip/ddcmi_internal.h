@@ -134,6 +134,7 @@ struct ddcmi_ctx
    dbuf<unsigned short> nbr16; dbuf<unsigned int> tmp32; int tmpw = 0;
    unsigned long long arena_cap = 0;
    dbuf<double> kpartials;             /* per-workgroup kinetic terms (k_kick_ke) */
+   bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
    /* bonded */

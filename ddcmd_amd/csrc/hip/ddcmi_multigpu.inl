@@ -608,7 +608,7 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
       }
       if (rebuild) { if ((rc = group_rebuild(g))) return rc; }
       else if ((rc = group_refresh(g))) return rc;
-      for (ddcmi_ctx *c : g->ranks) if ((rc = step_post(c, dt))) return rc;
+      for (ddcmi_ctx *c : g->ranks) if ((rc = step_post(c, dt, s + 1 < nsteps))) return rc;
    }
    return DDCMI_OK;
 }

@@ -303,3 +303,25 @@ def test_exclude_potential_term_masks():
         for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
             assert abs(e[k] - e0[k]) < TIGHT * max(abs(e0[k]), 1e-9), (mask, k)
         m.close()
+
+
+def test_step_batching_is_bitwise_invariant():
+    """inside a batch the BACK kick of step n and the FRONT kick + drift of step n+1 run as one
+    kernel; 25 steps in one call, in 5 calls and in 25 calls must give identical bits"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(8, thermostat="berendsen")
+    out = []
+    for chunks in (1, 5, 25):
+        m = MartiniHIP(s)
+        m.eval_forces()
+        m.group_temperatures()
+        for _ in range(chunks):
+            m.step(25 // chunks)
+        d = m.download()
+        e, vir, rk, _ = m.energies()
+        out.append((np.stack(d["r"]), np.stack(d["v"]), np.stack(d["f"]), e["total"], rk))
+        m.close()
+    for other in out[1:]:
+        for a, b in zip(out[0][:3], other[:3]):
+            assert np.array_equal(a, b)
+        assert out[0][3] == other[3] and out[0][4] == other[4]
