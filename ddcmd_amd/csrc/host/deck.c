@@ -7,6 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <ctype.h>
+#include <unistd.h>
 #include <inttypes.h>
 
 #define FAIL(...) do { snprintf(err, errlen, __VA_ARGS__); goto fail; } while (0)
@@ -249,6 +250,11 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
    double velocity_convert = length_convert / time_convert;
    int cap = 0, n = 0;
    int nfiles = nfiles_hint > 0 ? nfiles_hint : 1;
+   /* column of each quantity in a record, from the header's field_names; default = the
+    * 10-field layout of the shipped decks.  Restart files written by collection_writeBLOCK
+    * (collection_write.c:57-186) lead with a checksum column and may append per-particle
+    * random/group state after vz, which this path does not use. */
+   int col_id = 0, col_type = 2, col_group = 3, col_r = 4, col_v = 7;
    for (int f = 0; f < nfiles; f++)
    {
       char fname[4096];
@@ -278,9 +284,21 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
          object_get(h, "nfiles", &nf, INT, 1, "1");
          nfiles = nf;
          object_get(h, "nrecord", &nrecord_here, INT, 1, "-1");
-         char *fmt = NULL;
-         if (object_testforkeyword(h, "field_format")) fmt = get_string(h, "field_format", "");
-         free(fmt);
+         if (object_testforkeyword(h, "field_names"))
+         {
+            char **names = NULL;
+            int nn = object_getv(h, "field_names", (void *)&names, STRING, IGNORE_IF_NOT_FOUND);
+            for (int k = 0; k < nn; k++)
+            {
+               if (strcmp(names[k], "id") == 0 || strcmp(names[k], "label") == 0) col_id = k;
+               else if (strcmp(names[k], "type") == 0) col_type = k;
+               else if (strcmp(names[k], "group") == 0) col_group = k;
+               else if (strcmp(names[k], "rx") == 0) col_r = k;
+               else if (strcmp(names[k], "vx") == 0) col_v = k;
+               free(names[k]);
+            }
+            free(names);
+         }
          object_free(h);
          p = buf + off;
       }
@@ -300,18 +318,28 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
                s->gid = realloc(s->gid, sizeof(uint64_t) * cap);
                s->species = realloc(s->species, sizeof(int) * cap); s->group = realloc(s->group, sizeof(int) * cap);
             }
-            char *end;
-            uint64_t label = strtoull(line, &end, 10);
-            char cls[64], spname[64], grname[64];
-            int consumed = 0;
-            if (sscanf(end, " %63s %63s %63s%n", cls, spname, grname, &consumed) != 3)
-            { snprintf(err, errlen, "%s: bad record '%s'", fname, line); free(buf); return -1; }
-            end += consumed;
+            /* split the record into whitespace-separated tokens (in place) */
+            char *tok[32];
+            int ntok = 0;
+            for (char *q = line; *q && ntok < 32;)
+            {
+               while (*q && isspace((unsigned char)*q)) q++;
+               if (!*q) break;
+               tok[ntok++] = q;
+               while (*q && !isspace((unsigned char)*q)) q++;
+               if (*q) *q++ = 0;
+            }
+            int need = col_v + 3;
+            if (col_r + 3 > need) need = col_r + 3;
+            if (ntok < need || col_id >= ntok || col_type >= ntok || col_group >= ntok)
+            { snprintf(err, errlen, "%s: record %d has %d fields, expected at least %d", fname, n, ntok, need); free(buf); return -1; }
+            uint64_t label = strtoull(tok[col_id], NULL, 10);
+            const char *spname = tok[col_type], *grname = tok[col_group];
             int sp = find_name(s->species_name, s->nspecies, spname);
             int gr = find_name(s->group_name, s->ngroup, grname);
             if (sp < 0 || gr < 0) { snprintf(err, errlen, "%s: unknown species '%s' or group '%s'", fname, spname, grname); free(buf); return -1; }
             double v[6];
-            for (int k = 0; k < 6; k++) v[k] = strtod(end, &end);
+            for (int k = 0; k < 3; k++) { v[k] = strtod(tok[col_r + k], NULL); v[3 + k] = strtod(tok[col_v + k], NULL); }
             s->gid[n] = label; s->species[n] = sp; s->group[n] = gr;
             s->rx[n] = length_convert * v[0]; s->ry[n] = length_convert * v[1]; s->rz[n] = length_convert * v[2];
             s->vx[n] = velocity_convert * v[3]; s->vy[n] = velocity_convert * v[4]; s->vz[n] = velocity_convert * v[5];
@@ -710,7 +738,34 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       OBJECT *co = cname ? object_find(cname, "COLLECTION") : NULL;
       if (!co) FAIL("COLLECTION object not found (is the restart file present?)");
       char *files = get_string(co, "files", "snapshot.mem/atoms#");
+      /* ddcMD resolves the path against its working directory = the deck directory.  Tried in
+       * turn: the object file's directory, the working directory, the restart file's directory and its parent */
       char *base = path_join(dir, files);
+      char probe[4200];
+      snprintf(probe, sizeof(probe), "%s%06d", base, 0);
+      if (files[0] != '/' && access(probe, R_OK) != 0)
+      {
+         snprintf(probe, sizeof(probe), "%s%06d", files, 0);
+         if (access(probe, R_OK) == 0) { free(base); base = strdup(files); }
+         else if (restart_file)
+         {
+            char *rdir = dir_of(restart_file);
+            char *alt = path_join(rdir, files);
+            snprintf(probe, sizeof(probe), "%s%06d", alt, 0);
+            if (access(probe, R_OK) == 0) { free(base); base = alt; }
+            else
+            {
+               /* snapshot.<loop>/restart names snapshot.<loop>/atoms# relative to the run directory */
+               free(alt);
+               char *rrdir = dir_of(rdir);
+               alt = path_join(rrdir, files);
+               snprintf(probe, sizeof(probe), "%s%06d", alt, 0);
+               if (access(probe, R_OK) == 0) { free(base); base = alt; } else free(alt);
+               free(rrdir);
+            }
+            free(rdir);
+         }
+      }
       int rc = read_atoms(s, base, 0, err, errlen);
       free(base); free(files); free(cname);
       if (rc != 0) goto fail;

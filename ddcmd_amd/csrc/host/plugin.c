@@ -7,6 +7,9 @@
 #include <string.h>
 #include <math.h>
 #include <inttypes.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <time.h>
 
 static ACCELERATOR *the_accelerator = NULL;
 
@@ -237,6 +240,105 @@ int sendHostState(SYSTEM *sys)
 }
 
 /* ------------------------------------------------------------------------- */
+/* restart writer */
+static uint32_t crc32_ieee(const unsigned char *p, size_t n)
+{
+   /* CRC-32 (IEEE 802.3, reflected 0xEDB88320) -- what pio's "CRC32" names; the util
+    * library with checksum_crc32_table is not in the reference tree, so this is the
+    * published algorithm, unverified against a ddcMD-written file */
+   static uint32_t table[256];
+   static int have = 0;
+   if (!have)
+   {
+      for (uint32_t i = 0; i < 256; i++)
+      {
+         uint32_t c = i;
+         for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+         table[i] = c;
+      }
+      have = 1;
+   }
+   uint32_t c = 0xFFFFFFFFu;
+   for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+   return c ^ 0xFFFFFFFFu;
+}
+
+int writeRestart(SIMULATE *simulate, const char *dir, int restartLink)
+{
+   SYSTEM *sys = simulate->system;
+   STATE *st = sys->state;
+   if (sendHostState(sys) != DDCMI_OK) return -1;
+   if (dir) snprintf(simulate->snapshotdir, sizeof(simulate->snapshotdir), "%s", dir);
+   else snprintf(simulate->snapshotdir, sizeof(simulate->snapshotdir), "snapshot.%012" PRId64, simulate->loop);    /* loopFormat, io.c:128-129 */
+   mkdir(simulate->snapshotdir, 0777);
+   char path[1024];
+   snprintf(path, sizeof(path), "%s/atoms#000000", simulate->snapshotdir);
+   FILE *f = fopen(path, "w");
+   if (!f) return -1;
+   const double cLen = units_convert(1.0, NULL, "l"), cVel = cLen / units_convert(1.0, NULL, "t");
+   const char *fmt = "%08x %12.12" PRIu64 " %s %s %s %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e";
+   /* record length: longest possible record, terminator, padded to 8 bytes (collection_write.c:87-96) */
+   size_t maxsp = 1, maxgr = 1;
+   for (int i = 0; i < sys->nspecies; i++) if (strlen(sys->species[i]->name) > maxsp) maxsp = strlen(sys->species[i]->name);
+   for (int g = 0; g < sys->ngroup; g++) if (strlen(sys->group[g]->name) > maxgr) maxgr = strlen(sys->group[g]->name);
+   char line[1024];
+   int lrec = snprintf(line, sizeof(line), fmt, 0u, (uint64_t)0, "ATOM", " ", " ", -1.0e-100, -1.0e-100, -1.0e-100, -1.0e-100, -1.0e-100, -1.0e-100);
+   lrec += (int)(maxsp - 1) + (int)(maxgr - 1) + 1;
+   lrec = 8 * ((lrec + 7) / 8);
+   const double *h = sys->box->h0;
+   time_t now = time(NULL);
+   char stamp[64];
+   strftime(stamp, sizeof(stamp), "%Y-%m-%d-%H:%M:%S", localtime(&now));
+   int key;
+   memcpy(&key, "1234", 4);
+   fprintf(f, "particle FILEHEADER {type=MULTILINE; datatype=FIXRECORDASCII; checksum=CRC32; create_time=%s; run_id=0x%08x;\n", stamp, 0u);
+   fprintf(f, "code_version=%s; srcpath=libddcmi;\n", ddcmi_version());
+   fprintf(f, "loop=%" PRId64 "; time=%f fs;\n", simulate->loop, units_convert(simulate->time, NULL, "t"));
+   fprintf(f, "nfiles=1; nrecord=%d; lrec=%d; nfields=11; endian_key=%d;\n", st->nlocal, lrec, key);
+   fprintf(f, "field_names=checksum id class type group rx ry rz vx vy vz;\n");
+   fprintf(f, "field_types=u u s s s f f f f f f;\n");
+   fprintf(f, "field_units=1 1 1 1 1 Ang Ang Ang Ang/fs Ang/fs Ang/fs;\n");
+   fprintf(f, "field_format=%s;\n", fmt);
+   fprintf(f, "reducedcorner=%21.14f %21.14f %21.14f;\n", -0.5, -0.5, -0.5);
+   fprintf(f, "h=%21.14f %21.14f %21.14f\n  %21.14f %21.14f %21.14f\n  %21.14f %21.14f %21.14f Ang;\n",
+           h[0] * cLen, h[1] * cLen, h[2] * cLen, h[3] * cLen, h[4] * cLen, h[5] * cLen, h[6] * cLen, h[7] * cLen, h[8] * cLen);
+   fprintf(f, "random = NONE;\nrandomFieldSize = 0;\ngroups =");
+   for (int g = 0; g < sys->ngroup; g++) fprintf(f, " %s", sys->group[g]->name);
+   fprintf(f, ";\nspecies =");
+   for (int i = 0; i < sys->nspecies; i++) fprintf(f, " %s", sys->species[i]->name);
+   fprintf(f, ";\ntypes = ATOM;\n}\n\n");
+   for (int i = 0; i < st->nlocal; i++)
+   {
+      /* positions come back wrapped into the box (ddcmi_download_state = backInBox) */
+      int len = snprintf(line, sizeof(line), fmt, 0u, (uint64_t)st->label[i], "ATOM", st->species[i]->name, st->group[i]->name,
+                         st->rx[i] * cLen, st->ry[i] * cLen, st->rz[i] * cLen, st->vx[i] * cVel, st->vy[i] * cVel, st->vz[i] * cVel);
+      if (len > lrec - 1) { fclose(f); return -1; }
+      for (int l = len; l < lrec; l++) line[l] = ' ';
+      line[lrec - 1] = '\n';
+      char tmp[16];
+      snprintf(tmp, sizeof(tmp), "%08x", crc32_ieee((const unsigned char *)line + 8, (size_t)lrec - 8));
+      memcpy(line, tmp, 8);
+      if (fwrite(line, 1, (size_t)lrec, f) != (size_t)lrec) { fclose(f); return -1; }
+   }
+   if (fclose(f) != 0) return -1;
+   snprintf(path, sizeof(path), "%s/restart", simulate->snapshotdir);
+   f = fopen(path, "w");
+   if (!f) return -1;
+   fprintf(f, "%s SIMULATE { run_id=0x%08x; loop=%" PRId64 "; time=%f fs;}\n", simulate->name, 0u, simulate->loop, units_convert(simulate->time, NULL, "t"));
+   /* box_write, box.c:91-108 */
+   fprintf(f, "box BOX {\n h  = %21.14e %21.14e %21.14e\n      %21.14e %21.14e %21.14e\n      %21.14e %21.14e %21.14e;\n}\n",
+           h[0] * cLen, h[1] * cLen, h[2] * cLen, h[3] * cLen, h[4] * cLen, h[5] * cLen, h[6] * cLen, h[7] * cLen, h[8] * cLen);
+   fprintf(f, "collection COLLECTION { size=%" PRIu64 "; files=%s/atoms#;}\n", (uint64_t)sys->nglobal, simulate->snapshotdir);
+   if (fclose(f) != 0) return -1;
+   if (restartLink)
+   {
+      unlink("restart");
+      if (symlink(path, "restart") != 0) return -1;
+   }
+   return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* simulate_init (simulate.c:104-297) + system_init (system.c:79-214) from the deck */
 SIMULATE *simulate_init(const char *object_file, const char *restart_file, const char *extra, char *err, int errlen)
 {
@@ -246,6 +348,7 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
    sim->name = strdup("simulate");
    sim->setup = s;
    sim->loop = s->loop; sim->maxloop = s->maxloop; sim->time = s->time; sim->dt = s->dt; sim->printrate = s->printrate > 0 ? s->printrate : 1;
+   sim->snapshotrate = s->snapshotrate; sim->checkpointrate = s->checkpointrate;
    SYSTEM *sys = sim->system = calloc(1, sizeof(SYSTEM));
    sys->name = strdup("system");
    sys->nspecies = s->nspecies;
@@ -339,6 +442,11 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
    while (simulate->loop < simulate->maxloop)
    {
       int64_t endLoop = (simulate->loop / simulate->printrate + 1) * simulate->printrate;
+      if (simulate->checkpointrate > 0)
+      {
+         int64_t nextCk = (simulate->loop / simulate->checkpointrate + 1) * simulate->checkpointrate;      /* masters.c:275-276 */
+         if (nextCk < endLoop) endLoop = nextCk;
+      }
       if (endLoop > simulate->maxloop) endLoop = simulate->maxloop;
       while (simulate->loop < endLoop)
          simulate->integrator->eval_integrator(simulate->ddc, simulate, simulate->integrator->parms);
@@ -357,6 +465,8 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
          break;
       }
       if (simulate->loop % simulate->printrate == 0) printinfo(simulate, e, 0);
+      if (simulate->checkpointrate > 0 && simulate->loop % simulate->checkpointrate == 0)      /* masters.c:318-322 */
+         if (writeRestart(simulate, NULL, 1) != 0) die("simulateMaster", "writeRestart failed");
    }
    sendHostState(sys);
    if (simulate->datafile) fclose(simulate->datafile);

@@ -110,7 +110,8 @@ typedef struct simulate_st
    DDC *ddc;
    int64_t loop, maxloop;
    double time, dt;
-   int printrate;
+   int printrate, snapshotrate, checkpointrate;
+   char snapshotdir[512];
    ddcmi_setup *setup;                  /* the parsed deck */
    FILE *datafile;
 } SIMULATE;
@@ -135,6 +136,10 @@ void simulate_free(SIMULATE *simulate);
 void printinfo(SIMULATE *simulate, ETYPE *energyInfo, int header);
 /* copy device state back into STATE (sendForceVelocityToHost + sendPosnToHost) */
 int sendHostState(SYSTEM *sys);
+/* writeRestart (io.c:58-113) + collection_writeBLOCK (collection_write.c:57-186): copies the state
+ * back, writes <dir>/atoms#000000 (FIXRECORDASCII, CRC32 column) and <dir>/restart; dir = NULL
+ * names it snapshot.<loop> (CreateSnapshotdir, io.c:115-142); restartLink: ./restart -> it */
+int writeRestart(SIMULATE *simulate, const char *dir, int restartLink);
 
 #ifdef __cplusplus
 }

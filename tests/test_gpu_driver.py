@@ -47,3 +47,41 @@ def test_ddcmi_md_rejects_unsupported_integrator(tmp_path):
     out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d"), "-x", "nglf INTEGRATOR {type = NGLFCONSTRAINT;}"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "NGLFCONSTRAINT" in out.stderr
+
+
+def test_ddcmi_md_checkpoint_restart(tmp_path):
+    """checkpointrate: the driver writes snapshot.<loop>/{atoms#000000,restart} in ddcMD's restart format
+    (io.c:58-113, collection_write.c:57-186) and ./restart; a second run from that restart continues the
+    trajectory: its final state equals the oracle's uninterrupted 40 steps"""
+    s0 = load_deck(DECK)
+    cwd = str(tmp_path)
+    x1 = "simulate SIMULATE { maxloop = 20; checkpointrate = 20; printrate = 10; }"
+    out = subprocess.run([EXE, "-o", DECK, "-d", "data1", "-x", x1], capture_output=True, text=True, timeout=300, cwd=cwd)
+    assert out.returncode == 0, out.stdout + out.stderr
+    snap = os.path.join(cwd, "snapshot.%012d" % 20)
+    assert os.path.isfile(os.path.join(snap, "atoms#000000")) and os.path.islink(os.path.join(cwd, "restart"))
+    head = open(os.path.join(snap, "atoms#000000")).read(600)
+    assert "datatype=FIXRECORDASCII" in head and "field_names=checksum id class type group rx ry rz vx vy vz;" in head
+    s1 = load_deck(DECK, restart_file=os.path.join(cwd, "restart"))
+    assert s1.loop == 20 and s1.natoms == s0.natoms and np.array_equal(s1.gid, s0.gid)
+    o = pyoracle.Oracle(s0)
+    o.forces()
+    o.step(20)
+    L = np.array([s0.h[0], s0.h[4], s0.h[8]])
+    for c, (a, b) in enumerate(((s1.rx, o.rx), (s1.ry, o.ry), (s1.rz, o.rz))):
+        d = a - b
+        d -= L[c] * np.rint(d / L[c])
+        assert np.abs(d).max() < 1e-7
+    assert np.abs(s1.vx - o.vx).max() < 1e-7 * np.abs(o.vx).max()
+    # continue from the checkpoint for 20 more steps, checkpoint again, compare with the uninterrupted oracle
+    x2 = "simulate SIMULATE { maxloop = 40; checkpointrate = 20; printrate = 10; }"
+    out = subprocess.run([EXE, "-o", DECK, "-r", "restart", "-d", "data2", "-x", x2], capture_output=True, text=True, timeout=300, cwd=cwd)
+    assert out.returncode == 0, out.stdout + out.stderr
+    s2 = load_deck(DECK, restart_file=os.path.join(cwd, "snapshot.%012d" % 40, "restart"))
+    assert s2.loop == 40
+    o.step(20)
+    for c, (a, b) in enumerate(((s2.rx, o.rx), (s2.ry, o.ry), (s2.rz, o.rz))):
+        d = a - b
+        d -= L[c] * np.rint(d / L[c])
+        assert np.abs(d).max() < 1e-6
+    assert np.abs(s2.vz - o.vz).max() < 1e-6 * np.abs(o.vz).max()

@@ -233,3 +233,35 @@ def test_lipid_oracle_finite_difference_all_terms():
             fd = -(ep - em) / (2 * delta)
             worst = max(worst, abs(fd - f0[c, i]) / np.abs(f0).max())
     assert worst < 2e-7
+
+
+def test_atoms_reader_follows_field_names(tmp_path):
+    """restart files written by collection_writeBLOCK lead with a checksum column and are fixed-record:
+    the reader takes the columns from the header's field_names (collection_write.c:57-186 layout)"""
+    import os
+    from ddcmd_amd.deck import load_deck, units_convert
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s0 = load_deck(os.path.join(deck, "object.data"))
+    A = units_convert(1.0, None, "Angstrom")
+    snap = tmp_path / "snapshot.000000000040"
+    snap.mkdir()
+    with open(snap / "atoms#000000", "w") as f:
+        f.write("particle FILEHEADER {type=MULTILINE; datatype=FIXRECORDASCII; checksum=CRC32; create_time=x; run_id=0x00000000;\n"
+                "loop=40; time=400.000000 fs;\nnfiles=1; nrecord=%d; lrec=232; nfields=11; endian_key=875770417;\n"
+                "field_names=checksum id class type group rx ry rz vx vy vz;\nfield_types=u u s s s f f f f f f;\n"
+                "field_units=1 1 1 1 1 Ang Ang Ang Ang/fs Ang/fs Ang/fs;\n"
+                "h=%f 0 0\n  0 %f 0\n  0 0 %f Ang;\nrandom = NONE;\nrandomFieldSize = 0;\ngroups = group;\ntypes = ATOM;\n}\n\n"
+                % (s0.natoms, s0.h[0] * A, s0.h[4] * A, s0.h[8] * A))
+        for i in range(s0.natoms):
+            rec = "%08x %12.12d ATOM %s group %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e" % (
+                0xdeadbeef, int(s0.gid[i]), s0.species_name[int(s0.species[i])], s0.rx[i] * A, s0.ry[i] * A, s0.rz[i] * A,
+                s0.vx[i] * A, s0.vy[i] * A, s0.vz[i] * A)
+            f.write(rec.ljust(231) + "\n")
+    with open(tmp_path / "restart", "w") as f:
+        f.write("simulate SIMULATE { run_id=0x0; loop=40; time=400.000000 fs;}\nbox BOX {\n h  = %.14e 0 0\n 0 %.14e 0\n 0 0 %.14e;\n}\n"
+                "collection COLLECTION { size=%d; files=snapshot.000000000040/atoms#;}\n" % (s0.h[0] * A, s0.h[4] * A, s0.h[8] * A, s0.natoms))
+    s = load_deck(os.path.join(deck, "object.data"), restart_file=str(tmp_path / "restart"))
+    assert s.natoms == s0.natoms and s.loop == 40
+    assert np.array_equal(s.gid, s0.gid) and np.array_equal(s.species, s0.species)
+    for a, b in ((s.rx, s0.rx), (s.ry, s0.ry), (s.rz, s0.rz), (s.vx, s0.vx), (s.vz, s0.vz)):
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-300)
