@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--workload", choices=("water", "lipid"), default="water",
                     help="water: the headline Martini water box; lipid: tests/golden/lipid_deck (DPPC-style bilayer patch in water, "
                          "all bonded term kinds, charges, Berendsen) tiled --reps times")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="N=1 only: reach the periodic images through a 1-rank RCCL communicator (the multi-GPU transport on one GPU)")
     ap.add_argument("--reps", default="12,12,6", help="lipid workload: copies of the 2363-bead deck along x,y,z (12,12,6 -> 2.04M beads)")
     args = ap.parse_args()
 
@@ -108,7 +110,14 @@ def main():
     grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
     if grid is None:
         raise SystemExit("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)")
-    if world == 1:
+    if world == 1 and args.rccl_loopback:
+        os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
+        m = MartiniRank(s, np.arange(s.natoms), device=local_rank)
+        buf = ctypes.create_string_buffer(128)
+        assert m.lib.ddcmi_comm_unique_id(buf) == 0
+        m.comm_init(0, 1, buf.raw, (1, 1, 1))
+        m.upload_local()
+    elif world == 1:
         m = MartiniHIP(s, device=local_rank)
     else:
         # spatial decomposition: this rank uploads the beads of its brick; halo exchange
@@ -185,7 +194,7 @@ def main():
                    "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
                    "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
                    "energy_virial_every_step": True,
-                   "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo" % grid) if world > 1 else "single GPU",
+                   "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo" % grid) if world > 1 else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),
                    "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
         "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

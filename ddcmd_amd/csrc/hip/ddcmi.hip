@@ -1734,7 +1734,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
    (void)hipSetDevice(ctx->device);
    int rc;
-   if (ctx->nranks > 1) return ddcmi_mg_rebuild(ctx);
+   if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
    if ((rc = bl_self_images(ctx))) return rc;
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
@@ -1840,7 +1840,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
-   if (ctx->nranks > 1 && !ctx->halo_fresh)
+   if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh)
    {
       int rc0 = ddcmi_mg_refresh_halo(ctx);
       if (rc0) return rc0;
@@ -2064,7 +2064,7 @@ int ddcmi_group_ke_sums(ddcmi_ctx *ctx)
    if (n > 0)
       hipLaunchKernelGGL(k_group_ke, dim3(cdiv(n, DDCMI_BLOCK)), dim3(DDCMI_BLOCK), 0, st, n, ng, ctx->d_mass.p, ctx->species.p, ctx->group.p,
                          ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->d_results + R_GROUP);
-   if (ctx->nranks > 1 && ctx->comm && !ctx->group_ && ng > 0)
+   if ((ctx->nranks > 1 || ctx->loopback) && ctx->comm && !ctx->group_ && ng > 0)
       if (ncclAllReduce(ctx->d_results + R_GROUP, ctx->d_results + R_GROUP, 2 * ng, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st) != ncclSuccess)
          SETERR(ctx, DDCMI_ECOMM, "ncclAllReduce of the group kinetic energies failed");
    return fetch_results(ctx);

@@ -57,6 +57,11 @@ struct GridParams
    int ncell;        /* T0*T1*T2*TCELLS */
 };
 
+/* segments of a halo send/recv buffer in BUFFER order: seg q holds direction code[q] and
+ * starts at off[q].  Remote segments are ordered by (peer rank, direction code), so everything
+ * for one peer is contiguous and travels as ONE message per step. */
+struct SegTab { int off[28]; signed char code[28]; int nseg; };
+
 template <class T> struct dbuf
 {
    T *p = nullptr;
@@ -161,6 +166,8 @@ struct ddcmi_ctx
    int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
    struct ddcmi_group *group_ = nullptr;        /* in-process multi-domain emulation (tests) */
    bool halo_fresh = false;
+   SegTab sseg, rseg;                  /* halo send / receive buffer layout (peer-major) */
+   bool loopback = false;              /* one rank whose periodic neighbours are reached through RCCL (test facility, DDCMI_RCCL_LOOPBACK=1) */
    int dir_dest[27], dir_shift[27][3];            /* 26 neighbour directions, code = (dx+1)+3(dy+1)+9(dz+1) */
    int hs_cap = 0, mig_cap = 0;
    dbuf<int> hs_idx, dir_cnt;                      /* halo send lists per direction */

@@ -1,0 +1,79 @@
+"""GPU test (-m gpu) of the RCCL transport on ONE GPU: with DDCMI_RCCL_LOOPBACK=1 a single rank
+reaches its periodic neighbours through a 1-rank RCCL communicator instead of local image copies,
+so the count exchange, the grouped ncclSend/ncclRecv of migration, halo build and per-step halo
+refresh, the message-matching order and ncclAllReduce all execute for real.  (A multi-GPU node is
+not available to the tests; the in-process group of test_gpu_domains.py covers the multi-domain
+logic, this covers the wire.)"""
+import ctypes
+import os
+import numpy as np
+import pytest
+
+import pyoracle
+from ddcmd_amd.synth import make_water_setup
+from conftest import rel_force_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _loopback_rank(s, monkeypatch):
+    from ddcmd_amd.martini import MartiniRank, _declare_domains
+    monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
+    m = MartiniRank(s, np.arange(s.natoms))
+    _declare_domains(m.lib)
+    buf = ctypes.create_string_buffer(128)
+    assert m.lib.ddcmi_comm_unique_id(buf) == 0
+    m.comm_init(0, 1, buf.raw, (1, 1, 1))
+    m.upload_local()
+    return m
+
+
+def test_water_through_rccl_loopback(monkeypatch):
+    s = make_water_setup(12)
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    m = _loopback_rank(s, monkeypatch)
+    e, vir = m.eval_forces()
+    p = m.download_particles()
+    order = np.argsort(p["gid"], kind="stable")
+    f = [p["f"][c][order] for c in range(3)]
+    assert np.array_equal(p["gid"][order], np.sort(s.gid))
+    assert rel_force_err(f, (o.fx, o.fy, o.fz)) < 1e-10
+    assert abs(e["lj"] - e0["lj"]) < 1e-10 * abs(e0["lj"])
+    # 45 steps: beads leave the box and come back in through the migration messages
+    for block in range(3):
+        eo, vo, rko, _ = o.step(15)
+        m.step(15)
+        e, vir, rk, _ = m.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko
+    tot = m.allreduce([1.0, 2.5])          # ncclAllReduce over the 1-rank communicator
+    assert tot[0] == 1.0 and tot[1] == 2.5
+    assert int(m.lib.ddcmi_nlocal(m.ctx)) == s.natoms
+    m.close()
+
+
+def test_lipid_deck_through_rccl_loopback(monkeypatch):
+    """bonded terms by gid + Berendsen group temperature (all-reduced) over the loopback wire"""
+    from ddcmd_amd.deck import load_deck
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    o.group_temperature()
+    m = _loopback_rank(s, monkeypatch)
+    e, vir = m.eval_forces()
+    for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
+        assert abs(e[k] - e0[k]) < 1e-9 * max(abs(e0[k]), 1e-12), k
+    Tg = m.group_temperatures()
+    assert abs(Tg[0] - o.groups[0].temperature) < 1e-10 * Tg[0]
+    for block in range(2):
+        eo, vo, rko, _ = o.step(10)
+        m.step(10)
+        e, vir, rk, _ = m.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko
+        o.group_temperature()
+        m.group_temperatures()
+    m.close()
