@@ -296,6 +296,7 @@ struct ShellCuts { float r0, inv_w; };
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
+   int nloc;                            /* staged indices >= nloc are image/halo beads */
    int pack_type;                       /* entries are (staged slot << 4) | LJ type (nlj <= 16, cap < 4096); else the bare slot */
    const int *cell_start_o;             /* owned beads per cell: exclusive scan, [ncell+1] */
    const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges */
@@ -314,7 +315,8 @@ struct NbTileArgs
    const long long *tile_base; const int *tile_width, *tile_rows;
    const unsigned short *nbr16;
    const int *nbr_cnt;
-   const int *sched;                    /* [9] tile range of each XCD (k_tile_schedule) */
+   const int *sched;                    /* [9] range of each XCD in perm[] (schedule_tiles) */
+   const int *perm;                     /* tile order: [interior tiles | tiles that stage image/halo beads] */
    int rot;                             /* tuning builds: rotate the range -> XCD assignment */
 };
 
@@ -343,6 +345,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    static_assert(CPT * TB_THREADS >= NRC && TB_THREADS >= 256, "region cell count / block size mismatch");
    int v[CPT], g[CPT];
    int vsum = 0;
+   __shared__ int s_halo;
+   if (threadIdx.x == 0) s_halo = 0;
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
@@ -357,8 +361,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       }
       vsum += v[h];
    }
+   /* does the neighbourhood hold image/halo beads?  (k_nonbond may run such tiles after the halo exchange) */
+   bool halo_here = false;
+#pragma unroll
+   for (int h = 0; h < CPT; h++) halo_here |= (v[h] > 0 && g[h] >= ta.nloc);
    int tot;
-   int ex = block_excl_scan<TB_THREADS / 64>(vsum, &tot, s_w);
+   int ex = block_excl_scan<TB_THREADS / 64>(vsum, &tot, s_w);          /* (its barriers also order the s_halo reset) */
+   if (halo_here) s_halo = 1;
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
@@ -526,56 +535,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       while (R > 1 && (R >> 1) * NWAVES >= nown) R >>= 1;
       int npass = ((nown + R - 1) / R + NWAVES - 1) / NWAVES;
       int ngrp = (ta.tile_width[t] + 7) >> 3, parts = 64 / R;
-      ta.tile_work[t] = npass * ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES + (5 * tot) / 2 + 1;
-   }
-}
-
-/* Split the tiles (raster order) into 8 contiguous ranges of equal estimated work,
- * one per XCD: the hardware deals workgroups round-robin over the XCDs, so k_nonbond
- * maps workgroup b to the (b>>3)-th tile of range b&7.  Equal COUNTS would leave the
- * XCDs that own the thin edge tiles idle at the end of the launch.  sched[0..8] =
- * range starts, flags[6] = longest range. */
-#define SCHED_THREADS 1024
-__global__ __launch_bounds__(SCHED_THREADS) void k_tile_schedule(int ntile, const int *__restrict__ work, int *__restrict__ sched, int *flags)
-{
-   __shared__ unsigned long long s_sum[SCHED_THREADS];
-   __shared__ int s_start[9];
-   int seg = (ntile + SCHED_THREADS - 1) / SCHED_THREADS;
-   int t0 = min(ntile, (int)threadIdx.x * seg), t1 = min(ntile, t0 + seg);
-   unsigned long long mine = 0;
-   for (int t = t0; t < t1; t++) mine += (unsigned long long)work[t];
-   s_sum[threadIdx.x] = mine;
-   if (threadIdx.x < 9) s_start[threadIdx.x] = (threadIdx.x == 8) ? ntile : 0;
-   __syncthreads();
-   /* exclusive prefix of the segment sums: Hillis-Steele over the shared array */
-   for (int off = 1; off < SCHED_THREADS; off <<= 1)
-   {
-      unsigned long long v = (threadIdx.x >= (unsigned)off) ? s_sum[threadIdx.x - off] : 0ull;
-      __syncthreads();
-      s_sum[threadIdx.x] += v;
-      __syncthreads();
-   }
-   unsigned long long W = s_sum[SCHED_THREADS - 1];
-   unsigned long long run = s_sum[threadIdx.x] - mine;          /* work before tile t0 */
-   for (int t = t0; t < t1; t++)
-   {
-      unsigned long long nxt = run + (unsigned long long)work[t];
-      /* range x starts at the first tile whose preceding work reaches x*W/8 */
-      for (int x = 1; x < 8; x++)
-      {
-         unsigned long long target = (W * (unsigned long long)x) >> 3;
-         if (run < target && nxt >= target) s_start[x] = t + 1;
-      }
-      run = nxt;
-   }
-   __syncthreads();
-   if (threadIdx.x == 0)
-   {
-      int longest = 0;
-      for (int x = 1; x < 9; x++) s_start[x] = max(s_start[x], s_start[x - 1]);     /* ranges may be empty, never reversed */
-      for (int x = 0; x < 9; x++) sched[x] = s_start[x];
-      for (int x = 0; x < 8; x++) longest = max(longest, s_start[x + 1] - s_start[x]);
-      flags[6] = longest;
+      ta.tile_work[t] = (npass * ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES + (5 * tot) / 2 + 1) | (s_halo ? (1 << 30) : 0);      /* bit 30: stages image/halo beads */
    }
 }
 
@@ -780,7 +740,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)smem != 0u) __builtin_trap();
    const unsigned q_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)q_s;
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
-    * give XCD x one contiguous tile range (k_tile_schedule: equal work per XCD):
+    * give XCD x one contiguous tile range (schedule_tiles: equal work per XCD):
     * neighbouring tiles, which stage overlapping neighbourhoods, then share one L2.
     * Speed only. */
    TRACE_MARK(0);
@@ -798,8 +758,9 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
 #else
    const int xcd = blockIdx.x & 7;
 #endif
-   const int t = ta.sched[xcd] + (int)(blockIdx.x >> 3);
-   const bool mine = t < ta.sched[xcd + 1];
+   const int slot = ta.sched[xcd] + (int)(blockIdx.x >> 3);
+   const bool mine = slot < ta.sched[xcd + 1];
+   const int t = mine ? ta.perm[slot] : 0;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* vLJ, vEle, xx,yy,zz,xy,xz,yz */
    int nown = 0, ts = 0;
    if (mine)
@@ -1312,7 +1273,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
-   { const char *nbv = getenv("DDCMI_NB_BLOCK"); if (nbv) ctx->nb_block = atoi(nbv); }
+   { const char *ov = getenv("DDCMI_HALO_OVERLAP"); ctx->halo_overlap = (ov && atoi(ov) != 0); }
    ctx->gtype.assign(1, DDCMI_FREE); ctx->ginterval.assign(1, 1); ctx->gTeq.assign(1, 0); ctx->gtau.assign(1, 0);
    ctx->glambda.assign(1, 1.0); ctx->gTsum.assign(1, 0); ctx->gT.assign(1, 0); ctx->gnT.assign(1, 0); ctx->gdoScaling.assign(1, 0);
    *out = ctx;
@@ -1332,7 +1293,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->cell_cnt_o, &ctx->cell_start_o,
                       &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt, &ctx->nimg, &ctx->img_off, &ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank,
                       &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt,
-                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched,
+                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched, &ctx->tile_perm,
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
@@ -1340,6 +1301,9 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+   if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
+   if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
+   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -1741,6 +1705,60 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    return ddcmi_bl_finish(ctx);
 }
 
+/* Tile order and XCD ranges of k_nonbond, on the host from the per-tile cost estimates
+ * (ntile ints read back with the rebuild's other flags).  The hardware deals workgroups
+ * round-robin over the 8 XCDs; workgroup b takes the (b>>3)-th tile of range b&7, a
+ * contiguous run of perm[] with 1/8 of the class's estimated work -- equal COUNTS would
+ * leave the XCDs that own the thin edge tiles idle at the end of a launch.  Decomposed runs
+ * can order the tiles in two classes, each with its own ranges: tiles whose neighbourhood is
+ * all owned beads run while the halo exchange is in flight, the others after it
+ * (DDCMI_HALO_OVERLAP=1; off by default: on one GPU through the RCCL loopback the split costs
+ * more -- two launch tails, the exchange competing for the CUs -- than the 40 us it hides). */
+static int schedule_tiles(ddcmi_ctx *ctx)
+{
+   const int ntile = ctx->ntile;
+   std::vector<int> work(ntile), perm(ntile), sched(32, 0);
+   HIPCHK(ctx, hipMemcpyAsync(work.data(), ctx->tile_work.p, (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   const bool two = ctx->halo_overlap && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
+   int n0 = 0;
+   if (two)
+   {
+      for (int t = 0; t < ntile; t++) if (!(work[t] >> 30)) perm[n0++] = t;
+      int k = n0;
+      for (int t = 0; t < ntile; t++) if (work[t] >> 30) perm[k++] = t;
+   }
+   else { for (int t = 0; t < ntile; t++) perm[t] = t; n0 = ntile; }
+   auto split = [&](int lo, int hi, int *out, int *longest)
+   {
+      unsigned long long W = 0, run = 0;
+      for (int q = lo; q < hi; q++) W += (unsigned)(work[perm[q]] & 0x3fffffff);
+      for (int x = 0; x < 9; x++) out[x] = (x == 8) ? hi : lo;
+      for (int q = lo; q < hi; q++)
+      {
+         unsigned long long nxt = run + (unsigned)(work[perm[q]] & 0x3fffffff);
+         for (int x = 1; x < 8; x++)
+         {
+            unsigned long long target = (W * (unsigned long long)x) >> 3;
+            if (run < target && nxt >= target) out[x] = q + 1;
+         }
+         run = nxt;
+      }
+      for (int x = 1; x < 9; x++) out[x] = std::max(out[x], out[x - 1]);
+      *longest = 0;
+      for (int x = 0; x < 8; x++) *longest = std::max(*longest, out[x + 1] - out[x]);
+   };
+   split(0, n0, &sched[0], &ctx->sched_longest[0]);
+   split(n0, ntile, &sched[16], &ctx->sched_longest[1]);
+   ctx->ntile_class[0] = n0; ctx->ntile_class[1] = ntile - n0;
+   ENSURE(ctx, ctx->tile_perm, (size_t)ntile + 1);
+   ENSURE(ctx, ctx->sched, 32);
+   HIPCHK(ctx, hipMemcpyAsync(ctx->tile_perm.p, perm.data(), (size_t)ntile * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+   HIPCHK(ctx, hipMemcpyAsync(ctx->sched.p, sched.data(), 32 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          /* perm/sched are stack/heap temporaries */
+   return DDCMI_OK;
+}
+
 /* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
 int ddcmi_bl_finish(ddcmi_ctx *ctx)
 {
@@ -1770,7 +1788,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
    ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
-   ENSURE(ctx, ctx->tile_work, ntile + 1); ENSURE(ctx, ctx->sched, 16);
+   ENSURE(ctx, ctx->tile_work, ntile + 1);
    if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
    double rcut = ctx->rmax, dR = ctx->deltaR;
    /* distance shells of the list order: entries a wave rejects as a whole come last */
@@ -1790,7 +1808,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
       ctx->pack_type = (ctx->nlj <= 16 && ctx->stage_cap < 4096);
       TileArgs ta;
-      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type ? 1 : 0;
+      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type ? 1 : 0; ta.nloc = n;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
       ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
@@ -1808,7 +1826,6 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
          hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta, shc);
       }
-      hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(SCHED_THREADS), 0, st, ntile, ctx->tile_work.p, ctx->sched.p, ctx->d_flags);
       HIPCHK(ctx, hipGetLastError());
       unsigned long long tot[3];
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1823,11 +1840,11 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       {
          ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
          ctx->maxnbr = ctx->h_flags[2];
-         ctx->sched_longest = ctx->h_flags[6];
          break;
       }
    }
    ENSURE(ctx, ctx->partials, (size_t)(ntile + 8) * 8);
+   { int rcs = schedule_tiles(ctx); if (rcs) return rcs; }
    ctx->list_valid = true;
    ctx->nrebuild++;
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
@@ -1840,12 +1857,37 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
-   if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh)
+   /* Decomposed runs, between rebuilds: the halo exchange (pack, one RCCL message per peer,
+    * unpack) runs on a second stream while this stream computes the tiles whose
+    * neighbourhoods hold owned beads only; the other tiles wait for it. */
+   bool halo_pending = false;
+   if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh && !ctx->halo_overlap)
    {
-      int rc0 = ddcmi_mg_refresh_halo(ctx);
+      int rc0 = ddcmi_mg_refresh_halo(ctx, st);
       if (rc0) return rc0;
+      if (nh > 0)
+         hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
+                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
    }
-   if (nh > 0)
+   else if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh)
+   {
+      if (!ctx->stream2)
+      {
+         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_drift, hipEventDisableTiming));
+         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->ev_drift, st));                  /* positions of this step are final */
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_drift, 0));
+      int rc0 = ddcmi_mg_refresh_halo(ctx, ctx->stream2);
+      if (rc0) return rc0;
+      if (nh > 0)
+         hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, ctx->stream2, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
+                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
+      HIPCHK(ctx, hipEventRecord(ctx->ev_halo, ctx->stream2));
+      halo_pending = true;
+   }
+   else if (nh > 0)
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
    const bool has_bonded = (ctx->nbond + ctx->nangle + ctx->ntors) > 0;
@@ -1853,7 +1895,6 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
       int ntile = ctx->ntile;
-      int grid = 8 * std::max(ctx->sched_longest, 1);
       bool useq = ctx->has_charge;
       bool packed = ctx->pack_type;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
@@ -1863,33 +1904,43 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nlj;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
-      na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.sched = ctx->sched.p;
+      na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       { const char *rv = getenv("DDCMI_XCD_ROT"); na.rot = rv ? atoi(rv) : 0; }
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (ctx->timing)
-      {
-         if (ctx->ev_used + 2 > ctx->ev.size())
-         {
-            size_t old = ctx->ev.size();
-            ctx->ev.resize(old + 256);
-            for (size_t k = old; k < ctx->ev.size(); k++) HIPCHK(ctx, hipEventCreate(&ctx->ev[k]));
-         }
-         e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
-         HIPCHK(ctx, hipEventRecord(e0, st));
-      }
 #define LAUNCH_NB(Q, P, NT) do { \
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
          hipLaunchKernelGGL((k_nonbond<Q, P, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
 #define LAUNCH_NB2(Q, P) LAUNCH_NB(Q, P, NB_THREADS)
-      if (useq && packed) LAUNCH_NB2(true, true);
-      else if (useq) LAUNCH_NB2(true, false);
-      else if (packed) LAUNCH_NB2(false, true);
-      else LAUNCH_NB2(false, false);
+      /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
+       * class 1: tiles that stage image/halo beads, after the halo exchange */
+      for (int cls = 0; cls < 2; cls++)
+      {
+         if (cls == 1 && halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }
+         if (ctx->ntile_class[cls] <= 0) continue;
+         const int grid = 8 * std::max(ctx->sched_longest[cls], 1);
+         na.sched = ctx->sched.p + 16 * cls;
+         hipEvent_t e0 = nullptr, e1 = nullptr;
+         if (ctx->timing)
+         {
+            if (ctx->ev_used + 2 > ctx->ev.size())
+            {
+               size_t old = ctx->ev.size();
+               ctx->ev.resize(old + 256);
+               for (size_t k = old; k < ctx->ev.size(); k++) HIPCHK(ctx, hipEventCreate(&ctx->ev[k]));
+            }
+            e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
+            HIPCHK(ctx, hipEventRecord(e0, st));
+         }
+         if (useq && packed) LAUNCH_NB2(true, true);
+         else if (useq) LAUNCH_NB2(true, false);
+         else if (packed) LAUNCH_NB2(false, true);
+         else LAUNCH_NB2(false, false);
+         if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
+      }
 #undef LAUNCH_NB2
 #undef LAUNCH_NB
-      if (ctx->timing) { HIPCHK(ctx, hipEventRecord(e1, st)); ctx->t_launches++; }
+      if (ctx->timing) ctx->t_launches++;          /* per force evaluation: the event pairs of both classes add up */
       /* without bonded terms the final energies are formed in the same launch */
       if (!defer_reduce)
       {
@@ -1902,6 +1953,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       if (!defer_reduce) HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, 8 * sizeof(double), st));
       hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
    }
+   if (halo_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0));      /* bonded partners may be halo beads */
    int rc = ddcmi_launch_bonded(ctx);
    if (rc) return rc;
    if (!defer_reduce && (has_bonded || (ctx->excludePotentialTerm & 128) != 0))

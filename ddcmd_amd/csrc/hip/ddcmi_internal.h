@@ -130,8 +130,11 @@ struct ddcmi_ctx
    /* lists */
    int maxnbr = 0, maxexcl = 0;
    dbuf<int> nbr_cnt, excl, excl_cnt;
-   dbuf<int> tile_work, sched;         /* per-tile cost estimate; [9] tile range per XCD */
-   int sched_longest = 0;
+   dbuf<int> tile_work, sched, tile_perm;   /* per-tile cost estimate (bit 30: stages halo beads); XCD ranges [2][16]; tile order */
+   int sched_longest[2] = {0, 0}, ntile_class[2] = {0, 0};      /* class 0: all-owned neighbourhoods (all tiles on one domain), class 1: the rest */
+   hipStream_t stream2 = nullptr;      /* decomposed runs: halo exchange, concurrent with the class-0 tiles */
+   hipEvent_t ev_drift = nullptr, ev_halo = nullptr;
+   bool halo_overlap = false;          /* DDCMI_HALO_OVERLAP=1: exchange on stream2 under the all-owned tiles */
    /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
    int ntile = 0, stage_cap = 0; bool pack_type = false;
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
@@ -159,7 +162,6 @@ struct ddcmi_ctx
    int *d_flags = nullptr; int *h_flags = nullptr;
    double self_ele = 0.0;
    bool forces_valid = false;
-   int nb_block = 256;                 /* threads per tile in k_nonbond (tunable: DDCMI_NB_BLOCK) */
    /* timing */
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
    /* comm */
@@ -198,6 +200,6 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx);
 int ddcmi_bl_finish(ddcmi_ctx *ctx);
 /* multi-domain path (ddcmi_multigpu.inl, compiled into ddcmi.hip) */
 int ddcmi_mg_rebuild(ddcmi_ctx *ctx);
-int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx);
+int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st);
 
 #endif

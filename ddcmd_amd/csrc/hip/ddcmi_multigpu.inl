@@ -318,9 +318,8 @@ static int mg_xchg_data_rccl(ddcmi_ctx *ctx, const double *sbase, const int *sof
 /* RCCL, halo beads (every step): the segments of one peer are contiguous in the send and
  * in the receive buffer (mg_layout_halo), so each peer pair exchanges ONE message -- 7 at
  * 2x2x2 instead of 26, which is what the grouped point-to-point kernel's time follows */
-static int mg_xchg_halo_rccl(ddcmi_ctx *ctx, const double *sbase, double *rbase, int width)
+static int mg_xchg_halo_rccl(ddcmi_ctx *ctx, const double *sbase, double *rbase, int width, hipStream_t st)
 {
-   hipStream_t st = ctx->stream;
    ncclComm_t comm = (ncclComm_t)ctx->comm;
    NCCLCHK2(ctx, ncclGroupStart());
    for (int q = 0; q < ctx->sseg.nseg;)
@@ -543,26 +542,26 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
    if ((rc = mg_phase2_migrate_in(ctx))) return rc;
    if ((rc = mg_xchg_counts_rccl(ctx, ctx->hs_cnt, ctx->hr_cnt))) return rc;
    if ((rc = mg_phase3_pack(ctx, 5))) return rc;
-   if ((rc = mg_xchg_halo_rccl(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5))) return rc;
+   if ((rc = mg_xchg_halo_rccl(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5, ctx->stream))) return rc;
    return mg_phase4_finish(ctx);
 }
 
 /* per-step halo refresh: pack x y z of the send lists, exchange, (k_halo_update places them) */
-static int mg_pack3(ddcmi_ctx *ctx)
+static int mg_pack3(ddcmi_ctx *ctx, hipStream_t st)
 {
    if (ctx->nsend > 0)
    {
-      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, ctx->stream, ctx->nsend, ctx->sseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, st, ctx->nsend, ctx->sseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, 3);
    }
    return DDCMI_OK;
 }
-int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx)
+int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st)
 {
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "in-process group: halos are refreshed by ddcmi_group_step_nglf / ddcmi_group_eval_forces");
    int rc;
-   if ((rc = mg_pack3(ctx))) return rc;
-   if ((rc = mg_xchg_halo_rccl(ctx, ctx->sendbuf.p, ctx->hrecv3.p, 3))) return rc;
+   if ((rc = mg_pack3(ctx, st))) return rc;
+   if ((rc = mg_xchg_halo_rccl(ctx, ctx->sendbuf.p, ctx->hrecv3.p, 3, st))) return rc;
    ctx->halo_fresh = true;
    return DDCMI_OK;
 }
@@ -595,7 +594,7 @@ static int group_rebuild(ddcmi_group *g)
 static int group_refresh(ddcmi_group *g)
 {
    int rc;
-   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_pack3(c))) return rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_pack3(c, c->stream))) return rc;
    if ((rc = mg_xchg_data_local(g, 2))) return rc;
    for (ddcmi_ctx *c : g->ranks) c->halo_fresh = true;
    return DDCMI_OK;

@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-def _loopback_rank(s, monkeypatch):
+def _loopback_rank(s, monkeypatch, overlap=False):
     from ddcmd_amd.martini import MartiniRank, _declare_domains
     monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
+    monkeypatch.setenv("DDCMI_HALO_OVERLAP", "1" if overlap else "0")
     m = MartiniRank(s, np.arange(s.natoms))
     _declare_domains(m.lib)
     buf = ctypes.create_string_buffer(128)
@@ -29,11 +30,13 @@ def _loopback_rank(s, monkeypatch):
     return m
 
 
-def test_water_through_rccl_loopback(monkeypatch):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_water_through_rccl_loopback(monkeypatch, overlap):
+    """overlap=True: the exchange runs on a second stream under the tiles with all-owned neighbourhoods"""
     s = make_water_setup(12)
     o = pyoracle.Oracle(s)
     e0, v0 = o.forces()
-    m = _loopback_rank(s, monkeypatch)
+    m = _loopback_rank(s, monkeypatch, overlap)
     e, vir = m.eval_forces()
     p = m.download_particles()
     order = np.argsort(p["gid"], kind="stable")
@@ -62,7 +65,7 @@ def test_lipid_deck_through_rccl_loopback(monkeypatch):
     o = pyoracle.Oracle(s)
     e0, v0 = o.forces()
     o.group_temperature()
-    m = _loopback_rank(s, monkeypatch)
+    m = _loopback_rank(s, monkeypatch, overlap=True)
     e, vir = m.eval_forces()
     for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
         assert abs(e[k] - e0[k]) < 1e-9 * max(abs(e0[k]), 1e-12), k
