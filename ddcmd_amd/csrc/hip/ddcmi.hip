@@ -1125,6 +1125,32 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
    }
    block_reduce_store<7>(acc, partials + (size_t)blockIdx.x * 8);
 }
+/* neighborCheck (neighbor.c:117-208), constant box: displacement of every owned bead since the
+ * list was built, measured relative to the centroid of the domain's beads (positions are not
+ * wrapped between rebuilds here, so r - r0 needs no image logic).  Pass 1: sum of r - r0. */
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_disp_sum(int nloc, const double4 *__restrict__ pos, const double4 *__restrict__ pos0, double *__restrict__ partials)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   double acc[3] = {0, 0, 0};
+   if (i < nloc) { double4 p = pos[i], q = pos0[i]; acc[0] = p.x - q.x; acc[1] = p.y - q.y; acc[2] = p.z - q.z; }
+   block_reduce_store<3>(acc, partials + (size_t)blockIdx.x * 8);
+}
+/* pass 2: max_i |(r_i - r0_i) - mean|^2; non-negative doubles order like their bit patterns */
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_disp_max(int nloc, const double4 *__restrict__ pos, const double4 *__restrict__ pos0, const double *__restrict__ sum, unsigned long long *out)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   double d2 = 0.0;
+   if (i < nloc)
+   {
+      double inv = 1.0 / (double)nloc;
+      double4 p = pos[i], q = pos0[i];
+      double x = (p.x - q.x) - sum[0] * inv, y = (p.y - q.y) - sum[1] * inv, z = (p.z - q.z) - sum[2] * inv;
+      d2 = x * x + y * y + z * z;
+   }
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_down(d2, off, 64));
+   if ((threadIdx.x & 63) == 0 && d2 > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(d2));
+}
 /* per-group kinetic energy and member count (energy.c:124-133) */
 __global__ __launch_bounds__(DDCMI_BLOCK) void k_group_ke(int nloc, int ngroup, const double *__restrict__ massv, const int *__restrict__ species,
                                                           const int *__restrict__ group,
@@ -1297,7 +1323,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
-   ctx->d_exmask.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
+   ctx->d_exmask.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -1418,7 +1444,7 @@ extern "C" int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_
 extern "C" int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate)
 {
    if (!ctx || deltaR < 0) return DDCMI_EINVAL;
-   if (updateRate <= 0) SETERR(ctx, DDCMI_EUNSUPPORTED, "updateRate must be > 0 (displacement-triggered rebuilds, ddcUpdateAll.c:56, are not implemented)");
+   if (updateRate < 0) SETERR(ctx, DDCMI_EINVAL, "updateRate must be >= 0 (0 = rebuild when neighborCheck says so, ddcUpdateAll.c:64-71)");
    ctx->deltaR = deltaR; ctx->updateRate = updateRate; ctx->list_valid = false;
    return DDCMI_OK;
 }
@@ -1694,7 +1720,7 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
 extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
 {
    if (!ctx) return DDCMI_EINVAL;
-   if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate <= 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
+   if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate < 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
    (void)hipSetDevice(ctx->device);
    int rc;
@@ -1845,6 +1871,12 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    ENSURE(ctx, ctx->partials, (size_t)(ntile + 8) * 8);
    { int rcs = schedule_tiles(ctx); if (rcs) return rcs; }
+   if (ctx->updateRate == 0)
+   {
+      /* neighborRef (neighbor.c:209-246): remember where every owned bead was */
+      if (ctx->pos0.ensure((size_t)std::max(n, 1))) SETERR(ctx, DDCMI_ENOMEM, "reference positions");
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pos0.p, ctx->pos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToDevice, st));
+   }
    ctx->list_valid = true;
    ctx->nrebuild++;
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
@@ -2065,6 +2097,46 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
    return DDCMI_OK;
 }
 
+/* updateRate == 0: does this domain's list need a rebuild?  (neighborCheck; one host
+ * round trip per step, as the reference pays an MPI_Allreduce per step in this mode) */
+int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need)
+{
+   hipStream_t st = ctx->stream;
+   const int n = ctx->nloc, nblk = cdiv(std::max(n, 1), DDCMI_BLOCK);
+   *need = 1;
+   if (!ctx->list_valid || ctx->pos0.cap < (size_t)n) return DDCMI_OK;
+   *need = 0;
+   if (n == 0) return DDCMI_OK;
+   ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
+   ENSURE(ctx, ctx->disp, 16);
+   HIPCHK(ctx, hipMemsetAsync(ctx->disp.p, 0, 16 * sizeof(double), st));
+   hipLaunchKernelGGL(k_disp_sum, dim3(nblk), dim3(DDCMI_BLOCK), 0, st, n, ctx->pos.p, ctx->pos0.p, ctx->kpartials.p);
+   RedJob js = {ctx->kpartials.p, nblk, 3, ctx->disp.p, 0};
+   hipLaunchKernelGGL(k_reduce_jobs, dim3(1), dim3(1024), 0, st, js, js, ctx->d_results, 0.0);
+   hipLaunchKernelGGL(k_disp_max, dim3(nblk), dim3(DDCMI_BLOCK), 0, st, n, ctx->pos.p, ctx->pos0.p, ctx->disp.p, (unsigned long long *)(ctx->disp.p + 4));
+   double d2max = 0.0;
+   HIPCHK(ctx, hipMemcpyAsync(&d2max, ctx->disp.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   *need = (2.0 * sqrt(d2max) < ctx->deltaR) ? 0 : 1;
+   return DDCMI_OK;
+}
+static int rebuild_due(ddcmi_ctx *ctx, bool *due)
+{
+   if (!ctx->list_valid) { *due = true; return DDCMI_OK; }
+   if (ctx->updateRate > 0) { *due = (ctx->loop % ctx->updateRate == 0); return DDCMI_OK; }
+   int need = 0, rc = ddcmi_displacement_check(ctx, &need);
+   if (rc) return rc;
+   if ((ctx->nranks > 1 || ctx->loopback) && ctx->comm)
+   {
+      /* check4updateNeighbor (ddcUpdateAll.c:56): anyone needs a rebuild -> everyone rebuilds */
+      double v = (double)need;
+      if ((rc = ddcmi_comm_allreduce_sum(ctx, &v, 1))) return rc;
+      need = v > 0.0;
+   }
+   *due = need != 0;
+   return DDCMI_OK;
+}
+
 extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
 {
    if (!ctx || nsteps < 0) return DDCMI_EINVAL;
@@ -2075,9 +2147,10 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
    for (int s = 0; s < nsteps; s++)
    {
       if ((rc = step_pre(ctx, dt))) return rc;
-      /* ddcUpdateAll.c:64-71: rebuild when loop % updateRate == 0 */
-      if (ctx->loop % ctx->updateRate == 0 || !ctx->list_valid)
-         if ((rc = ddcmi_build_list(ctx))) return rc;
+      /* ddcUpdateAll.c:64-71: rebuild when loop % updateRate == 0, or (updateRate == 0) when neighborCheck asks */
+      bool due = false;
+      if ((rc = rebuild_due(ctx, &due))) return rc;
+      if (due && (rc = ddcmi_build_list(ctx))) return rc;
       if ((rc = step_post(ctx, dt, s + 1 < nsteps))) return rc;
    }
    return DDCMI_OK;

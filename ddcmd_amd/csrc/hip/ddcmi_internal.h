@@ -142,6 +142,7 @@ struct ddcmi_ctx
    dbuf<unsigned short> nbr16; dbuf<unsigned int> tmp32; int tmpw = 0;
    unsigned long long arena_cap = 0;
    dbuf<double> kpartials;             /* per-workgroup kinetic terms (k_kick_ke) */
+   dbuf<double4> pos0; dbuf<double> disp;   /* updateRate == 0: positions at the last rebuild; [0..2] sum of r-r0, [4] max |dr|^2 */
    bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
@@ -189,6 +190,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
+int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */
 int ddcmi_launch_bonded(ddcmi_ctx *ctx);
 /* comm.hip */

@@ -644,7 +644,9 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
       for (ddcmi_ctx *c : g->ranks)
       {
          if ((rc = step_pre(c, dt))) return rc;
-         if (c->loop % c->updateRate == 0 || !c->list_valid) rebuild = true;
+         if (!c->list_valid) rebuild = true;
+         else if (c->updateRate > 0) { if (c->loop % c->updateRate == 0) rebuild = true; }
+         else { int need = 0; if ((rc = ddcmi_displacement_check(c, &need))) return rc; if (need) rebuild = true; }      /* check4updateNeighbor: any domain */
       }
       if (rebuild) { if ((rc = group_rebuild(g))) return rc; }
       else if ((rc = group_refresh(g))) return rc;

@@ -89,7 +89,8 @@ int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
                          int nangle, const uint64_t *angle_gid, const int *angle_func, const double *angle_k, const double *angle_t0,
                          int ntors, const uint64_t *tors_gid, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
                          int excludePotentialTerm);
-/* NEIGHBOR deltaR (neighbor.c:49) and DDC updateRate (ddc.c:96; >0 required) */
+/* NEIGHBOR deltaR (neighbor.c:49) and DDC updateRate (ddc.c:96).  updateRate = 0: rebuild when
+ * neighborCheck (neighbor.c:117-208) finds 2*max displacement >= deltaR (one host round trip per step) */
 int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);
 /* GROUP objects (group.c:48-90): type DDCMI_FREE / DDCMI_BERENDSEN{Teq,tau,interval} */
 int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval);

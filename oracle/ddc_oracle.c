@@ -67,12 +67,16 @@ struct orc_nbr
    int *start[2];  /* CSR row starts [n+1] : 0 kept list (ifirst[0]), 1 pruned list (ifirst[1]) */
    int *j[2];
    long npairs[2];
+   /* neighborRef (neighbor.c:209-246): reference positions and their centroid for neighborCheck */
+   double *r0[3];
+   double rbar[3];
 };
 
 void orc_nbr_free(orc_nbr *nb)
 {
    if (!nb) return;
    for (int l = 0; l < 2; l++) { free(nb->start[l]); free(nb->j[l]); }
+   for (int a = 0; a < 3; a++) free(nb->r0[a]);
    free(nb);
 }
 long orc_nbr_npairs(const orc_nbr *nb, int which) { return nb->npairs[which]; }
@@ -108,9 +112,12 @@ static int pair_is_pruned(const orc_params *p, const uint64_t *gid, const int *s
  * cells with gid_i < gid_j; min-image if r2 > R2cut; keep if r2 < (rcut+deltaR)^2.
  * The cell grid stands in for GeomBox (geom.c:311); the resulting pair SET is
  * the same, the in-row order differs (the reference prepends to a linked list). */
+static long orc_builds = 0;
+long orc_nbr_build_count(void) { return orc_builds; }
 orc_nbr *orc_nbr_build(const orc_params *p, int n, const double *rx, const double *ry, const double *rz,
                        const uint64_t *gid, const int *species)
 {
+   orc_builds++;
    double rlist = p->rmax + p->deltaR;
    double rmax_plus_delta2 = rlist * rlist;
    double ms = minspan(p);
@@ -208,6 +215,16 @@ orc_nbr *orc_nbr_build(const orc_params *p, int n, const double *rx, const doubl
    }
    nb->npairs[0] = np[0];
    nb->npairs[1] = np[1];
+   /* neighborRef: r0 = nearest image of r about the box centre (0 here), rbar = centroid of the locals */
+   for (int a = 0; a < 3; a++) { nb->r0[a] = malloc(sizeof(double) * (n > 0 ? n : 1)); nb->rbar[a] = 0.0; }
+   for (int i = 0; i < n; i++)
+   {
+      double x = rx[i], y = ry[i], z = rz[i];
+      nearestImage(p, &x, &y, &z);
+      nb->r0[0][i] = x; nb->r0[1][i] = y; nb->r0[2][i] = z;
+      nb->rbar[0] += x; nb->rbar[1] += y; nb->rbar[2] += z;
+   }
+   for (int a = 0; a < 3; a++) nb->rbar[a] /= (n > 0 ? n : 1);
    free(head); free(next); free(cellOf);
    return nb;
 }
@@ -687,6 +704,35 @@ static void berendsen_Update(orc_group *g, long loop, double dt_half)
 }
 
 /* nglf, nglf.c:67-112 */
+/* neighborCheck (neighbor.c:117-208) for a constant box (the strain term is zero): the list
+ * must be rebuilt once 2*max_i |(r_i - rbar) - (r0_i - rbar0)| reaches the skin deltaR.
+ * Used when updateRate == 0 (ddcUpdateAll.c:64-71). */
+int orc_neighbor_check(const orc_params *p, const orc_nbr *nb, int n, const double *rx, const double *ry, const double *rz)
+{
+   if (!nb || nb->n != n) return 1;
+   double rbar[3] = {0, 0, 0};
+   for (int i = 0; i < n; i++)
+   {
+      double x = rx[i], y = ry[i], z = rz[i];
+      nearestImage(p, &x, &y, &z);
+      rbar[0] += x; rbar[1] += y; rbar[2] += z;
+   }
+   for (int a = 0; a < 3; a++) rbar[a] /= (n > 0 ? n : 1);
+   double d2max = 0.0;
+   for (int i = 0; i < n; i++)
+   {
+      double x1 = rx[i] - rbar[0], y1 = ry[i] - rbar[1], z1 = rz[i] - rbar[2];
+      nearestImage_fast(p, &x1, &y1, &z1);
+      double x0 = nb->r0[0][i] - nb->rbar[0], y0 = nb->r0[1][i] - nb->rbar[1], z0 = nb->r0[2][i] - nb->rbar[2];
+      nearestImage_fast(p, &x0, &y0, &z0);
+      double x = x1 - x0, y = y1 - y0, z = z1 - z0;
+      nearestImage_fast(p, &x, &y, &z);
+      double dr2 = x * x + y * y + z * z;
+      if (dr2 > d2max) d2max = dr2;
+   }
+   return (2.0 * sqrt(d2max) < p->deltaR) ? 0 : 1;
+}
+
 void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt,
                    long *loop, double *time, int n,
                    double *rx, double *ry, double *rz, double *vx, double *vy, double *vz,
@@ -712,7 +758,7 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
    *time += dt;
    *loop += 1;
    /* :97 ddcenergy; rebuild test ddcUpdateAll.c:64-71 */
-   if (updateRate > 0 && (*loop % updateRate) == 0)
+   if ((updateRate > 0 && (*loop % updateRate) == 0) || (updateRate == 0 && orc_neighbor_check(p, *pnb, n, rx, ry, rz)))
    {
       orc_nbr_free(*pnb);
       *pnb = orc_nbr_build(p, n, rx, ry, rz, gid, species);

@@ -179,3 +179,25 @@ def test_decomposed_lipid_nvt_berendsen():
         Tg = g.group_temperatures()
         assert abs(Tg[0] - o.groups[0].temperature) < 1e-8 * Tg[0]
     g.close()
+
+
+def test_decomposed_displacement_triggered_rebuilds():
+    """updateRate = 0 on 2x2x1 domains: any domain whose beads moved half the skin triggers the
+    rebuild of all (check4updateNeighbor, ddcUpdateAll.c:56); the trajectory follows the oracle"""
+    from ddcmd_amd.martini import MartiniGroup
+    from ddcmd_amd.deck import units_convert
+    s = make_water_setup(15)
+    s.updateRate = 0
+    s.deltaR = units_convert(2.0, "Angstrom")
+    o = pyoracle.Oracle(s)
+    o.forces()
+    g = MartiniGroup(s, (2, 2, 1))
+    g.eval_forces()
+    for block in range(4):
+        eo, vo, rko, _ = o.step(10)
+        g.step(10)
+        e, vir, rk, _ = g.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko
+    assert g.ranks[0].list_stats()["rebuilds"] >= 3
+    g.close()

@@ -325,3 +325,35 @@ def test_step_batching_is_bitwise_invariant():
         for a, b in zip(out[0][:3], other[:3]):
             assert np.array_equal(a, b)
         assert out[0][3] == other[3] and out[0][4] == other[4]
+
+
+def test_displacement_triggered_rebuilds():
+    """updateRate = 0 (ddcUpdateAll.c:64-71): the list is rebuilt when neighborCheck (neighbor.c:117-208)
+    finds 2*max|dr - mean dr| >= deltaR; same rebuild steps and trajectory as the oracle"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(10)
+    s.updateRate = 0
+    s.deltaR = units_convert(1.5, "Angstrom")          # small skin: several rebuilds in 60 steps
+    o = pyoracle.Oracle(s)
+    o.forces()
+    m = MartiniHIP(s)
+    m.eval_forces()
+    rebuilds_gpu, rebuilds_cpu = [], []
+    last = m.list_stats()["rebuilds"]
+    for step in range(60):
+        o.L.orc_nbr_build_count.restype = __import__("ctypes").c_long
+        nb_before = o.L.orc_nbr_build_count()
+        eo, vo, rko, _ = o.step(1)
+        if o.L.orc_nbr_build_count() != nb_before:
+            rebuilds_cpu.append(step)
+        m.step(1)
+        now = m.list_stats()["rebuilds"]
+        if now != last:
+            rebuilds_gpu.append(step)
+            last = now
+        e, vir, rk, _ = m.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), step
+        assert abs(rk - rko) < TOL * rko
+    assert len(rebuilds_gpu) >= 3
+    assert rebuilds_gpu == rebuilds_cpu
+    m.close()
