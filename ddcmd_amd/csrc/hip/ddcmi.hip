@@ -997,14 +997,32 @@ __global__ void k_zero3(int n, double *a, double *b, double *c)
  * and the kinetic terms -- in one launch. */
 struct RedJob { const double *partials; int nblocks; int nv; double *out; int finish; };
 __device__ void finish_energy(double *r, double self_ele);
-__global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, double *results, double self_ele)
+/* RED_SPLIT workgroups share a job (one workgroup reading the 0.5 MB of per-tile partials of
+ * a 4 M-bead box took 21 us); each leaves its 8 sums in tmp, the last one to arrive (ticket)
+ * adds the RED_SPLIT rows in index order.  tmp: [2 jobs][RED_SPLIT][8] doubles, then 2 ticket
+ * counters (left at zero). */
+#define RED_SPLIT 8
+__global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp)
 {
-   const RedJob j = blockIdx.x ? j1 : j0;
+   const RedJob j = blockIdx.y ? j1 : j0;
    __shared__ double s[1024];
+   __shared__ int s_last;
    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
    double a = 0.0;
    if (k < j.nv)
-      for (int b = g; b < j.nblocks; b += 128) a += j.partials[(size_t)b * 8 + k];
+   {
+      /* independent partial sums: a single chain of dependent loads is latency-bound */
+      double p[4] = {0, 0, 0, 0};
+      int b = g + 128 * (int)blockIdx.x;
+      const int stride = 128 * RED_SPLIT;
+      for (; b + 3 * stride < j.nblocks; b += 4 * stride)
+      {
+#pragma unroll
+         for (int u = 0; u < 4; u++) p[u] += j.partials[(size_t)(b + u * stride) * 8 + k];
+      }
+      for (int u = 0; b < j.nblocks; b += stride, u++) p[u] += j.partials[(size_t)b * 8 + k];
+      a = (p[0] + p[1]) + (p[2] + p[3]);
+   }
    s[threadIdx.x] = a;
    __syncthreads();
    for (int off = 512; off >= 8; off >>= 1)
@@ -1012,7 +1030,27 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
       if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
       __syncthreads();
    }
-   if (threadIdx.x < j.nv) j.out[threadIdx.x] = s[threadIdx.x];
+   double *mytmp = tmp + ((size_t)blockIdx.y * RED_SPLIT + blockIdx.x) * 8;
+   unsigned int *ticket = (unsigned int *)(tmp + 2 * RED_SPLIT * 8) + blockIdx.y;
+   if (threadIdx.x < 8) { mytmp[threadIdx.x] = s[threadIdx.x]; __threadfence(); }
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      unsigned int t = atomicAdd(ticket, 1u);
+      s_last = (t == RED_SPLIT - 1);
+      if (s_last) { *ticket = 0u; __threadfence(); }
+   }
+   __syncthreads();
+   if (!s_last) return;
+   if (threadIdx.x < (unsigned)j.nv)
+   {
+      const double *row = tmp + (size_t)blockIdx.y * RED_SPLIT * 8 + threadIdx.x;
+      double t = 0.0;
+      __threadfence();          /* acquire: the other workgroups' rows, written on other XCDs */
+#pragma unroll
+      for (int q = 0; q < RED_SPLIT; q++) t += row[q * 8];
+      j.out[threadIdx.x] = t;
+   }
    if (j.finish)
    {
       __syncthreads();          /* orders the out[] stores before thread 0 reads them */
@@ -1065,6 +1103,7 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
    p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
    pos[i] = p;
 }
+#define KE_PER 4
 /* BACK half kick (nglf.c:100-104) fused with kinetic_terms (energy.c:48-163):
  * rk = sum 1/2 m v^2, tion = sum m v (x) v */
 __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, const double *__restrict__ invmass, const double *__restrict__ massv,
@@ -1073,10 +1112,13 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
                                                          double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
                                                          double *__restrict__ partials, int do_kick)
 {
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-   if (i < nloc)
+   /* KE_PER beads per thread: a quarter of the partial rows for the reduction launch to read */
+#pragma unroll
+   for (int u = 0; u < KE_PER; u++)
    {
+      int i = (blockIdx.x * KE_PER + u) * DDCMI_BLOCK + threadIdx.x;
+      if (i >= nloc) continue;
       int sp = species[i];
       double x = vx[i], y = vy[i], z = vz[i];
       if (do_kick)
@@ -1087,9 +1129,9 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
       }
       double m = massv[sp];
       double vxx = x * x, vyy = y * y, vzz = z * z;
-      acc[0] = 0.5 * m * (vxx + vyy + vzz);
-      acc[1] = m * vxx; acc[2] = m * vyy; acc[3] = m * vzz;
-      acc[4] = m * (x * y); acc[5] = m * (x * z); acc[6] = m * (y * z);
+      acc[0] += 0.5 * m * (vxx + vyy + vzz);
+      acc[1] += m * vxx; acc[2] += m * vyy; acc[3] += m * vzz;
+      acc[4] += m * (x * y); acc[5] += m * (x * z); acc[6] += m * (y * z);
    }
    block_reduce_store<7>(acc, partials + (size_t)blockIdx.x * 8);
 }
@@ -1102,19 +1144,21 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
                                                                double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
                                                                double4 *__restrict__ pos, double *__restrict__ partials)
 {
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-   if (i < nloc)
+#pragma unroll
+   for (int u = 0; u < KE_PER; u++)
    {
+      int i = (blockIdx.x * KE_PER + u) * DDCMI_BLOCK + threadIdx.x;
+      if (i >= nloc) continue;
       int sp = species[i];
       double a = (0.5 * dt) * invmass[sp];
       double f0 = fx[i], f1 = fy[i], f2 = fz[i];
       double x = fma(a, f0, vx[i]), y = fma(a, f1, vy[i]), z = fma(a, f2, vz[i]);
       double m = massv[sp];
       double vxx = x * x, vyy = y * y, vzz = z * z;
-      acc[0] = 0.5 * m * (vxx + vyy + vzz);
-      acc[1] = m * vxx; acc[2] = m * vyy; acc[3] = m * vzz;
-      acc[4] = m * (x * y); acc[5] = m * (x * z); acc[6] = m * (y * z);
+      acc[0] += 0.5 * m * (vxx + vyy + vzz);
+      acc[1] += m * vxx; acc[2] += m * vyy; acc[3] += m * vzz;
+      acc[4] += m * (x * y); acc[5] += m * (x * z); acc[6] += m * (y * z);
       double lam = glambda.v[group[i] & 31];
       if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
       x = fma(a, f0, x); y = fma(a, f1, y); z = fma(a, f2, z);
@@ -1298,6 +1342,8 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
+   if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; delete ctx; return DDCMI_ENOMEM; }
+   (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
    { const char *ov = getenv("DDCMI_HALO_OVERLAP"); ctx->halo_overlap = (ov && atoi(ov) != 0); }
    ctx->gtype.assign(1, DDCMI_FREE); ctx->ginterval.assign(1, 1); ctx->gTeq.assign(1, 0); ctx->gtau.assign(1, 0);
@@ -1325,7 +1371,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
-   ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->tmp32.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
@@ -1977,7 +2023,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       if (!defer_reduce)
       {
          RedJob j0 = {ctx->partials.p, ntile, 8, ctx->d_results + R_NB_LJ, has_bonded ? 0 : 1};
-         hipLaunchKernelGGL(k_reduce_jobs, dim3(1), dim3(1024), 0, st, j0, j0, ctx->d_results, self);
+         hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, st, j0, j0, ctx->d_results, self, ctx->red_tmp.p);
       }
    }
    else
@@ -2019,7 +2065,7 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
  * nonbonded partials of the force evaluation just queued and forms the final energies */
 static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false, const GroupLambda *then_drift = nullptr)
 {
-   int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK);
+   int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK * KE_PER);
    ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
    if (then_drift)
       hipLaunchKernelGGL(k_kick_ke_drift, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p, ctx->group.p, *then_drift,
@@ -2033,10 +2079,10 @@ static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forc
       const bool nb_on = (ctx->excludePotentialTerm & 128) == 0;
       const double self = nb_on ? ctx->self_ele : 0.0;
       RedJob jf = {ctx->partials.p, nb_on ? ctx->ntile : 0, 8, ctx->d_results + R_NB_LJ, 1};
-      hipLaunchKernelGGL(k_reduce_jobs, dim3(2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, self);
+      hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, self, ctx->red_tmp.p);
    }
    else
-      hipLaunchKernelGGL(k_reduce_jobs, dim3(1), dim3(1024), 0, ctx->stream, jk, jk, ctx->d_results, 0.0);
+      hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, ctx->stream, jk, jk, ctx->d_results, 0.0, ctx->red_tmp.p);
    return DDCMI_OK;
 }
 
@@ -2112,7 +2158,7 @@ int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need)
    HIPCHK(ctx, hipMemsetAsync(ctx->disp.p, 0, 16 * sizeof(double), st));
    hipLaunchKernelGGL(k_disp_sum, dim3(nblk), dim3(DDCMI_BLOCK), 0, st, n, ctx->pos.p, ctx->pos0.p, ctx->kpartials.p);
    RedJob js = {ctx->kpartials.p, nblk, 3, ctx->disp.p, 0};
-   hipLaunchKernelGGL(k_reduce_jobs, dim3(1), dim3(1024), 0, st, js, js, ctx->d_results, 0.0);
+   hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, st, js, js, ctx->d_results, 0.0, ctx->red_tmp.p);
    hipLaunchKernelGGL(k_disp_max, dim3(nblk), dim3(DDCMI_BLOCK), 0, st, n, ctx->pos.p, ctx->pos0.p, ctx->disp.p, (unsigned long long *)(ctx->disp.p + 4));
    double d2max = 0.0;
    HIPCHK(ctx, hipMemcpyAsync(&d2max, ctx->disp.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
