@@ -84,6 +84,7 @@ class CSetup(ctypes.Structure):
         ("accelerator_type", ctypes.c_char_p),
         ("u_pressure", ctypes.c_char_p), ("u_volume", ctypes.c_char_p), ("u_temperature", ctypes.c_char_p),
         ("u_energy", ctypes.c_char_p), ("u_time", ctypes.c_char_p), ("u_length", ctypes.c_char_p),
+        ("rng_seed", ctypes.c_uint64),
     ]
 
 

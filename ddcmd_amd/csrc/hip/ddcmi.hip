@@ -1084,20 +1084,55 @@ __global__ void k_finish_energy(double *r, double self_ele)
  * (nglf.c:80-87).  The wrap of nglf.c:90 is applied at rebuild/download time
  * instead (positions stay continuous between rebuilds so image atoms and the
  * list remain valid); the downloaded coordinates are identical up to rounding. */
-struct GroupLambda { double v[32]; };
+/* per-group data of the velocity updates, by value.  v = Berendsen scale factor of the FRONT
+ * kick (1 otherwise); groups in lang_mask use the Langevin update (langevin.c:92-128, vcm = 0):
+ *   FRONT  v = a v + c f + d g        BACK  v = a (v + c f + d g)
+ * a = exp(-dt_half/tau), c = dt_half/m, d = sqrt(2 dt_half kB T/(m tau)) = dfac/sqrt(m), g = three unit normals.
+ * The reference draws g from a per-particle LCG64 stream stored with the particle; here it is a
+ * counter-based stream keyed by (seed, gid, 2*loop + BACK): the same numbers whatever the domain
+ * decomposition or launch shape -- statistical, not bitwise, parity with ddcMD. */
+struct GroupLambda { double v[32]; double a[32]; double dfac[32]; unsigned lang_mask; unsigned long long seed, counter_front, counter_back; };
+__device__ __forceinline__ unsigned long long smix64(unsigned long long z)
+{
+   z += 0x9E3779B97F4A7C15ull;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+   return z ^ (z >> 31);
+}
+__device__ __forceinline__ void gauss3(unsigned long long seed, unsigned long long gid, unsigned long long counter, double &g0, double &g1, double &g2)
+{
+   const unsigned long long key = smix64(seed ^ smix64(gid)) + 4ull * counter;
+   const double two53 = 1.0 / 9007199254740992.0;
+   double u1 = ((double)(smix64(key) >> 11) + 0.5) * two53, u2 = ((double)(smix64(key + 1) >> 11) + 0.5) * two53;
+   double u3 = ((double)(smix64(key + 2) >> 11) + 0.5) * two53, u4 = ((double)(smix64(key + 3) >> 11) + 0.5) * two53;
+   double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
+   g0 = r * cos(t); g1 = r * sin(t);
+   g2 = sqrt(-2.0 * log(u3)) * cos(6.283185307179586476925 * u4);
+}
 __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ invmass, const int *__restrict__ species,
-                             const int *__restrict__ group, GroupLambda glambda,
+                             const int *__restrict__ group, GroupLambda glambda, const uint64_t *__restrict__ gid,
                              const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
                              double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz, double4 *__restrict__ pos)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= nloc) return;
-   double a = (0.5 * dt) * invmass[species[i]];
-   double lam = glambda.v[group[i] & 31];
+   const double im = invmass[species[i]];
+   double a = (0.5 * dt) * im;
+   const int gr = group[i] & 31;
+   double lam = glambda.v[gr];
    double x = vx[i], y = vy[i], z = vz[i];
-   if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
-   /* explicit fma: k_kick_ke_drift must produce the same bits as this kernel */
-   x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
+   if (glambda.lang_mask >> gr & 1u)
+   {
+      double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
+      gauss3(glambda.seed, gid[i], glambda.counter_front, g0, g1, g2);
+      x = fma(d, g0, fma(a, fx[i], al * x)); y = fma(d, g1, fma(a, fy[i], al * y)); z = fma(d, g2, fma(a, fz[i], al * z));
+   }
+   else
+   {
+      if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
+      /* explicit fma: k_kick_ke_drift must produce the same bits as this kernel */
+      x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
+   }
    vx[i] = x; vy[i] = y; vz[i] = z;
    double4 p = pos[i];
    p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
@@ -1110,7 +1145,8 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
                                                          const int *__restrict__ species,
                                                          const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
                                                          double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
-                                                         double *__restrict__ partials, int do_kick)
+                                                         double *__restrict__ partials, int do_kick,
+                                                         const int *__restrict__ group, GroupLambda glambda, const uint64_t *__restrict__ gid)
 {
    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
    /* KE_PER beads per thread: a quarter of the partial rows for the reduction launch to read */
@@ -1123,8 +1159,16 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
       double x = vx[i], y = vy[i], z = vz[i];
       if (do_kick)
       {
-         double a = (0.5 * dt) * invmass[sp];
-         x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
+         const double im = invmass[sp];
+         double a = (0.5 * dt) * im;
+         const int gr = group[i] & 31;
+         if (glambda.lang_mask >> gr & 1u)
+         {
+            double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
+            gauss3(glambda.seed, gid[i], glambda.counter_back, g0, g1, g2);
+            x = al * fma(d, g0, fma(a, fx[i], x)); y = al * fma(d, g1, fma(a, fy[i], y)); z = al * fma(d, g2, fma(a, fz[i], z));
+         }
+         else { x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z); }
          vx[i] = x; vy[i] = y; vz[i] = z;
       }
       double m = massv[sp];
@@ -1142,7 +1186,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
                                                                const int *__restrict__ species, const int *__restrict__ group, GroupLambda glambda,
                                                                const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
                                                                double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz,
-                                                               double4 *__restrict__ pos, double *__restrict__ partials)
+                                                               double4 *__restrict__ pos, double *__restrict__ partials, const uint64_t *__restrict__ gid)
 {
    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1151,17 +1195,35 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
       int i = (blockIdx.x * KE_PER + u) * DDCMI_BLOCK + threadIdx.x;
       if (i >= nloc) continue;
       int sp = species[i];
-      double a = (0.5 * dt) * invmass[sp];
+      const double im = invmass[sp];
+      double a = (0.5 * dt) * im;
       double f0 = fx[i], f1 = fy[i], f2 = fz[i];
-      double x = fma(a, f0, vx[i]), y = fma(a, f1, vy[i]), z = fma(a, f2, vz[i]);
+      const int gr = group[i] & 31;
+      const bool lang = glambda.lang_mask >> gr & 1u;
+      double x, y, z, g0, g1, g2, dl = 0.0, al = 0.0;
+      if (lang)
+      {
+         dl = glambda.dfac[gr] * sqrt(im); al = glambda.a[gr];
+         gauss3(glambda.seed, gid[i], glambda.counter_back, g0, g1, g2);
+         x = al * fma(dl, g0, fma(a, f0, vx[i])); y = al * fma(dl, g1, fma(a, f1, vy[i])); z = al * fma(dl, g2, fma(a, f2, vz[i]));
+      }
+      else { x = fma(a, f0, vx[i]); y = fma(a, f1, vy[i]); z = fma(a, f2, vz[i]); }
       double m = massv[sp];
       double vxx = x * x, vyy = y * y, vzz = z * z;
       acc[0] += 0.5 * m * (vxx + vyy + vzz);
       acc[1] += m * vxx; acc[2] += m * vyy; acc[3] += m * vzz;
       acc[4] += m * (x * y); acc[5] += m * (x * z); acc[6] += m * (y * z);
-      double lam = glambda.v[group[i] & 31];
-      if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
-      x = fma(a, f0, x); y = fma(a, f1, y); z = fma(a, f2, z);
+      if (lang)
+      {
+         gauss3(glambda.seed, gid[i], glambda.counter_front, g0, g1, g2);
+         x = fma(dl, g0, fma(a, f0, al * x)); y = fma(dl, g1, fma(a, f1, al * y)); z = fma(dl, g2, fma(a, f2, al * z));
+      }
+      else
+      {
+         double lam = glambda.v[gr];
+         if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
+         x = fma(a, f0, x); y = fma(a, f1, y); z = fma(a, f2, z);
+      }
       vx[i] = x; vy[i] = y; vz[i] = z;
       double4 p = pos[i];
       p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
@@ -1503,13 +1565,21 @@ extern "C" int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, con
    ctx->gTeq.assign(ngroup, 0.0); ctx->gtau.assign(ngroup, 0.0); ctx->ginterval.assign(ngroup, 1);
    for (int g = 0; g < ngroup; g++)
    {
-      if (type[g] != DDCMI_FREE && type[g] != DDCMI_BERENDSEN) SETERR(ctx, DDCMI_EUNSUPPORTED, "group %d: only FREE and BERENDSEN groups are supported", g);
+      if (type[g] != DDCMI_FREE && type[g] != DDCMI_BERENDSEN && type[g] != DDCMI_LANGEVIN) SETERR(ctx, DDCMI_EUNSUPPORTED, "group %d: only FREE, BERENDSEN and LANGEVIN groups are supported", g);
+      if (type[g] == DDCMI_LANGEVIN && (!tau || !(tau[g] > 0.0) || !Teq)) SETERR(ctx, DDCMI_EINVAL, "group %d: LANGEVIN needs Teq and tau > 0", g);
       if (Teq) ctx->gTeq[g] = Teq[g];
       if (tau) ctx->gtau[g] = tau[g];
       if (interval && interval[g] > 0) ctx->ginterval[g] = interval[g];
    }
    ctx->glambda.assign(ngroup, 1.0); ctx->gTsum.assign(ngroup, 0.0); ctx->gT.assign(ngroup, 0.0);
    ctx->gnT.assign(ngroup, 0); ctx->gdoScaling.assign(ngroup, 0);
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   ctx->rng_seed = seed;
    return DDCMI_OK;
 }
 
@@ -2063,16 +2133,18 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
 
 /* kinetic_terms (+ the BACK half kick); with_forces: the same launch also reduces the
  * nonbonded partials of the force evaluation just queued and forms the final energies */
-static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false, const GroupLambda *then_drift = nullptr)
+static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false, const GroupLambda *gk = nullptr, bool then_drift = false)
 {
+   GroupLambda plain;
+   if (!gk) { memset(&plain, 0, sizeof(plain)); for (int g = 0; g < 32; g++) { plain.v[g] = 1.0; plain.a[g] = 1.0; } gk = &plain; }
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK * KE_PER);
    ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
    if (then_drift)
-      hipLaunchKernelGGL(k_kick_ke_drift, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p, ctx->group.p, *then_drift,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, ctx->kpartials.p);
+      hipLaunchKernelGGL(k_kick_ke_drift, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p, ctx->group.p, *gk,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, ctx->kpartials.p, ctx->gid.p);
    else
    hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
-                      ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, do_kick);
+                      ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, do_kick, ctx->group.p, *gk, ctx->gid.p);
    RedJob jk = {ctx->kpartials.p, nblk, 7, ctx->d_results + R_RK, 0};
    if (with_forces)
    {
@@ -2104,11 +2176,26 @@ static void berendsen_update(ddcmi_ctx *ctx, double dt_half)
 }
 
 /* nglf.c:74-95: FRONT half kick + drift, clock advance */
-static GroupLambda front_lambda(const ddcmi_ctx *ctx)
+static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
 {
    GroupLambda lam;
-   /* lambda applies at the FRONT kick when doScaling is set (berendsen.c:74-80) */
-   for (int g = 0; g < 32; g++) lam.v[g] = (g < ctx->ngroup && ctx->gtype[g] == DDCMI_BERENDSEN && ctx->gdoScaling[g]) ? ctx->glambda[g] : 1.0;
+   lam.lang_mask = 0; lam.seed = ctx->rng_seed;
+   /* the FRONT update of a step sees the loop count before its increment, the BACK update the one after */
+   lam.counter_front = 2ull * (unsigned long long)ctx->loop;
+   lam.counter_back = 2ull * (unsigned long long)ctx->loop + 1ull;
+   const double dt_half = 0.5 * dt;
+   for (int g = 0; g < 32; g++)
+   {
+      /* lambda applies at the FRONT kick when doScaling is set (berendsen.c:74-80) */
+      lam.v[g] = (g < ctx->ngroup && ctx->gtype[g] == DDCMI_BERENDSEN && ctx->gdoScaling[g]) ? ctx->glambda[g] : 1.0;
+      lam.a[g] = 1.0; lam.dfac[g] = 0.0;
+      if (g < ctx->ngroup && ctx->gtype[g] == DDCMI_LANGEVIN)
+      {
+         lam.lang_mask |= 1u << g;
+         lam.a[g] = exp(-dt_half / ctx->gtau[g]);
+         lam.dfac[g] = sqrt(2.0 * dt_half * ctx->gTeq[g] / ctx->gtau[g]);          /* kB = 1 in internal units */
+      }
+   }
    return lam;
 }
 static int step_pre(ddcmi_ctx *ctx, double dt)
@@ -2116,9 +2203,9 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
    int n = ctx->nloc, nb = cdiv(n, 256);
    if (!ctx->drift_done)
    {
-      GroupLambda lam = front_lambda(ctx);
+      GroupLambda lam = front_lambda(ctx, dt);
       if (n > 0)
-         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam,
+         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
    }
    ctx->drift_done = false;             /* else: the previous step's last kernel already did this kick + drift */
@@ -2133,13 +2220,13 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
    int rc;
    if ((rc = launch_forces(ctx, true))) return rc;
    berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
+   GroupLambda lam = front_lambda(ctx, dt);
    if (more_steps && ctx->nloc > 0)
    {
-      GroupLambda lam = front_lambda(ctx);
-      if ((rc = launch_kinetic(ctx, dt, 1, true, &lam))) return rc;
+      if ((rc = launch_kinetic(ctx, dt, 1, true, &lam, true))) return rc;
       ctx->drift_done = true;
    }
-   else if ((rc = launch_kinetic(ctx, dt, 1, true))) return rc;
+   else if ((rc = launch_kinetic(ctx, dt, 1, true, &lam, false))) return rc;
    return DDCMI_OK;
 }
 

@@ -498,6 +498,14 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
          free(type);
       }
    }
+   /* RANDOM (system.c, random.c:44-60): only the seed is used (Langevin noise) */
+   {
+      char *rname = get_string(sys, "random", "NONE");
+      OBJECT *ro = strcmp(rname, "NONE") != 0 ? object_find(rname, "RANDOM") : NULL;
+      s->rng_seed = 0;
+      if (ro) object_get(ro, "seed", &s->rng_seed, U64, 1, "0");
+      free(rname);
+   }
    /* species: via MOLECULECLASS (system.c:139-146, molecule.c:39-66,226-246) or "species" */
    {
       char *mcname = get_string(sys, "moleculeClass", "NONE");

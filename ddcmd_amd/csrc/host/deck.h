@@ -74,6 +74,8 @@ typedef struct ddcmi_setup
    char *accelerator_type;
    /* PRINTINFO unit strings (printinfo.c:51-64) */
    char *u_pressure, *u_volume, *u_temperature, *u_energy, *u_time, *u_length;
+   /* RANDOM seed (random.c:44-60): seeds the Langevin noise */
+   uint64_t rng_seed;
 } ddcmi_setup;
 
 /* Load a deck.  object_file is required; restart_file may be NULL (then

@@ -119,9 +119,11 @@ static void martini_parms(POTENTIAL *potential, SIMULATE *simulate)
    {
       if (s->group_type[g] == DDCMI_GROUP_FREE) gtype[g] = DDCMI_FREE;
       else if (s->group_type[g] == DDCMI_GROUP_BERENDSEN) gtype[g] = DDCMI_BERENDSEN;
-      else die("group_init", "only FREE and BERENDSEN groups are supported on this path (LANGEVIN is a next-row item)");
+      else if (s->group_type[g] == DDCMI_GROUP_LANGEVIN) gtype[g] = DDCMI_LANGEVIN;
+      else die("group_init", "only FREE, BERENDSEN and LANGEVIN groups are supported on this path");
    }
    rc |= ddcmi_set_groups(ctx, s->ngroup, gtype, s->group_Teq, s->group_tau, s->group_interval);
+   rc |= ddcmi_set_random(ctx, s->rng_seed);
    rc |= martiniBondHIPParms(ctx, s);
    rc |= ddcmi_set_clock(ctx, s->loop, s->time);
    if (rc) die("martini_parms", ddcmi_last_error(ctx));

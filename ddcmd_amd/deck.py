@@ -65,6 +65,7 @@ class Setup(object):
         self.nConstraints = 0
         self.integrator_type = "NGLF"
         self.has_accelerator = 0
+        self.rng_seed = 0
         self.accelerator_type = "NONE"
         self.units = {}
 
@@ -99,6 +100,7 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
                   "nlj", "nspecies", "nmoltype", "nresi", "ngroup", "natoms", "nConstraints", "has_accelerator"):
             setattr(s, f, getattr(c, f))
         s.h = np.array(list(c.h), dtype=np.float64)
+        s.rng_seed = int(c.rng_seed)
         n2 = c.nlj * c.nlj
         s.sigma, s.eps, s.shift = (_arr(getattr(c, k), n2, np.float64) for k in ("sigma", "eps", "shift"))
         ns = c.nspecies

@@ -49,6 +49,7 @@ def _declare(lib):
     lib.ddcmi_set_neighbor.argtypes = [vp, ctypes.c_double, ctypes.c_int]
     lib.ddcmi_set_groups.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, _ip]
     lib.ddcmi_set_clock.argtypes = [vp, ctypes.c_int64, ctypes.c_double]
+    lib.ddcmi_set_random.argtypes = [vp, ctypes.c_uint64]
     lib.ddcmi_get_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp]
     lib.ddcmi_upload_state.argtypes = [vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up, _ip, _ip]
     lib.ddcmi_download_state.argtypes = [vp, ctypes.c_int] + [_dp] * 9
@@ -175,8 +176,9 @@ class MartiniHIP(object):
                                                 nt, _i(t["tors_ijkl"]), _i(t["tors_func"]), _i(t["tors_n"]), _d(t["tors_k"]), _d(t["tors_delta"]),
                                                 int(s.excludePotentialTerm)))
         self._chk(self.lib.ddcmi_set_neighbor(self.ctx, s.deltaR, int(s.updateRate)))
-        gt = i32(np.where(np.asarray(s.group_type) == 1, 1, 0))
+        gt = i32(np.where(np.isin(np.asarray(s.group_type), (1, 2)), np.asarray(s.group_type), 0))     # FREE / BERENDSEN / LANGEVIN
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
+        self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
         self._chk(self.lib.ddcmi_set_clock(self.ctx, int(s.loop), float(s.time)))
         self.n = s.natoms
         if upload:

@@ -40,7 +40,7 @@ enum { DDCMI_XX = 0, DDCMI_YY, DDCMI_ZZ, DDCMI_XY, DDCMI_XZ, DDCMI_YZ };
 /* download mask */
 enum { DDCMI_POS = 1, DDCMI_VEL = 2, DDCMI_FORCE = 4 };
 /* group (thermostat) kinds: free.c, berendsen.c */
-enum { DDCMI_FREE = 0, DDCMI_BERENDSEN = 1 };
+enum { DDCMI_FREE = 0, DDCMI_BERENDSEN = 1, DDCMI_LANGEVIN = 2 };
 
 /* ---- context -------------------------------------------------------------
  * replaces accelerator_init / accelerator_getAccelerator (accelerator.c:10-56)
@@ -92,8 +92,13 @@ int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
 /* NEIGHBOR deltaR (neighbor.c:49) and DDC updateRate (ddc.c:96).  updateRate = 0: rebuild when
  * neighborCheck (neighbor.c:117-208) finds 2*max displacement >= deltaR (one host round trip per step) */
 int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);
-/* GROUP objects (group.c:48-90): type DDCMI_FREE / DDCMI_BERENDSEN{Teq,tau,interval} */
+/* GROUP objects (group.c:48-90): type DDCMI_FREE / DDCMI_BERENDSEN{Teq,tau,interval} /
+ * DDCMI_LANGEVIN{Teq,tau} (langevin.c:92-128, constant Teq, vcm = 0).  Teq in internal energy units
+ * (kB = 1).  The Langevin noise is a counter-based normal stream keyed by (seed, gid, loop): the
+ * reference's per-particle LCG64 states are not reproduced -- statistical parity only. */
 int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval);
+/* RANDOM seed (random.c:44-60) for the Langevin noise */
+int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed);
 /* SIMULATE loop/time (simulate.c:146,155) */
 int ddcmi_set_clock(ddcmi_ctx *ctx, int64_t loop, double time);
 

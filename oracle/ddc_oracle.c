@@ -733,6 +733,29 @@ int orc_neighbor_check(const orc_params *p, const orc_nbr *nb, int n, const doub
    return (2.0 * sqrt(d2max) < p->deltaR) ? 0 : 1;
 }
 
+/* Langevin noise.  ddcMD draws three unit normals per particle and half step from a per-particle
+ * LCG64 stream (lcg64.c, gasdev3d random.c:135-160) whose state travels with the particle.  The
+ * device implementation replaces the stream by a counter-based one -- normals are a pure function
+ * of (seed, gid, counter = 2*loop + {0 FRONT, 1 BACK}) -- and this restates exactly that function:
+ * splitmix64 hashes, Box-Muller.  Parity with the reference is therefore statistical only. */
+static unsigned long long smix64(unsigned long long z)
+{
+   z += 0x9E3779B97F4A7C15ull;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+   return z ^ (z >> 31);
+}
+void orc_gauss3(unsigned long long seed, unsigned long long gid, unsigned long long counter, double g[3])
+{
+   const unsigned long long key = smix64(seed ^ smix64(gid)) + 4ull * counter;
+   const double two53 = 1.0 / 9007199254740992.0;
+   double u1 = ((double)(smix64(key) >> 11) + 0.5) * two53, u2 = ((double)(smix64(key + 1) >> 11) + 0.5) * two53;
+   double u3 = ((double)(smix64(key + 2) >> 11) + 0.5) * two53, u4 = ((double)(smix64(key + 3) >> 11) + 0.5) * two53;
+   double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
+   g[0] = r * cos(t); g[1] = r * sin(t);
+   g[2] = sqrt(-2.0 * log(u3)) * cos(6.283185307179586476925 * u4);
+}
+
 void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt,
                    long *loop, double *time, int n,
                    double *rx, double *ry, double *rz, double *vx, double *vy, double *vz,
@@ -746,6 +769,16 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
    {
       const orc_group *g = &groups[group[k]];
       double mass = p->mass[species[k]];
+      if (g->type == 2)
+      {
+         /* langevin_velocityUpdate FRONT_TIMESTEP (langevin.c:92-128), called with dt/2 */
+         double dth = 0.5 * dt, al = exp(-dth / g->tau), c = dth / mass, d = sqrt(2.0 * dth * g->Teq / (mass * g->tau)), gg[3];
+         orc_gauss3(g->seed, gid[k], 2ull * (unsigned long long)(*loop), gg);
+         vx[k] = al * vx[k] + c * fx[k] + d * gg[0];
+         vy[k] = al * vy[k] + c * fy[k] + d * gg[1];
+         vz[k] = al * vz[k] + c * fz[k] + d * gg[2];
+         continue;
+      }
       if (g->type == 1 && g->doScaling == 1) { vx[k] *= g->lambda; vy[k] *= g->lambda; vz[k] *= g->lambda; }
       double a = (0.5 * dt) / mass;
       vx[k] += a * fx[k]; vy[k] += a * fy[k]; vz[k] += a * fz[k];
@@ -767,7 +800,19 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
    /* :100-104 BACK velocityUpdate(dt/2) */
    for (int k = 0; k < n; k++)
    {
-      double a = (0.5 * dt) / p->mass[species[k]];
+      const orc_group *g = &groups[group[k]];
+      double mass = p->mass[species[k]];
+      if (g->type == 2)
+      {
+         /* BACK_TIMESTEP: v = a (v + c f + d g), loop already advanced */
+         double dth = 0.5 * dt, al = exp(-dth / g->tau), c = dth / mass, d = sqrt(2.0 * dth * g->Teq / (mass * g->tau)), gg[3];
+         orc_gauss3(g->seed, gid[k], 2ull * (unsigned long long)(*loop) + 1ull, gg);
+         vx[k] = al * (vx[k] + c * fx[k] + d * gg[0]);
+         vy[k] = al * (vy[k] + c * fy[k] + d * gg[1]);
+         vz[k] = al * (vz[k] + c * fz[k] + d * gg[2]);
+         continue;
+      }
+      double a = (0.5 * dt) / mass;
       vx[k] += a * fx[k]; vy[k] += a * fy[k]; vz[k] += a * fz[k];
    }
    /* :105 kinetic_terms */

@@ -127,12 +127,13 @@ void orc_energyinfo(const orc_params *p, double natoms, int nConstraints, double
 /* thermostat description per group (group.c:48-90) */
 typedef struct orc_group
 {
-   int type;         /* 0 FREE (free.c), 1 BERENDSEN (berendsen.c) */
-   double Teq, tau;  /* berendsen */
+   int type;         /* 0 FREE (free.c), 1 BERENDSEN (berendsen.c), 2 LANGEVIN (langevin.c, constant Teq, vcm = 0) */
+   double Teq, tau;  /* berendsen, langevin (Teq in energy units, kB = 1) */
    int interval;
    /* dynamic state (berendsen.c:12-20) */
    double lambda, Tsum; int nT, doScaling;
    double temperature; /* g->energyInfo.temperature, refreshed by orc_group_temperature */
+   unsigned long long seed;   /* langevin: seed of the counter-based normal stream (see orc_gauss3) */
 } orc_group;
 
 /* nglf (nglf.c:67-112): one velocity-Verlet step.  Rebuilds the list when

@@ -38,7 +38,7 @@ class OrcParams(ctypes.Structure):
 class OrcGroup(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int), ("Teq", ctypes.c_double), ("tau", ctypes.c_double), ("interval", ctypes.c_int),
                 ("lambda_", ctypes.c_double), ("Tsum", ctypes.c_double), ("nT", ctypes.c_int), ("doScaling", ctypes.c_int),
-                ("temperature", ctypes.c_double)]
+                ("temperature", ctypes.c_double), ("seed", ctypes.c_ulonglong)]
 
 
 def build(native=False, out=None):
@@ -127,7 +127,8 @@ class Oracle(object):
         self.group = np.ascontiguousarray(s.group, dtype=np.int32)
         self.groups = (OrcGroup * max(1, s.ngroup))()
         for g in range(s.ngroup):
-            self.groups[g].type = 1 if s.group_type[g] == 1 else 0
+            self.groups[g].type = int(s.group_type[g]) if int(s.group_type[g]) in (1, 2) else 0
+            self.groups[g].seed = int(getattr(s, "rng_seed", 0))
             self.groups[g].Teq = s.group_Teq[g]
             self.groups[g].tau = s.group_tau[g]
             self.groups[g].interval = max(1, int(s.group_interval[g]))

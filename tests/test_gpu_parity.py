@@ -357,3 +357,38 @@ def test_displacement_triggered_rebuilds():
     assert len(rebuilds_gpu) >= 3
     assert rebuilds_gpu == rebuilds_cpu
     m.close()
+
+
+def test_langevin_group_matches_oracle_and_thermalises():
+    """LANGEVIN group (langevin.c:92-128): the device update equals the oracle's restatement with the same
+    counter-based normal stream (trajectory parity), and drives a 50 K box to Teq (the statistical
+    parity the reference's own per-particle LCG64 streams allow)"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(10)
+    s.group_type = np.array([2], np.int32)
+    s.group_Teq = np.array([units_convert(310.0, "K")])
+    s.group_tau = np.array([units_convert(0.2, "ps")])
+    s.rng_seed = 12345
+    o = pyoracle.Oracle(s)
+    o.forces()
+    m = MartiniHIP(s)
+    m.eval_forces()
+    for block in range(4):
+        eo, vo, rko, _ = o.step(5)
+        m.step(5 if block % 2 else 1)           # fused and split kick kernels draw the same numbers
+        if block % 2 == 0:
+            m.step(4)
+        e, vir, rk, _ = m.energies()
+        assert abs(rk - rko) < TOL * rko, block
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+    d = m.download()
+    assert np.abs(d["v"][0] - o.vx).max() < 1e-6 * np.abs(o.vx).max()
+    # thermalisation: tau = 0.2 ps, 400 steps of 20 fs = 40 tau
+    m.step(400)
+    T = []
+    for _ in range(10):
+        m.step(20)
+        rk = m.energies()[2]
+        T.append(2.0 * rk / (3.0 * s.natoms) / units_convert(1.0, "K"))
+    assert abs(np.mean(T) - 310.0) < 0.03 * 310.0, T
+    m.close()
