@@ -472,11 +472,69 @@ static int localize_kind(ddcmi_ctx *ctx, int nterm, const uint64_t *tgid, dbuf<i
    return DDCMI_OK;
 }
 
+/* ---- RESTRAINT potential (restraint.c:259-361) --------------------------------------- */
+/* assignRestraintMap: the owned slot of each restrained gid (-1 when another rank owns it) */
+__global__ void k_rest_locate(int nrest, const uint64_t *__restrict__ rgid, int nloc, unsigned mask, const unsigned long long *keys, const int *vals, int *slot)
+{
+   int r = blockIdx.x * blockDim.x + threadIdx.x;
+   if (r >= nrest) return;
+   int s = gid_find(rgid[r], mask, keys, vals);
+   slot[r] = (s >= 0 && s < nloc) ? s : -1;
+}
+/* E = kb sum_c fc_c d_c^2, f_c = -2 kb fc_c d_c, virial += f (x) (fc d); d is the nearest image of
+ * r - r0 (the reference applies nearestImage only when a restrained component exceeds half the
+ * box: the same thing).  One workgroup, fixed summation order. */
+__global__ __launch_bounds__(256) void k_restraint(int nrest, BoxArgs box, int origin, const int *__restrict__ slot, const int *__restrict__ fc,
+                                                   const double *__restrict__ r0, const double *__restrict__ kb_, const double4 *__restrict__ pos,
+                                                   double *fx, double *fy, double *fz, double *out)
+{
+   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   for (int r = threadIdx.x; r < nrest; r += 256)
+   {
+      int i = slot[r];
+      if (i < 0) continue;
+      double4 p = pos[i];
+      double d[3], c[3], pp[3] = {p.x, p.y, p.z};
+      for (int a = 0; a < 3; a++)
+      {
+         double x0 = r0[3 * r + a] * box.L[a];
+         if (origin == 0) x0 -= 0.5 * box.L[a];
+         d[a] = pp[a] - x0;
+         if (box.pbc >> a & 1) d[a] -= box.L[a] * rint(box.Linv[a] * d[a]);
+         c[a] = fc[3 * r + a] * d[a];
+      }
+      double kb = kb_[r], kforce = -2 * kb;
+      double f0 = kforce * c[0], f1 = kforce * c[1], f2 = kforce * c[2];
+      atomicAdd(&fx[i], f0); atomicAdd(&fy[i], f1); atomicAdd(&fz[i], f2);
+      acc[0] += kb * (c[0] * d[0] + c[1] * d[1] + c[2] * d[2]);
+      acc[1] += f0 * c[0]; acc[2] += f1 * c[1]; acc[3] += f2 * c[2];
+      acc[4] += f0 * c[1]; acc[5] += f0 * c[2]; acc[6] += f1 * c[2];
+   }
+   block_store<8>(acc, out);
+}
+extern "C" int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, const int *fc, const double *r0, const double *kb, int origin)
+{
+   if (!ctx || n < 0 || (n > 0 && (!gid || !fc || !r0 || !kb))) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   int rc;
+   ctx->nrest = n; ctx->rest_origin = origin;
+   if (n > 0)
+   {
+      if ((rc = up(ctx, ctx->rest_gid, gid, (size_t)n)) || (rc = up(ctx, ctx->rest_fc, fc, 3 * (size_t)n)) ||
+          (rc = up(ctx, ctx->rest_r0, r0, 3 * (size_t)n)) || (rc = up(ctx, ctx->rest_kb, kb, (size_t)n))) return rc;
+      ENSURE(ctx, ctx->rest_slot, (size_t)n);
+   }
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_REST, 0, 8 * sizeof(double), ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   ctx->forces_valid = false; ctx->list_valid = false;
+   return DDCMI_OK;
+}
+
 /* decomposed runs, at every list rebuild: find the terms that touch an owned bead and
  * the device slots (owned or halo) of their atoms */
 int ddcmi_bonded_localize(ddcmi_ctx *ctx)
 {
-   if (!ctx->bonded_gid) return DDCMI_OK;
+   if (!ctx->bonded_gid && ctx->nrest == 0) return DDCMI_OK;
    hipStream_t st = ctx->stream;
    const int nall = ctx->nloc + ctx->nhalo;
    unsigned cap = 1024;
@@ -490,6 +548,9 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
       hipLaunchKernelGGL(k_gid_insert, dim3(cdiv(nall, 256)), dim3(256), 0, st, nall, ctx->gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p);
    int rc;
    int *d_total = ctx->d_flags + 8;
+   if (ctx->nrest > 0)
+      hipLaunchKernelGGL(k_rest_locate, dim3(cdiv(ctx->nrest, 256)), dim3(256), 0, st, ctx->nrest, ctx->rest_gid.p, ctx->nloc, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->rest_slot.p);
+   if (!ctx->bonded_gid) { HIPCHK(ctx, hipStreamSynchronize(st)); return DDCMI_OK; }
    if ((rc = localize_kind<2>(ctx, ctx->g_nbond, ctx->gbond_gid.p, ctx->l_bond_map, ctx->l_bond_atoms, &ctx->nbond, d_total))) return rc;
    if ((rc = localize_kind<3>(ctx, ctx->g_nangle, ctx->gangle_gid.p, ctx->l_angle_map, ctx->l_angle_atoms, &ctx->nangle, d_total))) return rc;
    if ((rc = localize_kind<4>(ctx, ctx->g_ntors, ctx->gtors_gid.p, ctx->l_tors_map, ctx->l_tors_atoms, &ctx->ntors, d_total))) return rc;
@@ -504,12 +565,16 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
 
 int ddcmi_launch_bonded(ddcmi_ctx *ctx)
 {
-   if (ctx->nbond + ctx->nangle + ctx->ntors == 0) return DDCMI_OK;
+   if (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest == 0) return DDCMI_OK;
    hipStream_t st = ctx->stream;
    BoxArgs box;
    box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
    for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
    box.pbc = ctx->pbc;
+   if (ctx->nrest > 0)
+      hipLaunchKernelGGL(k_restraint, dim3(1), dim3(256), 0, st, ctx->nrest, box, ctx->rest_origin, ctx->rest_slot.p, ctx->rest_fc.p, ctx->rest_r0.p, ctx->rest_kb.p,
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_REST);
+   if (ctx->nbond + ctx->nangle + ctx->ntors == 0) return DDCMI_OK;
    const bool gidmode = ctx->bonded_gid;
    int nbb = cdiv(ctx->nbond, 256), nab = cdiv(ctx->nangle, 256), ntb = cdiv(ctx->ntors, 256);
    ENSURE(ctx, ctx->bpartials, (size_t)(nbb + nab + ntb + 3) * 8);

@@ -1068,9 +1068,10 @@ __device__ void finish_energy(double *r, double self_ele)
    double eb[4] = {r[R_SCR_BOND], r[R_SCR_ANGLE], r[R_SCR_TORS], r[R_SCR_TORS + 1]};
    double etot = lj + ele;
    for (int k = 0; k < 4; k++) { r[R_E + DDCMI_E_BOND + k] = eb[k]; etot += eb[k]; }
-   r[R_E + DDCMI_E_TOTAL] = etot;
+   r[R_E + DDCMI_E_RESTRAINT] = r[R_SCR_REST];
+   r[R_E + DDCMI_E_TOTAL] = etot + r[R_SCR_REST];
    for (int k = 0; k < 6; k++)
-      r[R_VIR + k] = 0.5 * r[R_NB_VIR + k] + ((r[R_SCR_BOND + 1 + k] + r[R_SCR_ANGLE + 1 + k]) + r[R_SCR_TORS + 2 + k]);
+      r[R_VIR + k] = 0.5 * r[R_NB_VIR + k] + ((r[R_SCR_BOND + 1 + k] + r[R_SCR_ANGLE + 1 + k]) + r[R_SCR_TORS + 2 + k]) + r[R_SCR_REST + 1 + k];
 }
 
 __global__ void k_finish_energy(double *r, double self_ele)
@@ -1431,7 +1432,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
-   ctx->d_exmask.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
+   ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -2038,7 +2039,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
    else if (nh > 0)
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
-   const bool has_bonded = (ctx->nbond + ctx->nangle + ctx->ntors) > 0;
+   const bool has_bonded = (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) > 0;
    const double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
    if ((ctx->excludePotentialTerm & 128) == 0)
    {

@@ -87,6 +87,7 @@ enum
    R_SCR_BOND = 8,                                 /* bonded kernels' reduced sums: {e, vir6} */
    R_SCR_ANGLE = 16,                               /* {e, vir6} */
    R_SCR_TORS = 24,                                /* {e_tors, e_impr, vir6} */
+   R_SCR_REST = 32,                                /* RESTRAINT potential: {e, vir6} */
    R_RK = 56, R_TION = 57,
    R_E = 64,                                       /* final energies[DDCMI_NE] */
    R_VIR = 72,                                     /* final virial[6] */
@@ -153,6 +154,9 @@ struct ddcmi_ctx
    dbuf<int> bond_ij, angle_ijk, angle_func, tors_ijkl, tors_func, tors_n;
    /* decomposed runs: global terms by gid (ddcmi_set_bonded_gid) and, rebuilt with the
     * lists, the terms touching an owned bead with the device slots of their atoms */
+   /* RESTRAINT potential: restraints by gid; rest_slot = owned device slot of each (or -1), found at rebuilds */
+   int nrest = 0, rest_origin = 0;
+   dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
    bool bonded_gid = false;
    int g_nbond = 0, g_nangle = 0, g_ntors = 0;
    dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;

@@ -570,7 +570,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
    {
       char **pnames = NULL;
       int np = object_getv(sys, "potential", (void **)&pnames, STRING, IGNORE_IF_NOT_FOUND);
-      OBJECT *pot = NULL;
+      OBJECT *pot = NULL, *rpot = NULL;
       for (int i = 0; i < np; i++)
       {
          OBJECT *po = object_find(pnames[i], "POTENTIAL");
@@ -578,6 +578,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
          {
             char *type = get_string(po, "type", "");
             if (strcmp(type, "MARTINI") == 0 && !pot) pot = po;
+            if (strcmp(type, "RESTRAINT") == 0 && !rpot) rpot = po;
             free(type);
          }
          free(pnames[i]);
@@ -608,6 +609,39 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
          s->crf = 1.5 * irc;
       }
       s->keR = units_ke() / s->epsilon_r;   /* bioMartini.c:1033 */
+      /* POTENTIAL type=RESTRAINT (restraint.c:177-208, :57-120): parmfile -> RESTRAINTLIST "restraint" */
+      if (rpot)
+      {
+         char *rfile = get_string(rpot, "parmfile", "restraint.data");
+         char *rf = path_join(dir, rfile);
+         if (object_compilefile(rf) < 0) { free(rf); FAIL("cannot read restraint parmfile %s", rfile); }
+         free(rf); free(rfile);
+         OBJECT *rl = object_find("restraint", "RESTRAINTLIST");
+         if (!rl) FAIL("RESTRAINTLIST object 'restraint' not found");
+         object_get(rl, "origin", &s->rest_origin, INT, 1, "0");
+         char **rnames = NULL;
+         int nr = object_getv(rl, "restraintList", (void **)&rnames, STRING, IGNORE_IF_NOT_FOUND);
+         s->nrest = nr > 0 ? nr : 0;
+         s->rest_gid = calloc(s->nrest + 1, sizeof(uint64_t));
+         s->rest_fc = calloc(3 * s->nrest + 3, sizeof(int));
+         s->rest_r0 = calloc(3 * s->nrest + 3, sizeof(double));
+         s->rest_kb = calloc(s->nrest + 1, sizeof(double));
+         for (int r = 0; r < s->nrest; r++)
+         {
+            OBJECT *ro = object_find(rnames[r], "RESTRAINTPARMS");
+            if (!ro) FAIL("RESTRAINTPARMS %s not found", rnames[r]);
+            object_get(ro, "gid", &s->rest_gid[r], U64, 1, "0");
+            object_get(ro, "fcx", &s->rest_fc[3 * r], INT, 1, "0");
+            object_get(ro, "fcy", &s->rest_fc[3 * r + 1], INT, 1, "0");
+            object_get(ro, "fcz", &s->rest_fc[3 * r + 2], INT, 1, "0");
+            object_get(ro, "x0", &s->rest_r0[3 * r], DOUBLE, 1, "0");
+            object_get(ro, "y0", &s->rest_r0[3 * r + 1], DOUBLE, 1, "0");
+            object_get(ro, "z0", &s->rest_r0[3 * r + 2], DOUBLE, 1, "0");
+            object_get(ro, "kb", &s->rest_kb[r], WITH_UNITS, 1, "0.0", "kJ*mol^-1*nm^-2", NULL);
+            free(rnames[r]);
+         }
+         free(rnames);
+      }
    }
    /* MMFF (bioMMFF.c:236-270): object named "martini" */
    OBJECT *mmff = object_find("martini", "MMFF");
@@ -808,6 +842,7 @@ void ddcmi_setup_free(ddcmi_setup *s)
    for (int i = 0; i < s->ngroup; i++) if (s->group_name) free(s->group_name[i]);
    free(s->group_name); free(s->group_type); free(s->group_Teq); free(s->group_tau); free(s->group_interval);
    free(s->rx); free(s->ry); free(s->rz); free(s->vx); free(s->vy); free(s->vz); free(s->gid); free(s->species); free(s->group);
+   free(s->rest_gid); free(s->rest_fc); free(s->rest_r0); free(s->rest_kb);
    free(s->integrator_type); free(s->accelerator_type);
    free(s->u_pressure); free(s->u_volume); free(s->u_temperature); free(s->u_energy); free(s->u_time); free(s->u_length);
    free(s);

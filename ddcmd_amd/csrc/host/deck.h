@@ -76,6 +76,11 @@ typedef struct ddcmi_setup
    char *u_pressure, *u_volume, *u_temperature, *u_energy, *u_time, *u_length;
    /* RANDOM seed (random.c:44-60): seeds the Langevin noise */
    uint64_t rng_seed;
+   /* POTENTIAL type=RESTRAINT (restraint.c:28-49): restraints by gid, r0 as box fractions */
+   int nrest, rest_origin;
+   uint64_t *rest_gid;
+   int *rest_fc;
+   double *rest_r0, *rest_kb;
 } ddcmi_setup;
 
 /* Load a deck.  object_file is required; restart_file may be NULL (then

@@ -124,6 +124,8 @@ static void martini_parms(POTENTIAL *potential, SIMULATE *simulate)
    }
    rc |= ddcmi_set_groups(ctx, s->ngroup, gtype, s->group_Teq, s->group_tau, s->group_interval);
    rc |= ddcmi_set_random(ctx, s->rng_seed);
+   if (s->nrest > 0)      /* restraint_parms + restraintGPU_parms (restraint.c:177-208) */
+      rc |= ddcmi_set_restraints(ctx, s->nrest, s->rest_gid, s->rest_fc, s->rest_r0, s->rest_kb, s->rest_origin);
    rc |= martiniBondHIPParms(ctx, s);
    rc |= ddcmi_set_clock(ctx, s->loop, s->time);
    if (rc) die("martini_parms", ddcmi_last_error(ctx));

@@ -66,6 +66,11 @@ class Setup(object):
         self.integrator_type = "NGLF"
         self.has_accelerator = 0
         self.rng_seed = 0
+        self.nrest, self.rest_origin = 0, 0
+        self.rest_gid = np.zeros(0, np.uint64)
+        self.rest_fc = np.zeros((0, 3), np.int32)
+        self.rest_r0 = np.zeros((0, 3))
+        self.rest_kb = np.zeros(0)
         self.accelerator_type = "NONE"
         self.units = {}
 
@@ -101,6 +106,11 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
             setattr(s, f, getattr(c, f))
         s.h = np.array(list(c.h), dtype=np.float64)
         s.rng_seed = int(c.rng_seed)
+        s.nrest, s.rest_origin = int(c.nrest), int(c.rest_origin)
+        s.rest_gid = _arr(c.rest_gid, s.nrest, np.uint64) if s.nrest else np.zeros(0, np.uint64)
+        s.rest_fc = _arr(c.rest_fc, 3 * s.nrest, np.int32).reshape(-1, 3) if s.nrest else np.zeros((0, 3), np.int32)
+        s.rest_r0 = _arr(c.rest_r0, 3 * s.nrest, np.float64).reshape(-1, 3) if s.nrest else np.zeros((0, 3))
+        s.rest_kb = _arr(c.rest_kb, s.nrest, np.float64) if s.nrest else np.zeros(0)
         n2 = c.nlj * c.nlj
         s.sigma, s.eps, s.shift = (_arr(getattr(c, k), n2, np.float64) for k in ("sigma", "eps", "shift"))
         ns = c.nspecies

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 from . import _lib
 
-E_NAMES = ("lj", "ele", "bond", "angle", "tors", "impr", "total")
+E_NAMES = ("lj", "ele", "bond", "angle", "tors", "impr", "total", "restraint")
 POS, VEL, FORCE = 1, 2, 4
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -50,6 +50,7 @@ def _declare(lib):
     lib.ddcmi_set_groups.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, _ip]
     lib.ddcmi_set_clock.argtypes = [vp, ctypes.c_int64, ctypes.c_double]
     lib.ddcmi_set_random.argtypes = [vp, ctypes.c_uint64]
+    lib.ddcmi_set_restraints.argtypes = [vp, ctypes.c_int, _up, _ip, _dp, _dp, ctypes.c_int]
     lib.ddcmi_get_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp]
     lib.ddcmi_upload_state.argtypes = [vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up, _ip, _ip]
     lib.ddcmi_download_state.argtypes = [vp, ctypes.c_int] + [_dp] * 9
@@ -179,6 +180,12 @@ class MartiniHIP(object):
         gt = i32(np.where(np.isin(np.asarray(s.group_type), (1, 2)), np.asarray(s.group_type), 0))     # FREE / BERENDSEN / LANGEVIN
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
         self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
+        nrest = int(getattr(s, "nrest", 0))
+        if nrest > 0:     # RESTRAINT potential
+            self._rest = (np.ascontiguousarray(s.rest_gid, dtype=np.uint64), i32(np.asarray(s.rest_fc).ravel()),
+                          f64(np.asarray(s.rest_r0).ravel()), f64(s.rest_kb))
+            self._chk(self.lib.ddcmi_set_restraints(self.ctx, nrest, self._rest[0].ctypes.data_as(_up), _i(self._rest[1]), _d(self._rest[2]),
+                                                    _d(self._rest[3]), int(getattr(s, "rest_origin", 0))))
         self._chk(self.lib.ddcmi_set_clock(self.ctx, int(s.loop), float(s.time)))
         self.n = s.natoms
         if upload:
@@ -215,7 +222,7 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_build_list(self.ctx))
 
     def eval_forces(self):
-        e = np.zeros(7)
+        e = np.zeros(8)
         v = np.zeros(6)
         self._chk(self.lib.ddcmi_eval_forces(self.ctx, _d(e), _d(v)))
         return dict(zip(E_NAMES, e.tolist())), v
@@ -224,7 +231,7 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_step_nglf(self.ctx, float(self.s.dt if dt is None else dt), int(nsteps)))
 
     def energies(self):
-        e, v, t = np.zeros(7), np.zeros(6), np.zeros(6)
+        e, v, t = np.zeros(8), np.zeros(6), np.zeros(6)
         rk = ctypes.c_double(0)
         self._chk(self.lib.ddcmi_get_energies(self.ctx, _d(e), _d(v), ctypes.byref(rk), _d(t)))
         return dict(zip(E_NAMES, e.tolist())), v, rk.value, t

@@ -34,7 +34,7 @@ enum
 
 /* energies[] slots of ddcmi_eval_forces / ddcmi_get_energies (BIOENERGIES,
  * bioCharmmParms.h; e->eion is slot DDCMI_E_TOTAL) */
-enum { DDCMI_E_LJ = 0, DDCMI_E_ELE, DDCMI_E_BOND, DDCMI_E_ANGLE, DDCMI_E_TORS, DDCMI_E_IMPR, DDCMI_E_TOTAL, DDCMI_NE };
+enum { DDCMI_E_LJ = 0, DDCMI_E_ELE, DDCMI_E_BOND, DDCMI_E_ANGLE, DDCMI_E_TORS, DDCMI_E_IMPR, DDCMI_E_TOTAL, DDCMI_E_RESTRAINT, DDCMI_NE };
 /* virial / tion component order (THREE_SMATRIX as summed in bioMartini.c:1098-1103) */
 enum { DDCMI_XX = 0, DDCMI_YY, DDCMI_ZZ, DDCMI_XY, DDCMI_XZ, DDCMI_YZ };
 /* download mask */
@@ -89,6 +89,11 @@ int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
                          int nangle, const uint64_t *angle_gid, const int *angle_func, const double *angle_k, const double *angle_t0,
                          int ntors, const uint64_t *tors_gid, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
                          int excludePotentialTerm);
+/* POTENTIAL type=RESTRAINT (restraint.c:259-361; restraintGPU.cu): harmonic position restraints on the
+ * beads with the listed gids.  fc[3n] = fcx fcy fcz switches, r0[3n] = x0 y0 z0 as fractions of the box,
+ * kb[n]; origin 0: the box is centred on the origin (r0*L - L/2).  Energy lands in DDCMI_E_RESTRAINT
+ * and in DDCMI_E_TOTAL.  n = 0 removes them. */
+int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, const int *fc, const double *r0, const double *kb, int origin);
 /* NEIGHBOR deltaR (neighbor.c:49) and DDC updateRate (ddc.c:96).  updateRate = 0: rebuild when
  * neighborCheck (neighbor.c:117-208) finds 2*max displacement >= deltaR (one host round trip per step) */
 int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);

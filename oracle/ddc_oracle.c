@@ -590,6 +590,32 @@ void orc_forces(const orc_params *p, const orc_nbr *nb, int n,
    orc_bonded(p, n, rx, ry, rz, gid, species, fx, fy, fz, e4, virial);
    e[ORC_E_BOND] = e4[0]; e[ORC_E_ANGLE] = e4[1]; e[ORC_E_TORS] = e4[2]; e[ORC_E_IMPR] = e4[3];
    e[ORC_E_TOTAL] = e[ORC_E_LJ] + e[ORC_E_ELE] + e4[0] + e4[1] + e4[2] + e4[3];   /* e->eion */
+   /* restraint() (restraint.c:259-361): a second POTENTIAL adding to eion, f and the virial */
+   e[ORC_E_RESTRAINT] = 0.0;
+   for (int r = 0; r < p->nrest; r++)
+   {
+      int ii = -1;
+      for (int k = 0; k < n; k++) if (gid[k] == p->rest_gid[r]) { ii = k; break; }      /* restraintMap */
+      if (ii < 0) continue;
+      double L[3] = {p->hxx, p->hyy, p->hzz}, d[3], c[3], pos[3] = {rx[ii], ry[ii], rz[ii]};
+      for (int a = 0; a < 3; a++)
+      {
+         double x0 = p->rest_r0[3 * r + a] * L[a];
+         if (p->rest_origin == 0) x0 -= 0.5 * L[a];
+         d[a] = pos[a] - x0;
+      }
+      int wrap = 0;
+      for (int a = 0; a < 3; a++) if (p->rest_fc[3 * r + a] > 0 && fabs(d[a]) > 0.5 * L[a]) wrap = 1;
+      if (wrap) nearestImage(p, &d[0], &d[1], &d[2]);
+      for (int a = 0; a < 3; a++) c[a] = p->rest_fc[3 * r + a] * d[a];
+      double kb = p->rest_kb[r];
+      e[ORC_E_RESTRAINT] += kb * (c[0] * d[0] + c[1] * d[1] + c[2] * d[2]);
+      double kforce = -2 * kb, f[3] = {kforce * c[0], kforce * c[1], kforce * c[2]};
+      fx[ii] += f[0]; fy[ii] += f[1]; fz[ii] += f[2];
+      virial[0] += f[0] * c[0]; virial[1] += f[1] * c[1]; virial[2] += f[2] * c[2];
+      virial[3] += f[0] * c[1]; virial[4] += f[0] * c[2]; virial[5] += f[1] * c[2];
+   }
+   e[ORC_E_TOTAL] += e[ORC_E_RESTRAINT];
 }
 
 /* ------------------------------------------------------------------ */

@@ -69,10 +69,17 @@ typedef struct orc_params
    const int *torsI, *torsJ, *torsK, *torsL, *tors_func, *tors_n; /* func 1 proper, 2 improper */
    const double *tors_k, *tors_delta;
    int excludePotentialTerm;   /* bitmask bioCharmmParms.h:25-28 */
+   /* RESTRAINT potential (restraint.c:259-361): harmonic position restraints by gid */
+   int nrest;
+   const uint64_t *rest_gid;   /* [nrest] */
+   const int *rest_fc;         /* [3*nrest] fcx fcy fcz */
+   const double *rest_r0;      /* [3*nrest] x0 y0 z0 as fractions of the box */
+   const double *rest_kb;      /* [nrest] */
+   int rest_origin;            /* 0: box centred on the origin (x0*L - L/2) */
 } orc_params;
 
 /* energies returned by orc_forces: */
-enum { ORC_E_LJ = 0, ORC_E_ELE, ORC_E_BOND, ORC_E_ANGLE, ORC_E_TORS, ORC_E_IMPR, ORC_E_TOTAL, ORC_NE };
+enum { ORC_E_LJ = 0, ORC_E_ELE, ORC_E_BOND, ORC_E_ANGLE, ORC_E_TORS, ORC_E_IMPR, ORC_E_TOTAL, ORC_E_RESTRAINT, ORC_NE };
 
 typedef struct orc_nbr orc_nbr;   /* half neighbour list (opaque) */
 

@@ -15,7 +15,7 @@ dp = ctypes.POINTER(ctypes.c_double)
 ip = ctypes.POINTER(ctypes.c_int)
 up = ctypes.POINTER(ctypes.c_uint64)
 
-E_NAMES = ("lj", "ele", "bond", "angle", "tors", "impr", "total")
+E_NAMES = ("lj", "ele", "bond", "angle", "tors", "impr", "total", "restraint")
 
 
 class OrcParams(ctypes.Structure):
@@ -32,6 +32,7 @@ class OrcParams(ctypes.Structure):
         ("tors_off", ip), ("torsI", ip), ("torsJ", ip), ("torsK", ip), ("torsL", ip), ("tors_func", ip), ("tors_n", ip),
         ("tors_k", dp), ("tors_delta", dp),
         ("excludePotentialTerm", ctypes.c_int),
+        ("nrest", ctypes.c_int), ("rest_gid", up), ("rest_fc", ip), ("rest_r0", dp), ("rest_kb", dp), ("rest_origin", ctypes.c_int),
     ]
 
 
@@ -104,6 +105,18 @@ class Oracle(object):
         p.deltaR, p.rmax, p.krf, p.crf, p.keR = s.deltaR, s.rmax, s.krf, s.crf, s.keR
         p.nlj, p.nspecies, p.nmoltype, p.nresi = s.nlj, s.nspecies, s.nmoltype, s.nresi
         p.excludePotentialTerm = s.excludePotentialTerm
+        # RESTRAINT potential (optional Setup fields)
+        nrest = int(getattr(s, "nrest", 0))
+        p.nrest = nrest
+        p.rest_origin = int(getattr(s, "rest_origin", 0))
+        self._keep["rest_gid"] = np.ascontiguousarray(getattr(s, "rest_gid", np.zeros(1)), dtype=np.uint64) if nrest else np.zeros(1, np.uint64)
+        self._keep["rest_fc"] = np.ascontiguousarray(getattr(s, "rest_fc", np.zeros(3)), dtype=np.int32).ravel() if nrest else np.zeros(3, np.int32)
+        self._keep["rest_r0"] = np.ascontiguousarray(getattr(s, "rest_r0", np.zeros(3)), dtype=np.float64).ravel() if nrest else np.zeros(3)
+        self._keep["rest_kb"] = np.ascontiguousarray(getattr(s, "rest_kb", np.zeros(1)), dtype=np.float64) if nrest else np.zeros(1)
+        p.rest_gid = self._keep["rest_gid"].ctypes.data_as(up)
+        p.rest_fc = _i(self._keep["rest_fc"])
+        p.rest_r0 = _d(self._keep["rest_r0"])
+        p.rest_kb = _d(self._keep["rest_kb"])
         for k in ("sigma", "eps", "shift", "mass", "charge", "bond_kb", "bond_b0", "angle_k", "angle_t0", "tors_k", "tors_delta"):
             a = np.ascontiguousarray(getattr(s, k), dtype=np.float64)
             if a.size == 0:
@@ -136,7 +149,7 @@ class Oracle(object):
         self.nbr = None
         self.loop = ctypes.c_long(int(s.loop))
         self.time = ctypes.c_double(float(s.time))
-        self.e = np.zeros(7)
+        self.e = np.zeros(8)
         self.virial = np.zeros(6)
         self.rk = ctypes.c_double(0.0)
         self.tion = np.zeros(6)

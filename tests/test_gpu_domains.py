@@ -201,3 +201,26 @@ def test_decomposed_displacement_triggered_rebuilds():
         assert abs(rk - rko) < TOL * rko
     assert g.ranks[0].list_stats()["rebuilds"] >= 3
     g.close()
+
+
+def test_decomposed_restraints():
+    """restrained beads are located on whichever domain owns them after each migration"""
+    from ddcmd_amd.martini import MartiniGroup
+    from ddcmd_amd.deck import load_deck
+    x = ("system SYSTEM { potential = martini restraintPot; } restraintPot POTENTIAL { type = RESTRAINT; parmfile = restraint.data; }")
+    s = load_deck(LIPID_DECK, extra_objects=x)
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    g = MartiniGroup(s, (2, 2, 2))
+    g.eval_forces()
+    e, vir, _, _ = g.energies()
+    st = g.gather()
+    assert rel_force_err(st["f"], (o.fx, o.fy, o.fz)) < 1e-9
+    assert abs(e["restraint"] - e0["restraint"]) < 1e-10 * e0["restraint"]
+    assert np.abs(vir - v0).max() < 1e-9 * np.abs(v0).max()
+    eo, vo, rko, _ = o.step(20)
+    g.step(20)
+    e, vir, rk, _ = g.energies()
+    assert abs(e["restraint"] - eo["restraint"]) < TOL * eo["restraint"]
+    assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"])
+    g.close()

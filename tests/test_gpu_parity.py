@@ -30,7 +30,7 @@ def test_waterbox_step0_forces_energy_virial(waterbox):
     gold = (g["gold_fx"], g["gold_fy"], g["gold_fz"])
     err = rel_force_err(f, gold)
     assert err < TIGHT, err
-    ge = dict(zip(pyoracle.E_NAMES, g["gold_e"]))
+    ge = dict(zip(pyoracle.E_NAMES[:7], g["gold_e"]))
     assert abs(e["lj"] - ge["lj"]) < TIGHT * abs(ge["lj"])
     assert abs(e["total"] - ge["total"]) < TIGHT * abs(ge["total"])
     assert np.abs(vir - g["gold_virial"]).max() < TIGHT * np.abs(g["gold_virial"]).max()
@@ -391,4 +391,33 @@ def test_langevin_group_matches_oracle_and_thermalises():
         rk = m.energies()[2]
         T.append(2.0 * rk / (3.0 * s.natoms) / units_convert(1.0, "K"))
     assert abs(np.mean(T) - 310.0) < 0.03 * 310.0, T
+    m.close()
+
+
+RESTRAINT_X = ("system SYSTEM { potential = martini restraintPot; } "
+               "restraintPot POTENTIAL { type = RESTRAINT; parmfile = restraint.data; }")
+
+
+def test_restraint_potential():
+    """POTENTIAL type=RESTRAINT (restraint.c:259-361, restraintGPU.cu): harmonic position restraints by gid"""
+    from ddcmd_amd.martini import MartiniHIP
+    from ddcmd_amd.deck import load_deck
+    s = load_deck(LIPID_DECK, extra_objects=RESTRAINT_X)
+    assert s.nrest == 6
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    m = MartiniHIP(s)
+    e, vir = m.eval_forces()
+    f = _forces(m)
+    assert rel_force_err(f, (o.fx, o.fy, o.fz)) < TIGHT
+    for k in ("lj", "ele", "bond", "angle", "tors", "impr", "restraint", "total"):
+        assert abs(e[k] - e0[k]) < TIGHT * max(abs(e0[k]), 1e-12), k
+    assert np.abs(vir - v0).max() < TIGHT * np.abs(v0).max()
+    for step in range(20):
+        eo, vo, rko, _ = o.step(1)
+        m.step(1)
+        e, vir, rk, _ = m.energies()
+        assert abs(e["restraint"] - eo["restraint"]) < TOL * max(abs(eo["restraint"]), 1e-9), step
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), step
+        assert abs(rk - rko) < TOL * rko
     m.close()

@@ -40,7 +40,7 @@ def test_golden_waterbox_oracle(waterbox):
     npairs = o.build_list()
     assert npairs[0] == int(g["gold_npairs_list"])
     e, vir = o.forces()
-    assert np.allclose([e[k] for k in pyoracle.E_NAMES], g["gold_e"], rtol=1e-13, atol=0)
+    assert np.allclose([e[k] for k in pyoracle.E_NAMES[:7]], g["gold_e"], rtol=1e-13, atol=0)
     assert np.allclose(vir, g["gold_virial"], rtol=1e-12)
     for k, a in (("gold_fx", o.fx), ("gold_fy", o.fy), ("gold_fz", o.fz)):
         assert np.abs(a - g[k]).max() <= 1e-15
@@ -265,3 +265,40 @@ def test_atoms_reader_follows_field_names(tmp_path):
     assert np.array_equal(s.gid, s0.gid) and np.array_equal(s.species, s0.species)
     for a, b in ((s.rx, s0.rx), (s.ry, s0.ry), (s.rz, s0.rz), (s.vx, s0.vx), (s.vz, s0.vz)):
         assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-300)
+
+
+RESTRAINT_X = ("system SYSTEM { potential = martini restraintPot; } "
+               "restraintPot POTENTIAL { type = RESTRAINT; parmfile = restraint.data; }")
+
+
+def test_restraint_potential_deck_and_finite_differences():
+    """POTENTIAL type=RESTRAINT (restraint.c:259-361): deck loading (RESTRAINTLIST / RESTRAINTPARMS, kb units,
+    fractional x0) and the oracle's restatement checked by finite differences of the restraint energy"""
+    import os
+    from ddcmd_amd.deck import load_deck, units_convert
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck", "object.data")
+    s = load_deck(deck, extra_objects=RESTRAINT_X)
+    assert s.nrest == 6 and s.rest_origin == 0
+    assert list(s.rest_fc[0]) == [0, 0, 1] and list(s.rest_fc[4]) == [1, 1, 1]
+    assert abs(s.rest_kb[0] - units_convert(200.0, "kJ*mol^-1*nm^-2")) < 1e-15
+    assert abs(s.rest_r0[3][1] - 0.98) < 1e-15
+    o = pyoracle.Oracle(s)
+    e, vir = o.forces()
+    s0 = load_deck(deck)
+    o0 = pyoracle.Oracle(s0)
+    e0, vir0 = o0.forces()
+    assert e["restraint"] > 0 and abs(e["total"] - e0["total"] - e["restraint"]) < 1e-12 * abs(e["total"])
+    # the restraint force = difference to the unrestrained run; check it against -dE_restraint/dr
+    h = 1e-5
+    for r in range(s.nrest):
+        i = int(np.flatnonzero(np.asarray(s.gid) == s.rest_gid[r])[0])
+        for c, (arr, f, f0) in enumerate(((o.rx, o.fx, o0.fx), (o.ry, o.fy, o0.fy), (o.rz, o.fz, o0.fz))):
+            keep = arr[i]
+            arr[i] = keep + h
+            ep = o.forces()[0]["restraint"]
+            arr[i] = keep - h
+            em = o.forces()[0]["restraint"]
+            arr[i] = keep
+            fd = -(ep - em) / (2 * h)
+            o.forces()
+            assert abs((f[i] - f0[i]) - fd) < 1e-7 * max(abs(fd), 1e-6), (r, c)
