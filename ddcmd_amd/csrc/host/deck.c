@@ -428,6 +428,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       char *pname = get_string(sim, "printinfo", "printinfo");
       OBJECT *po = object_find(pname, "PRINTINFO");
       s->u_pressure = get_string(po, "PRESSURE", "GPa");
+      object_get(po, "printMolecularPressure", &s->printMolecularPressure, INT, 1, "0");
       s->u_volume = get_string(po, "VOLUME", "Ang^3");
       s->u_temperature = get_string(po, "TEMPERATURE", "K");
       s->u_energy = get_string(po, "ENERGY", "eV");

@@ -78,6 +78,7 @@ typedef struct ddcmi_setup
    uint64_t rng_seed;
    /* POTENTIAL type=RESTRAINT (restraint.c:28-49): restraints by gid, r0 as box fractions */
    int nrest, rest_origin;
+   int printMolecularPressure;        /* PRINTINFO printMolecularPressure (printinfo.c:56) */
    uint64_t *rest_gid;
    int *rest_fc;
    double *rest_r0, *rest_kb;

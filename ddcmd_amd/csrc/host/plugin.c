@@ -403,10 +403,66 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
 }
 
 /* printinfoA, printinfo.c:125-232: one line of the `data` file */
-void printinfo(SIMULATE *simulate, ETYPE *e, int header)
+/* molecularPressure (molecularPressure.c:22-67) + convertToMolecularPressures (printinfo.c:233-240):
+ * the atomic virial minus sum_atoms (r_a - R_mol).f_a per molecule (R_mol = centre of mass, nearest
+ * images about the molecule's first atom), plus N_mol kB T, over the volume.  Host side, from the
+ * state copied back at print steps.  Diagonal only, like the reference. */
+static int cmp_label_idx(const void *a, const void *b)
+{
+   const uint64_t *x = a, *y = b;
+   return x[0] < y[0] ? -1 : x[0] > y[0] ? 1 : 0;
+}
+static void convertToMolecularPressures(SIMULATE *simulate, ETYPE *e)
+{
+   SYSTEM *sys = simulate->system;
+   STATE *st = sys->state;
+   const ddcmi_setup *s = simulate->setup;
+   if (sendHostState(sys) != DDCMI_OK) die("convertToMolecularPressures", "state download failed");
+   int n = st->nlocal;
+   uint64_t *key = malloc(sizeof(uint64_t) * 2 * (size_t)(n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) { key[2 * i] = st->label[i]; key[2 * i + 1] = (uint64_t)i; }
+   qsort(key, n, 2 * sizeof(uint64_t), cmp_label_idx);
+   double L[3] = {sys->box->h0[0], sys->box->h0[4], sys->box->h0[8]};
+   double vxx = e->virial.xx, vyy = e->virial.yy, vzz = e->virial.zz;
+   int nmol = 0;
+   for (int k0 = 0; k0 < n;)
+   {
+      int k1 = k0;
+      while (k1 < n && (key[2 * k1] >> 32) == (key[2 * k0] >> 32)) k1++;
+      int i0 = (int)key[2 * k0 + 1];
+      double M = 0.0, R[3] = {0, 0, 0};
+      for (int k = k0; k < k1; k++)
+      {
+         int i = (int)key[2 * k + 1];
+         double m = s->mass[s->species[i]], d[3] = {st->rx[i] - st->rx[i0], st->ry[i] - st->ry[i0], st->rz[i] - st->rz[i0]};
+         for (int a = 0; a < 3; a++) { if (sys->box->pbc >> a & 1) d[a] -= L[a] * rint(d[a] / L[a]); R[a] += m * d[a]; }
+         M += m;
+      }
+      for (int a = 0; a < 3; a++) R[a] /= M;
+      for (int k = k0; k < k1; k++)
+      {
+         int i = (int)key[2 * k + 1];
+         double d[3] = {st->rx[i] - st->rx[i0], st->ry[i] - st->ry[i0], st->rz[i] - st->rz[i0]};
+         for (int a = 0; a < 3; a++) { if (sys->box->pbc >> a & 1) d[a] -= L[a] * rint(d[a] / L[a]); d[a] -= R[a]; }
+         vxx -= d[0] * st->fx[i]; vyy -= d[1] * st->fy[i]; vzz -= d[2] * st->fz[i];
+      }
+      nmol++;
+      k0 = k1;
+   }
+   free(key);
+   double vol = sys->box->volume, NkT = nmol * e->temperature;      /* kB = 1 */
+   double pxx = (vxx + NkT) / vol, pyy = (vyy + NkT) / vol, pzz = (vzz + NkT) / vol;
+   e->pion = (pxx + pyy + pzz) / 3.0;
+   e->sion.xx = -pxx; e->sion.yy = -pyy; e->sion.zz = -pzz;
+   e->sion.xy = -e->virial.xy / vol; e->sion.xz = -e->virial.xz / vol; e->sion.yz = -e->virial.yz / vol;
+}
+
+void printinfo(SIMULATE *simulate, ETYPE *e_in, int header)
 {
    const ddcmi_setup *s = simulate->setup;
    SYSTEM *sys = simulate->system;
+   ETYPE ecopy = *e_in, *e = &ecopy;                                   /* printinfoAll works on a copy (printinfo.c:250-253) */
+   if (s->printMolecularPressure) convertToMolecularPressures(simulate, e);
    double cE = units_convert(1.0, NULL, s->u_energy), cT = units_convert(1.0, NULL, s->u_temperature), cP = units_convert(1.0, NULL, s->u_pressure);
    double cV = units_convert(1.0, NULL, s->u_volume), ct = units_convert(1.0, NULL, s->u_time), cL = units_convert(1.0, NULL, s->u_length);
    double ng = (double)sys->nglobal;

@@ -85,3 +85,38 @@ def test_ddcmi_md_checkpoint_restart(tmp_path):
         d -= L[c] * np.rint(d / L[c])
         assert np.abs(d).max() < 1e-6
     assert np.abs(s2.vz - o.vz).max() < 1e-6 * np.abs(o.vz).max()
+
+
+def test_ddcmi_md_molecular_pressure(tmp_path):
+    """PRINTINFO printMolecularPressure=1 (molecularPressure.c:22-67): the Press column becomes the molecular
+    pressure = (atomic virial - sum_atoms (r - R_mol).f + N_mol kB T) / V"""
+    data = str(tmp_path / "data")
+    x = "printinfo PRINTINFO { printMolecularPressure = 1; } simulate SIMULATE { maxloop = 10; printrate = 10; }"
+    out = subprocess.run([EXE, "-o", DECK, "-d", data, "-x", x], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = np.array([[float(v) for v in l.split()] for l in open(data).read().splitlines()[1:] if l.strip()])
+    s = load_deck(DECK)
+    o = pyoracle.Oracle(s)
+    cP = units_convert(1, None, "bar")
+    L = np.array([s.h[0], s.h[4], s.h[8]])
+    mol = (np.asarray(s.gid) >> np.uint64(32)).astype(np.int64)
+    mass = np.asarray(s.mass)[np.asarray(s.species)]
+    e, vir = o.forces()
+    rk, tion = o.kinetic()
+    for k, row in enumerate(rows):
+        r = np.stack([o.rx, o.ry, o.rz], 1)
+        f = np.stack([o.fx, o.fy, o.fz], 1)
+        first = np.zeros(mol.max() + 1, np.int64)
+        first[mol[::-1]] = np.arange(s.natoms - 1, -1, -1)
+        d = r - r[first[mol]]
+        d -= L * np.rint(d / L)
+        M = np.bincount(mol, weights=mass)
+        R = np.stack([np.bincount(mol, weights=mass * d[:, c]) for c in range(3)], 1) / M[:, None]
+        d -= R[mol]
+        vdiag = np.array(vir[:3]) - np.sum(d * f, axis=0)
+        T = 2.0 * rk / (3.0 * s.natoms - s.nConstraints)
+        nmol = len(M)
+        pmol = np.mean((vdiag + nmol * T) / s.volume)
+        assert abs(row[6] - cP * pmol) < 1e-6 * abs(cP * pmol) + 1e-6, (k, row[6], cP * pmol)
+        if k + 1 < len(rows):
+            e, vir, rk, tion = o.step(10)
