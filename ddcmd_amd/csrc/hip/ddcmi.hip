@@ -297,7 +297,9 @@ struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
    int nloc;                            /* staged indices >= nloc are image/halo beads */
-   int pack_type;                       /* entries are (staged slot << 4) | LJ type (nlj <= 16, cap < 4096); else the bare slot */
+   int pack_type;                       /* entries are (staged slot << 4) | LJ type (nlj <= 16, cap < 4096); else the bare slot.
+                                           2: nlj <= 8, bit 3 of the nibble marks a periodically shifted partner */
+   const int *halo_shift;               /* halo_shift[j - nloc] != 13: bead j carries a periodic shift */
    const int *cell_start_o;             /* owned beads per cell: exclusive scan, [ncell+1] */
    const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges */
    int *stage_idx, *tile_nstage;
@@ -317,6 +319,8 @@ struct NbTileArgs
    const int *nbr_cnt;
    const int *sched;                    /* [9] range of each XCD in perm[] (schedule_tiles) */
    const int *perm;                     /* tile order: [interior tiles | tiles that stage image/halo beads] */
+   const int *tile_work;                /* bit 30: the tile stages image/halo beads */
+   const int *halo_shift; int nloc;     /* halo_shift[j - nloc] != 13: bead j carries a periodic shift */
    int rot;                             /* tuning builds: rotate the range -> XCD assignment */
 };
 
@@ -397,6 +401,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          sidx[o + k] = gj;
          double4 p = pos[gj];
          A_s[o + k] = make_double2(p.x, p.y);
+         if (ta.pack_type == 2 && gj >= ta.nloc && ta.halo_shift[gj - ta.nloc] != 13)
+            p.w = __longlong_as_double(__double_as_longlong(p.w) | 8ll);       /* travels into the entry's type nibble */
          B_s[o + k] = make_double2(p.z, p.w);
       }
    }
@@ -713,7 +719,7 @@ extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
 #else
 #define TRACE_MARK(slot) do { } while (0)
 #endif
-template <bool HAS_Q, bool PACKED, int NB_BLOCK, int WPE, int CH>
+template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ qatom,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    double4 *s_lj = (double4 *)(XY_s + ta.cap);
    double *q_s = (double *)(s_lj + ta.nlj * ta.nlj);
    unsigned char *T_s = (unsigned char *)(q_s + (HAS_Q ? ta.cap : 0));
+   unsigned char *S_s = T_s + (PACKED ? 0 : ta.cap);      /* 1: the staged bead is a periodically shifted copy */
    /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
     * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
     * starts at LDS address 0 and the z gather needs no base add.  Checked here, not assumed. */
@@ -773,18 +780,29 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
       for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) s_lj[k] = ljtab[k];
       int ns = ta.tile_nstage[t];
       const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
+      /* Virial.  A pair of two unshifted beads contributes f_ij (x) (r_i - r_j) from i's side and
+       * the mirror term from j's side; the two add up to 2 f_ij (x) r_i + 2 f_ji (x) r_j, so each
+       * side may book 2 f_ij (x) r_i instead -- summed over j that is 2 F_i (x) r_i, six FMAs per
+       * bead rather than per pair.  Pairs with a periodically shifted partner (and the excluded
+       * pairs) keep the per-pair form on both sides.  Only tiles that stage image/halo beads can
+       * hold shifted partners. */
+      const bool tshift = (ta.tile_work[t] >> 30) & 1;
       /* stage the neighbourhood: all index loads first, then all record gathers, then the
        * LDS writes -- a naive loop serialises ~9 dependent HBM/L2 round trips per thread */
       constexpr int SU = NB_SU;
       for (int k0 = threadIdx.x; k0 < ns; k0 += SU * NB_BLOCK)
       {
-         int gj[SU];
+         int gj[SU], sh[SU];
          double4 pp[SU];
          double qq[SU];
 #pragma unroll
          for (int u = 0; u < SU; u++) { int k = k0 + u * NB_BLOCK; gj[u] = (k < ns) ? sidx[k] : 0; }
 #pragma unroll
-         for (int u = 0; u < SU; u++) { pp[u] = pos[gj[u]]; if (HAS_Q) qq[u] = qatom[gj[u]]; }
+         for (int u = 0; u < SU; u++)
+         {
+            pp[u] = pos[gj[u]]; if (HAS_Q) qq[u] = qatom[gj[u]];
+            sh[u] = (!SHBIT && tshift && gj[u] >= ta.nloc) ? ta.halo_shift[gj[u] - ta.nloc] : 13;
+         }
 #pragma unroll
          for (int u = 0; u < SU; u++)
          {
@@ -795,6 +813,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                Z_s[k + 1] = pp[u].z;
                if (!PACKED) T_s[k + 1] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
                if (HAS_Q) q_s[k + 1] = qq[u];
+               if (tshift && !SHBIT) S_s[k + 1] = (unsigned char)(sh[u] != 13);
             }
          }
       }
@@ -805,6 +824,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = 1e30;
          if (!PACKED) T_s[0] = 0;
          if (HAS_Q) q_s[0] = 0.0;
+         if (!SHBIT) S_s[0] = 0;
       }
       __syncthreads();
       TRACE_MARK(1);
@@ -840,6 +860,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          int ng_full = (cnt_full + 7) >> 3;
          int ngl = (ng_full > sub) ? (ng_full - sub + parts - 1) / parts : 0;
          double fxi = 0, fyi = 0, fzi = 0;
+         double fsx = 0, fsy = 0, fsz = 0;          /* part of f_i from shifted / excluded partners (virial booked per pair) */
          /* 32-bit indexing inside the tile's slice (uniform 64-bit base + lane offset) */
          const uint4 *slice = (const uint4 *)(ta.nbr16 + base);
          const unsigned col = (unsigned)(sub * rows + al), cstride = (unsigned)(parts * rows);
@@ -868,7 +889,8 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
             const unsigned qw[4] = {q0.x, q0.y, q0.z, q0.w};
             /* pair math for slot u of the part; WD_ = the dword holding its entry, HI_ = upper half */
 #define NB_PAIR(u, WD_, HI_) do { \
-                  int tjj = PACKED ? (int)(((WD_) >> ((HI_) ? 16 : 0)) & 0xfu) : (int)T_s[o[u] >> 4]; \
+                  const int nib_ = (int)(((WD_) >> ((HI_) ? 16 : 0)) & 0xfu); \
+                  int tjj = PACKED ? (SHBIT ? (nib_ & 7) : nib_) : (int)T_s[o[u] >> 4]; \
                   double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
                   double ir = 0.0, ir2; \
                   if (HAS_Q) { ir = rsqrt_f64(r2[u]); ir2 = ir * ir; } \
@@ -887,8 +909,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                   } \
                   double fxij = -dvdr * x[u], fyij = -dvdr * y[u], fzij = -dvdr * z[u]; \
                   fxi += fxij; fyi += fyij; fzi += fzij; \
-                  acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u]; \
-                  acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u]; } while (0)
+                  if (tshift && (SHBIT ? (nib_ & 8) : (int)S_s[o[u] >> 4])) \
+                  { \
+                     fsx += fxij; fsy += fyij; fsz += fzij; \
+                     acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u]; \
+                     acc[5] += fxij * y[u]; acc[6] += fxij * z[u]; acc[7] += fyij * z[u]; \
+                  } } while (0)
             /* the group is walked in 8 / CH parts; the CH gathers and tests of a part are independent (ILP) */
 #pragma unroll
             for (int h = 0; h < 8 / CH; h++)
@@ -942,10 +968,17 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                   double dvdr = kqij * (2.0 * krf);
                   double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
                   fxi += fxij; fyi += fyij; fzi += fzij;
+                  fsx += fxij; fsy += fyij; fsz += fzij;
                   acc[2] += fxij * x; acc[3] += fyij * y; acc[4] += fzij * z;
                   acc[5] += fxij * y; acc[6] += fxij * z; acc[7] += fyij * z;
                }
             }
+         }
+         /* unshifted partners: 2 F (x) r_i; every sub-lane books its own share of F */
+         {
+            double px = 2.0 * (fxi - fsx), py = 2.0 * (fyi - fsy), pz = 2.0 * (fzi - fsz);
+            acc[2] += px * pi.x; acc[3] += py * pi.y; acc[4] += pz * pi.z;
+            acc[5] += px * pi.y; acc[6] += px * pi.z; acc[7] += py * pi.z;
          }
          for (int off = parts >> 1; off > 0; off >>= 1)
          {
@@ -1341,7 +1374,7 @@ __global__ void k_tilelist_to_csr(NbTileArgs ta, int pack_type, int nloc, const 
       for (int k = 0; k < cnt; k++)
       {
          int ee = ta.nbr16[base + ((size_t)(k >> 3) * rows + al) * 8 + (k & 7)];
-         int j = sidx[(pack_type ? (ee >> 4) : ee) - 1];
+         int j = sidx[(pack_type ? (ee >> 4) : ee) - 1];      /* (pack_type 2: the nibble's shift bit is not part of the slot) */
          if (j >= nloc) j = halo_src[j - nloc];
          jout[s + k] = orig[j];
       }
@@ -1949,9 +1982,9 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
-      ctx->pack_type = (ctx->nlj <= 16 && ctx->stage_cap < 4096);
+      ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nlj <= 8 ? 2 : ctx->nlj <= 16 ? 1 : 0) : 0;
       TileArgs ta;
-      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type ? 1 : 0; ta.nloc = n;
+      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
       ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
@@ -2045,22 +2078,24 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
    {
       int ntile = ctx->ntile;
       bool useq = ctx->has_charge;
-      bool packed = ctx->pack_type;
+      bool packed = ctx->pack_type != 0;
+      const bool shbit = ctx->pack_type == 2;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
-      size_t lds = capl * 24 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? capl * 8 : 0) + (packed ? 0 : capl);
+      size_t lds = capl * 24 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? capl * 8 : 0) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nlj;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
+      na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       { const char *rv = getenv("DDCMI_XCD_ROT"); na.rot = rv ? atoi(rv) : 0; }
-#define LAUNCH_NB(Q, P, NT) do { \
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
+#define LAUNCH_NB(Q, P, S, NT) do { \
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
-#define LAUNCH_NB2(Q, P) LAUNCH_NB(Q, P, NB_THREADS)
+#define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
       /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
        * class 1: tiles that stage image/halo beads, after the halo exchange */
       for (int cls = 0; cls < 2; cls++)
@@ -2081,10 +2116,12 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
             e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
             HIPCHK(ctx, hipEventRecord(e0, st));
          }
-         if (useq && packed) LAUNCH_NB2(true, true);
-         else if (useq) LAUNCH_NB2(true, false);
-         else if (packed) LAUNCH_NB2(false, true);
-         else LAUNCH_NB2(false, false);
+         if (useq && shbit) LAUNCH_NB2(true, true, true);
+         else if (useq && packed) LAUNCH_NB2(true, true, false);
+         else if (useq) LAUNCH_NB2(true, false, false);
+         else if (shbit) LAUNCH_NB2(false, true, true);
+         else if (packed) LAUNCH_NB2(false, true, false);
+         else LAUNCH_NB2(false, false, false);
          if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
       }
 #undef LAUNCH_NB2

@@ -137,7 +137,7 @@ struct ddcmi_ctx
    hipEvent_t ev_drift = nullptr, ev_halo = nullptr;
    bool halo_overlap = false;          /* DDCMI_HALO_OVERLAP=1: exchange on stream2 under the all-owned tiles */
    /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
-   int ntile = 0, stage_cap = 0; bool pack_type = false;
+   int ntile = 0, stage_cap = 0; int pack_type = 0;      /* 0 bare slots, 1 slot<<4|type, 2 + shift bit (see TileArgs) */
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
    dbuf<long long> tile_base;
    dbuf<unsigned short> nbr16; dbuf<unsigned int> tmp32; int tmpw = 0;

@@ -218,11 +218,13 @@ __global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab self
       int k = h - nself;
       x = hrecv5[5 * k]; y = hrecv5[5 * k + 1]; z = hrecv5[5 * k + 2];
       hsrc[h] = -1 - k;
-      hshift[h] = 13;
+      hshift[h] = 13;          /* fixed up below: 27 when the sender applied a periodic shift */
       /* received along the SENDER's direction `code`: it lies on my opposite side */
       int q = 0;
       while (k >= recvo.off[q + 1]) q++;
       const int code = recvo.code[q];
+      /* the sender's shift for its direction `code` is minus mine for the opposite direction */
+      if (dt.shift[26 - code][0] | dt.shift[26 - code][1] | dt.shift[26 - code][2]) hshift[h] = 27;
       side[0] = -(code % 3 - 1); side[1] = -((code / 3) % 3 - 1); side[2] = -(code / 9 - 1);
    }
    int c = halo_cell(gp, x, y, z, side);
