@@ -86,6 +86,8 @@ class CSetup(ctypes.Structure):
         ("u_energy", ctypes.c_char_p), ("u_time", ctypes.c_char_p), ("u_length", ctypes.c_char_p),
         ("rng_seed", ctypes.c_uint64),
         ("nrest", ctypes.c_int), ("rest_origin", ctypes.c_int), ("printMolecularPressure", ctypes.c_int),
+        ("nresicons", ctypes.c_int),
+        ("npt_T", ctypes.c_double), ("npt_P0", ctypes.c_double), ("npt_beta", ctypes.c_double), ("npt_tau", ctypes.c_double),
         ("rest_gid", c_u64_p), ("rest_fc", c_int_p), ("rest_r0", c_double_p), ("rest_kb", c_double_p),
     ]
 

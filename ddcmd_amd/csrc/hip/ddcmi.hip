@@ -1125,7 +1125,8 @@ __global__ void k_finish_energy(double *r, double self_ele)
  * The reference draws g from a per-particle LCG64 stream stored with the particle; here it is a
  * counter-based stream keyed by (seed, gid, 2*loop + BACK): the same numbers whatever the domain
  * decomposition or launch shape -- statistical, not bitwise, parity with ddcMD. */
-struct GroupLambda { double v[32]; double a[32]; double dfac[32]; unsigned lang_mask; unsigned long long seed, counter_front, counter_back; };
+struct GroupLambda { double v[32]; double a[32]; double dfac[32]; unsigned lang_mask; unsigned long long seed, counter_front, counter_back;
+                     double scale[3]; /* barostat: positions are scaled by this (adjustPosn) before the drift; 1 otherwise */ };
 __device__ __forceinline__ unsigned long long smix64(unsigned long long z)
 {
    z += 0x9E3779B97F4A7C15ull;
@@ -1169,7 +1170,7 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
    }
    vx[i] = x; vy[i] = y; vz[i] = z;
    double4 p = pos[i];
-   p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
+   p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
    pos[i] = p;
 }
 #define KE_PER 4
@@ -1260,7 +1261,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
       }
       vx[i] = x; vy[i] = y; vz[i] = z;
       double4 p = pos[i];
-      p.x = fma(dt, x, p.x); p.y = fma(dt, y, p.y); p.z = fma(dt, z, p.z);
+      p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
       pos[i] = p;
    }
    block_reduce_store<7>(acc, partials + (size_t)blockIdx.x * 8);
@@ -1607,6 +1608,25 @@ extern "C" int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, con
    }
    ctx->glambda.assign(ngroup, 1.0); ctx->gTsum.assign(ngroup, 0.0); ctx->gT.assign(ngroup, 0.0);
    ctx->gnT.assign(ngroup, 0); ctx->gdoScaling.assign(ngroup, 0);
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau)
+{
+   if (!ctx || beta < 0.0 || (beta > 0.0 && !(tau > 0.0))) return DDCMI_EINVAL;
+   if (beta > 0.0)
+   {
+      if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat is implemented for a single domain");
+      for (int m = 0; m < ctx->nmoltype; m++)
+         if (ctx->mol_nspecies[m] > 1) SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat needs the molecular pressure; only single-bead molecules are handled (molecule type %d has %d beads)", m, ctx->mol_nspecies[m]);
+   }
+   ctx->baro_T = T; ctx->baro_P0 = P0; ctx->baro_beta = beta; ctx->baro_tau = tau;
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_get_box(const ddcmi_ctx *ctx, double h[9])
+{
+   if (!ctx || !h) return DDCMI_EINVAL;
+   for (int k = 0; k < 9; k++) h[k] = ctx->h[k];
    return DDCMI_OK;
 }
 
@@ -2174,7 +2194,7 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
 static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false, const GroupLambda *gk = nullptr, bool then_drift = false)
 {
    GroupLambda plain;
-   if (!gk) { memset(&plain, 0, sizeof(plain)); for (int g = 0; g < 32; g++) { plain.v[g] = 1.0; plain.a[g] = 1.0; } gk = &plain; }
+   if (!gk) { memset(&plain, 0, sizeof(plain)); for (int g = 0; g < 32; g++) { plain.v[g] = 1.0; plain.a[g] = 1.0; } plain.scale[0] = plain.scale[1] = plain.scale[2] = 1.0; gk = &plain; }
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK * KE_PER);
    ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
    if (then_drift)
@@ -2218,6 +2238,7 @@ static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
 {
    GroupLambda lam;
    lam.lang_mask = 0; lam.seed = ctx->rng_seed;
+   lam.scale[0] = lam.scale[1] = lam.scale[2] = 1.0;
    /* the FRONT update of a step sees the loop count before its increment, the BACK update the one after */
    lam.counter_front = 2ull * (unsigned long long)ctx->loop;
    lam.counter_back = 2ull * (unsigned long long)ctx->loop + 1ull;
@@ -2242,6 +2263,28 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
    if (!ctx->drift_done)
    {
       GroupLambda lam = front_lambda(ctx, dt);
+      if (ctx->baro_beta > 0.0)
+      {
+         /* nglfconstraint.c:527-536 + changeVolume (:64-84): semi-isotropic Berendsen barostat from the
+          * molecular pressure of the last force evaluation (all molecules are single beads here, so the
+          * molecular virial is the atomic one: molecularPressure.c), at the TARGET temperature */
+         int rcb = fetch_results(ctx);
+         if (rcb) return rcb;
+         const double vol = ctx->h[0] * ctx->h[4] * ctx->h[8], NkT = (double)ctx->nloc * ctx->baro_T;
+         double pxx = (ctx->h_results[R_VIR + DDCMI_XX] + NkT) / vol - ctx->baro_P0;
+         double pyy = (ctx->h_results[R_VIR + DDCMI_YY] + NkT) / vol - ctx->baro_P0;
+         double pzz = (ctx->h_results[R_VIR + DDCMI_ZZ] + NkT) / vol - ctx->baro_P0;
+         const double btt = ctx->baro_beta * dt / ctx->baro_tau;
+         double pl = 0.5 * (pxx + pyy);
+         double l[3] = {cbrt(1.0 + pl * btt), cbrt(1.0 + pl * btt), cbrt(1.0 + pzz * btt)};
+         for (int a = 0; a < 3; a++)
+         {
+            if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;          /* box.c:44 */
+            lam.scale[a] = l[a];
+            ctx->h[4 * a] *= l[a];
+            ctx->gp.L[a] = ctx->h[4 * a];
+         }
+      }
       if (n > 0)
          hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
@@ -2259,7 +2302,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
    if ((rc = launch_forces(ctx, true))) return rc;
    berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
    GroupLambda lam = front_lambda(ctx, dt);
-   if (more_steps && ctx->nloc > 0)
+   if (more_steps && ctx->nloc > 0 && !(ctx->baro_beta > 0.0))      /* the barostat needs this step's virial before the next drift */
    {
       if ((rc = launch_kinetic(ctx, dt, 1, true, &lam, true))) return rc;
       ctx->drift_done = true;

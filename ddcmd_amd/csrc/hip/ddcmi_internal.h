@@ -145,6 +145,7 @@ struct ddcmi_ctx
    dbuf<double> kpartials;             /* per-workgroup kinetic terms (k_kick_ke) */
    dbuf<double> red_tmp;               /* k_reduce_jobs: per-workgroup rows of a split job + ticket counters */
    dbuf<double4> pos0; dbuf<double> disp;   /* updateRate == 0: positions at the last rebuild; [0..2] sum of r-r0, [4] max |dr|^2 */
+   double baro_T = 0, baro_P0 = 0, baro_beta = 0, baro_tau = 0;      /* NGLFCONSTRAINT's Berendsen barostat; beta = 0: off */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */
    bool list_valid = false;

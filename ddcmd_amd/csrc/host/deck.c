@@ -416,6 +416,13 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       OBJECT *io = object_find(iname, "INTEGRATOR");
       if (!io) FAIL("INTEGRATOR %s not found", iname);
       s->integrator_type = get_string(io, "type", "NGLF");
+      if (strcmp(s->integrator_type, "NGLFCONSTRAINT") == 0)
+      {
+         object_get(io, "T", &s->npt_T, WITH_UNITS, 1, "310", "T", NULL);
+         object_get(io, "P0", &s->npt_P0, WITH_UNITS, 1, "0.0", "pressure", NULL);
+         object_get(io, "beta", &s->npt_beta, WITH_UNITS, 1, "0.0", "1/pressure", NULL);
+         object_get(io, "tauBarostat", &s->npt_tau, WITH_UNITS, 1, "0.0", "t", NULL);
+      }
       free(iname);
       char *aname = get_string(sim, "accelerator", "NoAccelerator");
       OBJECT *ao = object_find(aname, "ACCELERATOR");
@@ -761,6 +768,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       {
          resiparms *r = &resi[s->resitype[own[m]]];
          total += r->nbonds + r->nexcl + r->ncons;
+         s->nresicons += r->ncons;
       }
       s->bpairI = calloc(total + 1, sizeof(int)); s->bpairJ = calloc(total + 1, sizeof(int));
       int k = 0;

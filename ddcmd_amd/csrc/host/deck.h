@@ -79,6 +79,9 @@ typedef struct ddcmi_setup
    /* POTENTIAL type=RESTRAINT (restraint.c:28-49): restraints by gid, r0 as box fractions */
    int nrest, rest_origin;
    int printMolecularPressure;        /* PRINTINFO printMolecularPressure (printinfo.c:56) */
+   int nresicons;                     /* constraint pairs in the residues of the molecules in use (nglfconstraint needs 0 here) */
+   /* INTEGRATOR type=NGLFCONSTRAINT (nglfconstraint.c:86-95): T, P0, beta, tauBarostat; beta = 0: no barostat */
+   double npt_T, npt_P0, npt_beta, npt_tau;
    uint64_t *rest_gid;
    int *rest_fc;
    double *rest_r0, *rest_kb;

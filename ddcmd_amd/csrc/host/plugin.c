@@ -163,8 +163,18 @@ INTEGRATOR *integrator_init(void *parent, const char *name, const char *type)
 {
    INTEGRATOR *in = calloc(1, sizeof(INTEGRATOR));
    in->name = strdup(name); in->type = strdup(type); in->parent = parent;
-   if (strcmp(type, "NGLF") == 0 || strcmp(type, "NVTGLF") == 0 || strcmp(type, "NGLFGPU") == 0 || strcmp(type, "NGLFHIP") == 0)
+   const ddcmi_setup *su = parent ? ((SIMULATE *)parent)->setup : NULL;
+   const int npt_ok = su && strcmp(type, "NGLFCONSTRAINT") == 0 && su->nConstraints == 0 && su->nresicons == 0;
+   if (strcmp(type, "NGLFCONSTRAINT") == 0 && !npt_ok)
+      die("integrator_init", "INTEGRATOR type NGLFCONSTRAINT is on this path only for systems without constraints (nglfconstraint.c's velocity constraint solver is not built)");
+   if (npt_ok || strcmp(type, "NGLF") == 0 || strcmp(type, "NVTGLF") == 0 || strcmp(type, "NGLFGPU") == 0 || strcmp(type, "NGLFHIP") == 0)
    {
+      /* NGLFCONSTRAINT without constraints = nglf + the barostat of changeVolume (nglfconstraint.c:64-84,527-536) */
+      if (npt_ok)
+      {
+         ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+         if (ddcmi_set_barostat(ctx, su->npt_T, su->npt_P0, su->npt_beta, su->npt_tau) != DDCMI_OK) die("integrator_init", ddcmi_last_error(ctx));
+      }
       in->eval_integrator = (void (*)(void *, void *, void *))nglfHIP;
       in->uses_gpu = 1;                                    /* state stays on the device between print steps (masters.c:389-403) */
    }
@@ -221,6 +231,9 @@ void kinetic_terms(SYSTEM *sys, int flag)
 void eval_energyInfo(SYSTEM *sys)
 {
    ETYPE *e = &sys->energyInfo;
+   /* the barostat moves the box on the device */
+   if (ddcmi_get_box(accelerator_getAccelerator(NULL)->parms, sys->box->h0) == DDCMI_OK)
+      sys->box->volume = sys->box->h0[0] * sys->box->h0[4] * sys->box->h0[8];
    double vol = sys->box->volume;
    const double *v = &e->virial.xx, *t = &e->tion.xx;
    double *s = &e->sion.xx;

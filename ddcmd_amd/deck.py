@@ -66,6 +66,8 @@ class Setup(object):
         self.integrator_type = "NGLF"
         self.has_accelerator = 0
         self.rng_seed = 0
+        self.npt_T = self.npt_P0 = self.npt_beta = self.npt_tau = 0.0
+        self.nresicons = 0
         self.nrest, self.rest_origin = 0, 0
         self.rest_gid = np.zeros(0, np.uint64)
         self.rest_fc = np.zeros((0, 3), np.int32)
@@ -106,6 +108,8 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
             setattr(s, f, getattr(c, f))
         s.h = np.array(list(c.h), dtype=np.float64)
         s.rng_seed = int(c.rng_seed)
+        s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = float(c.npt_T), float(c.npt_P0), float(c.npt_beta), float(c.npt_tau)
+        s.nresicons = int(c.nresicons)
         s.nrest, s.rest_origin = int(c.nrest), int(c.rest_origin)
         s.rest_gid = _arr(c.rest_gid, s.nrest, np.uint64) if s.nrest else np.zeros(0, np.uint64)
         s.rest_fc = _arr(c.rest_fc, 3 * s.nrest, np.int32).reshape(-1, 3) if s.nrest else np.zeros((0, 3), np.int32)

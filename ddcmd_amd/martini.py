@@ -50,6 +50,8 @@ def _declare(lib):
     lib.ddcmi_set_groups.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, _ip]
     lib.ddcmi_set_clock.argtypes = [vp, ctypes.c_int64, ctypes.c_double]
     lib.ddcmi_set_random.argtypes = [vp, ctypes.c_uint64]
+    lib.ddcmi_set_barostat.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.ddcmi_get_box.argtypes = [vp, _dp]
     lib.ddcmi_set_restraints.argtypes = [vp, ctypes.c_int, _up, _ip, _dp, _dp, ctypes.c_int]
     lib.ddcmi_get_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp]
     lib.ddcmi_upload_state.argtypes = [vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up, _ip, _ip]
@@ -180,6 +182,8 @@ class MartiniHIP(object):
         gt = i32(np.where(np.isin(np.asarray(s.group_type), (1, 2)), np.asarray(s.group_type), 0))     # FREE / BERENDSEN / LANGEVIN
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
         self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
+        if float(getattr(s, "npt_beta", 0.0)) > 0.0:      # INTEGRATOR type=NGLFCONSTRAINT (no constraints): barostat
+            self._chk(self.lib.ddcmi_set_barostat(self.ctx, float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau)))
         nrest = int(getattr(s, "nrest", 0))
         if nrest > 0:     # RESTRAINT potential
             self._rest = (np.ascontiguousarray(s.rest_gid, dtype=np.uint64), i32(np.asarray(s.rest_fc).ravel()),
@@ -241,6 +245,11 @@ class MartiniHIP(object):
         rk = ctypes.c_double(0)
         self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
         return rk.value, t
+
+    def box(self):
+        h = np.zeros(9)
+        self._chk(self.lib.ddcmi_get_box(self.ctx, _d(h)))
+        return h[[0, 4, 8]]
 
     def group_temperatures(self):
         T = np.zeros(max(1, self.s.ngroup))

@@ -102,6 +102,14 @@ int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);
  * (kB = 1).  The Langevin noise is a counter-based normal stream keyed by (seed, gid, loop): the
  * reference's per-particle LCG64 states are not reproduced -- statistical parity only. */
 int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval);
+/* INTEGRATOR type=NGLFCONSTRAINT without constraints (nglfconstraint.c:510-574): NGLF plus a
+ * semi-isotropic Berendsen barostat (changeVolume, :64-84) driven by the molecular pressure of the last
+ * force evaluation at the target temperature T: lambda_xy = cbrt(1 + beta dt/tau (Pxx+Pyy)/2 - ...),
+ * box and positions scaled before the FRONT kick.  beta = 0 switches it off.  Single domain,
+ * single-bead molecules (molecular = atomic virial); costs one host round trip per step.  Internal units. */
+int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau);
+/* current box (it changes under the barostat) */
+int ddcmi_get_box(const ddcmi_ctx *ctx, double h[9]);
 /* RANDOM seed (random.c:44-60) for the Langevin noise */
 int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed);
 /* SIMULATE loop/time (simulate.c:146,155) */

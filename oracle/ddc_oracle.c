@@ -730,6 +730,19 @@ static void berendsen_Update(orc_group *g, long loop, double dt_half)
 }
 
 /* nglf, nglf.c:67-112 */
+void orc_barostat(orc_params *p, int n, double *rx, double *ry, double *rz, const double virial[6],
+                  double T, double P0, double beta, double tau, double dt)
+{
+   double vol = p->hxx * p->hyy * p->hzz, NkT = (double)n * T;        /* N molecules = n beads; kB = 1 */
+   double pxx = (virial[0] + NkT) / vol - P0, pyy = (virial[1] + NkT) / vol - P0, pzz = (virial[2] + NkT) / vol - P0;
+   double btt = beta * dt / tau;
+   double Pxx = 0.5 * (pxx + pyy);                                     /* semi-isotropic: changeVolume */
+   double l[3] = {cbrt(1.0 + Pxx * btt), cbrt(1.0 + Pxx * btt), cbrt(1.0 + pzz * btt)};
+   for (int a = 0; a < 3; a++) if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;   /* box.c:44 */
+   p->hxx *= l[0]; p->hyy *= l[1]; p->hzz *= l[2];
+   for (int i = 0; i < n; i++) { rx[i] *= l[0]; ry[i] *= l[1]; rz[i] *= l[2]; }
+}
+
 /* neighborCheck (neighbor.c:117-208) for a constant box (the strain term is zero): the list
  * must be rebuilt once 2*max_i |(r_i - rbar) - (r0_i - rbar0)| reaches the skin deltaR.
  * Used when updateRate == 0 (ddcUpdateAll.c:64-71). */

@@ -160,6 +160,13 @@ void orc_group_temperature(const orc_params *p, int n, const double *vx, const d
 
 void orc_back_in_box(const orc_params *p, int n, double *rx, double *ry, double *rz);
 
+/* nglfconstraint's barostat for a system of single-bead molecules (nglfconstraint.c:527-536,
+ * changeVolume :64-84, molecularPressure molecularPressure.c:57-67, adjustPosn :44-56): from the virial
+ * of the last force evaluation, scales the box (p->hxx.. in place) and the positions.  Call before
+ * orc_nglf_step: together they are one nglfconstraint step without constraints. */
+void orc_barostat(orc_params *p, int n, double *rx, double *ry, double *rz, const double virial[6],
+                  double T, double P0, double beta, double tau, double dt);
+
 #ifdef __cplusplus
 }
 #endif

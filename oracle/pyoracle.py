@@ -210,6 +210,20 @@ class Oracle(object):
         self.L.orc_group_temperature(ctypes.byref(self.p), self.n, _d(self.vx), _d(self.vy), _d(self.vz),
                                      _i(self.species), _i(self.group), self.s.ngroup, self.groups)
 
+    def step_npt(self, nsteps, T, P0, beta, tau, dt=None):
+        """nglfconstraint without constraints: barostat (from the last virial) + nglf, per step"""
+        dt = self.s.dt if dt is None else dt
+        out = None
+        for _ in range(nsteps):
+            self.L.orc_barostat(ctypes.byref(self.p), self.n, _d(self.rx), _d(self.ry), _d(self.rz), _d(self.virial),
+                                ctypes.c_double(T), ctypes.c_double(P0), ctypes.c_double(beta), ctypes.c_double(tau), ctypes.c_double(dt))
+            out = self.step(1, dt)
+        return out
+
+    @property
+    def box(self):
+        return np.array([self.p.hxx, self.p.hyy, self.p.hzz])
+
     def step(self, nsteps=1, dt=None):
         """nglf steps; forces()/first energy call must have run once (firstEnergyCall, masters.c:579)."""
         dt = self.s.dt if dt is None else dt

@@ -44,9 +44,14 @@ def test_ddcmi_md_data_file(tmp_path):
 
 
 def test_ddcmi_md_rejects_unsupported_integrator(tmp_path):
-    out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d"), "-x", "nglf INTEGRATOR {type = NGLFCONSTRAINT;}"],
+    out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d"), "-x", "nglf INTEGRATOR {type = NGLFRATTLE;}"],
                          capture_output=True, text=True, timeout=120)
-    assert out.returncode != 0 and "NGLFCONSTRAINT" in out.stderr
+    assert out.returncode != 0 and "NGLFRATTLE" in out.stderr
+    # NGLFCONSTRAINT is accepted only without constraints; with the barostat only for single-bead molecules
+    out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d2"), "-x",
+                          "nglf INTEGRATOR {type = NGLFCONSTRAINT; beta = 3.0e-4 1/bar; tauBarostat = 1 ps;}"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "single-bead" in out.stderr
 
 
 def test_ddcmi_md_checkpoint_restart(tmp_path):
@@ -120,3 +125,37 @@ def test_ddcmi_md_molecular_pressure(tmp_path):
         assert abs(row[6] - cP * pmol) < 1e-6 * abs(cP * pmol) + 1e-6, (k, row[6], cP * pmol)
         if k + 1 < len(rows):
             e, vir, rk, tion = o.step(10)
+
+
+WATER_DECK = os.path.join(ROOT, "tests", "golden", "water_deck", "object.data")
+
+
+def test_ddcmi_md_runs_example_style_deck(tmp_path):
+    """a deck set up like the reference's shipped waterbox example -- INTEGRATOR NGLFCONSTRAINT with the barostat,
+    LANGEVIN groups, printMolecularPressure -- runs unmodified; its data file (energies, molecular pressure,
+    the moving volume and box lengths) matches the oracle"""
+    data = str(tmp_path / "data")
+    out = subprocess.run([EXE, "-o", WATER_DECK, "-d", data], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = np.array([[float(v) for v in l.split()] for l in open(data).read().splitlines()[1:] if l.strip()])
+    s = load_deck(WATER_DECK)
+    assert s.npt_beta > 0 and list(s.group_type) == [2, 2] and s.rng_seed == 20261002
+    o = pyoracle.Oracle(s)
+    e, vir = o.forces()
+    rk, tion = o.kinetic()
+    n = s.natoms
+    cE, cT, cP, cV, cL = (units_convert(1, None, u) for u in ("kJ/mol", "K", "bar", "Angstrom^3", "Angstrom"))
+    assert rows.shape[0] == 1 + (s.maxloop - s.loop) // s.printrate
+    for k, row in enumerate(rows):
+        vol = float(np.prod(o.box))
+        T = 2.0 * rk / (3.0 * n)
+        pmol = np.mean((np.array(vir[:3]) + n * T) / vol)
+        assert abs(row[2] - cE * (e["total"] + rk) / n) < 1e-6 * abs(row[2]) + 1e-9
+        assert abs(row[3] - cE * rk / n) < 1e-6 * abs(row[3])
+        assert abs(row[5] - cT * T) < 1e-6 * row[5]
+        assert abs(row[6] - cP * pmol) < 1e-6 * abs(cP * pmol) + 1e-6
+        assert abs(row[7] - cV * vol / n) < 1e-9 * row[7]
+        assert np.abs(row[8:11] - cL * o.box).max() < 1e-7
+        if k + 1 < len(rows):
+            e, vir, rk, tion = o.step_npt(s.printrate, s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau)
+    assert abs(rows[-1, 8] - rows[0, 8]) > 1e-6           # the barostat moved the box
