@@ -189,3 +189,43 @@ def test_lipid_bilayer_2M_beads_periodic_copies():
     assert abs(rk - ncopy * rko) < 1e-6 * ncopy * rko
     assert abs(e2["total"] - ncopy * eo["total"]) < 1e-6 * ncopy * abs(eo["total"])
     m.close()
+
+
+@pytest.mark.parametrize("ntypes", [12, 20])
+def test_many_lj_types(ntypes):
+    """9..16 LJ types: packed entries without the shift bit (shifted partners flagged in LDS);
+    > 16 types: bare 16-bit slots with the type table in LDS.  Charged beads on top."""
+    from ddcmd_amd.martini import MartiniHIP, MartiniGroup
+    s = make_water_setup(10)
+    rs = np.random.RandomState(7)
+    s.nspecies = ntypes
+    s.species_name = ["S%dxA" % k for k in range(ntypes)]
+    s.mass = np.full(ntypes, s.mass[0])
+    s.charge = np.where(np.arange(ntypes) % 5 == 0, 0.5, np.where(np.arange(ntypes) % 5 == 1, -0.5, 0.0))
+    s.ljtype = np.arange(ntypes, dtype=np.int32)
+    s.moltype = np.arange(ntypes, dtype=np.int32)
+    s.resitype = np.zeros(ntypes, np.int32)
+    s.atomoffset = np.zeros(ntypes, np.int32)
+    s.nmoltype = ntypes
+    s.mol_nspecies = np.ones(ntypes, np.int32)
+    s.bpair_off = np.zeros(ntypes + 1, np.int32)
+    s.nlj = ntypes
+    sig0, eps0 = s.sigma[0], s.eps[0]
+    sg = sig0 * (0.9 + 0.2 * rs.rand(ntypes, ntypes)); sg = 0.5 * (sg + sg.T)
+    ep = eps0 * (0.6 + 0.8 * rs.rand(ntypes, ntypes)); ep = 0.5 * (ep + ep.T)
+    from ddcmd_amd.synth import lj_shift
+    s.sigma, s.eps = sg.ravel(), ep.ravel()
+    s.shift = np.array([lj_shift(a, b, s.rmax) for a, b in zip(s.sigma, s.eps)])
+    s.species = rs.randint(0, ntypes, s.natoms).astype(np.int32)
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    for make in (lambda: MartiniHIP(s), lambda: MartiniGroup(s, (2, 1, 1))):
+        m = make()
+        m.eval_forces()
+        e, vir = m.energies()[:2]
+        f = m.download()["f"] if hasattr(m, "download") else m.gather()["f"]
+        assert rel_force_err(f, (o.fx, o.fy, o.fz)) < 1e-10
+        for k in ("lj", "ele", "total"):
+            assert abs(e[k] - e0[k]) < 1e-10 * abs(e0[k]), (ntypes, k)
+        assert np.abs(vir - v0).max() < 1e-10 * np.abs(v0).max()
+        m.close()
