@@ -721,7 +721,7 @@ extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
 #endif
 template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int npad,
-                                                         const double4 *__restrict__ pos, const double *__restrict__ qatom,
+                                                         const double4 *__restrict__ pos, const double *__restrict__ kqtab,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
                                                          double rc2, double krf, double crf, double keR,
@@ -734,8 +734,11 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    double *Z_s = (double *)smem;                 /* staged positions: z [cap], then {x,y} [cap] -- 24 B per bead */
    double2 *XY_s = (double2 *)(Z_s + ta.cap);
    double4 *s_lj = (double4 *)(XY_s + ta.cap);
-   double *q_s = (double *)(s_lj + ta.nlj * ta.nlj);
-   unsigned char *T_s = (unsigned char *)(q_s + (HAS_Q ? ta.cap : 0));
+   /* charges: a bead's "type" is its (LJ type, charge) class, so ke/eps_r q_i q_j is one more
+    * per-type-pair table entry -- no per-bead charge array in LDS (it cost 8 B/bead: one
+    * workgroup per CU instead of two) and no charge gather per pair */
+   double *s_kq = (double *)(s_lj + ta.nlj * ta.nlj);
+   unsigned char *T_s = (unsigned char *)(s_kq + (HAS_Q ? ta.nlj * ta.nlj : 0));
    unsigned char *S_s = T_s + (PACKED ? 0 : ta.cap);      /* 1: the staged bead is a periodically shifted copy */
    /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
     * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
@@ -745,7 +748,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    typedef __attribute__((address_space(3))) const xy_t lds_cxy;
    const unsigned xy_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)XY_s;
    if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)smem != 0u) __builtin_trap();
-   const unsigned q_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)q_s;
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
     * give XCD x one contiguous tile range (schedule_tiles: equal work per XCD):
     * neighbouring tiles, which stage overlapping neighbourhoods, then share one L2.
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
    }
    if (nown > 0)
    {
-      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) s_lj[k] = ljtab[k];
+      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) { s_lj[k] = ljtab[k]; if (HAS_Q) s_kq[k] = kqtab[k]; }
       int ns = ta.tile_nstage[t];
       const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
       /* Virial.  A pair of two unshifted beads contributes f_ij (x) (r_i - r_j) from i's side and
@@ -794,13 +796,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
       {
          int gj[SU], sh[SU];
          double4 pp[SU];
-         double qq[SU];
 #pragma unroll
          for (int u = 0; u < SU; u++) { int k = k0 + u * NB_BLOCK; gj[u] = (k < ns) ? sidx[k] : 0; }
 #pragma unroll
          for (int u = 0; u < SU; u++)
          {
-            pp[u] = pos[gj[u]]; if (HAS_Q) qq[u] = qatom[gj[u]];
+            pp[u] = pos[gj[u]];
             sh[u] = (!SHBIT && tshift && gj[u] >= ta.nloc) ? ta.halo_shift[gj[u] - ta.nloc] : 13;
          }
 #pragma unroll
@@ -812,7 +813,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                XY_s[k + 1] = make_double2(pp[u].x, pp[u].y);
                Z_s[k + 1] = pp[u].z;
                if (!PACKED) T_s[k + 1] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
-               if (HAS_Q) q_s[k + 1] = qq[u];
                if (tshift && !SHBIT) S_s[k + 1] = (unsigned char)(sh[u] != 13);
             }
          }
@@ -823,7 +823,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
           * at it, so the walk needs no per-slot validity masks. */
          XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = 1e30;
          if (!PACKED) T_s[0] = 0;
-         if (HAS_Q) q_s[0] = 0.0;
          if (!SHBIT) S_s[0] = 0;
       }
       __syncthreads();
@@ -853,8 +852,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          int a = ts + al;
          double4 pi = pos[a];
          int ti = (int)(__double_as_longlong(pi.w) & 0xffll);
-         double kqi = 0.0;
-         if (HAS_Q) kqi = keR * qatom[a];
          int cnt_full = active ? ta.nbr_cnt[a] : 0;
          /* this lane walks slot groups sub, sub+parts, ... (8 slots each) */
          int ng_full = (cnt_full + 7) >> 3;
@@ -903,7 +900,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                   double dvdr = lj.w * (s6 - 2.0 * s12) * ir2; \
                   if (HAS_Q) \
                   { \
-                     double kqij = kqi * *(lds_cdouble *)(__UINTPTR_TYPE__)(q_off + (o[u] >> 1)); \
+                     double kqij = s_kq[ti * nlj + tjj]; \
                      acc[1] += kqij * (ir + krf * r2[u] - crf); \
                      dvdr += kqij * (2.0 * krf - ir2 * ir); \
                   } \
@@ -963,7 +960,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
                double r2 = x * x + y * y + z * z;
                if (r2 < rc2)
                {
-                  double kqij = kqi * qatom[j];
+                  double kqij = s_kq[ti * nlj + (int)(__double_as_longlong(pj.w) & 0xffll)];
                   acc[1] += kqij * (krf * r2 - crf);
                   double dvdr = kqij * (2.0 * krf);
                   double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
@@ -1456,7 +1453,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    (void)hipStreamSynchronize(ctx->stream);
    ddcmi_comm_destroy(ctx);
    dbuf<double> *db[] = {&ctx->d_invmass, &ctx->d_mass, &ctx->d_charge_sp, &ctx->bpartials, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->vx2, &ctx->vy2, &ctx->vz2,
-                         &ctx->fx, &ctx->fy, &ctx->fz, &ctx->qatom, &ctx->bond_kb, &ctx->bond_b0, &ctx->angle_k, &ctx->angle_t0, &ctx->tors_k, &ctx->tors_delta, &ctx->partials};
+                         &ctx->fx, &ctx->fy, &ctx->fz, &ctx->qatom, &ctx->d_kqtab, &ctx->bond_kb, &ctx->bond_b0, &ctx->angle_k, &ctx->angle_t0, &ctx->tors_k, &ctx->tors_delta, &ctx->partials};
    for (auto b : db) b->release();
    dbuf<int> *ib[] = {&ctx->d_ljtype_sp, &ctx->d_moltype_sp, &ctx->d_mol_nspecies, &ctx->d_bpair_off, &ctx->d_bpairI, &ctx->d_bpairJ, &ctx->species, &ctx->species2,
                       &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->cell_cnt_o, &ctx->cell_start_o,
@@ -1517,6 +1514,7 @@ extern "C" int ddcmi_set_species(ddcmi_ctx *ctx, int nspecies, const double *mas
    ctx->moltype.assign(nspecies, 0);
    if (moltype) ctx->moltype.assign(moltype, moltype + nspecies);
    ctx->has_charge = false;
+   ctx->tables_dirty = true;
    std::vector<double> inv(nspecies);
    for (int s = 0; s < nspecies; s++)
    {
@@ -1528,7 +1526,6 @@ extern "C" int ddcmi_set_species(ddcmi_ctx *ctx, int nspecies, const double *mas
    if ((rc = upload_vec(ctx, ctx->d_invmass, inv.data(), nspecies))) return rc;
    if ((rc = upload_vec(ctx, ctx->d_mass, ctx->mass.data(), nspecies))) return rc;
    if ((rc = upload_vec(ctx, ctx->d_charge_sp, ctx->charge.data(), nspecies))) return rc;
-   if ((rc = upload_vec(ctx, ctx->d_ljtype_sp, ctx->ljtype.data(), nspecies))) return rc;
    if ((rc = upload_vec(ctx, ctx->d_moltype_sp, ctx->moltype.data(), nspecies))) return rc;
    return DDCMI_OK;
 }
@@ -1541,11 +1538,56 @@ extern "C" int ddcmi_set_nonbonded(ddcmi_ctx *ctx, int nlj, const double *sigma,
    ctx->nlj = nlj;
    ctx->sigma.assign(sigma, sigma + nlj * nlj); ctx->eps.assign(eps, eps + nlj * nlj); ctx->shift.assign(shift, shift + nlj * nlj);
    ctx->rmax = rmax; ctx->keR = keR; ctx->krf = krf; ctx->crf = crf;
-   std::vector<double4> tab(nlj * nlj);
-   /* table index = ti*nlj + tj; the reference indexes sj + nspecies*si (bioMartini.c:1052) on a symmetric table */
-   for (int k = 0; k < nlj * nlj; k++) tab[k] = make_double4(sigma[k] * sigma[k], 4.0 * eps[k], shift[k], 24.0 * eps[k]);
    ctx->list_valid = false;
-   return upload_vec(ctx, ctx->d_ljtab, tab.data(), tab.size());
+   ctx->tables_dirty = true;
+   return DDCMI_OK;
+}
+
+/* Pair tables of the nonbonded kernel.  The kernel's bead "type" (low byte of the record tag,
+ * nibble of a list entry) is the class (LJ type, charge) of the species: table entry
+ * [a*nnb + b] = {sigma^2, 4 eps, shift, 24 eps} of the two LJ types (the reference indexes
+ * sj + nspecies*si, bioMartini.c:1052, on a symmetric table) and ke/eps_r q_a q_b. */
+__global__ void k_retag(int n, const int *species, const int *nb_of_sp, double4 *pos)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   long long w = __double_as_longlong(pos[i].w);
+   pos[i].w = __longlong_as_double((w & ~0xffll) | (long long)(nb_of_sp[species[i]] & 0xff));
+}
+static int nb_tables(ddcmi_ctx *ctx)
+{
+   if (!ctx->tables_dirty) return DDCMI_OK;
+   if (ctx->nlj <= 0 || ctx->nspecies <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_species and ddcmi_set_nonbonded must both be called before the state is uploaded");
+   std::vector<int> nb(ctx->nspecies), cls_lj;
+   std::vector<double> cls_q;
+   for (int s = 0; s < ctx->nspecies; s++)
+   {
+      if (ctx->ljtype[s] < 0 || ctx->ljtype[s] >= ctx->nlj) SETERR(ctx, DDCMI_EINVAL, "species %d: LJ type %d outside the %d x %d table", s, ctx->ljtype[s], ctx->nlj, ctx->nlj);
+      int c = -1;
+      for (size_t k = 0; k < cls_lj.size(); k++) if (cls_lj[k] == ctx->ljtype[s] && cls_q[k] == ctx->charge[s]) { c = (int)k; break; }
+      if (c < 0) { c = (int)cls_lj.size(); cls_lj.push_back(ctx->ljtype[s]); cls_q.push_back(ctx->charge[s]); }
+      nb[s] = c;
+   }
+   const int nnb = (int)cls_lj.size();
+   if (nnb > 255) SETERR(ctx, DDCMI_EUNSUPPORTED, "%d (LJ type, charge) classes: more than the 255 the record tag holds", nnb);
+   std::vector<double4> tab((size_t)nnb * nnb);
+   std::vector<double> kq((size_t)nnb * nnb);
+   for (int a = 0; a < nnb; a++)
+      for (int b = 0; b < nnb; b++)
+      {
+         int k = cls_lj[a] * ctx->nlj + cls_lj[b];
+         tab[(size_t)a * nnb + b] = make_double4(ctx->sigma[k] * ctx->sigma[k], 4.0 * ctx->eps[k], ctx->shift[k], 24.0 * ctx->eps[k]);
+         kq[(size_t)a * nnb + b] = ctx->keR * cls_q[a] * cls_q[b];
+      }
+   int rc;
+   if ((rc = upload_vec(ctx, ctx->d_ljtab, tab.data(), tab.size())) || (rc = upload_vec(ctx, ctx->d_kqtab, kq.data(), kq.size())) ||
+       (rc = upload_vec(ctx, ctx->d_ljtype_sp, nb.data(), nb.size()))) return rc;
+   ctx->nnb = nnb;
+   ctx->tables_dirty = false;
+   if (ctx->nloc > 0 && ctx->pos.p)      /* parameters changed under an uploaded state: refresh the tags */
+      hipLaunchKernelGGL(k_retag, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, ctx->stream, ctx->nloc, ctx->species.p, ctx->d_ljtype_sp.p, ctx->pos.p);
+   ctx->list_valid = false;
+   return DDCMI_OK;
 }
 
 extern "C" int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_nspecies, const int *bpair_off, const int *bpairI, const int *bpairJ)
@@ -1666,6 +1708,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
 {
    if (!ctx || nlocal <= 0 || !rx || !ry || !rz || !species) return DDCMI_EINVAL;
    if (ctx->nspecies <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_species must be called before ddcmi_upload_state");
+   { int rct = nb_tables(ctx); if (rct) return rct; }
    (void)hipSetDevice(ctx->device);
    for (int i = 0; i < nlocal; i++)
       if (species[i] < 0 || species[i] >= ctx->nspecies) SETERR(ctx, DDCMI_EINVAL, "particle %d has species %d outside [0,%d)", i, species[i], ctx->nspecies);
@@ -1894,6 +1937,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
    (void)hipSetDevice(ctx->device);
    int rc;
+   if ((rc = nb_tables(ctx))) return rc;
    if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
    if ((rc = bl_self_images(ctx))) return rc;
@@ -2002,7 +2046,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
-      ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nlj <= 8 ? 2 : ctx->nlj <= 16 ? 1 : 0) : 0;
+      ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
       TileArgs ta;
       ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
@@ -2101,10 +2145,10 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       bool packed = ctx->pack_type != 0;
       const bool shbit = ctx->pack_type == 2;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
-      size_t lds = capl * 24 + (size_t)ctx->nlj * ctx->nlj * sizeof(double4) + (useq ? capl * 8 : 0) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
+      size_t lds = capl * 24 + (size_t)ctx->nnb * ctx->nnb * (sizeof(double4) + (useq ? sizeof(double) : 0)) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
-      na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nlj;
+      na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nnb;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
@@ -2112,7 +2156,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       { const char *rv = getenv("DDCMI_XCD_ROT"); na.rot = rv ? atoi(rv) : 0; }
 #define LAUNCH_NB(Q, P, S, NT) do { \
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->qatom.p, \
+         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
@@ -2457,7 +2501,7 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
       if (which == 0)
       {
          NbTileArgs na;
-         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nlj;
+         na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nnb;
          na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
          na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
          na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;

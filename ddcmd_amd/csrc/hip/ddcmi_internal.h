@@ -113,7 +113,8 @@ struct ddcmi_ctx
    int excludePotentialTerm = 0;
    bool has_charge = false;
    /* device tables */
-   dbuf<double> d_invmass, d_mass, d_charge_sp; dbuf<int> d_ljtype_sp, d_moltype_sp;
+   dbuf<double> d_invmass, d_mass, d_charge_sp; dbuf<int> d_ljtype_sp, d_moltype_sp;      /* d_ljtype_sp: (LJ type, charge) class of each species */
+   dbuf<double> d_kqtab; int nnb = 0; bool tables_dirty = true;                           /* ke/eps_r q_a q_b per class pair; classes; rebuild tables */
    dbuf<double4> d_ljtab;          /* nlj*nlj {sigma^2, 4eps, shift, 24eps} */
    dbuf<int> d_mol_nspecies, d_bpair_off, d_bpairI, d_bpairJ;
    dbuf<unsigned long long> d_exmask;   /* [nmoltype][64] bonded-pair masks by atom code (list build) */
