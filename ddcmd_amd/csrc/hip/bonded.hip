@@ -59,10 +59,13 @@ __device__ __forceinline__ void block_store(double (&v)[NV], double *out)
  * energy and virial with weight (atoms it owns)/(atoms of the term): every term is then
  * counted exactly once over all ranks, with no force return traffic. */
 struct TermMap { const int *atoms; const int *slot; const int *tmap; int nloc; };
+/* one domain: tmap (if set) is the evaluation ORDER -- terms sorted by the device slot of their first
+ * atom at every rebuild, so that neighbouring threads touch neighbouring beads -- and atoms[] is
+ * indexed by the term (= parameter row) it names; decomposed: atoms[] is indexed by the local term */
 __device__ __forceinline__ int term_atom(const TermMap &m, int na, int t, int a)
 {
-   int i = m.atoms[na * t + a];
-   return m.slot ? m.slot[i] : i;
+   if (m.slot) { int g = m.tmap ? m.tmap[t] : t; return m.slot[m.atoms[na * g + a]]; }
+   return m.atoms[na * t + a];
 }
 __device__ __forceinline__ int term_row(const TermMap &m, int t) { return m.tmap ? m.tmap[t] : t; }
 __device__ __forceinline__ void addf(const TermMap &m, double *fx, double *fy, double *fz, int i, double x, double y, double z)
@@ -285,6 +288,64 @@ __global__ __launch_bounds__(256) void k_reduce_b(RedB rb)
    }
 }
 
+/* ---- evaluation order of the terms of one domain: by the slot of the first atom ---------- */
+__global__ void k_tkey_hist(int nterm, int na, const int *__restrict__ atoms, const int *__restrict__ slot, int *key, int *cnt)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= nterm) return;
+   int k = slot[atoms[na * t]];
+   key[t] = k;
+   atomicAdd(&cnt[k], 1);
+}
+__global__ void k_tkey_place(int nterm, const int *__restrict__ key, const int *__restrict__ start, int *fill, int *perm)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= nterm) return;
+   int k = key[t];
+   perm[start[k] + atomicAdd(&fill[k], 1)] = t;
+}
+/* terms sharing a first atom: ascending term index, so the order does not depend on timing */
+__global__ void k_tkey_fix(int nkey, const int *__restrict__ start, int *perm)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= nkey) return;
+   int a = start[k], b = start[k + 1];
+   for (int i = a + 1; i < b; i++)
+   {
+      int v = perm[i], j = i - 1;
+      while (j >= a && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+      perm[j + 1] = v;
+   }
+}
+static int sort_terms(ddcmi_ctx *ctx, int nterm, int na, const int *atoms, dbuf<int> &perm)
+{
+   if (nterm <= 0) return DDCMI_OK;
+   hipStream_t st = ctx->stream;
+   const int nkey = ctx->nloc;
+   ENSURE(ctx, ctx->tk_key, (size_t)nterm);
+   ENSURE(ctx, ctx->tk_cnt, (size_t)nkey + 2);
+   ENSURE(ctx, ctx->tk_fill, (size_t)nkey + 2);
+   ENSURE(ctx, perm, (size_t)nterm);
+   HIPCHK(ctx, hipMemsetAsync(ctx->tk_cnt.p, 0, ((size_t)nkey + 2) * sizeof(int), st));
+   HIPCHK(ctx, hipMemsetAsync(ctx->tk_fill.p, 0, ((size_t)nkey + 2) * sizeof(int), st));
+   hipLaunchKernelGGL(k_tkey_hist, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, na, atoms, ctx->slot_of_orig.p, ctx->tk_key.p, ctx->tk_cnt.p);
+   int rc = ddcmi_scan_exclusive(ctx, ctx->tk_cnt.p, nkey + 1, ctx->d_flags + 8);
+   if (rc) return rc;
+   hipLaunchKernelGGL(k_tkey_place, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, ctx->tk_key.p, ctx->tk_cnt.p, ctx->tk_fill.p, perm.p);
+   hipLaunchKernelGGL(k_tkey_fix, dim3(cdiv(nkey, 256)), dim3(256), 0, st, nkey, ctx->tk_cnt.p, perm.p);
+   return DDCMI_OK;
+}
+/* one domain, at every rebuild: evaluation order of the caller-order term lists */
+int ddcmi_bonded_order(ddcmi_ctx *ctx)
+{
+   if (ctx->bonded_gid || ctx->nranks > 1 || ctx->group_) return DDCMI_OK;
+   int rc;
+   if ((rc = sort_terms(ctx, ctx->nbond, 2, ctx->bond_ij.p, ctx->o_bond)) || (rc = sort_terms(ctx, ctx->nangle, 3, ctx->angle_ijk.p, ctx->o_angle)) ||
+       (rc = sort_terms(ctx, ctx->ntors, 4, ctx->tors_ijkl.p, ctx->o_tors))) return rc;
+   ctx->bonded_ordered = true;
+   return DDCMI_OK;
+}
+
 /* ---- decomposed runs: terms are given by gid and located among the owned + halo beads - */
 #define GID_EMPTY 0xffffffffffffffffull
 __device__ __forceinline__ unsigned gid_hash(uint64_t g, unsigned mask)
@@ -373,7 +434,7 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
    if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    ctx->excludePotentialTerm = excludePotentialTerm;
-   ctx->bonded_gid = false;
+   ctx->bonded_gid = false; ctx->bonded_ordered = false; ctx->list_valid = false;
    ctx->nbond = (excludePotentialTerm & 1) ? 0 : nbond;
    ctx->nangle = nangle; ctx->ntors = ntors;
    int rc;
@@ -581,19 +642,19 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    double *pb = ctx->bpartials.p, *pa = pb + (size_t)nbb * 8, *pt = pa + (size_t)nab * 8;
    if (ctx->nbond > 0)
    {
-      TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, ctx->bonded_ordered ? ctx->o_bond.p : nullptr, ctx->nloc};
       hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ctx->bond_kb.p, ctx->bond_b0.p, ctx->pos.p,
                          ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
    }
    if (ctx->nangle > 0)
    {
-      TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, ctx->bonded_ordered ? ctx->o_angle.p : nullptr, ctx->nloc};
       hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
    }
    if (ctx->ntors > 0)
    {
-      TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, ctx->bonded_ordered ? ctx->o_tors.p : nullptr, ctx->nloc};
       hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
    }

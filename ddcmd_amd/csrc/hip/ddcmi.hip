@@ -1464,7 +1464,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
-   for (auto b : {&ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
+   for (auto b : {&ctx->o_bond, &ctx->o_angle, &ctx->o_tors, &ctx->tk_key, &ctx->tk_cnt, &ctx->tk_fill, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
@@ -2093,6 +2093,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    ctx->list_valid = true;
    ctx->nrebuild++;
+   { int rco = ddcmi_bonded_order(ctx); if (rco) return rco; }      /* caller-order terms: evaluation order by first-atom slot */
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }
 

@@ -159,6 +159,7 @@ struct ddcmi_ctx
    /* RESTRAINT potential: restraints by gid; rest_slot = owned device slot of each (or -1), found at rebuilds */
    int nrest = 0, rest_origin = 0;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
+   dbuf<int> o_bond, o_angle, o_tors, tk_key, tk_cnt, tk_fill; bool bonded_ordered = false;   /* one domain: evaluation order by first-atom slot */
    bool bonded_gid = false;
    int g_nbond = 0, g_nangle = 0, g_ntors = 0;
    dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;
@@ -197,6 +198,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 /* scan.hip */
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
+int ddcmi_bonded_order(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */
