@@ -52,20 +52,19 @@ __device__ __forceinline__ void block_store(double (&v)[NV], double *out)
 }
 /* Where a term's atoms and parameters live.
  *   one domain: atoms[] holds caller-order indices, translated through slot[] each
- *     launch (atoms are re-sorted at every rebuild); term t uses parameter row t.
+ *     launch (atoms are re-sorted at every rebuild); term t uses parameter row t.  After a rebuild
+ *     the lists are replaced by copies in the order of the first atom's device slot, atoms already
+ *     translated (ddcmi_bonded_order): neighbouring threads then touch neighbouring beads.
  *   decomposed run: atoms[] holds device slots (owned or halo) of the terms this rank
  *     touches, rebuilt with the lists (ddcmi_bonded_localize); tmap[t] = parameter row.
  * A rank adds forces only to the atoms it owns (slot < nloc) and counts a term's
  * energy and virial with weight (atoms it owns)/(atoms of the term): every term is then
  * counted exactly once over all ranks, with no force return traffic. */
 struct TermMap { const int *atoms; const int *slot; const int *tmap; int nloc; };
-/* one domain: tmap (if set) is the evaluation ORDER -- terms sorted by the device slot of their first
- * atom at every rebuild, so that neighbouring threads touch neighbouring beads -- and atoms[] is
- * indexed by the term (= parameter row) it names; decomposed: atoms[] is indexed by the local term */
 __device__ __forceinline__ int term_atom(const TermMap &m, int na, int t, int a)
 {
-   if (m.slot) { int g = m.tmap ? m.tmap[t] : t; return m.slot[m.atoms[na * g + a]]; }
-   return m.atoms[na * t + a];
+   int i = m.atoms[na * t + a];
+   return m.slot ? m.slot[i] : i;
 }
 __device__ __forceinline__ int term_row(const TermMap &m, int t) { return m.tmap ? m.tmap[t] : t; }
 __device__ __forceinline__ void addf(const TermMap &m, double *fx, double *fy, double *fz, int i, double x, double y, double z)
@@ -335,13 +334,58 @@ static int sort_terms(ddcmi_ctx *ctx, int nterm, int na, const int *atoms, dbuf<
    hipLaunchKernelGGL(k_tkey_fix, dim3(cdiv(nkey, 256)), dim3(256), 0, st, nkey, ctx->tk_cnt.p, perm.p);
    return DDCMI_OK;
 }
+/* ... and the terms' atoms (as device slots) and parameters copied into that order, so the
+ * kernels read everything but the bead records and forces with unit stride until the next rebuild */
+template <int NA>
+__global__ void k_term_slots(int nterm, const int *__restrict__ perm, const int *__restrict__ atoms, const int *__restrict__ slot, int *out)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= nterm) return;
+   int g = perm[t];
+#pragma unroll
+   for (int a = 0; a < NA; a++) out[NA * t + a] = slot[atoms[NA * g + a]];
+}
+template <class T>
+__global__ void k_gather_perm(int n, const int *__restrict__ perm, const T *__restrict__ src, T *dst)
+{
+   int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t < n) dst[t] = src[perm[t]];
+}
+template <class T>
+static int gather_perm(ddcmi_ctx *ctx, int n, const dbuf<int> &perm, const dbuf<T> &src, dbuf<T> &dst)
+{
+   ENSURE(ctx, dst, (size_t)n);
+   hipLaunchKernelGGL(k_gather_perm<T>, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, perm.p, src.p, dst.p);
+   return DDCMI_OK;
+}
 /* one domain, at every rebuild: evaluation order of the caller-order term lists */
 int ddcmi_bonded_order(ddcmi_ctx *ctx)
 {
    if (ctx->bonded_gid || ctx->nranks > 1 || ctx->group_) return DDCMI_OK;
+   hipStream_t st = ctx->stream;
    int rc;
    if ((rc = sort_terms(ctx, ctx->nbond, 2, ctx->bond_ij.p, ctx->o_bond)) || (rc = sort_terms(ctx, ctx->nangle, 3, ctx->angle_ijk.p, ctx->o_angle)) ||
        (rc = sort_terms(ctx, ctx->ntors, 4, ctx->tors_ijkl.p, ctx->o_tors))) return rc;
+   if (ctx->nbond > 0)
+   {
+      ENSURE(ctx, ctx->s_bond_atoms, 2 * (size_t)ctx->nbond);
+      hipLaunchKernelGGL(k_term_slots<2>, dim3(cdiv(ctx->nbond, 256)), dim3(256), 0, st, ctx->nbond, ctx->o_bond.p, ctx->bond_ij.p, ctx->slot_of_orig.p, ctx->s_bond_atoms.p);
+      if ((rc = gather_perm(ctx, ctx->nbond, ctx->o_bond, ctx->bond_kb, ctx->s_bond_kb)) || (rc = gather_perm(ctx, ctx->nbond, ctx->o_bond, ctx->bond_b0, ctx->s_bond_b0))) return rc;
+   }
+   if (ctx->nangle > 0)
+   {
+      ENSURE(ctx, ctx->s_angle_atoms, 3 * (size_t)ctx->nangle);
+      hipLaunchKernelGGL(k_term_slots<3>, dim3(cdiv(ctx->nangle, 256)), dim3(256), 0, st, ctx->nangle, ctx->o_angle.p, ctx->angle_ijk.p, ctx->slot_of_orig.p, ctx->s_angle_atoms.p);
+      if ((rc = gather_perm(ctx, ctx->nangle, ctx->o_angle, ctx->angle_func, ctx->s_angle_func)) || (rc = gather_perm(ctx, ctx->nangle, ctx->o_angle, ctx->angle_k, ctx->s_angle_k)) ||
+          (rc = gather_perm(ctx, ctx->nangle, ctx->o_angle, ctx->angle_t0, ctx->s_angle_t0))) return rc;
+   }
+   if (ctx->ntors > 0)
+   {
+      ENSURE(ctx, ctx->s_tors_atoms, 4 * (size_t)ctx->ntors);
+      hipLaunchKernelGGL(k_term_slots<4>, dim3(cdiv(ctx->ntors, 256)), dim3(256), 0, st, ctx->ntors, ctx->o_tors.p, ctx->tors_ijkl.p, ctx->slot_of_orig.p, ctx->s_tors_atoms.p);
+      if ((rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_func, ctx->s_tors_func)) || (rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_n, ctx->s_tors_n)) ||
+          (rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_k, ctx->s_tors_k)) || (rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_delta, ctx->s_tors_delta))) return rc;
+   }
    ctx->bonded_ordered = true;
    return DDCMI_OK;
 }
@@ -642,20 +686,27 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    double *pb = ctx->bpartials.p, *pa = pb + (size_t)nbb * 8, *pt = pa + (size_t)nab * 8;
    if (ctx->nbond > 0)
    {
-      TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, ctx->bonded_ordered ? ctx->o_bond.p : nullptr, ctx->nloc};
-      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ctx->bond_kb.p, ctx->bond_b0.p, ctx->pos.p,
+      const bool ord = !gidmode && ctx->bonded_ordered;
+      TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc}
+                 : ord ? TermMap{ctx->s_bond_atoms.p, nullptr, nullptr, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ord ? ctx->s_bond_kb.p : ctx->bond_kb.p, ord ? ctx->s_bond_b0.p : ctx->bond_b0.p, ctx->pos.p,
                          ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
    }
    if (ctx->nangle > 0)
    {
-      TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, ctx->bonded_ordered ? ctx->o_angle.p : nullptr, ctx->nloc};
-      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
+      const bool ord = !gidmode && ctx->bonded_ordered;
+      TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc}
+                 : ord ? TermMap{ctx->s_angle_atoms.p, nullptr, nullptr, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ord ? ctx->s_angle_func.p : ctx->angle_func.p, ord ? ctx->s_angle_k.p : ctx->angle_k.p, ord ? ctx->s_angle_t0.p : ctx->angle_t0.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
    }
    if (ctx->ntors > 0)
    {
-      TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, ctx->bonded_ordered ? ctx->o_tors.p : nullptr, ctx->nloc};
-      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
+      const bool ord = !gidmode && ctx->bonded_ordered;
+      TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc}
+                 : ord ? TermMap{ctx->s_tors_atoms.p, nullptr, nullptr, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
+      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ord ? ctx->s_tors_func.p : ctx->tors_func.p, ord ? ctx->s_tors_n.p : ctx->tors_n.p,
+                         ord ? ctx->s_tors_k.p : ctx->tors_k.p, ord ? ctx->s_tors_delta.p : ctx->tors_delta.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
    }
    RedB rb;

@@ -1464,7 +1464,8 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
-   for (auto b : {&ctx->o_bond, &ctx->o_angle, &ctx->o_tors, &ctx->tk_key, &ctx->tk_cnt, &ctx->tk_fill, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
+   for (auto b : {&ctx->s_bond_kb, &ctx->s_bond_b0, &ctx->s_angle_k, &ctx->s_angle_t0, &ctx->s_tors_k, &ctx->s_tors_delta}) b->release();
+   for (auto b : {&ctx->s_bond_atoms, &ctx->s_angle_atoms, &ctx->s_angle_func, &ctx->s_tors_atoms, &ctx->s_tors_func, &ctx->s_tors_n, &ctx->o_bond, &ctx->o_angle, &ctx->o_tors, &ctx->tk_key, &ctx->tk_cnt, &ctx->tk_fill, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);

@@ -160,6 +160,8 @@ struct ddcmi_ctx
    int nrest = 0, rest_origin = 0;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
    dbuf<int> o_bond, o_angle, o_tors, tk_key, tk_cnt, tk_fill; bool bonded_ordered = false;   /* one domain: evaluation order by first-atom slot */
+   dbuf<int> s_bond_atoms, s_angle_atoms, s_angle_func, s_tors_atoms, s_tors_func, s_tors_n;   /* ... and the lists copied into that order */
+   dbuf<double> s_bond_kb, s_bond_b0, s_angle_k, s_angle_t0, s_tors_k, s_tors_delta;
    bool bonded_gid = false;
    int g_nbond = 0, g_nangle = 0, g_ntors = 0;
    dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;
