@@ -716,3 +716,219 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    hipLaunchKernelGGL(k_reduce_b, dim3(3), dim3(256), 0, st, rb);
    return DDCMI_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * nglfconstraint (one domain): velocity constraints, resMoveConsOld (nglfconstraint.c:180-264).
+ * One lane per constraint group; the group's velocities, inverse masses and pair vectors live in
+ * LDS ([item][lane], so a wavefront's lanes hit different banks) for the Gauss-Seidel sweeps:
+ *   rvab = FRONT ((rab + dt vab)^2 - d^2) / (2 dt d^2) | BACK (rab . vab) / d^2
+ *   gab = -rvab / (1/ma + 1/mb);  va += gab/ma rab;  vb -= gab/mb rab
+ * until max |rvab dt| < 1e-12, at most 500 sweeps (the reference's tol and maxit).
+ * status[0] = largest sweep count, status[1] = groups that hit maxit. */
+#define CONS_T 64
+template <int LOC>
+__global__ __launch_bounds__(CONS_T) void k_constrain(int ngroups, const int *__restrict__ atom_off, const int *__restrict__ atoms, const int *__restrict__ pair_off,
+                                                      const unsigned char *__restrict__ pa, const unsigned char *__restrict__ pb, const double *__restrict__ dist,
+                                                      const int *__restrict__ slot, BoxArgs box, const double4 *__restrict__ pos, const int *__restrict__ species,
+                                                      const double *__restrict__ invmass, double *vx, double *vy, double *vz, double dt, int maxA, int maxP, int *status)
+{
+   extern __shared__ double cons_sh[];
+   const int t = threadIdx.x, g = blockIdx.x * CONS_T + t;
+   double *v = cons_sh, *rm = cons_sh + 3 * maxA * CONS_T, *rab = rm + maxA * CONS_T;
+   if (g >= ngroups) return;
+   const int a0 = atom_off[g], na = atom_off[g + 1] - a0, p0 = pair_off[g], np = pair_off[g + 1] - p0;
+   for (int a = 0; a < na; a++)
+   {
+      int s = slot[atoms[a0 + a]];
+      v[(3 * a + 0) * CONS_T + t] = vx[s]; v[(3 * a + 1) * CONS_T + t] = vy[s]; v[(3 * a + 2) * CONS_T + t] = vz[s];
+      rm[a * CONS_T + t] = invmass[species[s]];
+   }
+   for (int ab = 0; ab < np; ab++)
+   {
+      int sa = slot[atoms[a0 + pa[p0 + ab]]], sb = slot[atoms[a0 + pb[p0 + ab]]];
+      double x, y, z;
+      bioVec(box, pos[sa], pos[sb], x, y, z);
+      rab[(3 * ab + 0) * CONS_T + t] = x; rab[(3 * ab + 1) * CONS_T + t] = y; rab[(3 * ab + 2) * CONS_T + t] = z;
+   }
+   const double tol = 1.0e-12;
+   const int maxit = 500;
+   int it = 0;
+   for (; it < maxit; it++)
+   {
+      double errMax = 0.0;
+      for (int ab = 0; ab < np; ab++)
+      {
+         const int a = pa[p0 + ab], b = pb[p0 + ab];
+         const double d = dist[p0 + ab], dist2 = d * d;
+         const double rx = rab[(3 * ab + 0) * CONS_T + t], ry = rab[(3 * ab + 1) * CONS_T + t], rz = rab[(3 * ab + 2) * CONS_T + t];
+         double *va = v + 3 * a * CONS_T + t, *vb = v + 3 * b * CONS_T + t;
+         const double wx = va[0] - vb[0], wy = va[CONS_T] - vb[CONS_T], wz = va[2 * CONS_T] - vb[2 * CONS_T];
+         const double rma = rm[a * CONS_T + t], rmb = rm[b * CONS_T + t];
+         double rvab;
+         if (LOC == 0)
+         {
+            double px = rx + dt * wx, py = ry + dt * wy, pz = rz + dt * wz;
+            rvab = (px * px + py * py + pz * pz - dist2) / (2 * dt);
+         }
+         else rvab = rx * wx + ry * wy + rz * wz;
+         rvab /= dist2;
+         const double gab = -rvab / (rma + rmb);
+         errMax = fmax(errMax, fabs(rvab * dt));
+         const double ca = rma * gab, cb = rmb * gab;
+         va[0] += ca * rx; va[CONS_T] += ca * ry; va[2 * CONS_T] += ca * rz;
+         vb[0] -= cb * rx; vb[CONS_T] -= cb * ry; vb[2 * CONS_T] -= cb * rz;
+      }
+      if (errMax < tol) break;
+   }
+   for (int a = 0; a < na; a++)
+   {
+      int s = slot[atoms[a0 + a]];
+      vx[s] = v[(3 * a + 0) * CONS_T + t]; vy[s] = v[(3 * a + 1) * CONS_T + t]; vz[s] = v[(3 * a + 2) * CONS_T + t];
+   }
+   atomicMax(status, it < maxit ? it + 1 : maxit);
+   if (it == maxit) atomicAdd(status + 1, 1);
+}
+
+extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const int *pairI, const int *pairJ, const double *dist)
+{
+   if (!ctx || ngroups < 0 || (ngroups > 0 && (!pair_off || !pairI || !pairJ || !dist))) return DDCMI_EINVAL;
+   if (ngroups > 0 && (ctx->group_ || ctx->nranks > 1)) SETERR(ctx, DDCMI_EINVAL, "velocity constraints are implemented for one domain only");
+   (void)hipSetDevice(ctx->device);
+   ctx->ncgroup = 0; ctx->ncpair = 0;
+   if (ngroups == 0) return DDCMI_OK;
+   /* group-local atom lists (CONSTRAINT.atomIDList, bioMartini.c:405-425): pairs name positions in them */
+   std::vector<int> aoff(ngroups + 1, 0), alist;
+   const int np_tot = pair_off[ngroups];
+   std::vector<unsigned char> pa(np_tot), pb(np_tot);
+   int maxA = 0, maxP = 0;
+   for (int g = 0; g < ngroups; g++)
+   {
+      const int base = (int)alist.size();
+      for (int k = pair_off[g]; k < pair_off[g + 1]; k++)
+      {
+         if (pairI[k] == pairJ[k] || !(dist[k] > 0.0)) SETERR(ctx, DDCMI_EINVAL, "constraint %d of group %d: atoms %d %d, distance %g", k - pair_off[g], g, pairI[k], pairJ[k], dist[k]);
+         int loc[2];
+         for (int e = 0; e < 2; e++)
+         {
+            const int at = e ? pairJ[k] : pairI[k];
+            int f = -1;
+            for (int q = base; q < (int)alist.size(); q++) if (alist[q] == at) { f = q - base; break; }
+            if (f < 0) { f = (int)alist.size() - base; alist.push_back(at); }
+            loc[e] = f;
+         }
+         if (loc[0] > 255 || loc[1] > 255) SETERR(ctx, DDCMI_EINVAL, "constraint group %d has more than 256 atoms", g);
+         pa[k] = (unsigned char)loc[0]; pb[k] = (unsigned char)loc[1];
+      }
+      aoff[g + 1] = (int)alist.size();
+      maxA = std::max(maxA, aoff[g + 1] - aoff[g]);
+      maxP = std::max(maxP, pair_off[g + 1] - pair_off[g]);
+   }
+   if ((size_t)(4 * maxA + 3 * maxP) * CONS_T * sizeof(double) > 64 * 1024)
+      SETERR(ctx, DDCMI_EINVAL, "constraint group of %d atoms / %d pairs exceeds the LDS budget of the solver (4 atoms + 3 pairs <= 128)", maxA, maxP);
+   int rc;
+   if ((rc = up(ctx, ctx->cg_atom_off, aoff.data(), (size_t)ngroups + 1)) || (rc = up(ctx, ctx->cg_atoms, alist.data(), alist.size())) ||
+       (rc = up(ctx, ctx->cg_pair_off, pair_off, (size_t)ngroups + 1)) || (rc = up(ctx, ctx->cg_pa, pa.data(), (size_t)np_tot)) ||
+       (rc = up(ctx, ctx->cg_pb, pb.data(), (size_t)np_tot)) || (rc = up(ctx, ctx->cg_dist, dist, (size_t)np_tot))) return rc;
+   ENSURE(ctx, ctx->cons_status, 4);
+   HIPCHK(ctx, hipMemsetAsync(ctx->cons_status.p, 0, 4 * sizeof(int), ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   ctx->ncgroup = ngroups; ctx->ncpair = np_tot; ctx->cons_maxA = maxA; ctx->cons_maxP = maxP;
+   return DDCMI_OK;
+}
+
+int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location)
+{
+   if (ctx->ncgroup == 0) return DDCMI_OK;
+   BoxArgs box;
+   box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
+   for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
+   box.pbc = ctx->pbc;
+   const size_t lds = (size_t)(4 * ctx->cons_maxA + 3 * ctx->cons_maxP) * CONS_T * sizeof(double);
+   auto kern = location == 0 ? k_constrain<0> : k_constrain<1>;
+   hipLaunchKernelGGL(kern, dim3(cdiv(ctx->ncgroup, CONS_T)), dim3(CONS_T), lds, ctx->stream, ctx->ncgroup, ctx->cg_atom_off.p, ctx->cg_atoms.p, ctx->cg_pair_off.p,
+                      ctx->cg_pa.p, ctx->cg_pb.p, ctx->cg_dist.p, ctx->slot_of_orig.p, box, ctx->pos.p, ctx->species.p, ctx->d_invmass.p,
+                      ctx->vx.p, ctx->vy.p, ctx->vz.p, dt, ctx->cons_maxA, ctx->cons_maxP, ctx->cons_status.p);
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_constraint_stats(ddcmi_ctx *ctx, int *max_sweeps, int *unconverged, int reset)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   int h[2] = {0, 0};
+   if (ctx->ncgroup > 0)
+   {
+      (void)hipSetDevice(ctx->device);
+      HIPCHK(ctx, hipMemcpyAsync(h, ctx->cons_status.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->cons_status.p, 0, 4 * sizeof(int), ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   }
+   if (max_sweeps) *max_sweeps = h[0];
+   if (unconverged) *unconverged = h[1];
+   return DDCMI_OK;
+}
+
+/* molecularVirial (molecularPressure.c:23-56): sum over the beads of every molecule of (r - R) f on the
+ * diagonal, R = the molecule's centre of mass; images are resolved relative to the molecule's first
+ * listed atom (the reference uses its ownership species; any atom gives the same numbers while a
+ * molecule is smaller than half the box).  One lane per molecule of two or more beads. */
+__global__ __launch_bounds__(256) void k_mol_virial(int nmol, const int *__restrict__ mol_off, const int *__restrict__ atoms, const int *__restrict__ slot, BoxArgs box,
+                                                    const double4 *__restrict__ pos, const int *__restrict__ species, const double *__restrict__ mass,
+                                                    const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz, double *out)
+{
+   const int m = blockIdx.x * 256 + threadIdx.x;
+   double acc[3] = {0, 0, 0};
+   if (m < nmol)
+   {
+      const int a0 = mol_off[m], a1 = mol_off[m + 1];
+      const double4 p0 = pos[slot[atoms[a0]]];
+      double M = 0, Rx = 0, Ry = 0, Rz = 0;
+      for (int a = a0; a < a1; a++)
+      {
+         int s = slot[atoms[a]];
+         double x, y, z, w = mass[species[s]];
+         bioVec(box, pos[s], p0, x, y, z);
+         Rx += w * x; Ry += w * y; Rz += w * z; M += w;
+      }
+      Rx /= M; Ry /= M; Rz /= M;
+      for (int a = a0; a < a1; a++)
+      {
+         int s = slot[atoms[a]];
+         double x, y, z;
+         bioVec(box, pos[s], p0, x, y, z);
+         acc[0] += (x - Rx) * fx[s]; acc[1] += (y - Ry) * fy[s]; acc[2] += (z - Rz) * fz[s];
+      }
+   }
+#pragma unroll
+   for (int k = 0; k < 3; k++)
+   {
+      double w = wsum(acc[k]);
+      if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(out + k, w);
+   }
+}
+
+extern "C" int ddcmi_set_molecule_lists(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const int *mol_atoms)
+{
+   if (!ctx || nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atoms))) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   int rc;
+   ctx->nmol_total = nmol_total; ctx->nmol_multi = 0; ctx->molv_valid = false;
+   if (nmulti > 0)
+   {
+      if ((rc = up(ctx, ctx->mol_off, mol_off, (size_t)nmulti + 1)) || (rc = up(ctx, ctx->mol_atoms, mol_atoms, (size_t)mol_off[nmulti]))) return rc;
+      ctx->nmol_multi = nmulti;
+   }
+   return DDCMI_OK;
+}
+
+int ddcmi_launch_mol_virial(ddcmi_ctx *ctx)
+{
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_MOLV, 0, 3 * sizeof(double), ctx->stream));
+   if (ctx->nmol_multi == 0) return DDCMI_OK;
+   BoxArgs box;
+   box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
+   for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
+   box.pbc = ctx->pbc;
+   hipLaunchKernelGGL(k_mol_virial, dim3(cdiv(ctx->nmol_multi, 256)), dim3(256), 0, ctx->stream, ctx->nmol_multi, ctx->mol_off.p, ctx->mol_atoms.p, ctx->slot_of_orig.p, box,
+                      ctx->pos.p, ctx->species.p, ctx->d_mass.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_MOLV);
+   return DDCMI_OK;
+}

@@ -1144,10 +1144,19 @@ __device__ __forceinline__ void gauss3(unsigned long long seed, unsigned long lo
 __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ invmass, const int *__restrict__ species,
                              const int *__restrict__ group, GroupLambda glambda, const uint64_t *__restrict__ gid,
                              const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
-                             double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz, double4 *__restrict__ pos)
+                             double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz, double4 *__restrict__ pos, int mode)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= nloc) return;
+   if (mode != 3)
+   {
+      /* nglfconstraint splits the pass around the FRONT constraint solve: mode 1 = barostat scaling of the
+       * positions (adjustPosn) + kick, mode 2 = drift with the constrained velocities */
+      double4 p = pos[i];
+      if (mode == 2) { p.x = fma(dt, vx[i], p.x); p.y = fma(dt, vy[i], p.y); p.z = fma(dt, vz[i], p.z); pos[i] = p; return; }
+      if (glambda.scale[0] != 1.0 || glambda.scale[1] != 1.0 || glambda.scale[2] != 1.0)
+      { p.x *= glambda.scale[0]; p.y *= glambda.scale[1]; p.z *= glambda.scale[2]; pos[i] = p; }
+   }
    const double im = invmass[species[i]];
    double a = (0.5 * dt) * im;
    const int gr = group[i] & 31;
@@ -1166,6 +1175,7 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
       x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
    }
    vx[i] = x; vy[i] = y; vz[i] = z;
+   if (mode != 3) return;
    double4 p = pos[i];
    p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
    pos[i] = p;
@@ -1464,7 +1474,9 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
-   for (auto b : {&ctx->s_bond_kb, &ctx->s_bond_b0, &ctx->s_angle_k, &ctx->s_angle_t0, &ctx->s_tors_k, &ctx->s_tors_delta}) b->release();
+   for (auto b : {&ctx->s_bond_kb, &ctx->s_bond_b0, &ctx->s_angle_k, &ctx->s_angle_t0, &ctx->s_tors_k, &ctx->s_tors_delta, &ctx->cg_dist}) b->release();
+   for (auto b : {&ctx->cg_atom_off, &ctx->cg_atoms, &ctx->cg_pair_off, &ctx->cons_status, &ctx->mol_off, &ctx->mol_atoms}) b->release();
+   ctx->cg_pa.release(); ctx->cg_pb.release();
    for (auto b : {&ctx->s_bond_atoms, &ctx->s_angle_atoms, &ctx->s_angle_func, &ctx->s_tors_atoms, &ctx->s_tors_func, &ctx->s_tors_n, &ctx->o_bond, &ctx->o_angle, &ctx->o_tors, &ctx->tk_key, &ctx->tk_cnt, &ctx->tk_fill, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -1660,8 +1672,6 @@ extern "C" int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double be
    if (beta > 0.0)
    {
       if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat is implemented for a single domain");
-      for (int m = 0; m < ctx->nmoltype; m++)
-         if (ctx->mol_nspecies[m] > 1) SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat needs the molecular pressure; only single-bead molecules are handled (molecule type %d has %d beads)", m, ctx->mol_nspecies[m]);
    }
    ctx->baro_T = T; ctx->baro_P0 = P0; ctx->baro_beta = beta; ctx->baro_tau = tau;
    return DDCMI_OK;
@@ -1670,6 +1680,12 @@ extern "C" int ddcmi_get_box(const ddcmi_ctx *ctx, double h[9])
 {
    if (!ctx || !h) return DDCMI_EINVAL;
    for (int k = 0; k < 9; k++) h[k] = ctx->h[k];
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_get_barostat_pressure(const ddcmi_ctx *ctx, double p[3])
+{
+   if (!ctx || !p) return DDCMI_EINVAL;
+   for (int k = 0; k < 3; k++) p[k] = ctx->pmol[k];
    return DDCMI_OK;
 }
 
@@ -2229,6 +2245,7 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group evaluate forces with ddcmi_group_eval_forces");
    if (!ctx->list_valid && (rc = ddcmi_build_list(ctx))) return rc;
    if ((rc = launch_forces(ctx))) return rc;
+   ctx->molv_valid = false;
    if ((rc = fetch_results(ctx))) return rc;
    if (energies) for (int k = 0; k < DDCMI_NE; k++) energies[k] = ctx->h_results[R_E + k];
    if (virial) for (int k = 0; k < 6; k++) virial[k] = ctx->h_results[R_VIR + k];
@@ -2314,12 +2331,16 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
          /* nglfconstraint.c:527-536 + changeVolume (:64-84): semi-isotropic Berendsen barostat from the
           * molecular pressure of the last force evaluation (all molecules are single beads here, so the
           * molecular virial is the atomic one: molecularPressure.c), at the TARGET temperature */
-         int rcb = fetch_results(ctx);
-         if (rcb) return rcb;
-         const double vol = ctx->h[0] * ctx->h[4] * ctx->h[8], NkT = (double)ctx->nloc * ctx->baro_T;
-         double pxx = (ctx->h_results[R_VIR + DDCMI_XX] + NkT) / vol - ctx->baro_P0;
-         double pyy = (ctx->h_results[R_VIR + DDCMI_YY] + NkT) / vol - ctx->baro_P0;
-         double pzz = (ctx->h_results[R_VIR + DDCMI_ZZ] + NkT) / vol - ctx->baro_P0;
+         int rcb;
+         if (!ctx->molv_valid && (rcb = ddcmi_launch_mol_virial(ctx))) return rcb;     /* first step after ddcmi_eval_forces */
+         if ((rcb = fetch_results(ctx))) return rcb;
+         const double nmol = ctx->nmol_total > 0 ? (double)ctx->nmol_total : (double)ctx->nloc;
+         const double vol = ctx->h[0] * ctx->h[4] * ctx->h[8], NkT = nmol * ctx->baro_T;
+         const double *mv = ctx->h_results + R_SCR_MOLV;       /* zero unless molecule lists are set */
+         double pxx = (ctx->h_results[R_VIR + DDCMI_XX] - mv[0] + NkT) / vol - ctx->baro_P0;
+         double pyy = (ctx->h_results[R_VIR + DDCMI_YY] - mv[1] + NkT) / vol - ctx->baro_P0;
+         double pzz = (ctx->h_results[R_VIR + DDCMI_ZZ] - mv[2] + NkT) / vol - ctx->baro_P0;
+         ctx->pmol[0] = pxx + ctx->baro_P0; ctx->pmol[1] = pyy + ctx->baro_P0; ctx->pmol[2] = pzz + ctx->baro_P0;
          const double btt = ctx->baro_beta * dt / ctx->baro_tau;
          double pl = 0.5 * (pxx + pyy);
          double l[3] = {cbrt(1.0 + pl * btt), cbrt(1.0 + pl * btt), cbrt(1.0 + pzz * btt)};
@@ -2331,9 +2352,19 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
             ctx->gp.L[a] = ctx->h[4 * a];
          }
       }
-      if (n > 0)
+      if (n > 0 && ctx->ncgroup > 0)
+      {
+         /* nglfconstraint.c:538-553: FRONT kick, velocityConstraintOld(FRONT) at the (scaled) positions, drift */
+         int rcc;
          hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p);
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 1);
+         if ((rcc = ddcmi_launch_constraints(ctx, dt, 0))) return rcc;
+         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 2);
+      }
+      else if (n > 0)
+         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 3);
    }
    ctx->drift_done = false;             /* else: the previous step's last kernel already did this kick + drift */
    ctx->time += dt;
@@ -2348,6 +2379,22 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
    if ((rc = launch_forces(ctx, true))) return rc;
    berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
    GroupLambda lam = front_lambda(ctx, dt);
+   if (ctx->baro_beta > 0.0)      /* from this step's forces, for the next step's barostat */
+   {
+      if ((rc = ddcmi_launch_mol_virial(ctx))) return rc;
+      ctx->molv_valid = true;
+   }
+   if (ctx->ncgroup > 0 && ctx->nloc > 0)
+   {
+      /* nglfconstraint.c:567-571: BACK kick, velocityConstraintOld(BACK), then kinetic_terms */
+      GroupLambda lb = lam;
+      const int nblk = cdiv(ctx->nloc, DDCMI_BLOCK * KE_PER);
+      ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
+      hipLaunchKernelGGL(k_kick_ke, dim3(nblk), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->nloc, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, 1, ctx->group.p, lb, ctx->gid.p);
+      if ((rc = ddcmi_launch_constraints(ctx, dt, 1))) return rc;
+      return launch_kinetic(ctx, dt, 0, true, &lam, false);
+   }
    if (more_steps && ctx->nloc > 0 && !(ctx->baro_beta > 0.0))      /* the barostat needs this step's virial before the next drift */
    {
       if ((rc = launch_kinetic(ctx, dt, 1, true, &lam, true))) return rc;
@@ -2404,6 +2451,9 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are stepped with ddcmi_group_step_nglf");
    (void)hipSetDevice(ctx->device);
    int rc;
+   if (ctx->baro_beta > 0.0 && ctx->nmol_total == 0)
+      for (int m = 0; m < ctx->nmoltype; m++)
+         if (ctx->mol_nspecies[m] > 1) SETERR(ctx, DDCMI_EINVAL, "the barostat acts on the molecular pressure: molecule type %d has %d beads, call ddcmi_set_molecule_lists first", m, ctx->mol_nspecies[m]);
    for (int s = 0; s < nsteps; s++)
    {
       if ((rc = step_pre(ctx, dt))) return rc;

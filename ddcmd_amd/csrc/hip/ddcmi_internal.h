@@ -88,6 +88,7 @@ enum
    R_SCR_ANGLE = 16,                               /* {e, vir6} */
    R_SCR_TORS = 24,                                /* {e_tors, e_impr, vir6} */
    R_SCR_REST = 32,                                /* RESTRAINT potential: {e, vir6} */
+   R_SCR_MOLV = 40,                                /* molecularVirial correction: sum (r - R_mol) f, xx yy zz */
    R_RK = 56, R_TION = 57,
    R_E = 64,                                       /* final energies[DDCMI_NE] */
    R_VIR = 72,                                     /* final virial[6] */
@@ -147,6 +148,7 @@ struct ddcmi_ctx
    dbuf<double> red_tmp;               /* k_reduce_jobs: per-workgroup rows of a split job + ticket counters */
    dbuf<double4> pos0; dbuf<double> disp;   /* updateRate == 0: positions at the last rebuild; [0..2] sum of r-r0, [4] max |dr|^2 */
    double baro_T = 0, baro_P0 = 0, baro_beta = 0, baro_tau = 0;      /* NGLFCONSTRAINT's Berendsen barostat; beta = 0: off */
+   double pmol[3] = {0, 0, 0};                                      /* molecular pressure (xx, yy, zz) the barostat last acted on */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */
    bool list_valid = false;
@@ -158,6 +160,12 @@ struct ddcmi_ctx
     * lists, the terms touching an owned bead with the device slots of their atoms */
    /* RESTRAINT potential: restraints by gid; rest_slot = owned device slot of each (or -1), found at rebuilds */
    int nrest = 0, rest_origin = 0;
+   /* nglfconstraint (one domain): constraint groups over caller-order atoms; pairs name group-local atoms */
+   int ncgroup = 0, ncpair = 0, cons_maxA = 0, cons_maxP = 0;
+   dbuf<int> cg_atom_off, cg_atoms, cg_pair_off, cons_status; dbuf<unsigned char> cg_pa, cg_pb; dbuf<double> cg_dist;
+   /* molecules of more than one bead (molecular virial of the barostat), caller-order atoms */
+   long nmol_total = 0; int nmol_multi = 0; bool molv_valid = false;   /* R_SCR_MOLV belongs to the forces now in fx */
+   dbuf<int> mol_off, mol_atoms;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
    dbuf<int> o_bond, o_angle, o_tors, tk_key, tk_cnt, tk_fill; bool bonded_ordered = false;   /* one domain: evaluation order by first-atom slot */
    dbuf<int> s_bond_atoms, s_angle_atoms, s_angle_func, s_tors_atoms, s_tors_func, s_tors_n;   /* ... and the lists copied into that order */
@@ -205,6 +213,8 @@ int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */
 int ddcmi_launch_bonded(ddcmi_ctx *ctx);
+int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location);   /* 0 FRONT, 1 BACK */
+int ddcmi_launch_mol_virial(ddcmi_ctx *ctx);
 /* comm.hip */
 void ddcmi_comm_destroy(ddcmi_ctx *ctx);
 /* ddcmi.hip: rebuild phases shared by the single- and multi-domain paths */

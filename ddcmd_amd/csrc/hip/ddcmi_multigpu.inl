@@ -640,6 +640,8 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
    ddcmi_group *g = ctxs[0]->group_;
    int rc;
+   for (ddcmi_ctx *c : g->ranks)
+      if (c->ncgroup > 0) SETERR(c, DDCMI_EINVAL, "velocity constraints are implemented for one domain only");
    for (int s = 0; s < nsteps; s++)
    {
       bool rebuild = false;

@@ -54,7 +54,7 @@ static double lj_shift(double sigma, double eps, double rcut)
 }
 
 /* the MMFF object tree (bioMMFF.c:9-264) */
-typedef struct { int atomI, atomJ, func, valid; char *typeI, *typeJ; double kb, b0; } bondparms;
+typedef struct { int atomI, atomJ, func, valid; char *typeI, *typeJ; double kb, b0; int grp; } bondparms;   /* grp: CONSLISTPARMS index of a constraint */
 typedef struct { int atomI, atomJ, atomK, func; double ktheta, theta0; } angleparms;
 typedef struct { int atomI, atomJ, atomK, atomL, func, n; double kchi, delta; } torsparms;
 typedef struct
@@ -154,7 +154,10 @@ static int load_resi(const char *name, resiparms *r, char *err, int errlen)
             memset(b, 0, sizeof(*b));
             object_get(po, "atomI", &b->atomI, INT, 1, "0");
             object_get(po, "atomJ", &b->atomJ, INT, 1, "0");
-            b->valid = 1;
+            object_get(po, "func", &b->func, INT, 1, "1");
+            object_get(po, "r0", &b->b0, WITH_UNITS, 1, "0.0", "nm", NULL);     /* consparms_init, bioMMFF.c:64-85 */
+            b->valid = (b->func == 1);
+            b->grp = c;
             free(cn[i]);
          }
          free(cn);
@@ -754,6 +757,20 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
          }
       }
       s->bond_off[nresi] = nb; s->angle_off[nresi] = na; s->tors_off[nresi] = nt;
+      /* constraint groups (genConstraint, bioMartini.c:300-445): one group per CONSLISTPARMS, pairs in deck order */
+      int nc = 0;
+      for (int r = 0; r < nresi; r++) nc += resi[r].ncons;
+      s->cons_off = calloc(nresi + 1, sizeof(int));
+      s->consI = calloc(nc + 1, sizeof(int)); s->consJ = calloc(nc + 1, sizeof(int)); s->cons_grp = calloc(nc + 1, sizeof(int));
+      s->cons_r0 = calloc(nc + 1, sizeof(double));
+      nc = 0;
+      for (int r = 0; r < nresi; r++)
+      {
+         s->cons_off[r] = nc;
+         for (int i = 0; i < resi[r].ncons; i++, nc++)
+         { s->consI[nc] = resi[r].cons[i].atomI; s->consJ[nc] = resi[r].cons[i].atomJ; s->cons_grp[nc] = resi[r].cons[i].grp; s->cons_r0[nc] = resi[r].cons[i].b0; }
+      }
+      s->cons_off[nresi] = nc;
    }
    /* molecule type -> bpair list of the ownership species' residue
     * (reOrgPairs bioMartini.c:1416-1423; genMartiniBondPair :135-282).  The
@@ -852,6 +869,7 @@ void ddcmi_setup_free(ddcmi_setup *s)
    free(s->group_name); free(s->group_type); free(s->group_Teq); free(s->group_tau); free(s->group_interval);
    free(s->rx); free(s->ry); free(s->rz); free(s->vx); free(s->vy); free(s->vz); free(s->gid); free(s->species); free(s->group);
    free(s->rest_gid); free(s->rest_fc); free(s->rest_r0); free(s->rest_kb);
+   free(s->cons_off); free(s->consI); free(s->consJ); free(s->cons_grp); free(s->cons_r0);
    free(s->integrator_type); free(s->accelerator_type);
    free(s->u_pressure); free(s->u_volume); free(s->u_temperature); free(s->u_energy); free(s->u_time); free(s->u_length);
    free(s);

@@ -85,6 +85,10 @@ typedef struct ddcmi_setup
    uint64_t *rest_gid;
    int *rest_fc;
    double *rest_r0, *rest_kb;
+   /* RESIDUE types: distance constraints (CONSLISTPARMS/CONSPARMS, bioMMFF.c:64-104): pairs of residue r are
+    * [cons_off[r], cons_off[r+1]); cons_grp = the constraint list (group) of the pair inside its residue */
+   int *cons_off, *consI, *consJ, *cons_grp;
+   double *cons_r0;
 } ddcmi_setup;
 
 /* Load a deck.  object_file is required; restart_file may be NULL (then

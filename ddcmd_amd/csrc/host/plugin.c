@@ -158,23 +158,95 @@ void martiniHIP(SYSTEM *sys, void *parms, ETYPE *e)
    e->virial.xy += vir[DDCMI_XY]; e->virial.xz += vir[DDCMI_XZ]; e->virial.yz += vir[DDCMI_YZ];
 }
 
+/* nglfconstraint_parms (nglfconstraint.c:86-120) for the device: the constraint groups of every
+ * residue instance (genConstraint, bioMartini.c:300-445: one group per CONSLISTPARMS, pairs in deck
+ * order) and the molecule lists the barostat's molecular virial runs over (molecularPressure.c:23-56) */
+static void nglfconstraintHIP_parms(ddcmi_ctx *ctx, const ddcmi_setup *s)
+{
+   const uint64_t molResMask = 0xffffffffffff0000ull, molMask = 0xffffffff00000000ull;
+   int n = s->natoms;
+   gid_order *ord = malloc(sizeof(gid_order) * (n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) { ord[i].id = i; ord[i].gid = s->gid[i]; }
+   qsort(ord, n, sizeof(gid_order), cmp_gid);
+   if (s->nresicons > 0 && s->cons_off && s->cons_off[s->nresi] > 0)
+   {
+      size_t ng = 0, np = 0;
+      for (int pass = 0; pass < 2; pass++)
+      {
+         int *poff = NULL, *pi = NULL, *pj = NULL; double *dd = NULL;
+         if (pass == 1)
+         {
+            poff = malloc(sizeof(int) * (ng + 1)); pi = malloc(sizeof(int) * (np + 1)); pj = malloc(sizeof(int) * (np + 1)); dd = malloc(sizeof(double) * (np + 1));
+            ng = np = 0;
+         }
+         for (int first = 0; first < n;)
+         {
+            uint64_t key = ord[first].gid & molResMask;
+            int last = first;
+            while (last < n && (ord[last].gid & molResMask) == key) last++;
+            int rt = s->resitype[s->species[ord[first].id]];
+            if (last - first != s->resi_natoms[rt]) die("nglfconstraint_parms", "incomplete residue in the particle set");
+            for (int c0 = s->cons_off[rt]; c0 < s->cons_off[rt + 1];)
+            {
+               int c1 = c0;
+               while (c1 < s->cons_off[rt + 1] && s->cons_grp[c1] == s->cons_grp[c0]) c1++;
+               if (pass == 1)
+               {
+                  poff[ng] = (int)np;
+                  for (int c = c0; c < c1; c++) { pi[np + c - c0] = ord[first + s->consI[c]].id; pj[np + c - c0] = ord[first + s->consJ[c]].id; dd[np + c - c0] = s->cons_r0[c]; }
+               }
+               ng++; np += c1 - c0;
+               c0 = c1;
+            }
+            first = last;
+         }
+         if (pass == 1)
+         {
+            poff[ng] = (int)np;
+            if (ddcmi_set_constraints(ctx, (int)ng, poff, pi, pj, dd) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+            free(poff); free(pi); free(pj); free(dd);
+         }
+      }
+   }
+   if (s->npt_beta > 0.0)
+   {
+      long nmol = 0; int nmulti = 0, natm = 0;
+      for (int first = 0; first < n;)
+      {
+         int last = first;
+         while (last < n && (ord[last].gid & molMask) == (ord[first].gid & molMask)) last++;
+         nmol++;
+         if (last - first >= 2) { nmulti++; natm += last - first; }
+         first = last;
+      }
+      int *moff = malloc(sizeof(int) * (nmulti + 1)), *matm = malloc(sizeof(int) * (natm + 1));
+      nmulti = natm = 0;
+      for (int first = 0; first < n;)
+      {
+         int last = first;
+         while (last < n && (ord[last].gid & molMask) == (ord[first].gid & molMask)) last++;
+         if (last - first >= 2) { moff[nmulti++] = natm; for (int k = first; k < last; k++) matm[natm++] = ord[k].id; }
+         first = last;
+      }
+      moff[nmulti] = natm;
+      if (ddcmi_set_barostat(ctx, s->npt_T, s->npt_P0, s->npt_beta, s->npt_tau) != DDCMI_OK ||
+          ddcmi_set_molecule_lists(ctx, nmol, nmulti, moff, matm) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+      free(moff); free(matm);
+   }
+   free(ord);
+}
+
 /* integrator_init, integrator.c:37-167 */
 INTEGRATOR *integrator_init(void *parent, const char *name, const char *type)
 {
    INTEGRATOR *in = calloc(1, sizeof(INTEGRATOR));
    in->name = strdup(name); in->type = strdup(type); in->parent = parent;
    const ddcmi_setup *su = parent ? ((SIMULATE *)parent)->setup : NULL;
-   const int npt_ok = su && strcmp(type, "NGLFCONSTRAINT") == 0 && su->nConstraints == 0 && su->nresicons == 0;
-   if (strcmp(type, "NGLFCONSTRAINT") == 0 && !npt_ok)
-      die("integrator_init", "INTEGRATOR type NGLFCONSTRAINT is on this path only for systems without constraints (nglfconstraint.c's velocity constraint solver is not built)");
+   const int npt_ok = su && strcmp(type, "NGLFCONSTRAINT") == 0;
    if (npt_ok || strcmp(type, "NGLF") == 0 || strcmp(type, "NVTGLF") == 0 || strcmp(type, "NGLFGPU") == 0 || strcmp(type, "NGLFHIP") == 0)
    {
-      /* NGLFCONSTRAINT without constraints = nglf + the barostat of changeVolume (nglfconstraint.c:64-84,527-536) */
-      if (npt_ok)
-      {
-         ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
-         if (ddcmi_set_barostat(ctx, su->npt_T, su->npt_P0, su->npt_beta, su->npt_tau) != DDCMI_OK) die("integrator_init", ddcmi_last_error(ctx));
-      }
+      /* NGLFCONSTRAINT = nglf + velocity constraints + the barostat of changeVolume (nglfconstraint.c:510-574) */
+      if (npt_ok) nglfconstraintHIP_parms(accelerator_getAccelerator(NULL)->parms, su);
       in->eval_integrator = (void (*)(void *, void *, void *))nglfHIP;
       in->uses_gpu = 1;                                    /* state stays on the device between print steps (masters.c:389-403) */
    }

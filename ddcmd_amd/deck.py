@@ -54,6 +54,9 @@ class Setup(object):
         self.angle_k = self.angle_t0 = np.zeros(0)
         self.torsI = self.torsJ = self.torsK = self.torsL = self.tors_func = self.tors_n = np.zeros(0, np.int32)
         self.tors_k = self.tors_delta = np.zeros(0)
+        self.cons_off = np.zeros(1, np.int32)       # distance constraints per residue type (CONSLISTPARMS)
+        self.consI = self.consJ = self.cons_grp = np.zeros(0, np.int32)
+        self.cons_r0 = np.zeros(0)
         self.ngroup = 0
         self.group_name = []
         self.group_type = self.group_interval = np.zeros(0, np.int32)
@@ -147,6 +150,11 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
             setattr(s, k, _arr(getattr(c, k), ntor, np.int32))
         for k in ("tors_k", "tors_delta"):
             setattr(s, k, _arr(getattr(c, k), ntor, np.float64))
+        s.cons_off = _arr(c.cons_off, nr + 1, np.int32)
+        ncons = int(s.cons_off[-1]) if nr > 0 else 0
+        for k in ("consI", "consJ", "cons_grp"):
+            setattr(s, k, _arr(getattr(c, k), ncons, np.int32))
+        s.cons_r0 = _arr(c.cons_r0, ncons, np.float64)
         ng = c.ngroup
         s.group_name = [c.group_name[i].decode() for i in range(ng)]
         s.group_type = _arr(c.group_type, ng, np.int32)

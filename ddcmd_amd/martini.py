@@ -52,6 +52,10 @@ def _declare(lib):
     lib.ddcmi_set_random.argtypes = [vp, ctypes.c_uint64]
     lib.ddcmi_set_barostat.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     lib.ddcmi_get_box.argtypes = [vp, _dp]
+    lib.ddcmi_get_barostat_pressure.argtypes = [vp, _dp]
+    lib.ddcmi_set_molecule_lists.argtypes = [vp, ctypes.c_long, ctypes.c_int, _ip, _ip]
+    lib.ddcmi_set_constraints.argtypes = [vp, ctypes.c_int, _ip, _ip, _ip, _dp]
+    lib.ddcmi_constraint_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     lib.ddcmi_set_restraints.argtypes = [vp, ctypes.c_int, _up, _ip, _dp, _dp, ctypes.c_int]
     lib.ddcmi_get_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp]
     lib.ddcmi_upload_state.argtypes = [vp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _up, _ip, _ip]
@@ -136,10 +140,60 @@ def expand_bonded_terms(s):
     return out
 
 
+def expand_constraints(s):
+    """Residue-relative constraint lists -> constraint groups over caller-order atom indices.
+
+    One group per CONSLISTPARMS of every residue instance (genConstraint, bioMartini.c:300-445),
+    pairs in deck order.  Returns (pair_off, pairI, pairJ, dist)."""
+    n = s.natoms
+    cons_off = np.asarray(getattr(s, "cons_off", np.zeros(1, np.int32)))
+    if s.nresi == 0 or cons_off[-1] == 0:
+        return np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)
+    order = np.argsort(s.gid, kind="stable")
+    key = s.gid[order] & _MOLRES
+    first = np.flatnonzero(np.concatenate(([True], key[1:] != key[:-1])))
+    cnt = np.diff(np.concatenate((first, [n])))
+    rt = s.resitype[s.species[order[first]]]
+    if np.any(cnt != s.resi_natoms[rt]):
+        raise DdcmiError("incomplete residue in the particle set")
+    counts, pi, pj, dd = [], [], [], []
+    for r in range(s.nresi):
+        starts = first[rt == r]
+        if starts.size == 0 or cons_off[r + 1] == cons_off[r]:
+            continue
+        sl = np.arange(cons_off[r], cons_off[r + 1])
+        grp = s.cons_grp[sl]
+        for c in dict.fromkeys(grp.tolist()):
+            k = sl[grp == c]
+            I = order[starts[:, None] + s.consI[k][None, :]]
+            J = order[starts[:, None] + s.consJ[k][None, :]]
+            pi.append(I.ravel()); pj.append(J.ravel())
+            dd.append(np.tile(s.cons_r0[k], starts.size))
+            counts.append(np.full(starts.size, k.size, np.int64))
+    counts = np.concatenate(counts)
+    pair_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+    return (pair_off, np.ascontiguousarray(np.concatenate(pi), dtype=np.int32), np.ascontiguousarray(np.concatenate(pj), dtype=np.int32),
+            np.ascontiguousarray(np.concatenate(dd), dtype=np.float64))
+
+
+def molecule_lists(s):
+    """Molecules = runs of equal gid & molMask.  Returns (nmol_total, mol_off, mol_atoms) with only the
+    molecules of two or more beads listed (caller-order atom indices)."""
+    n = s.natoms
+    order = np.argsort(s.gid, kind="stable")
+    key = np.asarray(s.gid, dtype=np.uint64)[order] >> np.uint64(32)
+    first = np.flatnonzero(np.concatenate(([True], key[1:] != key[:-1])))
+    cnt = np.diff(np.concatenate((first, [n])))
+    multi = cnt >= 2
+    sel = np.repeat(multi, cnt)
+    mol_off = np.concatenate(([0], np.cumsum(cnt[multi]))).astype(np.int32)
+    return int(first.size), mol_off, np.ascontiguousarray(order[sel], dtype=np.int32)
+
+
 class MartiniHIP(object):
     """One device context running the Martini hot path for a Setup."""
 
-    def __init__(self, setup, device=0, upload=True, bonded_by_gid=False):
+    def __init__(self, setup, device=0, upload=True, bonded_by_gid=False, constraints=False):
         self.lib = _lib.load_library()
         _declare(self.lib)
         self.s = setup
@@ -182,8 +236,12 @@ class MartiniHIP(object):
         gt = i32(np.where(np.isin(np.asarray(s.group_type), (1, 2)), np.asarray(s.group_type), 0))     # FREE / BERENDSEN / LANGEVIN
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
         self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
-        if float(getattr(s, "npt_beta", 0.0)) > 0.0:      # INTEGRATOR type=NGLFCONSTRAINT (no constraints): barostat
-            self._chk(self.lib.ddcmi_set_barostat(self.ctx, float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau)))
+        if float(getattr(s, "npt_beta", 0.0)) > 0.0:      # INTEGRATOR type=NGLFCONSTRAINT: barostat on the molecular pressure
+            self.set_barostat(float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau))
+        if constraints:                                   # INTEGRATOR type=NGLFCONSTRAINT: velocity constraints
+            self._cons = expand_constraints(s)
+            po, pi, pj, dd = self._cons
+            self._chk(self.lib.ddcmi_set_constraints(self.ctx, int(po.size - 1), _i(po), _i(pi), _i(pj), _d(dd)))
         nrest = int(getattr(s, "nrest", 0))
         if nrest > 0:     # RESTRAINT potential
             self._rest = (np.ascontiguousarray(s.rest_gid, dtype=np.uint64), i32(np.asarray(s.rest_fc).ravel()),
@@ -245,6 +303,22 @@ class MartiniHIP(object):
         rk = ctypes.c_double(0)
         self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
         return rk.value, t
+
+    def set_barostat(self, T, P0, beta, tau):
+        """nglfconstraint's Berendsen barostat; the molecule lists feed its molecular virial"""
+        self._chk(self.lib.ddcmi_set_barostat(self.ctx, float(T), float(P0), float(beta), float(tau)))
+        nmol, off, atoms = self._mols = molecule_lists(self.s)
+        self._chk(self.lib.ddcmi_set_molecule_lists(self.ctx, nmol, int(off.size - 1), _i(off), _i(atoms if atoms.size else np.zeros(1, np.int32))))
+
+    def constraint_stats(self, reset=True):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        self._chk(self.lib.ddcmi_constraint_stats(self.ctx, ctypes.byref(a), ctypes.byref(b), int(reset)))
+        return a.value, b.value
+
+    def barostat_pressure(self):
+        p = np.zeros(3)
+        self._chk(self.lib.ddcmi_get_barostat_pressure(self.ctx, _d(p)))
+        return p
 
     def box(self):
         h = np.zeros(9)

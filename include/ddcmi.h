@@ -102,14 +102,30 @@ int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);
  * (kB = 1).  The Langevin noise is a counter-based normal stream keyed by (seed, gid, loop): the
  * reference's per-particle LCG64 states are not reproduced -- statistical parity only. */
 int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval);
-/* INTEGRATOR type=NGLFCONSTRAINT without constraints (nglfconstraint.c:510-574): NGLF plus a
- * semi-isotropic Berendsen barostat (changeVolume, :64-84) driven by the molecular pressure of the last
- * force evaluation at the target temperature T: lambda_xy = cbrt(1 + beta dt/tau (Pxx+Pyy)/2 - ...),
- * box and positions scaled before the FRONT kick.  beta = 0 switches it off.  Single domain,
- * single-bead molecules (molecular = atomic virial); costs one host round trip per step.  Internal units. */
+/* INTEGRATOR type=NGLFCONSTRAINT (nglfconstraint.c:510-574): NGLF plus a semi-isotropic Berendsen
+ * barostat (changeVolume, :64-84) driven by the molecular pressure of the last force evaluation at the
+ * target temperature T: lambda_xy = cbrt(1 + beta dt/tau ((Pxx+Pyy)/2 - P0)), lambda_z likewise from Pzz;
+ * box and positions scaled before the FRONT kick.  beta = 0 switches it off.  One domain; costs one host
+ * round trip per step.  Without ddcmi_set_molecule_lists every bead is its own molecule.  Internal units. */
 int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau);
 /* current box (it changes under the barostat) */
 int ddcmi_get_box(const ddcmi_ctx *ctx, double h[9]);
+/* the molecular pressure (xx, yy, zz; molecularPressure.c:57-67) the barostat acted on in the last step */
+int ddcmi_get_barostat_pressure(const ddcmi_ctx *ctx, double p[3]);
+/* Molecules for the barostat's molecular virial (molecularVirial, molecularPressure.c:23-56):
+ * nmol_total = N in the N kB T term; the nmulti molecules of two or more beads are listed as caller-order
+ * atom indices, molecule m = mol_atoms[mol_off[m] .. mol_off[m+1]).  One domain. */
+int ddcmi_set_molecule_lists(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const int *mol_atoms);
+/* nglfconstraint's velocity constraints (velocityConstraintOld/resMoveConsOld, nglfconstraint.c:180-264,
+ * 438-455; groups from genConstraint, bioMartini.c:300-445).  Group g holds the pairs
+ * [pair_off[g], pair_off[g+1]) in the order the reference sweeps them; pairI/pairJ are caller-order atom
+ * indices, dist the constrained lengths (internal units).  Groups must not share atoms.  With groups set,
+ * every step runs FRONT kick -> constraint ((r + dt v)^2 = d^2) -> drift -> forces -> BACK kick ->
+ * constraint (r.v = 0) -> kinetic terms.  Gauss-Seidel sweeps to |rvab dt| < 1e-12, at most 500, as the
+ * reference.  The constraint virial is not booked (the reference computes and drops it).  One domain. */
+int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const int *pairI, const int *pairJ, const double *dist);
+/* largest sweep count of any group since the last reset, and how many group solves hit the 500-sweep cap */
+int ddcmi_constraint_stats(ddcmi_ctx *ctx, int *max_sweeps, int *unconverged, int reset);
 /* RANDOM seed (random.c:44-60) for the Langevin noise */
 int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed);
 /* SIMULATE loop/time (simulate.c:146,155) */

@@ -822,6 +822,8 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
       double a = (0.5 * dt) / mass;
       vx[k] += a * fx[k]; vy[k] += a * fy[k]; vz[k] += a * fz[k];
    }
+   /* nglfconstraint.c:545 velocityConstraintOld(FRONT_TIMESTEP) */
+   if (p->cons_off) orc_velocity_constraint(p, n, dt, 0, rx, ry, rz, vx, vy, vz, gid, species);
    /* :80-87 drift */
    for (int k = 0; k < n; k++) { rx[k] += dt * vx[k]; ry[k] += dt * vy[k]; rz[k] += dt * vz[k]; }
    /* :90 backInBox_fast */
@@ -854,9 +856,130 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
       double a = (0.5 * dt) / mass;
       vx[k] += a * fx[k]; vy[k] += a * fy[k]; vz[k] += a * fz[k];
    }
+   /* nglfconstraint.c:569 velocityConstraintOld(BACK_TIMESTEP) */
+   if (p->cons_off) orc_velocity_constraint(p, n, dt, 1, rx, ry, rz, vx, vy, vz, gid, species);
    /* :105 kinetic_terms */
    orc_kinetic(p, n, vx, vy, vz, species, rk, tion);
    /* :108 group->Update(FRONT_TIMESTEP) */
    for (int g = 0; g < ngroup; g++)
       if (groups[g].type == 1) berendsen_Update(&groups[g], *loop, 0.5 * dt);
+}
+
+/* ------------------------------------------------------------------ */
+/* nglfconstraint: velocity constraints and the molecular-pressure barostat */
+int orc_velocity_constraint(const orc_params *p, int n, double dt, int location,
+                            const double *rx, const double *ry, const double *rz, double *vx, double *vy, double *vz,
+                            const uint64_t *gid, const int *species)
+{
+   const double tol = 1.0e-12;
+   const int maxit = 500;
+   int worst = 0;
+   if (!p->cons_off || p->nresi <= 0 || p->cons_off[p->nresi] == 0) return 0;
+   gid_order *ord = malloc(sizeof(gid_order) * (n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) { ord[i].id = i; ord[i].gid = gid[i]; }
+   qsort(ord, n, sizeof(gid_order), cmp_gid);
+   for (int first = 0; first < n;)
+   {
+      /* residue runs as charmmResidues cuts them (bioCharmmCovalent.c:48-93) */
+      uint64_t key = ord[first].gid & molResMask;
+      int last = first;
+      while (last < n && (ord[last].gid & molResMask) == key) last++;
+      int rt = p->resitype[species[ord[first].id]];
+      int c0 = p->cons_off[rt], c1 = p->cons_off[rt + 1];
+      for (int g0 = c0; g0 < c1;)
+      {
+         /* one CONSTRAINT = the pairs of one constraint list, in deck order */
+         int g1 = g0;
+         while (g1 < c1 && p->cons_grp[g1] == p->cons_grp[g0]) g1++;
+         int np = g1 - g0;
+         vec3 *rab = malloc(sizeof(vec3) * np);
+         for (int ab = 0; ab < np; ab++)
+         {
+            int a = ord[first + p->consI[g0 + ab]].id, b = ord[first + p->consJ[g0 + ab]].id;
+            rab[ab].x = rx[a] - rx[b]; rab[ab].y = ry[a] - ry[b]; rab[ab].z = rz[a] - rz[b];
+            nearestImage(p, &rab[ab].x, &rab[ab].y, &rab[ab].z);
+         }
+         int it = 0;
+         for (; it < maxit; it++)
+         {
+            double errMax = 0.0;
+            for (int ab = 0; ab < np; ab++)
+            {
+               int a = ord[first + p->consI[g0 + ab]].id, b = ord[first + p->consJ[g0 + ab]].id;
+               double dist2 = p->cons_r0[g0 + ab] * p->cons_r0[g0 + ab];
+               double vabx = vx[a] - vx[b], vaby = vy[a] - vy[b], vabz = vz[a] - vz[b];
+               double rma = 1.0 / p->mass[species[a]], rmb = 1.0 / p->mass[species[b]];
+               double rvab;
+               if (location == 0)
+               {
+                  double px = rab[ab].x + dt * vabx, py = rab[ab].y + dt * vaby, pz = rab[ab].z + dt * vabz;
+                  rvab = (px * px + py * py + pz * pz - dist2) / (2 * dt);
+               }
+               else rvab = rab[ab].x * vabx + rab[ab].y * vaby + rab[ab].z * vabz;
+               rvab /= dist2;
+               double gab = -rvab / (rma + rmb);
+               double err = fabs(rvab * dt);
+               if (err > errMax) errMax = err;
+               vx[a] += (rma * gab) * rab[ab].x; vy[a] += (rma * gab) * rab[ab].y; vz[a] += (rma * gab) * rab[ab].z;
+               vx[b] -= (rmb * gab) * rab[ab].x; vy[b] -= (rmb * gab) * rab[ab].y; vz[b] -= (rmb * gab) * rab[ab].z;
+            }
+            if (errMax < tol) break;
+         }
+         if (it + 1 > worst) worst = it + 1;
+         free(rab);
+         g0 = g1;
+      }
+      first = last;
+   }
+   free(ord);
+   return worst;
+}
+
+void orc_barostat_mol(orc_params *p, int n, double *rx, double *ry, double *rz,
+                      const double *fx, const double *fy, const double *fz, const uint64_t *gid, const int *species,
+                      const double virial[6], double T, double P0, double beta, double tau, double dt, double pmol[3])
+{
+   double v[3] = {virial[0], virial[1], virial[2]};
+   gid_order *ord = malloc(sizeof(gid_order) * (n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) { ord[i].id = i; ord[i].gid = gid[i]; }
+   qsort(ord, n, sizeof(gid_order), cmp_gid);
+   long nmol = 0;
+   for (int first = 0; first < n;)
+   {
+      uint64_t key = ord[first].gid & molMask;
+      int last = first;
+      while (last < n && (ord[last].gid & molMask) == key) last++;
+      int i0 = ord[first].id, na = last - first;
+      double M = 0.0, R[3] = {0, 0, 0};
+      vec3 *d = malloc(sizeof(vec3) * na);
+      for (int a = 0; a < na; a++)
+      {
+         int i = ord[first + a].id;
+         double mass = p->mass[species[i]];
+         d[a].x = rx[i] - rx[i0]; d[a].y = ry[i] - ry[i0]; d[a].z = rz[i] - rz[i0];
+         nearestImage(p, &d[a].x, &d[a].y, &d[a].z);
+         R[0] += mass * d[a].x; R[1] += mass * d[a].y; R[2] += mass * d[a].z;
+         M += mass;
+      }
+      R[0] /= M; R[1] /= M; R[2] /= M;
+      for (int a = 0; a < na; a++)
+      {
+         int i = ord[first + a].id;
+         v[0] -= (d[a].x - R[0]) * fx[i]; v[1] -= (d[a].y - R[1]) * fy[i]; v[2] -= (d[a].z - R[2]) * fz[i];
+      }
+      free(d);
+      nmol++;
+      first = last;
+   }
+   free(ord);
+   double vol = p->hxx * p->hyy * p->hzz, NkT = (double)nmol * T;
+   double pxx = (v[0] + NkT) / vol, pyy = (v[1] + NkT) / vol, pzz = (v[2] + NkT) / vol;
+   if (pmol) { pmol[0] = pxx; pmol[1] = pyy; pmol[2] = pzz; }
+   pxx -= P0; pyy -= P0; pzz -= P0;
+   double btt = beta * dt / tau;
+   double Pxx = 0.5 * (pxx + pyy);
+   double l[3] = {cbrt(1.0 + Pxx * btt), cbrt(1.0 + Pxx * btt), cbrt(1.0 + pzz * btt)};
+   for (int a = 0; a < 3; a++) if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;
+   p->hxx *= l[0]; p->hyy *= l[1]; p->hzz *= l[2];
+   for (int i = 0; i < n; i++) { rx[i] *= l[0]; ry[i] *= l[1]; rz[i] *= l[2]; }
 }

@@ -76,6 +76,11 @@ typedef struct orc_params
    const double *rest_r0;      /* [3*nrest] x0 y0 z0 as fractions of the box */
    const double *rest_kb;      /* [nrest] */
    int rest_origin;            /* 0: box centred on the origin (x0*L - L/2) */
+   /* distance constraints of nglfconstraint (CONSLISTPARMS/CONSPARMS bioMMFF.c:64-104; groups built by
+    * genConstraint bioMartini.c:300-445): pairs of residue type r are [cons_off[r], cons_off[r+1]),
+    * atom offsets inside the residue, cons_grp = constraint list of the pair.  NULL cons_off: none. */
+   const int *cons_off, *consI, *consJ, *cons_grp;
+   const double *cons_r0;
 } orc_params;
 
 /* energies returned by orc_forces: */
@@ -166,6 +171,22 @@ void orc_back_in_box(const orc_params *p, int n, double *rx, double *ry, double 
  * orc_nglf_step: together they are one nglfconstraint step without constraints. */
 void orc_barostat(orc_params *p, int n, double *rx, double *ry, double *rz, const double virial[6],
                   double T, double P0, double beta, double tau, double dt);
+
+/* velocityConstraintOld + resMoveConsOld (nglfconstraint.c:180-264, 438-455): Gauss-Seidel sweeps over the
+ * pairs of every constraint group until max |rvab dt| < 1e-12 (at most 500 sweeps).  location 0 = FRONT
+ * (frontFunc :122-131: the drifted pair r + dt v has the constrained length), 1 = BACK (backFunc :133-137:
+ * r.v = 0).  Velocities change in place.  Returns the largest sweep count used. */
+int orc_velocity_constraint(const orc_params *p, int n, double dt, int location,
+                            const double *rx, const double *ry, const double *rz, double *vx, double *vy, double *vz,
+                            const uint64_t *gid, const int *species);
+
+/* The barostat for molecules of several beads: molecularVirial (molecularPressure.c:23-56) takes
+ * sum_i (r_i - R_molecule) f_i off the diagonal of the virial (R = centre of mass, images resolved
+ * relative to one atom of the molecule), molecularPressure adds N_molecules kB T; then changeVolume.
+ * f = the forces of the last evaluation.  Molecules are runs of equal gid & molMask. */
+void orc_barostat_mol(orc_params *p, int n, double *rx, double *ry, double *rz,
+                      const double *fx, const double *fy, const double *fz, const uint64_t *gid, const int *species,
+                      const double virial[6], double T, double P0, double beta, double tau, double dt, double pmol[3]);
 
 #ifdef __cplusplus
 }

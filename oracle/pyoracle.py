@@ -33,6 +33,7 @@ class OrcParams(ctypes.Structure):
         ("tors_k", dp), ("tors_delta", dp),
         ("excludePotentialTerm", ctypes.c_int),
         ("nrest", ctypes.c_int), ("rest_gid", up), ("rest_fc", ip), ("rest_r0", dp), ("rest_kb", dp), ("rest_origin", ctypes.c_int),
+        ("cons_off", ip), ("consI", ip), ("consJ", ip), ("cons_grp", ip), ("cons_r0", dp),
     ]
 
 
@@ -80,6 +81,9 @@ def lib(path=None):
                                 ctypes.c_int, ctypes.POINTER(OrcGroup), dp, dp, dp, dp]
     L.orc_group_temperature.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp, ip, ip, ctypes.c_int, ctypes.POINTER(OrcGroup)]
     L.orc_back_in_box.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp]
+    L.orc_velocity_constraint.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, ctypes.c_double, ctypes.c_int, dp, dp, dp, dp, dp, dp, up, ip]
+    L.orc_velocity_constraint.restype = ctypes.c_int
+    L.orc_barostat_mol.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp, dp, dp, dp, up, ip, dp] + [ctypes.c_double] * 5 + [dp]
     _libs[path] = L
     return L
 
@@ -95,7 +99,7 @@ def _i(a):
 class Oracle(object):
     """The reference CPU path on one rank, driven from a ddcmd_amd.Setup."""
 
-    def __init__(self, setup, libpath=None):
+    def __init__(self, setup, libpath=None, constraints=False):
         self.L = lib(libpath)
         s = self.s = setup
         self._keep = {}
@@ -131,6 +135,14 @@ class Oracle(object):
                 a = np.zeros(1, np.int32)
             self._keep[k] = a
             setattr(p, k, _i(a))
+        # distance constraints (nglfconstraint); off unless constraints=True
+        self.constraints = bool(constraints) and int(np.asarray(getattr(s, "cons_off", [0]))[-1]) > 0
+        if self.constraints:
+            for k in ("cons_off", "consI", "consJ", "cons_grp"):
+                self._keep[k] = np.ascontiguousarray(getattr(s, k), dtype=np.int32)
+                setattr(p, k, _i(self._keep[k]))
+            self._keep["cons_r0"] = np.ascontiguousarray(s.cons_r0, dtype=np.float64)
+            p.cons_r0 = _d(self._keep["cons_r0"])
         n = self.n = s.natoms
         self.rx, self.ry, self.rz = (np.array(getattr(s, k), dtype=np.float64) for k in ("rx", "ry", "rz"))
         self.vx, self.vy, self.vz = (np.array(getattr(s, k), dtype=np.float64) for k in ("vx", "vy", "vz"))
@@ -210,15 +222,28 @@ class Oracle(object):
         self.L.orc_group_temperature(ctypes.byref(self.p), self.n, _d(self.vx), _d(self.vy), _d(self.vz),
                                      _i(self.species), _i(self.group), self.s.ngroup, self.groups)
 
-    def step_npt(self, nsteps, T, P0, beta, tau, dt=None):
+    def step_npt(self, nsteps, T, P0, beta, tau, dt=None, molecular=False):
         """nglfconstraint without constraints: barostat (from the last virial) + nglf, per step"""
         dt = self.s.dt if dt is None else dt
         out = None
         for _ in range(nsteps):
-            self.L.orc_barostat(ctypes.byref(self.p), self.n, _d(self.rx), _d(self.ry), _d(self.rz), _d(self.virial),
-                                ctypes.c_double(T), ctypes.c_double(P0), ctypes.c_double(beta), ctypes.c_double(tau), ctypes.c_double(dt))
+            if molecular:
+                pm = np.zeros(3)
+                self.L.orc_barostat_mol(ctypes.byref(self.p), self.n, _d(self.rx), _d(self.ry), _d(self.rz),
+                                        _d(self.fx), _d(self.fy), _d(self.fz), self.gid.ctypes.data_as(up), _i(self.species), _d(self.virial),
+                                        ctypes.c_double(T), ctypes.c_double(P0), ctypes.c_double(beta), ctypes.c_double(tau), ctypes.c_double(dt), _d(pm))
+                self.pmol = pm
+            else:
+                self.L.orc_barostat(ctypes.byref(self.p), self.n, _d(self.rx), _d(self.ry), _d(self.rz), _d(self.virial),
+                                    ctypes.c_double(T), ctypes.c_double(P0), ctypes.c_double(beta), ctypes.c_double(tau), ctypes.c_double(dt))
             out = self.step(1, dt)
         return out
+
+    def constraint_sweep(self, location, dt=None):
+        """one velocityConstraintOld call on the current state; returns the largest sweep count"""
+        dt = self.s.dt if dt is None else dt
+        return self.L.orc_velocity_constraint(ctypes.byref(self.p), self.n, ctypes.c_double(dt), int(location), _d(self.rx), _d(self.ry), _d(self.rz),
+                                              _d(self.vx), _d(self.vy), _d(self.vz), self.gid.ctypes.data_as(up), _i(self.species))
 
     @property
     def box(self):

@@ -47,11 +47,6 @@ def test_ddcmi_md_rejects_unsupported_integrator(tmp_path):
     out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d"), "-x", "nglf INTEGRATOR {type = NGLFRATTLE;}"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "NGLFRATTLE" in out.stderr
-    # NGLFCONSTRAINT is accepted only without constraints; with the barostat only for single-bead molecules
-    out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d2"), "-x",
-                          "nglf INTEGRATOR {type = NGLFCONSTRAINT; beta = 3.0e-4 1/bar; tauBarostat = 1 ps;}"],
-                         capture_output=True, text=True, timeout=120)
-    assert out.returncode != 0 and "single-bead" in out.stderr
 
 
 def test_ddcmi_md_checkpoint_restart(tmp_path):
@@ -159,3 +154,39 @@ def test_ddcmi_md_runs_example_style_deck(tmp_path):
         if k + 1 < len(rows):
             e, vir, rk, tion = o.step_npt(s.printrate, s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau)
     assert abs(rows[-1, 8] - rows[0, 8]) > 1e-6           # the barostat moved the box
+
+
+def test_ddcmi_md_nglfconstraint_with_constraint_lists(tmp_path):
+    """the driver with INTEGRATOR type=NGLFCONSTRAINT on a deck whose residues carry constraint lists and
+    the barostat switched on: the run follows the oracle's nglfconstraint steps (velocity constraints +
+    molecular-pressure barostat), and the temperature column uses 3N - nConstraints"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle import CONSTRAINT_X
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+    extra = (CONSTRAINT_X + " nglf INTEGRATOR {type = NGLFCONSTRAINT; T = 310 K; P0 = 1 bar; beta = 6.0e-3 1/bar; tauBarostat = 1 ps;}"
+             " simulate SIMULATE { printrate = 10; } system SYSTEM { nConstraints = 1000; }")
+    restart = os.path.join(deck, "relaxed", "restart")
+    data = str(tmp_path / "data")
+    out = subprocess.run([EXE, "-o", os.path.join(deck, "object_nvt.data"), "-r", restart, "-d", data, "-x", extra],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    rows = np.loadtxt(data, comments="#", ndmin=2)
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=restart, extra_objects=extra)
+    assert s.integrator_type == "NGLFCONSTRAINT" and s.nConstraints == 1000 and s.nresicons == 5
+    assert rows.shape[0] == 3
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    o.group_temperature()          # eval_energyInfo at the print steps refreshes the Berendsen group's temperature
+    n = s.natoms
+    cE, cT = units_convert(1, None, "kJ/mol"), units_convert(1, None, "K")
+    for k in (1, 2):
+        e, vir, rk, tion = o.step_npt(10, s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau, molecular=True)
+        o.group_temperature()
+        info = o.energy_info(e["total"], rk, vir, tion)
+        row = rows[k]
+        assert int(row[0]) == 10 * k
+        assert abs(row[3] - cE * rk / n) < 1e-6 * abs(row[3]) + 1e-9, k
+        assert abs(row[4] - cE * e["total"] / n) < 1e-6 * abs(row[4]) + 1e-9, k
+        assert abs(row[5] - cT * info["temperature"]) < 1e-6 * row[5], k
+        assert info["temperature"] > 2.0 * rk / (3.0 * n)          # 3N - nConstraints degrees of freedom

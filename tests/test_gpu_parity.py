@@ -450,3 +450,95 @@ def test_nglfconstraint_barostat_matches_oracle():
     assert np.abs(m.box() - L0).max() > 1e-4 * L0.max()          # the box really changed
     assert abs(m.box()[0] / L0[0] - m.box()[1] / L0[1]) < 1e-14  # semi-isotropic: x and y together
     m.close()
+
+
+def _relaxed_lipid(extra=None):
+    import os
+    from ddcmd_amd.deck import load_deck
+    deck = os.path.join(os.path.dirname(LIPID_DECK))
+    return load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=extra)
+
+
+def test_velocity_constraints_match_oracle():
+    """INTEGRATOR type=NGLFCONSTRAINT with constraint lists (nglfconstraint.c:180-264, 510-574): FRONT kick ->
+    constraint -> drift -> forces -> BACK kick -> constraint -> kinetic terms.  Constrained pairs keep their
+    length, the trajectory follows the oracle, batching the steps changes nothing"""
+    from ddcmd_amd.martini import MartiniHIP, expand_constraints
+    from test_oracle import CONSTRAINT_X
+    s = _relaxed_lipid(CONSTRAINT_X)
+    assert s.nresicons == 5
+    po, pi, pj, dd = expand_constraints(s)
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    m = MartiniHIP(s, constraints=True)
+    m.eval_forces()
+    o.group_temperature()
+    m.group_temperatures()
+    box = s.box
+    for block in range(4):
+        eo, vo, rko, tio = o.step(5)
+        m.step(5 if block % 2 else 1)
+        if block % 2 == 0:
+            m.step(4)
+        o.group_temperature()
+        m.group_temperatures()
+        e, vir, rk, tion = m.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko, block
+        assert np.abs(vir - vo).max() < TOL * np.abs(vo).max(), block
+        assert np.abs(tion - tio).max() < TOL * np.abs(tio).max(), block
+        st = m.download()
+        r, v = st["r"], st["v"]
+        d = np.stack([r[c][pi] - r[c][pj] for c in range(3)], axis=1)
+        d -= box * np.rint(d / box)
+        assert np.abs(np.sqrt((d * d).sum(axis=1)) / dd - 1.0).max() < 1e-10, block
+        w = np.stack([v[c][pi] - v[c][pj] for c in range(3)], axis=1)
+        assert np.abs((d * w).sum(axis=1) * s.dt / dd ** 2).max() < 1e-10, block
+        for c, (ro, vo_) in enumerate(((o.rx, o.vx), (o.ry, o.vy), (o.rz, o.vz))):
+            dr = r[c] - ro
+            dr -= box[c] * np.rint(dr / box[c])
+            assert np.abs(dr).max() < 1e-7 * box[c], (block, c)
+            assert np.abs(v[c] - vo_).max() < 1e-6 * np.abs(vo_).max(), (block, c)
+    sweeps, bad = m.constraint_stats()
+    assert bad == 0 and 1 < sweeps < 200
+    m.close()
+
+
+def test_barostat_with_molecular_virial_and_constraints():
+    """the barostat on a system of multi-bead molecules acts on the molecular pressure (molecularVirial,
+    molecularPressure.c:23-56: the intramolecular part of the virial is taken off); with the constraint
+    lists on top this is the full nglfconstraint step"""
+    from ddcmd_amd.martini import MartiniHIP
+    from test_oracle import CONSTRAINT_X
+    s = _relaxed_lipid(CONSTRAINT_X)
+    T = units_convert(310.0, "K")
+    P0 = units_convert(1.0, "bar")
+    beta = units_convert(3.0e-4, "1/bar") * 20.0
+    tau = units_convert(1.0, "ps")
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    m = MartiniHIP(s, constraints=True)
+    m.set_barostat(T, P0, beta, tau)
+    m.eval_forces()
+    o.group_temperature()
+    m.group_temperatures()
+    L0 = m.box().copy()
+    for block in range(3):
+        eo, vo, rko, _ = o.step_npt(5, T, P0, beta, tau, molecular=True)
+        m.step(5 if block % 2 else 2)
+        if block % 2 == 0:
+            m.step(3)
+        o.group_temperature()
+        m.group_temperatures()
+        e, vir, rk, _ = m.energies()
+        assert np.abs(m.barostat_pressure() - o.pmol).max() < 1e-8 * np.abs(o.pmol).max(), block
+        assert np.abs(m.box() - o.box).max() < 1e-10 * o.box.max(), block
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko
+        assert np.abs(vir - vo).max() < TOL * np.abs(vo).max()
+    assert np.abs(m.box() - L0).max() > 1e-5 * L0.max()
+    # the molecular pressure differs from the atomic one: the bonded part of the virial is gone
+    vol = float(np.prod(m.box()))
+    p_atomic = (vir[:3] + s.natoms * T) / vol
+    assert np.abs(p_atomic - m.barostat_pressure()).max() > 0.05 * np.abs(m.barostat_pressure()).max()
+    m.close()

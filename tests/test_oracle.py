@@ -302,3 +302,62 @@ def test_restraint_potential_deck_and_finite_differences():
             fd = -(ep - em) / (2 * h)
             o.forces()
             assert abs((f[i] - f0[i]) - fd) < 1e-7 * max(abs(fd), 1e-6), (r, c)
+
+
+# constraint lists added to the lipid deck's TSTM (a triangle 0-1-2 and the pair 3-4) and DPPC (the glycerol pair)
+# residues; the parmfile's own keys stay, the new constraintList key is added to them
+CONSTRAINT_X = ("TSTM RESIPARMS { constraintList = TSTM_cl0 TSTM_cl1; } "
+                "TSTM_cl0 CONSLISTPARMS { constraintSubList = TSTM_c0 TSTM_c1 TSTM_c2; } "
+                "TSTM_cl1 CONSLISTPARMS { constraintSubList = TSTM_c3; } "
+                "TSTM_c0 CONSPARMS { atomI=0; atomJ=1; func=1; r0=0.40 nm; } "
+                "TSTM_c1 CONSPARMS { atomI=1; atomJ=2; func=1; r0=0.40 nm; } "
+                "TSTM_c2 CONSPARMS { atomI=0; atomJ=2; func=1; r0=0.655 nm; } "
+                "TSTM_c3 CONSPARMS { atomI=3; atomJ=4; func=1; r0=0.40 nm; } "
+                "DPPC RESIPARMS { constraintList = DPPC_cl0; } "
+                "DPPC_cl0 CONSLISTPARMS { constraintSubList = DPPC_c0; } "
+                "DPPC_c0 CONSPARMS { atomI=2; atomJ=3; func=1; r0=0.37 nm; } ")
+
+
+def _constraint_lengths(s, rx, ry, rz, box):
+    from ddcmd_amd.martini import expand_constraints
+    po, pi, pj, dd = expand_constraints(s)
+    d = np.stack((rx[pi] - rx[pj], ry[pi] - ry[pj], rz[pi] - rz[pj]), axis=1)
+    d -= box * np.rint(d / box)
+    return np.sqrt((d * d).sum(axis=1)), dd, (po, pi, pj)
+
+
+def test_velocity_constraints_deck_and_solver():
+    """nglfconstraint's velocity constraints (nglfconstraint.c:180-264): the deck's CONSLISTPARMS/CONSPARMS
+    become one group per list and residue instance; after a step every constrained pair has its length r0
+    (FRONT: |r + dt v| = d) and no relative velocity along the pair (BACK: r.v = 0)"""
+    import os
+    from ddcmd_amd.deck import load_deck, units_convert
+    from ddcmd_amd.martini import expand_constraints
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    # the 310 K restart: bond lengths there are near the constrained lengths (the lattice start is not)
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=CONSTRAINT_X)
+    s0 = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    nd = int(np.sum(s.resitype[s.species] == list(s.resi_natoms).index(12)) // 12)
+    nt = int(np.sum(s.resi_natoms[s.resitype[s.species]] == 5) // 5)
+    assert nd > 0 and nt > 0
+    assert s.nresicons == 5 and int(s.cons_off[-1]) == 5
+    assert abs(s.cons_r0.max() - units_convert(0.655, "nm")) < 1e-12
+    po, pi, pj, dd = expand_constraints(s)
+    assert po.size - 1 == 2 * nt + nd and pi.size == 4 * nt + nd
+    # constrained pairs that are not func-1 bonds join the exclusion (bpair) lists (genMartiniBondPair)
+    assert s.bpair_off[-1] == s0.bpair_off[-1]          # 0-2 is already an exclusion, the rest are bonds
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    box = s.box
+    for step in range(3):
+        o.step(1)
+        L, d0, (po, pi, pj) = _constraint_lengths(s, o.rx, o.ry, o.rz, box)
+        assert np.abs(L / d0 - 1.0).max() < 1e-10, step
+        d = np.stack((o.rx[pi] - o.rx[pj], o.ry[pi] - o.ry[pj], o.rz[pi] - o.rz[pj]), axis=1)
+        d -= box * np.rint(d / box)
+        w = np.stack((o.vx[pi] - o.vx[pj], o.vy[pi] - o.vy[pj], o.vz[pi] - o.vz[pj]), axis=1)
+        assert np.abs((d * w).sum(axis=1) * s.dt / d0 ** 2).max() < 1e-10, step
+    # unconstrained beads are untouched by a sweep; a second BACK sweep is a no-op (one Gauss-Seidel pass)
+    v0 = o.vx.copy()
+    assert o.constraint_sweep(1) == 1
+    assert np.abs(o.vx - v0).max() < 1e-10 * np.abs(v0).max()
