@@ -90,7 +90,14 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # control plane (unique-id broadcast, barriers, max over ranks): torch.distributed over RCCL; the data path's
+        # RCCL communicator is libddcmi's own.  DDCMI_BENCH_CONTROL=gloo moves the control plane to CPU/TCP.
+        control = os.environ.get("DDCMI_BENCH_CONTROL", "nccl")
+        if control == "gloo":
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        ctl_dev = "cpu" if control == "gloo" else "cuda"
 
     import numpy as np
     import ddcmd_amd
@@ -124,11 +131,11 @@ def main():
         # and migration run inside libddcmi over RCCL point-to-point (include/ddcmi.h)
         owner = domain_of(s, grid)
         m = MartiniRank(s, np.flatnonzero(owner == rank), device=local_rank)
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(128, dtype=torch.uint8, device=ctl_dev)
         if rank == 0:
             buf = ctypes.create_string_buffer(128)
             assert m.lib.ddcmi_comm_unique_id(buf) == 0
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(ctl_dev)
         dist.broadcast(uid, src=0)
         m.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()), grid)
         m.upload_local()
@@ -162,7 +169,7 @@ def main():
     nlocal = int(m.lib.ddcmi_nlocal(m.ctx))
     epot, ekin = e["total"], rk
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         tot = m.allreduce([epot, ekin, float(nlocal)])      # energyInfo.c allreduce()

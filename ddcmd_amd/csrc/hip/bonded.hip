@@ -640,6 +640,8 @@ extern "C" int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, 
 int ddcmi_bonded_localize(ddcmi_ctx *ctx)
 {
    if (!ctx->bonded_gid && ctx->nrest == 0) return DDCMI_OK;
+   if (ctx->bonded_gid && ctx->g_nbond + ctx->g_nangle + ctx->g_ntors == 0 && ctx->nrest == 0)
+   { ctx->nbond = ctx->nangle = ctx->ntors = 0; return DDCMI_OK; }      /* water: nothing to locate, no gid table */
    hipStream_t st = ctx->stream;
    const int nall = ctx->nloc + ctx->nhalo;
    unsigned cap = 1024;

@@ -330,9 +330,14 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                                                             const int *bpairI, const int *bpairJ, const unsigned long long *exmask,
                                                             int maxexcl, int *excl, int *excl_cnt, int *flags, unsigned long long *totals)
 {
-   extern __shared__ double2 smem[];
-   double2 *A_s = smem, *B_s = smem + ta.cap;
-   int *ofs_s = (int *)(smem + 2 * (size_t)ta.cap);      /* [NRC+1] staged offset of each region cell */
+   /* LDS image of the neighbourhood: positions relative to the tile centre in single precision + the
+    * low tag word (16 B per bead, one ds_read_b128 per candidate) and the molecule ids (4 B).  The
+    * list criterion stays the reference's double-precision r^2 < rlist^2: candidates within 1e-4
+    * (relative) of the boundary are re-tested from the double positions in global memory. */
+   extern __shared__ float4 tb_smem[];
+   float4 *P_s = tb_smem;
+   unsigned *M_s = (unsigned *)(tb_smem + ta.cap);
+   int *ofs_s = (int *)(M_s + ta.cap);                     /* [NRC+1] staged offset of each region cell */
    int *gst_s = ofs_s + NRC + 8;                           /* [NRC] global start of each region cell */
    __shared__ int s_w[TB_THREADS / 64];
    int t = blockIdx.x;
@@ -391,6 +396,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    __syncthreads();
    /* phase 1: staging list (global indices) + positions into LDS */
    int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
+   const double ox = gp.lo[0] + (TCX * tx - gp.m[0] + 0.5 * TCX) / gp.cinv[0], oy = gp.lo[1] + (TCY * ty - gp.m[1] + 0.5 * TCY) / gp.cinv[1],
+                oz = gp.lo[2] + (TCZ * tz - gp.m[2] + 0.5 * TCZ) / gp.cinv[2];
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
@@ -400,14 +407,16 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          int gj = g[h] + k;
          sidx[o + k] = gj;
          double4 p = pos[gj];
-         A_s[o + k] = make_double2(p.x, p.y);
-         if (ta.pack_type == 2 && gj >= ta.nloc && ta.halo_shift[gj - ta.nloc] != 13)
-            p.w = __longlong_as_double(__double_as_longlong(p.w) | 8ll);       /* travels into the entry's type nibble */
-         B_s[o + k] = make_double2(p.z, p.w);
+         unsigned long long w = (unsigned long long)__double_as_longlong(p.w);
+         unsigned lo = (unsigned)w;
+         if (ta.pack_type == 2 && gj >= ta.nloc && ta.halo_shift[gj - ta.nloc] != 13) lo |= 8u;       /* travels into the entry's type nibble */
+         P_s[o + k] = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
+         M_s[o + k] = (unsigned)(w >> 32);
       }
    }
    __syncthreads();
    const double rl2 = gp.rlist * gp.rlist;
+   const float rl2_hi = (float)(rl2 * (1.0 + 1.0e-4)), rl2_lo = (float)(rl2 * (1.0 - 1.0e-4));
    const int rows = (nown + 63) & ~63;
    int mymax = 0;
    /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go
@@ -418,6 +427,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    {
       int a = ts + al;
       double4 pi = pos[a];
+      const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
       int cx, cy, cz;
       cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
       int lx = cx - TCX * tx, ly = cy - TCY * ty, lz = cz - TCZ * tz;
@@ -446,21 +456,28 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
             /* four candidates per trip: the LDS reads of a trip are independent (ILP at low occupancy) */
             for (int sj0 = s0; sj0 < s1; sj0 += 4)
             {
-               double2 pa4[4], pb4[4];
+               float4 q4[4];
 #pragma unroll
-               for (int u = 0; u < 4; u++) { int sq = min(sj0 + u, s1 - 1); pa4[u] = A_s[sq]; pb4[u] = B_s[sq]; }
+               for (int u = 0; u < 4; u++) q4[u] = P_s[min(sj0 + u, s1 - 1)];
 #pragma unroll
                for (int u = 0; u < 4; u++)
                {
                   int sj = sj0 + u;
-                  double2 pa = pa4[u], pb = pb4[u];
-                  double x = pi.x - pa.x, y = pi.y - pa.y, z = pi.z - pb.x;
-                  double r2 = x * x + y * y + z * z;
-                  if (sj < s1 && sj != self && r2 < rl2)
+                  const float4 q = q4[u];
+                  float x = fx - q.x, y = fy - q.y, z = fz - q.z;
+                  float r2 = x * x + y * y + z * z;
+                  if (sj < s1 && sj != self && r2 < rl2_hi)
                   {
+                     if (r2 > rl2_lo)
+                     {
+                        /* boundary band: the reference's test on the double positions */
+                        double4 pj = pos[sidx[sj]];
+                        double X = pi.x - pj.x, Y = pi.y - pj.y, Z = pi.z - pj.z;
+                        if (!(X * X + Y * Y + Z * Z < rl2)) continue;
+                     }
                      bool pruned = false;
-                     long long wj = __double_as_longlong(pb.y);
-                     if (nmoltype > 0 && (unsigned)(gi >> 32) == (unsigned)((unsigned long long)wj >> 32))
+                     const unsigned wj = __float_as_uint(q.w);
+                     if (nmoltype > 0 && (unsigned)(gi >> 32) == M_s[sj])
                      {
                         /* same molecule id (the tag holds all 32 bits of gid>>32) */
                         if (mns > 1)
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                         /* scratch word: final-format entry + r^2 as a 16-bit float (enough to pick the
                          * distance shell in k_tile_transpose).  This path runs for
                          * every candidate of the wave (some lane always accepts), so it is kept short. */
-                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | (__float_as_uint((float)r2) & 0xffff0000u);
+                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | (__float_as_uint(r2) & 0xffff0000u);
                         if (cnt & 1) { if (cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, wcur); }
                         else wprev = wcur;
                         cnt++;
@@ -2056,7 +2073,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    for (int attempt = 0;; attempt++)
    {
       if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
-      size_t lds = (size_t)ctx->stage_cap * 32 + (2 * NRC + 16) * sizeof(int);
+      size_t lds = (size_t)ctx->stage_cap * 20 + (2 * NRC + 16) * sizeof(int);
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
