@@ -628,45 +628,41 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta, Shel
          const int cnt = cnt_s[r_own];
          const int per = (cnt + TR_TPR - 1) / TR_TPR;
          const int k0 = min(q_own * per, cnt), k1 = min(k0 + per, cnt);
-         const unsigned int *row = rows_s + r_own * rs;
-         int o[NSHELL];
-#pragma unroll
-         for (int s = 0; s < NSHELL; s++) o[s] = 0;
-         auto shell_of = [&](unsigned wv) -> int
-         {
-            float rf = __builtin_amdgcn_sqrtf(__uint_as_float(wv & 0xffff0000u));
-            return min(max((int)floorf((rf - shc.r0) * shc.inv_w) + 1, 0), NSHELL - 1);
-         };
-         for (int k = k0; k < k1; k++)
-         {
-            int sh = shell_of(row[k]);
-#pragma unroll
-            for (int s = 0; s < NSHELL; s++) o[s] += (sh == s);
-         }
-         /* offsets: shells in order, inside a shell the row's parts in order */
-         int run = 0;
-#pragma unroll
-         for (int s = 0; s < NSHELL; s++)
-         {
-            int inc = o[s];
-#pragma unroll
-            for (int off = 1; off < TR_TPR; off <<= 1)
-            {
-               int v = __shfl_up(inc, off, TR_TPR);
-               if (q_own >= off) inc += v;
-            }
-            int tot = __shfl(inc, TR_TPR - 1, TR_TPR);
-            int mine = o[s];
-            o[s] = run + inc - mine;
-            run += tot;
-         }
+         unsigned int *row = rows_s + r_own * rs;
+         /* counting sort by shell with the eight counters packed as 16-bit fields of two 64-bit words
+          * (a row holds < 65536 entries): one shift and one add per entry instead of eight selects */
+         static_assert(NSHELL == 8, "two words of four 16-bit shell counters");
+         unsigned long long c0w = 0, c1w = 0;
          for (int k = k0; k < k1; k++)
          {
             unsigned wv = row[k];
-            int sh = shell_of(wv);
-            int slot = 0;
+            float rf = __builtin_amdgcn_sqrtf(__uint_as_float(wv & 0xffff0000u));
+            int sh = min(max((int)floorf((rf - shc.r0) * shc.inv_w) + 1, 0), NSHELL - 1);
+            row[k] = (wv & 0xffffu) | ((unsigned)sh << 16);          /* the second pass reads the shell back */
+            unsigned long long one = 1ull << (16 * (sh & 3));
+            if (sh < 4) c0w += one; else c1w += one;
+         }
+         /* offsets: shells in order, inside a shell the row's parts in order */
+         unsigned long long i0 = c0w, i1 = c1w;
 #pragma unroll
-            for (int s = 0; s < NSHELL; s++) { if (sh == s) slot = o[s]; o[s] += (sh == s); }
+         for (int off = 1; off < TR_TPR; off <<= 1)
+         {
+            unsigned long long v0 = __shfl_up(i0, off, TR_TPR), v1 = __shfl_up(i1, off, TR_TPR);
+            if (q_own >= off) { i0 += v0; i1 += v1; }
+         }
+         const unsigned long long t0 = __shfl(i0, TR_TPR - 1, TR_TPR), t1 = __shfl(i1, TR_TPR - 1, TR_TPR);
+         /* field i of (x << 16) + (x << 32) + (x << 48) = sum of the fields below i */
+         const unsigned long long b0 = (t0 << 16) + (t0 << 32) + (t0 << 48);
+         const unsigned long long n03 = ((b0 + t0) >> 48) & 0xffffull;                  /* entries in shells 0..3 */
+         const unsigned long long b1 = n03 * 0x0001000100010001ull + (t1 << 16) + (t1 << 32) + (t1 << 48);
+         unsigned long long s0 = b0 + i0 - c0w, s1 = b1 + i1 - c1w;
+         for (int k = k0; k < k1; k++)
+         {
+            unsigned wv = row[k];
+            int sh = (int)(wv >> 16), sft = 16 * (sh & 3);
+            int slot;
+            if (sh < 4) { slot = (int)((s0 >> sft) & 0xffffull); s0 += 1ull << sft; }
+            else { slot = (int)((s1 >> sft) & 0xffffull); s1 += 1ull << sft; }
             img[slot * IMG_STRIDE + r_own] = (unsigned short)(wv & 0xffffu);
          }
       }
