@@ -16,6 +16,8 @@
  */
 #include "ddcmi_internal.h"
 #include <math.h>
+#include <array>
+#include <map>
 
 #define FLOAT_EPS 1e-08
 #define NEAR_ZERO_ANGLE 0.017453292519943295
@@ -51,21 +53,14 @@ __device__ __forceinline__ void block_store(double (&v)[NV], double *out)
    if (threadIdx.x < NV) out[threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 /* Where a term's atoms and parameters live.
- *   one domain: atoms[] holds caller-order indices, translated through slot[] each
- *     launch (atoms are re-sorted at every rebuild); term t uses parameter row t.  After a rebuild
- *     the lists are replaced by copies in the order of the first atom's device slot, atoms already
- *     translated (ddcmi_bonded_order): neighbouring threads then touch neighbouring beads.
+ *   one domain: the bead-parallel kernel k_bonded_gather is used instead (no TermMap).
  *   decomposed run: atoms[] holds device slots (owned or halo) of the terms this rank
  *     touches, rebuilt with the lists (ddcmi_bonded_localize); tmap[t] = parameter row.
  * A rank adds forces only to the atoms it owns (slot < nloc) and counts a term's
  * energy and virial with weight (atoms it owns)/(atoms of the term): every term is then
  * counted exactly once over all ranks, with no force return traffic. */
 struct TermMap { const int *atoms; const int *slot; const int *tmap; int nloc; };
-__device__ __forceinline__ int term_atom(const TermMap &m, int na, int t, int a)
-{
-   int i = m.atoms[na * t + a];
-   return m.slot ? m.slot[i] : i;
-}
+__device__ __forceinline__ int term_atom(const TermMap &m, int na, int t, int a) { return m.atoms[na * t + a]; }
 __device__ __forceinline__ int term_row(const TermMap &m, int t) { return m.tmap ? m.tmap[t] : t; }
 __device__ __forceinline__ void addf(const TermMap &m, double *fx, double *fy, double *fz, int i, double x, double y, double z)
 {
@@ -80,6 +75,148 @@ __device__ __forceinline__ void weigh(double (&acc)[NV], const TermMap &m, int n
    for (int k = 0; k < NV; k++) acc[k] *= w;
 }
 
+/* resBondSorted (bioCharmmCovalentEnergiesSorted.c:18-116): fD = force on atom I, -fD on J */
+__device__ __forceinline__ void bond_eval(const BoxArgs &box, const double4 &pI, const double4 &pJ, double kb, double b0,
+                                          double &e, double (&fD)[3], double (&vir)[6])
+{
+   double x, y, z;
+   bioVec(box, pI, pJ, x, y, z);
+   /* b = r^2 / sqrt(r^2) and the unit vector by the reciprocal root: no division, no square root */
+   const double r2 = x * x + y * y + z * z, ib = rsqrt_f64(r2), b = r2 * ib;
+   double bDelta = b - b0;
+   e = kb * bDelta * bDelta;
+   double kforce = -2 * kb * bDelta * ib;
+   fD[0] = kforce * x; fD[1] = kforce * y; fD[2] = kforce * z;
+   vir[0] = fD[0] * x; vir[1] = fD[1] * y; vir[2] = fD[2] * z;
+   vir[3] = fD[0] * y; vir[4] = fD[0] * z; vir[5] = fD[1] * z;
+}
+/* resAngleSorted / resAngleCosineSorted / resAngleRestrainSorted (...Sorted.c:118-487): forces on I and K, J gets -(fI+fK).
+ * false: the kind is switched off by excludePotentialTerm */
+template <bool WITH_F1 = true>      /* false: the caller holds no func-1 (acos/sin) angles -- a third fewer registers */
+__device__ __forceinline__ bool angle_eval(const BoxArgs &box, const double4 &pI, const double4 &pJ, const double4 &pK, int f, double kt, double t0, int excl_mask,
+                                           double &e, double (&fI)[3], double (&fK)[3], double (&vir)[6])
+{
+   if ((f == 1 && (excl_mask & 2)) || (f == 2 && (excl_mask & 4)) || (f == 10 && (excl_mask & 256))) return false;
+   double ax, ay, az, cx, cy, cz;
+   bioVec(box, pI, pJ, ax, ay, az);
+   bioVec(box, pK, pJ, cx, cy, cz);
+   /* 1/b_ij, 1/b_kj by reciprocal roots; the unit vectors and coefficients multiply by them */
+   const double ib_ij = rsqrt_f64(ax * ax + ay * ay + az * az), ib_kj = rsqrt_f64(cx * cx + cy * cy + cz * cz);
+   double uix = ax * ib_ij, uiy = ay * ib_ij, uiz = az * ib_ij;
+   double ukx = cx * ib_kj, uky = cy * ib_kj, ukz = cz * ib_kj;
+   double cosT = uix * ukx + uiy * uky + uiz * ukz;
+   double coef_i, coef_k;
+   if (WITH_F1 && f == 1)
+   {
+      double a = acos(cosT);
+      double aDelta = a - t0;
+      e = kt * aDelta * aDelta;
+      double c = 2 * kt * aDelta / sin(a);
+      coef_i = c * ib_ij;
+      coef_k = c * ib_kj;
+   }
+   else if (f == 2)
+   {
+      double aDelta = cosT - t0;
+      e = kt * aDelta * aDelta;
+      coef_i = -2 * kt * aDelta * ib_ij;
+      coef_k = -2 * kt * aDelta * ib_kj;
+   }
+   else
+   {
+      double isin2 = rcp_f64(1 - cosT * cosT);
+      double aDelta = cosT - t0;
+      e = kt * aDelta * aDelta * isin2;
+      double coef_reb = -2 * kt * aDelta * (1 - cosT * t0) * (isin2 * isin2);
+      coef_i = coef_reb * ib_ij;
+      coef_k = coef_reb * ib_kj;
+   }
+   fI[0] = coef_i * (ukx - uix * cosT); fI[1] = coef_i * (uky - uiy * cosT); fI[2] = coef_i * (ukz - uiz * cosT);
+   fK[0] = coef_k * (uix - ukx * cosT); fK[1] = coef_k * (uiy - uky * cosT); fK[2] = coef_k * (uiz - ukz * cosT);
+   vir[0] = fI[0] * ax + fK[0] * cx; vir[1] = fI[1] * ay + fK[1] * cy; vir[2] = fI[2] * az + fK[2] * cz;
+   vir[3] = fI[0] * ay + fK[0] * cy; vir[4] = fI[0] * az + fK[0] * cz; vir[5] = fI[1] * az + fK[1] * cz;
+   return true;
+}
+/* bioDihedralFast (bioCharmmCovalentEnergies.c:266-351) + resTorsionSorted / resImproperSorted (...Sorted.c:577-848):
+ * e_t = proper, e_i = improper energy; forces on I, J, K, L */
+__device__ __forceinline__ bool tors_eval(const BoxArgs &box, const double4 &pI, const double4 &pJ, const double4 &pK, const double4 &pL,
+                                          int f, int n, double kpar, double dpar, int excl_mask,
+                                          double &e_t, double &e_i, double (&fI)[3], double (&fJ)[3], double (&fK)[3], double (&fL)[3], double (&vir)[6])
+{
+   if ((f == 1 && (excl_mask & 16)) || (f == 2 && (excl_mask & 32))) return false;
+   const double eps = 1e-12;
+   double ax, ay, az, bx, by, bz, cx, cy, cz;
+   bioVec(box, pI, pJ, ax, ay, az);
+   bioVec(box, pJ, pK, bx, by, bz);
+   bioVec(box, pK, pL, cx, cy, cz);
+   double a2 = ax * ax + ay * ay + az * az, b2 = bx * bx + by * by + bz * bz, c2 = cx * cx + cy * cy + cz * cz;
+   double ab = ax * bx + ay * by + az * bz, bc = bx * cx + by * cy + bz * cz, ac = ax * cx + ay * cy + az * cz;
+   double ff = ab * bc - ac * b2;
+   double g1 = a2 * b2 - ab * ab + eps;
+   double g2 = b2 * c2 - bc * bc + eps;
+   const double ig1 = rcp_f64(g1), ig2 = rcp_f64(g2);
+   double yy = rsqrt_f64(g1 * g2);
+   double xx = yy * ff;
+   double xab = yy * bc + xx * ig1 * ab;
+   double xbc = yy * ab + xx * ig2 * bc;
+   double xac = -yy * b2;
+   double xaa = -0.5 * xx * b2 * ig1;
+   double xcc = -0.5 * xx * b2 * ig2;
+   double xbb = -yy * ac - 0.5 * xx * (a2 * ig1 + c2 * ig2);
+   double cax = xab * bx + xac * cx + (2 * xaa) * ax, cay = xab * by + xac * cy + (2 * xaa) * ay, caz = xab * bz + xac * cz + (2 * xaa) * az;
+   double cbx = xab * ax + xbc * cx + (2 * xbb) * bx, cby = xab * ay + xbc * cy + (2 * xbb) * by, cbz = xab * az + xbc * cz + (2 * xbb) * bz;
+   double ccx = xbc * bx + xac * ax + (2 * xcc) * cx, ccy = xbc * by + xac * ay + (2 * xcc) * cy, ccz = xbc * bz + xac * az + (2 * xcc) * cz;
+   double mx = ay * bz - az * by, my = az * bx - ax * bz, mz = ax * by - ay * bx;
+   double nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
+   double qx = my * nz - mz * ny, qy = mz * nx - mx * nz, qz = mx * ny - my * nx;
+   double signnum = bx * qx + by * qy + bz * qz;
+   double sign = (signnum < 0.0) ? -1.0 : 1.0;
+   xx = fmax(fmin(xx, 1.0), -1.0);
+   double ang = sign * acos(xx);
+   double sinX = sin(ang);
+   double v0 = -(cax * ax + cbx * bx + ccx * cx), v3 = -(cax * ay + cbx * by + ccx * cy), v4 = -(cax * az + cbx * bz + ccx * cz);
+   double v1 = -(cay * ay + cby * by + ccy * cy), v5 = -(cay * az + cby * bz + ccy * cz), v2 = -(caz * az + cbz * bz + ccz * cz);
+   double kk;
+   e_t = 0.0; e_i = 0.0;
+   if (f == 1)
+   {
+      double kchi = kpar, delta = dpar;
+      e_t = kchi * (1 + cos(n * ang - delta));
+      if (fabs(sinX) > FLOAT_EPS) kk = kchi * n * sin(n * ang - delta) / sinX;
+      else
+      {
+         double nX = n * ang, nX2 = nX * nX, nX4 = nX2 * nX2, nX6 = nX4 * nX2, nX8 = nX4 * nX4, nX10 = nX8 * nX2;
+         double X2 = ang * ang, X4 = X2 * X2, X6 = X4 * X2, X8 = X4 * X4, X10 = X8 * X2;
+         double ratio = n * (1 - nX2 / 6 + nX4 / 120 - nX6 / 5040 + nX8 / 362880 - nX10 / 39916800) /
+                        (1 - X2 / 6 + X4 / 120 - X6 / 5040 + X8 / 362880 - X10 / 39916800);
+         if (delta < NEAR_ZERO_ANGLE) kk = kchi * n * ratio;
+         else if (delta > NEAR_180_ANGLE) kk = -kchi * n * ratio;
+         else kk = kchi * n * ratio;
+      }
+   }
+   else
+   {
+      double kpsi = kpar, psi0 = dpar;
+      double d = ang - psi0;
+      if (d < -M_PI) d += 2 * M_PI; else if (d > M_PI) d -= 2 * M_PI;
+      e_i = kpsi * d * d;
+      double absX = sinX < 0 ? -sinX : sinX;
+      if (absX > FLOAT_EPS) kk = -2 * kpsi * d / sinX;
+      else
+      {
+         double i2 = ang * ang, i4 = i2 * i2, i6 = i4 * i2, i8 = i4 * i4, i10 = i8 * i2;
+         kk = -2 * kpsi / (1 - i2 / 6 + i4 / 120 - i6 / 5040 + i8 / 362880 - i10 / 39916800);
+      }
+   }
+   fI[0] = -cax * kk; fI[1] = -cay * kk; fI[2] = -caz * kk;
+   fJ[0] = -(cbx - cax) * kk; fJ[1] = -(cby - cay) * kk; fJ[2] = -(cbz - caz) * kk;
+   fK[0] = -(ccx - cbx) * kk; fK[1] = -(ccy - cby) * kk; fK[2] = -(ccz - cbz) * kk;
+   fL[0] = ccx * kk; fL[1] = ccy * kk; fL[2] = ccz * kk;
+   vir[0] = v0 * kk; vir[1] = v1 * kk; vir[2] = v2 * kk; vir[3] = v3 * kk; vir[4] = v4 * kk; vir[5] = v5 * kk;
+   return true;
+}
+
+/* term-parallel kernels (decomposed runs): one lane per term, forces by atomic adds */
 __global__ __launch_bounds__(256) void k_bond(int nbond, BoxArgs box, TermMap tm, const double *__restrict__ kb_, const double *__restrict__ b0_,
                                               const double4 *__restrict__ pos,
                                               double *fx, double *fy, double *fz, double *partials)
@@ -90,19 +227,13 @@ __global__ __launch_bounds__(256) void k_bond(int nbond, BoxArgs box, TermMap tm
    {
       int I = term_atom(tm, 2, t, 0), J = term_atom(tm, 2, t, 1);
       const int g = term_row(tm, t);
-      const double kb = kb_[g], b0 = b0_[g];
-      double x, y, z;
-      bioVec(box, pos[I], pos[J], x, y, z);
-      double b = sqrt(x * x + y * y + z * z);
-      double bDelta = b - b0;
-      acc[0] = kb * bDelta * bDelta;
-      double ux = x / b, uy = y / b, uz = z / b;
-      double kforce = -2 * kb * bDelta;
-      double fxD = kforce * ux, fyD = kforce * uy, fzD = kforce * uz;
-      addf(tm, fx, fy, fz, I, fxD, fyD, fzD);
-      addf(tm, fx, fy, fz, J, -fxD, -fyD, -fzD);
-      acc[1] = fxD * x; acc[2] = fyD * y; acc[3] = fzD * z;
-      acc[4] = fxD * y; acc[5] = fxD * z; acc[6] = fyD * z;
+      double e, fD[3], vir[6];
+      bond_eval(box, pos[I], pos[J], kb_[g], b0_[g], e, fD, vir);
+      addf(tm, fx, fy, fz, I, fD[0], fD[1], fD[2]);
+      addf(tm, fx, fy, fz, J, -fD[0], -fD[1], -fD[2]);
+      acc[0] = e;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[1 + k] = vir[k];
       weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc), 2);
    }
    block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
@@ -118,53 +249,16 @@ __global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, TermMap 
    if (t < nangle)
    {
       const int g = term_row(tm, t);
-      int f = func[g];
-      bool skip = (f == 1 && (excl_mask & 2)) || (f == 2 && (excl_mask & 4)) || (f == 10 && (excl_mask & 256));
-      if (!skip)
+      int I = term_atom(tm, 3, t, 0), J = term_atom(tm, 3, t, 1), K = term_atom(tm, 3, t, 2);
+      double e, fI[3], fK[3], vir[6];
+      if (angle_eval(box, pos[I], pos[J], pos[K], func[g], kt_[g], t0_[g], excl_mask, e, fI, fK, vir))
       {
-         int I = term_atom(tm, 3, t, 0), J = term_atom(tm, 3, t, 1), K = term_atom(tm, 3, t, 2);
-         double4 pj = pos[J];
-         double ax, ay, az, cx, cy, cz;
-         bioVec(box, pos[I], pj, ax, ay, az);
-         bioVec(box, pos[K], pj, cx, cy, cz);
-         double b_ij = sqrt(ax * ax + ay * ay + az * az), b_kj = sqrt(cx * cx + cy * cy + cz * cz);
-         double uix = ax / b_ij, uiy = ay / b_ij, uiz = az / b_ij;
-         double ukx = cx / b_kj, uky = cy / b_kj, ukz = cz / b_kj;
-         double cosT = uix * ukx + uiy * uky + uiz * ukz;
-         double kt = kt_[g], t0 = t0_[g];
-         double coef_i, coef_k;
-         if (f == 1)
-         {
-            double a = acos(cosT);
-            double aDelta = a - t0;
-            acc[0] = kt * aDelta * aDelta;
-            double sinabs = sin(a);
-            coef_i = 2 * kt * aDelta / (b_ij * sinabs);
-            coef_k = 2 * kt * aDelta / (b_kj * sinabs);
-         }
-         else if (f == 2)
-         {
-            double aDelta = cosT - t0;
-            acc[0] = kt * aDelta * aDelta;
-            coef_i = -2 * kt * aDelta / b_ij;
-            coef_k = -2 * kt * aDelta / b_kj;
-         }
-         else
-         {
-            double sinAsq = 1 - cosT * cosT;
-            double aDelta = cosT - t0;
-            acc[0] = kt * aDelta * aDelta / sinAsq;
-            double coef_reb = -2 * kt * aDelta * (1 - cosT * t0) / (sinAsq * sinAsq);
-            coef_i = coef_reb / b_ij;
-            coef_k = coef_reb / b_kj;
-         }
-         double fxI = coef_i * (ukx - uix * cosT), fyI = coef_i * (uky - uiy * cosT), fzI = coef_i * (ukz - uiz * cosT);
-         double fxK = coef_k * (uix - ukx * cosT), fyK = coef_k * (uiy - uky * cosT), fzK = coef_k * (uiz - ukz * cosT);
-         addf(tm, fx, fy, fz, I, fxI, fyI, fzI);
-         addf(tm, fx, fy, fz, K, fxK, fyK, fzK);
-         addf(tm, fx, fy, fz, J, -(fxI + fxK), -(fyI + fyK), -(fzI + fzK));
-         acc[1] = fxI * ax + fxK * cx; acc[2] = fyI * ay + fyK * cy; acc[3] = fzI * az + fzK * cz;
-         acc[4] = fxI * ay + fxK * cy; acc[5] = fxI * az + fxK * cz; acc[6] = fyI * az + fyK * cz;
+         addf(tm, fx, fy, fz, I, fI[0], fI[1], fI[2]);
+         addf(tm, fx, fy, fz, K, fK[0], fK[1], fK[2]);
+         addf(tm, fx, fy, fz, J, -(fI[0] + fK[0]), -(fI[1] + fK[1]), -(fI[2] + fK[2]));
+         acc[0] = e;
+#pragma unroll
+         for (int k = 0; k < 6; k++) acc[1 + k] = vir[k];
          weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc) + (K < tm.nloc), 3);
       }
    }
@@ -181,85 +275,162 @@ __global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, TermMap
    if (t < ntors)
    {
       const int g = term_row(tm, t);
-      int f = func[g];
-      bool skip = (f == 1 && (excl_mask & 16)) || (f == 2 && (excl_mask & 32));
-      if (!skip)
+      int I = term_atom(tm, 4, t, 0), J = term_atom(tm, 4, t, 1), K = term_atom(tm, 4, t, 2), L = term_atom(tm, 4, t, 3);
+      double et, ei, fI[3], fJ[3], fK[3], fL[3], vir[6];
+      if (tors_eval(box, pos[I], pos[J], pos[K], pos[L], func[g], nn_[g], kk_[g], delta_[g], excl_mask, et, ei, fI, fJ, fK, fL, vir))
       {
-         int I = term_atom(tm, 4, t, 0), J = term_atom(tm, 4, t, 1), K = term_atom(tm, 4, t, 2), L = term_atom(tm, 4, t, 3);
-         double4 pI = pos[I], pJ = pos[J], pK = pos[K], pL = pos[L];
-         /* bioDihedralFast, bioCharmmCovalentEnergies.c:266-351 */
-         const double eps = 1e-12;
-         double ax, ay, az, bx, by, bz, cx, cy, cz;
-         bioVec(box, pI, pJ, ax, ay, az);
-         bioVec(box, pJ, pK, bx, by, bz);
-         bioVec(box, pK, pL, cx, cy, cz);
-         double a2 = ax * ax + ay * ay + az * az, b2 = bx * bx + by * by + bz * bz, c2 = cx * cx + cy * cy + cz * cz;
-         double ab = ax * bx + ay * by + az * bz, bc = bx * cx + by * cy + bz * cz, ac = ax * cx + ay * cy + az * cz;
-         double ff = ab * bc - ac * b2;
-         double g1 = a2 * b2 - ab * ab + eps;
-         double g2 = b2 * c2 - bc * bc + eps;
-         double yy = 1.0 / sqrt(g1 * g2);
-         double xx = yy * ff;
-         double xab = yy * bc + xx / g1 * ab;
-         double xbc = yy * ab + xx / g2 * bc;
-         double xac = -yy * b2;
-         double xaa = -0.5 * xx * b2 / g1;
-         double xcc = -0.5 * xx * b2 / g2;
-         double xbb = -yy * ac - 0.5 * xx * (a2 / g1 + c2 / g2);
-         double cax = xab * bx + xac * cx + (2 * xaa) * ax, cay = xab * by + xac * cy + (2 * xaa) * ay, caz = xab * bz + xac * cz + (2 * xaa) * az;
-         double cbx = xab * ax + xbc * cx + (2 * xbb) * bx, cby = xab * ay + xbc * cy + (2 * xbb) * by, cbz = xab * az + xbc * cz + (2 * xbb) * bz;
-         double ccx = xbc * bx + xac * ax + (2 * xcc) * cx, ccy = xbc * by + xac * ay + (2 * xcc) * cy, ccz = xbc * bz + xac * az + (2 * xcc) * cz;
-         double mx = ay * bz - az * by, my = az * bx - ax * bz, mz = ax * by - ay * bx;
-         double nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
-         double qx = my * nz - mz * ny, qy = mz * nx - mx * nz, qz = mx * ny - my * nx;
-         double signnum = bx * qx + by * qy + bz * qz;
-         double sign = (signnum < 0.0) ? -1.0 : 1.0;
-         xx = fmax(fmin(xx, 1.0), -1.0);
-         double ang = sign * acos(xx);
-         double sinX = sin(ang);
-         double v0 = -(cax * ax + cbx * bx + ccx * cx), v3 = -(cax * ay + cbx * by + ccx * cy), v4 = -(cax * az + cbx * bz + ccx * cz);
-         double v1 = -(cay * ay + cby * by + ccy * cy), v5 = -(cay * az + cby * bz + ccy * cz), v2 = -(caz * az + cbz * bz + ccz * cz);
-         double kk;
-         if (f == 1)
-         {
-            double kchi = kk_[g], delta = delta_[g];
-            int n = nn_[g];
-            acc[0] = kchi * (1 + cos(n * ang - delta));
-            if (fabs(sinX) > FLOAT_EPS) kk = kchi * n * sin(n * ang - delta) / sinX;
-            else
-            {
-               double nX = n * ang, nX2 = nX * nX, nX4 = nX2 * nX2, nX6 = nX4 * nX2, nX8 = nX4 * nX4, nX10 = nX8 * nX2;
-               double X2 = ang * ang, X4 = X2 * X2, X6 = X4 * X2, X8 = X4 * X4, X10 = X8 * X2;
-               double ratio = n * (1 - nX2 / 6 + nX4 / 120 - nX6 / 5040 + nX8 / 362880 - nX10 / 39916800) /
-                              (1 - X2 / 6 + X4 / 120 - X6 / 5040 + X8 / 362880 - X10 / 39916800);
-               if (delta < NEAR_ZERO_ANGLE) kk = kchi * n * ratio;
-               else if (delta > NEAR_180_ANGLE) kk = -kchi * n * ratio;
-               else kk = kchi * n * ratio;
-            }
-         }
-         else
-         {
-            double kpsi = kk_[g], psi0 = delta_[g];
-            double d = ang - psi0;
-            if (d < -M_PI) d += 2 * M_PI; else if (d > M_PI) d -= 2 * M_PI;
-            acc[1] = kpsi * d * d;
-            double absX = sinX < 0 ? -sinX : sinX;
-            if (absX > FLOAT_EPS) kk = -2 * kpsi * d / sinX;
-            else
-            {
-               double i2 = ang * ang, i4 = i2 * i2, i6 = i4 * i2, i8 = i4 * i4, i10 = i8 * i2;
-               kk = -2 * kpsi / (1 - i2 / 6 + i4 / 120 - i6 / 5040 + i8 / 362880 - i10 / 39916800);
-            }
-         }
-         addf(tm, fx, fy, fz, I, -cax * kk, -cay * kk, -caz * kk);
-         addf(tm, fx, fy, fz, J, -(cbx - cax) * kk, -(cby - cay) * kk, -(cbz - caz) * kk);
-         addf(tm, fx, fy, fz, K, -(ccx - cbx) * kk, -(ccy - cby) * kk, -(ccz - cbz) * kk);
-         addf(tm, fx, fy, fz, L, ccx * kk, ccy * kk, ccz * kk);
-         acc[2] = v0 * kk; acc[3] = v1 * kk; acc[4] = v2 * kk; acc[5] = v3 * kk; acc[6] = v4 * kk; acc[7] = v5 * kk;
+         addf(tm, fx, fy, fz, I, fI[0], fI[1], fI[2]);
+         addf(tm, fx, fy, fz, J, fJ[0], fJ[1], fJ[2]);
+         addf(tm, fx, fy, fz, K, fK[0], fK[1], fK[2]);
+         addf(tm, fx, fy, fz, L, fL[0], fL[1], fL[2]);
+         acc[0] = et; acc[1] = ei;
+#pragma unroll
+         for (int k = 0; k < 6; k++) acc[2 + k] = vir[k];
          weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc) + (K < tm.nloc) + (L < tm.nloc), 4);
       }
    }
    block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
+}
+
+/* bead-parallel kernel (one domain): one lane per bead walks the terms the bead takes part in, evaluates each
+ * and keeps the force on its own atom -- a term is evaluated once per atom it has, but no force is added
+ * atomically (the term-parallel kernels above are bound by the rate of double-precision atomic adds: 6 to
+ * 12 per term).  Rows (built once in ddcmi_set_bonded, by caller-order atom index, terms ascending: a fixed
+ * summation order) name the OTHER atoms of the term, the lane's role in it and a row of the table of
+ * distinct parameter sets: a bond costs one 8-byte row read, one index translation and one bead record.
+ * Energy and virial are booked by the lane holding role 0. */
+#define GB_NV 10      /* e_bond, e_angle, e_tors, e_impr, virial xx yy zz xy xz yz */
+struct GatherRows
+{
+   int nrow;
+   const int *boff, *aoff, *haoff, *toff; /* [nrow + 1] each; aoff: func 2/10 angles, haoff: func-1 angles */
+   const int2 *brow;                     /* {partner, pid << 2 | role} */
+   const int4 *arow, *harow;             /* {other atoms in term order, pid << 2 | role, 0} */
+   const int4 *trow;                     /* {other atoms in term order, pid << 2 | role} */
+   const double2 *bpar;                  /* {kb, b0} */
+   const double4 *apar;                  /* {k, theta0, func, 0} */
+   const double4 *tpar;                  /* {k, delta, func, n} */
+   int nheavy; const int *hatoms;        /* atoms with func-1 angles or dihedrals */
+};
+template <bool HEAVY>      /* false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers) */
+__global__ __launch_bounds__(256) void k_bonded_gather(int nloc, GatherRows gr, const int *__restrict__ orig, const int *__restrict__ slot, BoxArgs box, int excl_mask,
+                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double *partials)
+{
+   /* light launch: lane = device slot (coalesced force update); heavy launch: lane = entry of the short
+    * list of atoms that have heavy terms */
+   const int j = blockIdx.x * 256 + threadIdx.x;
+   double acc[GB_NV];
+#pragma unroll
+   for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
+   int i = j, o = gr.nrow;
+   if (HEAVY) { if (j < gr.nheavy) { o = gr.hatoms[j]; i = slot[o]; } }
+   else if (j < nloc) o = orig[j];
+   if (o < gr.nrow)
+   {
+      const int b0 = HEAVY ? 0 : gr.boff[o], b1 = HEAVY ? 0 : gr.boff[o + 1], a0 = HEAVY ? gr.haoff[o] : gr.aoff[o], a1 = HEAVY ? gr.haoff[o + 1] : gr.aoff[o + 1];
+      const int t0 = HEAVY ? gr.toff[o] : 0, t1 = HEAVY ? gr.toff[o + 1] : 0;
+      if (b1 + a1 + t1 > b0 + a0 + t0)
+      {
+         const double4 me = pos[i];
+         double fxi = 0, fyi = 0, fzi = 0;
+         /* three loops, each of one kind: the lanes of a wave run the same code in every trip */
+         if (!HEAVY)
+         for (int r = b0; r < b1; r++)
+         {
+            const int2 row = gr.brow[r];
+            const int role = row.y & 3;
+            const double2 par = gr.bpar[row.y >> 2];
+            const double4 q = pos[slot[row.x]];
+            double e, fD[3], vir[6];
+            bond_eval(box, role == 0 ? me : q, role == 0 ? q : me, par.x, par.y, e, fD, vir);
+            const double sg = role == 0 ? 1.0 : -1.0;
+            fxi += sg * fD[0]; fyi += sg * fD[1]; fzi += sg * fD[2];
+            if (role == 0)
+            {
+               acc[0] += e;
+#pragma unroll
+               for (int k = 0; k < 6; k++) acc[4 + k] += vir[k];
+            }
+         }
+         for (int r = a0; r < a1; r++)
+         {
+            const int4 row = HEAVY ? gr.harow[r] : gr.arow[r];
+            const int role = row.z & 3;
+            const double4 par = gr.apar[row.z >> 2];
+            const double4 q1 = pos[slot[row.x]], q2 = pos[slot[row.y]];
+            double e, fI[3], fK[3], vir[6];
+            if (angle_eval<HEAVY>(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role == 2 ? me : q2, (int)par.z, par.x, par.y, excl_mask, e, fI, fK, vir))
+            {
+               if (role == 0)
+               {
+                  fxi += fI[0]; fyi += fI[1]; fzi += fI[2]; acc[1] += e;
+#pragma unroll
+                  for (int k = 0; k < 6; k++) acc[4 + k] += vir[k];
+               }
+               else if (role == 2) { fxi += fK[0]; fyi += fK[1]; fzi += fK[2]; }
+               else { fxi -= fI[0] + fK[0]; fyi -= fI[1] + fK[1]; fzi -= fI[2] + fK[2]; }
+            }
+         }
+         if (HEAVY)
+         for (int r = t0; r < t1; r++)
+         {
+            const int4 row = gr.trow[r];
+            const int role = row.w & 3;
+            const double4 par = gr.tpar[row.w >> 2];
+            const double4 q1 = pos[slot[row.x]], q2 = pos[slot[row.y]], q3 = pos[slot[row.z]];
+            double et, ei, fI[3], fJ[3], fK[3], fL[3], vir[6];
+            if (tors_eval(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role <= 1 ? q2 : (role == 2 ? me : q3), role == 3 ? me : q3,
+                          (int)par.z, (int)par.w, par.x, par.y, excl_mask, et, ei, fI, fJ, fK, fL, vir))
+            {
+               if (role == 0)
+               {
+                  fxi += fI[0]; fyi += fI[1]; fzi += fI[2]; acc[2] += et; acc[3] += ei;
+#pragma unroll
+                  for (int k = 0; k < 6; k++) acc[4 + k] += vir[k];
+               }
+               else if (role == 1) { fxi += fJ[0]; fyi += fJ[1]; fzi += fJ[2]; }
+               else if (role == 2) { fxi += fK[0]; fyi += fK[1]; fzi += fK[2]; }
+               else { fxi += fL[0]; fyi += fL[1]; fzi += fL[2]; }
+            }
+         }
+         fx[i] += fxi; fy[i] += fyi; fz[i] += fzi;
+      }
+   }
+   /* block sums, GB_NV values per block at stride 16 */
+   __shared__ double s_red[4][GB_NV];
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+   for (int k = 0; k < GB_NV; k++)
+   {
+      double sv = wsum(acc[k]);
+      if (lane == 0) s_red[w][k] = sv;
+   }
+   __syncthreads();
+   if (threadIdx.x < GB_NV) partials[(size_t)blockIdx.x * 16 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+/* workgroup k sums column k of the gather kernel's partials in a fixed order and files it where
+ * finish_energy expects the per-kind sums (the whole bonded virial goes to the bond block) */
+__global__ __launch_bounds__(256) void k_reduce_gather(const double *__restrict__ partials, int nblocks, const double *__restrict__ partials2, int nblocks2, double *results)
+{
+   __shared__ double s[256];
+   const int k = blockIdx.x;
+   double a = 0.0;
+   for (int b = threadIdx.x; b < nblocks; b += 256) a += partials[(size_t)b * 16 + k];
+   for (int b = threadIdx.x; b < nblocks2; b += 256) a += partials2[(size_t)b * 16 + k];
+   s[threadIdx.x] = a;
+   __syncthreads();
+   for (int off = 128; off > 0; off >>= 1)
+   {
+      if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0)
+   {
+      const int dst = k == 0 ? R_SCR_BOND : k == 1 ? R_SCR_ANGLE : k == 2 ? R_SCR_TORS : k == 3 ? R_SCR_TORS + 1 : R_SCR_BOND + 1 + (k - 4);
+      results[dst] = s[0];
+      if (k == 1) for (int q = 1; q < 7; q++) results[R_SCR_ANGLE + q] = 0.0;
+      if (k == 2) for (int q = 2; q < 8; q++) results[R_SCR_TORS + q] = 0.0;
+   }
 }
 
 /* one launch for the three term kinds: workgroup b sums the partials of kind b in a fixed order */
@@ -285,109 +456,6 @@ __global__ __launch_bounds__(256) void k_reduce_b(RedB rb)
       if (threadIdx.x == 0) out[k] = s[0];
       __syncthreads();
    }
-}
-
-/* ---- evaluation order of the terms of one domain: by the slot of the first atom ---------- */
-__global__ void k_tkey_hist(int nterm, int na, const int *__restrict__ atoms, const int *__restrict__ slot, int *key, int *cnt)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t >= nterm) return;
-   int k = slot[atoms[na * t]];
-   key[t] = k;
-   atomicAdd(&cnt[k], 1);
-}
-__global__ void k_tkey_place(int nterm, const int *__restrict__ key, const int *__restrict__ start, int *fill, int *perm)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t >= nterm) return;
-   int k = key[t];
-   perm[start[k] + atomicAdd(&fill[k], 1)] = t;
-}
-/* terms sharing a first atom: ascending term index, so the order does not depend on timing */
-__global__ void k_tkey_fix(int nkey, const int *__restrict__ start, int *perm)
-{
-   int k = blockIdx.x * blockDim.x + threadIdx.x;
-   if (k >= nkey) return;
-   int a = start[k], b = start[k + 1];
-   for (int i = a + 1; i < b; i++)
-   {
-      int v = perm[i], j = i - 1;
-      while (j >= a && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
-      perm[j + 1] = v;
-   }
-}
-static int sort_terms(ddcmi_ctx *ctx, int nterm, int na, const int *atoms, dbuf<int> &perm)
-{
-   if (nterm <= 0) return DDCMI_OK;
-   hipStream_t st = ctx->stream;
-   const int nkey = ctx->nloc;
-   ENSURE(ctx, ctx->tk_key, (size_t)nterm);
-   ENSURE(ctx, ctx->tk_cnt, (size_t)nkey + 2);
-   ENSURE(ctx, ctx->tk_fill, (size_t)nkey + 2);
-   ENSURE(ctx, perm, (size_t)nterm);
-   HIPCHK(ctx, hipMemsetAsync(ctx->tk_cnt.p, 0, ((size_t)nkey + 2) * sizeof(int), st));
-   HIPCHK(ctx, hipMemsetAsync(ctx->tk_fill.p, 0, ((size_t)nkey + 2) * sizeof(int), st));
-   hipLaunchKernelGGL(k_tkey_hist, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, na, atoms, ctx->slot_of_orig.p, ctx->tk_key.p, ctx->tk_cnt.p);
-   int rc = ddcmi_scan_exclusive(ctx, ctx->tk_cnt.p, nkey + 1, ctx->d_flags + 8);
-   if (rc) return rc;
-   hipLaunchKernelGGL(k_tkey_place, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, ctx->tk_key.p, ctx->tk_cnt.p, ctx->tk_fill.p, perm.p);
-   hipLaunchKernelGGL(k_tkey_fix, dim3(cdiv(nkey, 256)), dim3(256), 0, st, nkey, ctx->tk_cnt.p, perm.p);
-   return DDCMI_OK;
-}
-/* ... and the terms' atoms (as device slots) and parameters copied into that order, so the
- * kernels read everything but the bead records and forces with unit stride until the next rebuild */
-template <int NA>
-__global__ void k_term_slots(int nterm, const int *__restrict__ perm, const int *__restrict__ atoms, const int *__restrict__ slot, int *out)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t >= nterm) return;
-   int g = perm[t];
-#pragma unroll
-   for (int a = 0; a < NA; a++) out[NA * t + a] = slot[atoms[NA * g + a]];
-}
-template <class T>
-__global__ void k_gather_perm(int n, const int *__restrict__ perm, const T *__restrict__ src, T *dst)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t < n) dst[t] = src[perm[t]];
-}
-template <class T>
-static int gather_perm(ddcmi_ctx *ctx, int n, const dbuf<int> &perm, const dbuf<T> &src, dbuf<T> &dst)
-{
-   ENSURE(ctx, dst, (size_t)n);
-   hipLaunchKernelGGL(k_gather_perm<T>, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, perm.p, src.p, dst.p);
-   return DDCMI_OK;
-}
-/* one domain, at every rebuild: evaluation order of the caller-order term lists */
-int ddcmi_bonded_order(ddcmi_ctx *ctx)
-{
-   if (ctx->bonded_gid || ctx->nranks > 1 || ctx->group_) return DDCMI_OK;
-   hipStream_t st = ctx->stream;
-   int rc;
-   if ((rc = sort_terms(ctx, ctx->nbond, 2, ctx->bond_ij.p, ctx->o_bond)) || (rc = sort_terms(ctx, ctx->nangle, 3, ctx->angle_ijk.p, ctx->o_angle)) ||
-       (rc = sort_terms(ctx, ctx->ntors, 4, ctx->tors_ijkl.p, ctx->o_tors))) return rc;
-   if (ctx->nbond > 0)
-   {
-      ENSURE(ctx, ctx->s_bond_atoms, 2 * (size_t)ctx->nbond);
-      hipLaunchKernelGGL(k_term_slots<2>, dim3(cdiv(ctx->nbond, 256)), dim3(256), 0, st, ctx->nbond, ctx->o_bond.p, ctx->bond_ij.p, ctx->slot_of_orig.p, ctx->s_bond_atoms.p);
-      if ((rc = gather_perm(ctx, ctx->nbond, ctx->o_bond, ctx->bond_kb, ctx->s_bond_kb)) || (rc = gather_perm(ctx, ctx->nbond, ctx->o_bond, ctx->bond_b0, ctx->s_bond_b0))) return rc;
-   }
-   if (ctx->nangle > 0)
-   {
-      ENSURE(ctx, ctx->s_angle_atoms, 3 * (size_t)ctx->nangle);
-      hipLaunchKernelGGL(k_term_slots<3>, dim3(cdiv(ctx->nangle, 256)), dim3(256), 0, st, ctx->nangle, ctx->o_angle.p, ctx->angle_ijk.p, ctx->slot_of_orig.p, ctx->s_angle_atoms.p);
-      if ((rc = gather_perm(ctx, ctx->nangle, ctx->o_angle, ctx->angle_func, ctx->s_angle_func)) || (rc = gather_perm(ctx, ctx->nangle, ctx->o_angle, ctx->angle_k, ctx->s_angle_k)) ||
-          (rc = gather_perm(ctx, ctx->nangle, ctx->o_angle, ctx->angle_t0, ctx->s_angle_t0))) return rc;
-   }
-   if (ctx->ntors > 0)
-   {
-      ENSURE(ctx, ctx->s_tors_atoms, 4 * (size_t)ctx->ntors);
-      hipLaunchKernelGGL(k_term_slots<4>, dim3(cdiv(ctx->ntors, 256)), dim3(256), 0, st, ctx->ntors, ctx->o_tors.p, ctx->tors_ijkl.p, ctx->slot_of_orig.p, ctx->s_tors_atoms.p);
-      if ((rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_func, ctx->s_tors_func)) || (rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_n, ctx->s_tors_n)) ||
-          (rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_k, ctx->s_tors_k)) || (rc = gather_perm(ctx, ctx->ntors, ctx->o_tors, ctx->tors_delta, ctx->s_tors_delta))) return rc;
-   }
-   ctx->bonded_ordered = true;
-   return DDCMI_OK;
 }
 
 /* ---- decomposed runs: terms are given by gid and located among the owned + halo beads - */
@@ -478,7 +546,7 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
    if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    ctx->excludePotentialTerm = excludePotentialTerm;
-   ctx->bonded_gid = false; ctx->bonded_ordered = false; ctx->list_valid = false;
+   ctx->bonded_gid = false; ctx->list_valid = false;
    ctx->nbond = (excludePotentialTerm & 1) ? 0 : nbond;
    ctx->nangle = nangle; ctx->ntors = ntors;
    int rc;
@@ -502,6 +570,99 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
          if (tors_func[t] != 1 && tors_func[t] != 2) SETERR(ctx, DDCMI_EINVAL, "dihedral %d: func %d is not 1 or 2", t, tors_func[t]);
       if ((rc = up(ctx, ctx->tors_ijkl, tors_ijkl, 4 * (size_t)ntors)) || (rc = up(ctx, ctx->tors_func, tors_func, ntors)) || (rc = up(ctx, ctx->tors_n, tors_n, ntors)) ||
           (rc = up(ctx, ctx->tors_k, tors_k, ntors)) || (rc = up(ctx, ctx->tors_delta, tors_delta, ntors))) return rc;
+   }
+   /* rows of k_bonded_gather */
+   ctx->inc_nrow = 0;
+   if (ctx->nbond + nangle + ntors > 0)
+   {
+      int amax = -1;
+      for (int k = 0; k < 2 * ctx->nbond; k++) { if (bond_ij[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a bond"); amax = std::max(amax, bond_ij[k]); }
+      for (int k = 0; k < 3 * nangle; k++) { if (angle_ijk[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in an angle"); amax = std::max(amax, angle_ijk[k]); }
+      for (int k = 0; k < 4 * ntors; k++) { if (tors_ijkl[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a dihedral"); amax = std::max(amax, tors_ijkl[k]); }
+      const int nrow = amax + 1;
+      /* distinct parameter sets per kind (a force field has a handful) */
+      std::map<std::array<double, 4>, int> ids[3];
+      std::vector<double> par[3];
+      auto pid = [&](int kind, double a, double b, double c, double d)
+      {
+         std::array<double, 4> key = {a, b, c, d};
+         auto it = ids[kind].find(key);
+         if (it != ids[kind].end()) return it->second;
+         int id = (int)ids[kind].size();
+         ids[kind][key] = id;
+         if (kind == 0) { par[0].push_back(a); par[0].push_back(b); } else for (double v : key) par[kind].push_back(v);
+         return id;
+      };
+      auto offsets = [&](const int *atoms, int nterm, int na)
+      {
+         std::vector<int> off((size_t)nrow + 1, 0);
+         for (size_t k = 0; k < (size_t)nterm * na; k++) off[atoms[k] + 1]++;
+         for (int a = 0; a < nrow; a++) off[a + 1] += off[a];
+         return off;
+      };
+      /* func-1 angles go with the dihedrals into the second, heavier launch */
+      std::vector<int> la, ha;
+      for (int t = 0; t < nangle; t++) (angle_func[t] == 1 ? ha : la).push_back(t);
+      auto offsets_sel = [&](const std::vector<int> &sel)
+      {
+         std::vector<int> off((size_t)nrow + 1, 0);
+         for (int t : sel) for (int r = 0; r < 3; r++) off[angle_ijk[3 * t + r] + 1]++;
+         for (int a = 0; a < nrow; a++) off[a + 1] += off[a];
+         return off;
+      };
+      std::vector<int> boff = offsets(bond_ij, ctx->nbond, 2), aoff = offsets_sel(la), haoff = offsets_sel(ha), toff = offsets(tors_ijkl, ntors, 4);
+      std::vector<int> brow(2 * (size_t)boff[nrow] + 2), arow(4 * (size_t)aoff[nrow] + 4), harow(4 * (size_t)haoff[nrow] + 4), trow(4 * (size_t)toff[nrow] + 4);
+      {
+         std::vector<int> fill(boff.begin(), boff.end() - 1);
+         for (int t = 0; t < ctx->nbond; t++)
+         {
+            const int id = pid(0, bond_kb[t], bond_b0[t], 0, 0);
+            for (int r = 0; r < 2; r++) { size_t w = fill[bond_ij[2 * t + r]]++; brow[2 * w] = bond_ij[2 * t + 1 - r]; brow[2 * w + 1] = (id << 2) | r; }
+         }
+      }
+      for (int pass = 0; pass < 2; pass++)
+      {
+         const std::vector<int> &sel = pass ? ha : la;
+         std::vector<int> &rows = pass ? harow : arow;
+         const std::vector<int> &o = pass ? haoff : aoff;
+         std::vector<int> fill(o.begin(), o.end() - 1);
+         for (int t : sel)
+         {
+            const int id = pid(1, angle_k[t], angle_t0[t], (double)angle_func[t], 0);
+            for (int r = 0; r < 3; r++)
+            {
+               size_t w = fill[angle_ijk[3 * t + r]]++;
+               int q = 0;
+               for (int a = 0; a < 3; a++) if (a != r) rows[4 * w + q++] = angle_ijk[3 * t + a];
+               rows[4 * w + 2] = (id << 2) | r; rows[4 * w + 3] = 0;
+            }
+         }
+      }
+      std::vector<int> hatoms;
+      for (int a = 0; a < nrow; a++) if (haoff[a + 1] > haoff[a] || toff[a + 1] > toff[a]) hatoms.push_back(a);
+      ctx->inc_heavy = (int)hatoms.size();
+      hatoms.push_back(0);
+      {
+         std::vector<int> fill(toff.begin(), toff.end() - 1);
+         for (int t = 0; t < ntors; t++)
+         {
+            const int id = pid(2, tors_k[t], tors_delta[t], (double)tors_func[t], (double)tors_n[t]);
+            for (int r = 0; r < 4; r++)
+            {
+               size_t w = fill[tors_ijkl[4 * t + r]]++;
+               int q = 0;
+               for (int a = 0; a < 4; a++) if (a != r) trow[4 * w + q++] = tors_ijkl[4 * t + a];
+               trow[4 * w + 3] = (id << 2) | r;
+            }
+         }
+      }
+      for (int k = 0; k < 3; k++) if (ids[k].size() >= (1u << 29)) SETERR(ctx, DDCMI_EINVAL, "too many distinct bonded parameter sets");
+      for (int k = 0; k < 3; k++) par[k].resize(par[k].size() + 4, 0.0);
+      if ((rc = up(ctx, ctx->inc_boff, boff.data(), boff.size())) || (rc = up(ctx, ctx->inc_aoff, aoff.data(), aoff.size())) || (rc = up(ctx, ctx->inc_toff, toff.data(), toff.size())) ||
+          (rc = up(ctx, ctx->inc_hatoms, hatoms.data(), hatoms.size())) || (rc = up(ctx, ctx->inc_haoff, haoff.data(), haoff.size())) || (rc = up(ctx, ctx->inc_harow, harow.data(), harow.size())) ||
+          (rc = up(ctx, ctx->inc_brow, brow.data(), brow.size())) || (rc = up(ctx, ctx->inc_arow, arow.data(), arow.size())) || (rc = up(ctx, ctx->inc_trow, trow.data(), trow.size())) ||
+          (rc = up(ctx, ctx->inc_bpar, par[0].data(), par[0].size())) || (rc = up(ctx, ctx->inc_apar, par[1].data(), par[1].size())) || (rc = up(ctx, ctx->inc_tpar, par[2].data(), par[2].size()))) return rc;
+      ctx->inc_nrow = nrow;
    }
    /* the per-kind sums are only written by kernels that run: clear stale ones */
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
@@ -682,33 +843,42 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
       hipLaunchKernelGGL(k_restraint, dim3(1), dim3(256), 0, st, ctx->nrest, box, ctx->rest_origin, ctx->rest_slot.p, ctx->rest_fc.p, ctx->rest_r0.p, ctx->rest_kb.p,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_REST);
    if (ctx->nbond + ctx->nangle + ctx->ntors == 0) return DDCMI_OK;
-   const bool gidmode = ctx->bonded_gid;
+   if (!ctx->bonded_gid)
+   {
+      /* one domain: one lane per bead, no atomics */
+      const int nblk = cdiv(ctx->nloc, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
+      ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
+      GatherRows gr = {ctx->inc_nrow, ctx->inc_boff.p, ctx->inc_aoff.p, ctx->inc_haoff.p, ctx->inc_toff.p, (const int2 *)ctx->inc_brow.p, (const int4 *)ctx->inc_arow.p,
+                       (const int4 *)ctx->inc_harow.p, (const int4 *)ctx->inc_trow.p,
+                       (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p};
+      double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
+      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, ctx->nloc, gr, ctx->orig.p, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->bpartials.p);
+      if (nblk2 > 0)
+         hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, ctx->nloc, gr, ctx->orig.p, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
+                            ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, p2);
+      hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
+      return DDCMI_OK;
+   }
+   /* decomposed run: the terms located on this rank, one lane per term */
    int nbb = cdiv(ctx->nbond, 256), nab = cdiv(ctx->nangle, 256), ntb = cdiv(ctx->ntors, 256);
    ENSURE(ctx, ctx->bpartials, (size_t)(nbb + nab + ntb + 3) * 8);
    double *pb = ctx->bpartials.p, *pa = pb + (size_t)nbb * 8, *pt = pa + (size_t)nab * 8;
    if (ctx->nbond > 0)
    {
-      const bool ord = !gidmode && ctx->bonded_ordered;
-      TermMap tm = gidmode ? TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc}
-                 : ord ? TermMap{ctx->s_bond_atoms.p, nullptr, nullptr, ctx->nloc} : TermMap{ctx->bond_ij.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
-      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ord ? ctx->s_bond_kb.p : ctx->bond_kb.p, ord ? ctx->s_bond_b0.p : ctx->bond_b0.p, ctx->pos.p,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
+      TermMap tm = TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc};
+      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ctx->bond_kb.p, ctx->bond_b0.p, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
    }
    if (ctx->nangle > 0)
    {
-      const bool ord = !gidmode && ctx->bonded_ordered;
-      TermMap tm = gidmode ? TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc}
-                 : ord ? TermMap{ctx->s_angle_atoms.p, nullptr, nullptr, ctx->nloc} : TermMap{ctx->angle_ijk.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
-      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ord ? ctx->s_angle_func.p : ctx->angle_func.p, ord ? ctx->s_angle_k.p : ctx->angle_k.p, ord ? ctx->s_angle_t0.p : ctx->angle_t0.p,
+      TermMap tm = TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc};
+      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
    }
    if (ctx->ntors > 0)
    {
-      const bool ord = !gidmode && ctx->bonded_ordered;
-      TermMap tm = gidmode ? TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc}
-                 : ord ? TermMap{ctx->s_tors_atoms.p, nullptr, nullptr, ctx->nloc} : TermMap{ctx->tors_ijkl.p, ctx->slot_of_orig.p, nullptr, ctx->nloc};
-      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ord ? ctx->s_tors_func.p : ctx->tors_func.p, ord ? ctx->s_tors_n.p : ctx->tors_n.p,
-                         ord ? ctx->s_tors_k.p : ctx->tors_k.p, ord ? ctx->s_tors_delta.p : ctx->tors_delta.p,
+      TermMap tm = TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc};
+      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
                          ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
    }
    RedB rb;

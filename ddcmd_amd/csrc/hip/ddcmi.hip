@@ -693,32 +693,6 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta, Shel
  *   vEle+= kqij(ir + krf r2 - crf) ; dvdr += kqij(2krf - ir^3)
  *   f_i -= dvdr d ;  virial += f (x) d
  */
-__device__ __forceinline__ double rsqrt_f64(double x)
-{
-   /* v_rsq_f32 seed (23 bits) + two Newton steps y += y*(1/2 - (x/2) y^2): 3 FP64 ops
-    * each, < 2 ulp; checked against the closed form in tests */
-   float xf = (float)x;
-   double y = (double)__builtin_amdgcn_rsqf(xf);      /* the bare instruction: __frsqrt_rn expands to a correctly rounded sequence */
-   double h = 0.5 * x;
-   double e = fma(-(h * y), y, 0.5);
-   y = fma(y, e, y);
-   e = fma(-(h * y), y, 0.5);
-   y = fma(y, e, y);
-   return y;
-}
-/* 1/x: v_rcp_f32 seed + two Newton steps y += y*(1 - x y): 2 FP64 ops each.  Used
- * when no bead carries a charge: Lennard-Jones needs 1/r^2 only, no square root. */
-__device__ __forceinline__ double rcp_f64(double x)
-{
-   float xf = (float)x;
-   double y = (double)__builtin_amdgcn_rcpf(xf);      /* the bare instruction: __frcp_rn expands to a 10-instruction IEEE division */
-   double e = fma(-x, y, 1.0);
-   y = fma(y, e, y);
-   e = fma(-x, y, 1.0);
-   y = fma(y, e, y);
-   return y;
-}
-
 /* 5 waves per tile: a tile holds 256 beads on average, so 256-thread workgroups
  * would make every second tile take a second, mostly idle pass */
 #ifdef DDCMI_TRACE_BLOCKS
@@ -1487,10 +1461,10 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
-   for (auto b : {&ctx->s_bond_kb, &ctx->s_bond_b0, &ctx->s_angle_k, &ctx->s_angle_t0, &ctx->s_tors_k, &ctx->s_tors_delta, &ctx->cg_dist}) b->release();
+   for (auto b : {&ctx->cg_dist, &ctx->inc_bpar, &ctx->inc_apar, &ctx->inc_tpar}) b->release();
    for (auto b : {&ctx->cg_atom_off, &ctx->cg_atoms, &ctx->cg_pair_off, &ctx->cons_status, &ctx->mol_off, &ctx->mol_atoms}) b->release();
    ctx->cg_pa.release(); ctx->cg_pb.release();
-   for (auto b : {&ctx->s_bond_atoms, &ctx->s_angle_atoms, &ctx->s_angle_func, &ctx->s_tors_atoms, &ctx->s_tors_func, &ctx->s_tors_n, &ctx->o_bond, &ctx->o_angle, &ctx->o_tors, &ctx->tk_key, &ctx->tk_cnt, &ctx->tk_fill, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
+   for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
@@ -2123,7 +2097,6 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    ctx->list_valid = true;
    ctx->nrebuild++;
-   { int rco = ddcmi_bonded_order(ctx); if (rco) return rco; }      /* caller-order terms: evaluation order by first-atom slot */
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }
 

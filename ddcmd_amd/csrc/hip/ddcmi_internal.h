@@ -167,9 +167,8 @@ struct ddcmi_ctx
    long nmol_total = 0; int nmol_multi = 0; bool molv_valid = false;   /* R_SCR_MOLV belongs to the forces now in fx */
    dbuf<int> mol_off, mol_atoms;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
-   dbuf<int> o_bond, o_angle, o_tors, tk_key, tk_cnt, tk_fill; bool bonded_ordered = false;   /* one domain: evaluation order by first-atom slot */
-   dbuf<int> s_bond_atoms, s_angle_atoms, s_angle_func, s_tors_atoms, s_tors_func, s_tors_n;   /* ... and the lists copied into that order */
-   dbuf<double> s_bond_kb, s_bond_b0, s_angle_k, s_angle_t0, s_tors_k, s_tors_delta;
+   /* one domain: rows of the bead-parallel bonded kernel (atom -> its terms), built in ddcmi_set_bonded */
+   int inc_nrow = 0, inc_heavy = 0; dbuf<int> inc_boff, inc_aoff, inc_haoff, inc_toff, inc_brow, inc_arow, inc_harow, inc_trow, inc_hatoms; dbuf<double> inc_bpar, inc_apar, inc_tpar;
    bool bonded_gid = false;
    int g_nbond = 0, g_nangle = 0, g_ntors = 0;
    dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;
@@ -205,10 +204,38 @@ struct ddcmi_ctx
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+#ifdef __HIPCC__
+/* double-precision 1/sqrt(x) and 1/x from the single-precision hardware seeds (shared by the pair and the bonded kernels) */
+__device__ __forceinline__ double rsqrt_f64(double x)
+{
+   /* v_rsq_f32 seed (23 bits) + two Newton steps y += y*(1/2 - (x/2) y^2): 3 FP64 ops
+    * each, < 2 ulp; checked against the closed form in tests */
+   float xf = (float)x;
+   double y = (double)__builtin_amdgcn_rsqf(xf);      /* the bare instruction: __frsqrt_rn expands to a correctly rounded sequence */
+   double h = 0.5 * x;
+   double e = fma(-(h * y), y, 0.5);
+   y = fma(y, e, y);
+   e = fma(-(h * y), y, 0.5);
+   y = fma(y, e, y);
+   return y;
+}
+/* 1/x: v_rcp_f32 seed + two Newton steps y += y*(1 - x y): 2 FP64 ops each.  Used
+ * when no bead carries a charge: Lennard-Jones needs 1/r^2 only, no square root. */
+__device__ __forceinline__ double rcp_f64(double x)
+{
+   float xf = (float)x;
+   double y = (double)__builtin_amdgcn_rcpf(xf);      /* the bare instruction: __frcp_rn expands to a 10-instruction IEEE division */
+   double e = fma(-x, y, 1.0);
+   y = fma(y, e, y);
+   e = fma(-x, y, 1.0);
+   y = fma(y, e, y);
+   return y;
+}
+#endif
+
 /* scan.hip */
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
-int ddcmi_bonded_order(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */
