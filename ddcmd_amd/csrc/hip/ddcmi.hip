@@ -324,6 +324,7 @@ struct NbTileArgs
    int rot;                             /* tuning builds: rotate the range -> XCD assignment */
 };
 
+template <bool HAS_MOL>      /* false: every molecule is a single bead -- no pair can be excluded, the molecule logic is compiled out */
 __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          unsigned lo = (unsigned)w;
          if (ta.pack_type == 2 && gj >= ta.nloc && ta.halo_shift[gj - ta.nloc] != 13) lo |= 8u;       /* travels into the entry's type nibble */
          P_s[o + k] = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
-         M_s[o + k] = (unsigned)(w >> 32);
+         if (HAS_MOL) M_s[o + k] = (unsigned)(w >> 32);
       }
    }
    __syncthreads();
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       /* exmask[mt*64 + a]: atoms (codes < 64) of molecule type mt bonded to atom a; bit 63 of
        * entry a = 0 is set when the whole type can be decided by mask */
       unsigned long long mask_i = 0; bool by_mask = false;
-      if (nmoltype > 0)
+      if (HAS_MOL && nmoltype > 0)
       {
          gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt];
          unsigned aI = (unsigned)(gi & 65535ull);
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      }
                      bool pruned = false;
                      const unsigned wj = __float_as_uint(q.w);
-                     if (nmoltype > 0 && (unsigned)(gi >> 32) == M_s[sj])
+                     if (HAS_MOL && nmoltype > 0 && (unsigned)(gi >> 32) == M_s[sj])
                      {
                         /* same molecule id (the tag holds all 32 bits of gid>>32) */
                         if (mns > 1)
@@ -1287,24 +1288,44 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_disp_max(int nloc, const double
    if ((threadIdx.x & 63) == 0 && d2 > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(d2));
 }
 /* per-group kinetic energy and member count (energy.c:124-133) */
+#define GKE_BLOCKS 512
+/* per-group kinetic energy and bead count: GKE_BLOCKS workgroups stride over the beads and leave one
+ * partial pair per group; k_group_ke_sum adds them in a fixed order */
 __global__ __launch_bounds__(DDCMI_BLOCK) void k_group_ke(int nloc, int ngroup, const double *__restrict__ massv, const int *__restrict__ species,
                                                           const int *__restrict__ group,
                                                           const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
-                                                          double *out /* [2*ngroup], zeroed */)
+                                                          double *partials /* [GKE_BLOCKS][2*ngroup] */)
 {
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   __shared__ double s_red[DDCMI_BLOCK / 64][2];
    for (int g = 0; g < ngroup; g++)
    {
       double k = 0.0, c = 0.0;
-      if (i < nloc && group[i] == g)
-      {
-         double m = massv[species[i]];
-         k = 0.5 * m * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
-         c = 1.0;
-      }
+      for (int i = blockIdx.x * DDCMI_BLOCK + threadIdx.x; i < nloc; i += GKE_BLOCKS * DDCMI_BLOCK)
+         if (group[i] == g)
+         {
+            double m = massv[species[i]];
+            k += 0.5 * m * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+            c += 1.0;
+         }
       k = wave_sum(k); c = wave_sum(c);
-      if ((threadIdx.x & 63) == 0 && c > 0.0) { atomicAdd(&out[2 * g], k); atomicAdd(&out[2 * g + 1], c); }
+      if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = k; s_red[threadIdx.x >> 6][1] = c; }
+      __syncthreads();
+      if (threadIdx.x < 2)
+      {
+         double a = 0.0;
+         for (int w = 0; w < DDCMI_BLOCK / 64; w++) a += s_red[w][threadIdx.x];
+         partials[(size_t)blockIdx.x * 2 * ngroup + 2 * g + threadIdx.x] = a;
+      }
+      __syncthreads();
    }
+}
+__global__ void k_group_ke_sum(int ngroup, const double *__restrict__ partials, double *out)
+{
+   int q = threadIdx.x;
+   if (q >= 2 * ngroup) return;
+   double a = 0.0;
+   for (int b = 0; b < GKE_BLOCKS; b++) a += partials[(size_t)b * 2 * ngroup + q];
+   out[q] = a;
 }
 
 /* download helpers: caller order + wrap */
@@ -2060,8 +2081,11 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw;
-      HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_tile_build, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
+      bool has_mol = false;
+      for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
+      auto kbuild = has_mol ? k_tile_build<true> : k_tile_build<false>;
+      HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
                          ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       {
@@ -2481,10 +2505,10 @@ int ddcmi_group_ke_sums(ddcmi_ctx *ctx)
    (void)hipSetDevice(ctx->device);
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, ng = ctx->ngroup;
-   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_GROUP, 0, 2 * ng * sizeof(double), st));
-   if (n > 0)
-      hipLaunchKernelGGL(k_group_ke, dim3(cdiv(n, DDCMI_BLOCK)), dim3(DDCMI_BLOCK), 0, st, n, ng, ctx->d_mass.p, ctx->species.p, ctx->group.p,
-                         ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->d_results + R_GROUP);
+   ENSURE(ctx, ctx->kpartials, (size_t)GKE_BLOCKS * 2 * std::max(ng, 1) + 64);
+   hipLaunchKernelGGL(k_group_ke, dim3(GKE_BLOCKS), dim3(DDCMI_BLOCK), 0, st, n, ng, ctx->d_mass.p, ctx->species.p, ctx->group.p,
+                      ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p);
+   hipLaunchKernelGGL(k_group_ke_sum, dim3(1), dim3(64), 0, st, ng, ctx->kpartials.p, ctx->d_results + R_GROUP);
    if ((ctx->nranks > 1 || ctx->loopback) && ctx->comm && !ctx->group_ && ng > 0)
       if (ncclAllReduce(ctx->d_results + R_GROUP, ctx->d_results + R_GROUP, 2 * ng, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st) != ncclSuccess)
          SETERR(ctx, DDCMI_ECOMM, "ncclAllReduce of the group kinetic energies failed");
