@@ -338,7 +338,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    extern __shared__ float4 tb_smem[];
    float4 *P_s = tb_smem;
    unsigned *M_s = (unsigned *)(tb_smem + ta.cap);
-   int *ofs_s = (int *)(M_s + ta.cap);                     /* [NRC+1] staged offset of each region cell */
+   int *ofs_s = (int *)(M_s + (HAS_MOL ? ta.cap : 0));     /* [NRC+1] staged offset of each region cell */
    int *gst_s = ofs_s + NRC + 8;                           /* [NRC] global start of each region cell */
    __shared__ int s_w[TB_THREADS / 64];
    int t = blockIdx.x;
@@ -2064,7 +2064,10 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    for (int attempt = 0;; attempt++)
    {
       if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
-      size_t lds = (size_t)ctx->stage_cap * 20 + (2 * NRC + 16) * sizeof(int);
+      bool has_mol = false;
+      for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
+      /* LDS image: 16 B per staged bead (+ 4 B molecule id when pairs can be excluded) + the region cell tables */
+      size_t lds = (size_t)ctx->stage_cap * (has_mol ? 20 : 16) + (2 * NRC + 16) * sizeof(int);
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
@@ -2081,8 +2084,6 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw;
-      bool has_mol = false;
-      for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
       auto kbuild = has_mol ? k_tile_build<true> : k_tile_build<false>;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
