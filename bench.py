@@ -141,6 +141,9 @@ def main():
         m.upload_local()
     nlocal0 = m.n
     m.eval_forces()                       # firstEnergyCall (masters.c:579)
+    # RCCL prints a version banner through C stdio at communicator creation; flush it now so that the JSON
+    # line below is the last line of stdout
+    ctypes.CDLL(None).fflush(None)
     thermostat = any(int(t) == 1 for t in np.asarray(s.group_type).ravel())
     if thermostat:
         m.group_temperatures()            # the temperature Berendsen scales with (published by eval_energyInfo in the reference)
@@ -209,13 +212,14 @@ def main():
                      "note": "rank 0's kernel on its own beads" if world > 1 else "whole box"},
         "check": {"epot": epot, "ekin": ekin},
     }
-    if rank == 0 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n)
-    if rank == 0:
-        print(json.dumps(out))
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n)      # N=1 only (the contract): a bounded sample on one host core
     m.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)                      # anything the libraries left in C stdio goes out first
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
