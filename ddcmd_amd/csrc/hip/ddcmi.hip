@@ -1495,6 +1495,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+   for (int k = 0; k < 3; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
    (void)hipStreamDestroy(ctx->stream);
    delete ctx;
 }
@@ -1981,10 +1982,13 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
  * more -- two launch tails, the exchange competing for the CUs -- than the 40 us it hides). */
 static int schedule_tiles(ddcmi_ctx *ctx)
 {
+   /* the tile costs came to the host with the build's flags (ddcmi_bl_finish), in pinned memory; the order
+    * and the ranges leave from pinned memory too, so this function costs no host round trip of its own */
    const int ntile = ctx->ntile;
-   std::vector<int> work(ntile), perm(ntile), sched(32, 0);
-   HIPCHK(ctx, hipMemcpyAsync(work.data(), ctx->tile_work.p, (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   const int *work = ctx->h_pin[0];
+   int *perm = ctx->pinned(1, (size_t)ntile + 64), *sched = perm ? perm + ntile : nullptr;
+   if (!work || !perm) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile schedule");
+   for (int k = 0; k < 32; k++) sched[k] = 0;
    const bool two = ctx->halo_overlap && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
    int n0 = 0;
    if (two)
@@ -2018,10 +2022,9 @@ static int schedule_tiles(ddcmi_ctx *ctx)
    ctx->ntile_class[0] = n0; ctx->ntile_class[1] = ntile - n0;
    ENSURE(ctx, ctx->tile_perm, (size_t)ntile + 1);
    ENSURE(ctx, ctx->sched, 32);
-   HIPCHK(ctx, hipMemcpyAsync(ctx->tile_perm.p, perm.data(), (size_t)ntile * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-   HIPCHK(ctx, hipMemcpyAsync(ctx->sched.p, sched.data(), 32 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          /* perm/sched are stack/heap temporaries */
-   return DDCMI_OK;
+   HIPCHK(ctx, hipMemcpyAsync(ctx->tile_perm.p, perm, (size_t)ntile * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+   HIPCHK(ctx, hipMemcpyAsync(ctx->sched.p, sched, 32 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+   return DDCMI_OK;       /* the pinned buffers are rewritten at the next rebuild, behind its own synchronisation */
 }
 
 /* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
@@ -2097,9 +2100,13 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       }
       HIPCHK(ctx, hipGetLastError());
       unsigned long long tot[3];
+      int *h_work = ctx->pinned(0, (size_t)ntile + 8);
+      if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
+      HIPCHK(ctx, hipMemcpyAsync(h_work + ntile, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
+      memcpy(tot, h_work + ntile, sizeof(tot));
       bool again = false;
       if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.05) + 32) + 63) & ~63; again = true; }
       if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }

@@ -179,6 +179,18 @@ struct ddcmi_ctx
    dbuf<double> partials, bpartials; int npartial_blocks = 0;
    double *d_results = nullptr; double *h_results = nullptr;
    int *d_flags = nullptr; int *h_flags = nullptr;
+   /* growable pinned host staging (so that small copies are truly asynchronous): [0] tile work, [1] tile order, [2] count exchange */
+   int *h_pin[3] = {nullptr, nullptr, nullptr}; size_t h_pin_cap[3] = {0, 0, 0};
+   int *pinned(int which, size_t n)
+   {
+      if (n <= h_pin_cap[which]) return h_pin[which];
+      if (h_pin[which]) (void)hipHostFree(h_pin[which]);
+      h_pin[which] = nullptr; h_pin_cap[which] = 0;
+      size_t cap = n + n / 4 + 64;
+      if (hipHostMalloc((void **)&h_pin[which], cap * sizeof(int), hipHostMallocDefault) != hipSuccess) return nullptr;
+      h_pin_cap[which] = cap;
+      return h_pin[which];
+   }
    double self_ele = 0.0;
    bool forces_valid = false;
    /* timing */

@@ -275,25 +275,25 @@ static inline int mg_opp(int code) { return 26 - code; }
 
 #define NCCLCHK2(ctx, call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) SETERR(ctx, DDCMI_ECOMM, "%s failed: %s", #call, ncclGetErrorString(_r)); } while (0)
 
-/* RCCL: exchange one int per remote direction (my count -> the neighbour) */
+/* RCCL: every rank learns every rank's 27 per-direction counts with ONE all-gather (26 four-byte
+ * point-to-point messages took 77 us; this is rebuild-time control traffic) and looks up what its
+ * neighbours send to it: the message a neighbour sends along ITS direction `code` comes from the
+ * rank in my direction opp(code).  Pinned staging on both sides. */
 static int mg_xchg_counts_rccl(ddcmi_ctx *ctx, const int *scnt, int *rcnt)
 {
    hipStream_t st = ctx->stream;
    ncclComm_t comm = (ncclComm_t)ctx->comm;
-   ENSURE(ctx, ctx->cnt_xchg, 64);
-   HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, scnt, 27 * sizeof(int), hipMemcpyHostToDevice, st));
-   NCCLCHK2(ctx, ncclGroupStart());
-   for (int code = 0; code < 27; code++)
-   {
-      if (mg_remote(ctx, code)) NCCLCHK2(ctx, ncclSend(ctx->cnt_xchg.p + code, 1, ncclInt, ctx->dir_dest[code], comm, st));
-      /* the message a neighbour sends along ITS direction `code` comes from the rank in my direction opp(code) */
-      if (mg_remote(ctx, mg_opp(code))) NCCLCHK2(ctx, ncclRecv(ctx->cnt_xchg.p + 27 + code, 1, ncclInt, ctx->dir_dest[mg_opp(code)], comm, st));
-   }
-   NCCLCHK2(ctx, ncclGroupEnd());
-   int tmp[27];
-   HIPCHK(ctx, hipMemcpyAsync(tmp, ctx->cnt_xchg.p + 27, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
+   const int nr = std::max(ctx->nranks, 1);
+   ENSURE(ctx, ctx->cnt_xchg, 32 + 27 * (size_t)nr);
+   int *h = ctx->pinned(2, 32 + 27 * (size_t)nr);
+   if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
+   for (int code = 0; code < 27; code++) h[code] = scnt[code];
+   HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, h, 27 * sizeof(int), hipMemcpyHostToDevice, st));
+   NCCLCHK2(ctx, ncclAllGather(ctx->cnt_xchg.p, ctx->cnt_xchg.p + 32, 27, ncclInt, comm, st));
+   HIPCHK(ctx, hipMemcpyAsync(h + 32, ctx->cnt_xchg.p + 32, 27 * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
    HIPCHK(ctx, hipStreamSynchronize(st));
-   for (int code = 0; code < 27; code++) rcnt[code] = mg_remote(ctx, mg_opp(code)) ? tmp[code] : 0;
+   for (int code = 0; code < 27; code++)
+      rcnt[code] = mg_remote(ctx, mg_opp(code)) ? h[32 + 27 * ctx->dir_dest[mg_opp(code)] + code] : 0;
    return DDCMI_OK;
 }
 /* RCCL, migration records: one message per direction (rebuilds only); segments are flattened
