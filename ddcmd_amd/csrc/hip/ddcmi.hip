@@ -1443,6 +1443,9 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = hipGetErrorString(e); return DDCMI_ENODEVICE; }
    ddcmi_ctx *ctx = new ddcmi_ctx();
    ctx->device = device;
+   /* the small host-side count arrays inside the context (migration / halo counts) become DMA targets */
+   ctx->self_pinned = hipHostRegister(ctx, sizeof(ddcmi_ctx), hipHostRegisterDefault) == hipSuccess;
+   if (!ctx->self_pinned) (void)hipGetLastError();
    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
        hipMalloc((void **)&ctx->d_results, R_SIZE * sizeof(double)) != hipSuccess ||
        hipHostMalloc((void **)&ctx->h_results, R_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess ||
@@ -1450,11 +1453,12 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
        hipHostMalloc((void **)&ctx->h_flags, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
    {
       g_create_err = "context allocation failed";
+      if (ctx->self_pinned) (void)hipHostUnregister(ctx);
       delete ctx;
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
-   if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; delete ctx; return DDCMI_ENOMEM; }
+   if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
    { const char *ov = getenv("DDCMI_HALO_OVERLAP"); ctx->halo_overlap = (ov && atoi(ov) != 0); }
@@ -1497,6 +1501,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
    for (int k = 0; k < 3; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
    (void)hipStreamDestroy(ctx->stream);
+   if (ctx->self_pinned) (void)hipHostUnregister(ctx);
    delete ctx;
 }
 

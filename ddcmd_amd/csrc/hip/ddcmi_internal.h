@@ -178,7 +178,7 @@ struct ddcmi_ctx
    /* reductions */
    dbuf<double> partials, bpartials; int npartial_blocks = 0;
    double *d_results = nullptr; double *h_results = nullptr;
-   int *d_flags = nullptr; int *h_flags = nullptr;
+   int *d_flags = nullptr; int *h_flags = nullptr; bool self_pinned = false;
    /* growable pinned host staging (so that small copies are truly asynchronous): [0] tile work, [1] tile order, [2] count exchange */
    int *h_pin[3] = {nullptr, nullptr, nullptr}; size_t h_pin_cap[3] = {0, 0, 0};
    int *pinned(int which, size_t n)
