@@ -1696,6 +1696,12 @@ extern "C" int ddcmi_get_box(const ddcmi_ctx *ctx, double h[9])
    for (int k = 0; k < 9; k++) h[k] = ctx->h[k];
    return DDCMI_OK;
 }
+extern "C" int ddcmi_set_barostat_isotropic(ddcmi_ctx *ctx, int on)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   ctx->baro_iso = on != 0;
+   return DDCMI_OK;
+}
 extern "C" int ddcmi_get_barostat_pressure(const ddcmi_ctx *ctx, double p[3])
 {
    if (!ctx || !p) return DDCMI_EINVAL;
@@ -2366,6 +2372,7 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
          ctx->pmol[0] = pxx + ctx->baro_P0; ctx->pmol[1] = pyy + ctx->baro_P0; ctx->pmol[2] = pzz + ctx->baro_P0;
          const double btt = ctx->baro_beta * dt / ctx->baro_tau;
          double pl = 0.5 * (pxx + pyy);
+         if (ctx->baro_iso) pl = pzz = (1.0 / 3.0) * (pxx + pyy + pzz);          /* molecularPressureGPU.cu:211 */
          double l[3] = {cbrt(1.0 + pl * btt), cbrt(1.0 + pl * btt), cbrt(1.0 + pzz * btt)};
          for (int a = 0; a < 3; a++)
          {

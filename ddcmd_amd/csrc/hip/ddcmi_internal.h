@@ -148,6 +148,7 @@ struct ddcmi_ctx
    dbuf<double> red_tmp;               /* k_reduce_jobs: per-workgroup rows of a split job + ticket counters */
    dbuf<double4> pos0; dbuf<double> disp;   /* updateRate == 0: positions at the last rebuild; [0..2] sum of r-r0, [4] max |dr|^2 */
    double baro_T = 0, baro_P0 = 0, baro_beta = 0, baro_tau = 0;      /* NGLFCONSTRAINT's Berendsen barostat; beta = 0: off */
+   bool baro_iso = false;                                           /* one scale factor from the mean of the three pressures (changeVolumeGPUisotropic) */
    double pmol[3] = {0, 0, 0};                                      /* molecular pressure (xx, yy, zz) the barostat last acted on */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */

@@ -419,7 +419,8 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       OBJECT *io = object_find(iname, "INTEGRATOR");
       if (!io) FAIL("INTEGRATOR %s not found", iname);
       s->integrator_type = get_string(io, "type", "NGLF");
-      if (strcmp(s->integrator_type, "NGLFCONSTRAINT") == 0)
+      s->npt_isotropic = strcmp(s->integrator_type, "NGLFGPULANGEVIN") == 0;      /* changeVolumeGPUisotropic, molecularPressureGPU.cu:204-239 */
+      if (strcmp(s->integrator_type, "NGLFCONSTRAINT") == 0 || s->npt_isotropic)
       {
          object_get(io, "T", &s->npt_T, WITH_UNITS, 1, "310", "T", NULL);
          object_get(io, "P0", &s->npt_P0, WITH_UNITS, 1, "0.0", "pressure", NULL);

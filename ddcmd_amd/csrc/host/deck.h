@@ -89,6 +89,8 @@ typedef struct ddcmi_setup
     * [cons_off[r], cons_off[r+1]); cons_grp = the constraint list (group) of the pair inside its residue */
    int *cons_off, *consI, *consJ, *cons_grp;
    double *cons_r0;
+   /* INTEGRATOR type=NGLFGPULANGEVIN (nglfGPU.cu:422-507): isotropic barostat, every bead under group 0's Langevin thermostat */
+   int npt_isotropic;
 } ddcmi_setup;
 
 /* Load a deck.  object_file is required; restart_file may be NULL (then

@@ -242,7 +242,20 @@ INTEGRATOR *integrator_init(void *parent, const char *name, const char *type)
    INTEGRATOR *in = calloc(1, sizeof(INTEGRATOR));
    in->name = strdup(name); in->type = strdup(type); in->parent = parent;
    const ddcmi_setup *su = parent ? ((SIMULATE *)parent)->setup : NULL;
-   const int npt_ok = su && strcmp(type, "NGLFCONSTRAINT") == 0;
+   const int gpulang = su && strcmp(type, "NGLFGPULANGEVIN") == 0;
+   const int npt_ok = su && (strcmp(type, "NGLFCONSTRAINT") == 0 || gpulang);
+   if (gpulang)
+   {
+      /* nglfGPULangevin (nglfGPU.cu:422-507): EVERY bead gets the Langevin update with the parameters of the
+       * first group (:469-473), whatever the GROUP objects say; the barostat is the isotropic one.  The
+       * reference leaves its T/P0/beta/tauBarostat uninitialised (nglf_parms, nglfGPU.cu:41-50): here they
+       * are read from the INTEGRATOR object like nglfconstraint_parms does. */
+      ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+      if (su->ngroup < 1 || su->group_type[0] != DDCMI_GROUP_LANGEVIN) die("integrator_init", "NGLFGPULANGEVIN needs the first GROUP to be of type LANGEVIN");
+      int gt[32]; double gT[32], gtau[32]; int giv[32];
+      for (int g = 0; g < su->ngroup && g < 32; g++) { gt[g] = DDCMI_LANGEVIN; gT[g] = su->group_Teq[0]; gtau[g] = su->group_tau[0]; giv[g] = 1; }
+      if (ddcmi_set_groups(ctx, su->ngroup, gt, gT, gtau, giv) != DDCMI_OK || ddcmi_set_barostat_isotropic(ctx, 1) != DDCMI_OK) die("integrator_init", ddcmi_last_error(ctx));
+   }
    if (npt_ok || strcmp(type, "NGLF") == 0 || strcmp(type, "NVTGLF") == 0 || strcmp(type, "NGLFGPU") == 0 || strcmp(type, "NGLFHIP") == 0)
    {
       /* NGLFCONSTRAINT = nglf + velocity constraints + the barostat of changeVolume (nglfconstraint.c:510-574) */
@@ -253,7 +266,7 @@ INTEGRATOR *integrator_init(void *parent, const char *name, const char *type)
    else
    {
       char msg[256];
-      snprintf(msg, sizeof(msg), "INTEGRATOR type %s is not on this path (NGLF, NVTGLF, NGLFGPU, NGLFHIP are)", type);
+      snprintf(msg, sizeof(msg), "INTEGRATOR type %s is not on this path (NGLF, NVTGLF, NGLFGPU, NGLFHIP, NGLFGPULANGEVIN, NGLFCONSTRAINT are)", type);
       die("integrator_init", msg);
    }
    return in;

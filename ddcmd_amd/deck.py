@@ -70,6 +70,7 @@ class Setup(object):
         self.has_accelerator = 0
         self.rng_seed = 0
         self.npt_T = self.npt_P0 = self.npt_beta = self.npt_tau = 0.0
+        self.npt_isotropic = 0
         self.nresicons = 0
         self.nrest, self.rest_origin = 0, 0
         self.rest_gid = np.zeros(0, np.uint64)
@@ -112,6 +113,7 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
         s.h = np.array(list(c.h), dtype=np.float64)
         s.rng_seed = int(c.rng_seed)
         s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = float(c.npt_T), float(c.npt_P0), float(c.npt_beta), float(c.npt_tau)
+        s.npt_isotropic = int(c.npt_isotropic)
         s.nresicons = int(c.nresicons)
         s.nrest, s.rest_origin = int(c.nrest), int(c.rest_origin)
         s.rest_gid = _arr(c.rest_gid, s.nrest, np.uint64) if s.nrest else np.zeros(0, np.uint64)

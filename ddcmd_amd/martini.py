@@ -53,6 +53,7 @@ def _declare(lib):
     lib.ddcmi_set_barostat.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     lib.ddcmi_get_box.argtypes = [vp, _dp]
     lib.ddcmi_get_barostat_pressure.argtypes = [vp, _dp]
+    lib.ddcmi_set_barostat_isotropic.argtypes = [vp, ctypes.c_int]
     lib.ddcmi_set_molecule_lists.argtypes = [vp, ctypes.c_long, ctypes.c_int, _ip, _ip]
     lib.ddcmi_set_constraints.argtypes = [vp, ctypes.c_int, _ip, _ip, _ip, _dp]
     lib.ddcmi_constraint_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -237,7 +238,7 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
         self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
         if float(getattr(s, "npt_beta", 0.0)) > 0.0:      # INTEGRATOR type=NGLFCONSTRAINT: barostat on the molecular pressure
-            self.set_barostat(float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau))
+            self.set_barostat(float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau), isotropic=bool(getattr(s, "npt_isotropic", 0)))
         if constraints:                                   # INTEGRATOR type=NGLFCONSTRAINT: velocity constraints
             self._cons = expand_constraints(s)
             po, pi, pj, dd = self._cons
@@ -304,9 +305,10 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
         return rk.value, t
 
-    def set_barostat(self, T, P0, beta, tau):
-        """nglfconstraint's Berendsen barostat; the molecule lists feed its molecular virial"""
+    def set_barostat(self, T, P0, beta, tau, isotropic=False):
+        """nglfconstraint's Berendsen barostat (isotropic: NGLFGPULANGEVIN's); the molecule lists feed its molecular virial"""
         self._chk(self.lib.ddcmi_set_barostat(self.ctx, float(T), float(P0), float(beta), float(tau)))
+        self._chk(self.lib.ddcmi_set_barostat_isotropic(self.ctx, int(bool(isotropic))))
         nmol, off, atoms = self._mols = molecule_lists(self.s)
         self._chk(self.lib.ddcmi_set_molecule_lists(self.ctx, nmol, int(off.size - 1), _i(off), _i(atoms if atoms.size else np.zeros(1, np.int32))))
 

@@ -108,6 +108,10 @@ int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *
  * box and positions scaled before the FRONT kick.  beta = 0 switches it off.  One domain; costs one host
  * round trip per step.  Without ddcmi_set_molecule_lists every bead is its own molecule.  Internal units. */
 int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau);
+/* on: ONE scale factor for the three axes, from the mean of Pxx, Pyy, Pzz -- what the reference's GPU integrator
+ * NGLFGPULANGEVIN applies (changeVolumeGPUisotropic, molecularPressureGPU.cu:204-239); off (default): changeVolume's
+ * semi-isotropic form */
+int ddcmi_set_barostat_isotropic(ddcmi_ctx *ctx, int on);
 /* current box (it changes under the barostat) */
 int ddcmi_get_box(const ddcmi_ctx *ctx, double h[9]);
 /* the molecular pressure (xx, yy, zz; molecularPressure.c:57-67) the barostat acted on in the last step */

@@ -737,6 +737,7 @@ void orc_barostat(orc_params *p, int n, double *rx, double *ry, double *rz, cons
    double pxx = (virial[0] + NkT) / vol - P0, pyy = (virial[1] + NkT) / vol - P0, pzz = (virial[2] + NkT) / vol - P0;
    double btt = beta * dt / tau;
    double Pxx = 0.5 * (pxx + pyy);                                     /* semi-isotropic: changeVolume */
+   if (p->baro_isotropic) Pxx = pzz = (1.0 / 3.0) * (pxx + pyy + pzz);
    double l[3] = {cbrt(1.0 + Pxx * btt), cbrt(1.0 + Pxx * btt), cbrt(1.0 + pzz * btt)};
    for (int a = 0; a < 3; a++) if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;   /* box.c:44 */
    p->hxx *= l[0]; p->hyy *= l[1]; p->hzz *= l[2];
@@ -978,6 +979,7 @@ void orc_barostat_mol(orc_params *p, int n, double *rx, double *ry, double *rz,
    pxx -= P0; pyy -= P0; pzz -= P0;
    double btt = beta * dt / tau;
    double Pxx = 0.5 * (pxx + pyy);
+   if (p->baro_isotropic) Pxx = pzz = (1.0 / 3.0) * (pxx + pyy + pzz);
    double l[3] = {cbrt(1.0 + Pxx * btt), cbrt(1.0 + Pxx * btt), cbrt(1.0 + pzz * btt)};
    for (int a = 0; a < 3; a++) if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;
    p->hxx *= l[0]; p->hyy *= l[1]; p->hzz *= l[2];

@@ -81,6 +81,7 @@ typedef struct orc_params
     * atom offsets inside the residue, cons_grp = constraint list of the pair.  NULL cons_off: none. */
    const int *cons_off, *consI, *consJ, *cons_grp;
    const double *cons_r0;
+   int baro_isotropic;         /* 1: changeVolumeGPUisotropic (molecularPressureGPU.cu:204-239) instead of changeVolume's semi-isotropic form */
 } orc_params;
 
 /* energies returned by orc_forces: */

@@ -34,6 +34,7 @@ class OrcParams(ctypes.Structure):
         ("excludePotentialTerm", ctypes.c_int),
         ("nrest", ctypes.c_int), ("rest_gid", up), ("rest_fc", ip), ("rest_r0", dp), ("rest_kb", dp), ("rest_origin", ctypes.c_int),
         ("cons_off", ip), ("consI", ip), ("consJ", ip), ("cons_grp", ip), ("cons_r0", dp),
+        ("baro_isotropic", ctypes.c_int),
     ]
 
 
@@ -135,6 +136,7 @@ class Oracle(object):
                 a = np.zeros(1, np.int32)
             self._keep[k] = a
             setattr(p, k, _i(a))
+        p.baro_isotropic = int(getattr(s, "npt_isotropic", 0))
         # distance constraints (nglfconstraint); off unless constraints=True
         self.constraints = bool(constraints) and int(np.asarray(getattr(s, "cons_off", [0]))[-1]) > 0
         if self.constraints:

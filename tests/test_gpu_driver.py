@@ -190,3 +190,30 @@ def test_ddcmi_md_nglfconstraint_with_constraint_lists(tmp_path):
         assert abs(row[4] - cE * e["total"] / n) < 1e-6 * abs(row[4]) + 1e-9, k
         assert abs(row[5] - cT * info["temperature"]) < 1e-6 * row[5], k
         assert info["temperature"] > 2.0 * rk / (3.0 * n)          # 3N - nConstraints degrees of freedom
+
+
+def test_ddcmi_md_nglfgpulangevin(tmp_path):
+    """INTEGRATOR type=NGLFGPULANGEVIN, the reference's GPU production integrator (nglfGPU.cu:422-507): the isotropic
+    barostat (changeVolumeGPUisotropic) and the Langevin update with the first group's parameters on every bead"""
+    data = str(tmp_path / "data")
+    extra = "nglf INTEGRATOR {type = NGLFGPULANGEVIN; T = 310 K; P0 = 1 bar; beta = 3.0e-4 1/bar; tauBarostat = 1 ps;}"
+    out = subprocess.run([EXE, "-o", WATER_DECK, "-d", data, "-x", extra], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    rows = np.loadtxt(data, comments="#", ndmin=2)
+    s = load_deck(WATER_DECK, extra_objects=extra)
+    assert s.integrator_type == "NGLFGPULANGEVIN" and s.npt_isotropic == 1 and s.npt_beta > 0
+    s.group_type[:] = 2                       # every bead under group 0's thermostat
+    s.group_Teq[:] = s.group_Teq[0]
+    s.group_tau[:] = s.group_tau[0]
+    o = pyoracle.Oracle(s)
+    e, vir = o.forces()
+    rk, tion = o.kinetic()
+    n = s.natoms
+    cE, cL = units_convert(1, None, "kJ/mol"), units_convert(1, None, "Angstrom")
+    for k, row in enumerate(rows):
+        assert abs(row[2] - cE * (e["total"] + rk) / n) < 1e-6 * abs(row[2]) + 1e-9, k
+        assert np.abs(row[8:11] - cL * o.box).max() < 1e-7, k
+        assert abs(row[8] - row[9]) < 1e-9 * row[8] and abs(row[8] - row[10]) < 1e-9 * row[8]       # one scale factor: the cube stays a cube
+        if k + 1 < len(rows):
+            e, vir, rk, tion = o.step_npt(s.printrate, s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau)
+    assert abs(rows[-1, 8] - rows[0, 8]) > 1e-6
