@@ -106,18 +106,34 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
 __global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int *rank, int *cell_cnt)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= nloc) return;
-   double4 p = pos[i];
-   /* backInBox_fast: PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
-   if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
-   if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
-   if (gp.pbc & 4) { if (p.z > 0.5 * gp.L[2]) p.z -= gp.L[2]; if (p.z < -0.5 * gp.L[2]) p.z += gp.L[2]; }
-   pos[i] = p;
-   int cx, cy, cz;
-   cell_coords(gp, p.x, p.y, p.z, true, cx, cy, cz);
-   int c = cell_linear(gp, cx, cy, cz);
-   cid[i] = c;
-   rank[i] = atomicAdd(&cell_cnt[c], 1);
+   int c = -1;
+   if (i < nloc)
+   {
+      double4 p = pos[i];
+      /* backInBox_fast: PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
+      if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
+      if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
+      if (gp.pbc & 4) { if (p.z > 0.5 * gp.L[2]) p.z -= gp.L[2]; if (p.z < -0.5 * gp.L[2]) p.z += gp.L[2]; }
+      pos[i] = p;
+      int cx, cy, cz;
+      cell_coords(gp, p.x, p.y, p.z, true, cx, cy, cz);
+      c = cell_linear(gp, cx, cy, cz);
+      cid[i] = c;
+   }
+   /* the beads arrive in the order of the previous sort, so a wave holds runs of beads of one cell: one
+    * atomic per run instead of one per bead (the final in-cell order is fixed by k_sort_cells) */
+   const int lane = threadIdx.x & 63;
+   const int cprev = __shfl_up(c, 1, 64);
+   const bool head = lane == 0 || cprev != c;
+   const unsigned long long hb = __ballot(head);
+   const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+   const int hl = 63 - __clzll((long long)(hb & upto));
+   const unsigned long long after = hl == 63 ? 0ull : (hb & ~((2ull << hl) - 1ull));
+   const int len = (after ? __ffsll((long long)after) - 1 : 64) - hl;
+   int base = 0;
+   if (head && c >= 0) base = atomicAdd(&cell_cnt[c], len);
+   base = __shfl(base, hl, 64);
+   if (c >= 0) rank[i] = base + (lane - hl);
 }
 __global__ void k_scatter_order(int n, const int *cid, const int *rank, const int *cell_start, int *order)
 {
