@@ -311,20 +311,21 @@ struct GatherRows
    const double4 *apar;                  /* {k, theta0, func, 0} */
    const double4 *tpar;                  /* {k, delta, func, n} */
    int nheavy; const int *hatoms;        /* atoms with func-1 angles or dihedrals */
+   int nlight; const int *latoms;        /* atoms with bonds or func 2/10 angles, caller order: a molecule's atoms are neighbouring lanes */
 };
 template <bool HEAVY>      /* false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers) */
-__global__ __launch_bounds__(256) void k_bonded_gather(int nloc, GatherRows gr, const int *__restrict__ orig, const int *__restrict__ slot, BoxArgs box, int excl_mask,
+__global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, BoxArgs box, int excl_mask,
                                                        const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double *partials)
 {
-   /* light launch: lane = device slot (coalesced force update); heavy launch: lane = entry of the short
-    * list of atoms that have heavy terms */
+   /* lane = entry of the list of atoms that have terms of this launch, in caller order: the lanes of a
+    * molecule sit together, so their rows are read with unit stride and the partners' bead records are the
+    * neighbouring lanes' own */
    const int j = blockIdx.x * 256 + threadIdx.x;
    double acc[GB_NV];
 #pragma unroll
    for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
    int i = j, o = gr.nrow;
-   if (HEAVY) { if (j < gr.nheavy) { o = gr.hatoms[j]; i = slot[o]; } }
-   else if (j < nloc) o = orig[j];
+   if (j < (HEAVY ? gr.nheavy : gr.nlight)) { o = HEAVY ? gr.hatoms[j] : gr.latoms[j]; i = slot[o]; }
    if (o < gr.nrow)
    {
       const int b0 = HEAVY ? 0 : gr.boff[o], b1 = HEAVY ? 0 : gr.boff[o + 1], a0 = HEAVY ? gr.haoff[o] : gr.aoff[o], a1 = HEAVY ? gr.haoff[o + 1] : gr.aoff[o + 1];
@@ -642,6 +643,10 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
       for (int a = 0; a < nrow; a++) if (haoff[a + 1] > haoff[a] || toff[a + 1] > toff[a]) hatoms.push_back(a);
       ctx->inc_heavy = (int)hatoms.size();
       hatoms.push_back(0);
+      std::vector<int> latoms;
+      for (int a = 0; a < nrow; a++) if (boff[a + 1] > boff[a] || aoff[a + 1] > aoff[a]) latoms.push_back(a);
+      ctx->inc_light = (int)latoms.size();
+      latoms.push_back(0);
       {
          std::vector<int> fill(toff.begin(), toff.end() - 1);
          for (int t = 0; t < ntors; t++)
@@ -659,7 +664,7 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
       for (int k = 0; k < 3; k++) if (ids[k].size() >= (1u << 29)) SETERR(ctx, DDCMI_EINVAL, "too many distinct bonded parameter sets");
       for (int k = 0; k < 3; k++) par[k].resize(par[k].size() + 4, 0.0);
       if ((rc = up(ctx, ctx->inc_boff, boff.data(), boff.size())) || (rc = up(ctx, ctx->inc_aoff, aoff.data(), aoff.size())) || (rc = up(ctx, ctx->inc_toff, toff.data(), toff.size())) ||
-          (rc = up(ctx, ctx->inc_hatoms, hatoms.data(), hatoms.size())) || (rc = up(ctx, ctx->inc_haoff, haoff.data(), haoff.size())) || (rc = up(ctx, ctx->inc_harow, harow.data(), harow.size())) ||
+          (rc = up(ctx, ctx->inc_hatoms, hatoms.data(), hatoms.size())) || (rc = up(ctx, ctx->inc_latoms, latoms.data(), latoms.size())) || (rc = up(ctx, ctx->inc_haoff, haoff.data(), haoff.size())) || (rc = up(ctx, ctx->inc_harow, harow.data(), harow.size())) ||
           (rc = up(ctx, ctx->inc_brow, brow.data(), brow.size())) || (rc = up(ctx, ctx->inc_arow, arow.data(), arow.size())) || (rc = up(ctx, ctx->inc_trow, trow.data(), trow.size())) ||
           (rc = up(ctx, ctx->inc_bpar, par[0].data(), par[0].size())) || (rc = up(ctx, ctx->inc_apar, par[1].data(), par[1].size())) || (rc = up(ctx, ctx->inc_tpar, par[2].data(), par[2].size()))) return rc;
       ctx->inc_nrow = nrow;
@@ -846,16 +851,17 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    if (!ctx->bonded_gid)
    {
       /* one domain: one lane per bead, no atomics */
-      const int nblk = cdiv(ctx->nloc, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
+      const int nblk = cdiv(ctx->inc_light, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
       ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
       GatherRows gr = {ctx->inc_nrow, ctx->inc_boff.p, ctx->inc_aoff.p, ctx->inc_haoff.p, ctx->inc_toff.p, (const int2 *)ctx->inc_brow.p, (const int4 *)ctx->inc_arow.p,
                        (const int4 *)ctx->inc_harow.p, (const int4 *)ctx->inc_trow.p,
-                       (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p};
+                       (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p, ctx->inc_light, ctx->inc_latoms.p};
       double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
-      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, ctx->nloc, gr, ctx->orig.p, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
+      if (nblk > 0)
+      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->bpartials.p);
       if (nblk2 > 0)
-         hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, ctx->nloc, gr, ctx->orig.p, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
+         hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
                             ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, p2);
       hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
       return DDCMI_OK;

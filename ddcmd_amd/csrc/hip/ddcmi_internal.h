@@ -169,7 +169,7 @@ struct ddcmi_ctx
    dbuf<int> mol_off, mol_atoms;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
    /* one domain: rows of the bead-parallel bonded kernel (atom -> its terms), built in ddcmi_set_bonded */
-   int inc_nrow = 0, inc_heavy = 0; dbuf<int> inc_boff, inc_aoff, inc_haoff, inc_toff, inc_brow, inc_arow, inc_harow, inc_trow, inc_hatoms; dbuf<double> inc_bpar, inc_apar, inc_tpar;
+   int inc_nrow = 0, inc_heavy = 0, inc_light = 0; dbuf<int> inc_boff, inc_aoff, inc_haoff, inc_toff, inc_brow, inc_arow, inc_harow, inc_trow, inc_hatoms, inc_latoms; dbuf<double> inc_bpar, inc_apar, inc_tpar;
    bool bonded_gid = false;
    int g_nbond = 0, g_nangle = 0, g_ntors = 0;
    dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;
