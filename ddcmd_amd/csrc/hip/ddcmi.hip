@@ -1478,6 +1478,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
    { const char *ov = getenv("DDCMI_HALO_OVERLAP"); ctx->halo_overlap = (ov && atoi(ov) != 0); }
+   { const char *gv = getenv("DDCMI_GRAPH_MAX_BEADS"); if (gv) ctx->graph_max_beads = atoi(gv); }      /* 0 switches the step graph off */
    ctx->gtype.assign(1, DDCMI_FREE); ctx->ginterval.assign(1, 1); ctx->gTeq.assign(1, 0); ctx->gtau.assign(1, 0);
    ctx->glambda.assign(1, 1.0); ctx->gTsum.assign(1, 0); ctx->gT.assign(1, 0); ctx->gnT.assign(1, 0); ctx->gdoScaling.assign(1, 0);
    *out = ctx;
@@ -1514,6 +1515,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
    for (int k = 0; k < 3; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
    (void)hipStreamDestroy(ctx->stream);
@@ -2055,11 +2057,13 @@ static int schedule_tiles(ddcmi_ctx *ctx)
 }
 
 /* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
+static void graph_drop(ddcmi_ctx *ctx);
 int ddcmi_bl_finish(ddcmi_ctx *ctx)
 {
    GridParams &gp = ctx->gp;
    hipStream_t st = ctx->stream;
    int n = ctx->nloc;
+   graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
    /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
    ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
    int ntile = gp.T[0] * gp.T[1] * gp.T[2];
@@ -2419,9 +2423,47 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
    return DDCMI_OK;
 }
 /* nglf.c:97-108: ddcenergy, BACK half kick, kinetic_terms, group Update */
+static void graph_drop(ddcmi_ctx *ctx)
+{
+   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+   ctx->graph_exec = nullptr; ctx->graph_state = 0;
+}
+/* may the steady-state step be replayed as a graph?  Only when its kernel arguments are the same every
+ * step: all groups FREE (no thermostat scalars), no barostat, no constraints, one domain, no event timing */
+static bool graph_ok(const ddcmi_ctx *ctx, double dt)
+{
+   if (ctx->graph_max_beads <= 0 || ctx->nloc > ctx->graph_max_beads || ctx->nloc <= 0) return false;
+   if (ctx->group_ || ctx->nranks > 1 || ctx->loopback || ctx->timing || ctx->baro_beta > 0.0 || ctx->ncgroup > 0) return false;
+   for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE) return false;
+   return ctx->graph_state < 2 || ctx->graph_dt == dt;
+}
 static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
 {
    int rc;
+   if (more_steps && graph_ok(ctx, dt))
+   {
+      GroupLambda lam = front_lambda(ctx, dt);
+      if (ctx->graph_state == 1)
+      {
+         /* the previous plain step sized every buffer: record this one */
+         hipGraph_t graph = nullptr;
+         HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+         rc = launch_forces(ctx, true);
+         if (!rc) rc = launch_kinetic(ctx, dt, 1, true, &lam, true);
+         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+         if (e == hipSuccess && graph && hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) { ctx->graph_state = 2; ctx->graph_dt = dt; }
+         else { (void)hipGetLastError(); ctx->graph_exec = nullptr; ctx->graph_state = 0; ctx->graph_max_beads = 0; }      /* no graphs on this runtime: plain launches from now on */
+         if (graph) (void)hipGraphDestroy(graph);
+      }
+      if (ctx->graph_state == 2)
+      {
+         HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+         ctx->drift_done = true;
+         return DDCMI_OK;
+      }
+      if (ctx->graph_state == 0 && ctx->graph_max_beads > 0) ctx->graph_state = 1;      /* after the plain step below */
+   }
    if ((rc = launch_forces(ctx, true))) return rc;
    berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
    GroupLambda lam = front_lambda(ctx, dt);

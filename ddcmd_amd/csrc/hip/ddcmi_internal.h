@@ -195,6 +195,12 @@ struct ddcmi_ctx
    double self_ele = 0.0;
    bool forces_valid = false;
    /* timing */
+   /* hipGraph of one steady-state step (forces + fused BACK kick / kinetic terms / FRONT kick / drift): small
+    * systems are launch-bound -- five short kernels per step -- and can replay the step as one graph launch
+    * between list rebuilds.  OFF by default (DDCMI_GRAPH_MAX_BEADS=<n> enables it up to n beads): on ROCm 7.2 /
+    * MI355X the replay is slower than the five plain launches (6.9 k beads: 86 vs 74 us per step, 62 k: 105 vs 92,
+    * 256 k: 136 vs 126).  graph_state 0: none, 1: buffers sized by a plain step, 2: graph_exec is valid */
+   int graph_state = 0; hipGraphExec_t graph_exec = nullptr; double graph_dt = 0; int graph_max_beads = 0;
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
    /* comm */
    int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
