@@ -52,29 +52,6 @@ __device__ __forceinline__ void block_store(double (&v)[NV], double *out)
    __syncthreads();
    if (threadIdx.x < NV) out[threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
-/* Where a term's atoms and parameters live.
- *   one domain: the bead-parallel kernel k_bonded_gather is used instead (no TermMap).
- *   decomposed run: atoms[] holds device slots (owned or halo) of the terms this rank
- *     touches, rebuilt with the lists (ddcmi_bonded_localize); tmap[t] = parameter row.
- * A rank adds forces only to the atoms it owns (slot < nloc) and counts a term's
- * energy and virial with weight (atoms it owns)/(atoms of the term): every term is then
- * counted exactly once over all ranks, with no force return traffic. */
-struct TermMap { const int *atoms; const int *slot; const int *tmap; int nloc; };
-__device__ __forceinline__ int term_atom(const TermMap &m, int na, int t, int a) { return m.atoms[na * t + a]; }
-__device__ __forceinline__ int term_row(const TermMap &m, int t) { return m.tmap ? m.tmap[t] : t; }
-__device__ __forceinline__ void addf(const TermMap &m, double *fx, double *fy, double *fz, int i, double x, double y, double z)
-{
-   if (i < m.nloc) { atomicAdd(&fx[i], x); atomicAdd(&fy[i], y); atomicAdd(&fz[i], z); }
-}
-template <int NV>
-__device__ __forceinline__ void weigh(double (&acc)[NV], const TermMap &m, int nown, int na)
-{
-   if (nown == na) return;
-   double w = (double)nown / (double)na;
-#pragma unroll
-   for (int k = 0; k < NV; k++) acc[k] *= w;
-}
-
 /* resBondSorted (bioCharmmCovalentEnergiesSorted.c:18-116): fD = force on atom I, -fD on J */
 __device__ __forceinline__ void bond_eval(const BoxArgs &box, const double4 &pI, const double4 &pJ, double kb, double b0,
                                           double &e, double (&fD)[3], double (&vir)[6])
@@ -216,89 +193,18 @@ __device__ __forceinline__ bool tors_eval(const BoxArgs &box, const double4 &pI,
    return true;
 }
 
-/* term-parallel kernels (decomposed runs): one lane per term, forces by atomic adds */
-__global__ __launch_bounds__(256) void k_bond(int nbond, BoxArgs box, TermMap tm, const double *__restrict__ kb_, const double *__restrict__ b0_,
-                                              const double4 *__restrict__ pos,
-                                              double *fx, double *fy, double *fz, double *partials)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* e, xx,yy,zz,xy,xz,yz */
-   if (t < nbond)
-   {
-      int I = term_atom(tm, 2, t, 0), J = term_atom(tm, 2, t, 1);
-      const int g = term_row(tm, t);
-      double e, fD[3], vir[6];
-      bond_eval(box, pos[I], pos[J], kb_[g], b0_[g], e, fD, vir);
-      addf(tm, fx, fy, fz, I, fD[0], fD[1], fD[2]);
-      addf(tm, fx, fy, fz, J, -fD[0], -fD[1], -fD[2]);
-      acc[0] = e;
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc[1 + k] = vir[k];
-      weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc), 2);
-   }
-   block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
-}
-
-__global__ __launch_bounds__(256) void k_angle(int nangle, BoxArgs box, TermMap tm, const int *__restrict__ func,
-                                               const double *__restrict__ kt_, const double *__restrict__ t0_, int excl_mask,
-                                               const double4 *__restrict__ pos,
-                                               double *fx, double *fy, double *fz, double *partials)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-   if (t < nangle)
-   {
-      const int g = term_row(tm, t);
-      int I = term_atom(tm, 3, t, 0), J = term_atom(tm, 3, t, 1), K = term_atom(tm, 3, t, 2);
-      double e, fI[3], fK[3], vir[6];
-      if (angle_eval(box, pos[I], pos[J], pos[K], func[g], kt_[g], t0_[g], excl_mask, e, fI, fK, vir))
-      {
-         addf(tm, fx, fy, fz, I, fI[0], fI[1], fI[2]);
-         addf(tm, fx, fy, fz, K, fK[0], fK[1], fK[2]);
-         addf(tm, fx, fy, fz, J, -(fI[0] + fK[0]), -(fI[1] + fK[1]), -(fI[2] + fK[2]));
-         acc[0] = e;
-#pragma unroll
-         for (int k = 0; k < 6; k++) acc[1 + k] = vir[k];
-         weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc) + (K < tm.nloc), 3);
-      }
-   }
-   block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
-}
-
-__global__ __launch_bounds__(256) void k_torsion(int ntors, BoxArgs box, TermMap tm, const int *__restrict__ func, const int *__restrict__ nn_,
-                                                 const double *__restrict__ kk_, const double *__restrict__ delta_, int excl_mask,
-                                                 const double4 *__restrict__ pos,
-                                                 double *fx, double *fy, double *fz, double *partials)
-{
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* e_tors, e_impr, xx,yy,zz,xy,xz,yz */
-   if (t < ntors)
-   {
-      const int g = term_row(tm, t);
-      int I = term_atom(tm, 4, t, 0), J = term_atom(tm, 4, t, 1), K = term_atom(tm, 4, t, 2), L = term_atom(tm, 4, t, 3);
-      double et, ei, fI[3], fJ[3], fK[3], fL[3], vir[6];
-      if (tors_eval(box, pos[I], pos[J], pos[K], pos[L], func[g], nn_[g], kk_[g], delta_[g], excl_mask, et, ei, fI, fJ, fK, fL, vir))
-      {
-         addf(tm, fx, fy, fz, I, fI[0], fI[1], fI[2]);
-         addf(tm, fx, fy, fz, J, fJ[0], fJ[1], fJ[2]);
-         addf(tm, fx, fy, fz, K, fK[0], fK[1], fK[2]);
-         addf(tm, fx, fy, fz, L, fL[0], fL[1], fL[2]);
-         acc[0] = et; acc[1] = ei;
-#pragma unroll
-         for (int k = 0; k < 6; k++) acc[2 + k] = vir[k];
-         weigh(acc, tm, (I < tm.nloc) + (J < tm.nloc) + (K < tm.nloc) + (L < tm.nloc), 4);
-      }
-   }
-   block_store<8>(acc, partials + (size_t)blockIdx.x * 8);
-}
-
-/* bead-parallel kernel (one domain): one lane per bead walks the terms the bead takes part in, evaluates each
+/* bead-parallel kernel: one lane per bead walks the terms the bead takes part in, evaluates each
  * and keeps the force on its own atom -- a term is evaluated once per atom it has, but no force is added
  * atomically (the term-parallel kernels above are bound by the rate of double-precision atomic adds: 6 to
  * 12 per term).  Rows (built once in ddcmi_set_bonded, by caller-order atom index, terms ascending: a fixed
  * summation order) name the OTHER atoms of the term, the lane's role in it and a row of the table of
  * distinct parameter sets: a bond costs one 8-byte row read, one index translation and one bead record.
- * Energy and virial are booked by the lane holding role 0. */
+ * Energy and virial are booked by the lane holding role 0.
+ * `slot` translates atom numbers to device slots: one domain -- caller-order index -> slot (slot_of_orig);
+ * decomposed run -- atoms are numbered by their place in the sorted list of gids that occur in terms, and
+ * slot_of_atom (refilled at every rebuild) holds the lowest slot carrying that gid here, owned copies
+ * first, or INT_MAX.  A rank works on the atoms it owns (slot < nown): forces need no return traffic, and
+ * every term's energy and virial are booked exactly once over all ranks, by the owner of its first atom. */
 #define GB_NV 10      /* e_bond, e_angle, e_tors, e_impr, virial xx yy zz xy xz yz */
 struct GatherRows
 {
@@ -314,7 +220,7 @@ struct GatherRows
    int nlight; const int *latoms;        /* atoms with bonds or func 2/10 angles, caller order: a molecule's atoms are neighbouring lanes */
 };
 template <bool HEAVY>      /* false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers) */
-__global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, BoxArgs box, int excl_mask,
+__global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, BoxArgs box, int excl_mask,
                                                        const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double *partials)
 {
    /* lane = entry of the list of atoms that have terms of this launch, in caller order: the lanes of a
@@ -326,7 +232,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
    for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
    int i = j, o = gr.nrow;
    if (j < (HEAVY ? gr.nheavy : gr.nlight)) { o = HEAVY ? gr.hatoms[j] : gr.latoms[j]; i = slot[o]; }
-   if (o < gr.nrow)
+   if (o < gr.nrow && i < nown)
    {
       const int b0 = HEAVY ? 0 : gr.boff[o], b1 = HEAVY ? 0 : gr.boff[o + 1], a0 = HEAVY ? gr.haoff[o] : gr.aoff[o], a1 = HEAVY ? gr.haoff[o + 1] : gr.aoff[o + 1];
       const int t0 = HEAVY ? gr.toff[o] : 0, t1 = HEAVY ? gr.toff[o + 1] : 0;
@@ -434,32 +340,7 @@ __global__ __launch_bounds__(256) void k_reduce_gather(const double *__restrict_
    }
 }
 
-/* one launch for the three term kinds: workgroup b sums the partials of kind b in a fixed order */
-struct RedB { const double *partials[3]; int nblocks[3]; int nv[3]; double *out[3]; };
-__global__ __launch_bounds__(256) void k_reduce_b(RedB rb)
-{
-   __shared__ double s[256];
-   const double *partials = rb.partials[blockIdx.x];
-   const int nblocks = rb.nblocks[blockIdx.x], nv = rb.nv[blockIdx.x];
-   double *out = rb.out[blockIdx.x];
-   if (nblocks <= 0) return;
-   for (int k = 0; k < nv; k++)
-   {
-      double a = 0.0;
-      for (int b = threadIdx.x; b < nblocks; b += 256) a += partials[(size_t)b * 8 + k];
-      s[threadIdx.x] = a;
-      __syncthreads();
-      for (int off = 128; off > 0; off >>= 1)
-      {
-         if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
-         __syncthreads();
-      }
-      if (threadIdx.x == 0) out[k] = s[0];
-      __syncthreads();
-   }
-}
-
-/* ---- decomposed runs: terms are given by gid and located among the owned + halo beads - */
+/* ---- decomposed runs: atoms of terms are named by gid and located among the owned + halo beads - */
 #define GID_EMPTY 0xffffffffffffffffull
 __device__ __forceinline__ unsigned gid_hash(uint64_t g, unsigned mask)
 {
@@ -493,39 +374,36 @@ __device__ __forceinline__ int gid_find(uint64_t g, unsigned mask, const unsigne
       h = (h + 1) & mask;
    }
 }
-/* pass 1: which of the global terms touch an owned bead; their slots.  flags[0] counts
- * terms with an owned atom whose partner is neither owned nor in the halo. */
-template <int NA>
-__global__ void k_term_locate(int nterm, const uint64_t *__restrict__ tgid, int nloc, unsigned mask, const unsigned long long *keys, const int *vals,
-                              int *sel, int *slots, int *flags)
+/* rebuild: slot_of_atom[a] = lowest slot holding the a-th gid of the term atoms, INT_MAX if it is not here */
+__global__ void k_atom_slots(int natom, const uint64_t *__restrict__ agid, unsigned mask, const unsigned long long *keys, const int *vals, int *slot_of_atom)
 {
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t >= nterm) return;
-   int s[NA], nown = 0, nmiss = 0;
-#pragma unroll
-   for (int a = 0; a < NA; a++)
-   {
-      s[a] = gid_find(tgid[(size_t)NA * t + a], mask, keys, vals);
-      nown += (s[a] >= 0 && s[a] < nloc);
-      nmiss += (s[a] < 0);
-   }
-   int take = nown > 0;
-   if (take && nmiss) { atomicAdd(&flags[0], 1); take = 0; }
-   sel[t] = take;
-#pragma unroll
-   for (int a = 0; a < NA; a++) slots[(size_t)NA * t + a] = s[a];
+   int a = blockIdx.x * blockDim.x + threadIdx.x;
+   if (a >= natom) return;
+   int s = gid_find(agid[a], mask, keys, vals);
+   slot_of_atom[a] = s < 0 ? 0x7fffffff : s;
 }
-/* pass 2: stable compaction (sel has been turned into an exclusive scan) */
-template <int NA>
-__global__ void k_term_compact(int nterm, const int *__restrict__ pre, const int *__restrict__ slots, int total, int *tmap, int *latoms)
+/* rebuild: every partner of an owned atom must be present (owned or halo); flags[0] counts the missing ones */
+__global__ void k_rows_check(GatherRows gr, const int *__restrict__ slot, int nown, int *flags)
 {
-   int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t >= nterm) return;
-   int o = pre[t], nxt = (t + 1 < nterm) ? pre[t + 1] : total;
-   if (nxt == o) return;
-   tmap[o] = t;
-#pragma unroll
-   for (int a = 0; a < NA; a++) latoms[(size_t)NA * o + a] = slots[(size_t)NA * t + a];
+   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+   int miss = 0;
+   for (int pass = 0; pass < 2; pass++)
+   {
+      if (j >= (pass ? gr.nheavy : gr.nlight)) continue;
+      const int o = pass ? gr.hatoms[j] : gr.latoms[j];
+      if (slot[o] >= nown) continue;
+      if (!pass)
+      {
+         for (int r = gr.boff[o]; r < gr.boff[o + 1]; r++) miss += slot[gr.brow[r].x] == 0x7fffffff;
+         for (int r = gr.aoff[o]; r < gr.aoff[o + 1]; r++) miss += (slot[gr.arow[r].x] == 0x7fffffff) + (slot[gr.arow[r].y] == 0x7fffffff);
+      }
+      else
+      {
+         for (int r = gr.haoff[o]; r < gr.haoff[o + 1]; r++) miss += (slot[gr.harow[r].x] == 0x7fffffff) + (slot[gr.harow[r].y] == 0x7fffffff);
+         for (int r = gr.toff[o]; r < gr.toff[o + 1]; r++) miss += (slot[gr.trow[r].x] == 0x7fffffff) + (slot[gr.trow[r].y] == 0x7fffffff) + (slot[gr.trow[r].z] == 0x7fffffff);
+      }
+   }
+   if (miss) atomicAdd(&flags[0], miss);
 }
 
 template <class T>
@@ -538,46 +416,23 @@ static int up(ddcmi_ctx *ctx, dbuf<T> &buf, const T *src, size_t n)
    return DDCMI_OK;
 }
 
-extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
-                                int nbond, const int *bond_ij, const double *bond_kb, const double *bond_b0,
-                                int nangle, const int *angle_ijk, const int *angle_func, const double *angle_k, const double *angle_t0,
-                                int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
-                                int excludePotentialTerm)
+/* Rows of k_bonded_gather from term lists over atom numbers (caller-order indices, or -- decomposed runs --
+ * positions in the sorted list of gids that occur in terms).  nbond = 0 when bonds are switched off. */
+static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const double *bond_kb, const double *bond_b0,
+                      int nangle, const int *angle_ijk, const int *angle_func, const double *angle_k, const double *angle_t0,
+                      int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta)
 {
-   if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
-   (void)hipSetDevice(ctx->device);
-   ctx->excludePotentialTerm = excludePotentialTerm;
-   ctx->bonded_gid = false; ctx->list_valid = false;
-   ctx->nbond = (excludePotentialTerm & 1) ? 0 : nbond;
-   ctx->nangle = nangle; ctx->ntors = ntors;
    int rc;
-   if (ctx->nbond > 0)
+   ctx->inc_nrow = 0; ctx->inc_light = 0; ctx->inc_heavy = 0;
+   ctx->nbond = nbond; ctx->nangle = nangle; ctx->ntors = ntors;
+   if (nbond + nangle + ntors > 0)
    {
-      if (!bond_ij || !bond_kb || !bond_b0) return DDCMI_EINVAL;
-      if ((rc = up(ctx, ctx->bond_ij, bond_ij, 2 * (size_t)nbond)) || (rc = up(ctx, ctx->bond_kb, bond_kb, nbond)) || (rc = up(ctx, ctx->bond_b0, bond_b0, nbond))) return rc;
-   }
-   if (nangle > 0)
-   {
-      if (!angle_ijk || !angle_func || !angle_k || !angle_t0) return DDCMI_EINVAL;
       for (int t = 0; t < nangle; t++)
          if (angle_func[t] != 1 && angle_func[t] != 2 && angle_func[t] != 10) SETERR(ctx, DDCMI_EINVAL, "angle %d: func %d is not 1, 2 or 10", t, angle_func[t]);
-      if ((rc = up(ctx, ctx->angle_ijk, angle_ijk, 3 * (size_t)nangle)) || (rc = up(ctx, ctx->angle_func, angle_func, nangle)) ||
-          (rc = up(ctx, ctx->angle_k, angle_k, nangle)) || (rc = up(ctx, ctx->angle_t0, angle_t0, nangle))) return rc;
-   }
-   if (ntors > 0)
-   {
-      if (!tors_ijkl || !tors_func || !tors_n || !tors_k || !tors_delta) return DDCMI_EINVAL;
       for (int t = 0; t < ntors; t++)
          if (tors_func[t] != 1 && tors_func[t] != 2) SETERR(ctx, DDCMI_EINVAL, "dihedral %d: func %d is not 1 or 2", t, tors_func[t]);
-      if ((rc = up(ctx, ctx->tors_ijkl, tors_ijkl, 4 * (size_t)ntors)) || (rc = up(ctx, ctx->tors_func, tors_func, ntors)) || (rc = up(ctx, ctx->tors_n, tors_n, ntors)) ||
-          (rc = up(ctx, ctx->tors_k, tors_k, ntors)) || (rc = up(ctx, ctx->tors_delta, tors_delta, ntors))) return rc;
-   }
-   /* rows of k_bonded_gather */
-   ctx->inc_nrow = 0;
-   if (ctx->nbond + nangle + ntors > 0)
-   {
       int amax = -1;
-      for (int k = 0; k < 2 * ctx->nbond; k++) { if (bond_ij[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a bond"); amax = std::max(amax, bond_ij[k]); }
+      for (int k = 0; k < 2 * nbond; k++) { if (bond_ij[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a bond"); amax = std::max(amax, bond_ij[k]); }
       for (int k = 0; k < 3 * nangle; k++) { if (angle_ijk[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in an angle"); amax = std::max(amax, angle_ijk[k]); }
       for (int k = 0; k < 4 * ntors; k++) { if (tors_ijkl[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a dihedral"); amax = std::max(amax, tors_ijkl[k]); }
       const int nrow = amax + 1;
@@ -611,11 +466,11 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
          for (int a = 0; a < nrow; a++) off[a + 1] += off[a];
          return off;
       };
-      std::vector<int> boff = offsets(bond_ij, ctx->nbond, 2), aoff = offsets_sel(la), haoff = offsets_sel(ha), toff = offsets(tors_ijkl, ntors, 4);
+      std::vector<int> boff = offsets(bond_ij, nbond, 2), aoff = offsets_sel(la), haoff = offsets_sel(ha), toff = offsets(tors_ijkl, ntors, 4);
       std::vector<int> brow(2 * (size_t)boff[nrow] + 2), arow(4 * (size_t)aoff[nrow] + 4), harow(4 * (size_t)haoff[nrow] + 4), trow(4 * (size_t)toff[nrow] + 4);
       {
          std::vector<int> fill(boff.begin(), boff.end() - 1);
-         for (int t = 0; t < ctx->nbond; t++)
+         for (int t = 0; t < nbond; t++)
          {
             const int id = pid(0, bond_kb[t], bond_b0[t], 0, 0);
             for (int r = 0; r < 2; r++) { size_t w = fill[bond_ij[2 * t + r]]++; brow[2 * w] = bond_ij[2 * t + 1 - r]; brow[2 * w + 1] = (id << 2) | r; }
@@ -672,10 +527,28 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
    /* the per-kind sums are only written by kernels that run: clear stale ones */
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->forces_valid = false;
+   ctx->forces_valid = false; ctx->list_valid = false;
    return DDCMI_OK;
 }
 
+extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
+                                int nbond, const int *bond_ij, const double *bond_kb, const double *bond_b0,
+                                int nangle, const int *angle_ijk, const int *angle_func, const double *angle_k, const double *angle_t0,
+                                int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
+                                int excludePotentialTerm)
+{
+   if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
+   if ((nbond > 0 && (!bond_ij || !bond_kb || !bond_b0)) || (nangle > 0 && (!angle_ijk || !angle_func || !angle_k || !angle_t0)) ||
+       (ntors > 0 && (!tors_ijkl || !tors_func || !tors_n || !tors_k || !tors_delta))) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   ctx->excludePotentialTerm = excludePotentialTerm;
+   ctx->bonded_gid = false; ctx->natom_g = 0;
+   return build_rows(ctx, (excludePotentialTerm & 1) ? 0 : nbond, bond_ij, bond_kb, bond_b0, nangle, angle_ijk, angle_func, angle_k, angle_t0,
+                     ntors, tors_ijkl, tors_func, tors_n, tors_k, tors_delta);
+}
+
+/* decomposed runs: every rank gets the whole system's terms with atoms named by gid.  The gids that occur
+ * are sorted once; an atom's number is its place in that list, and the rows are built over these numbers. */
 extern "C" int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
                                     int nbond, const uint64_t *bond_gid, const double *bond_kb, const double *bond_b0,
                                     int nangle, const uint64_t *angle_gid, const int *angle_func, const double *angle_k, const double *angle_t0,
@@ -683,64 +556,30 @@ extern "C" int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
                                     int excludePotentialTerm)
 {
    if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
+   if ((nbond > 0 && (!bond_gid || !bond_kb || !bond_b0)) || (nangle > 0 && (!angle_gid || !angle_func || !angle_k || !angle_t0)) ||
+       (ntors > 0 && (!tors_gid || !tors_func || !tors_n || !tors_k || !tors_delta))) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    ctx->excludePotentialTerm = excludePotentialTerm;
    ctx->bonded_gid = true;
-   ctx->g_nbond = (excludePotentialTerm & 1) ? 0 : nbond;
-   ctx->g_nangle = nangle; ctx->g_ntors = ntors;
-   ctx->nbond = ctx->nangle = ctx->ntors = 0;           /* local counts: set by ddcmi_bonded_localize at every rebuild */
+   if (excludePotentialTerm & 1) nbond = 0;
+   std::vector<uint64_t> ug;
+   ug.reserve(2 * (size_t)nbond + 3 * (size_t)nangle + 4 * (size_t)ntors);
+   ug.insert(ug.end(), bond_gid, bond_gid + 2 * (size_t)nbond);
+   ug.insert(ug.end(), angle_gid, angle_gid + 3 * (size_t)nangle);
+   ug.insert(ug.end(), tors_gid, tors_gid + 4 * (size_t)ntors);
+   std::sort(ug.begin(), ug.end());
+   ug.erase(std::unique(ug.begin(), ug.end()), ug.end());
+   auto number = [&](const uint64_t *g, size_t n)
+   {
+      std::vector<int> out(n + 1);
+      for (size_t k = 0; k < n; k++) out[k] = (int)(std::lower_bound(ug.begin(), ug.end(), g[k]) - ug.begin());
+      return out;
+   };
+   std::vector<int> bi = number(bond_gid, 2 * (size_t)nbond), ai = number(angle_gid, 3 * (size_t)nangle), ti = number(tors_gid, 4 * (size_t)ntors);
    int rc;
-   if (ctx->g_nbond > 0)
-   {
-      if (!bond_gid || !bond_kb || !bond_b0) return DDCMI_EINVAL;
-      if ((rc = up(ctx, ctx->gbond_gid, bond_gid, 2 * (size_t)nbond)) || (rc = up(ctx, ctx->bond_kb, bond_kb, nbond)) || (rc = up(ctx, ctx->bond_b0, bond_b0, nbond))) return rc;
-   }
-   if (nangle > 0)
-   {
-      if (!angle_gid || !angle_func || !angle_k || !angle_t0) return DDCMI_EINVAL;
-      for (int t = 0; t < nangle; t++)
-         if (angle_func[t] != 1 && angle_func[t] != 2 && angle_func[t] != 10) SETERR(ctx, DDCMI_EINVAL, "angle %d: func %d is not 1, 2 or 10", t, angle_func[t]);
-      if ((rc = up(ctx, ctx->gangle_gid, angle_gid, 3 * (size_t)nangle)) || (rc = up(ctx, ctx->angle_func, angle_func, nangle)) ||
-          (rc = up(ctx, ctx->angle_k, angle_k, nangle)) || (rc = up(ctx, ctx->angle_t0, angle_t0, nangle))) return rc;
-   }
-   if (ntors > 0)
-   {
-      if (!tors_gid || !tors_func || !tors_n || !tors_k || !tors_delta) return DDCMI_EINVAL;
-      for (int t = 0; t < ntors; t++)
-         if (tors_func[t] != 1 && tors_func[t] != 2) SETERR(ctx, DDCMI_EINVAL, "dihedral %d: func %d is not 1 or 2", t, tors_func[t]);
-      if ((rc = up(ctx, ctx->gtors_gid, tors_gid, 4 * (size_t)ntors)) || (rc = up(ctx, ctx->tors_func, tors_func, ntors)) || (rc = up(ctx, ctx->tors_n, tors_n, ntors)) ||
-          (rc = up(ctx, ctx->tors_k, tors_k, ntors)) || (rc = up(ctx, ctx->tors_delta, tors_delta, ntors))) return rc;
-   }
-   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
-   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->forces_valid = false;
-   ctx->list_valid = false;               /* the local term lists are made with the neighbour list */
-   return DDCMI_OK;
-}
-
-template <int NA>
-static int localize_kind(ddcmi_ctx *ctx, int nterm, const uint64_t *tgid, dbuf<int> &tmap, dbuf<int> &latoms, int *nlocal, int *d_total)
-{
-   *nlocal = 0;
-   if (nterm <= 0) return DDCMI_OK;
-   hipStream_t st = ctx->stream;
-   ENSURE(ctx, ctx->term_sel, (size_t)nterm + 1);
-   ENSURE(ctx, ctx->term_slots, (size_t)NA * nterm);
-   hipLaunchKernelGGL(k_term_locate<NA>, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, tgid, ctx->nloc, ctx->hmask, ctx->hkeys.p, ctx->hvals.p,
-                      ctx->term_sel.p, ctx->term_slots.p, ctx->d_flags);
-   int rc = ddcmi_scan_exclusive(ctx, ctx->term_sel.p, nterm, d_total);
-   if (rc) return rc;
-   int total = 0;
-   HIPCHK(ctx, hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
-   HIPCHK(ctx, hipStreamSynchronize(st));
-   if (total > 0)
-   {
-      ENSURE(ctx, tmap, (size_t)total);
-      ENSURE(ctx, latoms, (size_t)NA * total);
-      hipLaunchKernelGGL(k_term_compact<NA>, dim3(cdiv(nterm, 256)), dim3(256), 0, st, nterm, ctx->term_sel.p, ctx->term_slots.p, total, tmap.p, latoms.p);
-   }
-   *nlocal = total;
-   return DDCMI_OK;
+   ctx->natom_g = (int)ug.size();
+   if (ctx->natom_g > 0 && (rc = up(ctx, ctx->atom_gid, ug.data(), ug.size()))) return rc;
+   return build_rows(ctx, nbond, bi.data(), bond_kb, bond_b0, nangle, ai.data(), angle_func, angle_k, angle_t0, ntors, ti.data(), tors_func, tors_n, tors_k, tors_delta);
 }
 
 /* ---- RESTRAINT potential (restraint.c:259-361) --------------------------------------- */
@@ -801,13 +640,21 @@ extern "C" int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, 
    return DDCMI_OK;
 }
 
-/* decomposed runs, at every list rebuild: find the terms that touch an owned bead and
- * the device slots (owned or halo) of their atoms */
+static GatherRows gather_rows(const ddcmi_ctx *ctx)
+{
+   GatherRows gr = {ctx->inc_nrow, ctx->inc_boff.p, ctx->inc_aoff.p, ctx->inc_haoff.p, ctx->inc_toff.p, (const int2 *)ctx->inc_brow.p, (const int4 *)ctx->inc_arow.p,
+                    (const int4 *)ctx->inc_harow.p, (const int4 *)ctx->inc_trow.p,
+                    (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p, ctx->inc_light, ctx->inc_latoms.p};
+   return gr;
+}
+
+/* decomposed runs, at every list rebuild: where are the atoms of the terms (and the restrained beads)?
+ * One table gid -> lowest slot over the owned + halo beads, then slot_of_atom for the term atoms and a
+ * check that no owned atom misses a partner. */
 int ddcmi_bonded_localize(ddcmi_ctx *ctx)
 {
-   if (!ctx->bonded_gid && ctx->nrest == 0) return DDCMI_OK;
-   if (ctx->bonded_gid && ctx->g_nbond + ctx->g_nangle + ctx->g_ntors == 0 && ctx->nrest == 0)
-   { ctx->nbond = ctx->nangle = ctx->ntors = 0; return DDCMI_OK; }      /* water: nothing to locate, no gid table */
+   const bool terms = ctx->bonded_gid && ctx->inc_nrow > 0;
+   if (!terms && ctx->nrest == 0) return DDCMI_OK;      /* water without restraints: nothing to locate, no gid table */
    hipStream_t st = ctx->stream;
    const int nall = ctx->nloc + ctx->nhalo;
    unsigned cap = 1024;
@@ -819,26 +666,25 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
    HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
    if (nall > 0)
       hipLaunchKernelGGL(k_gid_insert, dim3(cdiv(nall, 256)), dim3(256), 0, st, nall, ctx->gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p);
-   int rc;
-   int *d_total = ctx->d_flags + 8;
    if (ctx->nrest > 0)
       hipLaunchKernelGGL(k_rest_locate, dim3(cdiv(ctx->nrest, 256)), dim3(256), 0, st, ctx->nrest, ctx->rest_gid.p, ctx->nloc, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->rest_slot.p);
-   if (!ctx->bonded_gid) { HIPCHK(ctx, hipStreamSynchronize(st)); return DDCMI_OK; }
-   if ((rc = localize_kind<2>(ctx, ctx->g_nbond, ctx->gbond_gid.p, ctx->l_bond_map, ctx->l_bond_atoms, &ctx->nbond, d_total))) return rc;
-   if ((rc = localize_kind<3>(ctx, ctx->g_nangle, ctx->gangle_gid.p, ctx->l_angle_map, ctx->l_angle_atoms, &ctx->nangle, d_total))) return rc;
-   if ((rc = localize_kind<4>(ctx, ctx->g_ntors, ctx->gtors_gid.p, ctx->l_tors_map, ctx->l_tors_atoms, &ctx->ntors, d_total))) return rc;
+   if (!terms) { HIPCHK(ctx, hipStreamSynchronize(st)); return DDCMI_OK; }
+   ENSURE(ctx, ctx->slot_of_atom, (size_t)ctx->natom_g + 1);
+   hipLaunchKernelGGL(k_atom_slots, dim3(cdiv(ctx->natom_g, 256)), dim3(256), 0, st, ctx->natom_g, ctx->atom_gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->slot_of_atom.p);
+   const int nl = std::max(ctx->inc_light, ctx->inc_heavy);
+   if (nl > 0)
+      hipLaunchKernelGGL(k_rows_check, dim3(cdiv(nl, 256)), dim3(256), 0, st, gather_rows(ctx), ctx->slot_of_atom.p, ctx->nloc, ctx->d_flags);
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-   HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), st));
    HIPCHK(ctx, hipStreamSynchronize(st));
    if (ctx->h_flags[0] > 0)
-      SETERR(ctx, DDCMI_EUNSUPPORTED, "%d bonded terms reach beyond the halo (rmax+deltaR=%g): a partner of an owned bead is on no neighbouring domain's send list",
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "%d bonded partners of owned beads lie beyond the halo (rmax+deltaR=%g): they are on no neighbouring domain's send list",
              ctx->h_flags[0], ctx->rmax + ctx->deltaR);
    return DDCMI_OK;
 }
 
 int ddcmi_launch_bonded(ddcmi_ctx *ctx)
 {
-   if (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest == 0) return DDCMI_OK;
+   if (ctx->inc_nrow == 0 && ctx->nrest == 0) return DDCMI_OK;
    hipStream_t st = ctx->stream;
    BoxArgs box;
    box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
@@ -847,51 +693,21 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    if (ctx->nrest > 0)
       hipLaunchKernelGGL(k_restraint, dim3(1), dim3(256), 0, st, ctx->nrest, box, ctx->rest_origin, ctx->rest_slot.p, ctx->rest_fc.p, ctx->rest_r0.p, ctx->rest_kb.p,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_REST);
-   if (ctx->nbond + ctx->nangle + ctx->ntors == 0) return DDCMI_OK;
-   if (!ctx->bonded_gid)
-   {
-      /* one domain: one lane per bead, no atomics */
-      const int nblk = cdiv(ctx->inc_light, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
-      ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
-      GatherRows gr = {ctx->inc_nrow, ctx->inc_boff.p, ctx->inc_aoff.p, ctx->inc_haoff.p, ctx->inc_toff.p, (const int2 *)ctx->inc_brow.p, (const int4 *)ctx->inc_arow.p,
-                       (const int4 *)ctx->inc_harow.p, (const int4 *)ctx->inc_trow.p,
-                       (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p, ctx->inc_light, ctx->inc_latoms.p};
-      double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
-      if (nblk > 0)
-      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
+   if (ctx->inc_nrow == 0) return DDCMI_OK;
+   /* one lane per atom with terms; a decomposed run launches over the global atom lists and every rank
+    * works on the atoms it owns */
+   const int *slot = ctx->bonded_gid ? ctx->slot_of_atom.p : ctx->slot_of_orig.p;
+   const int nblk = cdiv(ctx->inc_light, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
+   ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
+   GatherRows gr = gather_rows(ctx);
+   double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
+   if (nblk > 0)
+      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->bpartials.p);
-      if (nblk2 > 0)
-         hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, ctx->slot_of_orig.p, box, ctx->excludePotentialTerm,
-                            ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, p2);
-      hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
-      return DDCMI_OK;
-   }
-   /* decomposed run: the terms located on this rank, one lane per term */
-   int nbb = cdiv(ctx->nbond, 256), nab = cdiv(ctx->nangle, 256), ntb = cdiv(ctx->ntors, 256);
-   ENSURE(ctx, ctx->bpartials, (size_t)(nbb + nab + ntb + 3) * 8);
-   double *pb = ctx->bpartials.p, *pa = pb + (size_t)nbb * 8, *pt = pa + (size_t)nab * 8;
-   if (ctx->nbond > 0)
-   {
-      TermMap tm = TermMap{ctx->l_bond_atoms.p, nullptr, ctx->l_bond_map.p, ctx->nloc};
-      hipLaunchKernelGGL(k_bond, dim3(nbb), dim3(256), 0, st, ctx->nbond, box, tm, ctx->bond_kb.p, ctx->bond_b0.p, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pb);
-   }
-   if (ctx->nangle > 0)
-   {
-      TermMap tm = TermMap{ctx->l_angle_atoms.p, nullptr, ctx->l_angle_map.p, ctx->nloc};
-      hipLaunchKernelGGL(k_angle, dim3(nab), dim3(256), 0, st, ctx->nangle, box, tm, ctx->angle_func.p, ctx->angle_k.p, ctx->angle_t0.p,
-                         ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pa);
-   }
-   if (ctx->ntors > 0)
-   {
-      TermMap tm = TermMap{ctx->l_tors_atoms.p, nullptr, ctx->l_tors_map.p, ctx->nloc};
-      hipLaunchKernelGGL(k_torsion, dim3(ntb), dim3(256), 0, st, ctx->ntors, box, tm, ctx->tors_func.p, ctx->tors_n.p, ctx->tors_k.p, ctx->tors_delta.p,
-                         ctx->excludePotentialTerm, ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, pt);
-   }
-   RedB rb;
-   rb.partials[0] = pb; rb.nblocks[0] = (ctx->nbond > 0) ? nbb : 0; rb.nv[0] = 7; rb.out[0] = ctx->d_results + R_SCR_BOND;
-   rb.partials[1] = pa; rb.nblocks[1] = (ctx->nangle > 0) ? nab : 0; rb.nv[1] = 7; rb.out[1] = ctx->d_results + R_SCR_ANGLE;
-   rb.partials[2] = pt; rb.nblocks[2] = (ctx->ntors > 0) ? ntb : 0; rb.nv[2] = 8; rb.out[2] = ctx->d_results + R_SCR_TORS;
-   hipLaunchKernelGGL(k_reduce_b, dim3(3), dim3(256), 0, st, rb);
+   if (nblk2 > 0)
+      hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, box, ctx->excludePotentialTerm,
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, p2);
+   hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
    return DDCMI_OK;
 }
 

@@ -1492,21 +1492,20 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    (void)hipStreamSynchronize(ctx->stream);
    ddcmi_comm_destroy(ctx);
    dbuf<double> *db[] = {&ctx->d_invmass, &ctx->d_mass, &ctx->d_charge_sp, &ctx->bpartials, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->vx2, &ctx->vy2, &ctx->vz2,
-                         &ctx->fx, &ctx->fy, &ctx->fz, &ctx->qatom, &ctx->d_kqtab, &ctx->bond_kb, &ctx->bond_b0, &ctx->angle_k, &ctx->angle_t0, &ctx->tors_k, &ctx->tors_delta, &ctx->partials};
+                         &ctx->fx, &ctx->fy, &ctx->fz, &ctx->qatom, &ctx->d_kqtab, &ctx->partials};
    for (auto b : db) b->release();
    dbuf<int> *ib[] = {&ctx->d_ljtype_sp, &ctx->d_moltype_sp, &ctx->d_mol_nspecies, &ctx->d_bpair_off, &ctx->d_bpairI, &ctx->d_bpairJ, &ctx->species, &ctx->species2,
                       &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->cell_cnt_o, &ctx->cell_start_o,
                       &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt, &ctx->nimg, &ctx->img_off, &ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank,
                       &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt,
-                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched, &ctx->tile_perm,
-                      &ctx->bond_ij, &ctx->angle_ijk, &ctx->angle_func, &ctx->tors_ijkl, &ctx->tors_func, &ctx->tors_n};
+                      &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched, &ctx->tile_perm};
    for (auto b : ib) b->release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
-   ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->gbond_gid.release(); ctx->gangle_gid.release(); ctx->gtors_gid.release(); ctx->hkeys.release();
+   ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->atom_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->cg_dist, &ctx->inc_bpar, &ctx->inc_apar, &ctx->inc_tpar}) b->release();
    for (auto b : {&ctx->cg_atom_off, &ctx->cg_atoms, &ctx->cg_pair_off, &ctx->cons_status, &ctx->mol_off, &ctx->mol_atoms}) b->release();
    ctx->cg_pa.release(); ctx->cg_pb.release();
-   for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->l_bond_atoms, &ctx->l_bond_map, &ctx->l_angle_atoms, &ctx->l_angle_map, &ctx->l_tors_atoms, &ctx->l_tors_map, &ctx->term_sel, &ctx->term_slots, &ctx->hvals}) b->release();
+   for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->slot_of_atom, &ctx->hvals}) b->release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);

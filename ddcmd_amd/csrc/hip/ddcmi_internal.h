@@ -155,10 +155,7 @@ struct ddcmi_ctx
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
    /* bonded */
-   int nbond = 0, nangle = 0, ntors = 0;
-   dbuf<int> bond_ij, angle_ijk, angle_func, tors_ijkl, tors_func, tors_n;
-   /* decomposed runs: global terms by gid (ddcmi_set_bonded_gid) and, rebuilt with the
-    * lists, the terms touching an owned bead with the device slots of their atoms */
+   int nbond = 0, nangle = 0, ntors = 0;          /* term counts (of the whole system in a decomposed run) */
    /* RESTRAINT potential: restraints by gid; rest_slot = owned device slot of each (or -1), found at rebuilds */
    int nrest = 0, rest_origin = 0;
    /* nglfconstraint (one domain): constraint groups over caller-order atoms; pairs name group-local atoms */
@@ -168,14 +165,12 @@ struct ddcmi_ctx
    long nmol_total = 0; int nmol_multi = 0; bool molv_valid = false;   /* R_SCR_MOLV belongs to the forces now in fx */
    dbuf<int> mol_off, mol_atoms;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
-   /* one domain: rows of the bead-parallel bonded kernel (atom -> its terms), built in ddcmi_set_bonded */
+   /* rows of the bead-parallel bonded kernel (atom -> its terms), built once in ddcmi_set_bonded[_gid] */
    int inc_nrow = 0, inc_heavy = 0, inc_light = 0; dbuf<int> inc_boff, inc_aoff, inc_haoff, inc_toff, inc_brow, inc_arow, inc_harow, inc_trow, inc_hatoms, inc_latoms; dbuf<double> inc_bpar, inc_apar, inc_tpar;
    bool bonded_gid = false;
-   int g_nbond = 0, g_nangle = 0, g_ntors = 0;
-   dbuf<uint64_t> gbond_gid, gangle_gid, gtors_gid;
-   dbuf<int> l_bond_atoms, l_bond_map, l_angle_atoms, l_angle_map, l_tors_atoms, l_tors_map, term_sel, term_slots;
+   int natom_g = 0; dbuf<uint64_t> atom_gid;      /* sorted gids of the atoms that occur in terms: an atom's number is its place here */
+   dbuf<int> slot_of_atom;                         /* [natom_g] lowest slot holding that gid on this rank, INT_MAX if absent (refilled at rebuilds) */
    dbuf<unsigned long long> hkeys; dbuf<int> hvals; unsigned hmask = 0;
-   dbuf<double> bond_kb, bond_b0, angle_k, angle_t0, tors_k, tors_delta;
    /* reductions */
    dbuf<double> partials, bpartials; int npartial_blocks = 0;
    double *d_results = nullptr; double *h_results = nullptr;

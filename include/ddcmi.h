@@ -77,13 +77,13 @@ int ddcmi_set_bonded(ddcmi_ctx *ctx,
                      int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
                      int excludePotentialTerm);
 /* The same terms with atoms named by gid (gid_type, gid.h), for decomposed runs where a
- * bead's index does not survive migration: every rank passes the GLOBAL term list; at
- * each list rebuild it keeps the terms that touch a bead it owns and finds the
- * partners among its owned + halo beads.  The owner of each atom adds that atom's force;
- * energy and virial are weighted by (owned atoms)/(atoms of the term), so the sum over
- * ranks counts every term once and no force is sent back.  This replaces the
- * whole-molecule ownership of ddcRuleMartini (bioMartiniRule.c:64-85): a partner
- * further than rmax+deltaR from the owning domain is an error at the rebuild. */
+ * bead's index does not survive migration: every rank passes the GLOBAL term list.  At
+ * each list rebuild a rank finds the owned or halo copy of every term atom; it evaluates
+ * the terms of the atoms it owns and keeps those atoms' forces, so no force is sent back,
+ * and a term's energy and virial are booked by the owner of its first atom: the sums over
+ * ranks count every term once.  This replaces the whole-molecule ownership of
+ * ddcRuleMartini (bioMartiniRule.c:64-85): a partner further than rmax+deltaR from the
+ * owning domain is an error at the rebuild. */
 int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
                          int nbond, const uint64_t *bond_gid, const double *bond_kb, const double *bond_b0,
                          int nangle, const uint64_t *angle_gid, const int *angle_func, const double *angle_k, const double *angle_t0,
