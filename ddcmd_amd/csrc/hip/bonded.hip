@@ -1,18 +1,16 @@
 /*
- * bonded.hip -- Martini bonded terms on the device: one thread per TERM
- * (the reference CUDA path uses one thread per atom looping its terms,
- * bondedGPU.cu:1267-2672).  Formulas follow the CPU reference:
+ * bonded.hip -- Martini bonded terms, the RESTRAINT potential and nglfconstraint on the device.
+ * Bonded terms are evaluated bead-parallel, one lane per atom looping over its terms -- the layout of
+ * the reference's CUDA path (bondedGPU.cu:1267-2672) -- with the formulas of the CPU reference:
  *   resBondSorted            bioCharmmCovalentEnergiesSorted.c:18-116
  *   resAngleSorted           :118-242   (func 1)
  *   resAngleCosineSorted     :244-363   (func 2)
  *   resAngleRestrainSorted   :365-487   (func 10)
  *   resTorsionSorted         :577-721   (func 1) via bioDihedralFast
  *   resImproperSorted        :723-848   (func 2)   (bioCharmmCovalentEnergies.c:266-351)
- * Term atoms are caller-order indices translated through slot_of_orig each
- * launch (atoms are re-sorted at every rebuild).  Separations use the rint-based
- * nearestImage (Preduce, preduce.c:282-338) like bioVec.  Forces go to the
- * member atoms with FP64 hardware atomics (a handful per atom); energies and
- * virial use per-block partials + a fixed-order second stage.
+ * Separations use the rint-based nearestImage (Preduce, preduce.c:282-338) like bioVec.  A lane keeps
+ * the force on its own atom (no atomics, fixed summation order); energies and virial use per-block
+ * partials + a fixed-order second stage.
  */
 #include "ddcmi_internal.h"
 #include <math.h>
