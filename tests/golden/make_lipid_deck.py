@@ -34,8 +34,11 @@ DPPC_ANGLES = [(1, 2, 3, 2, 25.0, np.cos(np.radians(120.0))), (1, 2, 4, 2, 25.0,
                (5, 6, 7, 2, 25.0, -1.0), (3, 8, 9, 2, 25.0, -1.0), (8, 9, 10, 2, 25.0, -1.0), (9, 10, 11, 2, 25.0, -1.0)]
 TST_ATOMS = [("T1", "Na", 0.5), ("T2", "C1", 0.0), ("T3", "Na", -0.5), ("T4", "C1", 0.0), ("T5", "P4", 0.0)]
 TST_BONDS = [(0, 1, 0.40, 5000.0), (1, 2, 0.40, 5000.0), (2, 3, 0.40, 5000.0), (3, 4, 0.40, 5000.0)]
-TST_ANGLES = [(0, 1, 2, 1, 40.0, np.radians(110.0)), (1, 2, 3, 10, 30.0, np.cos(np.radians(120.0))), (2, 3, 4, 2, 35.0, np.cos(np.radians(130.0)))]
-TST_TORS = [(0, 1, 2, 3, 1, 2, 4.0, 0.6), (1, 2, 3, 4, 2, 1, 20.0, 0.5), (0, 1, 2, 4, 1, 3, 1.5, 0.0)]   # (I,J,K,L,func,n,k,delta)
+# The angles that enter a dihedral are stiff enough to stay away from 180 degrees, where bioDihedralFast is singular
+# (a 75 k-bead tiling of an earlier, softer version -- 40 and 35 kJ/mol, and a dihedral over the unbonded 2-4 --
+# produced a runaway test molecule after ~3000 steps at 310 K)
+TST_ANGLES = [(0, 1, 2, 1, 120.0, np.radians(110.0)), (1, 2, 3, 10, 30.0, np.cos(np.radians(120.0))), (2, 3, 4, 2, 350.0, np.cos(np.radians(130.0)))]
+TST_TORS = [(0, 1, 2, 3, 1, 2, 4.0, 0.6), (1, 2, 3, 4, 2, 1, 20.0, 0.5), (0, 1, 2, 3, 1, 3, 1.5, 0.0)]   # (I,J,K,L,func,n,k,delta)
 TST_EXCL = [(0, 2)]
 
 
