@@ -103,13 +103,17 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
 
 /* ------------------------------------------------------------------------- */
 /* sort: wrap + cell id + in-cell rank                                        */
-__global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int *rank, int *cell_cnt)
+__global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    int c = -1;
    if (i < nloc)
    {
       double4 p = pos[i];
+      /* a bead that is not a number, or more than a box length outside the box: the run has blown up (the
+       * reference would abort in its domain assignment); reported at this rebuild instead of as a full cell */
+      if (!(((gp.pbc & 1) ? fabs(p.x) < 1.5 * gp.L[0] : fabs(p.x) < 1e300) && ((gp.pbc & 2) ? fabs(p.y) < 1.5 * gp.L[1] : fabs(p.y) < 1e300) &&
+            ((gp.pbc & 4) ? fabs(p.z) < 1.5 * gp.L[2] : fabs(p.z) < 1e300))) atomicAdd(runaway, 1);
       /* backInBox_fast: PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
       if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
       if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
@@ -1907,7 +1911,8 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
    HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_h.p, 0, ncell * sizeof(int), st));
    if (n > 0)
    {
-      hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p);
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_flags + 12, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12);
    }
    HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_o.p, ctx->cell_cnt_o.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
@@ -2133,10 +2138,13 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       int *h_work = ctx->pinned(0, (size_t)ntile + 8);
       if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 12, ctx->d_flags + 12, sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
       HIPCHK(ctx, hipMemcpyAsync(h_work + ntile, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
       memcpy(tot, h_work + ntile, sizeof(tot));
+      if (ctx->h_flags[12] > 0)
+         SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)", ctx->h_flags[12], (long long)ctx->loop);
       bool again = false;
       if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.05) + 32) + 63) & ~63; again = true; }
       if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }

@@ -562,3 +562,15 @@ def test_step_graph_replay_is_bitwise_the_plain_step(monkeypatch):
         m.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_blown_up_run_is_reported_as_such():
+    """a run that has gone unstable (here: an absurd time step) ends with an error that says so at the next
+    list rebuild, not with a capacity message about an overfull cell"""
+    from ddcmd_amd.martini import MartiniHIP, DdcmiError
+    s = make_water_setup(8)
+    m = MartiniHIP(s)
+    m.eval_forces()
+    with pytest.raises(DdcmiError, match="unstable"):
+        m.step(200, dt=400.0 * s.dt)
+    m.close()
