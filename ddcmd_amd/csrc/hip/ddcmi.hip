@@ -884,7 +884,10 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          const int glast = max(ngl - 1, 0);
          auto load_group = [&](int g) -> uint4
          {
-            uint4 v = slice[col + (unsigned)min(g, glast) * cstride];
+            /* a lane without groups (inactive, or its part of a short row is empty) must not form an address
+             * from its column: with many parts per bead that column lies beyond the tile's slice -- for the
+             * last tile beyond the arena.  It reads entry 0 of the slice and masks it. */
+            uint4 v = slice[ngl > 0 ? col + (unsigned)min(g, glast) * cstride : 0u];
             /* lanes past their own last group (sub-lane split, short rows) get padding */
             if (g >= ngl) v = make_uint4(0, 0, 0, 0);
             return v;
@@ -1372,7 +1375,7 @@ __global__ void k_export3(int nloc, const double *a, const double *b, const doub
  * [7:0] LJ type.  The atom code lets the list build decide bonded-pair exclusions from
  * LDS instead of two dependent global loads per same-molecule candidate. */
 __global__ void k_init_state(int n, const double *rx, const double *ry, const double *rz, const int *species, const int *ljtype_sp,
-                             const double *charge_sp, const uint64_t *gid, double4 *pos, double *qatom, int *orig, int *slot)
+                             const uint64_t *gid, double4 *pos, int *orig, int *slot)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
@@ -1380,16 +1383,8 @@ __global__ void k_init_state(int n, const double *rx, const double *ry, const do
    unsigned code = (unsigned)(gid[i] & 0xffffull);
    long long w = (long long)((gid[i] >> 32) << 32) | ((long long)(sp & 0xffff) << 16) | ((long long)min(code, 255u) << 8) | (long long)(ljtype_sp[sp] & 0xff);
    pos[i] = make_double4(rx[i], ry[i], rz[i], __longlong_as_double(w));
-   qatom[i] = charge_sp[sp];
    orig[i] = i;
    slot[i] = i;
-}
-__global__ void k_fill_q(int n, const double4 *pos, const double *charge_sp, double *qatom)
-{
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= n) return;
-   int sp = (int)((__double_as_longlong(pos[i].w) >> 16) & 0xffff);
-   qatom[i] = charge_sp[sp];
 }
 /* test/inspection export: decode the tile ELL (16-bit staged indices) into CSR
  * over caller-order indices; image atoms map back to their source bead */
@@ -1496,7 +1491,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    (void)hipStreamSynchronize(ctx->stream);
    ddcmi_comm_destroy(ctx);
    dbuf<double> *db[] = {&ctx->d_invmass, &ctx->d_mass, &ctx->d_charge_sp, &ctx->bpartials, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->vx2, &ctx->vy2, &ctx->vz2,
-                         &ctx->fx, &ctx->fy, &ctx->fz, &ctx->qatom, &ctx->d_kqtab, &ctx->partials};
+                         &ctx->fx, &ctx->fy, &ctx->fz, &ctx->d_kqtab, &ctx->partials};
    for (auto b : db) b->release();
    dbuf<int> *ib[] = {&ctx->d_ljtype_sp, &ctx->d_moltype_sp, &ctx->d_mol_nspecies, &ctx->d_bpair_off, &ctx->d_bpairI, &ctx->d_bpairJ, &ctx->species, &ctx->species2,
                       &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->cell_cnt_o, &ctx->cell_start_o,
@@ -1775,7 +1770,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
          if (group[i] < 0 || group[i] >= ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "particle %d has group %d outside [0,%d)", i, group[i], ctx->ngroup);
    int n = nlocal;
    size_t cap = (size_t)n + n / 4 + 1024;     /* room for image atoms; grown on demand */
-   ENSURE(ctx, ctx->pos, cap); ENSURE(ctx, ctx->pos2, cap); ENSURE(ctx, ctx->qatom, cap);
+   ENSURE(ctx, ctx->pos, cap); ENSURE(ctx, ctx->pos2, cap);
    ENSURE(ctx, ctx->gid, cap); ENSURE(ctx, ctx->gid2, cap);
    dbuf<double> *d3[] = {&ctx->vx, &ctx->vy, &ctx->vz, &ctx->vx2, &ctx->vy2, &ctx->vz2, &ctx->fx, &ctx->fy, &ctx->fz};
    for (auto b : d3) ENSURE(ctx, *b, n);
@@ -1797,7 +1792,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    }
    hipLaunchKernelGGL(k_init_state, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species.p,
-                      ctx->d_ljtype_sp.p, ctx->d_charge_sp.p, ctx->gid.p, ctx->pos.p, ctx->qatom.p, ctx->orig.p, ctx->slot_of_orig.p);
+                      ctx->d_ljtype_sp.p, ctx->gid.p, ctx->pos.p, ctx->orig.p, ctx->slot_of_orig.p);
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    if (vx && vy && vz)
    {
@@ -1938,7 +1933,7 @@ int ddcmi_bl_reserve_halo(ddcmi_ctx *ctx, int nh)
    for (auto b : hb) ENSURE(ctx, *b, nh + 1);
    if ((size_t)(n + nh) > ctx->pos.cap)
    {
-      if (ctx->pos.ensure(n + nh, true, st) || ctx->pos2.ensure(n + nh) || ctx->qatom.ensure(n + nh) || ctx->gid.ensure(n + nh, true, st) || ctx->gid2.ensure(n + nh))
+      if (ctx->pos.ensure(n + nh, true, st) || ctx->pos2.ensure(n + nh) || ctx->gid.ensure(n + nh, true, st) || ctx->gid2.ensure(n + nh))
          SETERR(ctx, DDCMI_ENOMEM, "growing particle arrays for %d image atoms failed", nh);
    }
    return DDCMI_OK;
@@ -1984,8 +1979,6 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
    }
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
-   if (n + nh > 0)
-      hipLaunchKernelGGL(k_fill_q, dim3(cdiv(n + nh, 256)), dim3(256), 0, st, n + nh, ctx->pos.p, ctx->d_charge_sp.p, ctx->qatom.p);
    return DDCMI_OK;
 }
 

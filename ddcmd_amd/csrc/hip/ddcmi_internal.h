@@ -122,7 +122,7 @@ struct ddcmi_ctx
    /* particle state: [0,nloc) owned, [nloc,nloc+nhalo) images/halo */
    int nloc = 0, nhalo = 0, npad = 0;
    dbuf<double4> pos, pos2;
-   dbuf<double> vx, vy, vz, vx2, vy2, vz2, fx, fy, fz, qatom;
+   dbuf<double> vx, vy, vz, vx2, vy2, vz2, fx, fy, fz;
    dbuf<int> species, species2, group, group2, orig, orig2, slot_of_orig;
    dbuf<uint64_t> gid, gid2;
    /* sort / cells */

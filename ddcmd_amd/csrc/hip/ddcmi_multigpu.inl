@@ -236,10 +236,11 @@ __global__ void k_rec5to3(int n, const double *r5, double *r3)
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k < n) { r3[3 * k] = r5[5 * k]; r3[3 * k + 1] = r5[5 * k + 1]; r3[3 * k + 2] = r5[5 * k + 2]; }
 }
-__global__ void k_sum_q2(int n, const double *q, double *out)
+__global__ void k_sum_q2(int n, const double4 *pos, const double *charge_sp, double *out)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
-   double v = (i < n) ? q[i] * q[i] : 0.0;
+   double q = (i < n) ? charge_sp[(int)((__double_as_longlong(pos[i].w) >> 16) & 0xffff)] : 0.0;      /* species sits in the record tag */
+   double v = q * q;
    v = wave_sum(v);
    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
 }
@@ -259,7 +260,7 @@ static int mg_ensure_owned(ddcmi_ctx *ctx, size_t need)
    for (auto b : i1) if (b->ensure(want + 1, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
    dbuf<int> *i2[] = {&ctx->species2, &ctx->group2, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->nimg, &ctx->img_off, &ctx->keep};
    for (auto b : i2) if (b->ensure(want + 1)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
-   if (ctx->pos.ensure(want, true, st) || ctx->pos2.ensure(want) || ctx->qatom.ensure(want) || ctx->gid.ensure(want, true, st) || ctx->gid2.ensure(want))
+   if (ctx->pos.ensure(want, true, st) || ctx->pos2.ensure(want) || ctx->gid.ensure(want, true, st) || ctx->gid2.ensure(want))
       SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
    return DDCMI_OK;
 }
@@ -516,7 +517,7 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
    {
       double *d = ctx->d_results + R_GROUP;
       HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(double), st));
-      if (ctx->nloc > 0) hipLaunchKernelGGL(k_sum_q2, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, st, ctx->nloc, ctx->qatom.p, d);
+      if (ctx->nloc > 0) hipLaunchKernelGGL(k_sum_q2, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, st, ctx->nloc, ctx->pos.p, ctx->d_charge_sp.p, d);
       double q2 = 0;
       HIPCHK(ctx, hipMemcpyAsync(&q2, d, sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
