@@ -62,22 +62,42 @@ struct GridParams
  * for one peer is contiguous and travels as ONE message per step. */
 struct SegTab { int off[28]; signed char code[28]; int nseg; };
 
+/* DDCMI_DEBUG_GUARD=1 (debugging aid): device buffers get exactly the requested size plus a 256-byte canary that
+ * is verified when the buffer is grown or released -- a write beyond a buffer aborts with a message instead of
+ * landing in the slack the normal sizing leaves */
+static inline int ddcmi_debug_guard()
+{
+   static int g = -1;
+   if (g < 0) { const char *e = getenv("DDCMI_DEBUG_GUARD"); g = e ? atoi(e) : 0; }
+   return g;
+}
 template <class T> struct dbuf
 {
    T *p = nullptr;
    size_t cap = 0;
+   static size_t guard() { return ddcmi_debug_guard() ? (256 + sizeof(T) - 1) / sizeof(T) : 0; }
+   void check() const
+   {
+      if (!p || !ddcmi_debug_guard()) return;
+      unsigned char h[512];
+      const size_t nb = guard() * sizeof(T);
+      if (hipMemcpy(h, p + cap, nb, hipMemcpyDeviceToHost) != hipSuccess) return;
+      for (size_t k = 0; k < nb; k++)
+         if (h[k] != 0xA5) { fprintf(stderr, "ddcmi: write beyond a device buffer of %zu elements of %zu bytes (byte %zu of the canary)\n", cap, sizeof(T), k); abort(); }
+   }
    int ensure(size_t n, bool keep = false, hipStream_t s = 0)
    {
       if (n <= cap) return 0;
-      size_t ncap = n + n / 8 + 64;
+      size_t ncap = ddcmi_debug_guard() ? n : n + n / 8 + 64;
       T *q = nullptr;
-      if (hipMalloc((void **)&q, ncap * sizeof(T)) != hipSuccess) return -1;
+      if (hipMalloc((void **)&q, (ncap + guard()) * sizeof(T)) != hipSuccess) return -1;
+      if (guard() && hipMemset(q + ncap, 0xA5, guard() * sizeof(T)) != hipSuccess) return -1;
       if (keep && p && cap) { if (hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1; (void)hipStreamSynchronize(s); }
-      if (p) (void)hipFree(p);
+      if (p) { check(); (void)hipFree(p); }
       p = q; cap = ncap;
       return 0;
    }
-   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+   void release() { if (p) { check(); (void)hipFree(p); } p = nullptr; cap = 0; }
 };
 
 /* results block on the device / pinned host mirror */
