@@ -15,3 +15,11 @@ def test_random_water_systems_match_the_oracle(seed):
     from fuzz_parity import run_cases
     worst, worst_t, bad = run_cases(8, seed, verbose=False)
     assert bad == 0 and worst < 1e-9 and worst_t < 1e-6
+
+
+def test_random_lipid_tilings_shifts_and_domain_grids_match_the_oracle():
+    """the molecular path (exclusions, every bonded kind, charges, Berendsen) on random tilings of the lipid deck,
+    rigidly shifted by random vectors, on random grids of emulated domains (tools/fuzz_lipid.py)"""
+    from fuzz_lipid import run_cases
+    worst, worst_t, bad = run_cases(6, 5, verbose=False)
+    assert bad == 0 and worst < 1e-9 and worst_t < 1e-6
