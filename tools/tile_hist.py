@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ddcmd_amd
 from ddcmd_amd.martini import MartiniHIP
 s = ddcmd_amd.make_water_setup(50)
