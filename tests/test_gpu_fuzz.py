@@ -23,3 +23,11 @@ def test_random_lipid_tilings_shifts_and_domain_grids_match_the_oracle():
     from fuzz_lipid import run_cases
     worst, worst_t, bad = run_cases(6, 5, verbose=False)
     assert bad == 0 and worst < 1e-9 and worst_t < 1e-6
+
+
+def test_feature_combinations_match_the_oracle():
+    """thermostat kind (FREE / BERENDSEN / LANGEVIN) x velocity constraints x barostat x RESTRAINT potential on the
+    lipid deck: all 24 combinations follow the oracle over 25 steps with mixed step batching (tools/fuzz_features.py)"""
+    from fuzz_features import run
+    worst, bad = run(verbose=False)
+    assert bad == 0 and worst < 1e-6
