@@ -1473,6 +1473,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
+   (void)hipMemset(ctx->d_flags, 0, 16 * sizeof(int));
    if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
@@ -1759,7 +1760,8 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
                                   const double *vx, const double *vy, const double *vz,
                                   const uint64_t *gid, const int *species, const int *group)
 {
-   if (!ctx || nlocal <= 0 || !rx || !ry || !rz || !species) return DDCMI_EINVAL;
+   /* nlocal == 0: a domain of a decomposed run that holds no bead yet (vacuum, a droplet elsewhere) */
+   if (!ctx || nlocal < 0 || (nlocal > 0 && (!rx || !ry || !rz || !species))) return DDCMI_EINVAL;
    if (ctx->nspecies <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_species must be called before ddcmi_upload_state");
    { int rct = nb_tables(ctx); if (rct) return rct; }
    (void)hipSetDevice(ctx->device);
@@ -1773,9 +1775,15 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    ENSURE(ctx, ctx->pos, cap); ENSURE(ctx, ctx->pos2, cap);
    ENSURE(ctx, ctx->gid, cap); ENSURE(ctx, ctx->gid2, cap);
    dbuf<double> *d3[] = {&ctx->vx, &ctx->vy, &ctx->vz, &ctx->vx2, &ctx->vy2, &ctx->vz2, &ctx->fx, &ctx->fy, &ctx->fz};
-   for (auto b : d3) ENSURE(ctx, *b, n);
+   for (auto b : d3) ENSURE(ctx, *b, n + 1);
    dbuf<int> *i1[] = {&ctx->species, &ctx->species2, &ctx->group, &ctx->group2, &ctx->orig, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->nimg, &ctx->img_off};
    for (auto b : i1) ENSURE(ctx, *b, n + 1);
+   if (n == 0)
+   {
+      ctx->nloc = 0; ctx->nhalo = 0; ctx->npad = DDCMI_BLOCK; ctx->self_ele = 0.0;
+      ctx->list_valid = false; ctx->forces_valid = false;
+      return DDCMI_OK;
+   }
    /* stage through vx2/vy2/vz2 as scratch for the positions */
    HIPCHK(ctx, hipMemcpyAsync(ctx->vx2.p, rx, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
    HIPCHK(ctx, hipMemcpyAsync(ctx->vy2.p, ry, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1904,9 +1912,9 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
    for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
    HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_o.p, 0, (ncell + 1) * sizeof(int), st));
    HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_h.p, 0, ncell * sizeof(int), st));
+   HIPCHK(ctx, hipMemsetAsync(ctx->d_flags + 12, 0, sizeof(int), st));
    if (n > 0)
    {
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_flags + 12, 0, sizeof(int), st));
       hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12);
    }
    HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_o.p, ctx->cell_cnt_o.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -382,7 +382,7 @@ static int mg_xchg_data_local(ddcmi_group *g, int which /*0 migration, 1 halo5, 
             if (n <= 0) continue;
             int roff = 0;
             for (int c = 0; c < code; c++) roff += B->mig_rcnt[c];
-            HIPCHK(A, hipMemcpy(B->mig_in.p + (size_t)roff * 10, A->mig_out.p + (size_t)code * A->mig_cap * 10, (size_t)n * 10 * sizeof(double), hipMemcpyDeviceToDevice));
+            HIPCHK(A, hipMemcpyAsync(B->mig_in.p + (size_t)roff * 10, A->mig_out.p + (size_t)code * A->mig_cap * 10, (size_t)n * 10 * sizeof(double), hipMemcpyDeviceToDevice, A->stream));
          }
          else
          {
@@ -390,9 +390,13 @@ static int mg_xchg_data_local(ddcmi_group *g, int which /*0 migration, 1 halo5, 
             if (n <= 0) continue;
             int w = (which == 1) ? 5 : 3;
             double *dst = (which == 1 ? B->hrecv5.p : B->hrecv3.p) + (size_t)B->recv_off[code] * w;
-            HIPCHK(A, hipMemcpy(dst, A->sendbuf.p + (size_t)A->send_off[code] * w, (size_t)n * w * sizeof(double), hipMemcpyDeviceToDevice));
+            HIPCHK(A, hipMemcpyAsync(dst, A->sendbuf.p + (size_t)A->send_off[code] * w, (size_t)n * w * sizeof(double), hipMemcpyDeviceToDevice, A->stream));
          }
       }
+   /* a device-to-device hipMemcpy on the null stream is ordered neither with the host nor with the ranks'
+    * non-blocking streams: the copies go on the sender's stream and every stream is drained before the
+    * receivers' kernels are queued */
+   for (ddcmi_ctx *A : g->ranks) HIPCHK(A, hipStreamSynchronize(A->stream));
    return DDCMI_OK;
 }
 

@@ -31,3 +31,11 @@ def test_feature_combinations_match_the_oracle():
     from fuzz_features import run
     worst, bad = run(verbose=False)
     assert bad == 0 and worst < 1e-6
+
+
+def test_random_water_systems_on_random_domain_grids():
+    """the same random systems on grids of up to 3x3x3 emulated domains: narrow domains (down to one list radius),
+    domains that hold no bead at all, beads crossing faces"""
+    from fuzz_parity import run_cases
+    worst, worst_t, bad = run_cases(10, 21, verbose=False, domains=True)
+    assert bad == 0 and worst < 1e-9 and worst_t < 1e-6

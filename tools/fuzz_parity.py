@@ -8,9 +8,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import pyoracle
 import ddcmd_amd
-from ddcmd_amd.martini import MartiniHIP
+from ddcmd_amd.martini import MartiniHIP, MartiniGroup
 
-def run_cases(ncases, seed, verbose=True):
+def run_cases(ncases, seed, verbose=True, domains=False):
     """returns (worst step-0 error, worst 25-step error, number of mismatching cases)"""
     rng = np.random.default_rng(seed)
     worst = 0.0
@@ -42,10 +42,20 @@ def run_cases(ncases, seed, verbose=True):
         o = pyoracle.Oracle(s)
         o.L.orc_back_in_box(__import__("ctypes").byref(o.p), o.n, pyoracle._d(o.rx), pyoracle._d(o.ry), pyoracle._d(o.rz))
         e0, v0 = o.forces()
-        m = MartiniHIP(s)
-        e, vir = m.eval_forces()
-        f = m.download()["f"]
-        fo = np.stack((o.fx, o.fy, o.fz)); fg = np.stack(f)
+        grid = (1, 1, 1)
+        if domains:      # emulated domains, some of them possibly empty; a domain must be at least a list radius wide
+            box = np.array([s.h[0], s.h[4], s.h[8]])
+            grid = tuple(int(g) if box[a] / g >= 1.05 * (s.rmax + s.deltaR) else 1 for a, g in enumerate(rng.choice([1, 2, 2, 3], size=3)))
+        if grid == (1, 1, 1):
+            m = MartiniHIP(s)
+            e, vir = m.eval_forces()
+            fg = np.stack(m.download()["f"])
+            fo = np.stack((o.fx, o.fy, o.fz))
+        else:
+            m = MartiniGroup(s, grid)
+            e, vir = m.eval_forces()
+            fg = np.stack(m.gather()["f"])
+            fo = np.stack((o.fx, o.fy, o.fz))[:, np.argsort(s.gid, kind="stable")]
         scale = max(np.abs(fo).max(), 1e-30)
         err_f = np.abs(fg - fo).max() / scale
         err_e = abs(e["total"] - e0["total"]) / max(abs(e0["total"]), 1e-12)
@@ -60,11 +70,11 @@ def run_cases(ncases, seed, verbose=True):
         flag = "" if (err_f < 1e-9 and err_e < 1e-9 and err_t < 1e-6 and err_k < 1e-6) else "   <-- MISMATCH"
         bad += bool(flag)
         if verbose:
-          print("case %2d n=%d beads=%6d box x%.1f x%.1f x%.1f pbc=%d %-7s dF %.1e dE %.1e | 25 steps dE %.1e dKE %.1e%s" % (
-            case, n, s.natoms, fac[0], fac[1], fac[2], pbc, kind, err_f, err_e, err_t, err_k, flag), flush=True)
+          print("case %2d n=%d beads=%6d grid %s box x%.1f x%.1f x%.1f pbc=%d %-7s dF %.1e dE %.1e | 25 steps dE %.1e dKE %.1e%s" % (
+            case, n, s.natoms, grid, fac[0], fac[1], fac[2], pbc, kind, err_f, err_e, err_t, err_k, flag), flush=True)
     return worst, worst_t, bad
 
 
 if __name__ == "__main__":
-    w, wt, bad = run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    w, wt, bad = run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1, domains=len(sys.argv) > 3)
     print("worst step-0 error %.2e, worst 25-step error %.2e, %d mismatching cases" % (w, wt, bad))
