@@ -8,9 +8,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import pyoracle
 import ddcmd_amd
-from ddcmd_amd.martini import MartiniHIP, MartiniGroup
+from ddcmd_amd.martini import MartiniHIP, MartiniGroup, MartiniRank, _declare_domains
 
-def run_cases(ncases, seed, verbose=True, domains=False):
+def run_cases(ncases, seed, verbose=True, domains=False, loopback=False):
     """returns (worst step-0 error, worst 25-step error, number of mismatching cases)"""
     rng = np.random.default_rng(seed)
     worst = 0.0
@@ -22,6 +22,7 @@ def run_cases(ncases, seed, verbose=True, domains=False):
         L = s.h[0]
         fac = rng.choice([1.0, 1.0, 1.3, 1.9, 2.6], size=3)
         pbc = int(rng.choice([7, 7, 7, 0, 3, 5, 6, 1]))
+        s.updateRate = int(rng.choice([20, 20, 7, 0]))           # 0: rebuilds when neighborCheck asks
         s.pbc = pbc
         s.h = np.array([L * fac[0], 0, 0, 0, L * fac[1], 0, 0, 0, L * fac[2]])
         keep = np.ones(s.natoms, bool)
@@ -46,7 +47,21 @@ def run_cases(ncases, seed, verbose=True, domains=False):
         if domains:      # emulated domains, some of them possibly empty; a domain must be at least a list radius wide
             box = np.array([s.h[0], s.h[4], s.h[8]])
             grid = tuple(int(g) if box[a] / g >= 1.05 * (s.rmax + s.deltaR) else 1 for a, g in enumerate(rng.choice([1, 2, 2, 3], size=3)))
-        if grid == (1, 1, 1):
+        if loopback:     # the periodic images travel through a 1-rank RCCL communicator (the multi-GPU transport)
+            import ctypes
+            os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
+            m = MartiniRank(s, np.arange(s.natoms))
+            _declare_domains(m.lib)
+            buf = ctypes.create_string_buffer(128)
+            assert m.lib.ddcmi_comm_unique_id(buf) == 0
+            m.comm_init(0, 1, buf.raw, (1, 1, 1))
+            m.upload_local()
+            e, vir = m.eval_forces()
+            pp = m.download_particles()
+            fg = np.stack(pp["f"])[:, np.argsort(pp["gid"], kind="stable")]
+            fo = np.stack((o.fx, o.fy, o.fz))[:, np.argsort(s.gid, kind="stable")]
+            grid = "rccl"
+        elif grid == (1, 1, 1):
             m = MartiniHIP(s)
             e, vir = m.eval_forces()
             fg = np.stack(m.download()["f"])
@@ -76,5 +91,5 @@ def run_cases(ncases, seed, verbose=True, domains=False):
 
 
 if __name__ == "__main__":
-    w, wt, bad = run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1, domains=len(sys.argv) > 3)
+    w, wt, bad = run_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1, domains=len(sys.argv) > 3 and sys.argv[3] == "domains", loopback=len(sys.argv) > 3 and sys.argv[3] == "loopback")
     print("worst step-0 error %.2e, worst 25-step error %.2e, %d mismatching cases" % (w, wt, bad))
