@@ -1476,6 +1476,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    (void)hipMemset(ctx->d_flags, 0, 16 * sizeof(int));
    if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
+   (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the context's non-blocking stream */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
    { const char *ov = getenv("DDCMI_HALO_OVERLAP"); ctx->halo_overlap = (ov && atoi(ov) != 0); }
    { const char *gv = getenv("DDCMI_GRAPH_MAX_BEADS"); if (gv) ctx->graph_max_beads = atoi(gv); }      /* 0 switches the step graph off */

@@ -64,7 +64,7 @@ struct SegTab { int off[28]; signed char code[28]; int nseg; };
 
 /* DDCMI_DEBUG_GUARD=1 (debugging aid): device buffers get exactly the requested size plus a 256-byte canary that
  * is verified when the buffer is grown or released -- a write beyond a buffer aborts with a message instead of
- * landing in the slack the normal sizing leaves */
+ * landing in the slack the normal sizing leaves; =2 also fills fresh buffers with 0xFF bytes */
 static inline int ddcmi_debug_guard()
 {
    static int g = -1;
@@ -92,6 +92,8 @@ template <class T> struct dbuf
       T *q = nullptr;
       if (hipMalloc((void **)&q, (ncap + guard()) * sizeof(T)) != hipSuccess) return -1;
       if (guard() && hipMemset(q + ncap, 0xA5, guard() * sizeof(T)) != hipSuccess) return -1;
+      if (ddcmi_debug_guard() >= 2 && hipMemset(q, 0xFF, ncap * sizeof(T)) != hipSuccess) return -1;      /* 2: poison fresh buffers (NaN / -1): reads of never-written elements show */
+      if (ddcmi_debug_guard()) (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the contexts' non-blocking streams */
       if (keep && p && cap) { if (hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1; (void)hipStreamSynchronize(s); }
       if (p) { check(); (void)hipFree(p); }
       p = q; cap = ncap;
