@@ -18,7 +18,10 @@ def run_cases(ncases, seed, verbose=True, domains=False, loopback=False):
     bad = 0
     for case in range(ncases):
         n = int(rng.integers(6, 13))
-        s = ddcmd_amd.make_water_setup(n, seed=int(rng.integers(1, 1 << 30)), temperature_K=float(rng.choice([50.0, 310.0])))
+        rcut, skin = float(rng.choice([12.0, 12.0, 9.0, 11.0, 15.0])), float(rng.choice([4.0, 4.0, 2.0, 5.0]))      # list radius <= 20 A: a tile neighbourhood must fit the LDS (DESIGN.md limits)
+        if n * 8.12 < 2.05 * (rcut + skin):          # the box must hold two list radii per periodic axis
+            rcut, skin = 12.0, 4.0
+        s = ddcmd_amd.make_water_setup(n, seed=int(rng.integers(1, 1 << 30)), temperature_K=float(rng.choice([50.0, 310.0])), rcut_A=rcut, skin_A=skin)
         L = s.h[0]
         fac = rng.choice([1.0, 1.0, 1.3, 1.9, 2.6], size=3)
         pbc = int(rng.choice([7, 7, 7, 0, 3, 5, 6, 1]))
@@ -85,8 +88,8 @@ def run_cases(ncases, seed, verbose=True, domains=False, loopback=False):
         flag = "" if (err_f < 1e-9 and err_e < 1e-9 and err_t < 1e-6 and err_k < 1e-6) else "   <-- MISMATCH"
         bad += bool(flag)
         if verbose:
-          print("case %2d n=%d beads=%6d grid %s box x%.1f x%.1f x%.1f pbc=%d %-7s dF %.1e dE %.1e | 25 steps dE %.1e dKE %.1e%s" % (
-            case, n, s.natoms, grid, fac[0], fac[1], fac[2], pbc, kind, err_f, err_e, err_t, err_k, flag), flush=True)
+          print("case %2d n=%d rc %.0f+%.0f beads=%6d grid %s box x%.1f x%.1f x%.1f pbc=%d %-7s dF %.1e dE %.1e | 25 steps dE %.1e dKE %.1e%s" % (
+            case, n, rcut, skin, s.natoms, grid, fac[0], fac[1], fac[2], pbc, kind, err_f, err_e, err_t, err_k, flag), flush=True)
     return worst, worst_t, bad
 
 
