@@ -39,3 +39,11 @@ def test_random_water_systems_on_random_domain_grids():
     from fuzz_parity import run_cases
     worst, worst_t, bad = run_cases(10, 21, verbose=False, domains=True)
     assert bad == 0 and worst < 1e-9 and worst_t < 1e-6
+
+
+def test_one_context_reused_for_different_systems():
+    """new box + new beads uploaded into the same context, sizes growing and shrinking: every system matches the oracle
+    as on a fresh context (tools/fuzz_reuse.py)"""
+    from fuzz_reuse import run
+    worst, bad = run(8, 9, verbose=False)
+    assert bad == 0
