@@ -90,9 +90,12 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        # control plane (unique-id broadcast, barriers, max over ranks): torch.distributed over RCCL; the data path's
-        # RCCL communicator is libddcmi's own.  DDCMI_BENCH_CONTROL=gloo moves the control plane to CPU/TCP.
-        control = os.environ.get("DDCMI_BENCH_CONTROL", "nccl")
+        # The data path (halo exchange, migration, count all-gathers, energy all-reduce) runs over libddcmi's own RCCL
+        # communicator.  The control plane of this script (broadcast of the RCCL unique id, barriers, max of the
+        # timings) goes over gloo by default, so that the process holds exactly one RCCL communicator -- the
+        # configuration validated on one GPU through the loopback mode; DDCMI_BENCH_CONTROL=nccl uses torch's
+        # RCCL backend for it instead.
+        control = os.environ.get("DDCMI_BENCH_CONTROL", "gloo")
         if control == "gloo":
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
@@ -204,7 +207,7 @@ def main():
                    "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
                    "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
                    "energy_virial_every_step": True,
-                   "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo" % grid) if world > 1 else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),
+                   "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo (control plane: %s)" % (grid + (control,))) if world > 1 else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),
                    "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
         "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
