@@ -50,30 +50,37 @@ def run_cases(ncases, seed, verbose=True, domains=False, loopback=False):
         if domains:      # emulated domains, some of them possibly empty; a domain must be at least a list radius wide
             box = np.array([s.h[0], s.h[4], s.h[8]])
             grid = tuple(int(g) if box[a] / g >= 1.05 * (s.rmax + s.deltaR) else 1 for a, g in enumerate(rng.choice([1, 2, 2, 3], size=3)))
-        if loopback:     # the periodic images travel through a 1-rank RCCL communicator (the multi-GPU transport)
-            import ctypes
-            os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
-            m = MartiniRank(s, np.arange(s.natoms))
-            _declare_domains(m.lib)
-            buf = ctypes.create_string_buffer(128)
-            assert m.lib.ddcmi_comm_unique_id(buf) == 0
-            m.comm_init(0, 1, buf.raw, (1, 1, 1))
-            m.upload_local()
-            e, vir = m.eval_forces()
-            pp = m.download_particles()
-            fg = np.stack(pp["f"])[:, np.argsort(pp["gid"], kind="stable")]
-            fo = np.stack((o.fx, o.fy, o.fz))[:, np.argsort(s.gid, kind="stable")]
-            grid = "rccl"
-        elif grid == (1, 1, 1):
-            m = MartiniHIP(s)
-            e, vir = m.eval_forces()
-            fg = np.stack(m.download()["f"])
-            fo = np.stack((o.fx, o.fy, o.fz))
-        else:
-            m = MartiniGroup(s, grid)
-            e, vir = m.eval_forces()
-            fg = np.stack(m.gather()["f"])
-            fo = np.stack((o.fx, o.fy, o.fz))[:, np.argsort(s.gid, kind="stable")]
+        try:
+            if loopback:     # the periodic images travel through a 1-rank RCCL communicator (the multi-GPU transport)
+                import ctypes
+                os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
+                m = MartiniRank(s, np.arange(s.natoms))
+                _declare_domains(m.lib)
+                buf = ctypes.create_string_buffer(128)
+                assert m.lib.ddcmi_comm_unique_id(buf) == 0
+                m.comm_init(0, 1, buf.raw, (1, 1, 1))
+                m.upload_local()
+                e, vir = m.eval_forces()
+                pp = m.download_particles()
+                fg = np.stack(pp["f"])[:, np.argsort(pp["gid"], kind="stable")]
+                fo = np.stack((o.fx, o.fy, o.fz))[:, np.argsort(s.gid, kind="stable")]
+                grid = "rccl"
+            elif grid == (1, 1, 1):
+                m = MartiniHIP(s)
+                e, vir = m.eval_forces()
+                fg = np.stack(m.download()["f"])
+                fo = np.stack((o.fx, o.fy, o.fz))
+            else:
+                m = MartiniGroup(s, grid)
+                e, vir = m.eval_forces()
+                fg = np.stack(m.gather()["f"])
+                fo = np.stack((o.fx, o.fy, o.fz))[:, np.argsort(s.gid, kind="stable")]
+        except Exception as ex:
+            if "LDS" in str(ex):      # a stated limit: coarse cells of a narrow domain / a long list radius
+                if verbose:
+                    print("case %2d skipped: %s" % (case, str(ex)[-90:]), flush=True)
+                continue
+            raise
         scale = max(np.abs(fo).max(), 1e-30)
         err_f = np.abs(fg - fo).max() / scale
         err_e = abs(e["total"] - e0["total"]) / max(abs(e0["total"]), 1e-12)
