@@ -217,3 +217,15 @@ def test_ddcmi_md_nglfgpulangevin(tmp_path):
         if k + 1 < len(rows):
             e, vir, rk, tion = o.step_npt(s.printrate, s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau)
     assert abs(rows[-1, 8] - rows[0, 8]) > 1e-6
+
+
+def test_ddcmi_md_accepts_the_gpu_integrator_names(tmp_path):
+    """the reference's accelerator integrator names NGLFGPU (integrator.c:78-83) and our NGLFHIP select the same NGLF
+    step: identical data files"""
+    out = []
+    for name in ("NGLF", "NGLFGPU", "NGLFHIP"):
+        data = str(tmp_path / ("data_" + name))
+        r = subprocess.run([EXE, "-o", DECK, "-d", data, "-x", "nglf INTEGRATOR {type = %s;}" % name], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1000:]
+        out.append(open(data).read())
+    assert out[0] == out[1] == out[2]
