@@ -361,3 +361,21 @@ def test_velocity_constraints_deck_and_solver():
     v0 = o.vx.copy()
     assert o.constraint_sweep(1) == 1
     assert np.abs(o.vx - v0).max() < 1e-10 * np.abs(v0).max()
+
+
+def test_molecule_lists_of_the_lipid_deck():
+    """molecule_lists: molecules = runs of equal gid >> 32; the barostat's molecular virial runs over those of two or
+    more beads, N kB T counts all of them (molecularPressure.c:57-67)"""
+    import os
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.martini import molecule_lists
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck", "object.data")
+    s = load_deck(deck)
+    nmol, off, atoms = molecule_lists(s)
+    assert nmol == 120 + 8 + 883
+    assert off.size - 1 == 128 and atoms.size == 120 * 12 + 8 * 5
+    sizes = np.diff(off)
+    assert sorted(set(sizes.tolist())) == [5, 12]
+    for m in (0, 57, 127):          # every listed molecule is one gid >> 32 group, complete
+        g = np.asarray(s.gid)[atoms[off[m]:off[m + 1]]] >> np.uint64(32)
+        assert np.all(g == g[0]) and int(np.sum((np.asarray(s.gid) >> np.uint64(32)) == g[0])) == sizes[m]
