@@ -239,13 +239,19 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          const double4 me = pos[i];
          double fxi = 0, fyi = 0, fzi = 0;
          /* three loops, each of one kind: the lanes of a wave run the same code in every trip */
-         if (!HEAVY)
+         /* the row and the partner's slot of the NEXT trip are fetched while this trip's bead record is in
+          * flight and its term is evaluated: one exposed memory latency per trip instead of three */
+         if (!HEAVY && b1 > b0)
+         {
+         int2 row_n = gr.brow[b0];
+         int s_n = slot[row_n.x];
          for (int r = b0; r < b1; r++)
          {
-            const int2 row = gr.brow[r];
+            const int2 row = row_n;
+            const double4 q = pos[s_n];
+            if (r + 1 < b1) { row_n = gr.brow[r + 1]; s_n = slot[row_n.x]; }
             const int role = row.y & 3;
             const double2 par = gr.bpar[row.y >> 2];
-            const double4 q = pos[slot[row.x]];
             double e, fD[3], vir[6];
             bond_eval(box, role == 0 ? me : q, role == 0 ? q : me, par.x, par.y, e, fD, vir);
             const double sg = role == 0 ? 1.0 : -1.0;
@@ -257,12 +263,19 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
                for (int k = 0; k < 6; k++) acc[4 + k] += vir[k];
             }
          }
+         }
+         if (a1 > a0)
+         {
+         const int4 *arows = HEAVY ? gr.harow : gr.arow;
+         int4 arow_n = arows[a0];
+         int s1_n = slot[arow_n.x], s2_n = slot[arow_n.y];
          for (int r = a0; r < a1; r++)
          {
-            const int4 row = HEAVY ? gr.harow[r] : gr.arow[r];
+            const int4 row = arow_n;
+            const double4 q1 = pos[s1_n], q2 = pos[s2_n];
+            if (r + 1 < a1) { arow_n = arows[r + 1]; s1_n = slot[arow_n.x]; s2_n = slot[arow_n.y]; }
             const int role = row.z & 3;
             const double4 par = gr.apar[row.z >> 2];
-            const double4 q1 = pos[slot[row.x]], q2 = pos[slot[row.y]];
             double e, fI[3], fK[3], vir[6];
             if (angle_eval<HEAVY>(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role == 2 ? me : q2, (int)par.z, par.x, par.y, excl_mask, e, fI, fK, vir))
             {
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
                else if (role == 2) { fxi += fK[0]; fyi += fK[1]; fzi += fK[2]; }
                else { fxi -= fI[0] + fK[0]; fyi -= fI[1] + fK[1]; fzi -= fI[2] + fK[2]; }
             }
+         }
          }
          if (HEAVY)
          for (int r = t0; r < t1; r++)
