@@ -138,6 +138,33 @@ def test_synthetic_water_25_steps_with_rebuild():
     m.close()
 
 
+def test_water_64k_forces_and_energies_every_step():
+    """BASELINE configs[1]: the 64k-bead class water box (62.5k beads, rcut 12 A, skin 4 A), forces, energies,
+    kinetic energy and virial diffed against the CPU oracle after EVERY step, across the rebuild at step 20"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(25)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    m = MartiniHIP(s)
+    m.eval_forces()
+    worst = 0.0
+    for step in range(22):
+        eo, vo, rko, tiono = o.step(1)
+        m.step(1)
+        e, vir, rk, tion = m.energies()
+        assert abs(e["lj"] - eo["lj"]) < TOL * abs(eo["lj"]), step
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), step
+        assert abs(rk - rko) < TOL * rko, step
+        assert np.abs(vir - vo).max() < TOL * np.abs(vo).max(), step
+        assert np.abs(tion - tiono).max() < TOL * np.abs(tiono).max(), step
+        err = rel_force_err(_forces(m), (o.fx, o.fy, o.fz))
+        worst = max(worst, err)
+        assert err < TOL, step
+    assert m.list_stats()["rebuilds"] == 2
+    assert worst < 1e-9          # far inside the 1e-6 the north star asks for
+    m.close()
+
+
 def test_charged_beads_reaction_field():
     """HAS_Q kernel variant: random +-1 charges on water beads exercise LJ + RF Coulomb + self term"""
     from ddcmd_amd.martini import MartiniHIP
