@@ -151,6 +151,37 @@ def test_decomposition_consistent_at_1M():
     g.close()
 
 
+@pytest.fixture(scope="module")
+def water_4M_single():
+    """the headline box after 45 steps on one domain: energies, kinetic energy, virial"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(100)
+    m = MartiniHIP(s)
+    m.eval_forces()
+    m.step(45)
+    e1, v1, rk1, _ = m.energies()
+    m.close()
+    return s, e1, v1, rk1
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
+def test_bench_decompositions_at_4M(water_4M_single, grid):
+    """the bricks bench.py --gpus 2/4/8 uses, on the 4.0 M-bead box itself (emulated domains on one GPU):
+    same energies, kinetic energy and virial as the single domain after 45 steps (3 rebuilds with migration),
+    no bead lost -- the buffer sizes, halo tables and migration of the multi-GPU runs at their real sizes"""
+    from ddcmd_amd.martini import MartiniGroup
+    s, e1, v1, rk1 = water_4M_single
+    g = MartiniGroup(s, grid)
+    g.eval_forces()
+    g.step(45)
+    e, v, rk, _ = g.energies()
+    assert abs(e["total"] - e1["total"]) < 1e-9 * abs(e1["total"])
+    assert abs(rk - rk1) < 1e-9 * rk1
+    assert np.abs(v - v1).max() < 1e-9 * np.abs(v1).max()
+    assert sum(int(r.lib.ddcmi_nlocal(r.ctx)) for r in g.ranks) == s.natoms
+    g.close()
+
+
 def test_lipid_bilayer_2M_beads_periodic_copies():
     """BASELINE config 5 size: the lipid deck tiled 12x12x6 (2.04M beads, ~0.9M bonded terms).
     A periodic box repeated is the same system: every copy of a bead must feel the force the
