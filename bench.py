@@ -190,9 +190,9 @@ def main():
     # HBM bytes of the nonbonded kernel from the PMC passes committed under profiles/ (same workload only)
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if world == 1 and args.n == 100 and args.workload == "water":
-            traffic = tj["traffic_bytes_per_launch"]
+        pmc_file = {100: "r01_traffic.json", 64: "r01_1M_traffic.json"}.get(args.n)
+        if world == 1 and pmc_file and args.workload == "water":
+            traffic = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
     out = {
