@@ -575,11 +575,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       /* residency of the tile's workgroup in k_nonbond: (passes x list groups per lane),
        * scaled so that a full tile counts its list entries, + staging */
       constexpr int NWAVES = NB_THREADS / 64;
-      int R = 64;
-      while (R > 1 && (R >> 1) * NWAVES >= nown) R >>= 1;
-      int npass = ((nown + R - 1) / R + NWAVES - 1) / NWAVES;
-      int ngrp = (ta.tile_width[t] + 7) >> 3, parts = 64 / R;
-      ta.tile_work[t] = (npass * ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES + (5 * tot) / 2 + 1) | (s_halo ? (1 << 30) : 0);      /* bit 30: stages image/halo beads */
+      const int ngrp = (ta.tile_width[t] + 7) >> 3;
+      int work = 0;
+      for (int row0 = 0; row0 < nown; row0 += 64 * NWAVES)      /* k_nonbond's passes over a tile with more beads than threads */
+      {
+         const int nhere = min(nown - row0, 64 * NWAVES);
+         int R = 64;
+         while (R > 1 && (R >> 1) * NWAVES >= nhere) R >>= 1;
+         const int parts = 64 / R;
+         work += ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES;
+      }
+      ta.tile_work[t] = (work + (5 * tot) / 2 + 1) | (s_halo ? (1 << 30) : 0);      /* bit 30: stages image/halo beads */
    }
 }
 
@@ -845,18 +851,23 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
        * keeping the LDS of the CU busy with two working waves. */
       const int lane = threadIdx.x & 63;
       constexpr int NWAVES = NB_BLOCK / 64;
+      /* a tile with more beads than threads: the rows beyond the first 64*NWAVES are again spread over all
+       * waves (small R, many lanes per bead) instead of queueing behind the first waves as whole chunks */
+      for (int row0 = 0; row0 < nown; row0 += 64 * NWAVES)
+      {
+      const int nhere = min(nown - row0, 64 * NWAVES);
       int R = 64;
-      while (R > 1 && (R >> 1) * NWAVES >= nown) R >>= 1;
-      const int nchunks = (nown + R - 1) / R;
+      while (R > 1 && (R >> 1) * NWAVES >= nhere) R >>= 1;
+      const int nchunks = (nhere + R - 1) / R;
       for (int chunk = threadIdx.x >> 6; chunk < nchunks; chunk += NWAVES)
       {
-         int kb = min(R, nown - chunk * R);
+         int kb = min(R, nhere - chunk * R);
          int parts = 64 / R;
          while (parts * 2 * kb <= 64) parts *= 2;
          int sub = lane & (parts - 1);
          int ain = lane / parts;
          bool active = ain < kb;
-         int al = chunk * R + (active ? ain : 0);
+         int al = row0 + chunk * R + (active ? ain : 0);
          int a = ts + al;
          double4 pi = pos[a];
          int ti = (int)(__double_as_longlong(pi.w) & 0xffll);
@@ -993,6 +1004,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
             fxi += __shfl_xor(fxi, off, 64); fyi += __shfl_xor(fyi, off, 64); fzi += __shfl_xor(fzi, off, 64);
          }
          if (active && sub == 0) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; }
+      }
       }
    }
 #ifdef DDCMI_TRACE_BLOCKS
