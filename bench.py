@@ -29,38 +29,77 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DT_FS = 20.0
 
 
-def cpu_baseline(n_lattice, seconds_budget=20.0):
-    """Oracle (port of bioMartini.c/pairlist.c/nglf.c) on one core, bounded sample."""
+def cpu_baseline(n_lattice, seconds_budget=18.0):
+    """Oracle (port of bioMartini.c/pairlist.c/nglf.c) on one core, bounded samples: the synthetic water
+    box at n_lattice (62.5k beads) and -- SURVEY 8(d) -- the reference's own 6173-bead examples/waterbox."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     import ddcmd_amd
     import tempfile
+    import numpy as np
     native = os.path.join(tempfile.gettempdir(), "libddc_oracle_native_%d.so" % os.getpid())
     try:
         pyoracle.build(native=True, out=native)
         libpath = native
     except Exception:
         libpath = None
+
+    def timed(s, budget):
+        period = max(int(s.updateRate), 1)
+        o = pyoracle.Oracle(s, libpath)
+        o.forces()
+        t0 = time.time()
+        o.step(1)
+        per = max(time.time() - t0, 1e-4)
+        steps = int(max(period, min(10 * period, budget / per)))
+        steps = (steps // period) * period   # whole rebuild periods
+        o.step(period)                       # warm-up incl. one rebuild
+        t0 = time.time()
+        o.step(steps)
+        return steps, time.time() - t0
+
     s = ddcmd_amd.make_water_setup(n_lattice)
-    o = pyoracle.Oracle(s, libpath)
-    o.forces()
-    t0 = time.time()
-    o.step(1)
-    per = max(time.time() - t0, 1e-4)
-    steps = int(max(20, min(200, seconds_budget / per)))
-    steps = (steps // 20) * 20           # whole rebuild periods
-    o.step(20)                           # warm-up incl. one rebuild
-    t0 = time.time()
-    o.step(steps)
-    el = time.time() - t0
+    steps, el = timed(s, seconds_budget)
+    out = {"value": s.natoms * steps / el, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+           "host_cores": os.cpu_count(),
+           "sample": "%d-bead Martini water (n=%d lattice), %d NGLF steps incl. %d list rebuilds, gcc -O3 -march=native, 1 thread"
+                     % (s.natoms, n_lattice, steps, steps // max(int(s.updateRate), 1))}
+    try:
+        from ddcmd_amd.deck import setup_from_dict
+        w = setup_from_dict(dict(np.load(os.path.join(ROOT, "tests", "golden", "waterbox.npz"))))
+        steps, el = timed(w, 4.0)
+        out["also"] = [{"value": w.natoms * steps / el, "unit": "atom-steps/s", "cores": 1,
+                        "sample": "the reference's examples/waterbox (%d beads, rcut 11 A, skin 4 A), %d NGLF steps" % (w.natoms, steps)}]
+    except Exception as ex:      # the fixture is optional for the figure above
+        out["also"] = [{"error": str(ex)}]
     try:
         os.remove(native)
     except OSError:
         pass
-    return {"value": s.natoms * steps / el, "unit": "atom-steps/s", "cores": 1, "kind": "port",
-            "host_cores": os.cpu_count(),
-            "sample": "%d-bead Martini water (n=%d lattice), %d NGLF steps incl. %d list rebuilds, gcc -O3 -march=native, 1 thread"
-                      % (s.natoms, n_lattice, steps, steps // 20)}
+    return out
+
+
+def runtime_libs():
+    """which HIP / RCCL runtime this process has mapped (the library is built and validated against /opt/rocm)"""
+    libs = set()
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.split()[-1]
+            base = os.path.basename(path)
+            if base.startswith(("libamdhip64", "librccl", "libhsa-runtime64", "libtorch", "libc10")):
+                libs.add(path)
+    except OSError:
+        pass
+    return sorted(libs)
+
+
+def kernel_source_id():
+    """short hash of the device sources: a PMC file under profiles/ is quoted only for the kernels it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ddcmi.hip", "ddcmi_internal.h", "ddcmi_multigpu.inl"):
+        h.update(open(os.path.join(ROOT, "ddcmd_amd", "csrc", "hip", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -77,30 +116,35 @@ def main():
     ap.add_argument("--rccl-loopback", action="store_true",
                     help="N=1 only: reach the periodic images through a 1-rank RCCL communicator (the multi-GPU transport on one GPU)")
     ap.add_argument("--reps", default="12,12,6", help="lipid workload: copies of the 2363-bead deck along x,y,z (12,12,6 -> 2.04M beads)")
+    ap.add_argument("--check-runtime", action="store_true", help="rendezvous + library load only: print which HIP/RCCL runtime is mapped, touch no device")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("DDCMI_BENCH_SINGLE_DEVICE"):      # debugging aid: all ranks on device 0 (RCCL normally refuses)
+    if os.environ.get("DDCMI_BENCH_SINGLE_DEVICE"):      # all ranks on device 0 (tests on a one-GPU box; needs DDCMI_TRANSPORT=host: RCCL refuses two ranks on a device)
         local_rank = 0
-    dist = None
-    torch = None
+    transport = os.environ.get("DDCMI_TRANSPORT", "rccl")
+    # No torch in this process: libddcmi.so is built and validated against /opt/rocm's HIP and RCCL, and
+    # `import torch` would map torch's bundled copies of the same sonames first.  The control plane (the 128-byte
+    # RCCL id, barriers, the max of the timings) runs over libddcmi's own TCP rendezvous (host/rdzv.c); the data
+    # path (halo exchange, migration, count all-gathers, energy all-reduce) over libddcmi's RCCL communicator.
+    rdzv = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # The data path (halo exchange, migration, count all-gathers, energy all-reduce) runs over libddcmi's own RCCL
-        # communicator.  The control plane of this script (broadcast of the RCCL unique id, barriers, max of the
-        # timings) goes over gloo by default, so that the process holds exactly one RCCL communicator -- the
-        # configuration validated on one GPU through the loopback mode; DDCMI_BENCH_CONTROL=nccl uses torch's
-        # RCCL backend for it instead.
-        control = os.environ.get("DDCMI_BENCH_CONTROL", "gloo")
-        if control == "gloo":
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        ctl_dev = "cpu" if control == "gloo" else "cuda"
+        from ddcmd_amd.martini import Rendezvous
+        rdzv = Rendezvous.from_env()
+    if args.check_runtime:
+        # the launcher and the runtime binding, without touching a device
+        import ddcmd_amd
+        ddcmd_amd.load_library()
+        tok = rdzv.bcast(b"ddcmi-runtime-check-%06d" % os.getpid() if rank == 0 else bytes(26), 0) if rdzv else b""
+        n = rdzv.allreduce([1.0])[0] if rdzv else 1.0
+        print(json.dumps({"rank": rank, "world": world, "ranks_met": int(n), "token": tok.decode(), "runtime_libs": runtime_libs(),
+                          "torch_loaded": "torch" in sys.modules}), flush=True)
+        if rdzv:
+            rdzv.barrier()
+            rdzv.close()
+        return
 
     import numpy as np
     import ddcmd_amd
@@ -134,13 +178,13 @@ def main():
         # and migration run inside libddcmi over RCCL point-to-point (include/ddcmi.h)
         owner = domain_of(s, grid)
         m = MartiniRank(s, np.flatnonzero(owner == rank), device=local_rank)
-        uid = torch.zeros(128, dtype=torch.uint8, device=ctl_dev)
-        if rank == 0:
+        if transport == "host":
+            m.comm_init_host(rdzv, grid)
+        else:
             buf = ctypes.create_string_buffer(128)
-            assert m.lib.ddcmi_comm_unique_id(buf) == 0
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(ctl_dev)
-        dist.broadcast(uid, src=0)
-        m.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()), grid)
+            if rank == 0:
+                assert m.lib.ddcmi_comm_unique_id(buf) == 0
+            m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)      # MPI_Bcast of the id in ddcMD
         m.upload_local()
     nlocal0 = m.n
     m.eval_forces()                       # firstEnergyCall (masters.c:579)
@@ -156,10 +200,9 @@ def main():
     m.sync()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        m.sync()
+        m.sync()                          # this rank's stream is drained ...
+        if rdzv is not None:
+            rdzv.barrier()                # ... and so is everybody else's
 
     m.timing(True)
     barrier()
@@ -174,10 +217,8 @@ def main():
     st = m.list_stats()
     nlocal = int(m.lib.ddcmi_nlocal(m.ctx))
     epot, ekin = e["total"], rk
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=ctl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    if rdzv is not None:
+        el = float(rdzv.allreduce([el], "max")[0])           # the slowest rank's time
         tot = m.allreduce([epot, ekin, float(nlocal)])      # energyInfo.c allreduce()
         epot, ekin = float(tot[0]), float(tot[1])
         assert int(round(tot[2])) == s.natoms, "beads lost in migration"
@@ -187,12 +228,18 @@ def main():
     bytes_per_atom = 36.0 + 24.0 + 4.0 * L
     t_kernel = kernel_ms * 1e-3 / max(1, launches)
     achieved = bytes_per_atom * nlocal / t_kernel / 1e9
-    # HBM bytes of the nonbonded kernel from the PMC passes committed under profiles/ (same workload only)
+    # HBM bytes of the nonbonded kernel from the PMC passes committed under profiles/: quoted only when the file
+    # was collected on this workload AND on these device sources (kernel_src_id), else null
     traffic = None
     try:
-        pmc_file = {100: "r01_traffic.json", 64: "r01_1M_traffic.json"}.get(args.n)
-        if world == 1 and pmc_file and args.workload == "water":
-            traffic = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["traffic_bytes_per_launch"]
+        if world == 1 and not args.rccl_loopback:
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if not fn.endswith("traffic.json"):
+                    continue
+                t = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if t.get("workload") == wname and t.get("kernel_src_id") == kernel_source_id():
+                    traffic = float(t["traffic_bytes_per_launch"])
+                    break
     except Exception:
         traffic = None
     out = {
@@ -207,19 +254,24 @@ def main():
                    "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
                    "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
                    "energy_virial_every_step": True,
-                   "parallelism": ("spatial decomposition %dx%dx%d, RCCL p2p halo (control plane: %s)" % (grid + (control,))) if world > 1 else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),
+                   "parallelism": ("spatial decomposition %dx%dx%d, %s (control plane: libddcmi TCP rendezvous, no torch)"
+                                   % (grid + ("RCCL p2p halo" if transport != "host" else "host-staged TCP halo",))) if world > 1
+                                  else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),
                    "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
         "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "hbm_frac_measured": (traffic / t_kernel / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches,
                      "note": "rank 0's kernel on its own beads" if world > 1 else "whole box"},
         "check": {"epot": epot, "ekin": ekin},
+        "runtime_libs": runtime_libs(),
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)      # N=1 only (the contract): a bounded sample on one host core
     m.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
     if rank == 0:
         ctypes.CDLL(None).fflush(None)                      # anything the libraries left in C stdio goes out first
         print(json.dumps(out), flush=True)

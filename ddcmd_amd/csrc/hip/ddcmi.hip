@@ -2536,13 +2536,14 @@ int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need)
    *need = (2.0 * sqrt(d2max) < ctx->deltaR) ? 0 : 1;
    return DDCMI_OK;
 }
+static int mg_check_one_domain_features(ddcmi_ctx *ctx);
 static int rebuild_due(ddcmi_ctx *ctx, bool *due)
 {
    if (!ctx->list_valid) { *due = true; return DDCMI_OK; }
    if (ctx->updateRate > 0) { *due = (ctx->loop % ctx->updateRate == 0); return DDCMI_OK; }
    int need = 0, rc = ddcmi_displacement_check(ctx, &need);
    if (rc) return rc;
-   if ((ctx->nranks > 1 || ctx->loopback) && ctx->comm)
+   if ((ctx->nranks > 1 || ctx->loopback) && (ctx->comm || ctx->hcomm))
    {
       /* check4updateNeighbor (ddcUpdateAll.c:56): anyone needs a rebuild -> everyone rebuilds */
       double v = (double)need;
@@ -2560,6 +2561,7 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are stepped with ddcmi_group_step_nglf");
    (void)hipSetDevice(ctx->device);
    int rc;
+   if ((rc = mg_check_one_domain_features(ctx))) return rc;
    if (ctx->baro_beta > 0.0 && ctx->nmol_total == 0)
       for (int m = 0; m < ctx->nmoltype; m++)
          if (ctx->mol_nspecies[m] > 1) SETERR(ctx, DDCMI_EINVAL, "the barostat acts on the molecular pressure: molecule type %d has %d beads, call ddcmi_set_molecule_lists first", m, ctx->mol_nspecies[m]);
@@ -2611,7 +2613,12 @@ int ddcmi_group_ke_sums(ddcmi_ctx *ctx)
    if ((ctx->nranks > 1 || ctx->loopback) && ctx->comm && !ctx->group_ && ng > 0)
       if (ncclAllReduce(ctx->d_results + R_GROUP, ctx->d_results + R_GROUP, 2 * ng, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st) != ncclSuccess)
          SETERR(ctx, DDCMI_ECOMM, "ncclAllReduce of the group kinetic energies failed");
-   return fetch_results(ctx);
+   int rc = fetch_results(ctx);
+   if (rc) return rc;
+   if ((ctx->nranks > 1 || ctx->loopback) && ctx->hcomm && !ctx->group_ && ng > 0)      /* host transport: summed on the host copy */
+      if (ddcmi_rdzv_allreduce_f64(ctx->hcomm, ctx->h_results + R_GROUP, 2 * ng, 0) != DDCMI_OK)
+         SETERR(ctx, DDCMI_ECOMM, "all-reduce of the group kinetic energies failed: %s", ddcmi_rdzv_last_error(ctx->hcomm));
+   return DDCMI_OK;
 }
 extern "C" int ddcmi_group_temperatures(ddcmi_ctx *ctx, double *Tgroup)
 {

@@ -61,6 +61,8 @@ struct GridParams
  * starts at off[q].  Remote segments are ordered by (peer rank, direction code), so everything
  * for one peer is contiguous and travels as ONE message per step. */
 struct SegTab { int off[28]; signed char code[28]; int nseg; };
+/* the messages of the per-step halo exchange: one per peer and direction of travel (send / receive), in beads */
+struct HaloMsgs { int n; int peer[27], off[27], cnt[27]; };
 
 /* DDCMI_DEBUG_GUARD=1 (debugging aid): device buffers get exactly the requested size plus a 256-byte canary that
  * is verified when the buffer is grown or released -- a write beyond a buffer aborts with a message instead of
@@ -221,6 +223,9 @@ struct ddcmi_ctx
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
    /* comm */
    int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
+   ddcmi_rdzv *hcomm = nullptr;        /* host transport (ddcmi_comm_init_host): messages staged through the host, carried by TCP streams */
+   std::vector<double> hstage_s, hstage_r;      /* its staging */
+   HaloMsgs hmsg_s, hmsg_r;            /* per-step halo messages (mg_layout_halo) */
    struct ddcmi_group *group_ = nullptr;        /* in-process multi-domain emulation (tests) */
    bool halo_fresh = false;
    SegTab sseg, rseg;                  /* halo send / receive buffer layout (peer-major) */

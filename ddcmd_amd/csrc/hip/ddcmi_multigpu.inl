@@ -268,41 +268,166 @@ static int mg_ensure_owned(ddcmi_ctx *ctx, size_t need)
 /* ---- transport ------------------------------------------------------------ */
 struct ddcmi_group { std::vector<ddcmi_ctx *> ranks; };
 
-/* loopback: a single rank sends its periodic images to itself through RCCL, so the whole
- * transport (counts, grouped send/recv, message matching, all-reduce) runs on one GPU */
-static inline bool mg_remote(const ddcmi_ctx *ctx, int code) { return code != 13 && ctx->dir_dest[code] >= 0 && (ctx->dir_dest[code] != ctx->rank || ctx->loopback); }
+/* loopback: a single rank sends its periodic images to itself through the transport, so the whole
+ * exchange (counts, grouped send/recv, message matching, all-reduce) runs on one GPU */
+static inline bool dir_remote(const int *dest, int rank, bool loopback, int code) { return code != 13 && dest[code] >= 0 && (dest[code] != rank || loopback); }
+static inline bool mg_remote(const ddcmi_ctx *ctx, int code) { return dir_remote(ctx->dir_dest, ctx->rank, ctx->loopback, code); }
 static inline bool mg_selfdir(const ddcmi_ctx *ctx, int code) { return code != 13 && ctx->dir_dest[code] == ctx->rank && !ctx->loopback; }
 static inline int mg_opp(int code) { return 26 - code; }
+static inline bool mg_transport(const ddcmi_ctx *ctx) { return ctx->comm != nullptr || ctx->hcomm != nullptr; }
 
 #define NCCLCHK2(ctx, call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) SETERR(ctx, DDCMI_ECOMM, "%s failed: %s", #call, ncclGetErrorString(_r)); } while (0)
+#define HOSTCHK(ctx, call) do { int _r = (call); if (_r != DDCMI_OK) SETERR(ctx, DDCMI_ECOMM, "%s failed: %s", #call, ddcmi_rdzv_last_error((ctx)->hcomm)); } while (0)
 
-/* RCCL: every rank learns every rank's 27 per-direction counts with ONE all-gather (26 four-byte
+/* ---- host logic shared by every transport (and callable without a GPU) ------ */
+/* what this rank receives, from the all-gathered send counts: the message a neighbour sends along ITS
+ * direction `code` comes from the rank in my direction opp(code) */
+static void plan_recv_counts(const int *dest, int rank, bool loopback, const int *all_counts, int *rcnt)
+{
+   for (int code = 0; code < 27; code++)
+      rcnt[code] = dir_remote(dest, rank, loopback, mg_opp(code)) ? all_counts[27 * dest[mg_opp(code)] + code] : 0;
+}
+/* buffer layout of the halo exchange from the per-direction counts: remote segments ordered by
+ * (peer rank, direction code) on both sides, so the segments of one peer are contiguous and travel as
+ * ONE message (7 at 2x2x2 instead of 26); send_off/recv_off[code] index the same layout */
+static void plan_halo_layout(const int *dest, int rank, int nranks, bool loopback, const int *scnt, const int *rcnt,
+                             SegTab &ss, SegTab &rs, int *send_off, int *recv_off, int *nsend, int *nrecv, HaloMsgs &ms, HaloMsgs &mr)
+{
+   ss.nseg = rs.nseg = 0;
+   int ns = 0, nr = 0;
+   for (int code = 0; code < 28; code++) { send_off[code] = 0; recv_off[code] = 0; }
+   for (int peer = 0; peer < nranks; peer++)
+      for (int code = 0; code < 27; code++)
+      {
+         if (dir_remote(dest, rank, loopback, code) && dest[code] == peer)
+         { ss.code[ss.nseg] = (signed char)code; ss.off[ss.nseg++] = ns; send_off[code] = ns; ns += scnt[code]; }
+         if (dir_remote(dest, rank, loopback, mg_opp(code)) && dest[mg_opp(code)] == peer)
+         { rs.code[rs.nseg] = (signed char)code; rs.off[rs.nseg++] = nr; recv_off[code] = nr; nr += rcnt[code]; }
+      }
+   ss.off[ss.nseg] = ns; rs.off[rs.nseg] = nr;
+   for (int q = ss.nseg + 1; q < 28; q++) ss.off[q] = ns;
+   for (int q = rs.nseg + 1; q < 28; q++) rs.off[q] = nr;
+   send_off[27] = ns; recv_off[27] = nr;
+   *nsend = ns; *nrecv = nr;
+   ms.n = mr.n = 0;
+   for (int q = 0; q < ss.nseg;)
+   {
+      int peer = dest[(int)ss.code[q]], q1 = q;
+      while (q1 < ss.nseg && dest[(int)ss.code[q1]] == peer) q1++;
+      int cnt = ss.off[q1] - ss.off[q];
+      if (cnt > 0) { ms.peer[ms.n] = peer; ms.off[ms.n] = ss.off[q]; ms.cnt[ms.n] = cnt; ms.n++; }
+      q = q1;
+   }
+   for (int q = 0; q < rs.nseg;)
+   {
+      /* rseg.code = the SENDER's direction: it arrives from the rank in my opposite direction */
+      int peer = dest[mg_opp((int)rs.code[q])], q1 = q;
+      while (q1 < rs.nseg && dest[mg_opp((int)rs.code[q1])] == peer) q1++;
+      int cnt = rs.off[q1] - rs.off[q];
+      if (cnt > 0) { mr.peer[mr.n] = peer; mr.off[mr.n] = rs.off[q]; mr.cnt[mr.n] = cnt; mr.n++; }
+      q = q1;
+   }
+}
+extern "C" int ddcmi_plan_recv_counts(int px, int py, int pz, int rank, int pbc, int loopback, const int *all_counts, int *recv_cnt)
+{
+   int dest[27], shift[81];
+   if (!all_counts || !recv_cnt) return DDCMI_EINVAL;
+   int rc = ddcmi_plan_directions(px, py, pz, rank, pbc, dest, shift);
+   if (rc) return rc;
+   plan_recv_counts(dest, rank, loopback != 0, all_counts, recv_cnt);
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_plan_halo_layout(int px, int py, int pz, int rank, int pbc, int loopback, const int send_cnt[27], const int recv_cnt[27],
+                                      int send_off[28], int recv_off[28], int *msgs, int *msgr)
+{
+   int dest[27], shift[81];
+   if (!send_cnt || !recv_cnt || !send_off || !recv_off || !msgs || !msgr) return DDCMI_EINVAL;
+   int rc = ddcmi_plan_directions(px, py, pz, rank, pbc, dest, shift);
+   if (rc) return rc;
+   SegTab ss, rs; HaloMsgs ms, mr;
+   int ns, nr;
+   plan_halo_layout(dest, rank, px * py * pz, loopback != 0, send_cnt, recv_cnt, ss, rs, send_off, recv_off, &ns, &nr, ms, mr);
+   msgs[0] = ms.n; msgr[0] = mr.n;
+   for (int k = 0; k < ms.n; k++) { msgs[1 + 3 * k] = ms.peer[k]; msgs[2 + 3 * k] = ms.off[k]; msgs[3 + 3 * k] = ms.cnt[k]; }
+   for (int k = 0; k < mr.n; k++) { msgr[1 + 3 * k] = mr.peer[k]; msgr[2 + 3 * k] = mr.off[k]; msgr[3 + 3 * k] = mr.cnt[k]; }
+   return DDCMI_OK;
+}
+
+/* ---- transports ------------------------------------------------------------- */
+/* Every rank learns every rank's 27 per-direction counts with ONE all-gather (26 four-byte
  * point-to-point messages took 77 us; this is rebuild-time control traffic) and looks up what its
- * neighbours send to it: the message a neighbour sends along ITS direction `code` comes from the
- * rank in my direction opp(code).  Pinned staging on both sides. */
-static int mg_xchg_counts_rccl(ddcmi_ctx *ctx, const int *scnt, int *rcnt)
+ * neighbours send to it.  RCCL: pinned staging on both sides; host transport: the rendezvous' all-gather. */
+static int mg_xchg_counts(ddcmi_ctx *ctx, const int *scnt, int *rcnt)
 {
    hipStream_t st = ctx->stream;
-   ncclComm_t comm = (ncclComm_t)ctx->comm;
    const int nr = std::max(ctx->nranks, 1);
-   ENSURE(ctx, ctx->cnt_xchg, 32 + 27 * (size_t)nr);
    int *h = ctx->pinned(2, 32 + 27 * (size_t)nr);
    if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
    for (int code = 0; code < 27; code++) h[code] = scnt[code];
-   HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, h, 27 * sizeof(int), hipMemcpyHostToDevice, st));
-   NCCLCHK2(ctx, ncclAllGather(ctx->cnt_xchg.p, ctx->cnt_xchg.p + 32, 27, ncclInt, comm, st));
-   HIPCHK(ctx, hipMemcpyAsync(h + 32, ctx->cnt_xchg.p + 32, 27 * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
-   HIPCHK(ctx, hipStreamSynchronize(st));
-   for (int code = 0; code < 27; code++)
-      rcnt[code] = mg_remote(ctx, mg_opp(code)) ? h[32 + 27 * ctx->dir_dest[mg_opp(code)] + code] : 0;
+   if (ctx->hcomm) HOSTCHK(ctx, ddcmi_rdzv_allgather(ctx->hcomm, h, h + 32, 27 * sizeof(int)));
+   else
+   {
+      ncclComm_t comm = (ncclComm_t)ctx->comm;
+      ENSURE(ctx, ctx->cnt_xchg, 32 + 27 * (size_t)nr);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, h, 27 * sizeof(int), hipMemcpyHostToDevice, st));
+      NCCLCHK2(ctx, ncclAllGather(ctx->cnt_xchg.p, ctx->cnt_xchg.p + 32, 27, ncclInt, comm, st));
+      HIPCHK(ctx, hipMemcpyAsync(h + 32, ctx->cnt_xchg.p + 32, 27 * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+   }
+   plan_recv_counts(ctx->dir_dest, ctx->rank, ctx->loopback, h + 32, rcnt);
    return DDCMI_OK;
 }
-/* RCCL, migration records: one message per direction (rebuilds only); segments are flattened
+/* host transport: device segments -> host staging -> TCP streams -> host staging -> device segments.
+ * nm* messages; offsets and counts in doubles */
+static int mg_host_exchange(ddcmi_ctx *ctx, hipStream_t st, int nms, const int *speer, const double *const *sdev, const size_t *scount,
+                            int nmr, const int *rpeer, double *const *rdev, const size_t *rcount)
+{
+   size_t stot = 0, rtot = 0;
+   for (int k = 0; k < nms; k++) stot += scount[k];
+   for (int k = 0; k < nmr; k++) rtot += rcount[k];
+   ctx->hstage_s.resize(stot + 1); ctx->hstage_r.resize(rtot + 1);
+   const void *sb[27]; void *rb[27]; size_t sbytes[27], rbytes[27];
+   size_t o = 0;
+   for (int k = 0; k < nms; k++)
+   {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->hstage_s.data() + o, sdev[k], scount[k] * sizeof(double), hipMemcpyDeviceToHost, st));
+      sb[k] = ctx->hstage_s.data() + o; sbytes[k] = scount[k] * sizeof(double); o += scount[k];
+   }
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   o = 0;
+   for (int k = 0; k < nmr; k++) { rb[k] = ctx->hstage_r.data() + o; rbytes[k] = rcount[k] * sizeof(double); o += rcount[k]; }
+   HOSTCHK(ctx, ddcmi_rdzv_exchange(ctx->hcomm, nms, speer, sb, sbytes, nmr, rpeer, rb, rbytes));
+   o = 0;
+   for (int k = 0; k < nmr; k++)
+   {
+      HIPCHK(ctx, hipMemcpyAsync(rdev[k], ctx->hstage_r.data() + o, rcount[k] * sizeof(double), hipMemcpyHostToDevice, st));
+      o += rcount[k];
+   }
+   HIPCHK(ctx, hipStreamSynchronize(st));      /* the staging vector is reused by the next exchange */
+   return DDCMI_OK;
+}
+/* migration records: one message per direction (rebuilds only); segments are flattened
  * with the given offsets (send: by my direction code; recv: by the SENDER's direction code) */
-static int mg_xchg_data_rccl(ddcmi_ctx *ctx, const double *sbase, const int *soff, const int *scnt, size_t sstride_items,
-                             double *rbase, const int *roff, const int *rcnt, int width)
+static int mg_xchg_data(ddcmi_ctx *ctx, const double *sbase, const int *soff, const int *scnt, size_t sstride_items,
+                        double *rbase, const int *roff, const int *rcnt, int width)
 {
    hipStream_t st = ctx->stream;
+   if (ctx->hcomm)
+   {
+      int speer[27], rpeer[27], nms = 0, nmr = 0;
+      const double *sdev[27]; double *rdev[27]; size_t sc[27], rc_[27];
+      for (int code = 0; code < 27; code++)
+      {
+         if (mg_remote(ctx, code) && scnt[code] > 0)
+         {
+            sdev[nms] = sstride_items ? sbase + (size_t)code * sstride_items * width : sbase + (size_t)soff[code] * width;
+            sc[nms] = (size_t)scnt[code] * width; speer[nms++] = ctx->dir_dest[code];
+         }
+         if (mg_remote(ctx, mg_opp(code)) && rcnt[code] > 0)
+         { rdev[nmr] = rbase + (size_t)roff[code] * width; rc_[nmr] = (size_t)rcnt[code] * width; rpeer[nmr++] = ctx->dir_dest[mg_opp(code)]; }
+      }
+      return mg_host_exchange(ctx, st, nms, speer, sdev, sc, nmr, rpeer, rdev, rc_);
+   }
    ncclComm_t comm = (ncclComm_t)ctx->comm;
    NCCLCHK2(ctx, ncclGroupStart());
    for (int code = 0; code < 27; code++)
@@ -318,54 +443,29 @@ static int mg_xchg_data_rccl(ddcmi_ctx *ctx, const double *sbase, const int *sof
    NCCLCHK2(ctx, ncclGroupEnd());
    return DDCMI_OK;
 }
-/* RCCL, halo beads (every step): the segments of one peer are contiguous in the send and
- * in the receive buffer (mg_layout_halo), so each peer pair exchanges ONE message -- 7 at
- * 2x2x2 instead of 26, which is what the grouped point-to-point kernel's time follows */
-static int mg_xchg_halo_rccl(ddcmi_ctx *ctx, const double *sbase, double *rbase, int width, hipStream_t st)
+/* halo beads (every step): each peer pair exchanges ONE message (mg_layout_halo), which is what
+ * the grouped point-to-point kernel's time follows */
+static int mg_xchg_halo(ddcmi_ctx *ctx, const double *sbase, double *rbase, int width, hipStream_t st)
 {
+   const HaloMsgs &ms = ctx->hmsg_s, &mr = ctx->hmsg_r;
+   if (ctx->hcomm)
+   {
+      const double *sdev[27]; double *rdev[27]; size_t sc[27], rc_[27];
+      for (int k = 0; k < ms.n; k++) { sdev[k] = sbase + (size_t)ms.off[k] * width; sc[k] = (size_t)ms.cnt[k] * width; }
+      for (int k = 0; k < mr.n; k++) { rdev[k] = rbase + (size_t)mr.off[k] * width; rc_[k] = (size_t)mr.cnt[k] * width; }
+      return mg_host_exchange(ctx, st, ms.n, ms.peer, sdev, sc, mr.n, mr.peer, rdev, rc_);
+   }
    ncclComm_t comm = (ncclComm_t)ctx->comm;
    NCCLCHK2(ctx, ncclGroupStart());
-   for (int q = 0; q < ctx->sseg.nseg;)
-   {
-      int peer = ctx->dir_dest[(int)ctx->sseg.code[q]], q1 = q;
-      while (q1 < ctx->sseg.nseg && ctx->dir_dest[(int)ctx->sseg.code[q1]] == peer) q1++;
-      size_t cnt = (size_t)(ctx->sseg.off[q1] - ctx->sseg.off[q]);
-      if (cnt > 0) NCCLCHK2(ctx, ncclSend(sbase + (size_t)ctx->sseg.off[q] * width, cnt * width, ncclDouble, peer, comm, st));
-      q = q1;
-   }
-   for (int q = 0; q < ctx->rseg.nseg;)
-   {
-      /* rseg.code = the SENDER's direction: it arrives from the rank in my opposite direction */
-      int peer = ctx->dir_dest[mg_opp((int)ctx->rseg.code[q])], q1 = q;
-      while (q1 < ctx->rseg.nseg && ctx->dir_dest[mg_opp((int)ctx->rseg.code[q1])] == peer) q1++;
-      size_t cnt = (size_t)(ctx->rseg.off[q1] - ctx->rseg.off[q]);
-      if (cnt > 0) NCCLCHK2(ctx, ncclRecv(rbase + (size_t)ctx->rseg.off[q] * width, cnt * width, ncclDouble, peer, comm, st));
-      q = q1;
-   }
+   for (int k = 0; k < ms.n; k++) NCCLCHK2(ctx, ncclSend(sbase + (size_t)ms.off[k] * width, (size_t)ms.cnt[k] * width, ncclDouble, ms.peer[k], comm, st));
+   for (int k = 0; k < mr.n; k++) NCCLCHK2(ctx, ncclRecv(rbase + (size_t)mr.off[k] * width, (size_t)mr.cnt[k] * width, ncclDouble, mr.peer[k], comm, st));
    NCCLCHK2(ctx, ncclGroupEnd());
    return DDCMI_OK;
 }
-/* buffer layout of the halo exchange from the per-direction counts: remote segments ordered by
- * (peer rank, direction code) on both sides; send_off/recv_off[code] index the same layout */
 static void mg_layout_halo(ddcmi_ctx *ctx)
 {
-   SegTab &ss = ctx->sseg, &rs = ctx->rseg;
-   ss.nseg = rs.nseg = 0;
-   int ns = 0, nr = 0;
-   for (int code = 0; code < 28; code++) { ctx->send_off[code] = 0; ctx->recv_off[code] = 0; }
-   for (int peer = 0; peer < ctx->nranks; peer++)
-      for (int code = 0; code < 27; code++)
-      {
-         if (mg_remote(ctx, code) && ctx->dir_dest[code] == peer)
-         { ss.code[ss.nseg] = (signed char)code; ss.off[ss.nseg++] = ns; ctx->send_off[code] = ns; ns += ctx->hs_cnt[code]; }
-         if (mg_remote(ctx, mg_opp(code)) && ctx->dir_dest[mg_opp(code)] == peer)
-         { rs.code[rs.nseg] = (signed char)code; rs.off[rs.nseg++] = nr; ctx->recv_off[code] = nr; nr += ctx->hr_cnt[code]; }
-      }
-   ss.off[ss.nseg] = ns; rs.off[rs.nseg] = nr;
-   for (int q = ss.nseg + 1; q < 28; q++) ss.off[q] = ns;
-   for (int q = rs.nseg + 1; q < 28; q++) rs.off[q] = nr;
-   ctx->send_off[27] = ns; ctx->recv_off[27] = nr;
-   ctx->nsend = ns; ctx->nrecv = nr;
+   plan_halo_layout(ctx->dir_dest, ctx->rank, ctx->nranks, ctx->loopback, ctx->hs_cnt, ctx->hr_cnt, ctx->sseg, ctx->rseg,
+                    ctx->send_off, ctx->recv_off, &ctx->nsend, &ctx->nrecv, ctx->hmsg_s, ctx->hmsg_r);
 }
 /* in-process emulation: same matching rule, direct device copies */
 static int mg_xchg_data_local(ddcmi_group *g, int which /*0 migration, 1 halo5, 2 halo3*/)
@@ -536,20 +636,20 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
 int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
 {
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are rebuilt with ddcmi_group_* calls");
-   if (!ctx->comm) SETERR(ctx, DDCMI_EINVAL, "ddcmi_comm_init has not been called");
+   if (!mg_transport(ctx)) SETERR(ctx, DDCMI_EINVAL, "ddcmi_comm_init has not been called");
    int rc;
    if ((rc = mg_phase1_migrate_out(ctx))) return rc;
-   if ((rc = mg_xchg_counts_rccl(ctx, ctx->mig_scnt, ctx->mig_rcnt))) return rc;
+   if ((rc = mg_xchg_counts(ctx, ctx->mig_scnt, ctx->mig_rcnt))) return rc;
    {
       int roff[27], acc = 0;
       for (int c = 0; c < 27; c++) { roff[c] = acc; acc += ctx->mig_rcnt[c]; }
       ENSURE(ctx, ctx->mig_in, (size_t)acc * 10 + 16);
-      if ((rc = mg_xchg_data_rccl(ctx, ctx->mig_out.p, nullptr, ctx->mig_scnt, ctx->mig_cap, ctx->mig_in.p, roff, ctx->mig_rcnt, 10))) return rc;
+      if ((rc = mg_xchg_data(ctx, ctx->mig_out.p, nullptr, ctx->mig_scnt, ctx->mig_cap, ctx->mig_in.p, roff, ctx->mig_rcnt, 10))) return rc;
    }
    if ((rc = mg_phase2_migrate_in(ctx))) return rc;
-   if ((rc = mg_xchg_counts_rccl(ctx, ctx->hs_cnt, ctx->hr_cnt))) return rc;
+   if ((rc = mg_xchg_counts(ctx, ctx->hs_cnt, ctx->hr_cnt))) return rc;
    if ((rc = mg_phase3_pack(ctx, 5))) return rc;
-   if ((rc = mg_xchg_halo_rccl(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5, ctx->stream))) return rc;
+   if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5, ctx->stream))) return rc;
    return mg_phase4_finish(ctx);
 }
 
@@ -568,7 +668,7 @@ int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st)
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "in-process group: halos are refreshed by ddcmi_group_step_nglf / ddcmi_group_eval_forces");
    int rc;
    if ((rc = mg_pack3(ctx, st))) return rc;
-   if ((rc = mg_xchg_halo_rccl(ctx, ctx->sendbuf.p, ctx->hrecv3.p, 3, st))) return rc;
+   if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv3.p, 3, st))) return rc;
    ctx->halo_fresh = true;
    return DDCMI_OK;
 }
@@ -617,6 +717,7 @@ extern "C" int ddcmi_group_create(ddcmi_ctx **ctxs, int n, int px, int py, int p
       g->ranks.push_back(ctxs[r]);
    }
    for (int r = 0; r < n; r++) { mg_set_topology(ctxs[r], r, n, px, py, pz); ctxs[r]->group_ = g; }
+   for (int r = 0; r < n; r++) { int rc = mg_check_one_domain_features(ctxs[r]); if (rc) return rc; }
    return DDCMI_OK;
 }
 extern "C" int ddcmi_group_destroy(ddcmi_ctx **ctxs, int n)
@@ -645,8 +746,7 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
    ddcmi_group *g = ctxs[0]->group_;
    int rc;
-   for (ddcmi_ctx *c : g->ranks)
-      if (c->ncgroup > 0) SETERR(c, DDCMI_EINVAL, "velocity constraints are implemented for one domain only");
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_check_one_domain_features(c))) return rc;
    for (int s = 0; s < nsteps; s++)
    {
       bool rebuild = false;
@@ -739,6 +839,15 @@ extern "C" int ddcmi_domain_bounds(const ddcmi_ctx *ctx, double lo[3], double hi
    return DDCMI_OK;
 }
 
+/* nglfconstraint's barostat and velocity constraints are solved per domain: with several domains each rank would
+ * scale its own box from its local virial and solve constraint groups without their halo partners -- silently
+ * wrong physics.  Checked where the decomposition is set up AND at every step call, whatever the call order. */
+static int mg_check_one_domain_features(ddcmi_ctx *ctx)
+{
+   if (ctx->nranks > 1 && (ctx->baro_beta > 0.0 || ctx->ncgroup > 0))
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat and the velocity constraints (NGLFCONSTRAINT) are implemented for a single domain: %d domains", ctx->nranks);
+   return DDCMI_OK;
+}
 /* RCCL bootstrap (the 128-byte id is distributed by the caller: MPI_Bcast in
  * ddcMD, torch.distributed in bench.py) */
 extern "C" int ddcmi_comm_unique_id(char id[128])
@@ -756,6 +865,7 @@ extern "C" int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char 
    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return DDCMI_EINVAL;
    if (px * py * pz != nranks) SETERR(ctx, DDCMI_EINVAL, "process grid %dx%dx%d does not match %d ranks", px, py, pz, nranks);
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "context already belongs to an in-process group");
+   if (mg_transport(ctx)) SETERR(ctx, DDCMI_EINVAL, "the context already has a communicator");
    (void)hipSetDevice(ctx->device);
    ncclUniqueId uid;
    memcpy(&uid, id, sizeof(uid));
@@ -764,6 +874,30 @@ extern "C" int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char 
    ctx->comm = (void *)comm;
    { const char *lb = getenv("DDCMI_RCCL_LOOPBACK"); ctx->loopback = (nranks == 1 && lb && atoi(lb) != 0); }
    mg_set_topology(ctx, rank, nranks, px, py, pz);
+   return mg_check_one_domain_features(ctx);
+}
+extern "C" int ddcmi_comm_init_host(ddcmi_ctx *ctx, ddcmi_rdzv *rdzv, int px, int py, int pz)
+{
+   if (!ctx || !rdzv) return DDCMI_EINVAL;
+   const int rank = ddcmi_rdzv_rank(rdzv), nranks = ddcmi_rdzv_world(rdzv);
+   if (px * py * pz != nranks) SETERR(ctx, DDCMI_EINVAL, "process grid %dx%dx%d does not match %d ranks", px, py, pz, nranks);
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "context already belongs to an in-process group");
+   if (mg_transport(ctx)) SETERR(ctx, DDCMI_EINVAL, "the context already has a communicator");
+   ctx->hcomm = rdzv;
+   { const char *lb = getenv("DDCMI_RCCL_LOOPBACK"); ctx->loopback = (nranks == 1 && lb && atoi(lb) != 0); }
+   mg_set_topology(ctx, rank, nranks, px, py, pz);
+   return mg_check_one_domain_features(ctx);
+}
+/* sum of n doubles over the ranks, in place on the host */
+static int mg_allreduce_host_values(ddcmi_ctx *ctx, double *values, int n)
+{
+   if ((ctx->nranks == 1 && !ctx->loopback) || !mg_transport(ctx)) return DDCMI_OK;
+   if (ctx->hcomm) { HOSTCHK(ctx, ddcmi_rdzv_allreduce_f64(ctx->hcomm, values, n, 0)); return DDCMI_OK; }
+   double *d = ctx->d_results + R_GROUP;   /* scratch */
+   HIPCHK(ctx, hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+   NCCLCHK2(ctx, ncclAllReduce(d, d, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+   HIPCHK(ctx, hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    return DDCMI_OK;
 }
 /* energyInfo.c:9-63 allreduce(): sum the ETYPE block across ranks */
@@ -776,15 +910,10 @@ extern "C" int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n)
       /* in-process group: only meaningful when called once for rank 0 with pre-summed values */
       return DDCMI_OK;
    }
-   if ((ctx->nranks == 1 && !ctx->loopback) || !ctx->comm) return DDCMI_OK;
-   double *d = ctx->d_results + R_GROUP;   /* scratch */
-   HIPCHK(ctx, hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-   NCCLCHK2(ctx, ncclAllReduce(d, d, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
-   HIPCHK(ctx, hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   return DDCMI_OK;
+   return mg_allreduce_host_values(ctx, values, n);
 }
 void ddcmi_comm_destroy(ddcmi_ctx *ctx)
 {
    if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+   ctx->hcomm = nullptr;      /* owned by the caller */
 }

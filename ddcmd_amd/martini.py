@@ -78,7 +78,130 @@ def _declare(lib):
     lib.ddcmi_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.ddcmi_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.ddcmi_comm_allreduce_sum.argtypes = [vp, _dp, ctypes.c_int]
+    lib.ddcmi_comm_init_host.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    # process rendezvous (host/rdzv.c)
+    szt = ctypes.c_size_t
+    lib.ddcmi_rdzv_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_double]
+    lib.ddcmi_rdzv_destroy.argtypes = [vp]
+    lib.ddcmi_rdzv_destroy.restype = None
+    lib.ddcmi_rdzv_last_error.argtypes = [vp]
+    lib.ddcmi_rdzv_last_error.restype = ctypes.c_char_p
+    lib.ddcmi_rdzv_rank.argtypes = [vp]
+    lib.ddcmi_rdzv_world.argtypes = [vp]
+    lib.ddcmi_rdzv_bcast.argtypes = [vp, vp, szt, ctypes.c_int]
+    lib.ddcmi_rdzv_barrier.argtypes = [vp]
+    lib.ddcmi_rdzv_allreduce_f64.argtypes = [vp, _dp, ctypes.c_int, ctypes.c_int]
+    lib.ddcmi_rdzv_allgather.argtypes = [vp, vp, vp, szt]
+    lib.ddcmi_rdzv_exchange.argtypes = [vp, ctypes.c_int, _ip, ctypes.POINTER(vp), ctypes.POINTER(szt), ctypes.c_int, _ip, ctypes.POINTER(vp), ctypes.POINTER(szt)]
+    lib.ddcmi_plan_recv_counts.argtypes = [ctypes.c_int] * 6 + [_ip, _ip]
+    lib.ddcmi_plan_halo_layout.argtypes = [ctypes.c_int] * 6 + [_ip, _ip, _ip, _ip, _ip, _ip]
     lib._ddcmi_declared = True
+
+
+def default_port_file():
+    """Where rank 0 publishes its port when the launcher keeps MASTER_PORT for itself
+    (torch.distributed.run's store listens there): one name per launch -- all workers of a
+    launch share the launcher as parent."""
+    import os
+    import tempfile
+    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    return os.environ.get("DDCMI_RDZV_FILE") or os.path.join(tempfile.gettempdir(), "ddcmi_rdzv_" + key.replace("/", "_"))
+
+
+class Rendezvous(object):
+    """Ranks of one launch meeting over TCP (host/rdzv.c): what ddcMD takes from MPI
+    (rank/size, Bcast, Barrier, Allreduce) for launches that only provide
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  No torch, no MPI."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=0, port_file=None, timeout=300.0):
+        self.lib = _lib.load_library()
+        _declare(self.lib)
+        self.h = ctypes.c_void_p()
+        pf = port_file.encode() if port_file else None
+        rc = self.lib.ddcmi_rdzv_create(ctypes.byref(self.h), int(rank), int(world), addr.encode(), int(port), pf, float(timeout))
+        if rc != 0:
+            raise DdcmiError("ddcmi_rdzv_create failed (%d): %s" % (rc, self.lib.ddcmi_rdzv_last_error(None).decode()))
+        self.rank, self.world = int(rank), int(world)
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        """RANK / WORLD_SIZE / MASTER_ADDR from the environment; the port through a file in the temporary
+        directory (MASTER_PORT itself belongs to the launcher) unless DDCMI_RDZV_PORT names a free one"""
+        import os
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("DDCMI_RDZV_PORT", "0"))
+        return cls(rank, world, addr, port, None if port > 0 else default_port_file(), timeout)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DdcmiError("rendezvous error %d: %s" % (rc, self.lib.ddcmi_rdzv_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.ddcmi_rdzv_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def bcast(self, data, root=0):
+        """bytes in (significant on root), bytes out; the length must agree on all ranks"""
+        buf = ctypes.create_string_buffer(bytes(data), len(data))
+        self._chk(self.lib.ddcmi_rdzv_bcast(self.h, ctypes.cast(buf, ctypes.c_void_p), len(data), int(root)))
+        return buf.raw
+
+    def barrier(self):
+        self._chk(self.lib.ddcmi_rdzv_barrier(self.h))
+
+    def allreduce(self, values, op="sum"):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(self.lib.ddcmi_rdzv_allreduce_f64(self.h, _d(v), v.size, 0 if op == "sum" else 1))
+        return v
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + a.shape, a.dtype)
+        self._chk(self.lib.ddcmi_rdzv_allgather(self.h, a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+        return out
+
+    def exchange(self, sends, recvs):
+        """sends: [(peer, ndarray)], recvs: [(peer, ndarray to fill)]; matched per peer in order"""
+        vp, szt = ctypes.c_void_p, ctypes.c_size_t
+        sends = [(p, np.ascontiguousarray(a)) for p, a in sends]
+        ns, nr = len(sends), len(recvs)
+        sp = (ctypes.c_int * max(ns, 1))(*[p for p, _ in sends])
+        sb = (vp * max(ns, 1))(*[a.ctypes.data for _, a in sends])
+        sz = (szt * max(ns, 1))(*[a.nbytes for _, a in sends])
+        rp = (ctypes.c_int * max(nr, 1))(*[p for p, _ in recvs])
+        rb = (vp * max(nr, 1))(*[a.ctypes.data for _, a in recvs])
+        rz = (szt * max(nr, 1))(*[a.nbytes for _, a in recvs])
+        self._chk(self.lib.ddcmi_rdzv_exchange(self.h, ns, sp, sb, sz, nr, rp, rb, rz))
+
+
+def plan_recv_counts(grid, rank, pbc, all_counts, loopback=False):
+    """recv_cnt[27] from the all-gathered send counts [nranks, 27] (host logic of libddcmi)"""
+    lib = _lib.load_library()
+    _declare(lib)
+    ac = np.ascontiguousarray(all_counts, dtype=np.int32)
+    out = np.zeros(27, np.int32)
+    rc = lib.ddcmi_plan_recv_counts(grid[0], grid[1], grid[2], int(rank), int(pbc), int(loopback), _i(ac), _i(out))
+    if rc != 0:
+        raise DdcmiError("ddcmi_plan_recv_counts failed: %d" % rc)
+    return out
+
+
+def plan_halo_layout(grid, rank, pbc, send_cnt, recv_cnt, loopback=False):
+    """(send_off[28], recv_off[28], send messages [(peer, off, cnt)], receive messages) of the per-step halo
+    exchange: libddcmi's own peer-major layout (ddcmi_multigpu.inl plan_halo_layout)"""
+    lib = _lib.load_library()
+    _declare(lib)
+    sc, rcn = np.ascontiguousarray(send_cnt, dtype=np.int32), np.ascontiguousarray(recv_cnt, dtype=np.int32)
+    so, ro = np.zeros(28, np.int32), np.zeros(28, np.int32)
+    ms, mr = np.zeros(1 + 3 * 27, np.int32), np.zeros(1 + 3 * 27, np.int32)
+    rc = lib.ddcmi_plan_halo_layout(grid[0], grid[1], grid[2], int(rank), int(pbc), int(loopback), _i(sc), _i(rcn), _i(so), _i(ro), _i(ms), _i(mr))
+    if rc != 0:
+        raise DdcmiError("ddcmi_plan_halo_layout failed: %d" % rc)
+    unpack = lambda m: [tuple(int(x) for x in m[1 + 3 * k:4 + 3 * k]) for k in range(int(m[0]))]
+    return so, ro, unpack(ms), unpack(mr)
 
 
 def expand_bonded_terms(s):
@@ -453,6 +576,11 @@ class MartiniRank(MartiniHIP, DomainMixin):
 
     def comm_init(self, rank, nranks, uid, grid):
         self._chk(self.lib.ddcmi_comm_init(self.ctx, rank, nranks, uid, grid[0], grid[1], grid[2]))
+
+    def comm_init_host(self, rdzv, grid):
+        """decomposition over the host transport (TCP streams of the rendezvous) instead of RCCL"""
+        self._rdzv = rdzv      # must outlive the context
+        self._chk(self.lib.ddcmi_comm_init_host(self.ctx, rdzv.h, grid[0], grid[1], grid[2]))
 
     def allreduce(self, values):
         v = np.ascontiguousarray(values, dtype=np.float64)

@@ -14,6 +14,7 @@
  */
 #ifndef DDCMI_H
 #define DDCMI_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -200,6 +201,46 @@ int ddcmi_comm_unique_id(char id[128]);
 int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char id[128], int px, int py, int pz);
 /* energyInfo.c:9-63 allreduce(): sum the 24-double ETYPE block across ranks */
 int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n);
+/* ---- process rendezvous without MPI (host/rdzv.c) ----------------------------
+ * ddcMD takes rank, size, MPI_Bcast, MPI_Barrier and MPI_Allreduce from its MPI launcher
+ * (ddcMD.c:93-139; energyInfo.c:9-63).  A one-process-per-GPU launch without MPI hands each
+ * process RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT only; these calls turn that into a
+ * full mesh of TCP streams.  Rank 0 listens on (addr, port); with port <= 0 (the launcher
+ * itself occupies MASTER_PORT, as torch.distributed.run does) rank 0 binds an ephemeral port
+ * and publishes it in port_file, which the other ranks poll.  All calls are collective,
+ * blocking, and fail with DDCMI_ECOMM after timeout_s (<= 0: 300 s) instead of hanging. */
+typedef struct ddcmi_rdzv ddcmi_rdzv;
+int ddcmi_rdzv_create(ddcmi_rdzv **out, int rank, int world, const char *addr, int port, const char *port_file, double timeout_s);
+void ddcmi_rdzv_destroy(ddcmi_rdzv *h);
+const char *ddcmi_rdzv_last_error(const ddcmi_rdzv *h);      /* h may be NULL: last create error */
+int ddcmi_rdzv_rank(const ddcmi_rdzv *h);
+int ddcmi_rdzv_world(const ddcmi_rdzv *h);
+int ddcmi_rdzv_bcast(ddcmi_rdzv *h, void *buf, size_t nbytes, int root);                 /* MPI_Bcast: the 128-byte RCCL id */
+int ddcmi_rdzv_barrier(ddcmi_rdzv *h);                                                   /* MPI_Barrier */
+int ddcmi_rdzv_allreduce_f64(ddcmi_rdzv *h, double *v, int n, int op);                   /* op 0 sum (rank order), 1 max */
+int ddcmi_rdzv_allgather(ddcmi_rdzv *h, const void *send, void *recv, size_t nbytes);    /* nbytes per rank */
+/* grouped point-to-point exchange, matched like ncclSend/ncclRecv inside one group: the k-th message
+ * sent to peer p is the k-th message p receives from this rank */
+int ddcmi_rdzv_exchange(ddcmi_rdzv *h, int nsend, const int *send_peer, const void *const *send_buf, const size_t *send_bytes,
+                        int nrecv, const int *recv_peer, void *const *recv_buf, const size_t *recv_bytes);
+/* Decomposition over the HOST transport: the same migration / halo / all-reduce protocol as
+ * ddcmi_comm_init, with every message staged through pinned host memory and carried by the
+ * rendezvous' TCP streams instead of RCCL.  For ranks that share one GPU (RCCL refuses two ranks
+ * on a device: tests on a single-GPU box) and for nodes without working GPU peer access; rank and
+ * size come from the rendezvous, which must outlive the context. */
+int ddcmi_comm_init_host(ddcmi_ctx *ctx, ddcmi_rdzv *rdzv, int px, int py, int pz);
+/* Host logic of the halo exchange (ddcSendRecvTables, ddcSendRecv.c:126-225), callable without a GPU.
+ * ddcmi_plan_recv_counts: from the all-gathered per-direction send counts all_counts[nranks][27], what
+ * this rank receives: recv_cnt[c] = what the rank in my direction opp(c) sends along ITS direction c.
+ * ddcmi_plan_halo_layout: buffer layout (in beads) and message list of the per-step exchange -- remote
+ * segments ordered by (peer rank, direction code) on both sides, so that each peer pair exchanges ONE
+ * message: send_off/recv_off[28] = offset of direction c's segment (send: my direction; receive: the
+ * SENDER's direction); msgs[0] = number of send messages, then {peer, offset, count} triples;
+ * msgr likewise for the receives (room for 1 + 3*27 ints each).  loopback != 0: a single rank whose
+ * periodic neighbours are itself exchanges with itself through the transport (test facility). */
+int ddcmi_plan_recv_counts(int px, int py, int pz, int rank, int pbc, int loopback, const int *all_counts, int *recv_cnt);
+int ddcmi_plan_halo_layout(int px, int py, int pz, int rank, int pbc, int loopback, const int send_cnt[27], const int recv_cnt[27],
+                           int send_off[28], int recv_off[28], int *msgs, int *msgr);
 /* Call order with decomposition: ddcmi_set_box -> ddcmi_comm_init -> set_* ->
  * ddcmi_upload_state with THIS rank's local beads (any beads inside the box are
  * accepted; the first rebuild migrates them to their owners, ddcAssignment.c) */

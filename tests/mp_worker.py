@@ -1,0 +1,67 @@
+"""One rank of a multi-process decomposed run (started by tests/test_gpu_multiproc.py as a fresh child
+process): rendezvous from RANK / WORLD_SIZE / MASTER_ADDR, libddcmi context on device 0, decomposition over
+the transport DDCMI_TRANSPORT names, a few NGLF steps, then every rank writes its own beads (by gid) and
+its partial sums to <outdir>/rank<r>.npz.  Never imports the oracle: the parent process is the checker."""
+import ctypes
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    workload, gridtxt, outdir, nsteps, block = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    grid = tuple(int(x) for x in gridtxt.split("x"))
+    import ddcmd_amd
+    from ddcmd_amd.martini import MartiniRank, Rendezvous, domain_of, _declare_domains
+    rdzv = Rendezvous.from_env(timeout=120.0)
+    rank, world = rdzv.rank, rdzv.world
+    if workload == "water":
+        s = ddcmd_amd.make_water_setup(12)
+    else:
+        from ddcmd_amd.deck import load_deck
+        deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    owner = domain_of(s, grid)
+    m = MartiniRank(s, np.flatnonzero(owner == rank), device=0)
+    _declare_domains(m.lib)
+    if os.environ.get("DDCMI_TRANSPORT", "host") == "host":
+        m.comm_init_host(rdzv, grid)
+    else:
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            assert m.lib.ddcmi_comm_unique_id(buf) == 0
+        m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)
+    m.upload_local()
+    n0 = m.n
+    rec = {}
+    e, vir = m.eval_forces()
+    p = m.download_particles()
+    rec.update(gid0=p["gid"], f0=np.stack(p["f"]), e0=np.array([e[k] for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total")]), vir0=vir)
+    Tg = []
+    if any(int(t) == 1 for t in np.asarray(s.group_type).ravel()):
+        Tg.append(m.group_temperatures().copy())
+    done = 0
+    traj = []
+    while done < nsteps:
+        k = min(block, nsteps - done)
+        m.step(k)
+        done += k
+        e, vir, rk, tion = m.energies()
+        tot = m.allreduce([e["total"], rk] + list(vir))              # energyInfo.c allreduce() over the transport
+        traj.append(tot)
+        if Tg:
+            Tg.append(m.group_temperatures().copy())
+    p = m.download_particles()
+    rec.update(gid=p["gid"], r=np.stack(p["r"]), v=np.stack(p["v"]), f=np.stack(p["f"]), traj=np.array(traj), Tg=np.array(Tg),
+               nloc=np.array([n0, int(m.lib.ddcmi_nlocal(m.ctx))]), rebuilds=np.array([m.list_stats()["rebuilds"]]))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **rec)
+    m.close()
+    rdzv.barrier()
+    rdzv.close()
+
+
+if __name__ == "__main__":
+    main()

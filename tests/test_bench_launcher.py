@@ -1,0 +1,46 @@
+"""CPU: bench.py under the driver's own multi-GPU launcher.
+
+The driver starts N>1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py ...`.  libddcmi.so is built and validated against /opt/rocm's HIP and RCCL; torch bundles
+its own copies under the same sonames, so a bench process that imports torch would bind libddcmi to a runtime it was
+never tested on.  bench.py therefore keeps torch out of the process and meets its peers over libddcmi's own TCP
+rendezvous (the launcher keeps MASTER_PORT for its store: the port travels through a file).  `--check-runtime`
+stops before the first device call, so this runs without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_world2_bench_process_maps_only_system_rocm(built):
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-runtime"]
+    env = dict(os.environ)
+    env.pop("DDCMI_RDZV_FILE", None); env.pop("DDCMI_RDZV_PORT", None)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert sorted(r["rank"] for r in recs) == [0, 1]
+    tokens = {r["token"] for r in recs}
+    assert len(tokens) == 1 and tokens.pop().startswith("ddcmi-runtime-check-")      # rank 0's broadcast reached rank 1
+    for r in recs:
+        assert r["world"] == 2 and r["ranks_met"] == 2
+        assert r["torch_loaded"] is False
+        hip = [l for l in r["runtime_libs"] if "libamdhip64" in l]
+        rccl = [l for l in r["runtime_libs"] if "librccl" in l]
+        assert hip and rccl
+        for l in r["runtime_libs"]:
+            assert os.path.realpath(l).startswith(os.path.realpath("/opt/rocm") + os.sep), "foreign runtime mapped: %s" % l
+            assert "torch" not in l
+
+
+def test_bench_source_has_no_torch_import():
+    import re
+    pat = re.compile(r"^\s*(import|from)\s+torch\b", re.M)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert not pat.search(src) and "torch.cuda" not in src
+    for f in ("martini.py", "_lib.py", "deck.py", "synth.py", "__init__.py"):
+        assert not pat.search(open(os.path.join(ROOT, "ddcmd_amd", f)).read())

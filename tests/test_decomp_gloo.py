@@ -1,14 +1,16 @@
-"""CPU, world_size=2, gloo: the host logic of the spatial decomposition.
+"""CPU, world_size=2: the host side of the spatial decomposition, between two real processes.
 
-The device path (ddcmi_multigpu.inl) builds, per neighbour direction, the list of
-owned beads within rmax+deltaR of that face, applies the periodic shift on the
-sender and posts one message per direction in increasing direction-code order;
-the receiver posts its receives in the order of the SENDER's codes, from the rank
-in its opposite direction.  This test runs exactly that protocol between two real
-processes over gloo, using ddcmi_plan_directions (the C host function the GPU
-path uses) for the topology, and checks that owned + received halo beads give
-every rank the complete neighbourhood: summed energies and per-bead forces equal
-the single-rank oracle."""
+What runs on the device in ddcmi_multigpu.inl (k_halo_select: which owned beads lie within
+rmax+deltaR of a face; k_pack_halo: the sender applies the periodic shift) is re-stated in numpy here;
+everything the HOST decides is libddcmi's own code, called through the C-ABI:
+  * ddcmi_plan_directions   -- destination rank and shift of the 26 directions (domain.c:61-208),
+  * ddcmi_plan_recv_counts  -- what a rank receives, from the all-gathered per-direction counts,
+  * ddcmi_plan_halo_layout  -- the peer-major send/receive buffer layout and the ONE message per peer
+                               (sseg/rseg of mg_layout_halo; ddcSendRecvTables, ddcSendRecv.c:126-225).
+Transport: gloo (torch.distributed) or libddcmi's own TCP rendezvous (host/rdzv.c, what bench.py uses).
+Check: owned + received halo beads give every rank its complete neighbourhood -- summed energies and
+per-bead forces equal the single-rank oracle -- and every received segment lies on the side of the
+domain its direction code says."""
 import os
 import sys
 import numpy as np
@@ -34,16 +36,64 @@ def _pair_terms(s, ri, ti, rj, tj, same):
     return 0.5 * e.sum(), f
 
 
-def _worker(rank, world, port, grid, q):
+class _Gloo(object):
+    def __init__(self, rank, world, port):
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.torch, self.dist, self.world = torch, dist, world
+
+    def allgather(self, a):
+        out = [self.torch.zeros(a.shape, dtype=self.torch.int32) for _ in range(self.world)]
+        self.dist.all_gather(out, self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)))
+        return np.stack([o.numpy() for o in out])
+
+    def exchange(self, sends, recvs):
+        reqs = [self.dist.isend(self.torch.from_numpy(np.ascontiguousarray(a)), p) for p, a in sends]
+        tens = [self.torch.zeros(a.shape, dtype=self.torch.float64) for _, a in recvs]
+        reqs += [self.dist.irecv(t, p) for (p, _), t in zip(recvs, tens)]
+        for rq in reqs:
+            rq.wait()
+        for (_, a), t in zip(recvs, tens):
+            a[...] = t.numpy()
+
+    def allreduce(self, v):
+        t = self.torch.tensor(v, dtype=self.torch.float64)
+        self.dist.all_reduce(t)
+        return t.numpy()
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+class _Tcp(object):
+    def __init__(self, rank, world, port):
+        from ddcmd_amd.martini import Rendezvous
+        self.r = Rendezvous(rank, world, "127.0.0.1", port, None, timeout=120.0)
+
+    def allgather(self, a):
+        return self.r.allgather(np.ascontiguousarray(a, dtype=np.int32))
+
+    def exchange(self, sends, recvs):
+        self.r.exchange(sends, recvs)
+
+    def allreduce(self, v):
+        return self.r.allreduce(v)
+
+    def close(self):
+        self.r.barrier()
+        self.r.close()
+
+
+def _worker(rank, world, port, grid, transport, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _Gloo(rank, world, port) if transport == "gloo" else _Tcp(rank, world, port)
     import ddcmd_amd
-    from ddcmd_amd.martini import plan_directions, domain_of
+    from ddcmd_amd.martini import plan_directions, domain_of, plan_recv_counts, plan_halo_layout
     s = ddcmd_amd.make_water_setup(6)            # 864 beads, box 48.7 A; 2 bricks of 24.4 A >= rlist 16 A
     L = s.box
     rlist = s.rmax + s.deltaR
@@ -58,8 +108,8 @@ def _worker(rank, world, port, grid, q):
     near_lo = r < lo + rlist
     near_hi = r >= lo + W - rlist
     halo_r, halo_t = [], []
-    reqs, recv_meta = [], []
-    sendbufs = {}
+    per_dir = {}
+    hs_cnt = np.zeros(27, np.int32)
     # selection per direction (k_halo_select) + sender-side shift (k_pack_halo)
     for code in range(27):
         if code == 13 or dest[code] < 0:
@@ -75,59 +125,56 @@ def _worker(rank, world, port, grid, q):
         if dest[code] == rank:
             halo_r.append(out[:, :3]); halo_t.append(out[:, 3].astype(np.int64))      # local periodic image
         else:
-            sendbufs[code] = out
-    # counts, then data: sends in increasing code; receives in increasing SENDER code from dest[opp(code)]
-    for phase in ("count", "data"):
-        reqs = []
-        bufs = {}
-        for code in range(27):
-            if code in sendbufs:
-                t = torch.tensor([len(sendbufs[code])], dtype=torch.int64) if phase == "count" else torch.from_numpy(np.ascontiguousarray(sendbufs[code]))
-                if phase == "count" or len(sendbufs[code]) > 0:
-                    reqs.append(dist.isend(t, int(dest[code])))
-            opp = 26 - code
-            if code != 13 and dest[opp] >= 0 and dest[opp] != rank:
-                if phase == "count":
-                    bufs[code] = torch.zeros(1, dtype=torch.int64)
-                    reqs.append(dist.irecv(bufs[code], int(dest[opp])))
-                elif rcnt[code] > 0:
-                    bufs[code] = torch.zeros(rcnt[code], 4, dtype=torch.float64)
-                    reqs.append(dist.irecv(bufs[code], int(dest[opp])))
-        for rq in reqs:
-            rq.wait()
-        if phase == "count":
-            rcnt = {c: int(b.item()) for c, b in bufs.items()}
-        else:
-            for c in sorted(bufs):
-                a = bufs[c].numpy()
-                halo_r.append(a[:, :3]); halo_t.append(a[:, 3].astype(np.int64))
+            per_dir[code] = out
+            hs_cnt[code] = len(out)
+    # mg_xchg_counts: one all-gather of the 27 counts, then libddcmi's lookup
+    allc = tr.allgather(hs_cnt)
+    rcnt = plan_recv_counts(grid, rank, s.pbc, allc)
+    # mg_layout_halo: libddcmi's peer-major layout and message list
+    so, ro, msgs, msgr = plan_halo_layout(grid, rank, s.pbc, hs_cnt, rcnt)
+    sendbuf = np.zeros((int(so[27]), 4))
+    for code, out in per_dir.items():
+        sendbuf[so[code]:so[code] + len(out)] = out
+    recvbuf = np.full((int(ro[27]), 4), np.nan)
+    npeers = len({int(d_) for d_ in dest if d_ >= 0 and d_ != rank})
+    assert len(msgs) == npeers and len(msgr) == npeers, "one message per peer and direction of travel"
+    tr.exchange([(p, sendbuf[o:o + c]) for p, o, c in msgs], [(p, recvbuf[o:o + c]) for p, o, c in msgr])
+    assert not np.isnan(recvbuf).any()
+    # every received segment lies where its (sender's) direction code says: sent towards +a => it is my -a side
+    side_ok = True
+    for code in range(27):
+        seg = recvbuf[ro[code]:ro[code] + rcnt[code], :3]
+        d = (code % 3 - 1, (code // 3) % 3 - 1, code // 9 - 1)
+        for a in range(3):
+            if d[a] > 0:
+                side_ok &= bool(np.all(seg[:, a] < lo[a]) and np.all(seg[:, a] >= lo[a] - rlist))
+            elif d[a] < 0:
+                side_ok &= bool(np.all(seg[:, a] >= lo[a] + W[a]) and np.all(seg[:, a] < lo[a] + W[a] + rlist))
+            else:
+                side_ok &= bool(np.all(seg[:, a] >= lo[a]) and np.all(seg[:, a] < lo[a] + W[a]))
+    halo_r.append(recvbuf[:, :3]); halo_t.append(recvbuf[:, 3].astype(np.int64))
     hr = np.concatenate(halo_r) if halo_r else np.zeros((0, 3))
     ht = np.concatenate(halo_t) if halo_t else np.zeros(0, np.int64)
     e1, f1 = _pair_terms(s, r, typ, r, typ, True)
     e2, f2 = _pair_terms(s, r, typ, hr, ht, False)
-    etot = torch.tensor([e1 + e2, float(len(mine)), float(len(hr))], dtype=torch.float64)
-    dist.all_reduce(etot)                                           # energyInfo.c allreduce()
-    if rank == 0:
-        import pyoracle
-        o = pyoracle.Oracle(s)
-        e0, _ = o.forces()
-        q.put(("energy", float(etot[0]), e0["lj"], int(etot[1]), s.natoms))
+    etot = tr.allreduce([e1 + e2, float(len(mine)), float(len(hr))])      # energyInfo.c allreduce()
     import pyoracle
     o = pyoracle.Oracle(s)
-    o.forces()
+    e0, _ = o.forces()
+    if rank == 0:
+        q.put(("energy", float(etot[0]), e0["lj"], int(etot[1]), s.natoms))
     ref = np.stack([o.fx[mine], o.fy[mine], o.fz[mine]], axis=1)
-    q.put(("force", rank, float(np.abs(f1 + f2 - ref).max() / np.abs(ref).max()), len(hr)))
-    dist.barrier()
-    dist.destroy_process_group()
+    q.put(("force", rank, float(np.abs(f1 + f2 - ref).max() / np.abs(ref).max()), len(hr), side_ok, len(msgs)))
+    tr.close()
 
 
-@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1)])
-def test_world2_gloo_halo_protocol(built, grid):
+@pytest.mark.parametrize("grid,transport", [((2, 1, 1), "gloo"), ((1, 2, 1), "gloo"), ((2, 1, 1), "tcp"), ((1, 1, 2), "tcp")])
+def test_world2_halo_protocol(built, grid, transport):
     import multiprocessing as mp          # plain spawn: the parent never loads torch (its bundled ROCm libs
     ctx = mp.get_context("spawn")         # must not meet the system ones already loaded through libddcmi.so)
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300) + (7 if grid[0] == 1 else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, grid, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 300) + 7 * (grid[1] + 2 * grid[2]) + (1000 if transport == "tcp" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, grid, transport, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(3)]
@@ -140,9 +187,50 @@ def test_world2_gloo_halo_protocol(built, grid):
             assert ntot == n
             assert abs(e - e0) < 1e-10 * abs(e0)
         else:
-            _, rank, err, nh = item
+            _, rank, err, nh, side_ok, nmsg = item
             assert err < 1e-10, (rank, err)
-            assert nh > 0
+            assert nh > 0 and side_ok
+            assert nmsg == 1          # both periodic sides of the split axis lead to the same peer: ONE message
+
+
+def test_halo_layout_is_consistent_across_ranks(built):
+    """ddcmi_plan_halo_layout on every rank of 2x2x2, 2x2x1, 3x2x1 and the loopback: what A sends to B as its
+    k-th message is what B expects from A as its k-th message, segment by segment"""
+    from ddcmd_amd.martini import plan_directions, plan_recv_counts, plan_halo_layout
+    rng = np.random.default_rng(5)
+    for grid, loop in [((2, 2, 2), False), ((2, 2, 1), False), ((3, 2, 1), False), ((2, 1, 1), False), ((1, 1, 1), True)]:
+        n = grid[0] * grid[1] * grid[2]
+        dests = [plan_directions(grid[0], grid[1], grid[2], r, 7)[0] for r in range(n)]
+        scnt = np.zeros((n, 27), np.int32)
+        for r in range(n):
+            for c in range(27):
+                if c != 13 and dests[r][c] >= 0 and (dests[r][c] != r or loop):
+                    scnt[r, c] = rng.integers(0, 50)
+        plans = []
+        for r in range(n):
+            rc = plan_recv_counts(grid, r, 7, scnt, loopback=loop)
+            for c in range(27):      # what the rank in my direction opp(c) sends along ITS direction c
+                src = dests[r][26 - c]
+                assert rc[c] == (scnt[src, c] if (c != 13 and src >= 0 and (src != r or loop)) else 0)
+            plans.append((rc,) + plan_halo_layout(grid, r, 7, scnt[r], rc, loopback=loop))
+        for a in range(n):
+            rc_a, so_a, ro_a, ms_a, mr_a = plans[a]
+            assert sum(c for _, _, c in ms_a) == scnt[a].sum() == so_a[27]
+            assert sum(c for _, _, c in mr_a) == rc_a.sum() == ro_a[27]
+            assert len({p for p, _, _ in ms_a}) == len(ms_a)          # one message per peer
+            if grid == (2, 2, 2):
+                assert len(ms_a) <= 7 and len(mr_a) <= 7               # the 7 xGMI peers
+            for peer, off, cnt in ms_a:
+                rc_b, so_b, ro_b, ms_b, mr_b = plans[peer]
+                back = [m for m in mr_b if m[0] == a]
+                assert len(back) == 1 and back[0][2] == cnt
+                # segment by segment: my direction codes towards `peer`, ascending, are the receiver's segments
+                # for sender codes ascending
+                codes = [c for c in range(27) if c != 13 and dests[a][c] == peer and (peer != a or loop)]
+                o_s, o_r = off, back[0][1]
+                for c in codes:
+                    assert so_a[c] == o_s and ro_b[c] == o_r
+                    o_s += scnt[a, c]; o_r += scnt[a, c]
 
 
 def test_plan_directions_topology(built):

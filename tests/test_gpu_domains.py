@@ -224,3 +224,23 @@ def test_decomposed_restraints():
     assert abs(e["restraint"] - eo["restraint"]) < TOL * eo["restraint"]
     assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"])
     g.close()
+
+
+def test_npt_and_constraints_are_refused_on_several_domains(monkeypatch):
+    """the barostat / velocity constraints set BEFORE the decomposition (the order MartiniRank uses) must not slip
+    through: each rank would scale its own box from its local virial"""
+    import ctypes
+    from ddcmd_amd.martini import MartiniRank, MartiniGroup, DdcmiError, _declare_domains
+    s = make_water_setup(10)
+    s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = 1e-3, 0.0, 1e-3, 1000.0
+    with pytest.raises(DdcmiError) as ei:
+        MartiniGroup(s, (2, 1, 1))
+    assert "single domain" in str(ei.value)
+    # RCCL path, one rank in loopback mode is still ONE domain: accepted
+    monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
+    m = MartiniRank(s, np.arange(s.natoms))
+    _declare_domains(m.lib)
+    buf = ctypes.create_string_buffer(128)
+    assert m.lib.ddcmi_comm_unique_id(buf) == 0
+    m.comm_init(0, 1, buf.raw, (1, 1, 1))
+    m.close()

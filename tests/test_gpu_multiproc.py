@@ -1,0 +1,143 @@
+"""GPU tests (-m gpu): the decomposed path between REAL processes on the one GPU a test box has.
+
+RCCL refuses two ranks of a communicator on one device ("Duplicate GPU detected"), so two processes cannot share
+a GPU over the RCCL transport; test_gpu_rccl_loopback.py covers the RCCL wire with one rank, test_gpu_domains.py
+the multi-domain logic inside one process.  Here every rank is a fresh child process with its own HIP context,
+its own address space and its own rank of the rendezvous, and the SAME libddcmi code path as the RCCL runs --
+mg_phase1..4, the count all-gather, plan_recv_counts, the peer-major halo layout, migration, per-step halo
+messages, the energy / group-temperature all-reduce -- with the messages carried by the host transport
+(ddcmi_comm_init_host: pinned staging + the rendezvous' TCP streams).  The parent process checks the merged
+result against the oracle.  The last test starts bench.py exactly as the driver does for N = 2."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import numpy as np
+import pytest
+
+import pyoracle
+import ddcmd_amd
+from conftest import rel_force_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KINDS = ("lj", "ele", "bond", "angle", "tors", "impr", "total")
+
+
+def _run_ranks(workload, grid, nsteps, block):
+    world = grid[0] * grid[1] * grid[2]
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ)
+            env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1",
+                        "DDCMI_RDZV_FILE": os.path.join(d, "port"), "DDCMI_TRANSPORT": "host"})
+            env.pop("DDCMI_RCCL_LOOPBACK", None)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), workload, "%dx%dx%d" % grid, d, str(nsteps), str(block)],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        for p in procs:
+            o, e = p.communicate(timeout=600)
+            assert p.returncode == 0, (o[-1500:], e[-3000:])
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+
+
+def _merge(recs, key_gid, key):
+    gid = np.concatenate([r[key_gid] for r in recs])
+    order = np.argsort(gid, kind="stable")
+    return gid[order], np.concatenate([r[key] for r in recs], axis=1)[:, order]
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 2)])
+def test_water_between_processes(grid):
+    """forces at step 0 and the state after 45 steps (two rebuilds with migration between the processes)"""
+    s = ddcmd_amd.make_water_setup(12)          # 6912 beads, box 97.5 A: bricks of 48.7 A
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    f_ref0 = (o.fx.copy(), o.fy.copy(), o.fz.copy())
+    recs = _run_ranks("water", grid, 45, 15)
+    gid, f0 = _merge(recs, "gid0", "f0")
+    assert np.array_equal(gid, np.sort(s.gid))
+    assert rel_force_err(f0, f_ref0) < 1e-10
+    assert abs(sum(r["e0"][0] for r in recs) - e0["lj"]) < 1e-10 * abs(e0["lj"])
+    assert np.abs(sum(r["vir0"] for r in recs) - v0).max() < 1e-10 * np.abs(v0).max()
+    for b in range(3):
+        eo, vo, rko, _ = o.step(15)
+        for r in recs:                          # every rank holds the same all-reduced numbers
+            assert abs(r["traj"][b][0] - eo["total"]) < 1e-6 * abs(eo["total"])
+            assert abs(r["traj"][b][1] - rko) < 1e-6 * rko
+            assert np.abs(r["traj"][b][2:8] - vo).max() < 1e-6 * np.abs(vo).max()
+            assert np.array_equal(r["traj"][b], recs[0]["traj"][b])
+    gid, f = _merge(recs, "gid", "f")
+    assert np.array_equal(gid, np.sort(s.gid)), "beads lost or duplicated in migration"
+    assert [int(r["nloc"][1]) for r in recs] != [int(r["nloc"][0]) for r in recs], "no bead changed owner"
+    assert all(int(r["rebuilds"][0]) >= 3 for r in recs)
+    assert rel_force_err(f, (o.fx, o.fy, o.fz)) < 1e-6
+    _, pos = _merge(recs, "gid", "r")
+    L = s.h[0]
+    for c, ref in enumerate((o.rx, o.ry, o.rz)):
+        dr = pos[c] - ref
+        dr -= L * np.rint(dr / L)
+        assert np.abs(dr).max() < 1e-8
+    _, vel = _merge(recs, "gid", "v")
+    for c, ref in enumerate((o.vx, o.vy, o.vz)):
+        assert np.abs(vel[c] - ref).max() < 1e-8 * np.abs(ref).max()
+
+
+def test_lipid_deck_between_processes():
+    """bonded terms by gid across a process boundary + the Berendsen group temperature, all-reduced over the transport"""
+    from ddcmd_amd.deck import load_deck
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    f_ref0 = (o.fx.copy(), o.fy.copy(), o.fz.copy())
+    o.group_temperature()
+    T0 = o.groups[0].temperature
+    recs = _run_ranks("lipid", (1, 1, 2), 20, 10)
+    gid, f0 = _merge(recs, "gid0", "f0")
+    assert np.array_equal(gid, np.sort(s.gid))
+    assert rel_force_err(f0, f_ref0) < 1e-9
+    for k, name in enumerate(KINDS):
+        assert abs(sum(r["e0"][k] for r in recs) - e0[name]) < 1e-9 * max(abs(e0[name]), 1e-12), name
+    for r in recs:
+        assert abs(r["Tg"][0][0] - T0) < 1e-10 * T0
+    for b in range(2):
+        eo, vo, rko, _ = o.step(10)
+        o.group_temperature()
+        for r in recs:
+            assert abs(r["traj"][b][0] - eo["total"]) < 1e-6 * abs(eo["total"])
+            assert abs(r["traj"][b][1] - rko) < 1e-6 * rko
+            assert abs(r["Tg"][b + 1][0] - o.groups[0].temperature) < 1e-6 * T0
+    gid, f = _merge(recs, "gid", "f")
+    assert np.array_equal(gid, np.sort(s.gid))
+    assert rel_force_err(f, (o.fx, o.fy, o.fz)) < 1e-6
+
+
+def test_bench_world2_as_the_driver_launches_it():
+    """python -m torch.distributed.run ... bench.py --gpus 2: two ranks, one device, host transport; the process maps
+    only /opt/rocm's runtime, no bead is lost (bench.py asserts it) and the JSON line carries the contract's fields"""
+    port = 29900 + os.getpid() % 90
+    env = dict(os.environ)
+    env.update({"DDCMI_BENCH_SINGLE_DEVICE": "1", "DDCMI_TRANSPORT": "host"})
+    env.pop("DDCMI_RDZV_FILE", None); env.pop("DDCMI_RDZV_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--lattice", "14"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["beads_total"] == 4 * 14 ** 3 and 0 < out["config"]["beads_rank0"] < out["config"]["beads_total"]
+    assert out["config"]["rebuilds_in_timed_region"] == 2
+    assert "cpu_baseline" not in out               # rank 0 at N = 1 only
+    for l in out["runtime_libs"]:
+        assert os.path.realpath(l).startswith(os.path.realpath("/opt/rocm") + os.sep), l
+    # the same box on one rank gives the same energies (the decomposition changes no physics)
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "20", "--lattice", "14", "--no-cpu"],
+                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
+    assert abs(out["check"]["epot"] - one["check"]["epot"]) < 1e-7 * abs(one["check"]["epot"])
+    assert abs(out["check"]["ekin"] - one["check"]["ekin"]) < 1e-7 * abs(one["check"]["ekin"])
