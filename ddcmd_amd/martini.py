@@ -603,7 +603,8 @@ class MartiniGroup(object):
         self.arr = (ctypes.c_void_p * self.n)(*[r.ctx for r in self.ranks])
         rc = self.lib.ddcmi_group_create(self.arr, self.n, grid[0], grid[1], grid[2])
         if rc != 0:
-            raise DdcmiError("ddcmi_group_create failed: %d" % rc)
+            msgs = [self.lib.ddcmi_last_error(r.ctx).decode() for r in self.ranks]
+            raise DdcmiError("ddcmi_group_create failed: %d %s" % (rc, "; ".join(sorted(set(m for m in msgs if m)))))
         for r in self.ranks:
             r.upload_local()
 
