@@ -26,6 +26,7 @@
 #include "ddcmi_internal.h"
 #include <math.h>
 #include <algorithm>
+#include <functional>
 #include <rccl/rccl.h>
 
 static std::string g_create_err;
@@ -333,12 +334,13 @@ struct NbTileArgs
 {
    int ntile, stage_stride, cap, nlj;
    const int *cell_start_o;
+   const int *cell_start, *cell_cnt;    /* merged owned/halo cell ranges (k_merge_cells): the staged order follows from them */
    const int *stage_idx, *tile_nstage;
    const long long *tile_base; const int *tile_width, *tile_rows;
    const unsigned short *nbr16;
    const int *nbr_cnt;
    const int *sched;                    /* [9] range of each XCD in perm[] (schedule_tiles) */
-   const int *perm;                     /* tile order: [interior tiles | tiles that stage image/halo beads] */
+   const int *perm;                     /* work items in launch order: tile | part << 24 | (nparts - 1) << 27 (schedule_tiles) */
    const int *tile_work;                /* bit 30: the tile stages image/halo beads */
    const int *halo_shift; int nloc;     /* halo_shift[j - nloc] != 13: bead j carries a periodic shift */
    int rot;                             /* tuning builds: rotate the range -> XCD assignment */
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    int nown = te - ts;
    if (nown <= 0)
    {
-      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 1; }
+      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 0; ta.tile_work[ta.ntile + t] = 0; }
       return;
    }
    int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    if (threadIdx.x == 0) { ofs_s[NRC] = tot; ta.tile_nstage[t] = tot; }
    if (tot > ta.cap || tot > (ta.pack_type ? 4095 : 65534))     /* staged slot 0 is the sentinel */
    {
-      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 1; }
+      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 0; ta.tile_work[ta.ntile + t] = 0; }
       return;      /* LDS capacity too small: the host retries with a larger cap */
    }
    __syncthreads();
@@ -585,7 +587,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          const int parts = 64 / R;
          work += ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES;
       }
-      ta.tile_work[t] = (work + (5 * tot) / 2 + 1) | (s_halo ? (1 << 30) : 0);      /* bit 30: stages image/halo beads */
+      /* [t]: the list walk (bit 30: the tile stages image/halo beads); [ntile + t]: staging, in the same unit --
+       * calibrated on per-workgroup timelines (tools/trace_gaps.py): a full tile walks ~80 k units in 25 us and
+       * stages 2400-3000 beads in 5-7.5 us */
+      ta.tile_work[t] = (work + 1) | (s_halo ? (1 << 30) : 0);
+      ta.tile_work[ta.ntile + t] = 7 * tot;
    }
 }
 
@@ -734,7 +740,7 @@ extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
 #define TRACE_MARK(slot) do { } while (0)
 #endif
 template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH>
-__global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int npad,
+__global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
                                                          const int *__restrict__ excl, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
@@ -783,19 +789,23 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
 #endif
    const int slot = ta.sched[xcd] + (int)(blockIdx.x >> 3);
    const bool mine = slot < ta.sched[xcd + 1];
-   const int t = mine ? ta.perm[slot] : 0;
+   /* a work item is a tile or -- in the last round of a launch, where whole tiles would leave most CUs idle --
+    * one of nparts row ranges of a tile: every part stages the tile's neighbourhood and walks its share of the rows
+    * with all eight waves (the sub-64-row chunks below give each bead several lanes) */
+   const int item = mine ? ta.perm[slot] : 0;
+   const int t = item & 0xffffff, part = (item >> 24) & 7, nparts = ((item >> 27) & 7) + 1;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* vLJ, vEle, xx,yy,zz,xy,xz,yz */
-   int nown = 0, ts = 0;
+   int nown = 0, ts = 0, r_lo = 0, r_hi = 0;
    if (mine)
    {
       ts = ta.cell_start_o[TCELLS * t];
       nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
+      r_lo = (int)(((long long)nown * part) / nparts); r_hi = (int)(((long long)nown * (part + 1)) / nparts);
    }
    if (nown > 0)
    {
       for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) { s_lj[k] = ljtab[k]; if (HAS_Q) s_kq[k] = kqtab[k]; }
       int ns = ta.tile_nstage[t];
-      const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
       /* Virial.  A pair of two unshifted beads contributes f_ij (x) (r_i - r_j) from i's side and
        * the mirror term from j's side; the two add up to 2 f_ij (x) r_i + 2 f_ji (x) r_j, so each
        * side may book 2 f_ij (x) r_i instead -- summed over j that is 2 F_i (x) r_i, six FMAs per
@@ -803,9 +813,102 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
        * pairs) keep the per-pair form on both sides.  Only tiles that stage image/halo beads can
        * hold shifted partners. */
       const bool tshift = (ta.tile_work[t] >> 30) & 1;
-      /* stage the neighbourhood: all index loads first, then all record gathers, then the
-       * LDS writes -- a naive loop serialises ~9 dependent HBM/L2 round trips per thread */
-      constexpr int SU = NB_SU;
+      /* Stage the neighbourhood.  The staged order is k_tile_build's: the cells of the 12x8x8 region in raster
+       * order, each cell's beads as they lie in the sorted arrays.  The global index of staged slot k follows from
+       * the cell tables (a few KB that stay in L2) instead of a per-tile index list (12 KB per tile and step from
+       * HBM, and a dependent load in front of every record gather): region cell counts -> block scan -> a
+       * slot -> cell map in LDS (aliased onto the not yet written position arrays) -> one index per thread and
+       * round in registers -> all record gathers of a batch in flight -> LDS writes. */
+      constexpr int SU = 4, MAXR = 8;
+      constexpr int NWV = NB_BLOCK / 64;
+      if (ns <= MAXR * NB_BLOCK)
+      {
+         int *ofs_s = (int *)smem;                                    /* [NRC]  staged offset of each region cell */
+         int *gst_s = ofs_s + NRC + 8;                                /* [NRC]  global index of its first bead */
+         int *s_w = gst_s + NRC + 8;                                  /* [NWV]  scan scratch */
+         unsigned short *cellof = (unsigned short *)(s_w + 16);       /* [ns]   region cell of each staged slot */
+         constexpr int CPT = (NRC + NB_BLOCK - 1) / NB_BLOCK;
+         const int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
+         int v[CPT], g[CPT], vsum = 0;
+#pragma unroll
+         for (int h = 0; h < CPT; h++)
+         {
+            const int c = CPT * (int)threadIdx.x + h;
+            v[h] = 0; g[h] = 0;
+            if (c < NRC)
+            {
+               const int cx = TCX * tx - 2 + (c % RGX), cy = TCY * ty - 2 + ((c / RGX) % RGY), cz = TCZ * tz - 2 + (c / (RGX * RGY));
+               if (cx >= 0 && cy >= 0 && cz >= 0 && cx < gp.g[0] && cy < gp.g[1] && cz < gp.g[2])
+               {
+                  const int id = cell_linear(gp, cx, cy, cz);
+                  v[h] = ta.cell_cnt[id]; g[h] = ta.cell_start[id];
+               }
+            }
+            vsum += v[h];
+         }
+         int inc = vsum;
+         {
+            const int ln = threadIdx.x & 63;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { int q = __shfl_up(inc, off, 64); if (ln >= off) inc += q; }
+            if (ln == 63) s_w[threadIdx.x >> 6] = inc;
+         }
+         __syncthreads();
+         int ex = inc - vsum;
+#pragma unroll
+         for (int q = 0; q < NWV; q++) if (q < (int)(threadIdx.x >> 6)) ex += s_w[q];
+#pragma unroll
+         for (int h = 0; h < CPT; h++)
+         {
+            const int c = CPT * (int)threadIdx.x + h;
+            if (c < NRC)
+            {
+               ofs_s[c] = ex; gst_s[c] = g[h];
+               for (int j = 0; j < v[h]; j++) cellof[ex + j] = (unsigned short)c;
+            }
+            ex += v[h];
+         }
+         __syncthreads();
+         int gj[MAXR];
+#pragma unroll
+         for (int u = 0; u < MAXR; u++)
+         {
+            const int k = (int)threadIdx.x + u * NB_BLOCK;
+            gj[u] = 0;
+            if (k < ns) { const int c = cellof[k]; gj[u] = gst_s[c] + (k - ofs_s[c]); }
+         }
+         __syncthreads();      /* the tables are dead: their bytes become staged positions */
+#pragma unroll
+         for (int b = 0; b < MAXR; b += SU)
+         {
+            if (b * NB_BLOCK >= ns) break;
+            double4 pp[SU];
+            int sh[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++)
+            {
+               pp[u] = pos[gj[b + u]];
+               sh[u] = (!SHBIT && tshift && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++)
+            {
+               const int k = (int)threadIdx.x + (b + u) * NB_BLOCK;
+               if (k < ns)
+               {
+                  XY_s[k + 1] = make_double2(pp[u].x, pp[u].y);
+                  Z_s[k + 1] = pp[u].z;
+                  if (!PACKED) T_s[k + 1] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
+                  if (tshift && !SHBIT) S_s[k + 1] = (unsigned char)(sh[u] != 13);
+               }
+            }
+         }
+      }
+      else
+      {
+      /* neighbourhoods beyond 4096 beads (bare 16-bit entries): through the tile's index list -- all index loads
+       * first, then all record gathers, then the LDS writes */
+      const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
       for (int k0 = threadIdx.x; k0 < ns; k0 += SU * NB_BLOCK)
       {
          int gj[SU], sh[SU];
@@ -831,6 +934,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
             }
          }
       }
+      }
       if (threadIdx.x == 0)
       {
          /* staged slot 0: a bead far outside every cutoff.  List padding (entry 0) points
@@ -853,9 +957,9 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
       constexpr int NWAVES = NB_BLOCK / 64;
       /* a tile with more beads than threads: the rows beyond the first 64*NWAVES are again spread over all
        * waves (small R, many lanes per bead) instead of queueing behind the first waves as whole chunks */
-      for (int row0 = 0; row0 < nown; row0 += 64 * NWAVES)
+      for (int row0 = r_lo; row0 < r_hi; row0 += 64 * NWAVES)
       {
-      const int nhere = min(nown - row0, 64 * NWAVES);
+      const int nhere = min(r_hi - row0, 64 * NWAVES);
       int R = 64;
       while (R > 1 && (R >> 1) * NWAVES >= nhere) R >>= 1;
       const int nchunks = (nhere + R - 1) / R;
@@ -1031,7 +1135,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(NbTileArgs ta, int np
          double a = s_red[threadIdx.x];
 #pragma unroll
          for (int q = 1; q < NB_BLOCK / 64; q++) a += s_red[q * 8 + threadIdx.x];
-         partials[(size_t)t * 8 + threadIdx.x] = a;
+         partials[(size_t)slot * 8 + threadIdx.x] = a;      /* one row per work item */
       }
    }
 }
@@ -2027,49 +2131,130 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
  * all owned beads run while the halo exchange is in flight, the others after it
  * (DDCMI_HALO_OVERLAP=1; off by default: on one GPU through the RCCL loopback the split costs
  * more -- two launch tails, the exchange competing for the CUs -- than the 40 us it hides). */
-static int schedule_tiles(ddcmi_ctx *ctx)
+static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
 {
    /* the tile costs came to the host with the build's flags (ddcmi_bl_finish), in pinned memory; the order
     * and the ranges leave from pinned memory too, so this function costs no host round trip of its own */
    const int ntile = ctx->ntile;
-   const int *work = ctx->h_pin[0];
-   int *perm = ctx->pinned(1, (size_t)ntile + 64), *sched = perm ? perm + ntile : nullptr;
+   const int *work = ctx->h_pin[0], *stage = work ? work + ntile : nullptr;
+   const size_t cap_items = (size_t)ntile + 8 * 64 * 8 + 64;      /* every tile once + the parts the 8 tails may add */
+   int *perm = ctx->pinned(1, cap_items + 64), *sched = perm ? perm + cap_items : nullptr;
    if (!work || !perm) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile schedule");
    for (int k = 0; k < 32; k++) sched[k] = 0;
    const bool two = ctx->halo_overlap && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
+   /* tiles without owned beads (the margin tiles, empty space) get no workgroup at all: a workgroup that finds
+    * nothing to do still has to be dispatched with its 72 KB of LDS and eight waves, and at 4 M beads 45 % of the
+    * grid were such workgroups -- the per-CU timeline showed one of the two slots of a CU empty a quarter of the
+    * time. */
+   std::vector<int> live;
+   live.reserve(ntile);
    int n0 = 0;
    if (two)
    {
-      for (int t = 0; t < ntile; t++) if (!(work[t] >> 30)) perm[n0++] = t;
-      int k = n0;
-      for (int t = 0; t < ntile; t++) if (work[t] >> 30) perm[k++] = t;
+      for (int t = 0; t < ntile; t++) if ((work[t] & 0x3fffffff) > 0 && !(work[t] >> 30)) live.push_back(t);
+      n0 = (int)live.size();
+      for (int t = 0; t < ntile; t++) if ((work[t] & 0x3fffffff) > 0 && (work[t] >> 30)) live.push_back(t);
    }
-   else { for (int t = 0; t < ntile; t++) perm[t] = t; n0 = ntile; }
+   else { for (int t = 0; t < ntile; t++) if ((work[t] & 0x3fffffff) > 0) live.push_back(t); n0 = (int)live.size(); }
+   const int nlive = (int)live.size();
+   auto cost_list = [&](int t) { return (double)(work[t] & 0x3fffffff); };
+   auto cost_stage = [&](int t) { return (double)stage[t]; };
+   /* greedy list scheduling of a range's items on the S workgroup slots of one XCD: the makespan */
+   const int S = std::max(1, wg_per_cu) * 32;
+   static const bool no_split = getenv("DDCMI_NO_TAIL_SPLIT") != nullptr;
+   std::vector<double> heap((size_t)S);
+   auto makespan = [&](const int *tl, int n, int m, int k) -> double
+   {
+      /* the last m tiles are cut into k parts each */
+      std::fill(heap.begin(), heap.end(), 0.0);      /* min-heap of slot finish times */
+      auto push_item = [&](double c)
+      {
+         std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
+         heap.back() += c;
+         std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+      };
+      for (int q = 0; q < n; q++)
+      {
+         const int t = tl[q];
+         if (q < n - m || k == 1) push_item(cost_stage(t) + cost_list(t));
+         else for (int p = 0; p < k; p++) push_item(cost_stage(t) + 1.08 * cost_list(t) / k + 2000.0);
+      }
+      double mx = 0.0;
+      for (double f : heap) mx = std::max(mx, f);
+      return mx;
+   };
+   int nitems = 0;
    auto split = [&](int lo, int hi, int *out, int *longest)
    {
-      unsigned long long W = 0, run = 0;
-      for (int q = lo; q < hi; q++) W += (unsigned)(work[perm[q]] & 0x3fffffff);
-      for (int x = 0; x < 9; x++) out[x] = (x == 8) ? hi : lo;
+      /* 8 contiguous runs of equal estimated work, one per XCD (equal COUNTS would leave the XCDs that own the
+       * thin edge tiles idle at the end of a launch) */
+      double W = 0, run = 0;
+      for (int q = lo; q < hi; q++) W += cost_list(live[q]) + cost_stage(live[q]);
+      int cut[9];
+      for (int x = 0; x < 9; x++) cut[x] = (x == 8) ? hi : lo;
       for (int q = lo; q < hi; q++)
       {
-         unsigned long long nxt = run + (unsigned)(work[perm[q]] & 0x3fffffff);
+         double nxt = run + cost_list(live[q]) + cost_stage(live[q]);
          for (int x = 1; x < 8; x++)
          {
-            unsigned long long target = (W * (unsigned long long)x) >> 3;
-            if (run < target && nxt >= target) out[x] = q + 1;
+            double target = W * x / 8.0;
+            if (run < target && nxt >= target) cut[x] = q + 1;
          }
          run = nxt;
       }
-      for (int x = 1; x < 9; x++) out[x] = std::max(out[x], out[x - 1]);
+      for (int x = 1; x < 9; x++) cut[x] = std::max(cut[x], cut[x - 1]);
       *longest = 0;
-      for (int x = 0; x < 8; x++) *longest = std::max(*longest, out[x + 1] - out[x]);
+      for (int x = 0; x < 8; x++)
+      {
+         const int *tl = live.data() + cut[x];
+         const int n = cut[x + 1] - cut[x];
+         /* the tail: how many of the run's last tiles to cut, and into how many parts, by simulated makespan */
+         int best_m = 0, best_k = 1;
+         /* (only where the last round weighs: with R rounds of workgroups per slot it is worth at most 1/(2R)).
+          * The search simulates a dozen schedules per XCD; tile counts barely move between rebuilds, so its answer
+          * is kept while the run's tile count stays within 3 % of the count it was found for and re-derived every
+          * 64th rebuild. */
+         int *cache = ctx->sched_cache[lo == 0 ? 0 : 1][x];
+         const bool cached = cache[0] > 0 && abs(cache[0] - n) <= 2 + n / 32 && (ctx->nrebuild & 63) != 0;
+         if (cached) { best_m = std::min(cache[1], n); best_k = cache[2]; }
+         else if (!no_split && n > 0 && n < 8 * S)
+         {
+            double best = makespan(tl, n, 0, 1);
+            const int r = n % S;
+            const int cand[] = {r, r + S / 2, r + S};
+            const int parts[] = {2, 3, 4, 6, 8};
+            for (int m : cand)
+            {
+               if (m <= 0 || m > n) continue;
+               for (int k : parts)
+               {
+                  if ((size_t)m * k > 64 * 8) continue;
+                  double ms = makespan(tl, n, m, k);
+                  if (ms < 0.985 * best) { best = ms; best_m = m; best_k = k; }
+               }
+            }
+         }
+         if (!cached) { cache[0] = n; cache[1] = best_m; cache[2] = best_k; }
+         if (getenv("DDCMI_DEBUG_SCHED")) fprintf(stderr, "ddcmi sched: xcd %d tiles %d tail %d tiles x %d parts\n", x, n, best_m, best_k);
+         out[x] = nitems;
+         for (int q = 0; q < n; q++)
+         {
+            if (q < n - best_m) perm[nitems++] = tl[q];
+            else for (int p = 0; p < best_k; p++) perm[nitems++] = tl[q] | (p << 24) | ((best_k - 1) << 27);
+         }
+         *longest = std::max(*longest, nitems - out[x]);
+      }
+      out[8] = nitems;
    };
+   if (ntile >= (1 << 24)) SETERR(ctx, DDCMI_EUNSUPPORTED, "%d tiles: more than a work item's 24 bits name", ntile);
    split(0, n0, &sched[0], &ctx->sched_longest[0]);
-   split(n0, ntile, &sched[16], &ctx->sched_longest[1]);
-   ctx->ntile_class[0] = n0; ctx->ntile_class[1] = ntile - n0;
-   ENSURE(ctx, ctx->tile_perm, (size_t)ntile + 1);
+   split(n0, nlive, &sched[16], &ctx->sched_longest[1]);
+   ctx->ntile_class[0] = sched[8] - sched[0]; ctx->ntile_class[1] = sched[24] - sched[16];
+   ctx->nitems = nitems;
+   ENSURE(ctx, ctx->tile_perm, cap_items + 1);
    ENSURE(ctx, ctx->sched, 32);
-   HIPCHK(ctx, hipMemcpyAsync(ctx->tile_perm.p, perm, (size_t)ntile * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+   ENSURE(ctx, ctx->partials, (size_t)(nitems + 8) * 8);
+   HIPCHK(ctx, hipMemcpyAsync(ctx->tile_perm.p, perm, (size_t)std::max(nitems, 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
    HIPCHK(ctx, hipMemcpyAsync(ctx->sched.p, sched, 32 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
    return DDCMI_OK;       /* the pinned buffers are rewritten at the next rebuild, behind its own synchronisation */
 }
@@ -2092,7 +2277,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    {
       double per_cell = dens / (gp.cinv[0] * gp.cinv[1] * gp.cinv[2]);
       ctx->stage_cap = (((int)((double)NRC * per_cell * 1.05) + 48) + 63) & ~63;
-      if (ctx->stage_cap < 256) ctx->stage_cap = 256;
+      if (ctx->stage_cap < 384) ctx->stage_cap = 384;      /* k_nonbond's cell tables alias the 24 B per bead position arrays */
       ctx->maxexcl = 1;
       for (int m = 0; m < ctx->nmoltype; m++) if (ctx->mol_nspecies[m] > 1) ctx->maxexcl = 16;
    }
@@ -2105,7 +2290,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
    ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
-   ENSURE(ctx, ctx->tile_work, ntile + 1);
+   ENSURE(ctx, ctx->tile_work, 2 * (size_t)ntile + 2);
    if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
    double rcut = ctx->rmax, dR = ctx->deltaR;
    /* distance shells of the list order: entries a wave rejects as a whole come last */
@@ -2149,14 +2334,14 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       }
       HIPCHK(ctx, hipGetLastError());
       unsigned long long tot[3];
-      int *h_work = ctx->pinned(0, (size_t)ntile + 8);
+      int *h_work = ctx->pinned(0, 2 * (size_t)ntile + 8);
       if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 12, ctx->d_flags + 12, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
-      HIPCHK(ctx, hipMemcpyAsync(h_work + ntile, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 2 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
+      HIPCHK(ctx, hipMemcpyAsync(h_work + 2 * (size_t)ntile, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
-      memcpy(tot, h_work + ntile, sizeof(tot));
+      memcpy(tot, h_work + 2 * (size_t)ntile, sizeof(tot));
       if (ctx->h_flags[12] > 0)
          SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)", ctx->h_flags[12], (long long)ctx->loop);
       bool again = false;
@@ -2171,8 +2356,13 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
          break;
       }
    }
-   ENSURE(ctx, ctx->partials, (size_t)(ntile + 8) * 8);
-   { int rcs = schedule_tiles(ctx); if (rcs) return rcs; }
+   {
+      /* workgroups of k_nonbond a CU holds: its LDS image of a neighbourhood (launch_forces), at most two by registers */
+      const size_t capl = (size_t)ctx->stage_cap + 2;
+      const size_t lds_nb = capl * 24 + (size_t)ctx->nnb * ctx->nnb * (sizeof(double4) + (ctx->has_charge ? sizeof(double) : 0)) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
+      int rcs = schedule_tiles(ctx, (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_nb, 1))));
+      if (rcs) return rcs;
+   }
    if (ctx->updateRate == 0)
    {
       /* neighborRef (neighbor.c:209-246): remember where every owned bead was */
@@ -2238,13 +2428,14 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nnb;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
+      na.cell_start = ctx->cell_start.p; na.cell_cnt = ctx->cell_cnt.p;
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       { const char *rv = getenv("DDCMI_XCD_ROT"); na.rot = rv ? atoi(rv) : 0; }
 #define LAUNCH_NB(Q, P, S, NT) do { \
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
+         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
@@ -2282,7 +2473,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       /* without bonded terms the final energies are formed in the same launch */
       if (!defer_reduce)
       {
-         RedJob j0 = {ctx->partials.p, ntile, 8, ctx->d_results + R_NB_LJ, has_bonded ? 0 : 1};
+         RedJob j0 = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, has_bonded ? 0 : 1};
          hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, st, j0, j0, ctx->d_results, self, ctx->red_tmp.p);
       }
    }
@@ -2341,7 +2532,7 @@ static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forc
    {
       const bool nb_on = (ctx->excludePotentialTerm & 128) == 0;
       const double self = nb_on ? ctx->self_ele : 0.0;
-      RedJob jf = {ctx->partials.p, nb_on ? ctx->ntile : 0, 8, ctx->d_results + R_NB_LJ, 1};
+      RedJob jf = {ctx->partials.p, nb_on ? ctx->nitems : 0, 8, ctx->d_results + R_NB_LJ, 1};
       hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, self, ctx->red_tmp.p);
    }
    else

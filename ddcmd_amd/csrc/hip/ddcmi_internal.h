@@ -158,6 +158,8 @@ struct ddcmi_ctx
    int maxnbr = 0, maxexcl = 0;
    dbuf<int> nbr_cnt, excl, excl_cnt;
    dbuf<int> tile_work, sched, tile_perm;   /* per-tile cost estimate (bit 30: stages halo beads); XCD ranges [2][16]; tile order */
+   int nitems = 0;                     /* work items of k_nonbond: the tiles with owned beads, the last ones of each XCD's run cut into parts */
+   int sched_cache[2][8][3] = {};      /* tail split of each class and XCD run: {tiles it was found for, tiles cut, parts} */
    int sched_longest[2] = {0, 0}, ntile_class[2] = {0, 0};      /* class 0: all-owned neighbourhoods (all tiles on one domain), class 1: the rest */
    hipStream_t stream2 = nullptr;      /* decomposed runs: halo exchange, concurrent with the class-0 tiles */
    hipEvent_t ev_drift = nullptr, ev_halo = nullptr;

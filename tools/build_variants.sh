@@ -8,7 +8,7 @@ mkdir -p ../lib/variants build/var
 while [ $# -ge 2 ]; do
    name=$1; flags=$2; shift 2
    for f in ddcmi scan bonded; do
-      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=fast -I../../include -Ihip $flags -c hip/$f.hip -o build/var/${name}_$f.o &
+      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -I../../include -Ihip $flags -c hip/$f.hip -o build/var/${name}_$f.o &
    done
    wait
    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/variants/libddcmi_$name.so build/host/*.o build/var/${name}_ddcmi.o build/var/${name}_scan.o build/var/${name}_bonded.o -L/opt/rocm/lib -lrccl -lm -Wl,-rpath,/opt/rocm/lib

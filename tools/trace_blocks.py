@@ -3,7 +3,7 @@
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
-import torch  # noqa: F401  (first, so its ROCm libs win)
+
 from ddcmd_amd.synth import make_water_setup
 from ddcmd_amd.martini import MartiniHIP
 from ddcmd_amd._lib import load_library
