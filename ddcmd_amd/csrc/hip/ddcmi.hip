@@ -362,6 +362,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    unsigned *M_s = (unsigned *)(tb_smem + ta.cap);
    int *ofs_s = (int *)(M_s + (HAS_MOL ? ta.cap : 0));     /* [NRC+1] staged offset of each region cell */
    int *gst_s = ofs_s + NRC + 8;                           /* [NRC] global start of each region cell */
+   unsigned short *cellof_s = (unsigned short *)(gst_s + NRC + 8);      /* [cap] region cell of each staged slot */
    __shared__ int s_w[TB_THREADS / 64];
    int t = blockIdx.x;
    int ts = ta.cell_start_o[TCELLS * t], te = ta.cell_start_o[TCELLS * t + TCELLS];
@@ -421,20 +422,48 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
    const double ox = gp.lo[0] + (TCX * tx - gp.m[0] + 0.5 * TCX) / gp.cinv[0], oy = gp.lo[1] + (TCY * ty - gp.m[1] + 0.5 * TCY) / gp.cinv[1],
                 oz = gp.lo[2] + (TCZ * tz - gp.m[2] + 0.5 * TCZ) / gp.cinv[2];
+   /* one thread per staged slot, four gathers in flight: a slot -> cell map in LDS gives every slot its global
+    * index (a loop over each cell's beads by the thread that owns the cell serialised a dozen memory round trips:
+    * 1.1 ms of this kernel's 2.4 at 4 M beads) */
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
-      int o = (CPT * threadIdx.x + h < NRC) ? ofs_s[CPT * threadIdx.x + h] : 0;
-      for (int k = 0; k < v[h]; k++)
+      const int c = CPT * threadIdx.x + h;
+      if (c < NRC) { const int o = ofs_s[c]; for (int k = 0; k < v[h]; k++) cellof_s[o + k] = (unsigned short)c; }
+   }
+   __syncthreads();
+   for (int k0 = threadIdx.x; k0 < tot; k0 += 4 * TB_THREADS)
+   {
+      int gj[4];
+      double4 p4[4];
+      int hs4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
       {
-         int gj = g[h] + k;
-         sidx[o + k] = gj;
-         double4 p = pos[gj];
-         unsigned long long w = (unsigned long long)__double_as_longlong(p.w);
-         unsigned lo = (unsigned)w;
-         if (ta.pack_type == 2 && gj >= ta.nloc && ta.halo_shift[gj - ta.nloc] != 13) lo |= 8u;       /* travels into the entry's type nibble */
-         P_s[o + k] = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
-         if (HAS_MOL) M_s[o + k] = (unsigned)(w >> 32);
+         const int k = k0 + u * TB_THREADS;
+         gj[u] = ts;
+         if (k < tot) { const int c = cellof_s[k]; gj[u] = gst_s[c] + (k - ofs_s[c]); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+         p4[u] = pos[gj[u]];
+         hs4[u] = (ta.pack_type == 2 && gj[u] >= ta.nloc) ? ta.halo_shift[gj[u] - ta.nloc] : 13;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+      {
+         const int k = k0 + u * TB_THREADS;
+         if (k < tot)
+         {
+            sidx[k] = gj[u];
+            const double4 p = p4[u];
+            unsigned long long w = (unsigned long long)__double_as_longlong(p.w);
+            unsigned lo = (unsigned)w;
+            if (hs4[u] != 13) lo |= 8u;       /* travels into the entry's type nibble */
+            P_s[k] = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
+            if (HAS_MOL) M_s[k] = (unsigned)(w >> 32);
+         }
       }
    }
    __syncthreads();
@@ -446,7 +475,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
     * to the bead's own row of a row-major scratch list (sequential 2-byte appends,
     * write-combined in L2) tagged with their distance shell; k_tile_transpose then
     * lays them out slot-major in shell order. */
+#if defined(TB_ABLATE) && TB_ABLATE == 2      /* tuning builds: staging only */
+   for (int al = threadIdx.x; al < 0; al += TB_THREADS)
+#else
    for (int al = threadIdx.x; al < nown; al += TB_THREADS)
+#endif
    {
       int a = ts + al;
       double4 pi = pos[a];
@@ -471,11 +504,31 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       /* scratch row: two words per 8-byte store (tmpw is even) */
       uint2 *row2 = (uint2 *)(ta.tmp32 + (size_t)a * ta.tmpw);
       unsigned wprev = 0;
+#if defined(TB_ST16)
+      unsigned w0_ = 0, w1_ = 0;
+#endif
+      /* Of the 5x5x5 cells around the bead's cell only those within the list radius of the BEAD are walked: per
+       * (y,z) row of cells the gap between the bead and the row's band, and from it the reach along x -- on average
+       * 60 % of the candidates of the full cube.  Conservative: gaps are measured to the cells' geometric bounds
+       * (a bead clamped into an edge cell from outside the grid lies further out, never nearer), the bead's own
+       * cell column is always inside the range, and the radius carries the margin of the single-precision image. */
+      const float ux = (float)((pi.x - gp.lo[0]) * gp.cinv[0]) + (float)(gp.m[0] - (TCX * tx - 2));      /* bead in region-cell units */
+      const float gfy = (float)((pi.y - gp.lo[1]) * gp.cinv[1]) + (float)(gp.m[1] - (TCY * ty - 2)) - (float)(ly + 2);
+      const float gfz = (float)((pi.z - gp.lo[2]) * gp.cinv[2]) + (float)(gp.m[2] - (TCZ * tz - 2)) - (float)(lz + 2);
+      const float csy = (float)(1.0 / gp.cinv[1]), csz = (float)(1.0 / gp.cinv[2]), cix = (float)gp.cinv[0];
+      const float rl2p = (float)(rl2 * (1.0 + 4.0e-4));
       for (int dz = 0; dz < 5; dz++)
+      {
+         const float gz = fmaxf(dz < 2 ? (gfz + (float)(1 - dz)) * csz : dz > 2 ? ((float)(dz - 2) - gfz) * csz : 0.0f, 0.0f);
          for (int dy = 0; dy < 5; dy++)
          {
-            int rc0 = (lz + dz) * (RGX * RGY) + (ly + dy) * RGX + lx;      /* 5 consecutive cells in x are contiguous */
-            int s0 = ofs_s[rc0], s1 = ofs_s[rc0 + 5];
+            const float gy = fmaxf(dy < 2 ? (gfy + (float)(1 - dy)) * csy : dy > 2 ? ((float)(dy - 2) - gfy) * csy : 0.0f, 0.0f);
+            const float d2yz = gy * gy + gz * gz;
+            if (d2yz >= rl2p) continue;
+            const float wx = __builtin_amdgcn_sqrtf(rl2p - d2yz) * cix * 1.0001f + 1.0e-4f;
+            const int xlo = max(min((int)floorf(ux - wx), lx + 2), lx), xhi = min(max((int)floorf(ux + wx), lx + 2), lx + 4);
+            const int rowb = (lz + dz) * (RGX * RGY) + (ly + dy) * RGX;      /* consecutive cells in x are contiguous */
+            int s0 = ofs_s[rowb + xlo], s1 = ofs_s[rowb + xhi + 1];
             /* four candidates per trip: the LDS reads of a trip are independent (ILP at low occupancy) */
             for (int sj0 = s0; sj0 < s1; sj0 += 4)
             {
@@ -489,7 +542,12 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                   const float4 q = q4[u];
                   float x = fx - q.x, y = fy - q.y, z = fz - q.z;
                   float r2 = x * x + y * y + z * z;
+#if defined(TB_ABLATE) && TB_ABLATE == 3      /* tuning builds: no accept path */
+                  if (sj < s1 && sj != self && r2 < rl2_hi) cnt++;
+                  if (false)
+#else
                   if (sj < s1 && sj != self && r2 < rl2_hi)
+#endif
                   {
                      if (r2 > rl2_lo)
                      {
@@ -528,15 +586,30 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                          * distance shell in k_tile_transpose).  This path runs for
                          * every candidate of the wave (some lane always accepts), so it is kept short. */
                         unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | (__float_as_uint(r2) & 0xffff0000u);
+#if defined(TB_ABLATE) && TB_ABLATE == 1      /* tuning builds: no scratch stores */
+                        wprev += wcur;
+#elif defined(TB_ST16)                        /* tuning builds: four words per 16-byte store (tmpw is a multiple of 8) */
+                        if ((cnt & 3) == 3) { if (cnt < ta.tmpw) ((uint4 *)row2)[cnt >> 2] = make_uint4(w0_, w1_, wprev, wcur); }
+                        else if ((cnt & 3) == 0) w0_ = wcur;
+                        else if ((cnt & 3) == 1) w1_ = wcur;
+                        else wprev = wcur;
+#else
                         if (cnt & 1) { if (cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, wcur); }
                         else wprev = wcur;
+#endif
                         cnt++;
                      }
                   }
                }
             }
          }
+      }
+#if defined(TB_ST16)
+      if ((cnt & 3) && (cnt & ~3) < ta.tmpw)
+         ((uint4 *)row2)[cnt >> 2] = make_uint4(w0_, (cnt & 3) > 1 ? w1_ : 0u, (cnt & 3) > 2 ? wprev : 0u, 0u);
+#else
       if ((cnt & 1) && cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, 0u);
+#endif
       mymax = max(mymax, cnt);
       ta.nbr_cnt[a] = min(cnt, ta.tmpw);
       excl_cnt[a] = min(ecnt, maxexcl);
@@ -819,7 +892,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
        * HBM, and a dependent load in front of every record gather): region cell counts -> block scan -> a
        * slot -> cell map in LDS (aliased onto the not yet written position arrays) -> one index per thread and
        * round in registers -> all record gathers of a batch in flight -> LDS writes. */
-      constexpr int SU = 4, MAXR = 8;
+      constexpr int SU = NB_SU, MAXR = 8;      /* record gathers in flight per thread and batch; rounds of the index-free path */
       constexpr int NWV = NB_BLOCK / 64;
       if (ns <= MAXR * NB_BLOCK)
       {
@@ -874,7 +947,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          for (int u = 0; u < MAXR; u++)
          {
             const int k = (int)threadIdx.x + u * NB_BLOCK;
-            gj[u] = 0;
+            gj[u] = ts;      /* rounds past the end re-read the tile's first bead (a cache hit) and drop it */
             if (k < ns) { const int c = cellof[k]; gj[u] = gst_s[c] + (k - ofs_s[c]); }
          }
          __syncthreads();      /* the tables are dead: their bytes become staged positions */
@@ -887,7 +960,11 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
 #pragma unroll
             for (int u = 0; u < SU; u++)
             {
+#if defined(NB_ABLATE) && NB_ABLATE == 5      /* tuning builds: no record gathers (every staged bead is the tile's first bead) */
+               pp[u] = pos[ts];
+#else
                pp[u] = pos[gj[b + u]];
+#endif
                sh[u] = (!SHBIT && tshift && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
             }
 #pragma unroll
@@ -990,6 +1067,11 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          int wmax = ngl;
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+#if defined(NB_ABLATE) && NB_ABLATE == 3      /* tuning builds: staging and epilogue only */
+         wmax = 0;
+#elif defined(NB_ABLATE) && NB_ABLATE == 4    /* tuning builds: half of the list */
+         wmax = (wmax + 1) >> 1;
+#endif
          /* The list stream: one 16-byte load per lane and group, kept two groups ahead of
           * the pair loop.  Three named buffers (the loop is unrolled by three) rather
           * than a rotating one, so each wait covers exactly the oldest load; the loads
@@ -1051,15 +1133,26 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   unsigned wd = qw[(h * CH + u) >> 1];
                   if (PACKED) o[u] = ((u & 1) ? (wd >> 16) : wd) & 0xfff0u;
                   else o[u] = ((u & 1) ? (wd >> 16) : (wd & 0xffffu)) << 4;
+#if defined(NB_ABLATE) && NB_ABLATE == 2      /* tuning builds: conflict-free gathers (every lane of a 16-lane group reads the same slot) */
+                  const unsigned oc_ = (unsigned)__builtin_amdgcn_readfirstlane((int)o[u]);
+                  xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + oc_);
+                  double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(oc_ >> 1);
+#else
                   xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + o[u]);
                   double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(o[u] >> 1);
+#endif
                   double px = pxy.x, py = pxy.y;
                   x[u] = pi.x - px; y[u] = pi.y - py; z[u] = pi.z - pz;
                   r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                }
+#if defined(NB_ABLATE) && NB_ABLATE == 1      /* tuning builds: distance tests only */
+#pragma unroll
+               for (int u = 0; u < CH; u++) if (r2[u] < rc2) fxi += r2[u];
+#else
 #pragma unroll
                for (int u = 0; u < CH; u++)
                   if (r2[u] < rc2) NB_PAIR(u, qw[(h * CH + u) >> 1], u & 1);
+#endif
             }
 #undef NB_PAIR
          };
@@ -2304,7 +2397,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       bool has_mol = false;
       for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
       /* LDS image: 16 B per staged bead (+ 4 B molecule id when pairs can be excluded) + the region cell tables */
-      size_t lds = (size_t)ctx->stage_cap * (has_mol ? 20 : 16) + (2 * NRC + 16) * sizeof(int);
+      size_t lds = (size_t)ctx->stage_cap * (has_mol ? 20 : 16) + (2 * NRC + 16) * sizeof(int) + (size_t)ctx->stage_cap * sizeof(unsigned short) + 16;
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);

@@ -34,7 +34,7 @@
 #define NB_WPE 4             /* waves per SIMD the register budget is sized for (2 workgroups per CU) */
 #endif
 #ifndef NB_SU
-#define NB_SU 5              /* staging gathers in flight per thread */
+#define NB_SU 4              /* staging gathers in flight per thread and batch (divides 8) */
 #endif
 #ifndef NB_CH
 #define NB_CH 4              /* list slots gathered and tested together */
