@@ -327,7 +327,8 @@ struct TileArgs
    long long *tile_base; int *tile_width, *tile_rows, *tile_work;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt;
-   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead: entry | bf16(r^2) << 16 */
+   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead: entry | distance shell << 16 */
+   ShellCuts shc;
 };
 
 struct NbTileArgs
@@ -582,10 +583,12 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      }
                      else
                      {
-                        /* scratch word: final-format entry + r^2 as a 16-bit float (enough to pick the
-                         * distance shell in k_tile_transpose).  This path runs for
-                         * every candidate of the wave (some lane always accepts), so it is kept short. */
-                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | (__float_as_uint(r2) & 0xffff0000u);
+                        /* scratch word: final-format entry + its distance shell (k_tile_transpose lays the
+                         * row out in shell order).  This path runs for every candidate of the wave (some lane
+                         * always accepts), so it is kept short. */
+                        /* (shell boundaries steer only the ORDER of a bead's entries: single precision is plenty) */
+                        const int sh_ = min(max((int)floorf((__builtin_amdgcn_sqrtf(r2) - ta.shc.r0) * ta.shc.inv_w) + 1, 0), NSHELL - 1);
+                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | ((unsigned)sh_ << 16);
 #if defined(TB_ABLATE) && TB_ABLATE == 1      /* tuning builds: no scratch stores */
                         wprev += wcur;
 #elif defined(TB_ST16)                        /* tuning builds: four words per 16-byte store (tmpw is a multiple of 8) */
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
 #define TR_ROWS 32
 #define TR_TPR (TR_THREADS / TR_ROWS)      /* threads per row */
 #define IMG_STRIDE (TR_ROWS + 2)           /* +2 entries: slot rows land on different LDS banks */
-__global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta, ShellCuts shc)
+__global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
 {
    extern __shared__ unsigned int tr_smem[];
    const int rs = ta.tmpw | 1;                       /* odd row stride: rows start on different banks */
@@ -741,10 +744,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta, Shel
          unsigned long long c0w = 0, c1w = 0;
          for (int k = k0; k < k1; k++)
          {
-            unsigned wv = row[k];
-            float rf = __builtin_amdgcn_sqrtf(__uint_as_float(wv & 0xffff0000u));
-            int sh = min(max((int)floorf((rf - shc.r0) * shc.inv_w) + 1, 0), NSHELL - 1);
-            row[k] = (wv & 0xffffu) | ((unsigned)sh << 16);          /* the second pass reads the shell back */
+            const int sh = (int)(row[k] >> 16);          /* the shell, from k_tile_build */
             unsigned long long one = 1ull << (16 * (sh & 3));
             if (sh < 4) c0w += one; else c1w += one;
          }
@@ -2413,7 +2413,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_tot + 2;
       ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
-      ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw;
+      ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
       auto kbuild = has_mol ? k_tile_build<true> : k_tile_build<false>;
       HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
@@ -2423,7 +2423,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
          size_t lds2 = (size_t)TR_ROWS * (ctx->tmpw | 1) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
          if (lds2 > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "lists of %d entries per bead do not fit the transpose kernel's LDS", ctx->tmpw);
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-         hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta, shc);
+         hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
       }
       HIPCHK(ctx, hipGetLastError());
       unsigned long long tot[3];
