@@ -114,6 +114,23 @@ __device__ __forceinline__ bool angle_eval(const BoxArgs &box, const double4 &pI
 }
 /* bioDihedralFast (bioCharmmCovalentEnergies.c:266-351) + resTorsionSorted / resImproperSorted (...Sorted.c:577-848):
  * e_t = proper, e_i = improper energy; forces on I, J, K, L */
+/* census of the rarely taken branches of the dihedral code (tests show with it that their inputs really drive
+ * them): [0] torsion series (|sin phi| <= 1e-8), of these [1] delta ~ 0, [2] delta ~ pi, [3] any other delta;
+ * [4] improper series; [5] improper difference wrapped by 2 pi; [6] cos phi clamped to +-1.  The adds sit inside
+ * those branches: they cost nothing on the common path. */
+__device__ unsigned long long g_branch_census[8];
+extern "C" int ddcmi_debug_branch_census(unsigned long long out[8], int reset)
+{
+   if (!out) return DDCMI_EINVAL;
+   if (hipDeviceSynchronize() != hipSuccess) return DDCMI_ENODEVICE;
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_branch_census), 8 * sizeof(unsigned long long)) != hipSuccess) return DDCMI_ENODEVICE;
+   if (reset)
+   {
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_branch_census), z, sizeof(z)) != hipSuccess) return DDCMI_ENODEVICE;
+   }
+   return DDCMI_OK;
+}
 __device__ __forceinline__ bool tors_eval(const BoxArgs &box, const double4 &pI, const double4 &pJ, const double4 &pK, const double4 &pL,
                                           int f, int n, double kpar, double dpar, int excl_mask,
                                           double &e_t, double &e_i, double (&fI)[3], double (&fJ)[3], double (&fK)[3], double (&fL)[3], double (&vir)[6])
@@ -146,6 +163,7 @@ __device__ __forceinline__ bool tors_eval(const BoxArgs &box, const double4 &pI,
    double qx = my * nz - mz * ny, qy = mz * nx - mx * nz, qz = mx * ny - my * nx;
    double signnum = bx * qx + by * qy + bz * qz;
    double sign = (signnum < 0.0) ? -1.0 : 1.0;
+   if (xx > 1.0 || xx < -1.0) atomicAdd(&g_branch_census[6], 1ull);
    xx = fmax(fmin(xx, 1.0), -1.0);
    double ang = sign * acos(xx);
    double sinX = sin(ang);
@@ -164,21 +182,23 @@ __device__ __forceinline__ bool tors_eval(const BoxArgs &box, const double4 &pI,
          double X2 = ang * ang, X4 = X2 * X2, X6 = X4 * X2, X8 = X4 * X4, X10 = X8 * X2;
          double ratio = n * (1 - nX2 / 6 + nX4 / 120 - nX6 / 5040 + nX8 / 362880 - nX10 / 39916800) /
                         (1 - X2 / 6 + X4 / 120 - X6 / 5040 + X8 / 362880 - X10 / 39916800);
-         if (delta < NEAR_ZERO_ANGLE) kk = kchi * n * ratio;
-         else if (delta > NEAR_180_ANGLE) kk = -kchi * n * ratio;
-         else kk = kchi * n * ratio;
+         atomicAdd(&g_branch_census[0], 1ull);
+         if (delta < NEAR_ZERO_ANGLE) { kk = kchi * n * ratio; atomicAdd(&g_branch_census[1], 1ull); }
+         else if (delta > NEAR_180_ANGLE) { kk = -kchi * n * ratio; atomicAdd(&g_branch_census[2], 1ull); }
+         else { kk = kchi * n * ratio; atomicAdd(&g_branch_census[3], 1ull); }
       }
    }
    else
    {
       double kpsi = kpar, psi0 = dpar;
       double d = ang - psi0;
-      if (d < -M_PI) d += 2 * M_PI; else if (d > M_PI) d -= 2 * M_PI;
+      if (d < -M_PI) { d += 2 * M_PI; atomicAdd(&g_branch_census[5], 1ull); } else if (d > M_PI) { d -= 2 * M_PI; atomicAdd(&g_branch_census[5], 1ull); }
       e_i = kpsi * d * d;
       double absX = sinX < 0 ? -sinX : sinX;
       if (absX > FLOAT_EPS) kk = -2 * kpsi * d / sinX;
       else
       {
+         atomicAdd(&g_branch_census[4], 1ull);
          double i2 = ang * ang, i4 = i2 * i2, i6 = i4 * i2, i8 = i4 * i4, i10 = i8 * i2;
          kk = -2 * kpsi / (1 - i2 / 6 + i4 / 120 - i6 / 5040 + i8 / 362880 - i10 / 39916800);
       }

@@ -189,6 +189,11 @@ int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int64_t *nentr
  * enable, run, then read {launch count, total ms}.  [sync] on read */
 int ddcmi_timing_enable(ddcmi_ctx *ctx, int on);
 int ddcmi_timing_read(ddcmi_ctx *ctx, int64_t *launches, double *total_ms, int reset);
+/* census of the rarely taken branches of the dihedral code since the last reset (bioCharmmCovalentEnergiesSorted.c:649-683,
+ * 793-810): [0] torsion series (|sin phi| <= 1e-8), of these [1] delta < 1 deg, [2] delta > 179 deg, [3] any other delta;
+ * [4] improper series; [5] improper difference wrapped by 2 pi; [6] cos phi clamped.  Counted per evaluation (a term is
+ * evaluated once per atom it has).  Test aid: shows that a test's geometry really drives those branches. [sync] */
+int ddcmi_debug_branch_census(unsigned long long out[8], int reset);
 /* native stream handle (hipStream_t) for callers that time with their own events */
 void *ddcmi_stream(ddcmi_ctx *ctx);
 

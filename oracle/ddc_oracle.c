@@ -114,6 +114,9 @@ static int pair_is_pruned(const orc_params *p, const uint64_t *gid, const int *s
  * the same, the in-row order differs (the reference prepends to a linked list). */
 static long orc_builds = 0;
 long orc_nbr_build_count(void) { return orc_builds; }
+/* census of the dihedral code's rarely taken branches (tests: same slots as ddcmi_debug_branch_census) */
+static long orc_census[8];
+void orc_branch_census(long out[8], int reset) { for (int k = 0; k < 8; k++) { out[k] = orc_census[k]; if (reset) orc_census[k] = 0; } }
 orc_nbr *orc_nbr_build(const orc_params *p, int n, const double *rx, const double *ry, const double *rz,
                        const uint64_t *gid, const int *species)
 {
@@ -537,9 +540,10 @@ void orc_bonded(const orc_params *p, int n,
                double X2 = ang * ang, X4 = X2 * X2, X6 = X4 * X2, X8 = X4 * X4, X10 = X8 * X2;
                double ratio = nn * (1 - nX2 / 6 + nX4 / 120 - nX6 / 5040 + nX8 / 362880 - nX10 / 39916800) /
                               (1 - X2 / 6 + X4 / 120 - X6 / 5040 + X8 / 362880 - X10 / 39916800);
-               if (delta < NEAR_ZERO_ANGLE) kk = kchi * nn * ratio;
-               else if (delta > NEAR_180_ANGLE) kk = -kchi * nn * ratio;
-               else kk = kchi * nn * ratio;
+               orc_census[0]++;
+               if (delta < NEAR_ZERO_ANGLE) { kk = kchi * nn * ratio; orc_census[1]++; }
+               else if (delta > NEAR_180_ANGLE) { kk = -kchi * nn * ratio; orc_census[2]++; }
+               else { kk = kchi * nn * ratio; orc_census[3]++; }
             }
          }
          else
@@ -547,12 +551,13 @@ void orc_bonded(const orc_params *p, int n,
             double kpsi = p->tors_k[t], psi0 = p->tors_delta[t];
             double PI2 = 2 * M_PI, PI_1 = -1 * M_PI;
             double d = ang - psi0;
-            if (d < PI_1) d = d + PI2; else if (d > M_PI) d = d - PI2;
+            if (d < PI_1) { d = d + PI2; orc_census[5]++; } else if (d > M_PI) { d = d - PI2; orc_census[5]++; }
             eimpr += kpsi * d * d;
             double absX = sinX < 0 ? -sinX : sinX;
             if (absX > FLOAT_EPS) kk = -2 * kpsi * d / sinX;
             else
             {
+               orc_census[4]++;
                double i2 = ang * ang, i4 = i2 * i2, i6 = i4 * i2, i8 = i4 * i4, i10 = i8 * i2;
                kk = -2 * kpsi / (1 - i2 / 6 + i4 / 120 - i6 / 5040 + i8 / 362880 - i10 / 39916800);
             }

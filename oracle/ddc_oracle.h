@@ -95,6 +95,7 @@ typedef struct orc_nbr orc_nbr;   /* half neighbour list (opaque) */
 orc_nbr *orc_nbr_build(const orc_params *p, int n, const double *rx, const double *ry, const double *rz,
                        const uint64_t *gid, const int *species);
 void orc_nbr_free(orc_nbr *nb);
+void orc_branch_census(long out[8], int reset);                   /* dihedral series / wrap branches taken (process-wide; tests) */
 long orc_nbr_build_count(void);                                   /* list builds so far (process-wide; tests) */
 /* neighborCheck (neighbor.c:117-208), constant box: 1 = the list must be rebuilt (updateRate == 0 decks) */
 int orc_neighbor_check(const orc_params *p, const orc_nbr *nb, int n, const double *rx, const double *ry, const double *rz);
