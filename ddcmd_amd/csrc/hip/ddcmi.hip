@@ -2038,6 +2038,55 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    return DDCMI_OK;
 }
 
+/* new positions of the same beads, caller order -> device order; each taken at the periodic image nearest to the
+ * bead's previous position (the host integrator wraps into the box every step, the device keeps positions
+ * continuous between rebuilds so that images and lists stay valid) */
+__global__ void k_import_pos(int nloc, int pbc, double L0, double L1, double L2, const int *orig, const double *rx, const double *ry, const double *rz, double4 *pos)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= nloc) return;
+   const int o = orig[i];
+   double4 p = pos[i];
+   double x = rx[o], y = ry[o], z = rz[o];
+   if (pbc & 1) x += L0 * rint((p.x - x) / L0);
+   if (pbc & 2) y += L1 * rint((p.y - y) / L1);
+   if (pbc & 4) z += L2 * rint((p.z - z) / L2);
+   p.x = x; p.y = y; p.z = z;
+   pos[i] = p;
+}
+__global__ void k_import3(int nloc, const int *orig, const double *a, const double *b, const double *c, double *oa, double *ob, double *oc)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= nloc) return;
+   const int o = orig[i];
+   oa[i] = a[o]; ob[i] = b[o]; oc[i] = c[o];
+}
+extern "C" int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const double *ry, const double *rz, const double *vx, const double *vy, const double *vz)
+{
+   if (!ctx || !rx || !ry || !rz) return DDCMI_EINVAL;
+   if (ctx->nloc <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_upload_positions needs an uploaded state (ddcmi_upload_state)");
+   if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "ddcmi_upload_positions: caller-order arrays do not survive migration between domains");
+   (void)hipSetDevice(ctx->device);
+   const int n = ctx->nloc, nb = cdiv(n, 256);
+   hipStream_t st = ctx->stream;
+   /* staging: vx2, vy2, vz2 are free between rebuilds */
+   HIPCHK(ctx, hipMemcpyAsync(ctx->vx2.p, rx, n * sizeof(double), hipMemcpyHostToDevice, st));
+   HIPCHK(ctx, hipMemcpyAsync(ctx->vy2.p, ry, n * sizeof(double), hipMemcpyHostToDevice, st));
+   HIPCHK(ctx, hipMemcpyAsync(ctx->vz2.p, rz, n * sizeof(double), hipMemcpyHostToDevice, st));
+   hipLaunchKernelGGL(k_import_pos, dim3(nb), dim3(256), 0, st, n, ctx->pbc, ctx->h[0], ctx->h[4], ctx->h[8], ctx->orig.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->pos.p);
+   if (vx && vy && vz)
+   {
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->vx2.p, vx, n * sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->vy2.p, vy, n * sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->vz2.p, vz, n * sizeof(double), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_import3, dim3(nb), dim3(256), 0, st, n, ctx->orig.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->vx.p, ctx->vy.p, ctx->vz.p);
+   }
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   ctx->forces_valid = false; ctx->halo_fresh = false; ctx->drift_done = false;
+   return DDCMI_OK;
+}
+
 extern "C" int ddcmi_download_state(ddcmi_ctx *ctx, int mask, double *rx, double *ry, double *rz, double *vx, double *vy, double *vz,
                                     double *fx, double *fy, double *fz)
 {

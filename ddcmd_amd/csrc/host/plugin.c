@@ -130,10 +130,28 @@ static void martini_parms(POTENTIAL *potential, SIMULATE *simulate)
    rc |= ddcmi_set_clock(ctx, s->loop, s->time);
    if (rc) die("martini_parms", ddcmi_last_error(ctx));
    printf("using HIP martini parms\n");                 /* bioMartini.c:1339 prints "using gpu martini parms" */
+   MARTINIHIP_PARMS *parms = calloc(1, sizeof(MARTINIHIP_PARMS));
+   parms->ctx = ctx; parms->rmax = s->rmax; parms->simulate = simulate;
+   potential->itype = MARTINI;
    potential->use_gpu_list = 1;
+   potential->call_fsumX = 0;
+   potential->commMode = POT_TWOSIDED;
    potential->neighborTableType = NEIGHBORTABLE_GPU;
    potential->eval_potential = (void (*)(void *, void *, void *))martiniHIP;
-   potential->parms = ctx;
+   potential->getCutoffs = (RCUT_TYPE * (*)(void *, void *, int *))martiniCutoff;
+   potential->write_dynamics = NULL;
+   potential->parms = parms;
+}
+
+/* charmmCutoff (bioCharmm.c:386-414): one cutoff, rmax, first vertex of a pair local */
+RCUT_TYPE *martiniCutoff(SYSTEM *sys, void *parms_, int *n)
+{
+   (void)sys;
+   MARTINIHIP_PARMS *parms = parms_;
+   parms->rcut[0].value = parms->rmax; parms->rcut[0].mode = RCUT_LOCAL; parms->rcut[0].type = -1;
+   parms->rcut[1].value = parms->rmax; parms->rcut[1].mode = RCUT_ALL; parms->rcut[1].type = -1;
+   *n = 1;
+   return parms->rcut;
 }
 
 POTENTIAL *potential_init(void *parent, const char *name, const char *type)
@@ -147,12 +165,33 @@ POTENTIAL *potential_init(void *parent, const char *name, const char *type)
 
 /* martiniGPU1 (bioMartini.cu:146-171) / martini (bioMartini.c:1357-1390):
  * accumulate into e->eion and e->virial */
-void martiniHIP(SYSTEM *sys, void *parms, ETYPE *e)
+void martiniHIP(SYSTEM *sys, void *parms_, ETYPE *e)
 {
-   (void)sys;
-   ddcmi_ctx *ctx = parms;
+   MARTINIHIP_PARMS *parms = parms_;
+   ddcmi_ctx *ctx = parms->ctx;
+   SIMULATE *sim = parms->simulate;
+   /* gpu_integrate == 0 (bioMartini.cu:153-166): the integrator runs on the host over STATE -- positions go up
+    * before the evaluation (sendGPUState) and the forces come back, ACCUMULATED into state->f like every
+    * potential's (the POTENTIAL contract: ddcenergy.c:212 after zeroAll) */
+   const int gpu_integrate = (sim && sim->integrator) ? sim->integrator->uses_gpu : 1;
+   STATE *st = sys->state;
+   if (!gpu_integrate)
+   {
+      if (ddcmi_upload_positions(ctx, st->rx, st->ry, st->rz, st->vx, st->vy, st->vz) != DDCMI_OK) die("martiniHIP", ddcmi_last_error(ctx));
+      /* constructList on rebuild steps (ddcUpdateAll.c:64-71,136-139) */
+      if (sim->ddc->updateRate == 0 || sys->loop % sim->ddc->updateRate == 0)
+         if (ddcmi_build_list(ctx) != DDCMI_OK) die("martiniHIP", ddcmi_last_error(ctx));
+   }
    double en[DDCMI_NE], vir[6];
    if (ddcmi_eval_forces(ctx, en, vir) != DDCMI_OK) die("martiniHIP", ddcmi_last_error(ctx));
+   if (!gpu_integrate)
+   {
+      int n = st->nlocal;
+      double *f = malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+      if (ddcmi_download_state(ctx, DDCMI_FORCE, NULL, NULL, NULL, NULL, NULL, NULL, f, f + n, f + 2 * (size_t)n) != DDCMI_OK) die("martiniHIP", ddcmi_last_error(ctx));
+      for (int i = 0; i < n; i++) { st->fx[i] += f[i]; st->fy[i] += f[n + i]; st->fz[i] += f[2 * (size_t)n + i]; }
+      free(f);
+   }
    e->eion += en[DDCMI_E_TOTAL];
    e->virial.xx += vir[DDCMI_XX]; e->virial.yy += vir[DDCMI_YY]; e->virial.zz += vir[DDCMI_ZZ];
    e->virial.xy += vir[DDCMI_XY]; e->virial.xz += vir[DDCMI_XZ]; e->virial.yz += vir[DDCMI_YZ];
@@ -260,8 +299,18 @@ INTEGRATOR *integrator_init(void *parent, const char *name, const char *type)
    {
       /* NGLFCONSTRAINT = nglf + velocity constraints + the barostat of changeVolume (nglfconstraint.c:510-574) */
       if (npt_ok) nglfconstraintHIP_parms(accelerator_getAccelerator(NULL)->parms, su);
+      in->itype = npt_ok ? NGLFCONSTRAINT : (strcmp(type, "NVTGLF") == 0 ? NVTGLF : NGLF);
       in->eval_integrator = (void (*)(void *, void *, void *))nglfHIP;
       in->uses_gpu = 1;                                    /* state stays on the device between print steps (masters.c:389-403) */
+      const char *cpu = getenv("DDCMI_CPU_INTEGRATOR");
+      if (cpu && atoi(cpu) != 0 && (strcmp(type, "NGLF") == 0 || strcmp(type, "NVTGLF") == 0))
+      {
+         /* the reference's own pairing for these type strings (integrator.c:59-64): nglf() on the host, the
+          * potential on the accelerator.  The default keeps the whole step on the device. */
+         in->eval_integrator = (void (*)(void *, void *, void *))nglf;
+         in->uses_gpu = 0;
+         printf("INTEGRATOR %s on the host (nglf.c), potential on the accelerator\n", type);
+      }
    }
    else
    {
@@ -286,6 +335,56 @@ void nglfHIP(DDC *ddc, SIMULATE *simulate, void *parms)
    sys->time = simulate->time;
 }
 
+static int host_integrated(const SYSTEM *sys)
+{
+   const SIMULATE *sim = (sys->npotential > 0 && sys->potential[0]->parms) ? ((MARTINIHIP_PARMS *)sys->potential[0]->parms)->simulate : NULL;
+   return sim && sim->integrator && !sim->integrator->uses_gpu;
+}
+/* free_velocityUpdate (free.c:13-28) / berendsen_velocityUpdate (berendsen.c:64-89) / berendsen_Update (:30-62) on STATE */
+static void group_velocityUpdate(int front, int k, GROUP *g, STATE *st, double dt_half)
+{
+   const double a = dt_half / st->species[k]->mass;
+   if (g->itype == BERENDSEN && front && g->doScaling) { st->vx[k] *= g->lambda; st->vy[k] *= g->lambda; st->vz[k] *= g->lambda; }
+   st->vx[k] += a * st->fx[k]; st->vy[k] += a * st->fy[k]; st->vz[k] += a * st->fz[k];
+}
+static void group_Update_front(GROUP *g, int64_t loop, double dt_half)
+{
+   if (g->itype != BERENDSEN) return;
+   g->Tsum += g->energyInfo.temperature; g->nT += 1;
+   const double Tave = g->Tsum / g->nT, ratio = (Tave == 0) ? 0 : g->Teq / Tave;
+   g->lambda = (g->tau != 0) ? sqrt(1 + (2.0 * dt_half / g->tau) * (ratio - 1)) : sqrt(ratio);
+   g->doScaling = 0;
+   if (loop % g->interval == 0) { g->Tsum = 0; g->nT = 0; g->doScaling = 1; }
+}
+/* nglf (nglf.c:67-112): FRONT half kick, drift, backInBox_fast, ddcenergy, BACK half kick, kinetic_terms, group Update */
+void nglf(DDC *ddc, SIMULATE *simulate, void *parms)
+{
+   (void)parms;
+   const double dt = simulate->dt;
+   SYSTEM *sys = simulate->system;
+   STATE *st = sys->state;
+   const double L[3] = {sys->box->h0[0], sys->box->h0[4], sys->box->h0[8]};
+   for (int g = 0; g < sys->ngroup; g++)
+      if (sys->group[g]->itype != FREE && sys->group[g]->itype != BERENDSEN) die("nglf", "the host integrator handles FREE and BERENDSEN groups");
+   for (int k = 0; k < st->nlocal; k++) group_velocityUpdate(1, k, st->group[k], st, 0.5 * dt);
+   for (int k = 0; k < st->nlocal; k++)
+   {
+      double r[3] = {st->rx[k] + dt * st->vx[k], st->ry[k] + dt * st->vy[k], st->rz[k] + dt * st->vz[k]};
+      for (int a = 0; a < 3; a++)      /* PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
+         if (sys->box->pbc >> a & 1) { if (r[a] > 0.5 * L[a]) r[a] -= L[a]; if (r[a] < -0.5 * L[a]) r[a] += L[a]; }
+      st->rx[k] = r[0]; st->ry[k] = r[1]; st->rz[k] = r[2];
+   }
+   ddc->update = 0;
+   simulate->time += dt;
+   simulate->loop++;
+   sys->loop = simulate->loop;
+   sys->time = simulate->time;
+   if (ddcenergy(ddc, sys, 0) != 0) return;
+   for (int k = 0; k < st->nlocal; k++) group_velocityUpdate(0, k, st->group[k], st, 0.5 * dt);
+   kinetic_terms(sys, 1);
+   for (int g = 0; g < sys->ngroup; g++) group_Update_front(sys->group[g], simulate->loop, 0.5 * dt);
+}
+
 /* ddcenergy (ddcenergy.c:160-238) for the accelerated path: zero ETYPE, potentials */
 int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag)
 {
@@ -293,6 +392,13 @@ int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag)
    ETYPE *e = &sys->energyInfo;
    e->eion = 0.0;
    memset(&e->virial, 0, sizeof(e->virial));
+   if (host_integrated(sys))
+   {
+      /* zeroParticle: the reference skips it whenever an ACCELERATOR exists (ddcenergy.c:149-158) because its device
+       * potentials never write the host forces; a host integrator reads them, so they start from zero here */
+      STATE *st = sys->state;
+      memset(st->fx, 0, sizeof(double) * st->nlocal); memset(st->fy, 0, sizeof(double) * st->nlocal); memset(st->fz, 0, sizeof(double) * st->nlocal);
+   }
    for (int i = 0; i < sys->npotential; i++) sys->potential[i]->eval_potential(sys, sys->potential[i]->parms, e);
    if (e_eval_flag) { kinetic_terms(sys, 1); eval_energyInfo(sys); }
    return 0;
@@ -305,7 +411,25 @@ void kinetic_terms(SYSTEM *sys, int flag)
    ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
    ETYPE *e = &sys->energyInfo;
    double tion[6];
-   if (ddcmi_kinetic(ctx, &e->rk, tion) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
+   if (host_integrated(sys))
+   {
+      /* energy.c:48-163 over STATE: rk = sum 1/2 m v^2, tion = sum m v (x) v; per-group kinetic energy and count */
+      STATE *st = sys->state;
+      double rk = 0.0;
+      memset(tion, 0, sizeof(tion));
+      for (int g = 0; g < sys->ngroup; g++) { sys->group[g]->energyInfo.rk = 0.0; sys->group[g]->energyInfo.number = 0.0; }
+      for (int k = 0; k < st->nlocal; k++)
+      {
+         const double m = st->species[k]->mass, x = st->vx[k], y = st->vy[k], z = st->vz[k];
+         const double K = 0.5 * m * (x * x + y * y + z * z);
+         rk += K;
+         tion[DDCMI_XX] += m * x * x; tion[DDCMI_YY] += m * y * y; tion[DDCMI_ZZ] += m * z * z;
+         tion[DDCMI_XY] += m * x * y; tion[DDCMI_XZ] += m * x * z; tion[DDCMI_YZ] += m * y * z;
+         st->group[k]->energyInfo.rk += K; st->group[k]->energyInfo.number += 1.0;
+      }
+      e->rk = rk;
+   }
+   else if (ddcmi_kinetic(ctx, &e->rk, tion) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
    e->tion.xx = tion[DDCMI_XX]; e->tion.yy = tion[DDCMI_YY]; e->tion.zz = tion[DDCMI_ZZ];
    e->tion.xy = tion[DDCMI_XY]; e->tion.xz = tion[DDCMI_XZ]; e->tion.yz = tion[DDCMI_YZ];
    e->number = (double)sys->nlocal;
@@ -330,6 +454,12 @@ void eval_energyInfo(SYSTEM *sys)
    /* group branch :118-141: the temperatures BERENDSEN reads */
    ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
    double Tg[32];
+   if (host_integrated(sys))
+   {
+      for (int g = 0; g < sys->ngroup; g++)      /* energyInfo.c:139 */
+         if (sys->group[g]->energyInfo.number > 0.0) sys->group[g]->energyInfo.temperature = 2.0 * sys->group[g]->energyInfo.rk / (3.0 * sys->group[g]->energyInfo.number);
+      return;
+   }
    if (ddcmi_group_temperatures(ctx, Tg) != DDCMI_OK) die("eval_energyInfo", ddcmi_last_error(ctx));
    for (int g = 0; g < sys->ngroup && g < 32; g++) sys->group[g]->energyInfo.temperature = Tg[g];
 }
@@ -338,6 +468,7 @@ int sendHostState(SYSTEM *sys)
 {
    ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
    STATE *st = sys->state;
+   if (host_integrated(sys)) return DDCMI_OK;      /* STATE is the master copy */
    return ddcmi_download_state(ctx, DDCMI_POS | DDCMI_VEL | DDCMI_FORCE, st->rx, st->ry, st->rz, st->vx, st->vy, st->vz, st->fx, st->fy, st->fz);
 }
 
@@ -489,6 +620,17 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
    sys->npotential = 1;
    sys->potential = calloc(2, sizeof(POTENTIAL *));
    sys->potential[0] = potential_init(sim, "martini", "MARTINI");
+   {
+      /* cutoffs() (ddcenergy.c:43-55): the largest cutoff any potential reports, plus the skin */
+      double rmax = 0.0;
+      for (int i = 0; i < sys->npotential; i++)
+      {
+         int nc = 0;
+         RCUT_TYPE *rc = sys->potential[i]->getCutoffs(sys, sys->potential[i]->parms, &nc);
+         for (int k = 0; k < nc; k++) if (rc[k].value > rmax) rmax = rc[k].value;
+      }
+      ddc->rcut = rmax + s->deltaR;
+   }
    sim->integrator = integrator_init(sim, "nglf", s->integrator_type);
    /* sendGPUState + sendForceVelocityToGPU (masters.c:389-393) */
    ddcmi_ctx *ctx = sim->accelerator->parms;
@@ -643,7 +785,7 @@ void simulate_free(SIMULATE *sim)
       if (st) { free(st->fx); free(st->fy); free(st->fz); free(st->q); free(st->species); free(st->group); free(st); }
       for (int i = 0; i < sys->nspecies; i++) { free(sys->species[i]->name); free(sys->species[i]); }
       for (int g = 0; g < sys->ngroup; g++) { free(sys->group[g]->name); free(sys->group[g]); }
-      if (sys->potential) { free(sys->potential[0]->name); free(sys->potential[0]->type); free(sys->potential[0]); free(sys->potential); }
+      if (sys->potential) { free(sys->potential[0]->parms); free(sys->potential[0]->name); free(sys->potential[0]->type); free(sys->potential[0]); free(sys->potential); }
       free(sys->species); free(sys->group); free(sys->box); free(sys->name); free(sys);
    }
    if (sim->integrator) { free(sim->integrator->name); free(sim->integrator->type); free(sim->integrator); }

@@ -37,7 +37,9 @@ typedef struct etype_st
 
 typedef struct species_st { char *name; int index; double mass, charge; } SPECIES;
 enum GROUP_CLASS { FREE, BERENDSEN, LANGEVIN_GROUP, OTHER_GROUP };
-typedef struct group_st { char *name; int index; int itype; double Teq, tau; int interval; ETYPE energyInfo; } GROUP;
+typedef struct group_st { char *name; int index; int itype; double Teq, tau; int interval; ETYPE energyInfo;
+                          double Tsum, lambda; int nT, doScaling;      /* BERENDSEN_PARMS' running state (berendsen.c:30-62), host integrator */
+} GROUP;
 
 typedef struct state_st
 {
@@ -53,31 +55,76 @@ typedef struct state_st
 
 typedef struct box_st { double h0[9]; int pbc; double volume; } BOX_STRUCT;
 
-enum ACCELERATOR_CLASS { GPU_CUDA = 1, GPU_HIP = 2 };
+/* The three plugin structs below have EVERY member of the reference's declarations, in the reference's order
+ * (potential.h:42-58, integrator.h:5-17, accelerator.h:22-31), so that the glue of INTEGRATION.md compiles
+ * against ddcMD's own headers unchanged and objects can be handed across; tests/abi/layout_check.c compares
+ * offsets and sizes with a transcription of the reference's declarations.  The enums keep the reference's
+ * enumerators and values (new ones are appended). */
+enum ACCELERATOR_CLASS { GPU_CUDA, GPU_HIP };                /* accelerator.h:11; GPU_HIP: type=HIP */
 typedef struct accelerator_st
 {
-   char *name, *type;
+   char *name;
+   char *objclass;
+   char *value;
+   char *type;                          /* model */
+   void *parent;
    enum ACCELERATOR_CLASS itype;
-   void *parms;                         /* ddcmi_ctx* */
+   void *parms;                         /* ddcmi_ctx* (GPUCUDAPARMS* in the reference's CUDA build) */
 } ACCELERATOR;
 
+/* neighbor.h:42-50 */
+enum RCUT_ENUMS { RCUT_NONE = 0, RCUT_LOCAL = 1, RCUT_REMOTE = 2, RCUT_ALL = 3 };
 enum NEIGHBORTABLETYPE { NEIGHBORTABLE_NONE = 0, NEIGHBORTABLE_SKINNY = 1, NEIGHBORTABLE_FAT = 2, NEIGHBORTABLE_GPU = 4 };
+typedef struct rcut_str
+{
+   double value;
+   enum RCUT_ENUMS mode;
+   int type;
+} RCUT_TYPE;
+
+/* potential.h:7-31 */
+enum POTENTIAL_CLASS { NO_POTENTIAL = -1, ZEROPOTENTIAL, MGPT, EAM, EAM1PASS, EAM2PASS, EAM_OPT, EAM_ONEPASS, PAIR, CHARMM, MARTINI, RESTRAINT, EWALD,
+                       PLASMA, ORDERSH, ONEBODY, REFLECT, PAIRENERGY, MEAM, MIRRORSYM, LOCALYUKAWA, HYCOP, FMM, GPU_PAIR };
+enum POT_COMM_MODE { POT_ONESIDED, POT_TWOSIDED };
 typedef struct potential_st
 {
-   char *name, *type;
+   char *name;                          /* potential name */
+   char *objclass;
+   char *value;
+   char *type;                          /* model */
    void *parent;
+   enum POTENTIAL_CLASS itype;          /* integer label for type */
    void (*eval_potential)(void *sys, void *parms, void *e);
+   void (*write_dynamics)(void *potential, FILE *file);
+   RCUT_TYPE *(*getCutoffs)(void *sys, void *parms, int *nCutoffs);
    enum NEIGHBORTABLETYPE neighborTableType;
+   int call_fsumX;
    int use_gpu_list;
-   void *parms;
+   enum POT_COMM_MODE commMode;
+   void *parms;                         /* MARTINIHIP_PARMS* */
 } POTENTIAL;
+/* what POTENTIAL.parms points at for type=MARTINI on this path (CHARMMPOT_PARMS in the reference) */
+typedef struct martinihip_parms_st
+{
+   ddcmi_ctx *ctx;
+   double rmax;                         /* "cutoff" key (bioMartini.c:876-879) */
+   RCUT_TYPE rcut[2];                   /* charmmCutoff's answer (bioCharmm.c:386-414) */
+   void *simulate;                      /* SIMULATE*: is the integrator on the device (martiniGPU1, bioMartini.cu:146-171)? */
+} MARTINIHIP_PARMS;
 
+/* integrator.h:4 */
+enum INTEGRATOR_CLASS { NGLF, NGLFNEW, NGLFNK, NGLFRATTLE, NGLFCONSTRAINT, PNGLF, NGLFTEST, NVEGLF, NVEGLF_SIMPLE, NVTGLF, NPTGLF, STATIC, NEXTFILE, HYCOPINTEGRATOR };
 typedef struct integrator_st
 {
-   char *name, *type;
+   char *name;
+   char *objclass;
+   char *value;
+   char *type;
    void *parent;
+   enum INTEGRATOR_CLASS itype;
    int uses_gpu;
    void (*eval_integrator)(void *ddc, void *simulate, void *parms);
+   void (*writedynamic)(struct integrator_st *integrator, FILE *file);
    void *parms;
 } INTEGRATOR;
 
@@ -122,9 +169,13 @@ ACCELERATOR *accelerator_getAccelerator(ACCELERATOR *a);
 /* potential.c:85-300 (type=MARTINI only) and bioMartini.c:1210-1353 */
 POTENTIAL *potential_init(void *parent, const char *name, const char *type);
 void martiniHIP(SYSTEM *sys, void *parms, ETYPE *e);
+RCUT_TYPE *martiniCutoff(SYSTEM *sys, void *parms, int *n);      /* charmmCutoff, bioCharmm.c:386-414 */
 /* integrator.c:37-167 (NGLF, NGLFGPU, NGLFHIP) and nglf.c:67-112 */
 INTEGRATOR *integrator_init(void *parent, const char *name, const char *type);
 void nglfHIP(DDC *ddc, SIMULATE *simulate, void *parms);
+/* nglf (nglf.c:67-112) on the HOST over STATE, potential on the accelerator: INTEGRATOR.uses_gpu = 0, martiniHIP copies
+ * positions up and forces back every step.  Selected for type NGLF / NVTGLF when DDCMI_CPU_INTEGRATOR=1 */
+void nglf(DDC *ddc, SIMULATE *simulate, void *parms);
 /* ddcenergy.c:160-238, energy.c:48-163, energyInfo.c:75-148 */
 int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag);
 void kinetic_terms(SYSTEM *sys, int flag);

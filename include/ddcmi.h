@@ -143,6 +143,12 @@ int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal,
                        const double *rx, const double *ry, const double *rz,
                        const double *vx, const double *vy, const double *vz,
                        const uint64_t *gid, const int *species, const int *group);
+/* sendGPUState between list rebuilds (gpuMemUtils.cu; martiniGPU1 with a CPU integrator, bioMartini.cu:157): new
+ * positions (and velocities, if not NULL) of the SAME particles in caller order; the neighbour list stays valid.
+ * A position that was wrapped into the box on the host is taken at its periodic image nearest to where the bead
+ * was (the device keeps positions continuous between rebuilds). */
+int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const double *ry, const double *rz,
+                           const double *vx, const double *vy, const double *vz);
 /* sendHostState / sendForceVelocityToHost / sendPosnToHost: any pointer may be
  * NULL; positions come back wrapped into the box like backInBox_fast
  * (nglf.c:90). [sync] */

@@ -58,3 +58,25 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", ".inl")) and "build" not in dirpath:
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "ddc_oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_plugin_structs_are_layout_compatible_with_the_reference(built, tmp_path):
+    """POTENTIAL / INTEGRATOR / ACCELERATOR (+ RCUT_TYPE and the enumerators the glue tests) of host/plugin.h have the
+    offsets, sizes and values of the reference's declarations (potential.h:42-58, integrator.h:5-17, accelerator.h:22-31,
+    neighbor.h:42-50; transcribed in tests/abi/ref_structs.c)"""
+    import subprocess
+    abi = os.path.join(ROOT, "tests", "abi")
+    outs = []
+    for src, inc in (("ref_structs.c", []), ("our_structs.c", ["-I" + os.path.join(ROOT, "ddcmd_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "include")])):
+        exe = str(tmp_path / src.replace(".c", ""))
+        subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-I" + abi] + inc + ["-o", exe, os.path.join(abi, src)])
+        outs.append(subprocess.check_output([exe], text=True).splitlines())
+    ref, ours = outs
+    assert len(ref) > 40 and ref == ours, [(a, b) for a, b in zip(ref, ours) if a != b]
+
+
+def test_potential_object_is_complete(built):
+    """potential_init fills the members ddcMD's drivers read: itype, getCutoffs (charmmCutoff's answer), commMode"""
+    text = open(os.path.join(ROOT, "ddcmd_amd", "csrc", "host", "plugin.c")).read()
+    for needle in ("potential->getCutoffs =", "potential->itype = MARTINI", "RCUT_LOCAL", "in->itype ="):
+        assert needle in text, needle

@@ -229,3 +229,37 @@ def test_ddcmi_md_accepts_the_gpu_integrator_names(tmp_path):
         assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1000:]
         out.append(open(data).read())
     assert out[0] == out[1] == out[2]
+
+
+def test_ddcmi_md_host_integrator_matches_device_integrator(tmp_path):
+    """DDCMI_CPU_INTEGRATOR=1: NGLF / NVTGLF run as the reference pairs them -- nglf() on the host over STATE
+    (INTEGRATOR.uses_gpu = 0), martiniHIP copying positions up and accumulating the forces into state->f* every step
+    (martiniGPU1's contract, bioMartini.cu:146-171).  Same data file as the all-device run, and as the oracle."""
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck", "object_nvt.data")
+    restart = os.path.join(ROOT, "tests", "golden", "lipid_deck", "relaxed", "restart")
+    x = "simulate SIMULATE { maxloop = 30; printrate = 10; }"
+    rows = {}
+    for mode in ("device", "host"):
+        env = dict(os.environ)
+        env.pop("DDCMI_CPU_INTEGRATOR", None)
+        if mode == "host":
+            env["DDCMI_CPU_INTEGRATOR"] = "1"
+        data = str(tmp_path / ("data_" + mode))
+        out = subprocess.run([EXE, "-o", deck, "-r", restart, "-d", data, "-x", x], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert ("on the host (nglf.c)" in out.stdout) == (mode == "host")
+        lines = [l for l in open(data).read().splitlines() if l.strip() and not l.startswith("#")]
+        rows[mode] = np.array([[float(v) for v in l.split()] for l in lines])
+    assert rows["host"].shape == rows["device"].shape and rows["host"].shape[0] >= 3 and rows["host"].shape[1] == 11
+    # Etotal, Ekin, Epot, Temp, Press columns: the two integrators take the same trajectory
+    assert np.abs(rows["host"][:, 2:7] - rows["device"][:, 2:7]).max() < 1e-8 * np.abs(rows["device"][:, 2:7]).max()
+    s = load_deck(deck, restart_file=restart)
+    o = pyoracle.Oracle(s)
+    e, vir = o.forces()
+    o.group_temperature()
+    cE = units_convert(1, None, "kJ/mol")
+    for k in range(1, rows["host"].shape[0]):
+        e, vir, rk, tion = o.step(10)
+        o.group_temperature()
+        assert abs(rows["host"][k, 4] - cE * e["total"] / s.natoms) < 1e-6 * abs(rows["host"][k, 4])
+        assert abs(rows["host"][k, 3] - cE * rk / s.natoms) < 1e-6 * abs(rows["host"][k, 3])
