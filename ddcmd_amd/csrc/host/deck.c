@@ -36,6 +36,27 @@ static char *get_string(const OBJECT *o, const char *key, const char *dflt)
    object_get(o, key, &s, STRING, 1, dflt);
    return s;
 }
+/* CRC-32 (IEEE 802.3, reflected 0xEDB88320, initial value and final xor 0xffffffff): the algorithm of the reference's
+ * checksum_crc32 / checksum_crc32_table (crc32.c:46-84; its own check string "123456789" gives 0xcbf43926) */
+uint32_t ddcmi_crc32(const unsigned char *p, size_t n)
+{
+   static uint32_t table[256];
+   static int have = 0;
+   if (!have)
+   {
+      for (uint32_t i = 0; i < 256; i++)
+      {
+         uint32_t c = i;
+         for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+         table[i] = c;
+      }
+      have = 1;
+   }
+   uint32_t c = 0xFFFFFFFFu;
+   for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+   return c ^ 0xFFFFFFFFu;
+}
+
 static int find_name(char **names, int n, const char *name)
 {
    for (int i = 0; i < n; i++) if (strcmp(names[i], name) == 0) return i;
@@ -258,6 +279,10 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
     * (collection_write.c:57-186) lead with a checksum column and may append per-particle
     * random/group state after vz, which this path does not use. */
    int col_id = 0, col_type = 2, col_group = 3, col_r = 4, col_v = 7;
+   /* record checksums (collection_read.c:274-286 verifies them on read): header checksum=CRC32 + a leading
+    * "checksum" column of 8 hex digits over the rest of the fixed-length record; nrecord = records in all files */
+   int col_crc = -1, crc_on = 0, lrec = 0;
+   long nrecord_total = -1;
    for (int f = 0; f < nfiles; f++)
    {
       char fname[4096];
@@ -266,6 +291,7 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
       if (!fp) { snprintf(err, errlen, "cannot open atoms file %s", fname); return -1; }
       fseek(fp, 0, SEEK_END); long len = ftell(fp); fseek(fp, 0, SEEK_SET);
       char *buf = malloc(len + 1);
+      if (!buf) { fclose(fp); snprintf(err, errlen, "%s: out of memory reading %ld bytes", fname, len); return -1; }
       if (fread(buf, 1, len, fp) != (size_t)len) { fclose(fp); free(buf); snprintf(err, errlen, "short read on %s", fname); return -1; }
       buf[len] = 0;
       fclose(fp);
@@ -287,12 +313,20 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
          object_get(h, "nfiles", &nf, INT, 1, "1");
          nfiles = nf;
          object_get(h, "nrecord", &nrecord_here, INT, 1, "-1");
+         nrecord_total = nrecord_here;
+         object_get(h, "lrec", &lrec, INT, 1, "0");
+         {
+            char *ck = get_string(h, "checksum", "NONE");
+            crc_on = strcmp(ck, "CRC32") == 0;
+            free(ck);
+         }
          if (object_testforkeyword(h, "field_names"))
          {
             char **names = NULL;
             int nn = object_getv(h, "field_names", (void *)&names, STRING, IGNORE_IF_NOT_FOUND);
             for (int k = 0; k < nn; k++)
             {
+               if (strcmp(names[k], "checksum") == 0) col_crc = k;
                if (strcmp(names[k], "id") == 0 || strcmp(names[k], "label") == 0) col_id = k;
                else if (strcmp(names[k], "type") == 0) col_type = k;
                else if (strcmp(names[k], "group") == 0) col_group = k;
@@ -313,6 +347,15 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
          while (*line && isspace((unsigned char)*line)) line++;
          if (*line)
          {
+            if (crc_on && col_crc == 0 && lrec > 8 && eol && (long)(eol - p) + 1 == lrec)
+            {
+               /* the record as written: 8 hex digits, then lrec - 8 bytes up to and including the newline */
+               *eol = '\n';
+               unsigned long want = strtoul((char[]){p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], 0}, NULL, 16);
+               unsigned long have = ddcmi_crc32((const unsigned char *)p + 8, (size_t)lrec - 8);
+               *eol = 0;
+               if (want != have) { snprintf(err, errlen, "%s: record %d fails its CRC32 (file says %08lx, bytes give %08lx): truncated or corrupted snapshot", fname, n, want, have); free(buf); return -1; }
+            }
             if (n == cap)
             {
                cap = cap ? 2 * cap : 8192;
@@ -353,6 +396,8 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
       }
       free(buf);
    }
+   if (nrecord_total >= 0 && n != nrecord_total)
+   { snprintf(err, errlen, "%s: header announces nrecord=%ld but %d records were read: truncated snapshot?", basepath, nrecord_total, n); return -1; }
    s->natoms = n;
    return 0;
 }

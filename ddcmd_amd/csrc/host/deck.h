@@ -9,6 +9,7 @@
  */
 #ifndef DDCMI_DECK_H
 #define DDCMI_DECK_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -103,6 +104,9 @@ ddcmi_setup *ddcmi_deck_load(const char *object_file, const char *restart_file, 
 ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_file, const char *extra_objects, char *err, int errlen);
 void ddcmi_setup_free(ddcmi_setup *s);
 int ddcmi_setup_sizeof(void);
+
+/* CRC-32 of the record checksums (crc32.c:46-84 of the reference: standard IEEE CRC-32) */
+uint32_t ddcmi_crc32(const unsigned char *p, size_t n);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 /* plugin.c -- see plugin.h: ddcMD's plugin surface for the Martini path, in C, on
  * top of the C-ABI.  Reference lines are cited per function. */
 #include "plugin.h"
+#include <errno.h>
 #include "object.h"
 #include "units.h"
 #include <stdlib.h>
@@ -474,28 +475,6 @@ int sendHostState(SYSTEM *sys)
 
 /* ------------------------------------------------------------------------- */
 /* restart writer */
-static uint32_t crc32_ieee(const unsigned char *p, size_t n)
-{
-   /* CRC-32 (IEEE 802.3, reflected 0xEDB88320) -- what pio's "CRC32" names; the util
-    * library with checksum_crc32_table is not in the reference tree, so this is the
-    * published algorithm, unverified against a ddcMD-written file */
-   static uint32_t table[256];
-   static int have = 0;
-   if (!have)
-   {
-      for (uint32_t i = 0; i < 256; i++)
-      {
-         uint32_t c = i;
-         for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-         table[i] = c;
-      }
-      have = 1;
-   }
-   uint32_t c = 0xFFFFFFFFu;
-   for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
-   return c ^ 0xFFFFFFFFu;
-}
-
 int writeRestart(SIMULATE *simulate, const char *dir, int restartLink)
 {
    SYSTEM *sys = simulate->system;
@@ -503,10 +482,13 @@ int writeRestart(SIMULATE *simulate, const char *dir, int restartLink)
    if (sendHostState(sys) != DDCMI_OK) return -1;
    if (dir) snprintf(simulate->snapshotdir, sizeof(simulate->snapshotdir), "%s", dir);
    else snprintf(simulate->snapshotdir, sizeof(simulate->snapshotdir), "snapshot.%012" PRId64, simulate->loop);    /* loopFormat, io.c:128-129 */
-   mkdir(simulate->snapshotdir, 0777);
-   char path[1024];
+   if (mkdir(simulate->snapshotdir, 0777) != 0 && errno != EEXIST) return -1;
+   /* the files appear under their final names only once they are complete: a crash while writing leaves the previous
+    * snapshot and the previous ./restart intact */
+   char path[1024], tmppath[1100];
    snprintf(path, sizeof(path), "%s/atoms#000000", simulate->snapshotdir);
-   FILE *f = fopen(path, "w");
+   snprintf(tmppath, sizeof(tmppath), "%s.tmp", path);
+   FILE *f = fopen(tmppath, "w");
    if (!f) return -1;
    const double cLen = units_convert(1.0, NULL, "l"), cVel = cLen / units_convert(1.0, NULL, "t");
    const char *fmt = "%08x %12.12" PRIu64 " %s %s %s %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e";
@@ -549,13 +531,15 @@ int writeRestart(SIMULATE *simulate, const char *dir, int restartLink)
       for (int l = len; l < lrec; l++) line[l] = ' ';
       line[lrec - 1] = '\n';
       char tmp[16];
-      snprintf(tmp, sizeof(tmp), "%08x", crc32_ieee((const unsigned char *)line + 8, (size_t)lrec - 8));
+      snprintf(tmp, sizeof(tmp), "%08x", ddcmi_crc32((const unsigned char *)line + 8, (size_t)lrec - 8));
       memcpy(line, tmp, 8);
       if (fwrite(line, 1, (size_t)lrec, f) != (size_t)lrec) { fclose(f); return -1; }
    }
    if (fclose(f) != 0) return -1;
+   if (rename(tmppath, path) != 0) return -1;
    snprintf(path, sizeof(path), "%s/restart", simulate->snapshotdir);
-   f = fopen(path, "w");
+   snprintf(tmppath, sizeof(tmppath), "%s.tmp", path);
+   f = fopen(tmppath, "w");
    if (!f) return -1;
    fprintf(f, "%s SIMULATE { run_id=0x%08x; loop=%" PRId64 "; time=%f fs;}\n", simulate->name, 0u, simulate->loop, units_convert(simulate->time, NULL, "t"));
    /* box_write, box.c:91-108 */
@@ -563,10 +547,15 @@ int writeRestart(SIMULATE *simulate, const char *dir, int restartLink)
            h[0] * cLen, h[1] * cLen, h[2] * cLen, h[3] * cLen, h[4] * cLen, h[5] * cLen, h[6] * cLen, h[7] * cLen, h[8] * cLen);
    fprintf(f, "collection COLLECTION { size=%" PRIu64 "; files=%s/atoms#;}\n", (uint64_t)sys->nglobal, simulate->snapshotdir);
    if (fclose(f) != 0) return -1;
+   if (rename(tmppath, path) != 0) return -1;
    if (restartLink)
    {
-      unlink("restart");
-      if (symlink(path, "restart") != 0) return -1;
+      /* a new link under a temporary name, renamed over ./restart: there is a valid restart at every instant */
+      char lnk[64];
+      snprintf(lnk, sizeof(lnk), "restart.tmp.%d", (int)getpid());
+      unlink(lnk);
+      if (symlink(path, lnk) != 0) return -1;
+      if (rename(lnk, "restart") != 0) { unlink(lnk); return -1; }
    }
    return 0;
 }
@@ -747,9 +736,25 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
          int64_t nextCk = (simulate->loop / simulate->checkpointrate + 1) * simulate->checkpointrate;      /* masters.c:275-276 */
          if (nextCk < endLoop) endLoop = nextCk;
       }
+      if (simulate->snapshotrate > 0)
+      {
+         int64_t nextSn = (simulate->loop / simulate->snapshotrate + 1) * simulate->snapshotrate;          /* masters.c:275 */
+         if (nextSn < endLoop) endLoop = nextSn;
+      }
       if (endLoop > simulate->maxloop) endLoop = simulate->maxloop;
-      while (simulate->loop < endLoop)
-         simulate->integrator->eval_integrator(simulate->ddc, simulate, simulate->integrator->parms);
+      if (simulate->integrator->eval_integrator == (void (*)(void *, void *, void *))nglfHIP)
+      {
+         /* the device integrator takes the whole batch in one call: inside it the BACK kick of a step and the FRONT
+          * kick + drift of the next run as one pass (the path bench.py measures) */
+         if (ddcmi_step_nglf(ctx, simulate->dt, (int)(endLoop - simulate->loop)) != DDCMI_OK) die("nglfHIP", ddcmi_last_error(ctx));
+         simulate->ddc->update = 0;
+         for (int64_t k = simulate->loop; k < endLoop; k++) simulate->time += simulate->dt;      /* the sum nglf forms step by step */
+         simulate->loop = endLoop;
+         sys->loop = simulate->loop; sys->time = simulate->time;
+      }
+      else
+         while (simulate->loop < endLoop)
+            simulate->integrator->eval_integrator(simulate->ddc, simulate, simulate->integrator->parms);
       /* uses_gpu: sendForceEnergyToHost (masters.c:448-453), then kinetic_terms + eval_energyInfo (:454-455) */
       double en[DDCMI_NE], vir[6], rk, tion[6];
       if (ddcmi_get_energies(ctx, en, vir, &rk, tion) != DDCMI_OK) die("simulateMaster", ddcmi_last_error(ctx));
@@ -766,7 +771,9 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
       }
       if (simulate->loop % simulate->printrate == 0) printinfo(simulate, e, 0);
       if (simulate->checkpointrate > 0 && simulate->loop % simulate->checkpointrate == 0)      /* masters.c:318-322 */
-         if (writeRestart(simulate, NULL, 1) != 0) die("simulateMaster", "writeRestart failed");
+      { if (writeRestart(simulate, NULL, 1) != 0) die("simulateMaster", "writeRestart failed"); }
+      else if (simulate->snapshotrate > 0 && simulate->loop % simulate->snapshotrate == 0)     /* doSnapshot, masters.c:340-352: the particle files, no ./restart */
+      { if (writeRestart(simulate, NULL, 0) != 0) die("simulateMaster", "snapshot write failed"); }
    }
    sendHostState(sys);
    if (simulate->datafile) fclose(simulate->datafile);

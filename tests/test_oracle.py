@@ -252,11 +252,15 @@ def test_atoms_reader_follows_field_names(tmp_path):
                 "field_units=1 1 1 1 1 Ang Ang Ang Ang/fs Ang/fs Ang/fs;\n"
                 "h=%f 0 0\n  0 %f 0\n  0 0 %f Ang;\nrandom = NONE;\nrandomFieldSize = 0;\ngroups = group;\ntypes = ATOM;\n}\n\n"
                 % (s0.natoms, s0.h[0] * A, s0.h[4] * A, s0.h[8] * A))
+        import ctypes
+        lib = ddcmd_amd.load_library()
+        lib.ddcmi_crc32.restype = ctypes.c_uint32
+        lib.ddcmi_crc32.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         for i in range(s0.natoms):
-            rec = "%08x %12.12d ATOM %s group %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e" % (
-                0xdeadbeef, int(s0.gid[i]), s0.species_name[int(s0.species[i])], s0.rx[i] * A, s0.ry[i] * A, s0.rz[i] * A,
-                s0.vx[i] * A, s0.vy[i] * A, s0.vz[i] * A)
-            f.write(rec.ljust(231) + "\n")
+            body = (" %12.12d ATOM %s group %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e" % (
+                int(s0.gid[i]), s0.species_name[int(s0.species[i])], s0.rx[i] * A, s0.ry[i] * A, s0.rz[i] * A,
+                s0.vx[i] * A, s0.vy[i] * A, s0.vz[i] * A)).ljust(223) + "\n"
+            f.write("%08x" % lib.ddcmi_crc32(body.encode(), len(body)) + body)      # the reader verifies the record checksums
     with open(tmp_path / "restart", "w") as f:
         f.write("simulate SIMULATE { run_id=0x0; loop=40; time=400.000000 fs;}\nbox BOX {\n h  = %.14e 0 0\n 0 %.14e 0\n 0 0 %.14e;\n}\n"
                 "collection COLLECTION { size=%d; files=snapshot.000000000040/atoms#;}\n" % (s0.h[0] * A, s0.h[4] * A, s0.h[8] * A, s0.natoms))
@@ -379,3 +383,52 @@ def test_molecule_lists_of_the_lipid_deck():
     for m in (0, 57, 127):          # every listed molecule is one gid >> 32 group, complete
         g = np.asarray(s.gid)[atoms[off[m]:off[m + 1]]] >> np.uint64(32)
         assert np.all(g == g[0]) and int(np.sum((np.asarray(s.gid) >> np.uint64(32)) == g[0])) == sizes[m]
+
+
+def test_crc32_known_answer_and_corrupted_snapshots(tmp_path):
+    """the record checksum is the reference's checksum_crc32 (crc32.c:46-84): its own check string "123456789" gives
+    0xcbf43926.  A snapshot with a flipped byte, or fewer records than its header announces, is refused
+    (collection_read.c:274-286 verifies on read)"""
+    import ctypes
+    lib = ddcmd_amd.load_library()
+    lib.ddcmi_crc32.restype = ctypes.c_uint32
+    lib.ddcmi_crc32.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    assert lib.ddcmi_crc32(b"123456789", 9) == 0xCBF43926
+    assert lib.ddcmi_crc32(b"", 0) == 0
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s0 = load_deck(os.path.join(deck, "object.data"))
+    A = units_convert(1.0, None, "Angstrom")
+    lrec = 232
+
+    def write(snapdir, nrecord_header, flip=None, drop=0):
+        os.makedirs(snapdir, exist_ok=True)
+        with open(os.path.join(snapdir, "atoms#000000"), "wb") as f:
+            f.write(("particle FILEHEADER {type=MULTILINE; datatype=FIXRECORDASCII; checksum=CRC32;\nloop=0; time=0.000000 fs;\n"
+                     "nfiles=1; nrecord=%d; lrec=%d; nfields=11; endian_key=875770417;\n"
+                     "field_names=checksum id class type group rx ry rz vx vy vz;\nfield_types=u u s s s f f f f f f;\n"
+                     "h=%f 0 0\n  0 %f 0\n  0 0 %f Ang;\ngroups = group;\ntypes = ATOM;\n}\n\n"
+                     % (nrecord_header, lrec, s0.h[0] * A, s0.h[4] * A, s0.h[8] * A)).encode())
+            for i in range(s0.natoms - drop):
+                body = (" %12.12d ATOM %s group %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e" % (
+                    int(s0.gid[i]), s0.species_name[int(s0.species[i])], s0.rx[i] * A, s0.ry[i] * A, s0.rz[i] * A,
+                    s0.vx[i] * A, s0.vy[i] * A, s0.vz[i] * A)).ljust(lrec - 9).encode() + b"\n"
+                crc = lib.ddcmi_crc32(body, len(body))
+                rec = bytearray(("%08x" % crc).encode() + body)
+                if flip is not None and i == flip:
+                    rec[60] = ord("7") if rec[60] != ord("7") else ord("3")
+                f.write(bytes(rec))
+        with open(os.path.join(os.path.dirname(snapdir), "restart"), "w") as f:
+            f.write("simulate SIMULATE { run_id=0x0; loop=0; time=0.000000 fs;}\nbox BOX {\n h  = %.14e 0 0\n 0 %.14e 0\n 0 0 %.14e;\n}\n"
+                    "collection COLLECTION { size=%d; files=%s/atoms#;}\n" % (s0.h[0] * A, s0.h[4] * A, s0.h[8] * A, s0.natoms, snapdir))
+        return os.path.join(os.path.dirname(snapdir), "restart")
+    good = write(str(tmp_path / "a" / "snap"), s0.natoms)
+    s = load_deck(os.path.join(deck, "object.data"), restart_file=good)
+    assert s.natoms == s0.natoms and np.abs(s.rx - s0.rx).max() < 1e-10
+    bad = write(str(tmp_path / "b" / "snap"), s0.natoms, flip=17)
+    with pytest.raises(Exception) as ei:
+        load_deck(os.path.join(deck, "object.data"), restart_file=bad)
+    assert "CRC32" in str(ei.value)
+    short = write(str(tmp_path / "c" / "snap"), s0.natoms, drop=5)
+    with pytest.raises(Exception) as ei:
+        load_deck(os.path.join(deck, "object.data"), restart_file=short)
+    assert "nrecord" in str(ei.value)
