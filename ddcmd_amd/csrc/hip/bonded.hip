@@ -686,7 +686,8 @@ static GatherRows gather_rows(const ddcmi_ctx *ctx)
 int ddcmi_bonded_localize(ddcmi_ctx *ctx)
 {
    const bool terms = ctx->bonded_gid && ctx->inc_nrow > 0;
-   if (!terms && ctx->nrest == 0) return DDCMI_OK;      /* water without restraints: nothing to locate, no gid table */
+   const bool groups = (ctx->cons_gid && ctx->ncgroup > 0) || (ctx->mol_gid && ctx->nmol_multi > 0);
+   if (!terms && ctx->nrest == 0 && !groups) return DDCMI_OK;      /* water without restraints: nothing to locate, no gid table */
    hipStream_t st = ctx->stream;
    const int nall = ctx->nloc + ctx->nhalo;
    unsigned cap = 1024;
@@ -700,6 +701,7 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
       hipLaunchKernelGGL(k_gid_insert, dim3(cdiv(nall, 256)), dim3(256), 0, st, nall, ctx->gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p);
    if (ctx->nrest > 0)
       hipLaunchKernelGGL(k_rest_locate, dim3(cdiv(ctx->nrest, 256)), dim3(256), 0, st, ctx->nrest, ctx->rest_gid.p, ctx->nloc, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->rest_slot.p);
+   if (groups) { int rcg = ddcmi_groups_localize(ctx); if (rcg) return rcg; }
    if (!terms) { HIPCHK(ctx, hipStreamSynchronize(st)); return DDCMI_OK; }
    ENSURE(ctx, ctx->slot_of_atom, (size_t)ctx->natom_g + 1);
    hipLaunchKernelGGL(k_atom_slots, dim3(cdiv(ctx->natom_g, 256)), dim3(256), 0, st, ctx->natom_g, ctx->atom_gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->slot_of_atom.p);
@@ -756,22 +758,32 @@ template <int LOC>
 __global__ __launch_bounds__(CONS_T) void k_constrain(int ngroups, const int *__restrict__ atom_off, const int *__restrict__ atoms, const int *__restrict__ pair_off,
                                                       const unsigned char *__restrict__ pa, const unsigned char *__restrict__ pb, const double *__restrict__ dist,
                                                       const int *__restrict__ slot, BoxArgs box, const double4 *__restrict__ pos, const int *__restrict__ species,
-                                                      const double *__restrict__ invmass, double *vx, double *vy, double *vz, double dt, int maxA, int maxP, int *status)
+                                                      const double *__restrict__ invmass, double *vx, double *vy, double *vz, double dt, int maxA, int maxP, int *status, int nown)
 {
+   /* atoms == nullptr: slot[] is indexed by the position in the groups' atom lists (groups named by gid, decomposed
+    * runs).  There every rank that owns an atom of a group solves the WHOLE group from the owned and halo copies of
+    * its atoms (positions from the position halo, velocities from the velocity halo) and keeps the velocities of the
+    * atoms it owns: slots below nown. */
    extern __shared__ double cons_sh[];
    const int t = threadIdx.x, g = blockIdx.x * CONS_T + t;
    double *v = cons_sh, *rm = cons_sh + 3 * maxA * CONS_T, *rab = rm + maxA * CONS_T;
    if (g >= ngroups) return;
    const int a0 = atom_off[g], na = atom_off[g + 1] - a0, p0 = pair_off[g], np = pair_off[g + 1] - p0;
+#define CG_SLOT(k) (atoms ? slot[atoms[k]] : slot[k])
+   {
+      bool mine = false;
+      for (int a = 0; a < na; a++) mine |= CG_SLOT(a0 + a) < nown;
+      if (!mine) return;
+   }
    for (int a = 0; a < na; a++)
    {
-      int s = slot[atoms[a0 + a]];
+      int s = CG_SLOT(a0 + a);
       v[(3 * a + 0) * CONS_T + t] = vx[s]; v[(3 * a + 1) * CONS_T + t] = vy[s]; v[(3 * a + 2) * CONS_T + t] = vz[s];
-      rm[a * CONS_T + t] = invmass[species[s]];
+      rm[a * CONS_T + t] = invmass[(int)((__double_as_longlong(pos[s].w) >> 16) & 0xffff)];      /* the record's tag names the species of owned and halo beads alike */
    }
    for (int ab = 0; ab < np; ab++)
    {
-      int sa = slot[atoms[a0 + pa[p0 + ab]]], sb = slot[atoms[a0 + pb[p0 + ab]]];
+      int sa = CG_SLOT(a0 + pa[p0 + ab]), sb = CG_SLOT(a0 + pb[p0 + ab]);
       double x, y, z;
       bioVec(box, pos[sa], pos[sb], x, y, z);
       rab[(3 * ab + 0) * CONS_T + t] = x; rab[(3 * ab + 1) * CONS_T + t] = y; rab[(3 * ab + 2) * CONS_T + t] = z;
@@ -808,22 +820,27 @@ __global__ __launch_bounds__(CONS_T) void k_constrain(int ngroups, const int *__
    }
    for (int a = 0; a < na; a++)
    {
-      int s = slot[atoms[a0 + a]];
+      int s = CG_SLOT(a0 + a);
+      if (s >= nown) continue;
       vx[s] = v[(3 * a + 0) * CONS_T + t]; vy[s] = v[(3 * a + 1) * CONS_T + t]; vz[s] = v[(3 * a + 2) * CONS_T + t];
    }
+#undef CG_SLOT
    atomicMax(status, it < maxit ? it + 1 : maxit);
    if (it == maxit) atomicAdd(status + 1, 1);
 }
 
-extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const int *pairI, const int *pairJ, const double *dist)
+template <class KEY>
+static int set_constraints_impl(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const KEY *pairI, const KEY *pairJ, const double *dist, bool by_gid)
 {
    if (!ctx || ngroups < 0 || (ngroups > 0 && (!pair_off || !pairI || !pairJ || !dist))) return DDCMI_EINVAL;
-   if (ngroups > 0 && (ctx->group_ || ctx->nranks > 1)) SETERR(ctx, DDCMI_EINVAL, "velocity constraints are implemented for one domain only");
+   if (ngroups > 0 && !by_gid && (ctx->group_ || ctx->nranks > 1))
+      SETERR(ctx, DDCMI_EINVAL, "with several domains constraint groups must be given by gid (ddcmi_set_constraints_gid): caller-order indices do not survive migration");
    (void)hipSetDevice(ctx->device);
-   ctx->ncgroup = 0; ctx->ncpair = 0;
+   ctx->ncgroup = 0; ctx->ncpair = 0; ctx->cons_gid = false; ctx->cg_natom = 0;
    if (ngroups == 0) return DDCMI_OK;
    /* group-local atom lists (CONSTRAINT.atomIDList, bioMartini.c:405-425): pairs name positions in them */
-   std::vector<int> aoff(ngroups + 1, 0), alist;
+   std::vector<int> aoff(ngroups + 1, 0);
+   std::vector<KEY> alist;
    const int np_tot = pair_off[ngroups];
    std::vector<unsigned char> pa(np_tot), pb(np_tot);
    int maxA = 0, maxP = 0;
@@ -832,11 +849,11 @@ extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pai
       const int base = (int)alist.size();
       for (int k = pair_off[g]; k < pair_off[g + 1]; k++)
       {
-         if (pairI[k] == pairJ[k] || !(dist[k] > 0.0)) SETERR(ctx, DDCMI_EINVAL, "constraint %d of group %d: atoms %d %d, distance %g", k - pair_off[g], g, pairI[k], pairJ[k], dist[k]);
+         if (pairI[k] == pairJ[k] || !(dist[k] > 0.0)) SETERR(ctx, DDCMI_EINVAL, "constraint %d of group %d: atoms %lld %lld, distance %g", k - pair_off[g], g, (long long)pairI[k], (long long)pairJ[k], dist[k]);
          int loc[2];
          for (int e = 0; e < 2; e++)
          {
-            const int at = e ? pairJ[k] : pairI[k];
+            const KEY at = e ? pairJ[k] : pairI[k];
             int f = -1;
             for (int q = base; q < (int)alist.size(); q++) if (alist[q] == at) { f = q - base; break; }
             if (f < 0) { f = (int)alist.size() - base; alist.push_back(at); }
@@ -852,7 +869,10 @@ extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pai
    if ((size_t)(4 * maxA + 3 * maxP) * CONS_T * sizeof(double) > 64 * 1024)
       SETERR(ctx, DDCMI_EINVAL, "constraint group of %d atoms / %d pairs exceeds the LDS budget of the solver (4 atoms + 3 pairs <= 128)", maxA, maxP);
    int rc;
-   if ((rc = up(ctx, ctx->cg_atom_off, aoff.data(), (size_t)ngroups + 1)) || (rc = up(ctx, ctx->cg_atoms, alist.data(), alist.size())) ||
+   if (by_gid) { if ((rc = up(ctx, ctx->cg_atom_gid, (const uint64_t *)alist.data(), alist.size()))) return rc; ENSURE(ctx, ctx->cg_slot, alist.size() + 1); }
+   else if ((rc = up(ctx, ctx->cg_atoms, (const int *)alist.data(), alist.size()))) return rc;
+   ctx->cons_gid = by_gid; ctx->cg_natom = (int)alist.size(); ctx->list_valid = false;
+   if ((rc = up(ctx, ctx->cg_atom_off, aoff.data(), (size_t)ngroups + 1)) ||
        (rc = up(ctx, ctx->cg_pair_off, pair_off, (size_t)ngroups + 1)) || (rc = up(ctx, ctx->cg_pa, pa.data(), (size_t)np_tot)) ||
        (rc = up(ctx, ctx->cg_pb, pb.data(), (size_t)np_tot)) || (rc = up(ctx, ctx->cg_dist, dist, (size_t)np_tot))) return rc;
    ENSURE(ctx, ctx->cons_status, 4);
@@ -860,6 +880,14 @@ extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pai
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    ctx->ncgroup = ngroups; ctx->ncpair = np_tot; ctx->cons_maxA = maxA; ctx->cons_maxP = maxP;
    return DDCMI_OK;
+}
+extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const int *pairI, const int *pairJ, const double *dist)
+{
+   return set_constraints_impl<int>(ctx, ngroups, pair_off, pairI, pairJ, dist, false);
+}
+extern "C" int ddcmi_set_constraints_gid(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const uint64_t *pairI, const uint64_t *pairJ, const double *dist)
+{
+   return set_constraints_impl<uint64_t>(ctx, ngroups, pair_off, pairI, pairJ, dist, true);
 }
 
 int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location)
@@ -871,9 +899,10 @@ int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location)
    box.pbc = ctx->pbc;
    const size_t lds = (size_t)(4 * ctx->cons_maxA + 3 * ctx->cons_maxP) * CONS_T * sizeof(double);
    auto kern = location == 0 ? k_constrain<0> : k_constrain<1>;
-   hipLaunchKernelGGL(kern, dim3(cdiv(ctx->ncgroup, CONS_T)), dim3(CONS_T), lds, ctx->stream, ctx->ncgroup, ctx->cg_atom_off.p, ctx->cg_atoms.p, ctx->cg_pair_off.p,
-                      ctx->cg_pa.p, ctx->cg_pb.p, ctx->cg_dist.p, ctx->slot_of_orig.p, box, ctx->pos.p, ctx->species.p, ctx->d_invmass.p,
-                      ctx->vx.p, ctx->vy.p, ctx->vz.p, dt, ctx->cons_maxA, ctx->cons_maxP, ctx->cons_status.p);
+   hipLaunchKernelGGL(kern, dim3(cdiv(ctx->ncgroup, CONS_T)), dim3(CONS_T), lds, ctx->stream, ctx->ncgroup, ctx->cg_atom_off.p,
+                      ctx->cons_gid ? (const int *)nullptr : ctx->cg_atoms.p, ctx->cg_pair_off.p,
+                      ctx->cg_pa.p, ctx->cg_pb.p, ctx->cg_dist.p, ctx->cons_gid ? ctx->cg_slot.p : ctx->slot_of_orig.p, box, ctx->pos.p, ctx->species.p, ctx->d_invmass.p,
+                      ctx->vx.p, ctx->vy.p, ctx->vz.p, dt, ctx->cons_maxA, ctx->cons_maxP, ctx->cons_status.p, ctx->cons_gid ? ctx->nloc : 0x7fffffff);
    return DDCMI_OK;
 }
 
@@ -932,12 +961,185 @@ __global__ __launch_bounds__(256) void k_mol_virial(int nmol, const int *__restr
    }
 }
 
+/* The same for molecules named by gid (decomposed runs).  A rank sums over the atoms it OWNS, positions taken as nearest
+ * images about a reference point: a molecule all of whose atoms are here gives its whole term V - (P/M) o F (V = sum x o f,
+ * P = sum m x, F = sum f; reference = its first atom); a SPLIT molecule (atoms on several ranks) gives V to the same sum
+ * and leaves {P, F} in red[6k..] for the all-reduce -- the reference point is then the anchor all ranks agreed on at the
+ * rebuild (ddcmi_mol_split_finish), and (P/M) o F is subtracted once the sums are complete (ddcmi_mol_split_term). */
+__global__ __launch_bounds__(256) void k_mol_virial_gid(int nmol, int nown, const int *__restrict__ mol_off, const int *__restrict__ slot, const int *__restrict__ split,
+                                                        const double *__restrict__ info, const double *__restrict__ mtot, BoxArgs box,
+                                                        const double4 *__restrict__ pos, const double *__restrict__ mass,
+                                                        const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz, double *red, double *out)
+{
+   const int m = blockIdx.x * 256 + threadIdx.x;
+   double acc[3] = {0, 0, 0};
+   if (m < nmol)
+   {
+      const int a0 = mol_off[m], a1 = mol_off[m + 1];
+      const int k = split[m];
+      double4 ref = make_double4(0, 0, 0, 0);
+      bool any = false;
+      for (int a = a0; a < a1; a++) any |= slot[a] < nown;
+      if (any)
+      {
+         if (k >= 0) { ref.x = info[4 * m + 1]; ref.y = info[4 * m + 2]; ref.z = info[4 * m + 3]; }
+         else ref = pos[slot[a0]];
+         double P[3] = {0, 0, 0}, F[3] = {0, 0, 0}, V[3] = {0, 0, 0};
+         for (int a = a0; a < a1; a++)
+         {
+            const int s = slot[a];
+            if (s >= nown) continue;
+            const double4 p = pos[s];
+            double x, y, z;
+            bioVec(box, p, ref, x, y, z);
+            const double w = mass[(int)((__double_as_longlong(p.w) >> 16) & 0xffff)];
+            P[0] += w * x; P[1] += w * y; P[2] += w * z;
+            F[0] += fx[s]; F[1] += fy[s]; F[2] += fz[s];
+            V[0] += x * fx[s]; V[1] += y * fy[s]; V[2] += z * fz[s];
+         }
+         if (k >= 0)
+         {
+            for (int c = 0; c < 3; c++) { red[6 * k + c] = P[c]; red[6 * k + 3 + c] = F[c]; acc[c] = V[c]; }
+         }
+         else
+         {
+            const double iM = 1.0 / mtot[m];
+            for (int c = 0; c < 3; c++) acc[c] = V[c] - (P[c] * iM) * F[c];
+         }
+      }
+   }
+#pragma unroll
+   for (int c = 0; c < 3; c++)
+   {
+      double w = wsum(acc[c]);
+      if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(out + c, w);
+   }
+}
+/* rebuild: mol_info[4m] = 1 if this rank owns an atom of molecule m, [4m+1..3] = position of its first listed atom if
+ * this rank owns it; summed over the ranks that gives {owning ranks, anchor} */
+__global__ void k_mol_info(int nmol, int nown, const int *__restrict__ mol_off, const int *__restrict__ slot, const double4 *__restrict__ pos, double *info)
+{
+   const int m = blockIdx.x * blockDim.x + threadIdx.x;
+   if (m >= nmol) return;
+   const int a0 = mol_off[m], a1 = mol_off[m + 1];
+   bool any = false;
+   for (int a = a0; a < a1; a++) any |= slot[a] < nown;
+   double4 o = make_double4(any ? 1.0 : 0.0, 0, 0, 0);
+   if (slot[a0] < nown) { const double4 p = pos[slot[a0]]; o.y = p.x; o.z = p.y; o.w = p.z; }
+   info[4 * m] = o.x; info[4 * m + 1] = o.y; info[4 * m + 2] = o.z; info[4 * m + 3] = o.w;
+}
+__global__ void k_mol_split_flag(int nmol, const double *__restrict__ info, int *flag)
+{
+   const int m = blockIdx.x * blockDim.x + threadIdx.x;
+   if (m < nmol) flag[m] = info[4 * m] > 1.5 ? 1 : 0;
+}
+__global__ void k_mol_split_index(int nmol, const double *__restrict__ info, int *split /* in: exclusive scan of the flags */)
+{
+   const int m = blockIdx.x * blockDim.x + threadIdx.x;
+   if (m < nmol) split[m] = info[4 * m] > 1.5 ? split[m] : -1;
+}
+/* every atom of a molecule some of whose atoms are owned must be visible as far as THIS rank needs it: only the owned
+ * ones are read, so nothing to check; constraint groups need all their atoms: flags[0] counts groups with an owned
+ * and a missing atom */
+__global__ void k_groups_check(int ngroups, int nown, const int *__restrict__ atom_off, const int *__restrict__ slot, int *flags)
+{
+   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= ngroups) return;
+   bool mine = false, missing = false;
+   for (int a = atom_off[g]; a < atom_off[g + 1]; a++) { mine |= slot[a] < nown; missing |= slot[a] == 0x7fffffff; }
+   if (mine && missing) atomicAdd(&flags[0], 1);
+}
+/* sum over the split molecules of (P/M) o F from the all-reduced {P, F} */
+__global__ __launch_bounds__(256) void k_mol_split_term(int nmol, const int *__restrict__ split, const double *__restrict__ mtot, const double *__restrict__ red, double *out)
+{
+   const int m = blockIdx.x * 256 + threadIdx.x;
+   double acc[3] = {0, 0, 0};
+   if (m < nmol && split[m] >= 0)
+   {
+      const int k = split[m];
+      const double iM = 1.0 / mtot[m];
+      for (int c = 0; c < 3; c++) acc[c] = (red[6 * k + c] * iM) * red[6 * k + 3 + c];
+   }
+#pragma unroll
+   for (int c = 0; c < 3; c++)
+   {
+      double w = wsum(acc[c]);
+      if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(out + c, w);
+   }
+}
+
+extern "C" int ddcmi_set_molecule_lists_gid(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const uint64_t *mol_atom_gid, const double *mol_mass)
+{
+   if (!ctx || nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atom_gid || !mol_mass))) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   int rc;
+   ctx->nmol_total = nmol_total; ctx->nmol_multi = 0; ctx->molv_valid = false; ctx->mol_gid = true; ctx->mol_natom = 0; ctx->nsplit = 0; ctx->list_valid = false;
+   if (nmulti > 0)
+   {
+      const size_t na = (size_t)mol_off[nmulti];
+      if ((rc = up(ctx, ctx->mol_off, mol_off, (size_t)nmulti + 1)) || (rc = up(ctx, ctx->mol_atom_gid, mol_atom_gid, na)) || (rc = up(ctx, ctx->mol_mtot, mol_mass, (size_t)nmulti))) return rc;
+      ENSURE(ctx, ctx->mol_slot, na + 1); ENSURE(ctx, ctx->mol_split, (size_t)nmulti + 1); ENSURE(ctx, ctx->mol_info, 4 * (size_t)nmulti + 4);
+      ctx->nmol_multi = nmulti; ctx->mol_natom = (int)na;
+   }
+   return DDCMI_OK;
+}
+
+/* rebuild (after the gid table of ddcmi_bonded_localize): where are the atoms of the constraint groups and of the molecules? */
+int ddcmi_groups_localize(ddcmi_ctx *ctx)
+{
+   hipStream_t st = ctx->stream;
+   if (ctx->cons_gid && ctx->ncgroup > 0)
+   {
+      hipLaunchKernelGGL(k_atom_slots, dim3(cdiv(ctx->cg_natom, 256)), dim3(256), 0, st, ctx->cg_natom, ctx->cg_atom_gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->cg_slot.p);
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_groups_check, dim3(cdiv(ctx->ncgroup, 256)), dim3(256), 0, st, ctx->ncgroup, ctx->nloc, ctx->cg_atom_off.p, ctx->cg_slot.p, ctx->d_flags);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      if (ctx->h_flags[0] > 0)
+         SETERR(ctx, DDCMI_EUNSUPPORTED, "%d constraint groups have an atom on this domain and a partner beyond its halo (rmax+deltaR=%g)", ctx->h_flags[0], ctx->rmax + ctx->deltaR);
+   }
+   if (ctx->mol_gid && ctx->nmol_multi > 0)
+   {
+      hipLaunchKernelGGL(k_atom_slots, dim3(cdiv(ctx->mol_natom, 256)), dim3(256), 0, st, ctx->mol_natom, ctx->mol_atom_gid.p, ctx->hmask, ctx->hkeys.p, ctx->hvals.p, ctx->mol_slot.p);
+      hipLaunchKernelGGL(k_mol_info, dim3(cdiv(ctx->nmol_multi, 256)), dim3(256), 0, st, ctx->nmol_multi, ctx->nloc, ctx->mol_off.p, ctx->mol_slot.p, ctx->pos.p, ctx->mol_info.p);
+   }
+   return DDCMI_OK;
+}
+/* rebuild, after mol_info has been summed over the ranks: index the split molecules (the same numbers on every rank) */
+int ddcmi_mol_split_finish(ddcmi_ctx *ctx)
+{
+   ctx->nsplit = 0;
+   if (!ctx->mol_gid || ctx->nmol_multi == 0) return DDCMI_OK;
+   hipStream_t st = ctx->stream;
+   const int nm = ctx->nmol_multi;
+   hipLaunchKernelGGL(k_mol_split_flag, dim3(cdiv(nm, 256)), dim3(256), 0, st, nm, ctx->mol_info.p, ctx->mol_split.p);
+   int rc = ddcmi_scan_exclusive(ctx, ctx->mol_split.p, nm, ctx->d_flags + 9);
+   if (rc) return rc;
+   hipLaunchKernelGGL(k_mol_split_index, dim3(cdiv(nm, 256)), dim3(256), 0, st, nm, ctx->mol_info.p, ctx->mol_split.p);
+   HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 9, ctx->d_flags + 9, sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   ctx->nsplit = ctx->h_flags[9];
+   ENSURE(ctx, ctx->mol_red, 6 * (size_t)ctx->nsplit + 8);
+   return DDCMI_OK;
+}
+int ddcmi_mol_split_term(ddcmi_ctx *ctx, double out[3])
+{
+   out[0] = out[1] = out[2] = 0.0;
+   if (ctx->nsplit == 0) return DDCMI_OK;
+   double *d = ctx->d_results + R_SCR_MOLV + 4;
+   HIPCHK(ctx, hipMemsetAsync(d, 0, 3 * sizeof(double), ctx->stream));
+   hipLaunchKernelGGL(k_mol_split_term, dim3(cdiv(ctx->nmol_multi, 256)), dim3(256), 0, ctx->stream, ctx->nmol_multi, ctx->mol_split.p, ctx->mol_mtot.p, ctx->mol_red.p, d);
+   HIPCHK(ctx, hipMemcpyAsync(out, d, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   return DDCMI_OK;
+}
+
 extern "C" int ddcmi_set_molecule_lists(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const int *mol_atoms)
 {
    if (!ctx || nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atoms))) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
    int rc;
-   ctx->nmol_total = nmol_total; ctx->nmol_multi = 0; ctx->molv_valid = false;
+   ctx->nmol_total = nmol_total; ctx->nmol_multi = 0; ctx->molv_valid = false; ctx->mol_gid = false; ctx->nsplit = 0;
    if (nmulti > 0)
    {
       if ((rc = up(ctx, ctx->mol_off, mol_off, (size_t)nmulti + 1)) || (rc = up(ctx, ctx->mol_atoms, mol_atoms, (size_t)mol_off[nmulti]))) return rc;
@@ -954,6 +1156,13 @@ int ddcmi_launch_mol_virial(ddcmi_ctx *ctx)
    box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
    for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
    box.pbc = ctx->pbc;
+   if (ctx->mol_gid)
+   {
+      if (ctx->nsplit > 0) HIPCHK(ctx, hipMemsetAsync(ctx->mol_red.p, 0, 6 * (size_t)ctx->nsplit * sizeof(double), ctx->stream));
+      hipLaunchKernelGGL(k_mol_virial_gid, dim3(cdiv(ctx->nmol_multi, 256)), dim3(256), 0, ctx->stream, ctx->nmol_multi, ctx->nloc, ctx->mol_off.p, ctx->mol_slot.p, ctx->mol_split.p,
+                         ctx->mol_info.p, ctx->mol_mtot.p, box, ctx->pos.p, ctx->d_mass.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->mol_red.p, ctx->d_results + R_SCR_MOLV);
+      return DDCMI_OK;
+   }
    hipLaunchKernelGGL(k_mol_virial, dim3(cdiv(ctx->nmol_multi, 256)), dim3(256), 0, ctx->stream, ctx->nmol_multi, ctx->mol_off.p, ctx->mol_atoms.p, ctx->slot_of_orig.p, box,
                       ctx->pos.p, ctx->species.p, ctx->d_mass.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_MOLV);
    return DDCMI_OK;

@@ -1400,6 +1400,14 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
    p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
    pos[i] = p;
 }
+__global__ void k_scale_pos(int n, double s0, double s1, double s2, double4 *pos)
+{
+   int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   double4 p = pos[i];
+   p.x *= s0; p.y *= s1; p.z *= s2;
+   pos[i] = p;
+}
 #define KE_PER 4
 /* BACK half kick (nglf.c:100-104) fused with kinetic_terms (energy.c:48-163):
  * rk = sum 1/2 m v^2, tion = sum m v (x) v */
@@ -2198,6 +2206,9 @@ int ddcmi_bl_reserve_halo(ddcmi_ctx *ctx, int nh)
    int n = ctx->nloc;
    dbuf<int> *hb[] = {&ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank, &ctx->horder, &ctx->halo_src, &ctx->halo_shift};
    for (auto b : hb) ENSURE(ctx, *b, nh + 1);
+   if (ctx->cons_gid && ctx->ncgroup > 0 && (size_t)(n + nh) > ctx->vx.cap)      /* the velocity halo of the constraint solves */
+      if (ctx->vx.ensure(n + nh, true, st) || ctx->vy.ensure(n + nh, true, st) || ctx->vz.ensure(n + nh, true, st))
+         SETERR(ctx, DDCMI_ENOMEM, "growing velocity arrays for %d halo beads failed", nh);
    if ((size_t)(n + nh) > ctx->pos.cap)
    {
       if (ctx->pos.ensure(n + nh, true, st) || ctx->pos2.ensure(n + nh) || ctx->gid.ensure(n + nh, true, st) || ctx->gid2.ensure(n + nh))
@@ -2261,7 +2272,8 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
    if ((rc = bl_self_images(ctx))) return rc;
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
-   return ddcmi_bl_finish(ctx);
+   if ((rc = ddcmi_bl_finish(ctx))) return rc;
+   return ddcmi_mol_split_finish(ctx);      /* one domain: no molecule is split */
 }
 
 /* Tile order and XCD ranges of k_nonbond, on the host from the per-tile cost estimates
@@ -2723,58 +2735,106 @@ static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
    }
    return lam;
 }
-static int step_pre(ddcmi_ctx *ctx, double dt)
+/* The FRONT half of a step in phases, so that a decomposed run can put its exchanges between them (one context: step_pre
+ * calls them back to back, the transport's collectives in between; an in-process group: ddcmi_group_step_nglf calls each
+ * phase for every domain and moves the data itself):
+ *   a  barostat: this rank's sums of the last force evaluation -- virial diagonal and molecular term -- to the host
+ *      (+ {P, F} of the split molecules on the device)                       -> all-reduce
+ *   b  barostat: pressures, scale factors, box; FRONT half kick (+ drift unless constraints follow)
+ *                                                                            -> velocity halo (constraints only)
+ *   c  constraints: FRONT solve, drift; clock */
+static int mg_allreduce_host_values(ddcmi_ctx *ctx, double *values, int n);
+static int mg_allreduce_device(ddcmi_ctx *ctx, double *d, size_t n);
+int ddcmi_mg_refresh_vel(ddcmi_ctx *ctx);
+static inline bool decomposed(const ddcmi_ctx *ctx) { return ctx->nranks > 1 || ctx->loopback || ctx->group_ != nullptr; }
+static int step_pre_a(ddcmi_ctx *ctx)
+{
+   if (ctx->drift_done || !(ctx->baro_beta > 0.0)) return DDCMI_OK;
+   /* nglfconstraint.c:527-536 + changeVolume (:64-84): semi-isotropic Berendsen barostat from the molecular
+    * pressure of the last force evaluation, at the TARGET temperature */
+   int rcb;
+   if (!ctx->molv_valid && (rcb = ddcmi_launch_mol_virial(ctx))) return rcb;     /* first step after ddcmi_eval_forces */
+   if ((rcb = fetch_results(ctx))) return rcb;
+   const double *mv = ctx->h_results + R_SCR_MOLV;       /* zero unless molecule lists are set */
+   ctx->baro_sums[0] = ctx->h_results[R_VIR + DDCMI_XX]; ctx->baro_sums[1] = ctx->h_results[R_VIR + DDCMI_YY]; ctx->baro_sums[2] = ctx->h_results[R_VIR + DDCMI_ZZ];
+   ctx->baro_sums[3] = mv[0]; ctx->baro_sums[4] = mv[1]; ctx->baro_sums[5] = mv[2];
+   ctx->baro_sums[6] = (double)ctx->nloc;
+   return DDCMI_OK;
+}
+static int step_pre_b(ddcmi_ctx *ctx, double dt)
 {
    int n = ctx->nloc, nb = cdiv(n, 256);
-   if (!ctx->drift_done)
+   if (ctx->drift_done) return DDCMI_OK;
+   GroupLambda lam = front_lambda(ctx, dt);
+   if (ctx->baro_beta > 0.0)
    {
-      GroupLambda lam = front_lambda(ctx, dt);
-      if (ctx->baro_beta > 0.0)
+      int rcb;
+      double split[3];
+      if ((rcb = ddcmi_mol_split_term(ctx, split))) return rcb;      /* (P/M) o F of the molecules with atoms on several ranks, from the summed {P, F} */
+      const double nmol = ctx->nmol_total > 0 ? (double)ctx->nmol_total : ctx->baro_sums[6];
+      const double vol = ctx->h[0] * ctx->h[4] * ctx->h[8], NkT = nmol * ctx->baro_T;
+      double pxx = (ctx->baro_sums[0] - (ctx->baro_sums[3] - split[0]) + NkT) / vol - ctx->baro_P0;
+      double pyy = (ctx->baro_sums[1] - (ctx->baro_sums[4] - split[1]) + NkT) / vol - ctx->baro_P0;
+      double pzz = (ctx->baro_sums[2] - (ctx->baro_sums[5] - split[2]) + NkT) / vol - ctx->baro_P0;
+      ctx->pmol[0] = pxx + ctx->baro_P0; ctx->pmol[1] = pyy + ctx->baro_P0; ctx->pmol[2] = pzz + ctx->baro_P0;
+      const double btt = ctx->baro_beta * dt / ctx->baro_tau;
+      double pl = 0.5 * (pxx + pyy);
+      if (ctx->baro_iso) pl = pzz = (1.0 / 3.0) * (pxx + pyy + pzz);          /* molecularPressureGPU.cu:211 */
+      double l[3] = {cbrt(1.0 + pl * btt), cbrt(1.0 + pl * btt), cbrt(1.0 + pzz * btt)};
+      for (int a = 0; a < 3; a++)
       {
-         /* nglfconstraint.c:527-536 + changeVolume (:64-84): semi-isotropic Berendsen barostat from the
-          * molecular pressure of the last force evaluation (all molecules are single beads here, so the
-          * molecular virial is the atomic one: molecularPressure.c), at the TARGET temperature */
-         int rcb;
-         if (!ctx->molv_valid && (rcb = ddcmi_launch_mol_virial(ctx))) return rcb;     /* first step after ddcmi_eval_forces */
-         if ((rcb = fetch_results(ctx))) return rcb;
-         const double nmol = ctx->nmol_total > 0 ? (double)ctx->nmol_total : (double)ctx->nloc;
-         const double vol = ctx->h[0] * ctx->h[4] * ctx->h[8], NkT = nmol * ctx->baro_T;
-         const double *mv = ctx->h_results + R_SCR_MOLV;       /* zero unless molecule lists are set */
-         double pxx = (ctx->h_results[R_VIR + DDCMI_XX] - mv[0] + NkT) / vol - ctx->baro_P0;
-         double pyy = (ctx->h_results[R_VIR + DDCMI_YY] - mv[1] + NkT) / vol - ctx->baro_P0;
-         double pzz = (ctx->h_results[R_VIR + DDCMI_ZZ] - mv[2] + NkT) / vol - ctx->baro_P0;
-         ctx->pmol[0] = pxx + ctx->baro_P0; ctx->pmol[1] = pyy + ctx->baro_P0; ctx->pmol[2] = pzz + ctx->baro_P0;
-         const double btt = ctx->baro_beta * dt / ctx->baro_tau;
-         double pl = 0.5 * (pxx + pyy);
-         if (ctx->baro_iso) pl = pzz = (1.0 / 3.0) * (pxx + pyy + pzz);          /* molecularPressureGPU.cu:211 */
-         double l[3] = {cbrt(1.0 + pl * btt), cbrt(1.0 + pl * btt), cbrt(1.0 + pzz * btt)};
-         for (int a = 0; a < 3; a++)
-         {
-            if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;          /* box.c:44 */
-            lam.scale[a] = l[a];
-            ctx->h[4 * a] *= l[a];
-            ctx->gp.L[a] = ctx->h[4 * a];
-         }
+         if (fabs(l[a] - 1.0) < 1e-14) l[a] = 1.0;          /* box.c:44 */
+         lam.scale[a] = l[a];
+         ctx->h[4 * a] *= l[a];
+         ctx->gp.L[a] = ctx->h[4 * a];
       }
-      if (n > 0 && ctx->ncgroup > 0)
-      {
-         /* nglfconstraint.c:538-553: FRONT kick, velocityConstraintOld(FRONT) at the (scaled) positions, drift */
-         int rcc;
-         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 1);
-         if ((rcc = ddcmi_launch_constraints(ctx, dt, 0))) return rcc;
+   }
+   if (ctx->ncgroup > 0 && ctx->nhalo > 0 && (lam.scale[0] != 1.0 || lam.scale[1] != 1.0 || lam.scale[2] != 1.0))
+      /* the FRONT solve reads the (scaled) positions of partners that are image / halo beads: adjustPosn for them too (an image
+       * r + L goes to lambda r + lambda L, its place in the scaled box); the position halo after the drift replaces them */
+      hipLaunchKernelGGL(k_scale_pos, dim3(cdiv(ctx->nhalo, 256)), dim3(256), 0, ctx->stream, ctx->nhalo, lam.scale[0], lam.scale[1], lam.scale[2], ctx->pos.p + n);
+   if (n > 0 && ctx->ncgroup > 0)
+      /* nglfconstraint.c:538-553: FRONT kick, velocityConstraintOld(FRONT) at the (scaled) positions, drift */
+      hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 1);
+   else if (n > 0)
+      hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 3);
+   return DDCMI_OK;
+}
+static int step_pre_c(ddcmi_ctx *ctx, double dt)
+{
+   int n = ctx->nloc, nb = cdiv(n, 256);
+   if (!ctx->drift_done && ctx->ncgroup > 0)
+   {
+      int rcc;
+      GroupLambda lam = front_lambda(ctx, dt);
+      if ((rcc = ddcmi_launch_constraints(ctx, dt, 0))) return rcc;
+      if (n > 0)
          hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 2);
-      }
-      else if (n > 0)
-         hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 3);
    }
    ctx->drift_done = false;             /* else: the previous step's last kernel already did this kick + drift */
    ctx->time += dt;
    ctx->loop += 1;
    ctx->halo_fresh = false;
    return DDCMI_OK;
+}
+/* do the constraint solves of this context need its neighbours' velocities? */
+static inline bool cons_exchange(const ddcmi_ctx *ctx) { return ctx->ncgroup > 0 && ctx->cons_gid && decomposed(ctx); }
+static int step_pre(ddcmi_ctx *ctx, double dt)
+{
+   int rc;
+   if ((rc = step_pre_a(ctx))) return rc;
+   if (!ctx->drift_done && ctx->baro_beta > 0.0 && decomposed(ctx))
+   {
+      if ((rc = mg_allreduce_host_values(ctx, ctx->baro_sums, 7))) return rc;
+      if (ctx->nsplit > 0 && (rc = mg_allreduce_device(ctx, ctx->mol_red.p, 6 * (size_t)ctx->nsplit))) return rc;
+   }
+   const bool had_drift = ctx->drift_done;
+   if ((rc = step_pre_b(ctx, dt))) return rc;
+   if (!had_drift && cons_exchange(ctx) && (rc = ddcmi_mg_refresh_vel(ctx))) return rc;
+   return step_pre_c(ctx, dt);
 }
 /* nglf.c:97-108: ddcenergy, BACK half kick, kinetic_terms, group Update */
 static void graph_drop(ddcmi_ctx *ctx)
@@ -2790,6 +2850,13 @@ static bool graph_ok(const ddcmi_ctx *ctx, double dt)
    if (ctx->group_ || ctx->nranks > 1 || ctx->loopback || ctx->timing || ctx->baro_beta > 0.0 || ctx->ncgroup > 0) return false;
    for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE) return false;
    return ctx->graph_state < 2 || ctx->graph_dt == dt;
+}
+static int step_post_cons_b(ddcmi_ctx *ctx, double dt)
+{
+   int rc;
+   if ((rc = ddcmi_launch_constraints(ctx, dt, 1))) return rc;
+   GroupLambda lam = front_lambda(ctx, dt);
+   return launch_kinetic(ctx, dt, 0, true, &lam, false);
 }
 static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
 {
@@ -2826,16 +2893,21 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       if ((rc = ddcmi_launch_mol_virial(ctx))) return rc;
       ctx->molv_valid = true;
    }
-   if (ctx->ncgroup > 0 && ctx->nloc > 0)
+   if (ctx->ncgroup > 0)
    {
-      /* nglfconstraint.c:567-571: BACK kick, velocityConstraintOld(BACK), then kinetic_terms */
-      GroupLambda lb = lam;
-      const int nblk = cdiv(ctx->nloc, DDCMI_BLOCK * KE_PER);
-      ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
-      hipLaunchKernelGGL(k_kick_ke, dim3(nblk), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->nloc, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, 1, ctx->group.p, lb, ctx->gid.p);
-      if ((rc = ddcmi_launch_constraints(ctx, dt, 1))) return rc;
-      return launch_kinetic(ctx, dt, 0, true, &lam, false);
+      /* nglfconstraint.c:567-571: BACK kick, velocityConstraintOld(BACK), then kinetic_terms (a decomposed run puts the
+       * velocity halo between the kick and the solve: step_post_cons_b) */
+      if (ctx->nloc > 0)
+      {
+         GroupLambda lb = lam;
+         const int nblk = cdiv(ctx->nloc, DDCMI_BLOCK * KE_PER);
+         ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
+         hipLaunchKernelGGL(k_kick_ke, dim3(nblk), dim3(DDCMI_BLOCK), 0, ctx->stream, ctx->nloc, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, 1, ctx->group.p, lb, ctx->gid.p);
+      }
+      if (ctx->group_) return DDCMI_OK;      /* the group driver exchanges the velocities of all domains, then calls step_post_cons_b */
+      if (cons_exchange(ctx) && (rc = ddcmi_mg_refresh_vel(ctx))) return rc;
+      return step_post_cons_b(ctx, dt);
    }
    if (more_steps && ctx->nloc > 0 && !(ctx->baro_beta > 0.0))      /* the barostat needs this step's virial before the next drift */
    {
@@ -2895,6 +2967,7 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
    (void)hipSetDevice(ctx->device);
    int rc;
    if ((rc = mg_check_one_domain_features(ctx))) return rc;
+   if (ctx->baro_beta > 0.0 && ctx->nmol_total == 0 && decomposed(ctx)) SETERR(ctx, DDCMI_EINVAL, "the barostat of a decomposed run needs the molecule count: ddcmi_set_molecule_lists_gid");
    if (ctx->baro_beta > 0.0 && ctx->nmol_total == 0)
       for (int m = 0; m < ctx->nmoltype; m++)
          if (ctx->mol_nspecies[m] > 1) SETERR(ctx, DDCMI_EINVAL, "the barostat acts on the molecular pressure: molecule type %d has %d beads, call ddcmi_set_molecule_lists first", m, ctx->mol_nspecies[m]);

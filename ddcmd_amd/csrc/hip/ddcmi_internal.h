@@ -187,6 +187,18 @@ struct ddcmi_ctx
    /* nglfconstraint (one domain): constraint groups over caller-order atoms; pairs name group-local atoms */
    int ncgroup = 0, ncpair = 0, cons_maxA = 0, cons_maxP = 0;
    dbuf<int> cg_atom_off, cg_atoms, cg_pair_off, cons_status; dbuf<unsigned char> cg_pa, cg_pb; dbuf<double> cg_dist;
+   /* decomposed runs: constraint groups and molecules named by gid (ddcmi_set_constraints_gid / ddcmi_set_molecule_lists_gid);
+    * cg_slot / mol_slot = device slot of every listed atom, refilled at rebuilds (INT_MAX: not on this rank) */
+   bool cons_gid = false, mol_gid = false;
+   int cg_natom = 0, mol_natom = 0;
+   dbuf<uint64_t> cg_atom_gid, mol_atom_gid; dbuf<int> cg_slot, mol_slot;
+   /* molecules with atoms on several ranks ("split"): their centre of mass and total force need the ranks' partial sums.
+    * mol_info[4m..] = {owning ranks, anchor x y z} all-reduced at rebuilds (the anchor = where the molecule's first listed
+    * atom was then: the common reference for nearest images); mol_split[m] = index among the split ones or -1;
+    * mol_red[6k..] = this rank's {sum m x, sum f} of split molecule k, all-reduced every step the barostat acts */
+   int nsplit = 0;
+   dbuf<double> mol_mtot, mol_info, mol_red; dbuf<int> mol_split;
+   double baro_sums[12] = {0};         /* this step's {virial xx yy zz, molecular term xx yy zz, beads of multi... } before / after the all-reduce */
    /* molecules of more than one bead (molecular virial of the barostat), caller-order atoms */
    long nmol_total = 0; int nmol_multi = 0; bool molv_valid = false;   /* R_SCR_MOLV belongs to the forces now in fx */
    dbuf<int> mol_off, mol_atoms;
@@ -285,6 +297,9 @@ int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 int ddcmi_launch_bonded(ddcmi_ctx *ctx);
 int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location);   /* 0 FRONT, 1 BACK */
 int ddcmi_launch_mol_virial(ddcmi_ctx *ctx);
+int ddcmi_groups_localize(ddcmi_ctx *ctx);      /* rebuild: constraint groups / molecules named by gid -> device slots */
+int ddcmi_mol_split_finish(ddcmi_ctx *ctx);     /* rebuild, after mol_info has been summed over the ranks */
+int ddcmi_mol_split_term(ddcmi_ctx *ctx, double out[3]);      /* after mol_red has been summed: sum over split molecules of (P/M) o F */
 /* comm.hip */
 void ddcmi_comm_destroy(ddcmi_ctx *ctx);
 /* ddcmi.hip: rebuild phases shared by the single- and multi-domain paths */

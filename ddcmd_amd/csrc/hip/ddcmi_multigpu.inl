@@ -671,7 +671,10 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
    if ((rc = mg_xchg_counts(ctx, ctx->hs_cnt, ctx->hr_cnt))) return rc;
    if ((rc = mg_phase3_pack(ctx, 5))) return rc;
    if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5, ctx->stream))) return rc;
-   return mg_phase4_finish(ctx);
+   if ((rc = mg_phase4_finish(ctx))) return rc;
+   /* which molecules have atoms on several ranks, and where is their anchor? (one all-reduce of 4 doubles per multi-bead molecule) */
+   if (ctx->mol_gid && ctx->nmol_multi > 0 && (rc = mg_allreduce_device(ctx, ctx->mol_info.p, 4 * (size_t)ctx->nmol_multi))) return rc;
+   return ddcmi_mol_split_finish(ctx);
 }
 
 /* per-step halo refresh: pack x y z of the send lists, exchange, (k_halo_update places them) */
@@ -694,7 +697,96 @@ int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st)
    return DDCMI_OK;
 }
 
+/* velocity halo (constraint groups named by gid): the velocities of the beads on the halo send lists, same messages
+ * and layout as the positions; received beads land in the velocity slots behind the owned ones */
+__global__ void k_pack_vel(int nsend, SegTab so, int hs_cap, const int *hs_idx, const double *vx, const double *vy, const double *vz, double *out)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= nsend) return;
+   int q = 0;
+   while (k >= so.off[q + 1]) q++;
+   const int i = hs_idx[(size_t)so.code[q] * hs_cap + (k - so.off[q])];
+   out[3 * k] = vx[i]; out[3 * k + 1] = vy[i]; out[3 * k + 2] = vz[i];
+}
+__global__ void k_unpack_vel(int nloc, int nhalo, const int *halo_src, const double *vrecv, double *vx, double *vy, double *vz)
+{
+   int h = blockIdx.x * blockDim.x + threadIdx.x;
+   if (h >= nhalo) return;
+   const int s = halo_src[h];
+   if (s >= 0) { vx[nloc + h] = vx[s]; vy[nloc + h] = vy[s]; vz[nloc + h] = vz[s]; }      /* periodic self-image */
+   else { const int k = -1 - s; vx[nloc + h] = vrecv[3 * k]; vy[nloc + h] = vrecv[3 * k + 1]; vz[nloc + h] = vrecv[3 * k + 2]; }
+}
+static int mg_pack_vel(ddcmi_ctx *ctx, hipStream_t st)
+{
+   if (ctx->nsend > 0)
+      hipLaunchKernelGGL(k_pack_vel, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, st, ctx->nsend, ctx->sseg, ctx->hs_cap, ctx->hs_idx.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->sendbuf.p);
+   return DDCMI_OK;
+}
+static int mg_unpack_vel(ddcmi_ctx *ctx, hipStream_t st)
+{
+   if (ctx->nhalo > 0)
+      hipLaunchKernelGGL(k_unpack_vel, dim3(cdiv(ctx->nhalo, 256)), dim3(256), 0, st, ctx->nloc, ctx->nhalo, ctx->halo_src.p, ctx->hrecv3.p, ctx->vx.p, ctx->vy.p, ctx->vz.p);
+   return DDCMI_OK;
+}
+int ddcmi_mg_refresh_vel(ddcmi_ctx *ctx)
+{
+   if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "in-process group: velocities are exchanged by ddcmi_group_step_nglf");
+   int rc;
+   hipStream_t st = ctx->stream;
+   if (mg_transport(ctx))
+   {
+      if ((rc = mg_pack_vel(ctx, st))) return rc;
+      if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv3.p, 3, st))) return rc;
+   }
+   return mg_unpack_vel(ctx, st);
+}
+/* sum of n doubles on the device over the ranks, in place */
+static int mg_allreduce_device(ddcmi_ctx *ctx, double *d, size_t n)
+{
+   if (n == 0 || (ctx->nranks == 1 && !ctx->loopback) || !mg_transport(ctx)) return DDCMI_OK;
+   if (ctx->hcomm)
+   {
+      ctx->hstage_s.resize(n + 1);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->hstage_s.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HOSTCHK(ctx, ddcmi_rdzv_allreduce_f64(ctx->hcomm, ctx->hstage_s.data(), (int)n, 0));
+      HIPCHK(ctx, hipMemcpyAsync(d, ctx->hstage_s.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      return DDCMI_OK;
+   }
+   NCCLCHK2(ctx, ncclAllReduce(d, d, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+   return DDCMI_OK;
+}
+
 /* ---- in-process group (tests on one GPU) ----------------------------------- */
+/* the group's all-reduce: element-wise sum of one device array per domain, written back to all of them */
+static int group_sum_device(ddcmi_group *g, const std::vector<double *> &bufs, size_t n)
+{
+   if (n == 0) return DDCMI_OK;
+   std::vector<double> sum(n, 0.0), tmp(n);
+   for (size_t r = 0; r < g->ranks.size(); r++)
+   {
+      ddcmi_ctx *c = g->ranks[r];
+      HIPCHK(c, hipMemcpyAsync(tmp.data(), bufs[r], n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (size_t k = 0; k < n; k++) sum[k] += tmp[k];
+   }
+   for (size_t r = 0; r < g->ranks.size(); r++)
+   {
+      ddcmi_ctx *c = g->ranks[r];
+      HIPCHK(c, hipMemcpyAsync(bufs[r], sum.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+   }
+   return DDCMI_OK;
+}
+static int group_refresh_vel(ddcmi_group *g)
+{
+   int rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_pack_vel(c, c->stream))) return rc;
+   if ((rc = mg_xchg_data_local(g, 2))) return rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_unpack_vel(c, c->stream))) return rc;
+   return DDCMI_OK;
+}
 static int group_rebuild(ddcmi_group *g)
 {
    int rc;
@@ -717,6 +809,16 @@ static int group_rebuild(ddcmi_group *g)
    for (ddcmi_ctx *c : g->ranks) if ((rc = mg_phase3_pack(c, 5))) return rc;
    if ((rc = mg_xchg_data_local(g, 1))) return rc;
    for (ddcmi_ctx *c : g->ranks) if ((rc = mg_phase4_finish(c))) return rc;
+   {
+      ddcmi_ctx *c0 = g->ranks[0];
+      if (c0->mol_gid && c0->nmol_multi > 0)
+      {
+         std::vector<double *> bufs;
+         for (ddcmi_ctx *c : g->ranks) bufs.push_back(c->mol_info.p);
+         if ((rc = group_sum_device(g, bufs, 4 * (size_t)c0->nmol_multi))) return rc;
+      }
+      for (ddcmi_ctx *c : g->ranks) if ((rc = ddcmi_mol_split_finish(c))) return rc;
+   }
    return DDCMI_OK;
 }
 static int group_refresh(ddcmi_group *g)
@@ -771,9 +873,28 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
    for (int s = 0; s < nsteps; s++)
    {
       bool rebuild = false;
+      ddcmi_ctx *c0 = g->ranks[0];
+      const bool cons = c0->ncgroup > 0, baro = c0->baro_beta > 0.0;
+      std::vector<bool> had_drift;
+      for (ddcmi_ctx *c : g->ranks) { had_drift.push_back(c->drift_done); if ((rc = step_pre_a(c))) return rc; }
+      if (baro && !c0->drift_done)
+      {
+         /* energyInfo.c allreduce() of the barostat's inputs */
+         double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+         for (ddcmi_ctx *c : g->ranks) for (int k = 0; k < 7; k++) sum[k] += c->baro_sums[k];
+         for (ddcmi_ctx *c : g->ranks) for (int k = 0; k < 7; k++) c->baro_sums[k] = sum[k];
+         if (c0->nsplit > 0)
+         {
+            std::vector<double *> bufs;
+            for (ddcmi_ctx *c : g->ranks) bufs.push_back(c->mol_red.p);
+            if ((rc = group_sum_device(g, bufs, 6 * (size_t)c0->nsplit))) return rc;
+         }
+      }
+      for (ddcmi_ctx *c : g->ranks) if ((rc = step_pre_b(c, dt))) return rc;
+      if (cons && !had_drift[0] && (rc = group_refresh_vel(g))) return rc;
       for (ddcmi_ctx *c : g->ranks)
       {
-         if ((rc = step_pre(c, dt))) return rc;
+         if ((rc = step_pre_c(c, dt))) return rc;
          if (!c->list_valid) rebuild = true;
          else if (c->updateRate > 0) { if (c->loop % c->updateRate == 0) rebuild = true; }
          else { int need = 0; if ((rc = ddcmi_displacement_check(c, &need))) return rc; if (need) rebuild = true; }      /* check4updateNeighbor: any domain */
@@ -781,6 +902,12 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
       if (rebuild) { if ((rc = group_rebuild(g))) return rc; }
       else if ((rc = group_refresh(g))) return rc;
       for (ddcmi_ctx *c : g->ranks) if ((rc = step_post(c, dt, s + 1 < nsteps))) return rc;
+      if (cons)
+      {
+         /* BACK kick done by step_post: velocity halo, BACK solve, kinetic terms */
+         if ((rc = group_refresh_vel(g))) return rc;
+         for (ddcmi_ctx *c : g->ranks) if ((rc = step_post_cons_b(c, dt))) return rc;
+      }
    }
    return DDCMI_OK;
 }
@@ -860,13 +987,15 @@ extern "C" int ddcmi_domain_bounds(const ddcmi_ctx *ctx, double lo[3], double hi
    return DDCMI_OK;
 }
 
-/* nglfconstraint's barostat and velocity constraints are solved per domain: with several domains each rank would
- * scale its own box from its local virial and solve constraint groups without their halo partners -- silently
- * wrong physics.  Checked where the decomposition is set up AND at every step call, whatever the call order. */
+/* nglfconstraint's barostat and velocity constraints given by caller-order indices are solved per domain: with several
+ * domains each rank would scale its own box from its local virial and solve constraint groups without their halo
+ * partners -- silently wrong physics.  Checked where the decomposition is set up AND at every step call, whatever the
+ * call order.  The gid forms carry the cross-domain sums and the velocity halo. */
 static int mg_check_one_domain_features(ddcmi_ctx *ctx)
 {
-   if (ctx->nranks > 1 && (ctx->baro_beta > 0.0 || ctx->ncgroup > 0))
-      SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat and the velocity constraints (NGLFCONSTRAINT) are implemented for a single domain: %d domains", ctx->nranks);
+   if (ctx->nranks > 1 && ((ctx->baro_beta > 0.0 && !ctx->mol_gid) || (ctx->ncgroup > 0 && !ctx->cons_gid)))
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "%d domains: the barostat and the velocity constraints (NGLFCONSTRAINT) work on a single domain unless the molecules and the "
+             "constraint groups are named by gid (ddcmi_set_molecule_lists_gid, ddcmi_set_constraints_gid)", ctx->nranks);
    return DDCMI_OK;
 }
 /* RCCL bootstrap (the 128-byte id is distributed by the caller: MPI_Bcast in

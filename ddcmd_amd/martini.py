@@ -56,6 +56,8 @@ def _declare(lib):
     lib.ddcmi_set_barostat_isotropic.argtypes = [vp, ctypes.c_int]
     lib.ddcmi_set_molecule_lists.argtypes = [vp, ctypes.c_long, ctypes.c_int, _ip, _ip]
     lib.ddcmi_set_constraints.argtypes = [vp, ctypes.c_int, _ip, _ip, _ip, _dp]
+    lib.ddcmi_set_constraints_gid.argtypes = [vp, ctypes.c_int, _ip, _up, _up, _dp]
+    lib.ddcmi_set_molecule_lists_gid.argtypes = [vp, ctypes.c_long, ctypes.c_int, _ip, _up, _dp]
     lib.ddcmi_constraint_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     lib.ddcmi_set_restraints.argtypes = [vp, ctypes.c_int, _up, _ip, _dp, _dp, ctypes.c_int]
     lib.ddcmi_get_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), _dp]
@@ -361,11 +363,18 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
         self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
         if float(getattr(s, "npt_beta", 0.0)) > 0.0:      # INTEGRATOR type=NGLFCONSTRAINT: barostat on the molecular pressure
-            self.set_barostat(float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau), isotropic=bool(getattr(s, "npt_isotropic", 0)))
+            self.set_barostat(float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau), isotropic=bool(getattr(s, "npt_isotropic", 0)),
+                              by_gid=bonded_by_gid)
         if constraints:                                   # INTEGRATOR type=NGLFCONSTRAINT: velocity constraints
             self._cons = expand_constraints(s)
             po, pi, pj, dd = self._cons
-            self._chk(self.lib.ddcmi_set_constraints(self.ctx, int(po.size - 1), _i(po), _i(pi), _i(pj), _d(dd)))
+            if bonded_by_gid:                             # decomposed runs: the groups' atoms named by gid
+                gids = np.asarray(s.gid, dtype=np.uint64)
+                self._cons_gid = (np.ascontiguousarray(gids[pi]), np.ascontiguousarray(gids[pj]))
+                self._chk(self.lib.ddcmi_set_constraints_gid(self.ctx, int(po.size - 1), _i(po), self._cons_gid[0].ctypes.data_as(_up),
+                                                             self._cons_gid[1].ctypes.data_as(_up), _d(dd)))
+            else:
+                self._chk(self.lib.ddcmi_set_constraints(self.ctx, int(po.size - 1), _i(po), _i(pi), _i(pj), _d(dd)))
         nrest = int(getattr(s, "nrest", 0))
         if nrest > 0:     # RESTRAINT potential
             self._rest = (np.ascontiguousarray(s.rest_gid, dtype=np.uint64), i32(np.asarray(s.rest_fc).ravel()),
@@ -428,12 +437,20 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
         return rk.value, t
 
-    def set_barostat(self, T, P0, beta, tau, isotropic=False):
-        """nglfconstraint's Berendsen barostat (isotropic: NGLFGPULANGEVIN's); the molecule lists feed its molecular virial"""
+    def set_barostat(self, T, P0, beta, tau, isotropic=False, by_gid=False):
+        """nglfconstraint's Berendsen barostat (isotropic: NGLFGPULANGEVIN's); the molecule lists feed its molecular virial
+        (by_gid: atoms named by gid + the molecules' masses, for decomposed runs)"""
+        nmol, off, atoms = self._mols = molecule_lists(self.s)
+        if by_gid:
+            gids = np.ascontiguousarray(np.asarray(self.s.gid, dtype=np.uint64)[atoms]) if atoms.size else np.zeros(1, np.uint64)
+            m_at = np.asarray(self.s.mass, dtype=np.float64)[np.asarray(self.s.species)[atoms]] if atoms.size else np.zeros(0)
+            mtot = np.ascontiguousarray(np.add.reduceat(m_at, off[:-1])) if off.size > 1 else np.zeros(1)
+            self._mol_gid = (gids, mtot)
+            self._chk(self.lib.ddcmi_set_molecule_lists_gid(self.ctx, nmol, int(off.size - 1), _i(off), gids.ctypes.data_as(_up), _d(mtot)))
+        else:
+            self._chk(self.lib.ddcmi_set_molecule_lists(self.ctx, nmol, int(off.size - 1), _i(off), _i(atoms if atoms.size else np.zeros(1, np.int32))))
         self._chk(self.lib.ddcmi_set_barostat(self.ctx, float(T), float(P0), float(beta), float(tau)))
         self._chk(self.lib.ddcmi_set_barostat_isotropic(self.ctx, int(bool(isotropic))))
-        nmol, off, atoms = self._mols = molecule_lists(self.s)
-        self._chk(self.lib.ddcmi_set_molecule_lists(self.ctx, nmol, int(off.size - 1), _i(off), _i(atoms if atoms.size else np.zeros(1, np.int32))))
 
     def constraint_stats(self, reset=True):
         a, b = ctypes.c_int(0), ctypes.c_int(0)
@@ -559,8 +576,8 @@ class DomainMixin(object):
 class MartiniRank(MartiniHIP, DomainMixin):
     """One rank of a decomposed run: uploads only the beads `index` selects."""
 
-    def __init__(self, setup, index, device=0):
-        MartiniHIP.__init__(self, setup, device=device, upload=False, bonded_by_gid=True)
+    def __init__(self, setup, index, device=0, constraints=False):
+        MartiniHIP.__init__(self, setup, device=device, upload=False, bonded_by_gid=True, constraints=constraints)
         self.index = np.asarray(index)
 
     def upload_local(self):
@@ -592,12 +609,12 @@ class MartiniGroup(object):
     """px*py*pz domains emulated inside one process on one GPU (device copies
     instead of RCCL): exercises migration, halo tables and per-step halo refresh."""
 
-    def __init__(self, setup, grid, device=0):
+    def __init__(self, setup, grid, device=0, constraints=False):
         self.s = setup
         self.grid = tuple(grid)
         self.n = grid[0] * grid[1] * grid[2]
         owner = domain_of(setup, grid)
-        self.ranks = [MartiniRank(setup, select_rank(setup, owner, r), device=device) for r in range(self.n)]
+        self.ranks = [MartiniRank(setup, select_rank(setup, owner, r), device=device, constraints=constraints) for r in range(self.n)]
         self.lib = self.ranks[0].lib
         _declare_domains(self.lib)
         self.arr = (ctypes.c_void_p * self.n)(*[r.ctx for r in self.ranks])

@@ -106,8 +106,8 @@ int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *
 /* INTEGRATOR type=NGLFCONSTRAINT (nglfconstraint.c:510-574): NGLF plus a semi-isotropic Berendsen
  * barostat (changeVolume, :64-84) driven by the molecular pressure of the last force evaluation at the
  * target temperature T: lambda_xy = cbrt(1 + beta dt/tau ((Pxx+Pyy)/2 - P0)), lambda_z likewise from Pzz;
- * box and positions scaled before the FRONT kick.  beta = 0 switches it off.  One domain; costs one host
- * round trip per step.  Without ddcmi_set_molecule_lists every bead is its own molecule.  Internal units. */
+ * box and positions scaled before the FRONT kick.  beta = 0 switches it off.  Costs one host round trip per step
+ * (decomposed runs: one all-reduce of the virial and the molecular terms, ddcmi_set_molecule_lists_gid).  Without ddcmi_set_molecule_lists every bead is its own molecule.  Internal units. */
 int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau);
 /* on: ONE scale factor for the three axes, from the mean of Pxx, Pyy, Pzz -- what the reference's GPU integrator
  * NGLFGPULANGEVIN applies (changeVolumeGPUisotropic, molecularPressureGPU.cu:204-239); off (default): changeVolume's
@@ -121,14 +121,26 @@ int ddcmi_get_barostat_pressure(const ddcmi_ctx *ctx, double p[3]);
  * nmol_total = N in the N kB T term; the nmulti molecules of two or more beads are listed as caller-order
  * atom indices, molecule m = mol_atoms[mol_off[m] .. mol_off[m+1]).  One domain. */
 int ddcmi_set_molecule_lists(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const int *mol_atoms);
+/* The same with atoms named by gid, for decomposed runs (every rank passes the GLOBAL lists; mol_mass[m] = total mass of
+ * molecule m).  Beads migrate one by one, so a molecule may have atoms on several ranks: each rank sums over the atoms it
+ * owns; the centre of mass and total force of such SPLIT molecules are completed by an all-reduce of six doubles per split
+ * molecule in every step the barostat acts, together with the virial.  No limit on the molecule's extent. */
+int ddcmi_set_molecule_lists_gid(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const uint64_t *mol_atom_gid, const double *mol_mass);
 /* nglfconstraint's velocity constraints (velocityConstraintOld/resMoveConsOld, nglfconstraint.c:180-264,
  * 438-455; groups from genConstraint, bioMartini.c:300-445).  Group g holds the pairs
  * [pair_off[g], pair_off[g+1]) in the order the reference sweeps them; pairI/pairJ are caller-order atom
  * indices, dist the constrained lengths (internal units).  Groups must not share atoms.  With groups set,
  * every step runs FRONT kick -> constraint ((r + dt v)^2 = d^2) -> drift -> forces -> BACK kick ->
  * constraint (r.v = 0) -> kinetic terms.  Gauss-Seidel sweeps to |rvab dt| < 1e-12, at most 500, as the
- * reference.  The constraint virial is not booked (the reference computes and drops it).  One domain. */
+ * reference.  The constraint virial is not booked (the reference computes and drops it).  Caller-order indices: one domain
+ * (decomposed runs: ddcmi_set_constraints_gid). */
 int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const int *pairI, const int *pairJ, const double *dist);
+/* The same groups with atoms named by gid, for decomposed runs (every rank passes the GLOBAL list): at each rebuild a rank
+ * finds the owned or halo copy of every group atom; a rank that owns an atom of a group solves the whole group -- positions of
+ * the partners from the position halo, their velocities from a velocity halo exchanged before each of the two solves of a
+ * step -- and keeps the velocities of the atoms it owns.  A partner further than rmax+deltaR from the owning domain is an
+ * error at the rebuild. */
+int ddcmi_set_constraints_gid(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const uint64_t *pairI, const uint64_t *pairJ, const double *dist);
 /* largest sweep count of any group since the last reset, and how many group solves hit the 500-sweep cap */
 int ddcmi_constraint_stats(ddcmi_ctx *ctx, int *max_sweeps, int *unconverged, int reset);
 /* RANDOM seed (random.c:44-60) for the Langevin noise */

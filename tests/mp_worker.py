@@ -18,14 +18,23 @@ def main():
     from ddcmd_amd.martini import MartiniRank, Rendezvous, domain_of, _declare_domains
     rdzv = Rendezvous.from_env(timeout=120.0)
     rank, world = rdzv.rank, rdzv.world
+    cons = False
     if workload == "water":
         s = ddcmd_amd.make_water_setup(12)
     else:
-        from ddcmd_amd.deck import load_deck
+        from ddcmd_amd.deck import load_deck, units_convert
         deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
-        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+        extra = None
+        if workload == "lipid_npt":          # the full nglfconstraint step: constraint lists + barostat on the molecular pressure
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            extra = os.environ["DDCMI_TEST_CONSTRAINT_X"]
+            cons = True
+        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=extra)
+        if cons:
+            s.npt_T, s.npt_P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
+            s.npt_beta, s.npt_tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
     owner = domain_of(s, grid)
-    m = MartiniRank(s, np.flatnonzero(owner == rank), device=0)
+    m = MartiniRank(s, np.flatnonzero(owner == rank), device=0, constraints=cons)
     _declare_domains(m.lib)
     if os.environ.get("DDCMI_TRANSPORT", "host") == "host":
         m.comm_init_host(rdzv, grid)
@@ -45,6 +54,7 @@ def main():
         Tg.append(m.group_temperatures().copy())
     done = 0
     traj = []
+    baro = []
     while done < nsteps:
         k = min(block, nsteps - done)
         m.step(k)
@@ -52,10 +62,12 @@ def main():
         e, vir, rk, tion = m.energies()
         tot = m.allreduce([e["total"], rk] + list(vir))              # energyInfo.c allreduce() over the transport
         traj.append(tot)
+        if cons:
+            baro.append(np.concatenate((m.barostat_pressure(), m.box())))
         if Tg:
             Tg.append(m.group_temperatures().copy())
     p = m.download_particles()
-    rec.update(gid=p["gid"], r=np.stack(p["r"]), v=np.stack(p["v"]), f=np.stack(p["f"]), traj=np.array(traj), Tg=np.array(Tg),
+    rec.update(gid=p["gid"], r=np.stack(p["r"]), v=np.stack(p["v"]), f=np.stack(p["f"]), traj=np.array(traj), Tg=np.array(Tg), baro=np.array(baro),
                nloc=np.array([n0, int(m.lib.ddcmi_nlocal(m.ctx))]), rebuilds=np.array([m.list_stats()["rebuilds"]]))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **rec)
     m.close()

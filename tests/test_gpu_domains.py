@@ -8,6 +8,7 @@ import pyoracle
 import ddcmd_amd
 from ddcmd_amd.synth import make_water_setup
 from conftest import rel_force_err
+from ddcmd_amd.deck import units_convert
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -226,16 +227,21 @@ def test_decomposed_restraints():
     g.close()
 
 
-def test_npt_and_constraints_are_refused_on_several_domains(monkeypatch):
-    """the barostat / velocity constraints set BEFORE the decomposition (the order MartiniRank uses) must not slip
-    through: each rank would scale its own box from its local virial"""
+def test_index_based_npt_and_constraints_are_refused_on_several_domains(monkeypatch):
+    """the barostat / velocity constraints given by caller-order indices and set BEFORE the decomposition must not slip
+    through: each rank would scale its own box from its local virial.  The gid forms (what MartiniRank uses)
+    carry the cross-domain sums and are accepted: test_decomposed_barostat_... below"""
     import ctypes
-    from ddcmd_amd.martini import MartiniRank, MartiniGroup, DdcmiError, _declare_domains
+    from ddcmd_amd.martini import MartiniHIP, MartiniRank, _declare_domains
     s = make_water_setup(10)
     s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = 1e-3, 0.0, 1e-3, 1000.0
-    with pytest.raises(DdcmiError) as ei:
-        MartiniGroup(s, (2, 1, 1))
-    assert "single domain" in str(ei.value)
+    a, b = MartiniHIP(s, upload=False), MartiniHIP(s, upload=False)          # molecule lists by index
+    _declare_domains(a.lib)
+    arr = (ctypes.c_void_p * 2)(a.ctx, b.ctx)
+    assert a.lib.ddcmi_group_create(arr, 2, 2, 1, 1) == -4                   # DDCMI_EUNSUPPORTED
+    assert b"named by gid" in a.lib.ddcmi_last_error(a.ctx)
+    a.lib.ddcmi_group_destroy(arr, 2)
+    a.close(); b.close()
     # RCCL path, one rank in loopback mode is still ONE domain: accepted
     monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
     m = MartiniRank(s, np.arange(s.natoms))
@@ -244,3 +250,104 @@ def test_npt_and_constraints_are_refused_on_several_domains(monkeypatch):
     assert m.lib.ddcmi_comm_unique_id(buf) == 0
     m.comm_init(0, 1, buf.raw, (1, 1, 1))
     m.close()
+
+
+def _relaxed_lipid(extra=None):
+    from ddcmd_amd.deck import load_deck
+    deck = os.path.dirname(LIPID_DECK)
+    return load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=extra)
+
+
+def _check_constrained_state(s, st, o, pi_gid, pj_gid, dd, box, tag):
+    """st: gathered state ordered by gid; constrained pairs keep their length and have no relative velocity along the pair"""
+    order = np.argsort(np.asarray(s.gid, dtype=np.uint64), kind="stable")          # caller order -> gid order
+    rank_of = np.empty(s.natoms, np.int64)
+    rank_of[order] = np.arange(s.natoms)
+    pi, pj = rank_of[pi_gid], rank_of[pj_gid]
+    r, v = st["r"], st["v"]
+    d = np.stack([r[c][pi] - r[c][pj] for c in range(3)], axis=1)
+    d -= box * np.rint(d / box)
+    assert np.abs(np.sqrt((d * d).sum(axis=1)) / dd - 1.0).max() < 1e-10, tag
+    w = np.stack([v[c][pi] - v[c][pj] for c in range(3)], axis=1)
+    assert np.abs((d * w).sum(axis=1) * s.dt / dd ** 2).max() < 1e-10, tag
+    for c, (ro, vo_) in enumerate(((o.rx, o.vx), (o.ry, o.vy), (o.rz, o.vz))):
+        dr = r[c] - ro[order]
+        dr -= box[c] * np.rint(dr / box[c])
+        assert np.abs(dr).max() < 1e-7 * box[c], (tag, c)
+        assert np.abs(v[c] - vo_[order]).max() < 1e-6 * np.abs(vo_).max(), (tag, c)
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
+def test_decomposed_velocity_constraints_match_oracle(grid):
+    """nglfconstraint's velocity constraints across domain faces (nglfconstraint.c:180-264, 510-574): groups named by gid,
+    every rank that owns an atom of a group solves the whole group with the partners' positions from the position halo and
+    their velocities from the velocity halo (exchanged before the FRONT and before the BACK solve), and keeps its own atoms"""
+    from ddcmd_amd.martini import MartiniGroup, expand_constraints
+    from test_oracle import CONSTRAINT_X
+    s = _relaxed_lipid(CONSTRAINT_X)
+    po, pi, pj, dd = expand_constraints(s)
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    g = MartiniGroup(s, grid, constraints=True)
+    g.eval_forces()
+    o.group_temperature()
+    g.group_temperatures()
+    box = s.box
+    for block in range(4):
+        eo, vo, rko, tio = o.step(5)
+        g.step(5 if block % 2 else 1)
+        if block % 2 == 0:
+            g.step(4)
+        o.group_temperature()
+        g.group_temperatures()
+        e, vir, rk, tion = g.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko, block
+        assert np.abs(vir - vo).max() < TOL * np.abs(vo).max(), block
+        assert np.abs(tion - tio).max() < TOL * np.abs(tio).max(), block
+        st = g.gather()
+        assert np.array_equal(st["gid"], np.sort(s.gid))
+        _check_constrained_state(s, st, o, pi, pj, dd, box, block)
+    worst = [r.constraint_stats() for r in g.ranks]
+    assert all(bad == 0 for _, bad in worst) and max(sw for sw, _ in worst) > 1
+    g.close()
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 1, 2), (2, 2, 2)])
+def test_decomposed_barostat_with_molecular_virial_and_constraints(grid):
+    """the full nglfconstraint step on several domains: the barostat acts on the MOLECULAR pressure, whose intramolecular
+    term needs every molecule's centre of mass and total force -- lipids reach across domain faces, so the ranks' partial
+    sums of such split molecules are all-reduced with the virial every step (molecularPressure.c:22-67); every domain
+    scales its box with the same factors"""
+    from ddcmd_amd.martini import MartiniGroup
+    from test_oracle import CONSTRAINT_X
+    s = _relaxed_lipid(CONSTRAINT_X)
+    T = units_convert(310.0, "K")
+    P0 = units_convert(1.0, "bar")
+    beta = units_convert(3.0e-4, "1/bar") * 20.0
+    tau = units_convert(1.0, "ps")
+    s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = T, P0, beta, tau
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    g = MartiniGroup(s, grid, constraints=True)
+    g.eval_forces()
+    o.group_temperature()
+    g.group_temperatures()
+    L0 = g.ranks[0].box().copy()
+    nsplit = None
+    for block in range(3):
+        eo, vo, rko, _ = o.step_npt(5, T, P0, beta, tau, molecular=True)
+        g.step(5 if block % 2 else 2)
+        if block % 2 == 0:
+            g.step(3)
+        o.group_temperature()
+        g.group_temperatures()
+        e, vir, rk, _ = g.energies()
+        for r in g.ranks:                # every domain holds the same pressure and the same box
+            assert np.abs(r.barostat_pressure() - o.pmol).max() < 1e-8 * np.abs(o.pmol).max(), block
+            assert np.abs(r.box() - o.box).max() < 1e-10 * o.box.max(), block
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko
+        assert np.abs(vir - vo).max() < TOL * np.abs(vo).max()
+    assert np.abs(g.ranks[0].box() - L0).max() > 1e-5 * L0.max()
+    g.close()

@@ -19,6 +19,7 @@ import pytest
 import pyoracle
 import ddcmd_amd
 from conftest import rel_force_err
+from ddcmd_amd.deck import units_convert
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -141,3 +142,32 @@ def test_bench_world2_as_the_driver_launches_it():
     one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
     assert abs(out["check"]["epot"] - one["check"]["epot"]) < 1e-7 * abs(one["check"]["epot"])
     assert abs(out["check"]["ekin"] - one["check"]["ekin"]) < 1e-7 * abs(one["check"]["ekin"])
+
+
+def test_nglfconstraint_between_processes():
+    """constraints + barostat with the ranks in separate processes: velocity halo and the barostat's all-reduce (incl. the
+    split molecules' partial sums) travel over the transport; both processes arrive at the oracle's box and pressure"""
+    from test_oracle import CONSTRAINT_X
+    from ddcmd_amd.deck import load_deck
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=CONSTRAINT_X)
+    T, P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
+    beta, tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    o.group_temperature()
+    os.environ["DDCMI_TEST_CONSTRAINT_X"] = CONSTRAINT_X
+    try:
+        recs = _run_ranks("lipid_npt", (2, 1, 1), 15, 5)
+    finally:
+        os.environ.pop("DDCMI_TEST_CONSTRAINT_X", None)
+    for b in range(3):
+        eo, vo, rko, _ = o.step_npt(5, T, P0, beta, tau, molecular=True)
+        o.group_temperature()
+        for r in recs:
+            assert abs(r["traj"][b][0] - eo["total"]) < 1e-6 * abs(eo["total"])
+            assert abs(r["traj"][b][1] - rko) < 1e-6 * rko
+            assert np.abs(r["baro"][b][:3] - o.pmol).max() < 1e-8 * np.abs(o.pmol).max()
+            assert np.abs(r["baro"][b][3:] - o.box).max() < 1e-10 * o.box.max()
+    gid, _ = _merge(recs, "gid", "f")
+    assert np.array_equal(gid, np.sort(s.gid))

@@ -80,3 +80,44 @@ def test_lipid_deck_through_rccl_loopback(monkeypatch):
         o.group_temperature()
         m.group_temperatures()
     m.close()
+
+
+def test_nglfconstraint_through_rccl_loopback(monkeypatch):
+    """constraint groups and molecules named by gid over the RCCL wire: the velocity halo before each constraint solve and the
+    all-reduce of the barostat's sums (virial, molecular term, split-molecule {P, F}) are real RCCL calls"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle import CONSTRAINT_X
+    from ddcmd_amd.deck import load_deck, units_convert
+    from ddcmd_amd.martini import MartiniRank, _declare_domains
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=CONSTRAINT_X)
+    T, P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
+    beta, tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
+    s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = T, P0, beta, tau
+    o = pyoracle.Oracle(s, constraints=True)
+    o.forces()
+    o.group_temperature()
+    monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
+    monkeypatch.setenv("DDCMI_HALO_OVERLAP", "0")
+    m = MartiniRank(s, np.arange(s.natoms), constraints=True)
+    _declare_domains(m.lib)
+    buf = ctypes.create_string_buffer(128)
+    assert m.lib.ddcmi_comm_unique_id(buf) == 0
+    m.comm_init(0, 1, buf.raw, (1, 1, 1))
+    m.upload_local()
+    m.eval_forces()
+    m.group_temperatures()
+    for block in range(3):
+        eo, vo, rko, _ = o.step_npt(5, T, P0, beta, tau, molecular=True)
+        m.step(5)
+        o.group_temperature()
+        m.group_temperatures()
+        e, vir, rk, _ = m.energies()
+        assert np.abs(m.barostat_pressure() - o.pmol).max() < 1e-8 * np.abs(o.pmol).max(), block
+        assert np.abs(m.box() - o.box).max() < 1e-10 * o.box.max(), block
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko
+    sweeps, bad = m.constraint_stats()
+    assert bad == 0 and sweeps > 1
+    m.close()
