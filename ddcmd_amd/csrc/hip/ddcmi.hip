@@ -789,18 +789,30 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
 
 /* ------------------------------------------------------------------------- */
 /* THE hot kernel: martiniNonBond (bioMartini.c:989-1122) + martiniIntraMoleReaction
- * (:1124-1208) over the full list.  One lane per owned atom; the ELL list is
- * slot-major so a wave reads 256 contiguous bytes per slot; neighbour records
- * are gathered from L1/L2 (cell-sorted => local).  The LJ table sits in LDS.
+ * (:1124-1208) over the full list.
  *
- *   ir   = 1/sqrt(r2)           (v_rsq_f32 seed + 2 Newton steps: full FP64)
- *   s2   = sigma^2 ir^2 ; s6 = s2^3 ; s12 = s6^2
- *   vLJ += 4eps(s12-s6)+shift ; dvdr = 24eps(s6-2s12) ir^2
- *   vEle+= kqij(ir + krf r2 - crf) ; dvdr += kqij(2krf - ir^3)
- *   f_i -= dvdr d ;  virial += f (x) d
- */
-/* 5 waves per tile: a tile holds 256 beads on average, so 256-thread workgroups
- * would make every second tile take a second, mostly idle pass */
+ * One 512-thread workgroup per WORK ITEM: a tile (8x4x4 cells, ~500 owned beads) or, in the last round of a
+ * launch, one of several row ranges of a tile (schedule_tiles).  Two workgroups per CU (72 KB of LDS each).
+ *   1. staging: the tile's neighbourhood (the 12x8x8 cells around it, ~3000 beads, owned and image/halo alike)
+ *      goes to LDS as z[] and {x,y}[] (24 B per bead).  Its order is the list build's: region cells in raster
+ *      order; the global index of a staged slot comes from the cell tables, not from a per-tile index list.
+ *      Slot 0 is a sentinel bead at 1e30: list padding points at it, so the walk has no validity masks.
+ *   2. walk: one wave per chunk of R rows, one lane per bead (R = 64 for a full tile; thin tiles and row parts
+ *      give each bead 64/R lanes that split its list).  List entries are 16 bits, (staged slot + 1) << 4 | type
+ *      [| shifted-copy bit], stored per tile as [group of 8 slots][row][8]: one 16-byte load per lane and group,
+ *      kept two groups ahead.  Per slot: two LDS gathers by raw byte offset, the distance test, and under it
+ *        ir2  = 1/r2   (v_rcp_f32 seed + 2 Newton steps; with charges ir = 1/sqrt(r2) from v_rsq_f32)
+ *        s2   = sigma^2 ir2 ; s6 = s2^3 ; s12 = s6^2
+ *        vLJ += 4eps(s12-s6)+shift ; dvdr = 24eps(s6-2s12) ir2
+ *        vEle+= kqij(ir + krf r2 - crf) ; dvdr += kqij(2krf - ir^3)       (kqij from the type-pair table)
+ *        f_i -= dvdr d
+ *      Rows are ordered by distance shell at build time, so late groups are rejected by whole waves.
+ *   3. excluded same-molecule pairs (charged systems): reaction-field term only, from a short global list.
+ *   4. the bead's force is stored (full list: no atomics, no force return); energy and virial partial sums of the
+ *      item go to partials[item][8].  Virial: 2 F_i (x) r_i per bead for unshifted partners, per pair for
+ *      shifted copies and excluded pairs (see below).
+ * Bound: FP64 issue and LDS gathers behind s_waitcnt at 4 waves per SIMD -- DESIGN.md section 4 has the
+ * counters, the ablations and the per-CU timelines. */
 #ifdef DDCMI_TRACE_BLOCKS
 /* tuning builds only (tools/build_variants.sh): per-workgroup timeline of k_nonbond */
 __device__ unsigned long long g_trace[8 * 65536];
@@ -2927,13 +2939,37 @@ int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need)
    *need = 1;
    if (!ctx->list_valid || ctx->pos0.cap < (size_t)n) return DDCMI_OK;
    *need = 0;
-   if (n == 0) return DDCMI_OK;
+   if (n == 0)
+   {
+      if (decomposed(ctx) && !ctx->group_) { double z[4] = {0, 0, 0, 0}; return mg_allreduce_host_values(ctx, z, 4); }      /* an empty domain still takes part in the collective */
+      return DDCMI_OK;
+   }
    ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
    ENSURE(ctx, ctx->disp, 16);
    HIPCHK(ctx, hipMemsetAsync(ctx->disp.p, 0, 16 * sizeof(double), st));
    hipLaunchKernelGGL(k_disp_sum, dim3(nblk), dim3(DDCMI_BLOCK), 0, st, n, ctx->pos.p, ctx->pos0.p, ctx->kpartials.p);
    RedJob js = {ctx->kpartials.p, nblk, 3, ctx->disp.p, 0};
    hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, st, js, js, ctx->d_results, 0.0, ctx->red_tmp.p);
+   if (decomposed(ctx))
+   {
+      /* neighborCheck measures every particle of a rank -- halo included -- against ONE mean displacement; here a rank
+       * sees only its owned beads, and domains that each subtracted their own centroid would never count the drift of
+       * one domain against its neighbour (shear, flow across a face).  With a transport the mean is the global one
+       * (all-reduced sums); an in-process group subtracts nothing (conservative: a uniform drift then costs rebuilds,
+       * never a stale list). */
+      double hs[4] = {0, 0, 0, 0};
+      if (!ctx->group_)
+      {
+         HIPCHK(ctx, hipMemcpyAsync(hs, ctx->disp.p, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+         HIPCHK(ctx, hipStreamSynchronize(st));
+         hs[3] = (double)n;
+         int rca = mg_allreduce_host_values(ctx, hs, 4);
+         if (rca) return rca;
+         const double w = hs[3] > 0.0 ? (double)n / hs[3] : 0.0;      /* k_disp_max divides by this rank's bead count */
+         for (int k = 0; k < 3; k++) hs[k] *= w;
+      }
+      HIPCHK(ctx, hipMemcpyAsync(ctx->disp.p, hs, 3 * sizeof(double), hipMemcpyHostToDevice, st));
+   }
    hipLaunchKernelGGL(k_disp_max, dim3(nblk), dim3(DDCMI_BLOCK), 0, st, n, ctx->pos.p, ctx->pos0.p, ctx->disp.p, (unsigned long long *)(ctx->disp.p + 4));
    double d2max = 0.0;
    HIPCHK(ctx, hipMemcpyAsync(&d2max, ctx->disp.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
