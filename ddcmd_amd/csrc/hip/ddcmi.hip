@@ -352,7 +352,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ, const unsigned long long *exmask,
-                                                            int maxexcl, int *excl, int *excl_cnt, int *flags, unsigned long long *totals)
+                                                            int maxexcl, int *excl, unsigned short *excl16, int *excl_cnt, int *flags, unsigned long long *totals)
 {
    /* LDS image of the neighbourhood: positions relative to the tile centre in single precision + the
     * low tag word (16 B per bead, one ds_read_b128 per candidate) and the molecule ids (4 B).  The
@@ -578,7 +578,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      }
                      if (pruned)
                      {
-                        if (ecnt < maxexcl) excl[(size_t)ecnt * npad + a] = sidx[sj];
+                        if (ecnt < maxexcl)
+                        {
+                           excl[(size_t)ecnt * npad + a] = sidx[sj];      /* global index: list export */
+                           /* the pair kernel finds the partner among the staged beads (same molecule: always inside the tile's
+                            * neighbourhood): an entry in the list's own format */
+                           excl16[(size_t)ecnt * npad + a] = (unsigned short)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1);
+                        }
                         ecnt++;
                      }
                      else
@@ -827,7 +833,7 @@ extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
 template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
-                                                         const int *__restrict__ excl, const int *__restrict__ excl_cnt,
+                                                         const unsigned short *__restrict__ excl16, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
                                                          double rc2, double krf, double crf, double keR,
                                                          double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz,
@@ -1185,13 +1191,18 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             int ecnt = (active && sub == 0) ? excl_cnt[a] : 0;
             for (int k = 0; k < ecnt; k++)
             {
-               int j = excl[(size_t)k * npad + a];
-               double4 pj = pos[j];
-               double x = pi.x - pj.x, y = pi.y - pj.y, z = pi.z - pj.z;
+               /* the partner out of LDS, like a list entry (a global gather per excluded pair at the end of every wave was a
+                * memory round trip nothing overlapped) */
+               const unsigned e16 = excl16[(size_t)k * npad + a];
+               const unsigned oe = PACKED ? (e16 & 0xfff0u) : (e16 << 4);
+               const xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + oe);
+               const double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(oe >> 1);
+               const int tje = PACKED ? (SHBIT ? (int)(e16 & 7u) : (int)(e16 & 0xfu)) : (int)T_s[oe >> 4];
+               double x = pi.x - pxy.x, y = pi.y - pxy.y, z = pi.z - pz;
                double r2 = x * x + y * y + z * z;
                if (r2 < rc2)
                {
-                  double kqij = s_kq[ti * nlj + (int)(__double_as_longlong(pj.w) & 0xffll)];
+                  double kqij = s_kq[ti * nlj + tje];
                   acc[1] += kqij * (krf * r2 - crf);
                   double dvdr = kqij * (2.0 * krf);
                   double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
@@ -1736,7 +1747,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : {&ctx->cg_atom_off, &ctx->cg_atoms, &ctx->cg_pair_off, &ctx->cons_status, &ctx->mol_off, &ctx->mol_atoms}) b->release();
    ctx->cg_pa.release(); ctx->cg_pb.release();
    for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->slot_of_atom, &ctx->hvals}) b->release();
-   ctx->tile_base.release(); ctx->nbr16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->excl16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
@@ -2475,6 +2486,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
+      if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
       HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
       ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
@@ -2491,7 +2503,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
-                         ctx->maxexcl, ctx->excl.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+                         ctx->maxexcl, ctx->excl.p, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       {
          size_t lds2 = (size_t)TR_ROWS * (ctx->tmpw | 1) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
          if (lds2 > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "lists of %d entries per bead do not fit the transpose kernel's LDS", ctx->tmpw);
@@ -2602,7 +2614,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
 #define LAUNCH_NB(Q, P, S, NT) do { \
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
          hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
-                            ctx->excl.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
+                            ctx->excl16.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
       /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
