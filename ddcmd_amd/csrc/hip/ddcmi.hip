@@ -848,8 +848,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    /* charges: a bead's "type" is its (LJ type, charge) class, so ke/eps_r q_i q_j is one more
     * per-type-pair table entry -- no per-bead charge array in LDS (it cost 8 B/bead: one
     * workgroup per CU instead of two) and no charge gather per pair */
-   double *s_kq = (double *)(s_lj + ta.nlj * ta.nlj);
-   unsigned char *T_s = (unsigned char *)(s_kq + (HAS_Q ? ta.nlj * ta.nlj : 0));
+   unsigned char *T_s = (unsigned char *)(s_lj + ta.nlj * ta.nlj);
    unsigned char *S_s = T_s + (PACKED ? 0 : ta.cap);      /* 1: the staged bead is a periodically shifted copy */
    /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
     * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
@@ -895,7 +894,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    }
    if (nown > 0)
    {
-      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) { s_lj[k] = ljtab[k]; if (HAS_Q) s_kq[k] = kqtab[k]; }
+      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) { double4 e_ = ljtab[k]; if (HAS_Q) e_.w = kqtab[k]; s_lj[k] = e_; }
       int ns = ta.tile_nstage[t];
       /* Virial.  A pair of two unshifted beads contributes f_ij (x) (r_i - r_j) from i's side and
        * the mirror term from j's side; the two add up to 2 f_ij (x) r_i + 2 f_ji (x) r_j, so each
@@ -1123,10 +1122,11 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   double s6 = s4 * s2; \
                   double s12 = s6 * s6; \
                   acc[0] += lj.y * (s12 - s6) + lj.z; \
-                  double dvdr = lj.w * (s6 - 2.0 * s12) * ir2; \
+                  /* charged systems: the table's fourth entry is ke/eps_r q_i q_j (24 eps = 6 x 4 eps is formed here): one LDS read per pair less */ \
+                  double dvdr = (HAS_Q ? 6.0 * lj.y : lj.w) * (s6 - 2.0 * s12) * ir2; \
                   if (HAS_Q) \
                   { \
-                     double kqij = s_kq[ti * nlj + tjj]; \
+                     double kqij = lj.w; \
                      acc[1] += kqij * (ir + krf * r2[u] - crf); \
                      dvdr += kqij * (2.0 * krf - ir2 * ir); \
                   } \
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                double r2 = x * x + y * y + z * z;
                if (r2 < rc2)
                {
-                  double kqij = s_kq[ti * nlj + tje];
+                  double kqij = s_lj[ti * nlj + tje].w;
                   acc[1] += kqij * (krf * r2 - crf);
                   double dvdr = kqij * (2.0 * krf);
                   double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;
@@ -2537,7 +2537,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    {
       /* workgroups of k_nonbond a CU holds: its LDS image of a neighbourhood (launch_forces), at most two by registers */
       const size_t capl = (size_t)ctx->stage_cap + 2;
-      const size_t lds_nb = capl * 24 + (size_t)ctx->nnb * ctx->nnb * (sizeof(double4) + (ctx->has_charge ? sizeof(double) : 0)) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
+      const size_t lds_nb = capl * 24 + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
       int rcs = schedule_tiles(ctx, (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_nb, 1))));
       if (rcs) return rcs;
    }
@@ -2601,7 +2601,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       bool packed = ctx->pack_type != 0;
       const bool shbit = ctx->pack_type == 2;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
-      size_t lds = capl * 24 + (size_t)ctx->nnb * ctx->nnb * (sizeof(double4) + (useq ? sizeof(double) : 0)) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
+      size_t lds = capl * 24 + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nnb;
