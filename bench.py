@@ -7,7 +7,9 @@ One "step" is one NGLF velocity-Verlet step of the whole box (half kick, drift,
 image refresh, nonbonded + bonded forces with energy and virial, half kick +
 kinetic terms; neighbour-list rebuild every 20 steps inside the timed region).
 Workload at N=1: BASELINE.json's headline config, the 4.0M-bead Martini water
-box (FCC n=100 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM.
+box (FCC n=100 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM;
+200 untimed steps in front of the warm-up melt the lattice start (50 K) into the
+liquid (~307 K), so the timed steps see production list lengths.
 Prints ONE JSON line (rank 0).  `roofline` prices the nonbonded kernel with the
 ALGORITHMIC bytes of SURVEY 8(d): (36 + 24 + 4*L) B per atom-step, L = stored
 full-list entries per atom, over the HIP-event time of that kernel measured on
@@ -116,6 +118,9 @@ def main():
     ap.add_argument("--rccl-loopback", action="store_true",
                     help="N=1 only: reach the periodic images through a 1-rank RCCL communicator (the multi-GPU transport on one GPU)")
     ap.add_argument("--reps", default="12,12,6", help="lipid workload: copies of the 2363-bead deck along x,y,z (12,12,6 -> 2.04M beads)")
+    ap.add_argument("--equil", type=int, default=-1,
+                    help="untimed steps in front of the warm-up that take the synthetic water box from its lattice start (50 K, FCC + jitter) to its "
+                         "liquid state (~307 K after 200 steps): default 200 for water, 0 for the lipid deck (a relaxed restart)")
     ap.add_argument("--check-runtime", action="store_true", help="rendezvous + library load only: print which HIP/RCCL runtime is mapped, touch no device")
     args = ap.parse_args()
 
@@ -194,6 +199,14 @@ def main():
     thermostat = any(int(t) == 1 for t in np.asarray(s.group_type).ravel())
     if thermostat:
         m.group_temperatures()            # the temperature Berendsen scales with (published by eval_energyInfo in the reference)
+    equil = args.equil if args.equil >= 0 else (200 if args.workload == "water" else 0)
+    done = 0
+    while done < equil:                   # (in rebuild periods, so that a Berendsen group sees its temperature as in a production run)
+        k = min(20, equil - done)
+        m.step(k)
+        done += k
+        if thermostat:
+            m.group_temperatures()
     m.step(args.warmup)
     if thermostat:
         m.group_temperatures()
@@ -253,7 +266,7 @@ def main():
                    "rcut_A": float(ddcmd_amd.units_convert(s.rmax, None, "Angstrom")), "skin_A": float(ddcmd_amd.units_convert(s.deltaR, None, "Angstrom")),
                    "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
                    "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
-                   "energy_virial_every_step": True,
+                   "energy_virial_every_step": True, "equilibration_steps_untimed": equil,
                    "parallelism": ("spatial decomposition %dx%dx%d, %s (control plane: libddcmi TCP rendezvous, no torch)"
                                    % (grid + ("RCCL p2p halo" if transport != "host" else "host-staged TCP halo",))) if world > 1
                                   else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),

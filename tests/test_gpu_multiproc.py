@@ -171,3 +171,28 @@ def test_nglfconstraint_between_processes():
             assert np.abs(r["baro"][b][3:] - o.box).max() < 1e-10 * o.box.max()
     gid, _ = _merge(recs, "gid", "f")
     assert np.array_equal(gid, np.sort(s.gid))
+
+
+def test_bench_world8_on_one_device():
+    """the driver's N = 8 launch (2x2x2 bricks, 7 peers per rank) with all eight ranks on the one GPU of the test box over the
+    host transport: rendezvous of eight processes, migration and halo messages between every pair of neighbours, the
+    all-reduces; bench.py itself asserts that no bead is lost"""
+    port = 29800 + os.getpid() % 90
+    env = dict(os.environ)
+    env.update({"DDCMI_BENCH_SINGLE_DEVICE": "1", "DDCMI_TRANSPORT": "host"})
+    env.pop("DDCMI_RDZV_FILE", None); env.pop("DDCMI_RDZV_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "40", "--warmup", "20", "--lattice", "16"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["beads_total"] == 4 * 16 ** 3 and out["config"]["rebuilds_in_timed_region"] == 2
+    assert "2x2x2" in out["config"]["parallelism"]
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "20", "--lattice", "16", "--no-cpu"],
+                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
+    assert abs(out["check"]["epot"] - one["check"]["epot"]) < 1e-7 * abs(one["check"]["epot"])
+    assert abs(out["check"]["ekin"] - one["check"]["ekin"]) < 1e-7 * abs(one["check"]["ekin"])
