@@ -2383,8 +2383,14 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
       *longest = 0;
       for (int x = 0; x < 8; x++)
       {
-         const int *tl = live.data() + cut[x];
+         int *tl = live.data() + cut[x];
          const int n = cut[x + 1] - cut[x];
+         /* few rounds of workgroups per slot: the expensive tiles first, the thin edge tiles fill the end of the launch
+          * (at many rounds the raster order wins: neighbouring tiles share their neighbourhoods in L2) */
+         static const bool no_lpt = getenv("DDCMI_NO_LPT") != nullptr;
+         static const int lpt_rounds = getenv("DDCMI_LPT_ROUNDS") ? atoi(getenv("DDCMI_LPT_ROUNDS")) : 8;
+         if (!no_lpt && n < lpt_rounds * S)
+            std::stable_sort(tl, tl + n, [&](int ta_, int tb_) { return cost_list(ta_) + cost_stage(ta_) > cost_list(tb_) + cost_stage(tb_); });
          /* the tail: how many of the run's last tiles to cut, and into how many parts, by simulated makespan */
          int best_m = 0, best_k = 1;
          /* (only where the last round weighs: with R rounds of workgroups per slot it is worth at most 1/(2R)).
