@@ -2314,7 +2314,7 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
     * and the ranges leave from pinned memory too, so this function costs no host round trip of its own */
    const int ntile = ctx->ntile;
    const int *work = ctx->h_pin[0], *stage = work ? work + ntile : nullptr;
-   const size_t cap_items = (size_t)ntile + 8 * 64 * 8 + 64;      /* every tile once + the parts the 8 tails may add */
+   const size_t cap_items = (size_t)ntile + 8 * 64 * 8 * 2 + 64;      /* every tile once + the parts the 8 tails may add */
    int *perm = ctx->pinned(1, cap_items + 64), *sched = perm ? perm + cap_items : nullptr;
    if (!work || !perm) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile schedule");
    for (int k = 0; k < 32; k++) sched[k] = 0;
@@ -2404,14 +2404,14 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
          {
             double best = makespan(tl, n, 0, 1);
             const int r = n % S;
-            const int cand[] = {r, r + S / 2, r + S};
+            const int cand[] = {r, r + S / 2, r + S, r + 2 * S, n};
             const int parts[] = {2, 3, 4, 6, 8};
             for (int m : cand)
             {
                if (m <= 0 || m > n) continue;
                for (int k : parts)
                {
-                  if ((size_t)m * k > 64 * 8) continue;
+                  if ((size_t)m * k > 64 * 8 * 2) continue;
                   double ms = makespan(tl, n, m, k);
                   if (ms < 0.985 * best) { best = ms; best_m = m; best_k = k; }
                }
