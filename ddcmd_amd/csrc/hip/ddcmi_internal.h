@@ -247,6 +247,7 @@ struct ddcmi_ctx
    int dir_dest[27], dir_shift[27][3];            /* 26 neighbour directions, code = (dx+1)+3(dy+1)+9(dz+1) */
    int hs_cap = 0, mig_cap = 0;
    dbuf<int> hs_idx, dir_cnt;                      /* halo send lists per direction */
+   dbuf<unsigned> send_map;                        /* send slot -> owned bead | direction << 27 (flattened at rebuilds) */
    int hs_cnt[27], hr_cnt[27], send_off[28], recv_off[28], nsend = 0, nrecv = 0;
    int mig_scnt[27], mig_rcnt[27];
    dbuf<double> sendbuf, hrecv3, hrecv5, mig_out, mig_in;

@@ -197,15 +197,26 @@ struct OffTab { int off[28]; };   /* exclusive offsets of the flattened per-dire
 
 /* pack the beads a remote neighbour needs, shift applied: width 3 (x y z, every
  * step) or 5 (+ tag, gid: at rebuilds) */
-__global__ void k_pack_halo(int nsend, SegTab so, DirTab dt, int hs_cap, const int *hs_idx, double L0, double L1, double L2,
-                            const double4 *pos, const uint64_t *gid, double *out, int width)
+/* rebuild: send slot k of the halo buffer <- owned bead and direction, flattened once so that the per-step pack is a plain
+ * gather (a search through the segment table and two dependent index loads per bead and step before) */
+__global__ void k_send_map(int nsend, SegTab so, int hs_cap, const int *hs_idx, unsigned *send_map)
 {
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= nsend) return;
    int q = 0;
    while (k >= so.off[q + 1]) q++;
    const int code = so.code[q];
-   int i = hs_idx[(size_t)code * hs_cap + (k - so.off[q])];
+   send_map[k] = (unsigned)hs_idx[(size_t)code * hs_cap + (k - so.off[q])] | ((unsigned)code << 27);
+}
+/* pack the beads a remote neighbour needs, shift applied: width 3 (x y z, every
+ * step) or 5 (+ tag, gid: at rebuilds) */
+__global__ void k_pack_halo(int nsend, DirTab dt, const unsigned *__restrict__ send_map, double L0, double L1, double L2,
+                            const double4 *__restrict__ pos, const uint64_t *__restrict__ gid, double *__restrict__ out, int width)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= nsend) return;
+   const unsigned m = send_map[k];
+   const int i = (int)(m & 0x7ffffffu), code = (int)(m >> 27);
    double4 p = pos[i];
    double *o = out + (size_t)k * width;
    o[0] = p.x + dt.shift[code][0] * L0;
@@ -615,7 +626,10 @@ static int mg_phase3_pack(ddcmi_ctx *ctx, int width)
    ENSURE(ctx, ctx->sendbuf, (size_t)ns * 5 + 8); ENSURE(ctx, ctx->hrecv5, (size_t)nr * 5 + 8); ENSURE(ctx, ctx->hrecv3, (size_t)nr * 3 + 8);
    if (ns > 0)
    {
-      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, ctx->sseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+      if (ctx->nloc >= (1 << 27)) SETERR(ctx, DDCMI_EUNSUPPORTED, "%d beads on one rank: more than the halo send map's 27 bits name", ctx->nloc);
+      ENSURE(ctx, ctx->send_map, (size_t)ns + 8);
+      hipLaunchKernelGGL(k_send_map, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, ctx->sseg, ctx->hs_cap, ctx->hs_idx.p, ctx->send_map.p);
+      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, mg_dirtab(ctx), ctx->send_map.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, width);
    }
    return DDCMI_OK;
@@ -682,7 +696,7 @@ static int mg_pack3(ddcmi_ctx *ctx, hipStream_t st)
 {
    if (ctx->nsend > 0)
    {
-      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, st, ctx->nsend, ctx->sseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
+      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, st, ctx->nsend, mg_dirtab(ctx), ctx->send_map.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, 3);
    }
    return DDCMI_OK;
@@ -699,13 +713,11 @@ int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st)
 
 /* velocity halo (constraint groups named by gid): the velocities of the beads on the halo send lists, same messages
  * and layout as the positions; received beads land in the velocity slots behind the owned ones */
-__global__ void k_pack_vel(int nsend, SegTab so, int hs_cap, const int *hs_idx, const double *vx, const double *vy, const double *vz, double *out)
+__global__ void k_pack_vel(int nsend, const unsigned *__restrict__ send_map, const double *vx, const double *vy, const double *vz, double *out)
 {
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= nsend) return;
-   int q = 0;
-   while (k >= so.off[q + 1]) q++;
-   const int i = hs_idx[(size_t)so.code[q] * hs_cap + (k - so.off[q])];
+   const int i = (int)(send_map[k] & 0x7ffffffu);
    out[3 * k] = vx[i]; out[3 * k + 1] = vy[i]; out[3 * k + 2] = vz[i];
 }
 __global__ void k_unpack_vel(int nloc, int nhalo, const int *halo_src, const double *vrecv, double *vx, double *vy, double *vz)
@@ -719,7 +731,7 @@ __global__ void k_unpack_vel(int nloc, int nhalo, const int *halo_src, const dou
 static int mg_pack_vel(ddcmi_ctx *ctx, hipStream_t st)
 {
    if (ctx->nsend > 0)
-      hipLaunchKernelGGL(k_pack_vel, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, st, ctx->nsend, ctx->sseg, ctx->hs_cap, ctx->hs_idx.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->sendbuf.p);
+      hipLaunchKernelGGL(k_pack_vel, dim3(cdiv(ctx->nsend, 256)), dim3(256), 0, st, ctx->nsend, ctx->send_map.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->sendbuf.p);
    return DDCMI_OK;
 }
 static int mg_unpack_vel(ddcmi_ctx *ctx, hipStream_t st)
