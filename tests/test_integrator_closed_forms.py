@@ -1,0 +1,171 @@
+"""The integrator against closed forms and a numpy restatement written from nglf.c / berendsen.c / energy.c -- numbers that
+come neither from the oracle's C code nor from the device code:
+  * kinetic_terms (energy.c:48-163): rk = sum 1/2 m v^2, tion = sum m v (x) v;
+  * BERENDSEN on force-free beads: the temperature obeys T_1 = T_0, T_{k+1} = T_k (1 + (dt/tau)(Teq/T_{k-1} - 1))
+    (berendsen.c:30-89 with the lag of the published group temperature, nglf.c:74-108), positions follow the scaled flight;
+  * NGLF (velocity Verlet: half kick, drift, forces, half kick) on one bonded molecule, forces from central differences of
+    the closed-form energies of tests/closed_forms.py.
+The CPU tests check the oracle, the -m gpu ones the device."""
+import os
+import numpy as np
+import pytest
+
+import pyoracle
+import closed_forms as cf
+from ddcmd_amd.deck import load_deck, units_convert
+from ddcmd_amd.synth import make_water_setup
+from test_closed_forms import tstm_molecules, LIPID_DECK
+
+
+def force_free_water(n=5):
+    s = make_water_setup(n, thermostat="berendsen")
+    s.eps = np.zeros_like(s.eps)                  # no Lennard-Jones, no charges: beads fly freely
+    s.shift = np.zeros_like(s.shift)
+    s.group_interval = np.array([1], np.int32)
+    return s
+
+
+def berendsen_recursion(T0, Teq, dt, tau, nsteps):
+    T = [T0, T0]                                   # step 1: no scaling yet (doScaling starts at 0)
+    for k in range(1, nsteps):
+        T.append(T[k] * (1.0 + (dt / tau) * (Teq / T[k - 1] - 1.0)))
+    return np.array(T)
+
+
+class OracleEngine(object):
+    def __init__(self, s):
+        self.o = pyoracle.Oracle(s)
+        self.o.forces()
+        self.o.group_temperature()
+
+    def step(self):
+        e, vir, rk, tion = self.o.step(1)
+        self.o.group_temperature()
+        return rk, tion
+
+    def kinetic(self):
+        return self.o.kinetic()
+
+    def state(self):
+        return np.stack([self.o.rx, self.o.ry, self.o.rz]), np.stack([self.o.vx, self.o.vy, self.o.vz])
+
+    def close(self):
+        pass
+
+
+class DeviceEngine(object):
+    def __init__(self, s):
+        from ddcmd_amd.martini import MartiniHIP
+        self.m = MartiniHIP(s)
+        self.m.eval_forces()
+        self.m.group_temperatures()
+
+    def step(self):
+        self.m.step(1)
+        self.m.group_temperatures()
+        e, vir, rk, tion = self.m.energies()
+        return rk, tion
+
+    def kinetic(self):
+        return self.m.kinetic()
+
+    def state(self):
+        d = self.m.download()
+        return np.stack(d["r"]), np.stack(d["v"])
+
+    def close(self):
+        self.m.close()
+
+
+def check_kinetic_terms(make):
+    s = make_water_setup(5)
+    eng = make(s)
+    rk, tion = eng.kinetic()
+    m = s.mass[s.species]
+    v = np.stack([s.vx, s.vy, s.vz])
+    assert abs(rk - 0.5 * np.sum(m * (v ** 2).sum(axis=0))) < 1e-13 * rk
+    want = np.array([np.sum(m * v[0] * v[0]), np.sum(m * v[1] * v[1]), np.sum(m * v[2] * v[2]),
+                     np.sum(m * v[0] * v[1]), np.sum(m * v[0] * v[2]), np.sum(m * v[1] * v[2])])
+    assert np.abs(tion - want).max() < 1e-13 * np.abs(want).max()
+    eng.close()
+
+
+def check_berendsen_free_flight(make):
+    s = force_free_water()
+    n, dt, tau, Teq = s.natoms, s.dt, float(s.group_tau[0]), float(s.group_Teq[0])
+    m = s.mass[s.species]
+    v0 = np.stack([s.vx, s.vy, s.vz])
+    r0 = np.stack([s.rx, s.ry, s.rz])
+    T0 = np.sum(m * (v0 ** 2).sum(axis=0)) / (3.0 * n)
+    nsteps = 24
+    Tref = berendsen_recursion(T0, Teq, dt, tau, nsteps)
+    eng = make(s)
+    scale, path = 1.0, 0.0
+    L = s.box
+    for k in range(1, nsteps + 1):
+        rk, _ = eng.step()
+        assert abs(2.0 * rk / (3.0 * n) - Tref[k]) < 1e-12 * Tref[k], k
+        scale = np.sqrt(Tref[k] / T0)             # product of the scale factors applied so far
+        path += scale                             # r_k = r_0 + dt v_0 sum_j scale_j
+    r, v = eng.state()
+    assert np.abs(v - scale * v0).max() < 1e-12 * np.abs(v0).max()
+    d = r - (r0 + dt * path * v0)
+    d -= L[:, None] * np.rint(d / L[:, None])
+    assert np.abs(d).max() < 1e-10
+    assert Tref[-1] > 1.5 * T0                   # 50 K start, 310 K target: the thermostat really acted
+    eng.close()
+
+
+def check_nglf_on_one_molecule(make):
+    s = load_deck(LIPID_DECK)
+    s.excludePotentialTerm = 128                  # bonded terms only: every molecule moves on its own
+    mols, rt = tstm_molecules(s)
+    mol = mols[2]
+    mass = s.mass[s.species[mol]][:, None]
+    x = np.stack([s.rx[mol], s.ry[mol], s.rz[mol]], axis=1)
+    v = np.stack([s.vx[mol], s.vy[mol], s.vz[mol]], axis=1)
+    energy = lambda y: sum(cf.molecule_terms_E(s, y, rt).values())
+    f = cf.fd_forces(energy, x)
+    dt = s.dt
+    eng = make(s)
+    for step in range(6):
+        # nglf.c:74-104: FRONT half kick, drift, forces at the new positions, BACK half kick
+        v = v + 0.5 * dt * f / mass
+        x = x + dt * v
+        f = cf.fd_forces(energy, x)
+        v = v + 0.5 * dt * f / mass
+        eng.step()
+    r, vel = eng.state()
+    L = s.box
+    d = r[:, mol].T - x
+    d -= L[None, :] * np.rint(d / L[None, :])
+    assert np.abs(d).max() < 1e-7
+    assert np.abs(vel[:, mol].T - v).max() < 2e-6 * np.abs(v).max()
+    eng.close()
+
+
+def test_oracle_kinetic_terms():
+    check_kinetic_terms(OracleEngine)
+
+
+def test_oracle_berendsen_free_flight():
+    check_berendsen_free_flight(OracleEngine)
+
+
+def test_oracle_nglf_on_one_molecule():
+    check_nglf_on_one_molecule(OracleEngine)
+
+
+@pytest.mark.gpu
+def test_device_kinetic_terms():
+    check_kinetic_terms(DeviceEngine)
+
+
+@pytest.mark.gpu
+def test_device_berendsen_free_flight():
+    check_berendsen_free_flight(DeviceEngine)
+
+
+@pytest.mark.gpu
+def test_device_nglf_on_one_molecule():
+    check_nglf_on_one_molecule(DeviceEngine)
