@@ -1113,7 +1113,7 @@ int ddcmi_mol_split_finish(ddcmi_ctx *ctx)
    hipStream_t st = ctx->stream;
    const int nm = ctx->nmol_multi;
    hipLaunchKernelGGL(k_mol_split_flag, dim3(cdiv(nm, 256)), dim3(256), 0, st, nm, ctx->mol_info.p, ctx->mol_split.p);
-   int rc = ddcmi_scan_exclusive(ctx, ctx->mol_split.p, nm, ctx->d_flags + 9);
+   int rc = ddcmi_scan_exclusive(ctx, ctx->mol_split.p, ctx->mol_split.p, nm, ctx->d_flags + 9);
    if (rc) return rc;
    hipLaunchKernelGGL(k_mol_split_index, dim3(cdiv(nm, 256)), dim3(256), 0, st, nm, ctx->mol_info.p, ctx->mol_split.p);
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 9, ctx->d_flags + 9, sizeof(int), hipMemcpyDeviceToHost, st));

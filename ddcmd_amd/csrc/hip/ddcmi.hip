@@ -1704,8 +1704,8 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
        hipMalloc((void **)&ctx->d_results, R_SIZE * sizeof(double)) != hipSuccess ||
        hipHostMalloc((void **)&ctx->h_results, R_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-       hipMalloc((void **)&ctx->d_flags, 16 * sizeof(int)) != hipSuccess ||
-       hipHostMalloc((void **)&ctx->h_flags, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+       hipMalloc((void **)&ctx->d_flags, 32 * sizeof(int)) != hipSuccess ||
+       hipHostMalloc((void **)&ctx->h_flags, 32 * sizeof(int), hipHostMallocDefault) != hipSuccess)
    {
       g_create_err = "context allocation failed";
       if (ctx->self_pinned) (void)hipHostUnregister(ctx);
@@ -1713,7 +1713,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
-   (void)hipMemset(ctx->d_flags, 0, 16 * sizeof(int));
+   (void)hipMemset(ctx->d_flags, 0, 32 * sizeof(int));
    if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the context's non-blocking stream */
@@ -1751,6 +1751,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
+   if (ctx->ev_build) (void)hipEventDestroy(ctx->ev_build);
    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -2200,15 +2201,14 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
    int n = ctx->nloc, nb = cdiv(n, 256), ncell = gp.ncell, ncb = cdiv(ncell, 256);
    dbuf<int> *cb[] = {&ctx->cell_cnt_o, &ctx->cell_start_o, &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt};
    for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
-   HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_o.p, 0, (ncell + 1) * sizeof(int), st));
-   HIPCHK(ctx, hipMemsetAsync(ctx->cell_cnt_h.p, 0, ncell * sizeof(int), st));
-   HIPCHK(ctx, hipMemsetAsync(ctx->d_flags + 12, 0, sizeof(int), st));
+   /* the counters of the whole rebuild in one launch: cell counts, the capacity flags and totals of k_tile_build */
+   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1)
+                               .add(ctx->d_flags + 16, 6));
    if (n > 0)
    {
       hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12);
    }
-   HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_o.p, ctx->cell_cnt_o.p, (ncell + 1) * sizeof(int), hipMemcpyDeviceToDevice, st));
-   if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
+   if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
    if (n > 0)
    {
       hipLaunchKernelGGL(k_scatter_order, dim3(nb), dim3(256), 0, st, n, ctx->cid.p, ctx->crank.p, ctx->cell_start_o.p, ctx->order.p);
@@ -2247,8 +2247,7 @@ static int bl_self_images(ddcmi_ctx *ctx)
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nb = cdiv(n, 256), rc;
    hipLaunchKernelGGL(k_count_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->nimg.p);
-   HIPCHK(ctx, hipMemcpyAsync(ctx->img_off.p, ctx->nimg.p, n * sizeof(int), hipMemcpyDeviceToDevice, st));
-   if ((rc = ddcmi_scan_exclusive(ctx, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
+   if ((rc = ddcmi_scan_exclusive(ctx, ctx->nimg.p, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 8, ctx->d_flags + 8, sizeof(int), hipMemcpyDeviceToHost, st));
    HIPCHK(ctx, hipStreamSynchronize(st));
    int nh = ctx->h_flags[8];
@@ -2270,8 +2269,7 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
    if (nh > 0)
    {
       int nhb = cdiv(nh, 256);
-      HIPCHK(ctx, hipMemcpyAsync(ctx->cell_start_h.p, ctx->cell_cnt_h.p, ncell * sizeof(int), hipMemcpyDeviceToDevice, st));
-      if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_start_h.p, ncell, nullptr))) return rc;
+      if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ncell, nullptr))) return rc;
       hipLaunchKernelGGL(k_scatter_order, dim3(nhb), dim3(256), 0, st, nh, ctx->hcid.p, ctx->hrank.p, ctx->cell_start_h.p, ctx->horder.p);
       hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
       hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p);
@@ -2480,7 +2478,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    ShellCuts shc;
    shc.r0 = (float)(rcut - 0.25 * dR);
    shc.inv_w = (float)((NSHELL - 1) / (rcut + dR - (rcut - 0.25 * dR)));
-   unsigned long long *d_tot = (unsigned long long *)(ctx->d_results + R_FLAGS);    /* [0]=entries [1]=excluded [2]=arena used */
+   unsigned long long *d_tot = (unsigned long long *)(ctx->d_flags + 16);    /* [0]=entries [1]=excluded [2]=arena used; travels with the flags */
    for (int attempt = 0;; attempt++)
    {
       if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
@@ -2493,8 +2491,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
       ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
-      HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), st));
+      if (attempt > 0) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_tot, 6));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
       ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
       TileArgs ta;
       ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
@@ -2510,6 +2507,15 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
                          ctx->maxexcl, ctx->excl.p, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+      /* everything the host decides on (capacity flags, totals, the tiles' cost estimates) is final when k_tile_build
+       * ends: it travels behind an event, and the host reads it -- and orders the tiles -- while k_tile_transpose runs */
+      unsigned long long tot[3];
+      int *h_work = ctx->pinned(0, 2 * (size_t)ntile + 8);
+      if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
+      if (!ctx->ev_build) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_build, hipEventDisableTiming));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 32 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 2 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
+      HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
       {
          size_t lds2 = (size_t)TR_ROWS * (ctx->tmpw | 1) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
          if (lds2 > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "lists of %d entries per bead do not fit the transpose kernel's LDS", ctx->tmpw);
@@ -2517,15 +2523,8 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
          hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
       }
       HIPCHK(ctx, hipGetLastError());
-      unsigned long long tot[3];
-      int *h_work = ctx->pinned(0, 2 * (size_t)ntile + 8);
-      if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
-      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 12, ctx->d_flags + 12, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 2 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
-      HIPCHK(ctx, hipMemcpyAsync(h_work + 2 * (size_t)ntile, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      memcpy(tot, h_work + 2 * (size_t)ntile, sizeof(tot));
+      HIPCHK(ctx, hipEventSynchronize(ctx->ev_build));
+      memcpy(tot, ctx->h_flags + 16, sizeof(tot));
       if (ctx->h_flags[12] > 0)
          SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)", ctx->h_flags[12], (long long)ctx->loop);
       bool again = false;
@@ -2533,6 +2532,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }
       if (ctx->h_flags[1] > 0) { ctx->maxexcl = ctx->h_flags[1] + 4; again = true; }
       if (ctx->h_flags[5] > 0) { ctx->tmpw = ((int)(ctx->h_flags[5] * 1.1) + 8 + 7) & ~7; again = true; }
+      if (again) HIPCHK(ctx, hipStreamSynchronize(st));      /* the transposition still runs on buffers the next attempt may grow */
       if (!again)
       {
          ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];

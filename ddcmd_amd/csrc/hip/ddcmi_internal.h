@@ -162,7 +162,7 @@ struct ddcmi_ctx
    int sched_cache[2][8][3] = {};      /* tail split of each class and XCD run: {tiles it was found for, tiles cut, parts} */
    int sched_longest[2] = {0, 0}, ntile_class[2] = {0, 0};      /* class 0: all-owned neighbourhoods (all tiles on one domain), class 1: the rest */
    hipStream_t stream2 = nullptr;      /* decomposed runs: halo exchange, concurrent with the class-0 tiles */
-   hipEvent_t ev_drift = nullptr, ev_halo = nullptr;
+   hipEvent_t ev_drift = nullptr, ev_halo = nullptr, ev_build = nullptr;
    bool halo_overlap = false;          /* DDCMI_HALO_OVERLAP=1: exchange on stream2 under the all-owned tiles */
    /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
    int ntile = 0, stage_cap = 0; int pack_type = 0;      /* 0 bare slots, 1 slot<<4|type, 2 + shift bit (see TileArgs) */
@@ -290,7 +290,13 @@ __device__ __forceinline__ double rcp_f64(double x)
 #endif
 
 /* scan.hip */
-int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total);
+int ddcmi_scan_exclusive(ddcmi_ctx *ctx, const int *src, int *dst, int n, int *d_total);
+struct ZeroJobs
+{
+   int *p[8]; int n[8]; int cnt = 0;
+   ZeroJobs &add(void *ptr, size_t nints) { p[cnt] = (int *)ptr; n[cnt] = (int)nints; cnt++; return *this; }
+};
+int ddcmi_zero_ints(ddcmi_ctx *ctx, hipStream_t st, const ZeroJobs &z);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);

@@ -84,6 +84,7 @@ __global__ void k_mig_classify(MigGeom mg, int nloc, int mig_cap, double4 *pos, 
                                const uint64_t *gid, const int *group, int *keep, int *dir_cnt, double *mig_out, int *flags)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i == 0) dir_cnt[27] = mig_cap;      /* travels with the counts: every rank sees whether any rank's segments overflowed */
    if (i >= nloc) return;
    double4 p = pos[i];
    if (mg.pbc & 1) { if (p.x > 0.5 * mg.L[0]) p.x -= mg.L[0]; if (p.x < -0.5 * mg.L[0]) p.x += mg.L[0]; }
@@ -148,6 +149,7 @@ __global__ void k_halo_select(GridParams gp, DirTab dt, int nloc, int hs_cap, co
    if (threadIdx.x < 27) s_cnt[threadIdx.x] = 0;
    __syncthreads();
    int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i == 0) dir_cnt[27] = hs_cap;
    unsigned mask = 0;          /* directions this bead goes to */
    if (i < nloc)
    {
@@ -386,27 +388,41 @@ extern "C" int ddcmi_plan_halo_layout(int px, int py, int pz, int rank, int pbc,
 }
 
 /* ---- transports ------------------------------------------------------------- */
-/* Every rank learns every rank's 27 per-direction counts with ONE all-gather (26 four-byte
- * point-to-point messages took 77 us; this is rebuild-time control traffic) and looks up what its
- * neighbours send to it.  RCCL: pinned staging on both sides; host transport: the rendezvous' all-gather. */
-static int mg_xchg_counts(ddcmi_ctx *ctx, const int *scnt, int *rcnt)
+/* Every rank learns every rank's 27 per-direction counts (+ the capacity its segments had, slot 27) with ONE all-gather
+ * straight from the device counters (26 four-byte point-to-point messages took 77 us; this is rebuild-time control
+ * traffic) and looks up what its neighbours send to it.  One host synchronisation per round.
+ * RCCL: the all-gather reads dir_cnt on the device; host transport: the rendezvous' all-gather after the download. */
+static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over, int *my_max, bool with_flags)
 {
    hipStream_t st = ctx->stream;
    const int nr = std::max(ctx->nranks, 1);
-   int *h = ctx->pinned(2, 32 + 27 * (size_t)nr);
+   int *h = ctx->pinned(2, 32 + 55 * (size_t)nr);
    if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
-   for (int code = 0; code < 27; code++) h[code] = scnt[code];
-   if (ctx->hcomm) HOSTCHK(ctx, ddcmi_rdzv_allgather(ctx->hcomm, h, h + 32, 27 * sizeof(int)));
+   int *all = h + 32, *packed = h + 32 + 28 * (size_t)nr;
+   if (with_flags) HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+   if (ctx->hcomm)
+   {
+      HIPCHK(ctx, hipMemcpyAsync(h, ctx->dir_cnt.p, 28 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      HOSTCHK(ctx, ddcmi_rdzv_allgather(ctx->hcomm, h, all, 28 * sizeof(int)));
+   }
    else
    {
-      ncclComm_t comm = (ncclComm_t)ctx->comm;
-      ENSURE(ctx, ctx->cnt_xchg, 32 + 27 * (size_t)nr);
-      HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, h, 27 * sizeof(int), hipMemcpyHostToDevice, st));
-      NCCLCHK2(ctx, ncclAllGather(ctx->cnt_xchg.p, ctx->cnt_xchg.p + 32, 27, ncclInt, comm, st));
-      HIPCHK(ctx, hipMemcpyAsync(h + 32, ctx->cnt_xchg.p + 32, 27 * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
+      ENSURE(ctx, ctx->cnt_xchg, 32 + 28 * (size_t)nr);
+      NCCLCHK2(ctx, ncclAllGather(ctx->dir_cnt.p, ctx->cnt_xchg.p + 32, 28, ncclInt, (ncclComm_t)ctx->comm, st));
+      HIPCHK(ctx, hipMemcpyAsync(all, ctx->cnt_xchg.p + 32, 28 * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
    }
-   plan_recv_counts(ctx->dir_dest, ctx->rank, ctx->loopback, h + 32, rcnt);
+   *any_over = false;
+   for (int r = 0; r < nr; r++)
+   {
+      int mx = 0;
+      for (int c = 0; c < 27; c++) { mx = std::max(mx, all[28 * r + c]); packed[27 * r + c] = all[28 * r + c]; }
+      if (mx > all[28 * r + 27]) *any_over = true;
+      if (r == ctx->rank) *my_max = mx;
+   }
+   for (int c = 0; c < 27; c++) scnt[c] = all[28 * (size_t)ctx->rank + c];
+   plan_recv_counts(ctx->dir_dest, ctx->rank, ctx->loopback, packed, rcnt);
    return DDCMI_OK;
 }
 /* host transport: device segments -> host staging -> TCP streams -> host staging -> device segments.
@@ -533,7 +549,8 @@ static int mg_xchg_data_local(ddcmi_group *g, int which /*0 migration, 1 halo5, 
 }
 
 /* ---- rebuild phases --------------------------------------------------------- */
-static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
+/* enqueue the classification of the owned beads (stay / leave towards one of 26 directions); no host round trip */
+static int mg_phase1_launch(ddcmi_ctx *ctx)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, rc;
@@ -541,22 +558,29 @@ static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
       SETERR(ctx, DDCMI_EUNSUPPORTED, "with domain decomposition bonded terms must be given by gid (ddcmi_set_bonded_gid): caller-order indices do not survive migration");
    if ((rc = mg_ensure_owned(ctx, (size_t)n + 1))) return rc;
    if (ctx->mig_cap == 0) ctx->mig_cap = std::max(1024, n / 16);
+   ENSURE(ctx, ctx->mig_out, (size_t)27 * ctx->mig_cap * 10);
+   ENSURE(ctx, ctx->dir_cnt, 32);
+   ENSURE(ctx, ctx->keep, (size_t)n + 1);
+   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28).add(ctx->d_flags, 8));
+   MigGeom mg;
+   for (int a = 0; a < 3; a++) { mg.L[a] = ctx->h[4 * a]; mg.P[a] = ctx->pgrid[a]; mg.W[a] = mg.L[a] / mg.P[a]; mg.pc[a] = ctx->pcoord[a]; }
+   mg.pbc = ctx->pbc;
+   if (n > 0)
+   {
+      hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
+      hipLaunchKernelGGL(k_mig_classify, dim3(cdiv(n, 256)), dim3(256), 0, st, mg, n, ctx->mig_cap, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
+                         ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags);
+   }
+   return DDCMI_OK;
+}
+/* in-process groups: the counts come to the host per context */
+static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
+{
+   hipStream_t st = ctx->stream;
+   int rc;
    for (;;)
    {
-      ENSURE(ctx, ctx->mig_out, (size_t)27 * ctx->mig_cap * 10);
-      ENSURE(ctx, ctx->dir_cnt, 32);
-      ENSURE(ctx, ctx->keep, (size_t)n + 1);
-      HIPCHK(ctx, hipMemsetAsync(ctx->dir_cnt.p, 0, 27 * sizeof(int), st));
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_flags, 0, 8 * sizeof(int), st));
-      MigGeom mg;
-      for (int a = 0; a < 3; a++) { mg.L[a] = ctx->h[4 * a]; mg.P[a] = ctx->pgrid[a]; mg.W[a] = mg.L[a] / mg.P[a]; mg.pc[a] = ctx->pcoord[a]; }
-      mg.pbc = ctx->pbc;
-      if (n > 0)
-      {
-         hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
-         hipLaunchKernelGGL(k_mig_classify, dim3(cdiv(n, 256)), dim3(256), 0, st, mg, n, ctx->mig_cap, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
-                            ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags);
-      }
+      if ((rc = mg_phase1_launch(ctx))) return rc;
       HIPCHK(ctx, hipMemcpyAsync(ctx->mig_scnt, ctx->dir_cnt.p, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
@@ -581,8 +605,7 @@ static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
    if ((rc = mg_ensure_owned(ctx, (size_t)nkeep + narr + 1))) return rc;
    if (nleave > 0)
    {
-      HIPCHK(ctx, hipMemcpyAsync(ctx->img_off.p, ctx->keep.p, n * sizeof(int), hipMemcpyDeviceToDevice, st));
-      if ((rc = ddcmi_scan_exclusive(ctx, ctx->img_off.p, n, nullptr))) return rc;
+      if ((rc = ddcmi_scan_exclusive(ctx, ctx->keep.p, ctx->img_off.p, n, nullptr))) return rc;
       hipLaunchKernelGGL(k_compact_order, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->keep.p, ctx->img_off.p, ctx->order.p);
       if (nkeep > 0)
       {
@@ -601,13 +624,28 @@ static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
    if (n > 0) hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
    /* sort the owned beads, then pick what each neighbour direction needs */
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
+   return DDCMI_OK;
+}
+/* which owned beads does each neighbour direction need?  enqueue only */
+static int mg_halo_select_launch(ddcmi_ctx *ctx)
+{
+   hipStream_t st = ctx->stream;
+   const int n = ctx->nloc;
    if (ctx->hs_cap == 0) ctx->hs_cap = std::max(4096, n / 4);
+   ENSURE(ctx, ctx->hs_idx, (size_t)27 * ctx->hs_cap);
+   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28));
+   if (n > 0)
+      hipLaunchKernelGGL(k_halo_select, dim3(cdiv(n, 256)), dim3(256), 0, st, ctx->gp, mg_dirtab(ctx), n, ctx->hs_cap, ctx->pos.p, ctx->dir_cnt.p, ctx->hs_idx.p);
+   return DDCMI_OK;
+}
+/* in-process groups: counts to the host per context */
+static int mg_halo_select(ddcmi_ctx *ctx)
+{
+   hipStream_t st = ctx->stream;
+   int rc;
    for (;;)
    {
-      ENSURE(ctx, ctx->hs_idx, (size_t)27 * ctx->hs_cap);
-      HIPCHK(ctx, hipMemsetAsync(ctx->dir_cnt.p, 0, 27 * sizeof(int), st));
-      if (n > 0)
-         hipLaunchKernelGGL(k_halo_select, dim3(cdiv(n, 256)), dim3(256), 0, st, ctx->gp, mg_dirtab(ctx), n, ctx->hs_cap, ctx->pos.p, ctx->dir_cnt.p, ctx->hs_idx.p);
+      if ((rc = mg_halo_select_launch(ctx))) return rc;
       HIPCHK(ctx, hipMemcpyAsync(ctx->hs_cnt, ctx->dir_cnt.p, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
       int mx = 0;
@@ -654,15 +692,14 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
    if (ctx->has_charge)
    {
+      /* sum of q^2 over this rank's beads: reaches the host with ddcmi_bl_finish's own round trip (pinned h_results) */
       double *d = ctx->d_results + R_GROUP;
       HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(double), st));
       if (ctx->nloc > 0) hipLaunchKernelGGL(k_sum_q2, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, st, ctx->nloc, ctx->pos.p, ctx->d_charge_sp.p, d);
-      double q2 = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&q2, d, sizeof(double), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;     /* bioMartini.c:1030-1035 over this rank's local beads */
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_results + R_GROUP, d, sizeof(double), hipMemcpyDeviceToHost, st));
    }
    if ((rc = ddcmi_bl_finish(ctx))) return rc;
+   if (ctx->has_charge) ctx->self_ele = -0.5 * ctx->h_results[R_GROUP] * ctx->keR * ctx->crf;     /* bioMartini.c:1030-1035 over this rank's local beads */
    ctx->halo_fresh = true;
    return DDCMI_OK;
 }
@@ -673,8 +710,19 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are rebuilt with ddcmi_group_* calls");
    if (!mg_transport(ctx)) SETERR(ctx, DDCMI_EINVAL, "ddcmi_comm_init has not been called");
    int rc;
-   if ((rc = mg_phase1_migrate_out(ctx))) return rc;
-   if ((rc = mg_xchg_counts(ctx, ctx->mig_scnt, ctx->mig_rcnt))) return rc;
+   /* the per-direction counts never wait on the host between the kernel that counts and the exchange: the all-gather reads the
+    * device counters, and ONE synchronisation brings every rank's counts (and capacities: a rank whose segments overflowed makes
+    * all ranks repeat the round together) to the host */
+   for (;;)
+   {
+      bool over = false;
+      int mx = 0;
+      if ((rc = mg_phase1_launch(ctx))) return rc;
+      if ((rc = mg_counts_round(ctx, ctx->mig_scnt, ctx->mig_rcnt, &over, &mx, true))) return rc;
+      if (ctx->h_flags[6]) SETERR(ctx, DDCMI_EINVAL, "a bead moved further than one domain between rebuilds");
+      if (!over) break;
+      if (mx > ctx->mig_cap) ctx->mig_cap = mx + mx / 4 + 64;     /* positions were only wrapped (idempotent): simply redo */
+   }
    {
       int roff[27], acc = 0;
       for (int c = 0; c < 27; c++) { roff[c] = acc; acc += ctx->mig_rcnt[c]; }
@@ -682,7 +730,15 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
       if ((rc = mg_xchg_data(ctx, ctx->mig_out.p, nullptr, ctx->mig_scnt, ctx->mig_cap, ctx->mig_in.p, roff, ctx->mig_rcnt, 10))) return rc;
    }
    if ((rc = mg_phase2_migrate_in(ctx))) return rc;
-   if ((rc = mg_xchg_counts(ctx, ctx->hs_cnt, ctx->hr_cnt))) return rc;
+   for (;;)
+   {
+      bool over = false;
+      int mx = 0;
+      if ((rc = mg_halo_select_launch(ctx))) return rc;
+      if ((rc = mg_counts_round(ctx, ctx->hs_cnt, ctx->hr_cnt, &over, &mx, false))) return rc;
+      if (!over) break;
+      if (mx > ctx->hs_cap) ctx->hs_cap = mx + mx / 4 + 64;
+   }
    if ((rc = mg_phase3_pack(ctx, 5))) return rc;
    if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5, ctx->stream))) return rc;
    if ((rc = mg_phase4_finish(ctx))) return rc;
@@ -815,6 +871,7 @@ static int group_rebuild(ddcmi_group *g)
    }
    if ((rc = mg_xchg_data_local(g, 0))) return rc;
    for (ddcmi_ctx *c : g->ranks) if ((rc = mg_phase2_migrate_in(c))) return rc;
+   for (ddcmi_ctx *c : g->ranks) if ((rc = mg_halo_select(c))) return rc;
    for (ddcmi_ctx *B : g->ranks)
       for (int code = 0; code < 27; code++)
          B->hr_cnt[code] = mg_remote(B, mg_opp(code)) ? g->ranks[B->dir_dest[mg_opp(code)]]->hs_cnt[code] : 0;

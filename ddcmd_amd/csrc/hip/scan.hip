@@ -2,11 +2,15 @@
  * scan.hip -- hand-written exclusive prefix sum over int arrays (cell counts,
  * image counts).  Replaces the reference's three-stage generateBinPermutation*
  * kernels and cub::DeviceScan (pairProcessGPU.cu:763-1058, prefixScan.cu) --
- * no cub/hipcub/rocPRIM.  Two levels: 2048-element tiles scanned by one
- * 256-thread block each (wave64 shuffles + LDS), tile sums scanned by a single
- * block, then added back.  In place; optional grand total written to d_total.
+ * no cub/hipcub/rocPRIM.  Two launches: 2048-element tiles scanned by one
+ * 256-thread block each (wave64 shuffles + LDS); then every tile's block sums
+ * the totals of the tiles before it (at most a few thousand ints out of L2) and
+ * adds that to its elements.  src -> dst (may be the same array); optional
+ * grand total written to d_total.  The rebuild is bound by its number of small
+ * launches: the earlier copy + three-kernel form cost four of them per scan.
  */
 #include "ddcmi_internal.h"
+#include <algorithm>
 
 #define SCAN_TILE 2048   /* 256 threads x 8 items */
 
@@ -35,39 +39,39 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot)
    __syncthreads();
    return base + inc - v;
 }
-__global__ __launch_bounds__(256) void k_scan_tiles(int *data, int n, int *tile_sums)
+__global__ __launch_bounds__(256) void k_scan_tiles(const int *src, int *dst, int n, int *tile_sums, int *d_total)
 {
    int base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
    int v[8], s = 0;
 #pragma unroll
-   for (int k = 0; k < 8; k++) { v[k] = (base + k < n) ? data[base + k] : 0; s += v[k]; }
+   for (int k = 0; k < 8; k++) { v[k] = (base + k < n) ? src[base + k] : 0; s += v[k]; }
    int tot;
    int ex = block_excl_scan(s, &tot);
 #pragma unroll
-   for (int k = 0; k < 8; k++) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
-   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+   for (int k = 0; k < 8; k++) { if (base + k < n) dst[base + k] = ex; ex += v[k]; }
+   if (threadIdx.x == 0) { tile_sums[blockIdx.x] = tot; if (d_total && gridDim.x == 1) *d_total = tot; }
 }
-__global__ __launch_bounds__(256) void k_scan_sums(int *sums, int nt, int *d_total)
+/* tile b: + the totals of tiles 0..b-1 (fixed summation order: thread-strided partial sums, then the block tree) */
+__global__ __launch_bounds__(256) void k_scan_finish(int *data, int n, const int *__restrict__ tile_sums, int *d_total)
 {
-   int carry = 0;
-   for (int base = 0; base < nt; base += 256)
+   const int b = blockIdx.x;
+   int p = 0;
+   for (int k = threadIdx.x; k < b; k += 256) p += tile_sums[k];
+   int tot;
+   (void)block_excl_scan(p, &tot);
+   if (b > 0)
    {
-      int i = base + threadIdx.x;
-      int v = (i < nt) ? sums[i] : 0;
-      int tot;
-      int ex = block_excl_scan(v, &tot);
-      if (i < nt) sums[i] = carry + ex;
-      carry += tot;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+      {
+         int i = b * SCAN_TILE + k * 256 + threadIdx.x;
+         if (i < n) data[i] += tot;
+      }
    }
-   if (threadIdx.x == 0 && d_total) *d_total = carry;
-}
-__global__ void k_scan_add(int *data, int n, const int *tile_sums)
-{
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i < n) data[i] += tile_sums[i / SCAN_TILE];
+   if (d_total && b == (int)gridDim.x - 1 && threadIdx.x == 0) *d_total = tot + tile_sums[b];
 }
 
-int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total)
+int ddcmi_scan_exclusive(ddcmi_ctx *ctx, const int *src, int *dst, int n, int *d_total)
 {
    if (n <= 0)
    {
@@ -76,8 +80,24 @@ int ddcmi_scan_exclusive(ddcmi_ctx *ctx, int *data, int n, int *d_total)
    }
    int nt = cdiv(n, SCAN_TILE);
    ENSURE(ctx, ctx->scan_tmp, nt + 1);
-   hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, ctx->stream, data, n, ctx->scan_tmp.p);
-   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_tmp.p, nt, d_total);
-   hipLaunchKernelGGL(k_scan_add, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, data, n, ctx->scan_tmp.p);
+   hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, ctx->stream, src, dst, n, ctx->scan_tmp.p, d_total);
+   if (nt > 1) hipLaunchKernelGGL(k_scan_finish, dim3(nt), dim3(256), 0, ctx->stream, dst, n, ctx->scan_tmp.p, d_total);
+   return DDCMI_OK;
+}
+
+/* several small arrays zeroed by ONE launch (a hipMemsetAsync each is a launch each, and an odd byte count two) */
+__global__ void k_zero_multi(ZeroJobs z)
+{
+   const int j = blockIdx.y;
+   int *p = z.p[j];
+   const int n = z.n[j];
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+int ddcmi_zero_ints(ddcmi_ctx *ctx, hipStream_t st, const ZeroJobs &z)
+{
+   int mx = 0;
+   for (int j = 0; j < z.cnt; j++) mx = std::max(mx, z.n[j]);
+   if (z.cnt <= 0 || mx <= 0) return DDCMI_OK;
+   hipLaunchKernelGGL(k_zero_multi, dim3(std::min(cdiv(mx, 256), 1024), z.cnt), dim3(256), 0, st, z);
    return DDCMI_OK;
 }
