@@ -311,9 +311,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 #ifndef NSHELL
 #define NSHELL 8            /* distance shells of the list order */
 #endif
-/* shell 0 = r < r0, shells 1.. = equal widths up to the list radius: boundaries only
+/* shell 0 = r < r0, shells 1.. = equal steps of r^2 (ddcmi_bl_finish): boundaries only
  * steer the ORDER of a bead's entries, so single precision is plenty */
-struct ShellCuts { float r0, inv_w; };
+struct ShellCuts { float a, b; };      /* shell = clamp((int)(a r^2 + b), 0, NSHELL-1) */
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
@@ -347,6 +347,25 @@ struct NbTileArgs
    int rot;                             /* tuning builds: rotate the range -> XCD assignment */
 };
 
+#ifdef DDCMI_TRACE_BLOCKS
+/* tuning builds only (tools/build_variants.sh): per-workgroup timeline of k_nonbond */
+__device__ unsigned long long g_trace[8 * 65536];
+#define TRACE_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
+{
+   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+/* the same for k_tile_build: [0] start [1] staged [2] end (100 MHz wall clock) [3] shader cycles start..end [4] xcc [5] hw id [6] owned beads [7] staged beads */
+__device__ unsigned long long g_trace_tb[8 * 65536];
+#define TRACE_TB(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace_tb[8 * blockIdx.x + (slot)] = (unsigned long long)(val); } while (0)
+extern "C" int ddcmi_debug_trace_build(unsigned long long *out, int nblocks)
+{
+   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace_tb), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#else
+#define TRACE_MARK(slot) do { } while (0)
+#define TRACE_TB(slot, val) do { } while (0)
+#endif
 template <bool HAS_MOL>      /* false: every molecule is a single bead -- no pair can be excluded, the molecule logic is compiled out */
 __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
                                                             const int *__restrict__ species,
@@ -368,6 +387,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    int t = blockIdx.x;
    int ts = ta.cell_start_o[TCELLS * t], te = ta.cell_start_o[TCELLS * t + TCELLS];
    int nown = te - ts;
+   TRACE_TB(0, wall_clock64()); TRACE_TB(6, nown > 0 ? nown : 0); TRACE_TB(2, 0);
+#ifdef DDCMI_TRACE_BLOCKS
+   const unsigned long long tb_c0 = clock64();
+   if (threadIdx.x == 0 && blockIdx.x < 65536)
+   {
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      g_trace_tb[8 * blockIdx.x + 4] = xcc; g_trace_tb[8 * blockIdx.x + 5] = hw;
+   }
+#endif
    if (nown <= 0)
    {
       if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 0; ta.tile_work[ta.ntile + t] = 0; }
@@ -468,6 +498,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       }
    }
    __syncthreads();
+   TRACE_TB(1, wall_clock64()); TRACE_TB(7, tot);
    const double rl2 = gp.rlist * gp.rlist;
    const float rl2_hi = (float)(rl2 * (1.0 + 1.0e-4)), rl2_lo = (float)(rl2 * (1.0 - 1.0e-4));
    const int rows = (nown + 63) & ~63;
@@ -502,12 +533,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          if (mns > 1 && aI < 63u && (exmask[(size_t)mt * 64] >> 63)) { by_mask = true; mask_i = exmask[(size_t)mt * 64 + aI]; }
       }
       int cnt = 0, ecnt = 0;
-      /* scratch row: two words per 8-byte store (tmpw is even) */
+      /* scratch row: two words per 8-byte store (tmpw is even); one 4-byte store per accepted candidate has fewer VALU
+       * instructions but twice the scattered store instructions, and measured 12 % slower */
       uint2 *row2 = (uint2 *)(ta.tmp32 + (size_t)a * ta.tmpw);
       unsigned wprev = 0;
-#if defined(TB_ST16)
-      unsigned w0_ = 0, w1_ = 0;
-#endif
       /* Of the 5x5x5 cells around the bead's cell only those within the list radius of the BEAD are walked: per
        * (y,z) row of cells the gap between the bead and the row's band, and from it the reach along x -- on average
        * 60 % of the candidates of the full cube.  Conservative: gaps are measured to the cells' geometric bounds
@@ -535,7 +564,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
             {
                float4 q4[4];
 #pragma unroll
-               for (int u = 0; u < 4; u++) q4[u] = P_s[min(sj0 + u, s1 - 1)];
+               for (int u = 0; u < 4; u++) q4[u] = P_s[sj0 + u];      /* past s1: another cell's bead or the tables behind P_s, masked by sj < s1 */
 #pragma unroll
                for (int u = 0; u < 4; u++)
                {
@@ -592,16 +621,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                         /* scratch word: final-format entry + its distance shell (k_tile_transpose lays the
                          * row out in shell order).  This path runs for every candidate of the wave (some lane
                          * always accepts), so it is kept short. */
-                        /* (shell boundaries steer only the ORDER of a bead's entries: single precision is plenty) */
-                        const int sh_ = min(max((int)floorf((__builtin_amdgcn_sqrtf(r2) - ta.shc.r0) * ta.shc.inv_w) + 1, 0), NSHELL - 1);
+                        /* (shell boundaries steer only the ORDER of a bead's entries: single precision, and linear in r^2 --
+                         * one fma, one conversion, one clamp; the square root and floor of equal-width shells in r were a
+                         * quarter of this path, and the kernel is bound by VALU issue) */
+                        const int sh_ = min(max((int)fmaf(r2, ta.shc.a, ta.shc.b), 0), NSHELL - 1);
                         unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | ((unsigned)sh_ << 16);
 #if defined(TB_ABLATE) && TB_ABLATE == 1      /* tuning builds: no scratch stores */
                         wprev += wcur;
-#elif defined(TB_ST16)                        /* tuning builds: four words per 16-byte store (tmpw is a multiple of 8) */
-                        if ((cnt & 3) == 3) { if (cnt < ta.tmpw) ((uint4 *)row2)[cnt >> 2] = make_uint4(w0_, w1_, wprev, wcur); }
-                        else if ((cnt & 3) == 0) w0_ = wcur;
-                        else if ((cnt & 3) == 1) w1_ = wcur;
-                        else wprev = wcur;
+#elif defined(TB_ST4)                         /* tuning builds: one 4-byte store per entry */
+                        if (cnt < ta.tmpw) ((unsigned *)row2)[cnt] = wcur;
 #else
                         if (cnt & 1) { if (cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, wcur); }
                         else wprev = wcur;
@@ -613,10 +641,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
             }
          }
       }
-#if defined(TB_ST16)
-      if ((cnt & 3) && (cnt & ~3) < ta.tmpw)
-         ((uint4 *)row2)[cnt >> 2] = make_uint4(w0_, (cnt & 3) > 1 ? w1_ : 0u, (cnt & 3) > 2 ? wprev : 0u, 0u);
-#else
+#if defined(TB_ABLATE) && TB_ABLATE == 1
+      if (wprev == 0x12345u) cnt++;
+#elif !defined(TB_ST4)
       if ((cnt & 1) && cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, 0u);
 #endif
       mymax = max(mymax, cnt);
@@ -675,27 +702,35 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       ta.tile_work[t] = (work + 1) | (s_halo ? (1 << 30) : 0);
       ta.tile_work[ta.ntile + t] = 7 * tot;
    }
+#ifdef DDCMI_TRACE_BLOCKS
+   TRACE_TB(2, wall_clock64()); TRACE_TB(3, clock64() - tb_c0);
+#endif
 }
 
 /* second half of the build: row-major scratch -> the tile's slot-major ELL slice
  * with entries ordered by distance shell.  Rows are brought into LDS in chunks of
- * TR_ROWS with coalesced loads; TR_TPR threads share a row, each running a
- * sequential counting sort over its contiguous part (stable, so the result does
- * not depend on timing); the sorted entries land in an LDS image of the slice,
- * which is written out with coalesced stores.  No cross-lane ranking: the earlier
- * wave-per-row version spent its time in ballot/popcount chains. */
+ * TR_ROWS with 16-byte loads; TR_TPR threads share a row, each running a sequential
+ * counting sort over its contiguous part (stable, so the result does not depend on
+ * timing); the sorted entries land in an LDS image of the slice, which is written
+ * out with 16-byte stores.  The kernel is bound by VALU issue, so the per-entry work
+ * is kept to a handful of instructions: the shell counters and cursors of a thread
+ * live in LDS ([shell][thread]: conflict-free) and are advanced by LDS atomics --
+ * ds_add / ds_add_rtn instead of shifts and selects on packed registers. */
 #define TR_THREADS 256
 #define TR_ROWS 32
 #define TR_TPR (TR_THREADS / TR_ROWS)      /* threads per row */
 #define IMG_STRIDE (TR_ROWS + 2)           /* +2 entries: slot rows land on different LDS banks */
+#define TR_RS(tmpw) ((tmpw) + 4)           /* row stride of the scratch image in words: rows stay 16-byte aligned */
 __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
 {
    extern __shared__ unsigned int tr_smem[];
-   const int rs = ta.tmpw | 1;                       /* odd row stride: rows start on different banks */
+   const int rs = TR_RS(ta.tmpw);
    unsigned int *rows_s = tr_smem;                   /* [TR_ROWS][rs] scratch words */
-   unsigned int *img32 = rows_s + TR_ROWS * rs;      /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for fill/copy */
+   unsigned int *img32 = rows_s + TR_ROWS * rs;      /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for the fill */
    unsigned short *img = (unsigned short *)img32;
    __shared__ int cnt_s[TR_ROWS];
+   __shared__ unsigned cur_s[NSHELL * TR_THREADS];   /* [shell][thread]: counts, then cursors */
+   static_assert(NSHELL == 8, "two words of four 16-bit shell counters");
    int t = blockIdx.x;
    int ts = ta.cell_start_o[TCELLS * t];
    int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
@@ -705,36 +740,38 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
    long long base = ta.tile_base[t];
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
    const int r_own = threadIdx.x / TR_TPR, q_own = threadIdx.x % TR_TPR;
+   unsigned *mycur = cur_s + threadIdx.x;
    for (int c0 = 0; c0 < rows; c0 += TR_ROWS)
    {
       for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += TR_THREADS) img32[idx] = 0;     /* width is a multiple of 8 <= tmpw */
+#pragma unroll
+      for (int sh = 0; sh < NSHELL; sh++) mycur[sh * TR_THREADS] = 0u;
       if (threadIdx.x < TR_ROWS) cnt_s[threadIdx.x] = (c0 + threadIdx.x < nown) ? ta.nbr_cnt[ts + c0 + threadIdx.x] : 0;
       __syncthreads();
       {
          /* all loads of the wave's rows are issued before the first LDS write: a plain
           * row loop pays one memory round trip per row */
          constexpr int RPW = TR_ROWS / (TR_THREADS / 64);
-         unsigned int v[RPW][3];
+         uint4 v[RPW];
 #pragma unroll
          for (int j = 0; j < RPW; j++)
          {
-            int r = w + j * (TR_THREADS / 64);
-            int cnt = cnt_s[r];
-            const unsigned int *src = ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw;
-#pragma unroll
-            for (int q = 0; q < 3; q++) { int k = lane + 64 * q; v[j][q] = (k < cnt) ? src[k] : 0u; }
+            const int r = w + j * (TR_THREADS / 64);
+            const int nq = (cnt_s[r] + 3) >> 2;
+            const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw);      /* tmpw is a multiple of 8 */
+            v[j] = (lane < nq) ? src[lane] : make_uint4(0, 0, 0, 0);
          }
 #pragma unroll
          for (int j = 0; j < RPW; j++)
          {
-            int r = w + j * (TR_THREADS / 64);
-            int cnt = cnt_s[r];
-#pragma unroll
-            for (int q = 0; q < 3; q++) { int k = lane + 64 * q; if (k < cnt) rows_s[r * rs + k] = v[j][q]; }
-            if (cnt > 192)
+            const int r = w + j * (TR_THREADS / 64);
+            const int nq = (cnt_s[r] + 3) >> 2;
+            uint4 *dst = (uint4 *)(rows_s + r * rs);
+            if (lane < nq) dst[lane] = v[j];
+            if (nq > 64)
             {
-               const unsigned int *src = ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw;
-               for (int k = lane + 192; k < cnt; k += 64) rows_s[r * rs + k] = src[k];
+               const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw);
+               for (int q = lane + 64; q < nq; q += 64) dst[q] = src[q];
             }
          }
       }
@@ -743,18 +780,17 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
          const int cnt = cnt_s[r_own];
          const int per = (cnt + TR_TPR - 1) / TR_TPR;
          const int k0 = min(q_own * per, cnt), k1 = min(k0 + per, cnt);
-         unsigned int *row = rows_s + r_own * rs;
-         /* counting sort by shell with the eight counters packed as 16-bit fields of two 64-bit words
-          * (a row holds < 65536 entries): one shift and one add per entry instead of eight selects */
-         static_assert(NSHELL == 8, "two words of four 16-bit shell counters");
+         const unsigned int *row = rows_s + r_own * rs;
+         for (int k = k0; k < k1; k++) atomicAdd(mycur + (row[k] >> 16) * TR_THREADS, 1u);      /* the shell, from k_tile_build */
+         /* offsets: shells in order, inside a shell the row's parts in order -- on the eight counts packed as 16-bit
+          * fields of two 64-bit words (a row holds < 65536 entries) */
          unsigned long long c0w = 0, c1w = 0;
-         for (int k = k0; k < k1; k++)
+#pragma unroll
+         for (int sh = 0; sh < 4; sh++)
          {
-            const int sh = (int)(row[k] >> 16);          /* the shell, from k_tile_build */
-            unsigned long long one = 1ull << (16 * (sh & 3));
-            if (sh < 4) c0w += one; else c1w += one;
+            c0w |= (unsigned long long)mycur[sh * TR_THREADS] << (16 * sh);
+            c1w |= (unsigned long long)mycur[(sh + 4) * TR_THREADS] << (16 * sh);
          }
-         /* offsets: shells in order, inside a shell the row's parts in order */
          unsigned long long i0 = c0w, i1 = c1w;
 #pragma unroll
          for (int off = 1; off < TR_TPR; off <<= 1)
@@ -767,27 +803,38 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
          const unsigned long long b0 = (t0 << 16) + (t0 << 32) + (t0 << 48);
          const unsigned long long n03 = ((b0 + t0) >> 48) & 0xffffull;                  /* entries in shells 0..3 */
          const unsigned long long b1 = n03 * 0x0001000100010001ull + (t1 << 16) + (t1 << 32) + (t1 << 48);
-         unsigned long long s0 = b0 + i0 - c0w, s1 = b1 + i1 - c1w;
+         const unsigned long long s0 = b0 + i0 - c0w, s1 = b1 + i1 - c1w;
+#pragma unroll
+         for (int sh = 0; sh < 4; sh++)
+         {
+            mycur[sh * TR_THREADS] = (unsigned)((s0 >> (16 * sh)) & 0xffffull);
+            mycur[(sh + 4) * TR_THREADS] = (unsigned)((s1 >> (16 * sh)) & 0xffffull);
+         }
          for (int k = k0; k < k1; k++)
          {
-            unsigned wv = row[k];
-            int sh = (int)(wv >> 16), sft = 16 * (sh & 3);
-            int slot;
-            if (sh < 4) { slot = (int)((s0 >> sft) & 0xffffull); s0 += 1ull << sft; }
-            else { slot = (int)((s1 >> sft) & 0xffffull); s1 += 1ull << sft; }
+            const unsigned wv = row[k];
+            const unsigned slot = atomicAdd(mycur + (wv >> 16) * TR_THREADS, 1u);
             img[slot * IMG_STRIDE + r_own] = (unsigned short)(wv & 0xffffu);
          }
       }
       __syncthreads();
-      /* slice layout: [slot group g][row][8 slots] -> a lane reads its 8 slots of a group with one 16-byte load */
-      int nr = min(TR_ROWS, rows - c0);
-      int ngrp = width >> 3;
-      for (int idx = threadIdx.x; idx < ngrp * nr * 4; idx += TR_THREADS)
+      /* slice layout: [slot group g][row][8 slots] -> a lane reads its 8 slots of a group with one 16-byte load;
+       * written the same way: thread (g, r) packs the group's 8 entries of its row */
       {
-         int q = idx & 3, r = (idx >> 2) % nr, g = (idx >> 2) / nr;
-         int k = 8 * g + 2 * q;
-         unsigned int lo = img[k * IMG_STRIDE + r], hi = img[(k + 1) * IMG_STRIDE + r];
-         *(unsigned int *)(ta.nbr16 + base + ((size_t)g * rows + c0 + r) * 8 + 2 * q) = lo | (hi << 16);
+         const int nr = min(TR_ROWS, rows - c0);
+         const int ngrp = width >> 3;
+         const int r = threadIdx.x & (TR_ROWS - 1);
+         if (r < nr)
+            for (int g = threadIdx.x / TR_ROWS; g < ngrp; g += TR_THREADS / TR_ROWS)
+            {
+               const unsigned short *e = img + (8 * g) * IMG_STRIDE + r;
+               uint4 o;
+               o.x = (unsigned)e[0] | ((unsigned)e[IMG_STRIDE] << 16);
+               o.y = (unsigned)e[2 * IMG_STRIDE] | ((unsigned)e[3 * IMG_STRIDE] << 16);
+               o.z = (unsigned)e[4 * IMG_STRIDE] | ((unsigned)e[5 * IMG_STRIDE] << 16);
+               o.w = (unsigned)e[6 * IMG_STRIDE] | ((unsigned)e[7 * IMG_STRIDE] << 16);
+               *(uint4 *)(ta.nbr16 + base + ((size_t)g * rows + c0 + r) * 8) = o;
+            }
       }
       __syncthreads();
    }
@@ -819,17 +866,6 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
  *      shifted copies and excluded pairs (see below).
  * Bound: FP64 issue and LDS gathers behind s_waitcnt at 4 waves per SIMD -- DESIGN.md section 4 has the
  * counters, the ablations and the per-CU timelines. */
-#ifdef DDCMI_TRACE_BLOCKS
-/* tuning builds only (tools/build_variants.sh): per-workgroup timeline of k_nonbond */
-__device__ unsigned long long g_trace[8 * 65536];
-#define TRACE_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
-extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
-{
-   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)nblocks * 8 * sizeof(unsigned long long));
-}
-#else
-#define TRACE_MARK(slot) do { } while (0)
-#endif
 template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
@@ -2476,8 +2512,13 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    double rcut = ctx->rmax, dR = ctx->deltaR;
    /* distance shells of the list order: entries a wave rejects as a whole come last */
    ShellCuts shc;
-   shc.r0 = (float)(rcut - 0.25 * dR);
-   shc.inv_w = (float)((NSHELL - 1) / (rcut + dR - (rcut - 0.25 * dR)));
+   {
+      /* shell 0: r < rcut - dR/4; shells 1..NSHELL-2: equal steps of r^2 up to rcut + 3/4 dR (0.7 A wide at the cut-off for
+       * the Martini numbers); the last shell: everything beyond, which no drift brings inside the cut-off */
+      const double r0 = rcut - 0.25 * dR, rh = rcut + 0.75 * dR;
+      const double a = (dR > 1e-9 * rcut) ? (NSHELL - 2) / (rh * rh - r0 * r0) : 0.0;      /* no skin: one shell */
+      shc.a = (float)a; shc.b = (float)(1.0 - r0 * r0 * a);
+   }
    unsigned long long *d_tot = (unsigned long long *)(ctx->d_flags + 16);    /* [0]=entries [1]=excluded [2]=arena used; travels with the flags */
    for (int attempt = 0;; attempt++)
    {
@@ -2517,7 +2558,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 2 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
       HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
       {
-         size_t lds2 = (size_t)TR_ROWS * (ctx->tmpw | 1) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
+         size_t lds2 = (size_t)TR_ROWS * TR_RS(ctx->tmpw) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
          if (lds2 > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "lists of %d entries per bead do not fit the transpose kernel's LDS", ctx->tmpw);
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
          hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
