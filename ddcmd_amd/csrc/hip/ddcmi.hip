@@ -728,7 +728,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
    unsigned int *rows_s = tr_smem;                   /* [TR_ROWS][rs] scratch words */
    unsigned int *img32 = rows_s + TR_ROWS * rs;      /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for the fill */
    unsigned short *img = (unsigned short *)img32;
-   __shared__ int cnt_s[TR_ROWS];
+   __shared__ int cnt2_s[2][TR_ROWS];                /* entry counts of the rows of this chunk and the next */
    __shared__ unsigned cur_s[NSHELL * TR_THREADS];   /* [shell][thread]: counts, then cursors */
    static_assert(NSHELL == 8, "two words of four 16-bit shell counters");
    int t = blockIdx.x;
@@ -741,47 +741,65 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
    const int r_own = threadIdx.x / TR_TPR, q_own = threadIdx.x % TR_TPR;
    unsigned *mycur = cur_s + threadIdx.x;
-   for (int c0 = 0; c0 < rows; c0 += TR_ROWS)
+   /* A workgroup spends its life in round trips (a chunk's rows from memory, then three barriers), and the kernel's
+    * time is that latency over the workgroups a CU holds: the rows of chunk c + 1 are requested before chunk c is
+    * sorted and wait in registers; the counts that size those loads run one chunk further ahead. */
+   constexpr int RPW = TR_ROWS / (TR_THREADS / 64);
+   uint4 vn[RPW];
+   auto row_count = [&](int r) -> int { return r < nown ? ta.nbr_cnt[ts + r] : 0; };
+   auto request = [&](int c0n, const int *cnt)
    {
+#pragma unroll
+      for (int j = 0; j < RPW; j++)
+      {
+         const int r = w + j * (TR_THREADS / 64);
+         const int nq = (cnt[r] + 3) >> 2;
+         const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0n + r, nown - 1)) * ta.tmpw);      /* tmpw is a multiple of 8 */
+         vn[j] = (lane < nq) ? src[lane] : make_uint4(0, 0, 0, 0);
+      }
+   };
+   if (threadIdx.x < 2 * TR_ROWS) cnt2_s[0][threadIdx.x] = row_count(threadIdx.x);      /* both buffers: chunks 0 and 1 */
+   __syncthreads();
+   request(0, cnt2_s[0]);
+   for (int c0 = 0, ci = 0; c0 < rows; c0 += TR_ROWS, ci++)
+   {
+      const int *cnt_s = cnt2_s[ci & 1];
+      const int cn2 = (threadIdx.x < TR_ROWS) ? row_count(c0 + 2 * TR_ROWS + threadIdx.x) : 0;
       for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += TR_THREADS) img32[idx] = 0;     /* width is a multiple of 8 <= tmpw */
 #pragma unroll
       for (int sh = 0; sh < NSHELL; sh++) mycur[sh * TR_THREADS] = 0u;
-      if (threadIdx.x < TR_ROWS) cnt_s[threadIdx.x] = (c0 + threadIdx.x < nown) ? ta.nbr_cnt[ts + c0 + threadIdx.x] : 0;
-      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RPW; j++)
       {
-         /* all loads of the wave's rows are issued before the first LDS write: a plain
-          * row loop pays one memory round trip per row */
-         constexpr int RPW = TR_ROWS / (TR_THREADS / 64);
-         uint4 v[RPW];
-#pragma unroll
-         for (int j = 0; j < RPW; j++)
+         const int r = w + j * (TR_THREADS / 64);
+         const int nq = (cnt_s[r] + 3) >> 2;
+         uint4 *dst = (uint4 *)(rows_s + r * rs);
+         if (lane < nq) dst[lane] = vn[j];
+         if (nq > 64)
          {
-            const int r = w + j * (TR_THREADS / 64);
-            const int nq = (cnt_s[r] + 3) >> 2;
-            const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw);      /* tmpw is a multiple of 8 */
-            v[j] = (lane < nq) ? src[lane] : make_uint4(0, 0, 0, 0);
-         }
-#pragma unroll
-         for (int j = 0; j < RPW; j++)
-         {
-            const int r = w + j * (TR_THREADS / 64);
-            const int nq = (cnt_s[r] + 3) >> 2;
-            uint4 *dst = (uint4 *)(rows_s + r * rs);
-            if (lane < nq) dst[lane] = v[j];
-            if (nq > 64)
-            {
-               const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw);
-               for (int q = lane + 64; q < nq; q += 64) dst[q] = src[q];
-            }
+            const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw);
+            for (int q = lane + 64; q < nq; q += 64) dst[q] = src[q];
          }
       }
+      if (c0 + TR_ROWS < rows) request(c0 + TR_ROWS, cnt2_s[(ci + 1) & 1]);
       __syncthreads();
       {
          const int cnt = cnt_s[r_own];
          const int per = (cnt + TR_TPR - 1) / TR_TPR;
          const int k0 = min(q_own * per, cnt), k1 = min(k0 + per, cnt);
          const unsigned int *row = rows_s + r_own * rs;
-         for (int k = k0; k < k1; k++) atomicAdd(mycur + (row[k] >> 16) * TR_THREADS, 1u);      /* the shell, from k_tile_build */
+         /* (four entries per trip: the LDS reads and atomics of a trip are issued back to back -- LDS executes a wave's
+          * operations in order, so same-counter atomics of one thread still see each other) */
+         int k = k0;
+         for (; k + 4 <= k1; k += 4)
+         {
+            unsigned wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) wv[u] = row[k + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) atomicAdd(mycur + (wv[u] >> 16) * TR_THREADS, 1u);      /* the shell, from k_tile_build */
+         }
+         for (; k < k1; k++) atomicAdd(mycur + (row[k] >> 16) * TR_THREADS, 1u);
          /* offsets: shells in order, inside a shell the row's parts in order -- on the eight counts packed as 16-bit
           * fields of two 64-bit words (a row holds < 65536 entries) */
          unsigned long long c0w = 0, c1w = 0;
@@ -810,7 +828,18 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
             mycur[sh * TR_THREADS] = (unsigned)((s0 >> (16 * sh)) & 0xffffull);
             mycur[(sh + 4) * TR_THREADS] = (unsigned)((s1 >> (16 * sh)) & 0xffffull);
          }
-         for (int k = k0; k < k1; k++)
+         k = k0;
+         for (; k + 4 <= k1; k += 4)
+         {
+            unsigned wv[4], slot[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) wv[u] = row[k + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) slot[u] = atomicAdd(mycur + (wv[u] >> 16) * TR_THREADS, 1u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) img[slot[u] * IMG_STRIDE + r_own] = (unsigned short)(wv[u] & 0xffffu);
+         }
+         for (; k < k1; k++)
          {
             const unsigned wv = row[k];
             const unsigned slot = atomicAdd(mycur + (wv >> 16) * TR_THREADS, 1u);
@@ -836,6 +865,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
                *(uint4 *)(ta.nbr16 + base + ((size_t)g * rows + c0 + r) * 8) = o;
             }
       }
+      if (threadIdx.x < TR_ROWS) cnt2_s[ci & 1][threadIdx.x] = cn2;      /* this buffer's next user is chunk ci + 2 */
       __syncthreads();
    }
 }
