@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
 {
    /* LDS image of the neighbourhood: positions relative to the tile centre in single precision + the
     * low tag word (16 B per bead, one ds_read_b128 per candidate) and the molecule ids (4 B).  The
-    * list criterion stays the reference's double-precision r^2 < rlist^2: candidates within 1e-4
+    * list criterion stays the reference's double-precision r^2 < rlist^2: candidates within TB_BAND
     * (relative) of the boundary are re-tested from the double positions in global memory. */
    extern __shared__ float4 tb_smem[];
    float4 *P_s = tb_smem;
@@ -463,6 +463,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       if (c < NRC) { const int o = ofs_s[c]; for (int k = 0; k < v[h]; k++) cellof_s[o + k] = (unsigned short)c; }
    }
    __syncthreads();
+   float amax = 0.0f;      /* largest staged coordinate: sizes the band of the exact test */
    for (int k0 = threadIdx.x; k0 < tot; k0 += 4 * TB_THREADS)
    {
       int gj[4];
@@ -492,15 +493,29 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
             unsigned long long w = (unsigned long long)__double_as_longlong(p.w);
             unsigned lo = (unsigned)w;
             if (hs4[u] != 13) lo |= 8u;       /* travels into the entry's type nibble */
-            P_s[k] = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
+            const float4 ps = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
+            amax = fmaxf(amax, fmaxf(fabsf(ps.x), fmaxf(fabsf(ps.y), fabsf(ps.z))));
+            P_s[k] = ps;
             if (HAS_MOL) M_s[k] = (unsigned)(w >> 32);
          }
       }
    }
-   __syncthreads();
    TRACE_TB(1, wall_clock64()); TRACE_TB(7, tot);
    const double rl2 = gp.rlist * gp.rlist;
-   const float rl2_hi = (float)(rl2 * (1.0 + 1.0e-4)), rl2_lo = (float)(rl2 * (1.0 - 1.0e-4));
+   /* Error of the single-precision r^2: the staged coordinates are rounded once (half an ulp of the largest coordinate
+    * A relative to the tile centre: A 2^-24), so a separation component is off by < 2 A 2^-24 and r^2 at r = rlist by
+    * < 2 sqrt(3) rlist 2 A 2^-24 + 4 rlist^2 2^-24 of arithmetic rounding.  The band is four times that: 6e-6 relative
+    * for rlist = 16 A (A = 48 A); beads far outside an open box widen it.  (A fixed 1e-4 sent every 120th candidate slot
+    * of a wave through the two dependent global loads of the exact test.) */
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+   __shared__ float s_amax[TB_THREADS / 64];
+   if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = amax;
+   __syncthreads();
+#pragma unroll
+   for (int q = 0; q < TB_THREADS / 64; q++) amax = fmaxf(amax, s_amax[q]);
+   const double band = 4.0 * (4.0 * 1.7320508 * gp.rlist * (double)amax + 4.0 * rl2) * 5.9604645e-8 / rl2;
+   const float rl2_hi = (float)(rl2 * (1.0 + band)), rl2_lo = (float)(rl2 * (1.0 - band));
    const int rows = (nown + 63) & ~63;
    int mymax = 0;
    /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go
