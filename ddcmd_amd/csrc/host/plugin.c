@@ -21,6 +21,87 @@ static void die(const char *where, const char *msg)
    exit(1);
 }
 
+/* ------------------------------------------------------------------------- */
+/* More than one rank: what ddcMD takes from MPI and the DDC object (ddc.c: lx ly lz, COMM_LOCAL rank/size).
+ * The ranks of a launch are started by any launcher that hands each process RANK / WORLD_SIZE / LOCAL_RANK
+ * (python -m torch.distributed.run, or a shell loop); they meet over libddcmi's TCP rendezvous and exchange
+ * halos over RCCL (one GPU per rank) or, with DDCMI_TRANSPORT=host, over the rendezvous' streams (ranks that
+ * share a GPU).  Rank 0 owns stdout, the data file and the restart files; STATE on rank 0 is the gathered
+ * global state at print / checkpoint steps, exactly what it is on one rank. */
+typedef struct { int rank, world, local_rank, grid[3], host_transport; ddcmi_rdzv *rdzv; } PARENV;
+static PARENV par = {0, 1, 0, {1, 1, 1}, 0, NULL};
+static int env_int(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+static void parallel_init(const ddcmi_setup *s)
+{
+   par.rank = env_int("RANK", 0); par.world = env_int("WORLD_SIZE", 1); par.local_rank = env_int("LOCAL_RANK", par.rank);
+   par.grid[0] = par.grid[1] = par.grid[2] = 1;
+   if (par.world <= 1) { par.world = 1; par.rank = 0; return; }
+   if (par.rank < 0 || par.rank >= par.world) die("parallel_init", "RANK outside 0..WORLD_SIZE-1");
+   if ((long)s->lx * s->ly * s->lz == par.world) { par.grid[0] = s->lx; par.grid[1] = s->ly; par.grid[2] = s->lz; }      /* ddc { lx ly lz } */
+   else
+   {
+      /* no matching DDC object: factor WORLD_SIZE over the axes, largest factors first, always onto the axis with the
+       * widest bricks (2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2 for a cubic box) */
+      int w = par.world;
+      double L[3] = {s->h[0], s->h[4], s->h[8]};
+      for (int f = 2; w > 1;)
+      {
+         if (w % f) { f++; continue; }
+         int a = 0;
+         for (int b = 1; b < 3; b++) if (L[b] / par.grid[b] > L[a] / par.grid[a] * (1.0 + 1e-12)) a = b;
+         par.grid[a] *= f; w /= f;
+      }
+   }
+   const char *addr = getenv("MASTER_ADDR");
+   if (!addr || !*addr) addr = "127.0.0.1";
+   char pf[1024];
+   const char *file = getenv("DDCMI_RDZV_FILE");
+   if (!file || !*file)
+   {
+      /* one name per launch: the workers of a launch share the launcher as parent (the same key bench.py uses) */
+      const char *tmp = getenv("TMPDIR"), *mp = getenv("MASTER_PORT"), *rid = getenv("TORCHELASTIC_RUN_ID");
+      snprintf(pf, sizeof(pf), "%s/ddcmi_rdzv_%s_%s_%s_%d", (tmp && *tmp) ? tmp : "/tmp", addr, (mp && *mp) ? mp : "0", (rid && *rid) ? rid : "none", (int)getppid());
+      for (char *c = pf + strlen((tmp && *tmp) ? tmp : "/tmp") + 1; *c; c++) if (*c == '/') *c = '_';
+      file = pf;
+   }
+   if (ddcmi_rdzv_create(&par.rdzv, par.rank, par.world, addr, env_int("DDCMI_RDZV_PORT", 0), file, 300.0) != DDCMI_OK)
+      die("parallel_init", ddcmi_rdzv_last_error(NULL));
+   const char *tr = getenv("DDCMI_TRANSPORT");
+   par.host_transport = tr && strcmp(tr, "host") == 0;
+}
+static void parallel_comm_init(ddcmi_ctx *ctx)
+{
+   if (par.world <= 1) return;
+   if (par.host_transport)
+   {
+      if (ddcmi_comm_init_host(ctx, par.rdzv, par.grid[0], par.grid[1], par.grid[2]) != DDCMI_OK) die("ddcmi_comm_init_host", ddcmi_last_error(ctx));
+      return;
+   }
+   char id[128];
+   memset(id, 0, sizeof(id));
+   if (par.rank == 0 && ddcmi_comm_unique_id(id) != DDCMI_OK) die("ddcmi_comm_unique_id", ddcmi_last_error(ctx));
+   if (ddcmi_rdzv_bcast(par.rdzv, id, sizeof(id), 0) != DDCMI_OK) die("parallel_comm_init", ddcmi_rdzv_last_error(par.rdzv));      /* MPI_Bcast of the RCCL id */
+   if (ddcmi_comm_init(ctx, par.rank, par.world, id, par.grid[0], par.grid[1], par.grid[2]) != DDCMI_OK) die("ddcmi_comm_init", ddcmi_last_error(ctx));
+}
+/* owner of a bead in the px x py x pz brick decomposition of a box centred on the origin (domain.c:191-208 for a cubic
+ * lattice of domain centres) */
+static int brick_of(const ddcmi_setup *s, double x, double y, double z)
+{
+   const double r[3] = {x, y, z}, L[3] = {s->h[0], s->h[4], s->h[8]};
+   int out = 0, mult = 1;
+   for (int a = 0; a < 3; a++)
+   {
+      const int P = par.grid[a];
+      double w = r[a] - L[a] * rint(r[a] / L[a]);
+      int b = (int)floor((w + 0.5 * L[a]) / (L[a] / P));
+      if (b < 0) b = 0;
+      if (b > P - 1) b = P - 1;
+      out += mult * b; mult *= P;
+   }
+   return out;
+}
+
+
 /* accelerator_init, accelerator.c:10-56 */
 ACCELERATOR *accelerator_init(void *parent, const char *name, const char *type)
 {
@@ -32,7 +113,8 @@ ACCELERATOR *accelerator_init(void *parent, const char *name, const char *type)
    else if (strcmp(a->type, "HIP") == 0) a->itype = GPU_HIP;
    else die("accelerator_init", "ACCELERATOR type must be CUDA or HIP");
    ddcmi_ctx *ctx = NULL;
-   int dev = 0;
+   /* one GPU per rank (LOCAL_RANK) unless the ranks are told to share one (tests on a one-GPU box) */
+   int dev = (par.world > 1 && !env_int("DDCMI_SINGLE_DEVICE", 0)) ? par.local_rank : 0;
    const char *env = getenv("DDCMI_DEVICE");
    if (env) dev = atoi(env);
    if (ddcmi_create(&ctx, dev) != DDCMI_OK) die("accelerator_init", ddcmi_last_error(NULL));
@@ -75,6 +157,10 @@ static int martiniBondHIPParms(ddcmi_ctx *ctx, const ddcmi_setup *s)
    }
    int *bij = malloc(sizeof(int) * (2 * nb + 2)), *aijk = malloc(sizeof(int) * (3 * na + 3)), *af = malloc(sizeof(int) * (na + 1));
    int *tijkl = malloc(sizeof(int) * (4 * nt + 4)), *tf = malloc(sizeof(int) * (nt + 1)), *tn = malloc(sizeof(int) * (nt + 1));
+   /* more than one rank: the atoms of a term are named by gid (ddcmi_set_bonded_gid): beads migrate one by one */
+   const int by_gid = par.world > 1;
+   uint64_t *bg = by_gid ? malloc(sizeof(uint64_t) * (2 * nb + 2)) : NULL, *ag = by_gid ? malloc(sizeof(uint64_t) * (3 * na + 3)) : NULL,
+            *tg = by_gid ? malloc(sizeof(uint64_t) * (4 * nt + 4)) : NULL;
    double *kb = malloc(sizeof(double) * (nb + 1)), *b0 = malloc(sizeof(double) * (nb + 1));
    double *ak = malloc(sizeof(double) * (na + 1)), *a0 = malloc(sizeof(double) * (na + 1));
    double *tk = malloc(sizeof(double) * (nt + 1)), *td = malloc(sizeof(double) * (nt + 1));
@@ -96,7 +182,16 @@ static int martiniBondHIPParms(ddcmi_ctx *ctx, const ddcmi_setup *s)
 #undef AT
       first = last;
    }
-   int rc = ddcmi_set_bonded(ctx, (int)nb, bij, kb, b0, (int)na, aijk, af, ak, a0, (int)nt, tijkl, tf, tn, tk, td, s->excludePotentialTerm);
+   int rc;
+   if (by_gid)
+   {
+      for (size_t k = 0; k < 2 * nb; k++) bg[k] = s->gid[bij[k]];
+      for (size_t k = 0; k < 3 * na; k++) ag[k] = s->gid[aijk[k]];
+      for (size_t k = 0; k < 4 * nt; k++) tg[k] = s->gid[tijkl[k]];
+      rc = ddcmi_set_bonded_gid(ctx, (int)nb, bg, kb, b0, (int)na, ag, af, ak, a0, (int)nt, tg, tf, tn, tk, td, s->excludePotentialTerm);
+      free(bg); free(ag); free(tg);
+   }
+   else rc = ddcmi_set_bonded(ctx, (int)nb, bij, kb, b0, (int)na, aijk, af, ak, a0, (int)nt, tijkl, tf, tn, tk, td, s->excludePotentialTerm);
    free(ord); free(bij); free(aijk); free(af); free(tijkl); free(tf); free(tn); free(kb); free(b0); free(ak); free(a0); free(tk); free(td);
    return rc;
 }
@@ -130,7 +225,7 @@ static void martini_parms(POTENTIAL *potential, SIMULATE *simulate)
    rc |= martiniBondHIPParms(ctx, s);
    rc |= ddcmi_set_clock(ctx, s->loop, s->time);
    if (rc) die("martini_parms", ddcmi_last_error(ctx));
-   printf("using HIP martini parms\n");                 /* bioMartini.c:1339 prints "using gpu martini parms" */
+   if (par.rank == 0) printf("using HIP martini parms\n");                 /* bioMartini.c:1339 prints "using gpu martini parms" */
    MARTINIHIP_PARMS *parms = calloc(1, sizeof(MARTINIHIP_PARMS));
    parms->ctx = ctx; parms->rmax = s->rmax; parms->simulate = simulate;
    potential->itype = MARTINI;
@@ -243,7 +338,14 @@ static void nglfconstraintHIP_parms(ddcmi_ctx *ctx, const ddcmi_setup *s)
          if (pass == 1)
          {
             poff[ng] = (int)np;
-            if (ddcmi_set_constraints(ctx, (int)ng, poff, pi, pj, dd) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+            if (par.world > 1)
+            {
+               uint64_t *gi = malloc(sizeof(uint64_t) * (np + 1)), *gj = malloc(sizeof(uint64_t) * (np + 1));
+               for (size_t k = 0; k < np; k++) { gi[k] = s->gid[pi[k]]; gj[k] = s->gid[pj[k]]; }
+               if (ddcmi_set_constraints_gid(ctx, (int)ng, poff, gi, gj, dd) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+               free(gi); free(gj);
+            }
+            else if (ddcmi_set_constraints(ctx, (int)ng, poff, pi, pj, dd) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
             free(poff); free(pi); free(pj); free(dd);
          }
       }
@@ -269,8 +371,17 @@ static void nglfconstraintHIP_parms(ddcmi_ctx *ctx, const ddcmi_setup *s)
          first = last;
       }
       moff[nmulti] = natm;
-      if (ddcmi_set_barostat(ctx, s->npt_T, s->npt_P0, s->npt_beta, s->npt_tau) != DDCMI_OK ||
-          ddcmi_set_molecule_lists(ctx, nmol, nmulti, moff, matm) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+      if (ddcmi_set_barostat(ctx, s->npt_T, s->npt_P0, s->npt_beta, s->npt_tau) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+      if (par.world > 1)
+      {
+         uint64_t *mg = malloc(sizeof(uint64_t) * (natm + 1));
+         double *mm = calloc(nmulti + 1, sizeof(double));      /* total mass of each multi-bead molecule */
+         for (int k = 0; k < natm; k++) mg[k] = s->gid[matm[k]];
+         for (int m = 0; m < nmulti; m++) for (int k = moff[m]; k < moff[m + 1]; k++) mm[m] += s->mass[s->species[matm[k]]];
+         if (ddcmi_set_molecule_lists_gid(ctx, nmol, nmulti, moff, mg, mm) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
+         free(mg); free(mm);
+      }
+      else if (ddcmi_set_molecule_lists(ctx, nmol, nmulti, moff, matm) != DDCMI_OK) die("nglfconstraint_parms", ddcmi_last_error(ctx));
       free(moff); free(matm);
    }
    free(ord);
@@ -433,7 +544,7 @@ void kinetic_terms(SYSTEM *sys, int flag)
    else if (ddcmi_kinetic(ctx, &e->rk, tion) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
    e->tion.xx = tion[DDCMI_XX]; e->tion.yy = tion[DDCMI_YY]; e->tion.zz = tion[DDCMI_ZZ];
    e->tion.xy = tion[DDCMI_XY]; e->tion.xz = tion[DDCMI_XZ]; e->tion.yz = tion[DDCMI_YZ];
-   e->number = (double)sys->nlocal;
+   e->number = (par.world > 1) ? (double)ddcmi_nlocal(ctx) : (double)sys->nlocal;      /* this rank's beads (they migrate); eval_energyInfo sums the ranks */
    e->temperature = 2.0 * e->rk / (3.0 * (double)sys->nglobal);        /* energy.c:151 */
 }
 
@@ -441,6 +552,16 @@ void kinetic_terms(SYSTEM *sys, int flag)
 void eval_energyInfo(SYSTEM *sys)
 {
    ETYPE *e = &sys->energyInfo;
+   if (par.world > 1)
+   {
+      /* allreduce(energyInfo), energyInfo.c:9-63: the members this path fills */
+      double b[15] = {e->rk, e->eion, e->virial.xx, e->virial.yy, e->virial.zz, e->virial.xy, e->virial.xz, e->virial.yz,
+                      e->number, e->tion.xx, e->tion.yy, e->tion.zz, e->tion.xy, e->tion.xz, e->tion.yz};
+      ddcmi_ctx *c = accelerator_getAccelerator(NULL)->parms;
+      if (ddcmi_comm_allreduce_sum(c, b, 15) != DDCMI_OK) die("eval_energyInfo", ddcmi_last_error(c));
+      e->rk = b[0]; e->eion = b[1]; e->virial.xx = b[2]; e->virial.yy = b[3]; e->virial.zz = b[4]; e->virial.xy = b[5]; e->virial.xz = b[6]; e->virial.yz = b[7];
+      e->number = b[8]; e->tion.xx = b[9]; e->tion.yy = b[10]; e->tion.zz = b[11]; e->tion.xy = b[12]; e->tion.xz = b[13]; e->tion.yz = b[14];
+   }
    /* the barostat moves the box on the device */
    if (ddcmi_get_box(accelerator_getAccelerator(NULL)->parms, sys->box->h0) == DDCMI_OK)
       sys->box->volume = sys->box->h0[0] * sys->box->h0[4] * sys->box->h0[8];
@@ -465,21 +586,98 @@ void eval_energyInfo(SYSTEM *sys)
    for (int g = 0; g < sys->ngroup && g < 32; g++) sys->group[g]->energyInfo.temperature = Tg[g];
 }
 
+/* more than one rank: the beads every rank owns now (they migrate), identified by gid, gathered on rank 0 in rank order;
+ * collective.  Species and group come back as the deck's objects (the group of a bead is looked up by its gid). */
+typedef struct { uint64_t gid; int species, pad; double r[3], v[3], f[3]; } PREC;
+static const ddcmi_setup *gather_setup = NULL;
+static gid_order *gather_tab = NULL;
+static int gather_state(SYSTEM *sys)
+{
+   ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+   STATE *st = sys->state;
+   const ddcmi_setup *s = gather_setup;
+   const int cap = (int)sys->nglobal + 16;
+   int n = 0;
+   uint64_t *gid = malloc(sizeof(uint64_t) * (size_t)cap);
+   int *sp = malloc(sizeof(int) * (size_t)cap);
+   double *a = malloc(sizeof(double) * 9 * (size_t)cap);
+   if (ddcmi_download_particles(ctx, cap, &n, gid, sp, a, a + cap, a + 2 * (size_t)cap, a + 3 * (size_t)cap, a + 4 * (size_t)cap, a + 5 * (size_t)cap,
+                                a + 6 * (size_t)cap, a + 7 * (size_t)cap, a + 8 * (size_t)cap) != DDCMI_OK) die("sendHostState", ddcmi_last_error(ctx));
+   sys->nlocal = sys->nion = (unsigned)n;
+   int *cnt = malloc(sizeof(int) * (size_t)par.world);
+   if (ddcmi_rdzv_allgather(par.rdzv, &n, cnt, sizeof(int)) != DDCMI_OK) die("sendHostState", ddcmi_rdzv_last_error(par.rdzv));
+   long tot = 0;
+   for (int r = 0; r < par.world; r++) tot += cnt[r];
+   if (tot != (long)sys->nglobal) die("sendHostState", "the ranks' bead counts do not add up to the global count");
+   PREC *rec = malloc(sizeof(PREC) * (size_t)(par.rank == 0 ? tot : n) + 8);
+   for (int i = 0; i < n; i++)
+   {
+      PREC *q = rec + i;
+      q->gid = gid[i]; q->species = sp[i]; q->pad = 0;
+      for (int k = 0; k < 3; k++) { q->r[k] = a[(size_t)k * cap + i]; q->v[k] = a[(size_t)(3 + k) * cap + i]; q->f[k] = a[(size_t)(6 + k) * cap + i]; }
+   }
+   free(gid); free(sp); free(a);
+   if (par.rank != 0)
+   {
+      const int peer = 0; const void *sb = rec; const size_t sbytes = sizeof(PREC) * (size_t)n;
+      if (ddcmi_rdzv_exchange(par.rdzv, n > 0 ? 1 : 0, &peer, &sb, &sbytes, 0, NULL, NULL, NULL) != DDCMI_OK) die("sendHostState", ddcmi_rdzv_last_error(par.rdzv));
+   }
+   else
+   {
+      int *peer = malloc(sizeof(int) * (size_t)par.world); void **rb = malloc(sizeof(void *) * (size_t)par.world); size_t *rbytes = malloc(sizeof(size_t) * (size_t)par.world);
+      int nr = 0; size_t off = (size_t)n;
+      for (int r = 1; r < par.world; r++)
+      {
+         if (cnt[r] > 0) { peer[nr] = r; rb[nr] = rec + off; rbytes[nr] = sizeof(PREC) * (size_t)cnt[r]; nr++; }
+         off += (size_t)cnt[r];
+      }
+      if (ddcmi_rdzv_exchange(par.rdzv, 0, NULL, NULL, NULL, nr, peer, rb, rbytes) != DDCMI_OK) die("sendHostState", ddcmi_rdzv_last_error(par.rdzv));
+      free(peer); free(rb); free(rbytes);
+      for (long i = 0; i < tot; i++)
+      {
+         const PREC *q = rec + i;
+         gid_order key = {q->gid, 0};
+         const gid_order *hit = bsearch(&key, gather_tab, (size_t)s->natoms, sizeof(gid_order), cmp_gid);
+         if (!hit) die("sendHostState", "a bead came back with a gid the deck does not have");
+         st->label[i] = q->gid; st->species[i] = sys->species[q->species]; st->group[i] = sys->group[s->group[hit->id]]; st->q[i] = st->species[i]->charge;
+         st->rx[i] = q->r[0]; st->ry[i] = q->r[1]; st->rz[i] = q->r[2]; st->vx[i] = q->v[0]; st->vy[i] = q->v[1]; st->vz[i] = q->v[2];
+         st->fx[i] = q->f[0]; st->fy[i] = q->f[1]; st->fz[i] = q->f[2];
+      }
+      st->nlocal = st->nion = (int)tot;
+   }
+   free(rec); free(cnt);
+   return DDCMI_OK;
+}
 int sendHostState(SYSTEM *sys)
 {
    ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
    STATE *st = sys->state;
+   if (par.world > 1) return gather_state(sys);
    if (host_integrated(sys)) return DDCMI_OK;      /* STATE is the master copy */
    return ddcmi_download_state(ctx, DDCMI_POS | DDCMI_VEL | DDCMI_FORCE, st->rx, st->ry, st->rz, st->vx, st->vy, st->vz, st->fx, st->fy, st->fz);
 }
 
 /* ------------------------------------------------------------------------- */
 /* restart writer */
+static int writeRestart_rank0(SIMULATE *simulate, const char *dir, int restartLink);
 int writeRestart(SIMULATE *simulate, const char *dir, int restartLink)
 {
    SYSTEM *sys = simulate->system;
-   STATE *st = sys->state;
    if (sendHostState(sys) != DDCMI_OK) return -1;
+   if (par.world > 1)
+   {
+      /* rank 0 holds the gathered state and writes the files of a one-rank run; the others wait until they exist */
+      int rc0 = (par.rank == 0) ? writeRestart_rank0(simulate, dir, restartLink) : 0;
+      double flag = (double)rc0;
+      if (ddcmi_rdzv_allreduce_f64(par.rdzv, &flag, 1, 0) != DDCMI_OK) return -1;
+      return flag != 0.0 ? -1 : 0;
+   }
+   return writeRestart_rank0(simulate, dir, restartLink);
+}
+static int writeRestart_rank0(SIMULATE *simulate, const char *dir, int restartLink)
+{
+   SYSTEM *sys = simulate->system;
+   STATE *st = sys->state;
    if (dir) snprintf(simulate->snapshotdir, sizeof(simulate->snapshotdir), "%s", dir);
    else snprintf(simulate->snapshotdir, sizeof(simulate->snapshotdir), "snapshot.%012" PRId64, simulate->loop);    /* loopFormat, io.c:128-129 */
    if (mkdir(simulate->snapshotdir, 0777) != 0 && errno != EEXIST) return -1;
@@ -566,6 +764,7 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
 {
    ddcmi_setup *s = ddcmi_deck_load_with(object_file, restart_file, extra, err, errlen);
    if (!s) return NULL;
+   parallel_init(s);
    SIMULATE *sim = calloc(1, sizeof(SIMULATE));
    sim->name = strdup("simulate");
    sim->setup = s;
@@ -594,17 +793,30 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
    int n = s->natoms;
    STATE *st = sys->state = calloc(1, sizeof(STATE));
    st->nlocal = st->nion = n;
-   st->rx = s->rx; st->ry = s->ry; st->rz = s->rz; st->vx = s->vx; st->vy = s->vy; st->vz = s->vz;    /* aliases of the deck arrays */
+   if (par.world > 1)
+   {
+      /* STATE is the gathered global state on rank 0 (sendHostState): its own arrays, in gather order */
+      double **a6[] = {&st->rx, &st->ry, &st->rz, &st->vx, &st->vy, &st->vz};
+      const double *src[] = {s->rx, s->ry, s->rz, s->vx, s->vy, s->vz};
+      for (int k = 0; k < 6; k++) { *a6[k] = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1)); memcpy(*a6[k], src[k], sizeof(double) * (size_t)n); }
+      st->label = malloc(sizeof(gid_type) * (size_t)(n > 0 ? n : 1));
+      memcpy(st->label, s->gid, sizeof(gid_type) * (size_t)n);
+   }
+   else
+   {
+      st->rx = s->rx; st->ry = s->ry; st->rz = s->rz; st->vx = s->vx; st->vy = s->vy; st->vz = s->vz;    /* aliases of the deck arrays */
+      st->label = s->gid;
+   }
    st->fx = calloc(n, sizeof(double)); st->fy = calloc(n, sizeof(double)); st->fz = calloc(n, sizeof(double));
    st->q = calloc(n, sizeof(double));
-   st->label = s->gid;
    st->species = calloc(n, sizeof(SPECIES *)); st->group = calloc(n, sizeof(GROUP *));
    for (int i = 0; i < n; i++) { st->species[i] = sys->species[s->species[i]]; st->group[i] = sys->group[s->group[i]]; st->q[i] = st->species[i]->charge; }
    sys->nlocal = sys->nion = n; sys->nglobal = n; sys->loop = s->loop; sys->time = s->time; sys->nConstraints = s->nConstraints; sys->deltaR = s->deltaR;
    DDC *ddc = sim->ddc = calloc(1, sizeof(DDC));
-   ddc->updateRate = s->updateRate; ddc->lx = s->lx; ddc->ly = s->ly; ddc->lz = s->lz; ddc->rcut = s->rmax + s->deltaR;   /* ddcenergy.c:43-55 cutoffs() */
+   ddc->updateRate = s->updateRate; ddc->lx = s->lx; ddc->ly = s->ly; ddc->lz = s->lz;
+   if (par.world > 1) { ddc->lx = par.grid[0]; ddc->ly = par.grid[1]; ddc->lz = par.grid[2]; } ddc->rcut = s->rmax + s->deltaR;   /* ddcenergy.c:43-55 cutoffs() */
    /* simulate.c:172: accelerator_init when the deck names one; this library always needs one */
-   if (!s->has_accelerator) printf("no ACCELERATOR object in the deck: running on HIP device 0 (this library has no CPU force path)\n");
+   if (!s->has_accelerator && par.rank == 0) printf("no ACCELERATOR object in the deck: running on HIP device 0 (this library has no CPU force path)\n");
    sim->accelerator = accelerator_init(sim, "accelerator", s->has_accelerator ? s->accelerator_type : "HIP");
    sys->npotential = 1;
    sys->potential = calloc(2, sizeof(POTENTIAL *));
@@ -623,6 +835,35 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
    sim->integrator = integrator_init(sim, "nglf", s->integrator_type);
    /* sendGPUState + sendForceVelocityToGPU (masters.c:389-393) */
    ddcmi_ctx *ctx = sim->accelerator->parms;
+   if (par.world > 1)
+   {
+      gather_setup = s;
+      gather_tab = malloc(sizeof(gid_order) * (size_t)(n > 0 ? n : 1));
+      for (int i = 0; i < n; i++) { gather_tab[i].gid = s->gid[i]; gather_tab[i].id = i; }
+      qsort(gather_tab, (size_t)n, sizeof(gid_order), cmp_gid);
+      /* ddcAssignment: every rank read the whole particle set and keeps the beads of its brick */
+      if (sim->integrator->uses_gpu == 0) die("simulate_init", "DDCMI_CPU_INTEGRATOR runs on one rank only");
+      parallel_comm_init(ctx);
+      int m = 0;
+      int *sp = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *gr = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+      double *a[6];
+      for (int k = 0; k < 6; k++) a[k] = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+      uint64_t *lab = malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+      for (int i = 0; i < n; i++)
+         if (brick_of(s, s->rx[i], s->ry[i], s->rz[i]) == par.rank)
+         {
+            a[0][m] = s->rx[i]; a[1][m] = s->ry[i]; a[2][m] = s->rz[i]; a[3][m] = s->vx[i]; a[4][m] = s->vy[i]; a[5][m] = s->vz[i];
+            lab[m] = s->gid[i]; sp[m] = s->species[i]; gr[m] = s->group[i]; m++;
+         }
+      int rcu = ddcmi_upload_state(ctx, m, a[0], a[1], a[2], a[3], a[4], a[5], lab, sp, gr);
+      for (int k = 0; k < 6; k++) free(a[k]);
+      free(lab); free(sp); free(gr);
+      if (rcu != DDCMI_OK) die("simulate_init", ddcmi_last_error(ctx));      /* (a rank that returned would leave the others in their collectives) */
+      sys->nlocal = sys->nion = (unsigned)m;
+      if (par.rank == 0) printf("%d ranks on a %d x %d x %d grid of domains (%s transport); rank 0 owns %d of %d beads\n", par.world, par.grid[0], par.grid[1], par.grid[2],
+                                par.host_transport ? "host" : "RCCL", m, n);
+      return sim;
+   }
    if (ddcmi_upload_state(ctx, n, st->rx, st->ry, st->rz, st->vx, st->vy, st->vz, st->label, s->species, s->group) != DDCMI_OK)
    {
       snprintf(err, errlen, "%s", ddcmi_last_error(ctx));
@@ -645,8 +886,8 @@ static void convertToMolecularPressures(SIMULATE *simulate, ETYPE *e)
 {
    SYSTEM *sys = simulate->system;
    STATE *st = sys->state;
-   const ddcmi_setup *s = simulate->setup;
-   if (sendHostState(sys) != DDCMI_OK) die("convertToMolecularPressures", "state download failed");
+   if (sendHostState(sys) != DDCMI_OK) die("convertToMolecularPressures", "state download failed");      /* (collective) */
+   if (par.rank != 0) return;
    int n = st->nlocal;
    uint64_t *key = malloc(sizeof(uint64_t) * 2 * (size_t)(n > 0 ? n : 1));
    for (int i = 0; i < n; i++) { key[2 * i] = st->label[i]; key[2 * i + 1] = (uint64_t)i; }
@@ -663,7 +904,7 @@ static void convertToMolecularPressures(SIMULATE *simulate, ETYPE *e)
       for (int k = k0; k < k1; k++)
       {
          int i = (int)key[2 * k + 1];
-         double m = s->mass[s->species[i]], d[3] = {st->rx[i] - st->rx[i0], st->ry[i] - st->ry[i0], st->rz[i] - st->rz[i0]};
+         double m = st->species[i]->mass, d[3] = {st->rx[i] - st->rx[i0], st->ry[i] - st->ry[i0], st->rz[i] - st->rz[i0]};
          for (int a = 0; a < 3; a++) { if (sys->box->pbc >> a & 1) d[a] -= L[a] * rint(d[a] / L[a]); R[a] += m * d[a]; }
          M += m;
       }
@@ -692,6 +933,7 @@ void printinfo(SIMULATE *simulate, ETYPE *e_in, int header)
    SYSTEM *sys = simulate->system;
    ETYPE ecopy = *e_in, *e = &ecopy;                                   /* printinfoAll works on a copy (printinfo.c:250-253) */
    if (s->printMolecularPressure) convertToMolecularPressures(simulate, e);
+   if (par.rank != 0) return;
    double cE = units_convert(1.0, NULL, s->u_energy), cT = units_convert(1.0, NULL, s->u_temperature), cP = units_convert(1.0, NULL, s->u_pressure);
    double cV = units_convert(1.0, NULL, s->u_volume), ct = units_convert(1.0, NULL, s->u_time), cL = units_convert(1.0, NULL, s->u_length);
    double ng = (double)sys->nglobal;
@@ -724,7 +966,7 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
 {
    SYSTEM *sys = simulate->system;
    ddcmi_ctx *ctx = simulate->accelerator->parms;
-   simulate->datafile = datafile_path ? fopen(datafile_path, "a") : NULL;
+   simulate->datafile = (datafile_path && par.rank == 0) ? fopen(datafile_path, "a") : NULL;
    simulate->ddc->update = 3;                                     /* firstEnergyCall :579-620 */
    ddcenergy(simulate->ddc, sys, 1);
    printinfo(simulate, &sys->energyInfo, 1);
@@ -766,7 +1008,7 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
       eval_energyInfo(sys);
       if (!isfinite(e->eion))                                     /* masters.c:470-475 */
       {
-         printf("eion = %e is bad. Simulation is being killed at loop = %" PRId64 "\n", e->eion, simulate->loop);
+         if (par.rank == 0) printf("eion = %e is bad. Simulation is being killed at loop = %" PRId64 "\n", e->eion, simulate->loop);
          break;
       }
       if (simulate->loop % simulate->printrate == 0) printinfo(simulate, e, 0);
@@ -789,6 +1031,7 @@ void simulate_free(SIMULATE *sim)
    if (sys)
    {
       STATE *st = sys->state;
+      if (st && par.world > 1) { free(st->rx); free(st->ry); free(st->rz); free(st->vx); free(st->vy); free(st->vz); free(st->label); }      /* own arrays, not the deck's */
       if (st) { free(st->fx); free(st->fy); free(st->fz); free(st->q); free(st->species); free(st->group); free(st); }
       for (int i = 0; i < sys->nspecies; i++) { free(sys->species[i]->name); free(sys->species[i]); }
       for (int g = 0; g < sys->ngroup; g++) { free(sys->group[g]->name); free(sys->group[g]); }
@@ -797,6 +1040,9 @@ void simulate_free(SIMULATE *sim)
    }
    if (sim->integrator) { free(sim->integrator->name); free(sim->integrator->type); free(sim->integrator); }
    free(sim->ddc);
+   if (par.rdzv) { ddcmi_rdzv_barrier(par.rdzv); ddcmi_rdzv_destroy(par.rdzv); par.rdzv = NULL; }      /* (the context that used it is gone) */
+   free(gather_tab); gather_tab = NULL; gather_setup = NULL;
+   par.world = 1; par.rank = 0;
    ddcmi_setup_free(sim->setup);
    free(sim->name);
    free(sim);

@@ -263,3 +263,82 @@ def test_ddcmi_md_host_integrator_matches_device_integrator(tmp_path):
         o.group_temperature()
         assert abs(rows["host"][k, 4] - cE * e["total"] / s.natoms) < 1e-6 * abs(rows["host"][k, 4])
         assert abs(rows["host"][k, 3] - cE * rk / s.natoms) < 1e-6 * abs(rows["host"][k, 3])
+
+
+# ---- more than one rank: the driver under a launcher that only sets RANK / WORLD_SIZE / LOCAL_RANK ----
+def _run_ranks(world, args, cwd, extra_env=None, timeout=600):
+    """start `world` ddcmi_md processes like a launcher does (all on the one GPU of a test box: host transport)"""
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", DDCMI_TRANSPORT="host", DDCMI_SINGLE_DEVICE="1",
+               DDCMI_RDZV_FILE=os.path.join(cwd, "rdzv_port"))
+    env.update(extra_env or {})
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([EXE] + args, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, er = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, er))
+    return outs
+
+
+def _rows(path):
+    lines = [l for l in open(path).read().splitlines() if l.strip() and not l.startswith("#")]
+    return np.array([[float(x) for x in l.split()] for l in lines])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ddcmi_md_on_several_ranks_matches_one_rank(tmp_path, world):
+    """simulateMaster under the decomposition (ddcUpdate / ddcAssignment, energyInfo.c's allreduce, collection_write on
+    the gathered state): the `data` file and the checkpoint of a 2- and 4-rank run of the lipid deck (every bonded kind by
+    gid, Berendsen group, beads migrating) are those of the one-rank run"""
+    x = "simulate SIMULATE { deltaloop = 40; maxloop = 40; checkpointrate = 40; printrate = 10; }"
+    d1 = tmp_path / "one"; d1.mkdir()
+    out = subprocess.run([EXE, "-o", DECK, "-d", "data", "-x", x], capture_output=True, text=True, timeout=300, cwd=str(d1))
+    assert out.returncode == 0, out.stdout + out.stderr
+    dn = tmp_path / "many"; dn.mkdir()
+    outs = _run_ranks(world, ["-o", DECK, "-d", "data", "-x", x], str(dn))
+    for rc, o, er in outs:
+        assert rc == 0, o + er
+    assert "%d ranks on a" % world in outs[0][1] and all("ranks on a" not in o for _, o, _ in outs[1:])      # rank 0 owns stdout
+    a, b = _rows(str(d1 / "data")), _rows(str(dn / "data"))
+    assert a.shape == b.shape and a.shape[0] == 5
+    assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
+    s1 = load_deck(DECK, restart_file=str(d1 / "restart"))
+    sn = load_deck(DECK, restart_file=str(dn / "restart"))
+    assert sn.loop == 40 and sn.natoms == s1.natoms
+    i1, i2 = np.argsort(s1.gid), np.argsort(sn.gid)
+    assert np.array_equal(s1.gid[i1], sn.gid[i2]) and np.array_equal(s1.species[i1], sn.species[i2]) and np.array_equal(s1.group[i1], sn.group[i2])
+    L = np.array([s1.h[0], s1.h[4], s1.h[8]])
+    for c, (p, q) in enumerate(((s1.rx, sn.rx), (s1.ry, sn.ry), (s1.rz, sn.rz))):
+        d = p[i1] - q[i2]
+        d -= L[c] * np.rint(d / L[c])
+        assert np.abs(d).max() < 1e-7
+    assert np.abs(s1.vx[i1] - sn.vx[i2]).max() < 1e-7 * np.abs(s1.vx).max()
+
+
+def test_ddcmi_md_nglfconstraint_on_two_ranks(tmp_path):
+    """NGLFCONSTRAINT (velocity constraints + molecular-pressure barostat) through the driver on two ranks: constraint groups
+    and molecule lists go in by gid, the box and the molecular-pressure column follow the one-rank run"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle import CONSTRAINT_X
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+    extra = (CONSTRAINT_X + " nglf INTEGRATOR {type = NGLFCONSTRAINT; T = 310 K; P0 = 1 bar; beta = 6.0e-3 1/bar; tauBarostat = 1 ps;}"
+             " simulate SIMULATE { printrate = 5; } system SYSTEM { nConstraints = 1000; } printinfo PRINTINFO { printMolecularPressure = 1; }")
+    args = ["-o", os.path.join(deck, "object_nvt.data"), "-r", os.path.join(deck, "relaxed", "restart"), "-d", "data", "-x", extra]
+    d1 = tmp_path / "one"; d1.mkdir()
+    out = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=300, cwd=str(d1))
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    dn = tmp_path / "two"; dn.mkdir()
+    for rc, o, er in _run_ranks(2, args, str(dn)):
+        assert rc == 0, o[-1000:] + er[-2000:]
+    a, b = _rows(str(d1 / "data")), _rows(str(dn / "data"))
+    assert a.shape == b.shape and a.shape[0] >= 3
+    assert np.abs(a[:, 8:] - b[:, 8:]).max() < 1e-9 * a[:, 8:].max()          # lx ly lz: the barostat moved the box the same way
+    assert np.abs(a - b).max() <= 1e-7 * np.abs(a).max()
