@@ -342,3 +342,25 @@ def test_ddcmi_md_nglfconstraint_on_two_ranks(tmp_path):
     assert a.shape == b.shape and a.shape[0] >= 3
     assert np.abs(a[:, 8:] - b[:, 8:]).max() < 1e-9 * a[:, 8:].max()          # lx ly lz: the barostat moved the box the same way
     assert np.abs(a - b).max() <= 1e-7 * np.abs(a).max()
+
+
+def test_ddcmi_md_under_the_launcher(tmp_path):
+    """`python -m torch.distributed.run --no-python ddcmi_md ...`: the ranks find each other through the port file the launch's
+    MASTER_PORT / run id / launcher pid name (no DDCMI_RDZV_* set), exactly like bench.py's ranks; same data file as one rank"""
+    import sys
+    x = "simulate SIMULATE { deltaloop = 20; maxloop = 20; printrate = 10; checkpointrate = 0; }"
+    d1 = tmp_path / "one"; d1.mkdir()
+    out = subprocess.run([EXE, "-o", DECK, "-d", "data", "-x", x], capture_output=True, text=True, timeout=300, cwd=str(d1))
+    assert out.returncode == 0, out.stdout + out.stderr
+    dn = tmp_path / "two"; dn.mkdir()
+    env = dict(os.environ, DDCMI_TRANSPORT="host", DDCMI_SINGLE_DEVICE="1")
+    env.pop("DDCMI_RDZV_FILE", None); env.pop("DDCMI_RDZV_PORT", None)
+    port = 29700 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--no-python", EXE, "-o", DECK, "-d", "data", "-x", x]
+    p = subprocess.run(cmd, cwd=str(dn), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert p.stdout.count("2 ranks on a") == 1
+    a, b = _rows(str(d1 / "data")), _rows(str(dn / "data"))
+    assert a.shape == b.shape and a.shape[0] == 3
+    assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
