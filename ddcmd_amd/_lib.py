@@ -26,6 +26,9 @@ def load_library():
         raise LibraryMissing(
             "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ddcmd_amd/csrc`)" % LIB_PATH)
+    # several processes sharing device memory (RCCL between the ranks of a node): this pool's host driver only supports
+    # dmabuf IPC; the HIP runtime reads the switch when it initialises, i.e. after this line
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     _declare(_lib)
     return _lib

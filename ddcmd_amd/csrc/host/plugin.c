@@ -37,6 +37,7 @@ static void parallel_init(const ddcmi_setup *s)
    par.grid[0] = par.grid[1] = par.grid[2] = 1;
    if (par.world <= 1) { par.world = 1; par.rank = 0; return; }
    if (par.rank < 0 || par.rank >= par.world) die("parallel_init", "RANK outside 0..WORLD_SIZE-1");
+   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      /* RCCL between processes: dmabuf IPC (read when the HIP runtime initialises, below) */
    if ((long)s->lx * s->ly * s->lz == par.world) { par.grid[0] = s->lx; par.grid[1] = s->ly; par.grid[2] = s->lz; }      /* ddc { lx ly lz } */
    else
    {
