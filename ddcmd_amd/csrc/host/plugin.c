@@ -31,6 +31,23 @@ static void die(const char *where, const char *msg)
 typedef struct { int rank, world, local_rank, grid[3], host_transport; ddcmi_rdzv *rdzv; } PARENV;
 static PARENV par = {0, 1, 0, {1, 1, 1}, 0, NULL};
 static int env_int(const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+/* the process grid: the deck's ddc DDC { lx ly lz } when it multiplies to the number of ranks; otherwise WORLD_SIZE factored
+ * over the axes, smallest prime factors first, each onto the axis whose bricks are widest at that point (2 -> 2x1x1,
+ * 4 -> 2x2x1, 8 -> 2x2x2 for a cubic box: bench.py's grids) */
+void plugin_plan_grid(int world, int lx, int ly, int lz, const double h[9], int grid[3])
+{
+   grid[0] = grid[1] = grid[2] = 1;
+   if (world <= 1) return;
+   if (lx > 0 && ly > 0 && lz > 0 && (long)lx * ly * lz == world) { grid[0] = lx; grid[1] = ly; grid[2] = lz; return; }
+   const double L[3] = {h[0], h[4], h[8]};
+   for (int f = 2, w = world; w > 1;)
+   {
+      if (w % f) { f++; continue; }
+      int a = 0;
+      for (int b = 1; b < 3; b++) if (L[b] / grid[b] > L[a] / grid[a] * (1.0 + 1e-12)) a = b;
+      grid[a] *= f; w /= f;
+   }
+}
 static void parallel_init(const ddcmi_setup *s)
 {
    par.rank = env_int("RANK", 0); par.world = env_int("WORLD_SIZE", 1); par.local_rank = env_int("LOCAL_RANK", par.rank);
@@ -38,21 +55,7 @@ static void parallel_init(const ddcmi_setup *s)
    if (par.world <= 1) { par.world = 1; par.rank = 0; return; }
    if (par.rank < 0 || par.rank >= par.world) die("parallel_init", "RANK outside 0..WORLD_SIZE-1");
    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      /* RCCL between processes: dmabuf IPC (read when the HIP runtime initialises, below) */
-   if ((long)s->lx * s->ly * s->lz == par.world) { par.grid[0] = s->lx; par.grid[1] = s->ly; par.grid[2] = s->lz; }      /* ddc { lx ly lz } */
-   else
-   {
-      /* no matching DDC object: factor WORLD_SIZE over the axes, largest factors first, always onto the axis with the
-       * widest bricks (2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2 for a cubic box) */
-      int w = par.world;
-      double L[3] = {s->h[0], s->h[4], s->h[8]};
-      for (int f = 2; w > 1;)
-      {
-         if (w % f) { f++; continue; }
-         int a = 0;
-         for (int b = 1; b < 3; b++) if (L[b] / par.grid[b] > L[a] / par.grid[a] * (1.0 + 1e-12)) a = b;
-         par.grid[a] *= f; w /= f;
-      }
-   }
+   plugin_plan_grid(par.world, s->lx, s->ly, s->lz, s->h, par.grid);
    const char *addr = getenv("MASTER_ADDR");
    if (!addr || !*addr) addr = "127.0.0.1";
    char pf[1024];

@@ -180,6 +180,8 @@ void nglf(DDC *ddc, SIMULATE *simulate, void *parms);
 int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag);
 void kinetic_terms(SYSTEM *sys, int flag);
 void eval_energyInfo(SYSTEM *sys);
+/* more than one rank (RANK / WORLD_SIZE / LOCAL_RANK in the environment): the process grid simulate_init uses */
+void plugin_plan_grid(int world, int lx, int ly, int lz, const double h[9], int grid[3]);
 /* simulate.c:104-297, masters.c:369-559 (MD loop), printinfo.c:125-232 (data file) */
 SIMULATE *simulate_init(const char *object_file, const char *restart_file, const char *extra_objects, char *err, int errlen);
 int simulateMaster(SIMULATE *simulate, const char *datafile_path);

@@ -80,3 +80,26 @@ def test_potential_object_is_complete(built):
     text = open(os.path.join(ROOT, "ddcmd_amd", "csrc", "host", "plugin.c")).read()
     for needle in ("potential->getCutoffs =", "potential->itype = MARTINI", "RCUT_LOCAL", "in->itype ="):
         assert needle in text, needle
+
+
+def test_driver_process_grid(built):
+    """the multi-rank driver's process grid: the deck's ddc { lx ly lz } when it fits the launch, else WORLD_SIZE factored
+    onto the axes with the widest bricks (bench.py's 2x1x1 / 2x2x1 / 2x2x2 for a cubic box)"""
+    lib = ddcmd_amd.load_library()
+    lib.plugin_plan_grid.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    lib.plugin_plan_grid.restype = None
+
+    def plan(world, l, box):
+        h = (ctypes.c_double * 9)(box[0], 0, 0, 0, box[1], 0, 0, 0, box[2])
+        g = (ctypes.c_int * 3)()
+        lib.plugin_plan_grid(world, l[0], l[1], l[2], h, g)
+        return tuple(g)
+
+    cube = (100.0, 100.0, 100.0)
+    assert plan(1, (1, 1, 1), cube) == (1, 1, 1)
+    assert plan(2, (1, 1, 1), cube) == (2, 1, 1) and plan(4, (1, 1, 1), cube) == (2, 2, 1) and plan(8, (1, 1, 1), cube) == (2, 2, 2)
+    assert plan(8, (4, 2, 1), cube) == (4, 2, 1)                 # the DDC object wins when it multiplies to the rank count
+    assert plan(8, (4, 4, 1), cube) == (2, 2, 2)                 # ... and is ignored when it does not
+    assert plan(6, (0, 0, 0), cube) == (2, 3, 1)
+    assert plan(4, (1, 1, 1), (200.0, 50.0, 50.0)) == (4, 1, 1)  # a slab is cut along its long axis
+    assert plan(8, (1, 1, 1), (50.0, 50.0, 400.0)) == (1, 1, 8)
