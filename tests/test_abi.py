@@ -103,3 +103,17 @@ def test_driver_process_grid(built):
     assert plan(6, (0, 0, 0), cube) == (2, 3, 1)
     assert plan(4, (1, 1, 1), (200.0, 50.0, 50.0)) == (4, 1, 1)  # a slab is cut along its long axis
     assert plan(8, (1, 1, 1), (50.0, 50.0, 400.0)) == (1, 1, 8)
+
+
+def test_driver_fails_loudly_without_a_gpu(built, tmp_path):
+    """ddcmi_md (the C host layer) on a machine without a HIP device: a message and a non-zero exit, no CPU force path"""
+    import subprocess
+    lib = ddcmd_amd.load_library()
+    lib.ddcmi_device_count.restype = ctypes.c_int
+    if lib.ddcmi_device_count() > 0:
+        return
+    exe = os.path.join(ROOT, "ddcmd_amd", "bin", "ddcmi_md")
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck", "object.data")
+    out = subprocess.run([exe, "-o", deck, "-d", str(tmp_path / "data")], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "no HIP device" in out.stderr
+    assert not os.path.exists(str(tmp_path / "data")) or os.path.getsize(str(tmp_path / "data")) == 0
