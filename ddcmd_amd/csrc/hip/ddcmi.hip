@@ -160,6 +160,28 @@ __global__ void k_sort_cells(int ncell, const int *cell_start, const int *cell_c
       order[s + b + 1] = v;
    }
 }
+/* the same by a key that does not depend on how the beads arrived (decomposed runs: migrants and halo beads land in the order
+ * atomics and messages deliver them): the bead's gid, then -- copies of one bead in a halo -- its shift code, then the index */
+__global__ void k_sort_cells_key(int ncell, const int *cell_start, const int *cell_cnt, int *order, const uint64_t *__restrict__ key, const int *__restrict__ key2)
+{
+   int c = blockIdx.x * blockDim.x + threadIdx.x;
+   if (c >= ncell) return;
+   int s = cell_start[c], n = cell_cnt[c];
+   auto before = [&](int a, int b)      /* does a come before b? */
+   {
+      const uint64_t ka = key[a], kb = key[b];
+      if (ka != kb) return ka < kb;
+      if (key2) { const int sa = key2[a], sb = key2[b]; if (sa != sb) return sa < sb; }
+      return a < b;
+   };
+   for (int a = 1; a < n; a++)
+   {
+      int v = order[s + a];
+      int b = a - 1;
+      while (b >= 0 && before(v, order[s + b])) { order[s + b + 1] = order[s + b]; b--; }
+      order[s + b + 1] = v;
+   }
+}
 __global__ void k_gather_state(int nloc, const int *order,
                                const double4 *pos, const double *vx, const double *vy, const double *vz,
                                const int *species, const int *group, const uint64_t *gid, const int *orig,
@@ -2293,7 +2315,10 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
    if (n > 0)
    {
       hipLaunchKernelGGL(k_scatter_order, dim3(nb), dim3(256), 0, st, n, ctx->cid.p, ctx->crank.p, ctx->cell_start_o.p, ctx->order.p);
-      hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
+      if (ctx->nranks > 1 || ctx->loopback || ctx->group_)      /* migrants arrive in message order: sort by gid, so that a run repeats bit for bit */
+         hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p, ctx->gid.p, (const int *)nullptr);
+      else
+         hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
       hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
                          ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
                          ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p);
@@ -2324,6 +2349,7 @@ int ddcmi_bl_reserve_halo(ddcmi_ctx *ctx, int nh)
 /* rebuild phase 2 (single domain): periodic self-images */
 static int bl_self_images(ddcmi_ctx *ctx)
 {
+   ctx->hkey_valid = false;      /* self-images are laid out by a scan over the owned beads: already independent of timing */
    GridParams &gp = ctx->gp;
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nb = cdiv(n, 256), rc;
@@ -2352,7 +2378,10 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
       int nhb = cdiv(nh, 256);
       if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ncell, nullptr))) return rc;
       hipLaunchKernelGGL(k_scatter_order, dim3(nhb), dim3(256), 0, st, nh, ctx->hcid.p, ctx->hrank.p, ctx->cell_start_h.p, ctx->horder.p);
-      hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
+      if (ctx->hkey_valid)      /* decomposed runs: halo descriptors arrive in the order atomics filled the send lists */
+         hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p, ctx->hkey.p, ctx->hshift_t.p);
+      else
+         hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
       hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p);
       hipLaunchKernelGGL(k_halo_update, dim3(nhb), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
                          ctx->hrecv3.p, ctx->hrecv5.p);

@@ -157,6 +157,7 @@ struct ddcmi_ctx
    /* lists */
    int maxnbr = 0, maxexcl = 0;
    dbuf<int> nbr_cnt, excl, excl_cnt;
+   dbuf<uint64_t> hkey; bool hkey_valid = false;      /* gid of every halo descriptor (k_halo_assemble): the key of the halo's in-cell order */
    dbuf<int> tile_work, sched, tile_perm;   /* per-tile cost estimate (bit 30: stages halo beads); XCD ranges [2][16]; tile order */
    int nitems = 0;                     /* work items of k_nonbond: the tiles with owned beads, the last ones of each XCD's run cut into parts */
    int sched_cache[2][8][3] = {};      /* tail split of each class and XCD run: {tiles it was found for, tiles cut, parts} */

@@ -229,7 +229,8 @@ __global__ void k_pack_halo(int nsend, DirTab dt, const unsigned *__restrict__ s
 /* halo descriptors: first the local images (directions that wrap onto this rank),
  * then the beads received from other ranks */
 __global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab selfo, SegTab recvo, DirTab dt, int hs_cap, const int *hs_idx,
-                                const double4 *pos, const double *hrecv5, int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h)
+                                const double4 *pos, const double *hrecv5, int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h,
+                                const uint64_t *__restrict__ gid, uint64_t *hkey)
 {
    int h = blockIdx.x * blockDim.x + threadIdx.x;
    if (h >= nself + nrecv) return;
@@ -243,6 +244,7 @@ __global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab self
       double4 p = pos[i];
       x = p.x + dt.shift[code][0] * gp.L[0]; y = p.y + dt.shift[code][1] * gp.L[1]; z = p.z + dt.shift[code][2] * gp.L[2];
       hsrc[h] = i;
+      hkey[h] = gid[i];
       hshift[h] = (dt.shift[code][0] + 1) + 3 * (dt.shift[code][1] + 1) + 9 * (dt.shift[code][2] + 1);
       /* an image sent in direction d appears on the opposite side of this (same) domain */
       side[0] = -(code % 3 - 1); side[1] = -((code / 3) % 3 - 1); side[2] = -(code / 9 - 1);
@@ -252,6 +254,7 @@ __global__ void k_halo_assemble(GridParams gp, int nself, int nrecv, OffTab self
       int k = h - nself;
       x = hrecv5[5 * k]; y = hrecv5[5 * k + 1]; z = hrecv5[5 * k + 2];
       hsrc[h] = -1 - k;
+      hkey[h] = (uint64_t)__double_as_longlong(hrecv5[5 * k + 4]);
       hshift[h] = 13;          /* fixed up below: 27 when the sender applied a periodic shift */
       /* received along the SENDER's direction `code`: it lies on my opposite side */
       int q = 0;
@@ -682,11 +685,14 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
    selfo.off[27] = nself;
    int nh = nself + ctx->nrecv;
    ctx->nhalo = nh;
+   ctx->hkey_valid = false;
    if (nh > 0)
    {
       if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
+      ENSURE(ctx, ctx->hkey, (size_t)nh + 1);
       hipLaunchKernelGGL(k_halo_assemble, dim3(cdiv(nh, 256)), dim3(256), 0, st, ctx->gp, nself, ctx->nrecv, selfo, ctx->rseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
-                         ctx->pos.p, ctx->hrecv5.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
+                         ctx->pos.p, ctx->hrecv5.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p, ctx->gid.p, ctx->hkey.p);
+      ctx->hkey_valid = true;
       if (ctx->nrecv > 0) hipLaunchKernelGGL(k_rec5to3, dim3(cdiv(ctx->nrecv, 256)), dim3(256), 0, st, ctx->nrecv, ctx->hrecv5.p, ctx->hrecv3.p);
    }
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;

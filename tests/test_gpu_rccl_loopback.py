@@ -121,3 +121,20 @@ def test_nglfconstraint_through_rccl_loopback(monkeypatch):
     sweeps, bad = m.constraint_stats()
     assert bad == 0 and sweeps > 1
     m.close()
+
+
+def test_loopback_run_repeats_bit_for_bit(monkeypatch):
+    """the RCCL path twice: the order in which atomics fill the send lists does not reach the neighbour lists (in-cell order by
+    gid), so energies, positions and forces of two runs are identical in every bit"""
+    outs = []
+    for _ in range(2):
+        m = _loopback_rank(make_water_setup(12), monkeypatch)
+        m.eval_forces()
+        m.step(45)
+        e, vir, rk, tion = m.energies()
+        p = m.download_particles()
+        order = np.argsort(p["gid"], kind="stable")
+        outs.append((e["total"], rk, vir.copy(), np.stack(p["r"])[:, order], np.stack(p["f"])[:, order]))
+        m.close()
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
