@@ -646,7 +646,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      {
                         if (ecnt < maxexcl)
                         {
-                           excl[(size_t)ecnt * npad + a] = sidx[sj];      /* global index: list export */
+                           /* global index (list export) out of the LDS cell tables, like the staging formed it: a global load of
+                            * sidx[sj] here stalled the wave once per excluded pair -- ~11 per lipid bead, 700 per wave */
+                           const int cj_ = cellof_s[sj];
+                           excl[(size_t)ecnt * npad + a] = gst_s[cj_] + (sj - ofs_s[cj_]);
                            /* the pair kernel finds the partner among the staged beads (same molecule: always inside the tile's
                             * neighbourhood): an entry in the list's own format */
                            excl16[(size_t)ecnt * npad + a] = (unsigned short)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1);

@@ -9,7 +9,14 @@ from ddcmd_amd.martini import MartiniHIP
 from ddcmd_amd._lib import load_library
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-m = MartiniHIP(make_water_setup(n))
+if os.environ.get("TRACE_WORKLOAD") == "lipid":      # the lipid deck tiled n x n x n/2
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import replicate_setup
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "lipid_deck")
+    setup = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), (n, n, max(1, n // 2)))
+else:
+    setup = make_water_setup(n)
+m = MartiniHIP(setup)
 m.eval_forces()
 m.step(45)          # two more rebuilds in a running simulation: the last one is what is read
 m.sync()
