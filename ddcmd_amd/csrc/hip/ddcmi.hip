@@ -393,7 +393,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ, const unsigned long long *exmask,
-                                                            int maxexcl, int *excl, unsigned short *excl16, int *excl_cnt, int *flags, unsigned long long *totals)
+                                                            int maxexcl, unsigned short *excl16, int *excl_cnt, int *flags, unsigned long long *totals)
 {
    /* LDS image of the neighbourhood: positions relative to the tile centre in single precision + the
     * low tag word (16 B per bead, one ds_read_b128 per candidate) and the molecule ids (4 B).  The
@@ -646,12 +646,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                      {
                         if (ecnt < maxexcl)
                         {
-                           /* global index (list export) out of the LDS cell tables, like the staging formed it: a global load of
-                            * sidx[sj] here stalled the wave once per excluded pair -- ~11 per lipid bead, 700 per wave */
-                           const int cj_ = cellof_s[sj];
-                           excl[(size_t)ecnt * npad + a] = gst_s[cj_] + (sj - ofs_s[cj_]);
                            /* the pair kernel finds the partner among the staged beads (same molecule: always inside the tile's
-                            * neighbourhood): an entry in the list's own format */
+                            * neighbourhood): an entry in the list's own format.  (ddcmi_get_list derives the partner's index from
+                            * it: a second array of global indices cost a store per excluded pair and 64 B per bead.) */
                            excl16[(size_t)ecnt * npad + a] = (unsigned short)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1);
                         }
                         ecnt++;
@@ -1757,6 +1754,29 @@ __global__ void k_tilelist_to_csr(NbTileArgs ta, int pack_type, int nloc, const 
       }
    }
 }
+/* the same for the excluded (same-molecule bonded) pairs: their list-format entries (excl16) name staged slots of the bead's tile */
+__global__ void k_tileexcl_to_csr(NbTileArgs ta, int pack_type, int nloc, int npad, const unsigned short *excl16, const int *excl_cnt,
+                                  const int *orig, const int *halo_src, const int *start, int *jout)
+{
+   int t = blockIdx.x;
+   int ts = ta.cell_start_o[TCELLS * t];
+   int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
+   if (nown <= 0) return;
+   const int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
+   for (int al = threadIdx.x; al < nown; al += blockDim.x)
+   {
+      int a = ts + al;
+      int s = start[orig[a]];
+      int cnt = excl_cnt[a];
+      for (int k = 0; k < cnt; k++)
+      {
+         int ee = excl16[(size_t)k * npad + a];
+         int j = sidx[(pack_type ? (ee >> 4) : ee) - 1];
+         if (j >= nloc) j = halo_src[j - nloc];
+         jout[s + k] = orig[j];
+      }
+   }
+}
 __global__ void k_list_to_csr(int nloc, int npad, const int *lst, const int *cnt, const int *orig, const int *halo_src, const int *start, int *jout)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2607,7 +2627,6 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
-      ENSURE(ctx, ctx->excl, (size_t)ctx->maxexcl * ctx->npad);
       if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
       if (attempt > 0) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_tot, 6));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
       ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
@@ -2624,7 +2643,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
-                         ctx->maxexcl, ctx->excl.p, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+                         ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
       /* everything the host decides on (capacity flags, totals, the tiles' cost estimates) is final when k_tile_build
        * ends: it travels behind an event, and the host reads it -- and orders the tiles -- while k_tile_transpose runs */
       unsigned long long tot[3];
@@ -3244,17 +3263,18 @@ extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int
    {
       if (d_j.ensure(tot)) { d_start.release(); SETERR(ctx, DDCMI_ENOMEM, "get_list alloc"); }
       HIPCHK(ctx, hipMemcpyAsync(d_start.p, start, (n + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-      if (which == 0)
       {
          NbTileArgs na;
          na.ntile = ctx->ntile; na.stage_stride = ctx->stage_cap; na.cap = ctx->stage_cap; na.nlj = ctx->nnb;
          na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
          na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
          na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p;
-         hipLaunchKernelGGL(k_tilelist_to_csr, dim3(ctx->ntile), dim3(256), 0, st, na, ctx->pack_type ? 1 : 0, n, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
+         if (which == 0)
+            hipLaunchKernelGGL(k_tilelist_to_csr, dim3(ctx->ntile), dim3(256), 0, st, na, ctx->pack_type ? 1 : 0, n, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
+         else
+            hipLaunchKernelGGL(k_tileexcl_to_csr, dim3(ctx->ntile), dim3(256), 0, st, na, ctx->pack_type ? 1 : 0, n, ctx->npad, ctx->excl16.p, ctx->excl_cnt.p,
+                               ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
       }
-      else
-         hipLaunchKernelGGL(k_list_to_csr, dim3(nb), dim3(256), 0, st, n, ctx->npad, ctx->excl.p, cnt, ctx->orig.p, ctx->halo_src.p, d_start.p, d_j.p);
       HIPCHK(ctx, hipMemcpyAsync(j, d_j.p, tot * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
    }
