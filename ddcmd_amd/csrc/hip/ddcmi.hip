@@ -182,15 +182,24 @@ __global__ void k_sort_cells_key(int ncell, const int *cell_start, const int *ce
       order[s + b + 1] = v;
    }
 }
+__device__ __forceinline__ void image_dirs(const GridParams &gp, const double4 &p, int d[3]);
+/* nimg (one domain): the number of periodic self-images of the bead, counted here because the record is in registers anyway
+ * (a pass of its own read all positions again: 33 us at 4 M beads) */
 __global__ void k_gather_state(int nloc, const int *order,
                                const double4 *pos, const double *vx, const double *vy, const double *vz,
                                const int *species, const int *group, const uint64_t *gid, const int *orig,
                                double4 *pos2, double *vx2, double *vy2, double *vz2,
-                               int *species2, int *group2, uint64_t *gid2, int *orig2, int *slot_of_orig)
+                               int *species2, int *group2, uint64_t *gid2, int *orig2, int *slot_of_orig, GridParams gp, int *nimg)
 {
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= nloc) return;
    int i = order[k];
+   if (nimg)
+   {
+      int d[3];
+      image_dirs(gp, pos[i], d);
+      nimg[k] = (1 + (d[0] != 0)) * (1 + (d[1] != 0)) * (1 + (d[2] != 0)) - 1;
+   }
    pos2[k] = pos[i];
    vx2[k] = vx[i]; vy2[k] = vy[i]; vz2[k] = vz[i];
    species2[k] = species[i]; group2[k] = group[i]; gid2[k] = gid[i];
@@ -213,19 +222,11 @@ __device__ __forceinline__ void image_dirs(const GridParams &gp, const double4 &
       else if (r[a] >= gp.lo[a] + gp.n[a] / gp.cinv[a] - gp.rlist) d[a] = -1;   /* image at r-L */
    }
 }
-__global__ void k_count_images(GridParams gp, int nloc, const double4 *pos, int *nimg)
-{
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= nloc) return;
-   int d[3];
-   image_dirs(gp, pos[i], d);
-   nimg[i] = (1 + (d[0] != 0)) * (1 + (d[1] != 0)) * (1 + (d[2] != 0)) - 1;
-}
-__global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const int *img_off,
+__global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const int *img_off, const int *nimg,
                               int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= nloc) return;
+   if (i >= nloc || nimg[i] == 0) return;      /* three beads in four have no image: their records are not read */
    double4 p = pos[i];
    int d[3];
    image_dirs(gp, p, d);
@@ -2344,7 +2345,8 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
          hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
       hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
                          ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
-                         ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p);
+                         ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p,
+                         gp, (ctx->nranks == 1 && !ctx->loopback && !ctx->group_) ? ctx->nimg.p : (int *)nullptr);
       std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
       std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
    }
@@ -2376,7 +2378,7 @@ static int bl_self_images(ddcmi_ctx *ctx)
    GridParams &gp = ctx->gp;
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nb = cdiv(n, 256), rc;
-   hipLaunchKernelGGL(k_count_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->nimg.p);
+   /* (nimg was counted by k_gather_state) */
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->nimg.p, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 8, ctx->d_flags + 8, sizeof(int), hipMemcpyDeviceToHost, st));
    HIPCHK(ctx, hipStreamSynchronize(st));
@@ -2385,7 +2387,7 @@ static int bl_self_images(ddcmi_ctx *ctx)
    if (nh > 0)
    {
       if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
-      hipLaunchKernelGGL(k_fill_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->img_off.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
+      hipLaunchKernelGGL(k_fill_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->img_off.p, ctx->nimg.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
    }
    return DDCMI_OK;
 }
