@@ -331,12 +331,14 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 }
 
 #define TB_THREADS 512      /* k_tile_build workgroup: one lane per owned bead of the tile */
+#define TB_RING 8           /* accepted words a lane keeps in LDS before they leave as 16-byte stores: [TB_RING][TB_THREADS] */
+#define TB_RING_BYTES (TB_RING * TB_THREADS * 4)
 #ifndef NSHELL
 #define NSHELL 8            /* distance shells of the list order */
 #endif
-/* shell 0 = r < r0, shells 1.. = equal steps of r^2 (ddcmi_bl_finish): boundaries only
+/* shell 0 = r < r0, shells 1..NSHELL-1 = equal steps of r^2 up to the list radius (k_tile_build): boundaries only
  * steer the ORDER of a bead's entries, so single precision is plenty */
-struct ShellCuts { float a, b; };      /* shell = clamp((int)(a r^2 + b), 0, NSHELL-1) */
+struct ShellCuts { float r0sq; int one; };      /* one: no skin, a single shell */
 struct TileArgs
 {
    int ntile, stage_stride, cap;        /* cap = LDS capacity in staged beads */
@@ -367,63 +369,48 @@ struct NbTileArgs
    const int *perm;                     /* work items in launch order: tile | part << 24 | (nparts - 1) << 27 (schedule_tiles) */
    const int *tile_work;                /* bit 30: the tile stages image/halo beads */
    const int *halo_shift; int nloc;     /* halo_shift[j - nloc] != 13: bead j carries a periodic shift */
-   int rot;                             /* tuning builds: rotate the range -> XCD assignment */
 };
 
-#ifdef DDCMI_TRACE_BLOCKS
-/* tuning builds only (tools/build_variants.sh): per-workgroup timeline of k_nonbond */
-__device__ unsigned long long g_trace[8 * 65536];
-#define TRACE_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
-extern "C" int ddcmi_debug_trace(unsigned long long *out, int nblocks)
-{
-   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)nblocks * 8 * sizeof(unsigned long long));
-}
-/* the same for k_tile_build: [0] start [1] staged [2] end (100 MHz wall clock) [3] shader cycles start..end [4] xcc [5] hw id [6] owned beads [7] staged beads */
-__device__ unsigned long long g_trace_tb[8 * 65536];
-#define TRACE_TB(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_trace_tb[8 * blockIdx.x + (slot)] = (unsigned long long)(val); } while (0)
-extern "C" int ddcmi_debug_trace_build(unsigned long long *out, int nblocks)
-{
-   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace_tb), (size_t)nblocks * 8 * sizeof(unsigned long long));
-}
-#else
-#define TRACE_MARK(slot) do { } while (0)
-#define TRACE_TB(slot, val) do { } while (0)
-#endif
-template <bool HAS_MOL>      /* false: every molecule is a single bead -- no pair can be excluded, the molecule logic is compiled out */
+/* The neighbour search of one tile (first half of the list build).
+ *
+ * LDS image of the tile's neighbourhood: 16 B per staged bead -- position relative to the tile centre in single
+ * precision and, in the fourth word, the bead's finished 16-bit list entry ((staged slot + 1) << 4 | type nibble, or
+ * the bare slot + 1); for molecular systems the word also carries the atom-in-molecule code (6 bits, 63 = "ask the
+ * record") and the low byte of the molecule id, and the full ids sit in a second array.  One lane per owned bead walks
+ * the 5x5 rows of cells around its own cell, four candidates per trip.  The trip is free of divergent code: distance,
+ * three compares, the scratch word (entry | distance shell << 16: one fma, one conversion, one shift-or), a masked
+ * 4-byte store to the bead's scratch row and a carry add for its count.  Two things leave the straight path, each
+ * behind ONE wave-wide branch per trip: candidates inside the error band of the single-precision r^2 (re-tested from
+ * the double positions: the list criterion stays the reference's r^2 < rlist^2, pairlist.c:262-282) and candidates of
+ * the bead's own molecule (reOrgPairs, bioMartini.c:1392-1485: bonded partners go to the excluded list instead).
+ * (The per-candidate accept branch of the first version -- parity logic for paired 8-byte stores, shell clamps, the
+ * pack-type selects -- was 60 % of this kernel's vector instructions and most of its scalar branches.) */
+template <bool HAS_MOL, int PACK>      /* HAS_MOL false: every molecule is a single bead, the molecule logic is compiled out; PACK = TileArgs::pack_type */
 __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileArgs ta, int npad, const double4 *__restrict__ pos, const uint64_t *__restrict__ gid,
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ, const unsigned long long *exmask,
-                                                            int maxexcl, unsigned short *excl16, int *excl_cnt, int *flags, unsigned long long *totals)
+                                                            int maxexcl, unsigned short *excl16, int *excl_cnt, int *flags)
 {
-   /* LDS image of the neighbourhood: positions relative to the tile centre in single precision + the
-    * low tag word (16 B per bead, one ds_read_b128 per candidate) and the molecule ids (4 B).  The
-    * list criterion stays the reference's double-precision r^2 < rlist^2: candidates within TB_BAND
-    * (relative) of the boundary are re-tested from the double positions in global memory. */
+   /* dynamic LDS only, so that the ring of accepted words starts at LDS address 0 (its address arithmetic is one and-or) */
    extern __shared__ float4 tb_smem[];
-   float4 *P_s = tb_smem;
-   unsigned *M_s = (unsigned *)(tb_smem + ta.cap);
-   int *ofs_s = (int *)(M_s + (HAS_MOL ? ta.cap : 0));     /* [NRC+1] staged offset of each region cell */
+   float4 *P_s = tb_smem + TB_RING_BYTES / sizeof(float4);
+   int *ofs_s = (int *)(P_s + ta.cap);                     /* [NRC+1] staged offset of each region cell */
    int *gst_s = ofs_s + NRC + 8;                           /* [NRC] global start of each region cell */
-   unsigned short *cellof_s = (unsigned short *)(gst_s + NRC + 8);      /* [cap] region cell of each staged slot */
-   __shared__ int s_w[TB_THREADS / 64];
+   int *s_w = gst_s + NRC + 8;                             /* [TB_THREADS / 64] scan scratch */
+   float *s_amax = (float *)(s_w + TB_THREADS / 64);       /* [TB_THREADS / 64] */
+   int *s_halo_p = (int *)(s_amax + TB_THREADS / 64);      /* [8]: [0] the neighbourhood holds image/halo beads, [1] a molecule id beyond 24 bits */
+   unsigned short *M_s = (unsigned short *)(s_halo_p + 8); /* [cap] (HAS_MOL) bits 8-23 of the staged beads' molecule ids; bits 0-7 ride in the image */
+   /* [cap] region cell of each staged slot: staging only, in the bytes that become the ring (behind everything else if it outgrows them: bare 16-bit entries) */
+   unsigned short *cellof_s = (size_t)ta.cap * sizeof(unsigned short) <= TB_RING_BYTES ? (unsigned short *)tb_smem : M_s + (HAS_MOL ? ta.cap : 0);
+   if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)tb_smem != 0u) __builtin_trap();
+#define s_halo (*s_halo_p)
    int t = blockIdx.x;
    int ts = ta.cell_start_o[TCELLS * t], te = ta.cell_start_o[TCELLS * t + TCELLS];
    int nown = te - ts;
-   TRACE_TB(0, wall_clock64()); TRACE_TB(6, nown > 0 ? nown : 0); TRACE_TB(2, 0);
-#ifdef DDCMI_TRACE_BLOCKS
-   const unsigned long long tb_c0 = clock64();
-   if (threadIdx.x == 0 && blockIdx.x < 65536)
-   {
-      unsigned xcc, hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      g_trace_tb[8 * blockIdx.x + 4] = xcc; g_trace_tb[8 * blockIdx.x + 5] = hw;
-   }
-#endif
    if (nown <= 0)
    {
-      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 0; ta.tile_work[ta.ntile + t] = 0; }
+      if (threadIdx.x == 0) { ta.tile_nstage[t] = 0; ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; for (int q = 0; q < 5; q++) ta.tile_work[q * ta.ntile + t] = 0; }
       return;
    }
    int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
@@ -432,8 +419,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    static_assert(CPT * TB_THREADS >= NRC && TB_THREADS >= 256, "region cell count / block size mismatch");
    int v[CPT], g[CPT];
    int vsum = 0;
-   __shared__ int s_halo;
-   if (threadIdx.x == 0) s_halo = 0;
+   if (threadIdx.x == 0) { s_halo = 0; s_halo_p[1] = 0; }
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
@@ -466,19 +452,18 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       ex += v[h];
    }
    if (threadIdx.x == 0) { ofs_s[NRC] = tot; ta.tile_nstage[t] = tot; }
-   if (tot > ta.cap || tot > (ta.pack_type ? 4095 : 65534))     /* staged slot 0 is the sentinel */
+   if (tot > ta.cap || tot > (PACK ? 4095 : 65534))     /* staged slot 0 is the sentinel */
    {
-      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; ta.tile_work[t] = 0; ta.tile_work[ta.ntile + t] = 0; }
+      if (threadIdx.x == 0) { atomicMax(&flags[4], tot); ta.tile_rows[t] = 0; ta.tile_width[t] = 0; ta.tile_base[t] = 0; for (int q = 0; q < 5; q++) ta.tile_work[q * ta.ntile + t] = 0; }
       return;      /* LDS capacity too small: the host retries with a larger cap */
    }
    __syncthreads();
-   /* phase 1: staging list (global indices) + positions into LDS */
+   /* phase 1: staging list (global indices) + the LDS image */
    int *sidx = ta.stage_idx + (size_t)t * ta.stage_stride;
    const double ox = gp.lo[0] + (TCX * tx - gp.m[0] + 0.5 * TCX) / gp.cinv[0], oy = gp.lo[1] + (TCY * ty - gp.m[1] + 0.5 * TCY) / gp.cinv[1],
                 oz = gp.lo[2] + (TCZ * tz - gp.m[2] + 0.5 * TCZ) / gp.cinv[2];
    /* one thread per staged slot, four gathers in flight: a slot -> cell map in LDS gives every slot its global
-    * index (a loop over each cell's beads by the thread that owns the cell serialised a dozen memory round trips:
-    * 1.1 ms of this kernel's 2.4 at 4 M beads) */
+    * index (a loop over each cell's beads by the thread that owns the cell serialised a dozen memory round trips) */
 #pragma unroll
    for (int h = 0; h < CPT; h++)
    {
@@ -503,7 +488,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       for (int u = 0; u < 4; u++)
       {
          p4[u] = pos[gj[u]];
-         hs4[u] = (ta.pack_type == 2 && gj[u] >= ta.nloc) ? ta.halo_shift[gj[u] - ta.nloc] : 13;
+         hs4[u] = (PACK == 2 && gj[u] >= ta.nloc) ? ta.halo_shift[gj[u] - ta.nloc] : 13;
       }
 #pragma unroll
       for (int u = 0; u < 4; u++)
@@ -513,68 +498,221 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          {
             sidx[k] = gj[u];
             const double4 p = p4[u];
-            unsigned long long w = (unsigned long long)__double_as_longlong(p.w);
-            unsigned lo = (unsigned)w;
-            if (hs4[u] != 13) lo |= 8u;       /* travels into the entry's type nibble */
-            const float4 ps = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(lo));
+            const unsigned long long w = (unsigned long long)__double_as_longlong(p.w);
+            const unsigned lo = (unsigned)w;
+            unsigned nib = lo & 0xfu;
+            if (PACK == 2 && hs4[u] != 13) nib |= 8u;      /* a periodically shifted copy: bit 3 of the entry's type nibble */
+            unsigned wv = PACK ? (((unsigned)(k + 1) << 4) | nib) : (unsigned)(k + 1);      /* the bead's list entry, finished */
+            if (HAS_MOL)
+            {
+               const unsigned mol = (unsigned)(w >> 32);
+               wv |= (min((lo >> 8) & 0xffu, 63u) << 16) | ((mol & 0xffu) << 24);
+               M_s[k] = (unsigned short)(mol >> 8);
+               if (mol >> 24) s_halo_p[1] = 1;      /* (more than 16.7 M molecules: a match of the 24 staged bits is confirmed from the record) */
+            }
+            const float4 ps = make_float4((float)(p.x - ox), (float)(p.y - oy), (float)(p.z - oz), __uint_as_float(wv));
             amax = fmaxf(amax, fmaxf(fabsf(ps.x), fmaxf(fabsf(ps.y), fabsf(ps.z))));
             P_s[k] = ps;
-            if (HAS_MOL) M_s[k] = (unsigned)(w >> 32);
          }
       }
    }
-   TRACE_TB(1, wall_clock64()); TRACE_TB(7, tot);
    const double rl2 = gp.rlist * gp.rlist;
    /* Error of the single-precision r^2: the staged coordinates are rounded once (half an ulp of the largest coordinate
     * A relative to the tile centre: A 2^-24), so a separation component is off by < 2 A 2^-24 and r^2 at r = rlist by
     * < 2 sqrt(3) rlist 2 A 2^-24 + 4 rlist^2 2^-24 of arithmetic rounding.  The band is four times that: 6e-6 relative
-    * for rlist = 16 A (A = 48 A); beads far outside an open box widen it.  (A fixed 1e-4 sent every 120th candidate slot
-    * of a wave through the two dependent global loads of the exact test.) */
+    * for rlist = 16 A (A = 48 A); beads far outside an open box widen it. */
 #pragma unroll
    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-   __shared__ float s_amax[TB_THREADS / 64];
    if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = amax;
    __syncthreads();
 #pragma unroll
    for (int q = 0; q < TB_THREADS / 64; q++) amax = fmaxf(amax, s_amax[q]);
    const double band = 4.0 * (4.0 * 1.7320508 * gp.rlist * (double)amax + 4.0 * rl2) * 5.9604645e-8 / rl2;
    const float rl2_hi = (float)(rl2 * (1.0 + band)), rl2_lo = (float)(rl2 * (1.0 - band));
+   /* distance shell of an accepted candidate (the order of a bead's entries, k_tile_transpose): 0 below r0, then
+    * NSHELL-1 equal steps of r^2 up to the list radius -- one fma and one saturating conversion (negative -> 0; every
+    * accepted r^2 is < rl2_hi, which maps below NSHELL: no clamp).  Boundaries only steer the ORDER: single precision */
+   const float shA = ta.shc.one ? 0.0f : (float)(NSHELL - 1.01) / (rl2_hi - ta.shc.r0sq), shB = ta.shc.one ? 0.0f : 1.0f - ta.shc.r0sq * shA;
    const int rows = (nown + 63) & ~63;
+   const bool mol_wide = HAS_MOL && s_halo_p[1] != 0;
    int mymax = 0;
-   /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go
-    * to the bead's own row of a row-major scratch list (sequential 2-byte appends,
-    * write-combined in L2) tagged with their distance shell; k_tile_transpose then
-    * lays them out slot-major in shell order. */
-#if defined(TB_ABLATE) && TB_ABLATE == 2      /* tuning builds: staging only */
-   for (int al = threadIdx.x; al < 0; al += TB_THREADS)
-#else
+   /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go to the bead's own row of a
+    * row-major scratch list tagged with their distance shell; k_tile_transpose lays them out slot-major in shell order */
+   unsigned *const trow = ta.tmp32 + (size_t)ts * ta.tmpw;      /* the tile's scratch rows (wave-uniform base, 32-bit lane offsets) */
+   const int wlim = ta.tmpw - 4;                                /* a trip stores while its row has room for four more words */
    for (int al = threadIdx.x; al < nown; al += TB_THREADS)
-#endif
    {
-      int a = ts + al;
-      double4 pi = pos[a];
+      const int a = ts + al;
+      const double4 pi = pos[a];
       const float fx = (float)(pi.x - ox), fy = (float)(pi.y - oy), fz = (float)(pi.z - oz);
       int cx, cy, cz;
       cell_coords(gp, pi.x, pi.y, pi.z, true, cx, cy, cz);
-      int lx = cx - TCX * tx, ly = cy - TCY * ty, lz = cz - TCZ * tz;
-      int rc_own = (lz + 2) * (RGX * RGY) + (ly + 2) * RGX + (lx + 2);
-      int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
+      const int lx = cx - TCX * tx, ly = cy - TCY * ty, lz = cz - TCZ * tz;
+      const int rc_own = (lz + 2) * (RGX * RGY) + (ly + 2) * RGX + (lx + 2);
+      const int self = ofs_s[rc_own] + (a - gst_s[rc_own]);
+      /* molecule data of the bead.  exmask[mt*64 + a]: atoms (codes < 63) of molecule type mt bonded to atom a; bit 63 of
+       * entry a = 0 is set when the whole type can be decided by mask */
       uint64_t gi = 0;
       int mt = 0, mns = 1;
-      /* exmask[mt*64 + a]: atoms (codes < 64) of molecule type mt bonded to atom a; bit 63 of
-       * entry a = 0 is set when the whole type can be decided by mask */
       unsigned long long mask_i = 0; bool by_mask = false;
-      if (HAS_MOL && nmoltype > 0)
+      unsigned key_i = 0;
+      if (HAS_MOL)
       {
          gi = gid[a]; mt = moltype_sp[species[a]]; mns = mol_nspecies[mt];
-         unsigned aI = (unsigned)(gi & 65535ull);
+         const unsigned aI = (unsigned)(gi & 65535ull);
          if (mns > 1 && aI < 63u && (exmask[(size_t)mt * 64] >> 63)) { by_mask = true; mask_i = exmask[(size_t)mt * 64 + aI]; }
+         key_i = ((unsigned)(gi >> 32) & 0xffu) << 24;
       }
-      int cnt = 0, ecnt = 0;
-      /* scratch row: two words per 8-byte store (tmpw is even); one 4-byte store per accepted candidate has fewer VALU
-       * instructions but twice the scattered store instructions, and measured 12 % slower */
-      uint2 *row2 = (uint2 *)(ta.tmp32 + (size_t)a * ta.tmpw);
-      unsigned wprev = 0;
+      int ecnt = 0;
+      /* c11 / f11: words accepted / flushed so far, in units of RING_STEP (the byte stride of a ring slot: the ring address of word c is
+       * one and-or away); gofs: byte offset of the row's next 16-byte group in the tile's scratch */
+      typedef __attribute__((address_space(3))) unsigned lds_uint;
+      constexpr unsigned RING_STEP = TB_THREADS * 4u, RING_MASK = (TB_RING - 1u) * RING_STEP;
+      static_assert(TB_RING == 8 && (RING_STEP & (RING_STEP - 1)) == 0, "ring of eight words per lane");
+      const unsigned tid4 = threadIdx.x * 4u, lim11 = (unsigned)wlim * RING_STEP;
+      unsigned c11 = 0, f11 = 0, gofs = (unsigned)al * (unsigned)ta.tmpw * 4u;
+      bool ovf = false;      /* an accepted candidate found its row full: the host grows the rows and builds again */
+      /* one row of cells: candidates [s0, s1) of the LDS image.  SELF: the row holds the bead itself */
+      auto scan_row = [&](const int s0, const int s1, auto self_row)
+      {
+         constexpr bool SELF = decltype(self_row)::value;
+         /* four candidates per trip: the LDS reads of a trip are independent (ILP at low occupancy) */
+         for (int sj0 = s0; sj0 < s1; sj0 += 4)
+         {
+            float4 q4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q4[u] = P_s[sj0 + u];      /* past s1: another cell's bead or the tables behind P_s, masked by u < nrem */
+            const int nrem = s1 - sj0;
+            float r2[4];
+            bool ok[4];
+            unsigned long long rare = 0;      /* lanes with a candidate inside the error band (wave-wide: scalar mask arithmetic, one scalar branch) */
+#pragma unroll
+            for (int u = 0; u < 4; u += 2)
+            {
+               /* two candidates per packed multiply / fma (the six differences are scalar subtractions into register pairs: packing their operands would cost moves) */
+               typedef float f2 __attribute__((ext_vector_type(2)));
+               float d[6];
+               const float pc[3] = {fx, fy, fz}, qa[3] = {q4[u].x, q4[u].y, q4[u].z}, qb[3] = {q4[u + 1].x, q4[u + 1].y, q4[u + 1].z};
+#pragma unroll
+               for (int k = 0; k < 3; k++)
+               {
+                  asm("v_sub_f32 %0, %1, %2" : "=v"(d[2 * k]) : "v"(pc[k]), "v"(qa[k]));
+                  asm("v_sub_f32 %0, %1, %2" : "=v"(d[2 * k + 1]) : "v"(pc[k]), "v"(qb[k]));
+               }
+               const f2 x = {d[0], d[1]}, y = {d[2], d[3]}, z = {d[4], d[5]};
+               const f2 rr = __builtin_elementwise_fma(z, z, __builtin_elementwise_fma(y, y, x * x));
+               r2[u] = rr.x; r2[u + 1] = rr.y;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+               /* (ballots of plain compares are the compares' own lane masks: the band test costs one compare per candidate, the rest is scalar) */
+               const bool in = u < nrem, lt = r2[u] < rl2_hi;
+               ok[u] = in & lt;
+               unsigned long long rm = __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(lt) & __builtin_amdgcn_ballot_w64(r2[u] > rl2_lo);
+               if (SELF) { const bool ns = sj0 + u != self; ok[u] &= ns; rm &= __builtin_amdgcn_ballot_w64(ns); }
+               rare |= rm;
+            }
+            if (rare)
+            {
+               /* boundary band: the reference's test on the double positions */
+#pragma unroll
+               for (int u = 0; u < 4; u++)
+                  if (ok[u] && r2[u] > rl2_lo)
+                  {
+                     const double4 pj = pos[sidx[sj0 + u]];
+                     const double X = pi.x - pj.x, Y = pi.y - pj.y, Z = pi.z - pj.z;
+                     ok[u] = X * X + Y * Y + Z * Z < rl2;
+                  }
+            }
+            if (HAS_MOL)
+            {
+               /* candidates of the bead's own molecule (the low byte of the id rides in the image: a filter, confirmed
+                * against the full id) are pruned if the molecule has one species, or if the two atoms are a bonded pair
+                * of the residue (bpairList: bonds, exclusions, constraints) */
+               bool sm[4];
+               unsigned long long anys = 0;
+#pragma unroll
+               for (int u = 0; u < 4; u++) { sm[u] = ok[u] & ((__float_as_uint(q4[u].w) ^ key_i) < (1u << 24)); anys |= __builtin_amdgcn_ballot_w64(sm[u]); }
+               if (anys)
+               {
+#pragma unroll
+                  for (int u = 0; u < 4; u++)
+                     if (sm[u] && M_s[sj0 + u] == (unsigned short)(gi >> 40) &&
+                         (!mol_wide || (unsigned)((unsigned long long)__double_as_longlong(pos[sidx[sj0 + u]].w) >> 32) == (unsigned)(gi >> 32)))
+                     {
+                        const int sj = sj0 + u;
+                        const unsigned wj = __float_as_uint(q4[u].w);
+                        bool pruned = true;
+                        if (mns > 1)
+                        {
+                           const unsigned aI = (unsigned)(gi & 65535ull);
+                           unsigned aJ = (wj >> 16) & 63u;
+                           if (by_mask && aJ < 63u) pruned = (mask_i >> aJ) & 1ull;
+                           else
+                           {
+                              if (aJ == 63u)
+                              {
+                                 /* the image holds codes up to 62: the record's tag has 8 bits, and 255 there sends us to the gid */
+                                 const int gj = sidx[sj];
+                                 aJ = (unsigned)(((unsigned long long)__double_as_longlong(pos[gj].w) >> 8) & 0xffull);
+                                 if (aJ == 255u) aJ = (unsigned)(gid[gj] & 65535ull);
+                              }
+                              if (by_mask && aJ < 63u) pruned = (mask_i >> aJ) & 1ull;
+                              else
+                              {
+                                 pruned = false;
+                                 for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
+                                 {
+                                    const unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
+                                    if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
+                                 }
+                              }
+                           }
+                        }
+                        if (pruned)
+                        {
+                           /* the pair kernel finds the partner among the staged beads (same molecule: always inside the tile's
+                            * neighbourhood): an entry in the list's own format.  (ddcmi_get_list derives the partner's index from it.) */
+                           if (ecnt < maxexcl) excl16[(size_t)ecnt * npad + a] = (unsigned short)(wj & 0xffffu);
+                           ecnt++;
+                           ok[u] = false;
+                        }
+                     }
+               }
+            }
+            /* accepted words go to the lane's ring in LDS ([slot][lane]: conflict-free) and leave as 16-byte stores once four
+             * are waiting: 4-byte stores straight to the scratch row -- one per candidate slot, each lane its own cache
+             * line -- ran into the rate at which L2 takes write requests (2.5 ms per build at 4 M beads against 2.3 for
+             * paired 8-byte stores behind three times the vector instructions) */
+            const bool room = c11 <= lim11;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+               unsigned sh;
+               const float st = fmaf(r2[u], shA, shB);
+               asm("v_cvt_u32_f32 %0, %1" : "=v"(sh) : "v"(st));      /* saturating: negative -> 0 (a C cast of a negative float is undefined) */
+               const unsigned word = (sh << 16) | (HAS_MOL ? (__float_as_uint(q4[u].w) & 0xffffu) : __float_as_uint(q4[u].w));
+               if (ok[u] & room)
+               {
+                  *(lds_uint *)(__UINTPTR_TYPE__)((c11 & RING_MASK) | tid4) = word;
+                  c11 += RING_STEP;
+               }
+               ovf |= ok[u] & !room;
+            }
+            if (c11 - f11 >= 4u * RING_STEP)
+            {
+               const unsigned ra = (f11 & (4u * RING_STEP)) | tid4;      /* f11 counts whole groups of four: ring slots 0-3 or 4-7 */
+               uint4 o;
+               o.x = *(lds_uint *)(__UINTPTR_TYPE__)(ra);
+               o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
+               o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
+               o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
+               *(uint4 *)((char *)trow + gofs) = o;      /* wave-uniform base + 32-bit lane offset */
+               gofs += 16u; f11 += 4u * RING_STEP;
+            }
+         }
+      };
       /* Of the 5x5x5 cells around the bead's cell only those within the list radius of the BEAD are walked: per
        * (y,z) row of cells the gap between the bead and the row's band, and from it the reach along x -- on average
        * 60 % of the candidates of the full cube.  Conservative: gaps are measured to the cells' geometric bounds
@@ -585,110 +723,43 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       const float gfz = (float)((pi.z - gp.lo[2]) * gp.cinv[2]) + (float)(gp.m[2] - (TCZ * tz - 2)) - (float)(lz + 2);
       const float csy = (float)(1.0 / gp.cinv[1]), csz = (float)(1.0 / gp.cinv[2]), cix = (float)gp.cinv[0];
       const float rl2p = (float)(rl2 * (1.0 + 4.0e-4));
+#pragma unroll 1
       for (int dz = 0; dz < 5; dz++)
       {
          const float gz = fmaxf(dz < 2 ? (gfz + (float)(1 - dz)) * csz : dz > 2 ? ((float)(dz - 2) - gfz) * csz : 0.0f, 0.0f);
+#pragma unroll 1
          for (int dy = 0; dy < 5; dy++)
          {
             const float gy = fmaxf(dy < 2 ? (gfy + (float)(1 - dy)) * csy : dy > 2 ? ((float)(dy - 2) - gfy) * csy : 0.0f, 0.0f);
             const float d2yz = gy * gy + gz * gz;
-            if (d2yz >= rl2p) continue;
-            const float wx = __builtin_amdgcn_sqrtf(rl2p - d2yz) * cix * 1.0001f + 1.0e-4f;
-            const int xlo = max(min((int)floorf(ux - wx), lx + 2), lx), xhi = min(max((int)floorf(ux + wx), lx + 2), lx + 4);
-            const int rowb = (lz + dz) * (RGX * RGY) + (ly + dy) * RGX;      /* consecutive cells in x are contiguous */
-            int s0 = ofs_s[rowb + xlo], s1 = ofs_s[rowb + xhi + 1];
-            /* four candidates per trip: the LDS reads of a trip are independent (ILP at low occupancy) */
-            for (int sj0 = s0; sj0 < s1; sj0 += 4)
+            int s0 = 0, s1 = 0;
+            if (d2yz < rl2p)
             {
-               float4 q4[4];
-#pragma unroll
-               for (int u = 0; u < 4; u++) q4[u] = P_s[sj0 + u];      /* past s1: another cell's bead or the tables behind P_s, masked by sj < s1 */
-#pragma unroll
-               for (int u = 0; u < 4; u++)
-               {
-                  int sj = sj0 + u;
-                  const float4 q = q4[u];
-                  float x = fx - q.x, y = fy - q.y, z = fz - q.z;
-                  float r2 = x * x + y * y + z * z;
-#if defined(TB_ABLATE) && TB_ABLATE == 3      /* tuning builds: no accept path */
-                  if (sj < s1 && sj != self && r2 < rl2_hi) cnt++;
-                  if (false)
-#else
-                  if (sj < s1 && sj != self && r2 < rl2_hi)
-#endif
-                  {
-                     if (r2 > rl2_lo)
-                     {
-                        /* boundary band: the reference's test on the double positions */
-                        double4 pj = pos[sidx[sj]];
-                        double X = pi.x - pj.x, Y = pi.y - pj.y, Z = pi.z - pj.z;
-                        if (!(X * X + Y * Y + Z * Z < rl2)) continue;
-                     }
-                     bool pruned = false;
-                     const unsigned wj = __float_as_uint(q.w);
-                     if (HAS_MOL && nmoltype > 0 && (unsigned)(gi >> 32) == M_s[sj])
-                     {
-                        /* same molecule id (the tag holds all 32 bits of gid>>32) */
-                        if (mns > 1)
-                        {
-                           unsigned aI = (unsigned)(gi & 65535ull), aJ = (unsigned)((wj >> 8) & 0xff);
-                           if (aJ == 255u) aJ = (unsigned)(gid[sidx[sj]] & 65535ull);
-                           if (by_mask && aJ < 63u) pruned = (mask_i >> aJ) & 1ull;
-                           else
-                              for (int k = bpair_off[mt]; k < bpair_off[mt + 1]; k++)
-                              {
-                                 unsigned eI = (unsigned)bpairI[k], eJ = (unsigned)bpairJ[k];
-                                 if ((aI == eI && aJ == eJ) || (aJ == eI && aI == eJ)) { pruned = true; break; }
-                              }
-                        }
-                        else pruned = true;
-                     }
-                     if (pruned)
-                     {
-                        if (ecnt < maxexcl)
-                        {
-                           /* the pair kernel finds the partner among the staged beads (same molecule: always inside the tile's
-                            * neighbourhood): an entry in the list's own format.  (ddcmi_get_list derives the partner's index from
-                            * it: a second array of global indices cost a store per excluded pair and 64 B per bead.) */
-                           excl16[(size_t)ecnt * npad + a] = (unsigned short)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1);
-                        }
-                        ecnt++;
-                     }
-                     else
-                     {
-                        /* scratch word: final-format entry + its distance shell (k_tile_transpose lays the
-                         * row out in shell order).  This path runs for every candidate of the wave (some lane
-                         * always accepts), so it is kept short. */
-                        /* (shell boundaries steer only the ORDER of a bead's entries: single precision, and linear in r^2 --
-                         * one fma, one conversion, one clamp; the square root and floor of equal-width shells in r were a
-                         * quarter of this path, and the kernel is bound by VALU issue) */
-                        const int sh_ = min(max((int)fmaf(r2, ta.shc.a, ta.shc.b), 0), NSHELL - 1);
-                        unsigned wcur = (unsigned)(ta.pack_type ? (((sj + 1) << 4) | (int)(wj & 0xf)) : sj + 1) | ((unsigned)sh_ << 16);
-#if defined(TB_ABLATE) && TB_ABLATE == 1      /* tuning builds: no scratch stores */
-                        wprev += wcur;
-#elif defined(TB_ST4)                         /* tuning builds: one 4-byte store per entry */
-                        if (cnt < ta.tmpw) ((unsigned *)row2)[cnt] = wcur;
-#else
-                        if (cnt & 1) { if (cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, wcur); }
-                        else wprev = wcur;
-#endif
-                        cnt++;
-                     }
-                  }
-               }
+               const float wx = __builtin_amdgcn_sqrtf(rl2p - d2yz) * cix * 1.0001f + 1.0e-4f;
+               const int xlo = max(min((int)floorf(ux - wx), lx + 2), lx), xhi = min(max((int)floorf(ux + wx), lx + 2), lx + 4);
+               const int rowb = (lz + dz) * (RGX * RGY) + (ly + dy) * RGX;      /* consecutive cells in x are contiguous */
+               s0 = ofs_s[rowb + xlo]; s1 = ofs_s[rowb + xhi + 1];
             }
+            if (dz == 2 && dy == 2) scan_row(s0, s1, std::true_type()); else scan_row(s0, s1, std::false_type());
          }
       }
-#if defined(TB_ABLATE) && TB_ABLATE == 1
-      if (wprev == 0x12345u) cnt++;
-#elif !defined(TB_ST4)
-      if ((cnt & 1) && cnt < ta.tmpw) row2[cnt >> 1] = make_uint2(wprev, 0u);
-#endif
-      mymax = max(mymax, cnt);
+      if (c11 != f11)
+      {
+         /* the last one to three words (the group's tail is never read: the row's count says so) */
+         const unsigned ra = (f11 & (4u * RING_STEP)) | tid4;
+         uint4 o;
+         o.x = *(lds_uint *)(__UINTPTR_TYPE__)(ra);
+         o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
+         o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
+         o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
+         *(uint4 *)((char *)trow + gofs) = o;
+      }
+      const int cnt = (int)(c11 / RING_STEP);
+      mymax = max(mymax, min(cnt, ta.tmpw));
       ta.nbr_cnt[a] = min(cnt, ta.tmpw);
       excl_cnt[a] = min(ecnt, maxexcl);
       if (ecnt > maxexcl) atomicMax(&flags[1], ecnt);
-      if (cnt > ta.tmpw) atomicMax(&flags[5], cnt);
+      if (ovf) atomicMax(&flags[5], ta.tmpw + ta.tmpw / 4);
    }
    /* block max -> ELL width of this tile; one thread takes the arena slice */
    int m = mymax;
@@ -708,19 +779,23 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       else sb = (long long)b0;
       ta.tile_base[t] = sb < 0 ? 0 : sb;
       ta.tile_width[t] = width; ta.tile_rows[t] = sb < 0 ? 0 : rows;
-      atomicMax(&flags[2], width);
+      ta.tile_work[4 * ta.ntile + t] = width;
    }
-   /* statistics: entries of this tile */
-   unsigned long long mine = 0, mex = 0;
+   /* statistics: entries of this tile.  They leave as per-tile numbers that the host adds up (it reads the tiles' cost
+    * estimates anyway): with one atomic per wave on a device-wide total -- eighteen same-address atomics per tile, all on
+    * one cache line with the arena counter -- the atomics were this kernel: 1.8 ms of its 2.3 at 4 M beads for an
+    * instance that staged its neighbourhood and searched nothing */
+   int mine = 0, mex = 0;
    for (int al = threadIdx.x; al < nown; al += TB_THREADS) { mine += ta.nbr_cnt[ts + al]; mex += excl_cnt[ts + al]; }
    for (int off = 32; off > 0; off >>= 1) { mine += __shfl_down(mine, off, 64); mex += __shfl_down(mex, off, 64); }
-   if ((threadIdx.x & 63) == 0) { atomicAdd(&totals[0], mine); atomicAdd(&totals[1], mex); }
-   /* cost estimate of this tile in k_nonbond (list slots + staging), for k_tile_schedule */
    __syncthreads();
-   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (int)mine;
+   if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = mine; s_amax[threadIdx.x >> 6] = __int_as_float(mex); }
    __syncthreads();
    if (threadIdx.x == 0)
    {
+      int te_ = 0, tx_ = 0;
+      for (int q = 0; q < TB_THREADS / 64; q++) { te_ += s_w[q]; tx_ += __float_as_int(s_amax[q]); }
+      ta.tile_work[2 * ta.ntile + t] = te_; ta.tile_work[3 * ta.ntile + t] = tx_;
       /* residency of the tile's workgroup in k_nonbond: (passes x list groups per lane),
        * scaled so that a full tile counts its list entries, + staging */
       constexpr int NWAVES = NB_THREADS / 64;
@@ -735,14 +810,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          work += ((ngrp + parts - 1) / parts) * 8 * 64 * NWAVES;
       }
       /* [t]: the list walk (bit 30: the tile stages image/halo beads); [ntile + t]: staging, in the same unit --
-       * calibrated on per-workgroup timelines (tools/trace_gaps.py): a full tile walks ~80 k units in 25 us and
-       * stages 2400-3000 beads in 5-7.5 us */
+       * calibrated on per-workgroup timelines: a full tile walks ~80 k units in 25 us and stages 2400-3000 beads in 5-7.5 us */
       ta.tile_work[t] = (work + 1) | (s_halo ? (1 << 30) : 0);
       ta.tile_work[ta.ntile + t] = 7 * tot;
    }
-#ifdef DDCMI_TRACE_BLOCKS
-   TRACE_TB(2, wall_clock64()); TRACE_TB(3, clock64() - tb_c0);
-#endif
+#undef s_halo
 }
 
 /* second half of the build: row-major scratch -> the tile's slot-major ELL slice
@@ -966,21 +1038,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
     * give XCD x one contiguous tile range (schedule_tiles: equal work per XCD):
     * neighbouring tiles, which stage overlapping neighbourhoods, then share one L2.
     * Speed only. */
-   TRACE_MARK(0);
-#ifdef DDCMI_TRACE_BLOCKS
-   if (threadIdx.x == 0 && blockIdx.x < 65536)
-   {
-      unsigned xcc, hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      g_trace[8 * blockIdx.x + 4] = xcc; g_trace[8 * blockIdx.x + 5] = hw;
-   }
-#endif
-#ifdef DDCMI_TRACE_BLOCKS
-   const int xcd = (blockIdx.x + ta.rot) & 7;
-#else
    const int xcd = blockIdx.x & 7;
-#endif
    const int slot = ta.sched[xcd] + (int)(blockIdx.x >> 3);
    const bool mine = slot < ta.sched[xcd + 1];
    /* a work item is a tile or -- in the last round of a launch, where whole tiles would leave most CUs idle --
@@ -1081,11 +1139,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
 #pragma unroll
             for (int u = 0; u < SU; u++)
             {
-#if defined(NB_ABLATE) && NB_ABLATE == 5      /* tuning builds: no record gathers (every staged bead is the tile's first bead) */
-               pp[u] = pos[ts];
-#else
                pp[u] = pos[gj[b + u]];
-#endif
                sh[u] = (!SHBIT && tshift && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
             }
 #pragma unroll
@@ -1142,7 +1196,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          if (!SHBIT) S_s[0] = 0;
       }
       __syncthreads();
-      TRACE_MARK(1);
       long long base = ta.tile_base[t];
       int rows = ta.tile_rows[t];
       const int nlj = ta.nlj;
@@ -1188,11 +1241,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          int wmax = ngl;
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-#if defined(NB_ABLATE) && NB_ABLATE == 3      /* tuning builds: staging and epilogue only */
-         wmax = 0;
-#elif defined(NB_ABLATE) && NB_ABLATE == 4    /* tuning builds: half of the list */
-         wmax = (wmax + 1) >> 1;
-#endif
          /* The list stream: one 16-byte load per lane and group, kept two groups ahead of
           * the pair loop.  Three named buffers (the loop is unrolled by three) rather
           * than a rotating one, so each wait covers exactly the oldest load; the loads
@@ -1255,26 +1303,15 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   unsigned wd = qw[(h * CH + u) >> 1];
                   if (PACKED) o[u] = ((u & 1) ? (wd >> 16) : wd) & 0xfff0u;
                   else o[u] = ((u & 1) ? (wd >> 16) : (wd & 0xffffu)) << 4;
-#if defined(NB_ABLATE) && NB_ABLATE == 2      /* tuning builds: conflict-free gathers (every lane of a 16-lane group reads the same slot) */
-                  const unsigned oc_ = (unsigned)__builtin_amdgcn_readfirstlane((int)o[u]);
-                  xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + oc_);
-                  double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(oc_ >> 1);
-#else
                   xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + o[u]);
                   double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(o[u] >> 1);
-#endif
                   double px = pxy.x, py = pxy.y;
                   x[u] = pi.x - px; y[u] = pi.y - py; z[u] = pi.z - pz;
                   r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                }
-#if defined(NB_ABLATE) && NB_ABLATE == 1      /* tuning builds: distance tests only */
-#pragma unroll
-               for (int u = 0; u < CH; u++) if (r2[u] < rc2) fxi += r2[u];
-#else
 #pragma unroll
                for (int u = 0; u < CH; u++)
                   if (r2[u] < rc2) NB_PAIR(u, qw[(h * CH + u) >> 1], u & 1);
-#endif
             }
 #undef NB_PAIR
          };
@@ -1331,11 +1368,6 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
       }
       }
    }
-#ifdef DDCMI_TRACE_BLOCKS
-   __syncthreads();
-   TRACE_MARK(2);
-   if (threadIdx.x == 0 && blockIdx.x < 65536) { g_trace[8 * blockIdx.x + 6] = (unsigned long long)t; g_trace[8 * blockIdx.x + 7] = (unsigned long long)nown; }
-#endif
    if (mine)
    {
       /* the tile's LDS doubles as reduction scratch: no static LDS in this kernel, so the
@@ -1831,8 +1863,8 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
        hipMalloc((void **)&ctx->d_results, R_SIZE * sizeof(double)) != hipSuccess ||
        hipHostMalloc((void **)&ctx->h_results, R_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-       hipMalloc((void **)&ctx->d_flags, 32 * sizeof(int)) != hipSuccess ||
-       hipHostMalloc((void **)&ctx->h_flags, 32 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+       hipMalloc((void **)&ctx->d_flags, 64 * sizeof(int)) != hipSuccess ||
+       hipHostMalloc((void **)&ctx->h_flags, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess)
    {
       g_create_err = "context allocation failed";
       if (ctx->self_pinned) (void)hipHostUnregister(ctx);
@@ -1840,7 +1872,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
-   (void)hipMemset(ctx->d_flags, 0, 32 * sizeof(int));
+   (void)hipMemset(ctx->d_flags, 0, 64 * sizeof(int));
    if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the context's non-blocking stream */
@@ -2330,7 +2362,7 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
    for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
    /* the counters of the whole rebuild in one launch: cell counts, the capacity flags and totals of k_tile_build */
    ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1)
-                               .add(ctx->d_flags + 16, 6));
+                               .add(ctx->d_flags + 32, 2));
    if (n > 0)
    {
       hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12);
@@ -2606,54 +2638,56 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
    ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
-   ENSURE(ctx, ctx->tile_work, 2 * (size_t)ntile + 2);
+   ENSURE(ctx, ctx->tile_work, 5 * (size_t)ntile + 2);
    if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
    double rcut = ctx->rmax, dR = ctx->deltaR;
-   /* distance shells of the list order: entries a wave rejects as a whole come last */
+   /* distance shells of the list order: entries a wave rejects as a whole come last.  Shell 0: r < rcut - dR/4; shells
+    * 1..NSHELL-1: equal steps of r^2 from there to the list radius (0.7 A wide at the cut-off for the Martini numbers; the
+    * last one, beyond rcut + 0.85 dR, holds what no drift brings inside the cut-off) */
    ShellCuts shc;
    {
-      /* shell 0: r < rcut - dR/4; shells 1..NSHELL-2: equal steps of r^2 up to rcut + 3/4 dR (0.7 A wide at the cut-off for
-       * the Martini numbers); the last shell: everything beyond, which no drift brings inside the cut-off */
-      const double r0 = rcut - 0.25 * dR, rh = rcut + 0.75 * dR;
-      const double a = (dR > 1e-9 * rcut) ? (NSHELL - 2) / (rh * rh - r0 * r0) : 0.0;      /* no skin: one shell */
-      shc.a = (float)a; shc.b = (float)(1.0 - r0 * r0 * a);
+      const double r0 = rcut - 0.25 * dR;
+      shc.r0sq = (float)(r0 * r0); shc.one = !(dR > 1e-9 * rcut);      /* no skin: one shell */
    }
-   unsigned long long *d_tot = (unsigned long long *)(ctx->d_flags + 16);    /* [0]=entries [1]=excluded [2]=arena used; travels with the flags */
+   unsigned long long *d_arena = (unsigned long long *)(ctx->d_flags + 32);    /* arena entries handed out: the one device-wide counter of the build, on a cache line of its own */
    for (int attempt = 0;; attempt++)
    {
       if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
       bool has_mol = false;
       for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
       /* LDS image: 16 B per staged bead (+ 4 B molecule id when pairs can be excluded) + the region cell tables */
-      size_t lds = (size_t)ctx->stage_cap * (has_mol ? 20 : 16) + (2 * NRC + 16) * sizeof(int) + (size_t)ctx->stage_cap * sizeof(unsigned short) + 16;
+      /* LDS image: the ring of accepted words (16 KB), 16 B per staged bead (+ 2 B of molecule id when pairs can be excluded), the region cell tables */
+      size_t lds = TB_RING_BYTES + (size_t)ctx->stage_cap * (has_mol ? 18 : 16) + (2 * NRC + 16 + 2 * (TB_THREADS / 64) + 8) * sizeof(int) + 16;
+      if ((size_t)ctx->stage_cap * sizeof(unsigned short) > TB_RING_BYTES) lds += (size_t)ctx->stage_cap * sizeof(unsigned short);      /* (bare 16-bit entries: the slot -> cell map outgrows the ring) */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
       ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
       if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
       if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
-      if (attempt > 0) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_tot, 6));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
+      if (attempt > 0) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_arena, 2));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
       ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
       TileArgs ta;
       ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
       ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
       ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
-      ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_tot + 2;
+      ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_arena;
       ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
-      auto kbuild = has_mol ? k_tile_build<true> : k_tile_build<false>;
+      auto kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
+                            : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
       HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
-                         ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags, d_tot);
+                         ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags);
       /* everything the host decides on (capacity flags, totals, the tiles' cost estimates) is final when k_tile_build
        * ends: it travels behind an event, and the host reads it -- and orders the tiles -- while k_tile_transpose runs */
       unsigned long long tot[3];
-      int *h_work = ctx->pinned(0, 2 * (size_t)ntile + 8);
+      int *h_work = ctx->pinned(0, 5 * (size_t)ntile + 8);      /* per tile: list cost, staging cost, entries, excluded entries, width */
       if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
       if (!ctx->ev_build) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_build, hipEventDisableTiming));
-      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 32 * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 2 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 5 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
       HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
       {
          size_t lds2 = (size_t)TR_ROWS * TR_RS(ctx->tmpw) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
@@ -2663,7 +2697,10 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       }
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventSynchronize(ctx->ev_build));
-      memcpy(tot, ctx->h_flags + 16, sizeof(tot));
+      tot[0] = tot[1] = 0;
+      int maxw = 0;
+      for (int t = 0; t < ntile; t++) { tot[0] += (unsigned)h_work[2 * (size_t)ntile + t]; tot[1] += (unsigned)h_work[3 * (size_t)ntile + t]; maxw = std::max(maxw, h_work[4 * (size_t)ntile + t]); }
+      memcpy(&tot[2], ctx->h_flags + 32, sizeof(unsigned long long));
       if (ctx->h_flags[12] > 0)
          SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)", ctx->h_flags[12], (long long)ctx->loop);
       bool again = false;
@@ -2675,7 +2712,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (!again)
       {
          ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
-         ctx->maxnbr = ctx->h_flags[2];
+         ctx->maxnbr = maxw;
          break;
       }
    }
@@ -2755,7 +2792,6 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
-      { const char *rv = getenv("DDCMI_XCD_ROT"); na.rot = rv ? atoi(rv) : 0; }
 #define LAUNCH_NB(Q, P, S, NT) do { \
          HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
          hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \

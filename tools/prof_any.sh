@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel-trace stats of an arbitrary bench invocation: bash tools/prof_any.sh <tag> <bench args...>
+set -u
 tag=$1; shift
 export TMPDIR=/tmp
 root=$PWD

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Tuning builds that never touch the product: copy csrc/hip to a scratch directory, apply text substitutions,
+compile for gfx950 and link tuning/libddcmi_<name>.so (git-ignored; select it with DDCMI_LIB=...).
+
+   python3 tools/variant.py <name> [-D FLAG ...] [--sub 'old' 'new' ...] [--patch file.py]
+
+--patch file.py: a python file defining edit(src: str) -> str, applied to ddcmi.hip."""
+import os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ddcmd_amd", "csrc")
+
+
+def main():
+    name = sys.argv[1]
+    flags, subs, patch = [], [], None
+    a = sys.argv[2:]
+    while a:
+        if a[0] == "-D": flags.append("-D" + a[1]); a = a[2:]
+        elif a[0] == "--sub": subs.append((a[1], a[2])); a = a[3:]
+        elif a[0] == "--patch": patch = a[1]; a = a[2:]
+        else: raise SystemExit("unknown argument " + a[0])
+    work = os.path.join("/tmp", "ddcmi_variant_" + name)
+    shutil.rmtree(work, ignore_errors=True)
+    shutil.copytree(os.path.join(CSRC, "hip"), os.path.join(work, "hip"))
+    fn = os.path.join(work, "hip", "ddcmi.hip")
+    src = open(fn).read()
+    for old, new in subs:
+        if old not in src: raise SystemExit("substitution source not found: " + old[:60])
+        src = src.replace(old, new)
+    if patch:
+        g = {}
+        exec(open(patch).read(), g)
+        src = g["edit"](src)
+    open(fn, "w").write(src)
+    subprocess.check_call(["make", "-s", "-C", CSRC])      # host objects
+    objs = []
+    procs = []
+    for f in ("ddcmi", "scan", "bonded"):
+        o = os.path.join(work, f + ".o")
+        objs.append(o)
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
+                                       "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(work, "hip")] + flags +
+                                      ["-c", os.path.join(work, "hip", f + ".hip"), "-o", o]))
+    if any(p.wait() for p in procs): raise SystemExit("compile failed")
+    out = os.path.join(ROOT, "tuning", "libddcmi_%s.so" % name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    host = [os.path.join(CSRC, "build", "host", f) for f in os.listdir(os.path.join(CSRC, "build", "host")) if f.endswith(".o")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + host + objs + ["-L/opt/rocm/lib", "-lrccl", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
+    print("built", out)
+
+
+if __name__ == "__main__":
+    main()
