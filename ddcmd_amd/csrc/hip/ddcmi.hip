@@ -817,166 +817,121 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
 #undef s_halo
 }
 
-/* second half of the build: row-major scratch -> the tile's slot-major ELL slice
- * with entries ordered by distance shell.  Rows are brought into LDS in chunks of
- * TR_ROWS with 16-byte loads; TR_TPR threads share a row, each running a sequential
- * counting sort over its contiguous part (stable, so the result does not depend on
- * timing); the sorted entries land in an LDS image of the slice, which is written
- * out with 16-byte stores.  The kernel is bound by VALU issue, so the per-entry work
- * is kept to a handful of instructions: the shell counters and cursors of a thread
- * live in LDS ([shell][thread]: conflict-free) and are advanced by LDS atomics --
- * ds_add / ds_add_rtn instead of shifts and selects on packed registers. */
+/* second half of the build: row-major scratch -> the tile's slot-major ELL slice with entries ordered by distance
+ * shell.  Every WAVE works alone on eight rows at a time (eight lanes per row): no workgroup barriers, no staging of
+ * the scratch rows in LDS.  A lane loads its share of the row -- the 16-byte quads q, q+8, q+16, ... of the row, so the
+ * eight lanes of a row read 128 contiguous bytes per load -- and keeps the words in registers through both passes of a
+ * counting sort by shell: counts and cursors are per-lane columns of an LDS table ([shell][thread]: conflict-free),
+ * advanced by LDS atomics; a prefix over the eight lanes of a row turns counts into cursors; the entries land in a
+ * small LDS image of the eight rows ([slot][row]) and leave as 16-byte stores, 128 contiguous bytes per slot group.
+ * The order inside a shell is (lane, quad, word): fixed by the data alone, so a run repeats bit for bit.
+ * (The first version staged 32 rows per workgroup in LDS and read every word back twice: the LDS pipe was busy 60 % of
+ * that kernel's 0.95 ms at 4 M beads, three barriers per chunk kept its waves in step.) */
 #define TR_THREADS 256
-#define TR_ROWS 32
-#define TR_TPR (TR_THREADS / TR_ROWS)      /* threads per row */
-#define IMG_STRIDE (TR_ROWS + 2)           /* +2 entries: slot rows land on different LDS banks */
-#define TR_RS(tmpw) ((tmpw) + 4)           /* row stride of the scratch image in words: rows stay 16-byte aligned */
+#define TR_WROWS 8                         /* rows a wave sorts together */
+#define TR_S 9                             /* row stride of the wave's image in 16-bit entries: [slot][TR_S] */
+template <int NQ>                          /* quads a lane may hold: rows of up to 32 NQ words */
 __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
 {
    extern __shared__ unsigned int tr_smem[];
-   const int rs = TR_RS(ta.tmpw);
-   unsigned int *rows_s = tr_smem;                   /* [TR_ROWS][rs] scratch words */
-   unsigned int *img32 = rows_s + TR_ROWS * rs;      /* [width][IMG_STRIDE] 16-bit entries, accessed as dwords for the fill */
-   unsigned short *img = (unsigned short *)img32;
-   __shared__ int cnt2_s[2][TR_ROWS];                /* entry counts of the rows of this chunk and the next */
    __shared__ unsigned cur_s[NSHELL * TR_THREADS];   /* [shell][thread]: counts, then cursors */
    static_assert(NSHELL == 8, "two words of four 16-bit shell counters");
-   int t = blockIdx.x;
-   int ts = ta.cell_start_o[TCELLS * t];
-   int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
-   int rows = ta.tile_rows[t];
+   const int t = blockIdx.x;
+   const int ts = ta.cell_start_o[TCELLS * t];
+   const int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
+   const int rows = ta.tile_rows[t];
    if (nown <= 0 || rows <= 0) return;
-   int width = ta.tile_width[t];
-   long long base = ta.tile_base[t];
+   const int width = ta.tile_width[t];
+   const long long base = ta.tile_base[t];
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int r_own = threadIdx.x / TR_TPR, q_own = threadIdx.x % TR_TPR;
+   const int rl = lane >> 3, q = lane & 7;      /* row of the batch, lane of the row */
+   unsigned short *img = (unsigned short *)tr_smem + (size_t)w * ta.tmpw * TR_S;      /* this wave's image: [width][TR_S] */
    unsigned *mycur = cur_s + threadIdx.x;
-   /* A workgroup spends its life in round trips (a chunk's rows from memory, then three barriers), and the kernel's
-    * time is that latency over the workgroups a CU holds: the rows of chunk c + 1 are requested before chunk c is
-    * sorted and wait in registers; the counts that size those loads run one chunk further ahead. */
-   constexpr int RPW = TR_ROWS / (TR_THREADS / 64);
-   uint4 vn[RPW];
-   auto row_count = [&](int r) -> int { return r < nown ? ta.nbr_cnt[ts + r] : 0; };
-   auto request = [&](int c0n, const int *cnt)
+   const int ngrp = width >> 3;
+   for (int r0 = w * TR_WROWS; r0 < rows; r0 += TR_WROWS * (TR_THREADS / 64))
    {
+      const int row = r0 + rl;
+      const int cnt = row < nown ? ta.nbr_cnt[ts + row] : 0;
+      const int nq = (cnt + 3) >> 2;
+      const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(row, nown - 1)) * ta.tmpw);      /* tmpw is a multiple of 8 */
+      uint4 wv[NQ];
 #pragma unroll
-      for (int j = 0; j < RPW; j++)
-      {
-         const int r = w + j * (TR_THREADS / 64);
-         const int nq = (cnt[r] + 3) >> 2;
-         const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0n + r, nown - 1)) * ta.tmpw);      /* tmpw is a multiple of 8 */
-         vn[j] = (lane < nq) ? src[lane] : make_uint4(0, 0, 0, 0);
-      }
-   };
-   if (threadIdx.x < 2 * TR_ROWS) cnt2_s[0][threadIdx.x] = row_count(threadIdx.x);      /* both buffers: chunks 0 and 1 */
-   __syncthreads();
-   request(0, cnt2_s[0]);
-   for (int c0 = 0, ci = 0; c0 < rows; c0 += TR_ROWS, ci++)
-   {
-      const int *cnt_s = cnt2_s[ci & 1];
-      const int cn2 = (threadIdx.x < TR_ROWS) ? row_count(c0 + 2 * TR_ROWS + threadIdx.x) : 0;
-      for (int idx = threadIdx.x; idx < width * (IMG_STRIDE / 2); idx += TR_THREADS) img32[idx] = 0;     /* width is a multiple of 8 <= tmpw */
+      for (int j = 0; j < NQ; j++) wv[j] = (q + 8 * j < nq) ? src[q + 8 * j] : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int sh = 0; sh < NSHELL; sh++) mycur[sh * TR_THREADS] = 0u;
+      /* padding of the row (entry 0 = the sentinel bead): slots cnt .. width-1 */
+      for (int s = cnt + q; s < width; s += 8) img[s * TR_S + rl] = 0;
+      /* counts per shell */
 #pragma unroll
-      for (int j = 0; j < RPW; j++)
+      for (int j = 0; j < NQ; j++)
       {
-         const int r = w + j * (TR_THREADS / 64);
-         const int nq = (cnt_s[r] + 3) >> 2;
-         uint4 *dst = (uint4 *)(rows_s + r * rs);
-         if (lane < nq) dst[lane] = vn[j];
-         if (nq > 64)
+         const unsigned x[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
+         const int k = 4 * (q + 8 * j);
+#pragma unroll
+         for (int i = 0; i < 4; i++)
+            if (k + i < cnt) atomicAdd(mycur + (x[i] >> 16) * TR_THREADS, 1u);      /* the shell, from k_tile_build */
+      }
+      /* offsets: shells in order, inside a shell the row's lanes in order -- on the eight counts packed as 16-bit
+       * fields of two 64-bit words (a row holds < 65536 entries) */
+      unsigned long long c0w = 0, c1w = 0;
+#pragma unroll
+      for (int sh = 0; sh < 4; sh++)
+      {
+         c0w |= (unsigned long long)mycur[sh * TR_THREADS] << (16 * sh);
+         c1w |= (unsigned long long)mycur[(sh + 4) * TR_THREADS] << (16 * sh);
+      }
+      unsigned long long i0 = c0w, i1 = c1w;
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1)
+      {
+         unsigned long long v0 = __shfl_up(i0, off, 8), v1 = __shfl_up(i1, off, 8);
+         if (q >= off) { i0 += v0; i1 += v1; }
+      }
+      const unsigned long long t0 = __shfl(i0, 7, 8), t1 = __shfl(i1, 7, 8);
+      /* field i of (x << 16) + (x << 32) + (x << 48) = sum of the fields below i */
+      const unsigned long long b0 = (t0 << 16) + (t0 << 32) + (t0 << 48);
+      const unsigned long long n03 = ((b0 + t0) >> 48) & 0xffffull;                  /* entries in shells 0..3 */
+      const unsigned long long b1 = n03 * 0x0001000100010001ull + (t1 << 16) + (t1 << 32) + (t1 << 48);
+      const unsigned long long s0 = b0 + i0 - c0w, s1 = b1 + i1 - c1w;
+#pragma unroll
+      for (int sh = 0; sh < 4; sh++)
+      {
+         mycur[sh * TR_THREADS] = (unsigned)((s0 >> (16 * sh)) & 0xffffull);
+         mycur[(sh + 4) * TR_THREADS] = (unsigned)((s1 >> (16 * sh)) & 0xffffull);
+      }
+      /* placement */
+#pragma unroll
+      for (int j = 0; j < NQ; j++)
+      {
+         const unsigned x[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
+         const int k = 4 * (q + 8 * j);
+         unsigned slot[4];
+#pragma unroll
+         for (int i = 0; i < 4; i++) slot[i] = (k + i < cnt) ? atomicAdd(mycur + (x[i] >> 16) * TR_THREADS, 1u) : 0u;
+#pragma unroll
+         for (int i = 0; i < 4; i++) if (k + i < cnt) img[slot[i] * TR_S + rl] = (unsigned short)(x[i] & 0xffffu);
+      }
+      /* the wave's LDS operations complete in order: the image is whole when the reads below are issued */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      /* slice layout: [slot group g][row][8 slots] -> a lane of k_nonbond reads its 8 slots of a group with one 16-byte
+       * load; written the same way: lane (g, r) packs the group's 8 entries of its row, 8 rows = 128 contiguous bytes */
+      {
+         const int ro = lane & 7;
+         for (int g = lane >> 3; g < ngrp; g += 8)
          {
-            const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(c0 + r, nown - 1)) * ta.tmpw);
-            for (int q = lane + 64; q < nq; q += 64) dst[q] = src[q];
+            const unsigned short *e = img + (8 * g) * TR_S + ro;
+            uint4 o;
+            o.x = (unsigned)e[0] | ((unsigned)e[TR_S] << 16);
+            o.y = (unsigned)e[2 * TR_S] | ((unsigned)e[3 * TR_S] << 16);
+            o.z = (unsigned)e[4 * TR_S] | ((unsigned)e[5 * TR_S] << 16);
+            o.w = (unsigned)e[6 * TR_S] | ((unsigned)e[7 * TR_S] << 16);
+            *(uint4 *)(ta.nbr16 + base + ((size_t)g * rows + r0 + ro) * 8) = o;
          }
       }
-      if (c0 + TR_ROWS < rows) request(c0 + TR_ROWS, cnt2_s[(ci + 1) & 1]);
-      __syncthreads();
-      {
-         const int cnt = cnt_s[r_own];
-         const int per = (cnt + TR_TPR - 1) / TR_TPR;
-         const int k0 = min(q_own * per, cnt), k1 = min(k0 + per, cnt);
-         const unsigned int *row = rows_s + r_own * rs;
-         /* (four entries per trip: the LDS reads and atomics of a trip are issued back to back -- LDS executes a wave's
-          * operations in order, so same-counter atomics of one thread still see each other) */
-         int k = k0;
-         for (; k + 4 <= k1; k += 4)
-         {
-            unsigned wv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) wv[u] = row[k + u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) atomicAdd(mycur + (wv[u] >> 16) * TR_THREADS, 1u);      /* the shell, from k_tile_build */
-         }
-         for (; k < k1; k++) atomicAdd(mycur + (row[k] >> 16) * TR_THREADS, 1u);
-         /* offsets: shells in order, inside a shell the row's parts in order -- on the eight counts packed as 16-bit
-          * fields of two 64-bit words (a row holds < 65536 entries) */
-         unsigned long long c0w = 0, c1w = 0;
-#pragma unroll
-         for (int sh = 0; sh < 4; sh++)
-         {
-            c0w |= (unsigned long long)mycur[sh * TR_THREADS] << (16 * sh);
-            c1w |= (unsigned long long)mycur[(sh + 4) * TR_THREADS] << (16 * sh);
-         }
-         unsigned long long i0 = c0w, i1 = c1w;
-#pragma unroll
-         for (int off = 1; off < TR_TPR; off <<= 1)
-         {
-            unsigned long long v0 = __shfl_up(i0, off, TR_TPR), v1 = __shfl_up(i1, off, TR_TPR);
-            if (q_own >= off) { i0 += v0; i1 += v1; }
-         }
-         const unsigned long long t0 = __shfl(i0, TR_TPR - 1, TR_TPR), t1 = __shfl(i1, TR_TPR - 1, TR_TPR);
-         /* field i of (x << 16) + (x << 32) + (x << 48) = sum of the fields below i */
-         const unsigned long long b0 = (t0 << 16) + (t0 << 32) + (t0 << 48);
-         const unsigned long long n03 = ((b0 + t0) >> 48) & 0xffffull;                  /* entries in shells 0..3 */
-         const unsigned long long b1 = n03 * 0x0001000100010001ull + (t1 << 16) + (t1 << 32) + (t1 << 48);
-         const unsigned long long s0 = b0 + i0 - c0w, s1 = b1 + i1 - c1w;
-#pragma unroll
-         for (int sh = 0; sh < 4; sh++)
-         {
-            mycur[sh * TR_THREADS] = (unsigned)((s0 >> (16 * sh)) & 0xffffull);
-            mycur[(sh + 4) * TR_THREADS] = (unsigned)((s1 >> (16 * sh)) & 0xffffull);
-         }
-         k = k0;
-         for (; k + 4 <= k1; k += 4)
-         {
-            unsigned wv[4], slot[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) wv[u] = row[k + u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) slot[u] = atomicAdd(mycur + (wv[u] >> 16) * TR_THREADS, 1u);
-#pragma unroll
-            for (int u = 0; u < 4; u++) img[slot[u] * IMG_STRIDE + r_own] = (unsigned short)(wv[u] & 0xffffu);
-         }
-         for (; k < k1; k++)
-         {
-            const unsigned wv = row[k];
-            const unsigned slot = atomicAdd(mycur + (wv >> 16) * TR_THREADS, 1u);
-            img[slot * IMG_STRIDE + r_own] = (unsigned short)(wv & 0xffffu);
-         }
-      }
-      __syncthreads();
-      /* slice layout: [slot group g][row][8 slots] -> a lane reads its 8 slots of a group with one 16-byte load;
-       * written the same way: thread (g, r) packs the group's 8 entries of its row */
-      {
-         const int nr = min(TR_ROWS, rows - c0);
-         const int ngrp = width >> 3;
-         const int r = threadIdx.x & (TR_ROWS - 1);
-         if (r < nr)
-            for (int g = threadIdx.x / TR_ROWS; g < ngrp; g += TR_THREADS / TR_ROWS)
-            {
-               const unsigned short *e = img + (8 * g) * IMG_STRIDE + r;
-               uint4 o;
-               o.x = (unsigned)e[0] | ((unsigned)e[IMG_STRIDE] << 16);
-               o.y = (unsigned)e[2 * IMG_STRIDE] | ((unsigned)e[3 * IMG_STRIDE] << 16);
-               o.z = (unsigned)e[4 * IMG_STRIDE] | ((unsigned)e[5 * IMG_STRIDE] << 16);
-               o.w = (unsigned)e[6 * IMG_STRIDE] | ((unsigned)e[7 * IMG_STRIDE] << 16);
-               *(uint4 *)(ta.nbr16 + base + ((size_t)g * rows + c0 + r) * 8) = o;
-            }
-      }
-      if (threadIdx.x < TR_ROWS) cnt2_s[ci & 1][threadIdx.x] = cn2;      /* this buffer's next user is chunk ci + 2 */
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();      /* (the next batch rewrites the image) */
    }
 }
 
@@ -1006,7 +961,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
  *      shifted copies and excluded pairs (see below).
  * Bound: FP64 issue and LDS gathers behind s_waitcnt at 4 waves per SIMD -- DESIGN.md section 4 has the
  * counters, the ablations and the per-CU timelines. */
-template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH>
+template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
                                                          const unsigned short *__restrict__ excl16, const int *__restrict__ excl_cnt,
@@ -1018,9 +973,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    /* LDS: staged neighbourhood as {x,y} pairs + z (24 B per bead), LJ table, and --
     * only when needed -- per-bead LJ types (nlj > 16) and charges */
    extern __shared__ double2 smem[];
-   double *Z_s = (double *)smem;                 /* staged positions: z [cap], then {x,y} [cap] -- 24 B per bead */
-   double2 *XY_s = (double2 *)(Z_s + ta.cap);
-   double4 *s_lj = (double4 *)(XY_s + ta.cap);
+   /* staged positions, 24 B per bead.  ZOFF > 0 (neighbourhoods of up to ZOFF/16 beads: every Martini system): {x,y} [cap] at LDS
+    * address 0 and z [cap] at the compile-time byte offset ZOFF, so a gather's addresses are the entry's slot bits themselves
+    * (slot * 16 for {x,y}; slot * 8 + the instruction's immediate offset for z).  ZOFF = 0: z [cap], then {x,y} [cap] at a run-time offset */
+   double2 *XY_s = ZOFF ? (double2 *)smem : (double2 *)((double *)smem + ta.cap);
+   double *Z_s = ZOFF ? (double *)((char *)smem + ZOFF) : (double *)smem;
+   double4 *s_lj = ZOFF ? (double4 *)(Z_s + ta.cap) : (double4 *)(XY_s + ta.cap);
    /* charges: a bead's "type" is its (LJ type, charge) class, so ke/eps_r q_i q_j is one more
     * per-type-pair table entry -- no per-bead charge array in LDS (it cost 8 B/bead: one
     * workgroup per CU instead of two) and no charge gather per pair */
@@ -1032,7 +990,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    typedef __attribute__((address_space(3))) const double lds_cdouble;
    typedef double xy_t __attribute__((ext_vector_type(2)));
    typedef __attribute__((address_space(3))) const xy_t lds_cxy;
-   const unsigned xy_off = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)XY_s;
+   const unsigned xy_off = ZOFF ? 0u : (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)XY_s;
    if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)smem != 0u) __builtin_trap();
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
     * give XCD x one contiguous tile range (schedule_tiles: equal work per XCD):
@@ -1304,7 +1262,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   if (PACKED) o[u] = ((u & 1) ? (wd >> 16) : wd) & 0xfff0u;
                   else o[u] = ((u & 1) ? (wd >> 16) : (wd & 0xffffu)) << 4;
                   xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + o[u]);
-                  double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(o[u] >> 1);
+                  double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)((o[u] >> 1) + (unsigned)ZOFF);
                   double px = pxy.x, py = pxy.y;
                   x[u] = pi.x - px; y[u] = pi.y - py; z[u] = pi.z - pz;
                   r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
@@ -1337,7 +1295,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                const unsigned e16 = excl16[(size_t)k * npad + a];
                const unsigned oe = PACKED ? (e16 & 0xfff0u) : (e16 << 4);
                const xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + oe);
-               const double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)(oe >> 1);
+               const double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)((oe >> 1) + (unsigned)ZOFF);
                const int tje = PACKED ? (SHBIT ? (int)(e16 & 7u) : (int)(e16 & 0xfu)) : (int)T_s[oe >> 4];
                double x = pi.x - pxy.x, y = pi.y - pxy.y, z = pi.z - pz;
                double r2 = x * x + y * y + z * z;
@@ -2633,7 +2591,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    {
       double expect = 4.0 / 3.0 * M_PI * gp.rlist * gp.rlist * gp.rlist * dens;
       ctx->tmpw = ((int)(expect * 1.25) + 24 + 7) & ~7;
-      if (ctx->tmpw > 768) ctx->tmpw = 768;          /* k_tile_transpose keeps TR_ROWS rows + their image in LDS */
+      if (ctx->tmpw > 768) ctx->tmpw = 768;          /* k_tile_transpose keeps a row in the registers of eight lanes: at most 24 quads each */
       ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
    }
    ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
@@ -2690,10 +2648,10 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 5 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
       HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
       {
-         size_t lds2 = (size_t)TR_ROWS * TR_RS(ctx->tmpw) * sizeof(unsigned int) + (size_t)ctx->tmpw * IMG_STRIDE * sizeof(unsigned short);
-         if (lds2 > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "lists of %d entries per bead do not fit the transpose kernel's LDS", ctx->tmpw);
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_tile_transpose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-         hipLaunchKernelGGL(k_tile_transpose, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
+         const size_t lds2 = (size_t)(TR_THREADS / 64) * ctx->tmpw * TR_S * sizeof(unsigned short);
+         auto ktr = ctx->tmpw <= 192 ? k_tile_transpose<6> : ctx->tmpw <= 384 ? k_tile_transpose<12> : k_tile_transpose<24>;
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)ktr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+         hipLaunchKernelGGL(ktr, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
       }
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventSynchronize(ctx->ev_build));
@@ -2708,6 +2666,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }
       if (ctx->h_flags[1] > 0) { ctx->maxexcl = ctx->h_flags[1] + 4; again = true; }
       if (ctx->h_flags[5] > 0) { ctx->tmpw = ((int)(ctx->h_flags[5] * 1.1) + 8 + 7) & ~7; again = true; }
+      if (ctx->tmpw > 768) SETERR(ctx, DDCMI_EUNSUPPORTED, "neighbour lists of more than 768 entries per bead (list radius %g) are not supported", gp.rlist);
       if (again) HIPCHK(ctx, hipStreamSynchronize(st));      /* the transposition still runs on buffers the next attempt may grow */
       if (!again)
       {
@@ -2719,7 +2678,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    {
       /* workgroups of k_nonbond a CU holds: its LDS image of a neighbourhood (launch_forces), at most two by registers */
       const size_t capl = (size_t)ctx->stage_cap + 2;
-      const size_t lds_nb = capl * 24 + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
+      const size_t lds_nb = (capl * 16 <= NB_ZOFF ? NB_ZOFF + capl * 8 : capl * 24) + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
       int rcs = schedule_tiles(ctx, (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_nb, 1))));
       if (rcs) return rcs;
    }
@@ -2729,6 +2688,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->pos0.ensure((size_t)std::max(n, 1))) SETERR(ctx, DDCMI_ENOMEM, "reference positions");
       HIPCHK(ctx, hipMemcpyAsync(ctx->pos0.p, ctx->pos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToDevice, st));
    }
+   if (ctx->nrebuild == 0 && getenv("DDCMI_DEBUG_SCHED")) fprintf(stderr, "ddcmi build: stage_cap %d tmpw %d maxexcl %d pack_type %d tiles %d\n", ctx->stage_cap, ctx->tmpw, ctx->maxexcl, ctx->pack_type, ctx->ntile);
    ctx->list_valid = true;
    ctx->nrebuild++;
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
@@ -2783,7 +2743,9 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       bool packed = ctx->pack_type != 0;
       const bool shbit = ctx->pack_type == 2;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
-      size_t lds = capl * 24 + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
+      /* fixed LDS layout ({x,y} at 0, z at NB_ZOFF) for neighbourhoods of up to NB_ZOFF/16 beads, which is every Martini system; else the run-time layout */
+      const bool zfix = capl * 16 <= NB_ZOFF;
+      size_t lds = (zfix ? NB_ZOFF + capl * 8 : capl * 24) + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nnb;
@@ -2792,9 +2754,10 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
-#define LAUNCH_NB(Q, P, S, NT) do { \
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
+#define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
+#define LAUNCH_NBZ(Q, P, S, NT, Z) do { \
+         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl16.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
@@ -2828,6 +2791,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       }
 #undef LAUNCH_NB2
 #undef LAUNCH_NB
+#undef LAUNCH_NBZ
       if (ctx->timing) ctx->t_launches++;          /* per force evaluation: the event pairs of both classes add up */
       /* without bonded terms the final energies are formed in the same launch */
       if (!defer_reduce)

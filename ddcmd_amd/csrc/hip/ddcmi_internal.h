@@ -39,6 +39,7 @@
 #ifndef NB_CH
 #define NB_CH 4              /* list slots gathered and tested together */
 #endif
+#define NB_ZOFF 54400        /* k_nonbond's fixed LDS layout: byte offset of the staged z array (3400 beads x 16 B of {x,y} in front of it) */
 
 /* cell grid over the local domain plus a margin of image/halo cells.
  * Cells are numbered tile-major (4x4x4 cells per tile) so that 256 consecutive

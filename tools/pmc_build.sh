@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of the list-rebuild kernels (k_tile_build, k_tile_transpose): bash tools/pmc_build.sh [bench args]
-cd $GRAFT_REPO_ROOT
+set -u
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 export TMPDIR=/tmp
 root=$PWD
 out=gpurun_out/pmc_build
