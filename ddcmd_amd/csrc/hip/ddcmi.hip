@@ -2437,7 +2437,7 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
     * and the ranges leave from pinned memory too, so this function costs no host round trip of its own */
    const int ntile = ctx->ntile;
    const int *work = ctx->h_pin[0], *stage = work ? work + ntile : nullptr;
-   const size_t cap_items = (size_t)ntile + 8 * 64 * 8 * 2 + 64;      /* every tile once + the parts the 8 tails may add */
+   const size_t cap_items = (size_t)ntile + 16 * 1024 + 64;      /* every tile once + the parts the tails may add: 8 XCD runs x 2 classes, at most 1024 items each */
    int *perm = ctx->pinned(1, cap_items + 64), *sched = perm ? perm + cap_items : nullptr;
    if (!work || !perm) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile schedule");
    for (int k = 0; k < 32; k++) sched[k] = 0;
@@ -2542,6 +2542,7 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
          }
          if (!cached) { cache[0] = n; cache[1] = best_m; cache[2] = best_k; }
          if (getenv("DDCMI_DEBUG_SCHED")) fprintf(stderr, "ddcmi sched: xcd %d tiles %d tail %d tiles x %d parts\n", x, n, best_m, best_k);
+         if ((size_t)nitems + (size_t)n + (size_t)best_m * (best_k - 1) > cap_items) { best_m = 0; best_k = 1; }      /* (cannot happen: m k <= 1024 per run) */
          out[x] = nitems;
          for (int q = 0; q < n; q++)
          {

@@ -101,7 +101,7 @@ __global__ void k_mig_classify(MigGeom mg, int nloc, int mig_cap, double4 *pos, 
       int dd = b - mg.pc[a];
       if (dd > 1) dd -= mg.P[a];
       if (dd < -1) dd += mg.P[a];
-      if (dd > 1 || dd < -1) { atomicMax(&flags[6], 1); dd = 0; }
+      if (dd > 1 || dd < -1) { atomicMax(&flags[6], 1); atomicMax(&dir_cnt[29], 1); dd = 0; }      /* [29] travels with the counts: every rank learns of it in the same round */
       d[a] = dd;
    }
    int code = (d[0] + 1) + 3 * (d[1] + 1) + 9 * (d[2] + 1);
@@ -394,39 +394,101 @@ extern "C" int ddcmi_plan_halo_layout(int px, int py, int pz, int rank, int pbc,
 /* Every rank learns every rank's 27 per-direction counts (+ the capacity its segments had, slot 27) with ONE all-gather
  * straight from the device counters (26 four-byte point-to-point messages took 77 us; this is rebuild-time control
  * traffic) and looks up what its neighbours send to it.  One host synchronisation per round.
+ * The block of a rank is 32 ints: slot 28 carries the rank's pending error code (local_err: an allocation or a check that
+ * failed on the way to this round), slot 29 the device's "a bead moved further than one domain" flag -- so a hard error
+ * of ONE rank ends the rebuild on EVERY rank in the same round, instead of leaving the others inside the next exchange.
  * RCCL: the all-gather reads dir_cnt on the device; host transport: the rendezvous' all-gather after the download. */
-static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over, int *my_max, bool with_flags)
+#define MG_BLK 32
+static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over, int *my_max, bool with_flags, int local_err)
 {
    hipStream_t st = ctx->stream;
    const int nr = std::max(ctx->nranks, 1);
-   int *h = ctx->pinned(2, 32 + 55 * (size_t)nr);
+   const std::string local_msg = ctx->err;
+   int *h = ctx->pinned(2, 64 + (MG_BLK + 27) * (size_t)nr);
    if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
-   int *all = h + 32, *packed = h + 32 + 28 * (size_t)nr;
+   int *all = h + 64, *packed = h + 64 + MG_BLK * (size_t)nr;
    if (with_flags) HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+   if (ctx->dir_cnt.cap < MG_BLK && ctx->dir_cnt.ensure(MG_BLK)) SETERR(ctx, DDCMI_ENOMEM, "direction counters");
+   if (local_err)
+   {
+      /* this rank takes part with empty segments and its error code */
+      memset(h + 32, 0, MG_BLK * sizeof(int));
+      h[32 + 28] = local_err;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->dir_cnt.p, h + 32, MG_BLK * sizeof(int), hipMemcpyHostToDevice, st));
+   }
    if (ctx->hcomm)
    {
-      HIPCHK(ctx, hipMemcpyAsync(h, ctx->dir_cnt.p, 28 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipMemcpyAsync(h, ctx->dir_cnt.p, MG_BLK * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
-      HOSTCHK(ctx, ddcmi_rdzv_allgather(ctx->hcomm, h, all, 28 * sizeof(int)));
+      HOSTCHK(ctx, ddcmi_rdzv_allgather(ctx->hcomm, h, all, MG_BLK * sizeof(int)));
    }
    else
    {
-      ENSURE(ctx, ctx->cnt_xchg, 32 + 28 * (size_t)nr);
-      NCCLCHK2(ctx, ncclAllGather(ctx->dir_cnt.p, ctx->cnt_xchg.p + 32, 28, ncclInt, (ncclComm_t)ctx->comm, st));
-      HIPCHK(ctx, hipMemcpyAsync(all, ctx->cnt_xchg.p + 32, 28 * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
+      ENSURE(ctx, ctx->cnt_xchg, 32 + MG_BLK * (size_t)nr);
+      NCCLCHK2(ctx, ncclAllGather(ctx->dir_cnt.p, ctx->cnt_xchg.p + 32, MG_BLK, ncclInt, (ncclComm_t)ctx->comm, st));
+      HIPCHK(ctx, hipMemcpyAsync(all, ctx->cnt_xchg.p + 32, MG_BLK * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
    }
    *any_over = false;
    for (int r = 0; r < nr; r++)
    {
       int mx = 0;
-      for (int c = 0; c < 27; c++) { mx = std::max(mx, all[28 * r + c]); packed[27 * r + c] = all[28 * r + c]; }
-      if (mx > all[28 * r + 27]) *any_over = true;
+      for (int c = 0; c < 27; c++) { mx = std::max(mx, all[MG_BLK * r + c]); packed[27 * r + c] = all[MG_BLK * r + c]; }
+      if (mx > all[MG_BLK * r + 27]) *any_over = true;
       if (r == ctx->rank) *my_max = mx;
    }
-   for (int c = 0; c < 27; c++) scnt[c] = all[28 * (size_t)ctx->rank + c];
+   /* errors first, the lowest rank's: every rank returns from the same round */
+   for (int r = 0; r < nr; r++)
+   {
+      if (all[MG_BLK * r + 28])
+      {
+         if (r == ctx->rank) { ctx->err = local_msg; return all[MG_BLK * r + 28]; }
+         SETERR(ctx, DDCMI_ECOMM, "rank %d failed during the list rebuild (error %d): its own message says why", r, all[MG_BLK * r + 28]);
+      }
+      if (all[MG_BLK * r + 29]) SETERR(ctx, DDCMI_EINVAL, "a bead moved further than one domain between rebuilds (rank %d)", r);
+   }
+   for (int c = 0; c < 27; c++) scnt[c] = all[MG_BLK * (size_t)ctx->rank + c];
    plan_recv_counts(ctx->dir_dest, ctx->rank, ctx->loopback, packed, rcnt);
    return DDCMI_OK;
+}
+/* the ranks agree on the outcome of a phase that has no count round behind it: max of the error codes (one small collective) */
+static int mg_agree(ddcmi_ctx *ctx, int local_rc)
+{
+   if ((ctx->nranks == 1 && !ctx->loopback) || !mg_transport(ctx)) return local_rc;
+   const std::string local_msg = ctx->err;
+   hipStream_t st = ctx->stream;
+   int worst = local_rc < 0 ? -local_rc : local_rc;
+   if (ctx->hcomm)
+   {
+      double v = (double)worst;
+      HOSTCHK(ctx, ddcmi_rdzv_allreduce_f64(ctx->hcomm, &v, 1, 1));
+      worst = (int)v;
+   }
+   else
+   {
+      int *h = ctx->pinned(2, 64);
+      if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
+      ENSURE(ctx, ctx->cnt_xchg, 32);
+      h[0] = worst;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, h, sizeof(int), hipMemcpyHostToDevice, st));
+      NCCLCHK2(ctx, ncclAllReduce(ctx->cnt_xchg.p, ctx->cnt_xchg.p + 1, 1, ncclInt, ncclMax, (ncclComm_t)ctx->comm, st));
+      HIPCHK(ctx, hipMemcpyAsync(h + 1, ctx->cnt_xchg.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      worst = h[1];
+   }
+   if (local_rc) { ctx->err = local_msg; return local_rc; }
+   if (worst) SETERR(ctx, DDCMI_ECOMM, "another rank failed during the list rebuild (error %d): its own message says why", worst);
+   return DDCMI_OK;
+}
+/* a rank that cannot go on at a point where its peers already wait for its data leaves the job: the host transport's
+ * streams are closed (the peers' receives fail at once with "peer closed"), an RCCL communicator is aborted (peers inside
+ * a kernel are released when the launcher tears the job down on this rank's non-zero exit) */
+static int mg_fatal(ddcmi_ctx *ctx, int code, const char *msg)
+{
+   if (msg) ctx->err = msg;
+   if (ctx->hcomm) ddcmi_rdzv_abort(ctx->hcomm);
+   else if (ctx->comm) { (void)ncclCommAbort((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+   return code;
 }
 /* host transport: device segments -> host staging -> TCP streams -> host staging -> device segments.
  * nm* messages; offsets and counts in doubles */
@@ -564,7 +626,7 @@ static int mg_phase1_launch(ddcmi_ctx *ctx)
    ENSURE(ctx, ctx->mig_out, (size_t)27 * ctx->mig_cap * 10);
    ENSURE(ctx, ctx->dir_cnt, 32);
    ENSURE(ctx, ctx->keep, (size_t)n + 1);
-   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28).add(ctx->d_flags, 8));
+   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 32).add(ctx->d_flags, 8));
    MigGeom mg;
    for (int a = 0; a < 3; a++) { mg.L[a] = ctx->h[4 * a]; mg.P[a] = ctx->pgrid[a]; mg.W[a] = mg.L[a] / mg.P[a]; mg.pc[a] = ctx->pcoord[a]; }
    mg.pbc = ctx->pbc;
@@ -636,7 +698,7 @@ static int mg_halo_select_launch(ddcmi_ctx *ctx)
    const int n = ctx->nloc;
    if (ctx->hs_cap == 0) ctx->hs_cap = std::max(4096, n / 4);
    ENSURE(ctx, ctx->hs_idx, (size_t)27 * ctx->hs_cap);
-   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28));
+   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 32));
    if (n > 0)
       hipLaunchKernelGGL(k_halo_select, dim3(cdiv(n, 256)), dim3(256), 0, st, ctx->gp, mg_dirtab(ctx), n, ctx->hs_cap, ctx->pos.p, ctx->dir_cnt.p, ctx->hs_idx.p);
    return DDCMI_OK;
@@ -718,36 +780,43 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
    int rc;
    /* the per-direction counts never wait on the host between the kernel that counts and the exchange: the all-gather reads the
     * device counters, and ONE synchronisation brings every rank's counts (and capacities: a rank whose segments overflowed makes
-    * all ranks repeat the round together) to the host */
+    * all ranks repeat the round together) to the host.  A rank on which something failed on the way still joins the round, with
+    * its error code in its block, and every rank returns from the rebuild together (mg_counts_round, mg_agree): none is left
+    * waiting inside the next exchange for a peer that has gone. */
    for (;;)
    {
       bool over = false;
       int mx = 0;
-      if ((rc = mg_phase1_launch(ctx))) return rc;
-      if ((rc = mg_counts_round(ctx, ctx->mig_scnt, ctx->mig_rcnt, &over, &mx, true))) return rc;
-      if (ctx->h_flags[6]) SETERR(ctx, DDCMI_EINVAL, "a bead moved further than one domain between rebuilds");
+      const int lrc = mg_phase1_launch(ctx);
+      if ((rc = mg_counts_round(ctx, ctx->mig_scnt, ctx->mig_rcnt, &over, &mx, true, lrc))) return rc;
       if (!over) break;
       if (mx > ctx->mig_cap) ctx->mig_cap = mx + mx / 4 + 64;     /* positions were only wrapped (idempotent): simply redo */
    }
+   int lrc = DDCMI_OK;
    {
       int roff[27], acc = 0;
       for (int c = 0; c < 27; c++) { roff[c] = acc; acc += ctx->mig_rcnt[c]; }
-      ENSURE(ctx, ctx->mig_in, (size_t)acc * 10 + 16);
+      /* (between a count round and its data exchange only an allocation of a few MB can fail: that rank leaves the job, mg_fatal) */
+      if (ctx->mig_in.ensure((size_t)acc * 10 + 16)) return mg_fatal(ctx, DDCMI_ENOMEM, "device allocation for the arriving beads failed");
       if ((rc = mg_xchg_data(ctx, ctx->mig_out.p, nullptr, ctx->mig_scnt, ctx->mig_cap, ctx->mig_in.p, roff, ctx->mig_rcnt, 10))) return rc;
    }
-   if ((rc = mg_phase2_migrate_in(ctx))) return rc;
+   lrc = mg_phase2_migrate_in(ctx);
    for (;;)
    {
       bool over = false;
       int mx = 0;
-      if ((rc = mg_halo_select_launch(ctx))) return rc;
-      if ((rc = mg_counts_round(ctx, ctx->hs_cnt, ctx->hr_cnt, &over, &mx, false))) return rc;
+      if (!lrc) lrc = mg_halo_select_launch(ctx);
+      if ((rc = mg_counts_round(ctx, ctx->hs_cnt, ctx->hr_cnt, &over, &mx, false, lrc))) return rc;
       if (!over) break;
       if (mx > ctx->hs_cap) ctx->hs_cap = mx + mx / 4 + 64;
    }
-   if ((rc = mg_phase3_pack(ctx, 5))) return rc;
+   if ((lrc = mg_phase3_pack(ctx, 5))) return mg_fatal(ctx, lrc, nullptr);
    if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv5.p, 5, ctx->stream))) return rc;
-   if ((rc = mg_phase4_finish(ctx))) return rc;
+   /* the list build, the bonded terms' and the constraint groups' partners (beads that are not numbers, a partner beyond the
+    * halo ...): local checks, agreed on before anybody enters the next collective -- the one collective of a rebuild that
+    * exists for errors only (one small all-reduce: 2 us per step at a 20-step period) */
+   lrc = mg_phase4_finish(ctx);
+   if ((rc = mg_agree(ctx, lrc))) return rc;
    /* which molecules have atoms on several ranks, and where is their anchor? (one all-reduce of 4 doubles per multi-bead molecule) */
    if (ctx->mol_gid && ctx->nmol_multi > 0 && (rc = mg_allreduce_device(ctx, ctx->mol_info.p, 4 * (size_t)ctx->nmol_multi))) return rc;
    return ddcmi_mol_split_finish(ctx);

@@ -165,6 +165,12 @@ const char *ddcmi_rdzv_last_error(const ddcmi_rdzv *h) { return h ? h->err : g_r
 int ddcmi_rdzv_rank(const ddcmi_rdzv *h) { return h ? h->rank : -1; }
 int ddcmi_rdzv_world(const ddcmi_rdzv *h) { return h ? h->world : 0; }
 
+/* leave the job at once: every stream is shut down, so the peers' pending and next transfers fail instead of waiting */
+void ddcmi_rdzv_abort(ddcmi_rdzv *h)
+{
+   if (!h || !h->fd) return;
+   for (int r = 0; r < h->world; r++) if (h->fd[r] >= 0) { (void)shutdown(h->fd[r], SHUT_RDWR); close(h->fd[r]); h->fd[r] = -1; }
+}
 void ddcmi_rdzv_destroy(ddcmi_rdzv *h)
 {
    if (!h) return;
@@ -196,17 +202,34 @@ int ddcmi_rdzv_create(ddcmi_rdzv **out, int rank, int world, const char *addr, i
    const int use_file = (port <= 0) || (port_file && *port_file);
    uint32_t ip0 = htonl(INADDR_LOOPBACK);
    if (addr && *addr) { struct in_addr ia; if (inet_pton(AF_INET, addr, &ia) == 1) ip0 = ia.s_addr; }
+   if (use_file && ip0 != htonl(INADDR_LOOPBACK))
+   {
+      /* the port travels through a file, which the ranks of ONE node share: an address this host cannot bind is another node's */
+      int pfd = listen_on(addr, 0, NULL);
+      if (pfd < 0 && errno == EADDRNOTAVAIL)
+      {
+         fail(NULL, "rank %d: MASTER_ADDR %s is not an address of this host, and the rendezvous port travels through a file (%s) that only the ranks of one node see: set DDCMI_RDZV_PORT to a free port for launches over several nodes",
+              rank, addr, port_file && *port_file ? port_file : "?");
+         goto done;
+      }
+      if (pfd >= 0) close(pfd);
+   }
    if (rank == 0)
    {
       int myport = 0;
-      lfd = listen_on(NULL, use_file ? 0 : port, &myport);
+      /* on the address the ranks were given (loopback for 127.0.0.1), not on every interface: nobody else reaches the port */
+      lfd = listen_on(addr && *addr ? addr : "127.0.0.1", use_file ? 0 : port, &myport);
+      if (lfd < 0) lfd = listen_on(NULL, use_file ? 0 : port, &myport);      /* MASTER_ADDR is a name or not an address of this host: any interface */
       if (lfd < 0) { fail(NULL, "rank 0: cannot listen on port %d: %s", port, strerror(errno)); goto done; }
       if (use_file)
       {
          char tmp[1100];
          snprintf(tmp, sizeof(tmp), "%s.%d.tmp", port_file, (int)getpid());
-         FILE *f = fopen(tmp, "w");
-         if (!f) { fail(NULL, "rank 0: cannot write %s: %s", tmp, strerror(errno)); goto done; }
+         /* a fresh file of our own: never through a link somebody planted under the predictable name */
+         (void)unlink(tmp);
+         int tfd = open(tmp, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+         FILE *f = tfd >= 0 ? fdopen(tfd, "w") : NULL;
+         if (!f) { if (tfd >= 0) close(tfd); fail(NULL, "rank 0: cannot write %s: %s", tmp, strerror(errno)); goto done; }
          fprintf(f, "%d %d\n", myport, (int)getpid());
          fclose(f);
          if (rename(tmp, port_file) != 0) { fail(NULL, "rank 0: rename to %s failed: %s", port_file, strerror(errno)); unlink(tmp); goto done; }
@@ -217,7 +240,11 @@ int ddcmi_rdzv_create(ddcmi_rdzv **out, int rank, int world, const char *addr, i
          int fd = accept_one(lfd, &pip, deadline);
          if (fd < 0) { fail(NULL, "rank 0: only %d of %d ranks arrived within %.0f s", k, world, h->timeout_s); goto done; }
          uint32_t hello[4];
-         if (xfer(fd, hello, sizeof(hello), 0, deadline) || hello[0] != RDZV_MAGIC || (int)hello[2] != world || hello[1] == 0 || (int)hello[1] >= world || h->fd[hello[1]] >= 0)
+         /* the peer's numbers are compared as the unsigned values they index with; a connection that stays silent
+          * for two seconds is dropped instead of holding the accept loop up to the global deadline */
+         const double hello_by = now_s() + 2.0 < deadline ? now_s() + 2.0 : deadline;
+         if (xfer(fd, hello, sizeof(hello), 0, hello_by) || hello[0] != RDZV_MAGIC || hello[2] != (uint32_t)world || hello[1] == 0 || hello[1] >= (uint32_t)world ||
+             hello[3] == 0 || hello[3] > 65535u || h->fd[hello[1]] >= 0)
          { close(fd); k--; if (now_s() > deadline) { fail(NULL, "rank 0: rendezvous timed out"); goto done; } continue; }      /* a stray connection: ignore it */
          h->fd[hello[1]] = fd; ip[hello[1]] = pip; lport[hello[1]] = (int)hello[3];
       }
@@ -237,8 +264,13 @@ int ddcmi_rdzv_create(ddcmi_rdzv **out, int rank, int world, const char *addr, i
          if (use_file)
          {
             p0 = 0;
-            FILE *f = fopen(port_file, "r");
-            if (f) { int pid = 0; if (fscanf(f, "%d %d", &p0, &pid) < 1) p0 = 0; fclose(f); }
+            /* the file must be a plain file of this user: a planted one would send the ranks (and the RCCL id) elsewhere */
+            int pfd = open(port_file, O_RDONLY | O_NOFOLLOW);
+            struct stat stf;
+            FILE *f = NULL;
+            if (pfd >= 0 && fstat(pfd, &stf) == 0 && S_ISREG(stf.st_mode) && stf.st_uid == geteuid()) f = fdopen(pfd, "r");
+            else if (pfd >= 0) close(pfd);
+            if (f) { int pid = 0; if (fscanf(f, "%d %d", &p0, &pid) < 1 || p0 > 65535) p0 = 0; fclose(f); }
          }
          if (p0 > 0)
          {
@@ -269,7 +301,9 @@ int ddcmi_rdzv_create(ddcmi_rdzv **out, int rank, int world, const char *addr, i
          int fd = accept_one(lfd, NULL, deadline);
          if (fd < 0) { fail(NULL, "rank %d: ranks above did not connect", rank); goto done; }
          uint32_t hello[2];
-         if (xfer(fd, hello, sizeof(hello), 0, deadline) || hello[0] != RDZV_MAGIC || (int)hello[1] <= rank || (int)hello[1] >= world || h->fd[hello[1]] >= 0) { close(fd); k--; continue; }
+         const double hello_by = now_s() + 2.0 < deadline ? now_s() + 2.0 : deadline;
+         if (xfer(fd, hello, sizeof(hello), 0, hello_by) || hello[0] != RDZV_MAGIC || hello[1] <= (uint32_t)rank || hello[1] >= (uint32_t)world || h->fd[hello[1]] >= 0)
+         { close(fd); k--; if (now_s() > deadline) { fail(NULL, "rank %d: ranks above did not connect", rank); goto done; } continue; }
          h->fd[hello[1]] = fd;
       }
    }

@@ -235,6 +235,9 @@ int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n);
 typedef struct ddcmi_rdzv ddcmi_rdzv;
 int ddcmi_rdzv_create(ddcmi_rdzv **out, int rank, int world, const char *addr, int port, const char *port_file, double timeout_s);
 void ddcmi_rdzv_destroy(ddcmi_rdzv *h);
+/* leave the job at once (a rank that failed where its peers already wait for it): every stream is shut down, the peers'
+ * transfers fail with "peer closed" instead of waiting out their timeout.  The handle stays valid for ddcmi_rdzv_destroy. */
+void ddcmi_rdzv_abort(ddcmi_rdzv *h);
 const char *ddcmi_rdzv_last_error(const ddcmi_rdzv *h);      /* h may be NULL: last create error */
 int ddcmi_rdzv_rank(const ddcmi_rdzv *h);
 int ddcmi_rdzv_world(const ddcmi_rdzv *h);

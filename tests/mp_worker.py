@@ -19,7 +19,7 @@ def main():
     rdzv = Rendezvous.from_env(timeout=120.0)
     rank, world = rdzv.rank, rdzv.world
     cons = False
-    if workload == "water":
+    if workload in ("water", "water_fault"):
         s = ddcmd_amd.make_water_setup(12)
     else:
         from ddcmd_amd.deck import load_deck, units_convert
@@ -34,6 +34,11 @@ def main():
             s.npt_T, s.npt_P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
             s.npt_beta, s.npt_tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
     owner = domain_of(s, grid)
+    if workload == "water_fault":
+        # one bead of the LAST rank is not a number: that rank's list build refuses the state, and every rank must
+        # come back from the rebuild with an error instead of waiting for the one that has gone
+        s.rx = np.array(s.rx, dtype=float)
+        s.rx[np.flatnonzero(owner == world - 1)[0]] = float("nan")
     m = MartiniRank(s, np.flatnonzero(owner == rank), device=0, constraints=cons)
     _declare_domains(m.lib)
     if os.environ.get("DDCMI_TRANSPORT", "host") == "host":
@@ -46,6 +51,14 @@ def main():
     m.upload_local()
     n0 = m.n
     rec = {}
+    if workload == "water_fault":
+        from ddcmd_amd.martini import DdcmiError
+        try:
+            m.eval_forces()
+        except DdcmiError as ex:
+            sys.stderr.write("FAULT rank %d: %s\n" % (rank, ex))
+            sys.exit(3)
+        sys.exit(0)
     e, vir = m.eval_forces()
     p = m.download_particles()
     rec.update(gid0=p["gid"], f0=np.stack(p["f"]), e0=np.array([e[k] for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total")]), vir0=vir)

@@ -43,6 +43,34 @@ def _run_ranks(workload, grid, nsteps, block):
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
 
 
+def test_a_failing_rank_ends_the_rebuild_on_every_rank():
+    """a hard error of one rank inside the rebuild (here: a bead that is not a number, found by the last rank's
+    list build) used to leave the other ranks inside the next exchange until the transport's 300 s timeout.  Every rank
+    must return an error from the same rebuild, at once, and say whose error it is."""
+    import time
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        t0 = time.time()
+        for rank in range(world):
+            env = dict(os.environ)
+            env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1",
+                        "DDCMI_RDZV_FILE": os.path.join(d, "port"), "DDCMI_TRANSPORT": "host"})
+            env.pop("DDCMI_RCCL_LOOPBACK", None)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), "water_fault", "2x1x1", d, "0", "1"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=120) for p in procs]
+        assert time.time() - t0 < 100, "the ranks waited for each other"
+        assert [p.returncode for p in procs] == [3, 3], [(p.returncode, o[1][-800:]) for p, o in zip(procs, outs)]
+        errs = [o[1] for o in outs]
+        # the rank that holds the bead (migration may have handed it to the neighbour first) says what is wrong, its peer is told
+        # whose error it is -- or both learn of a bead "further than one domain" away in the same count round
+        own = [("non-finite" in e) for e in errs]
+        told = [("failed during the list rebuild" in e) for e in errs]
+        both = [("further than one domain" in e) for e in errs]
+        assert all(both) or (any(own) and any(told) and all(a or b for a, b in zip(own, told))), errs
+
+
 def _merge(recs, key_gid, key):
     gid = np.concatenate([r[key_gid] for r in recs])
     order = np.argsort(gid, kind="stable")
