@@ -10,6 +10,11 @@ Workload at N=1: BASELINE.json's headline config, the 4.0M-bead Martini water
 box (FCC n=100 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM;
 200 untimed steps in front of the warm-up melt the lattice start (50 K) into the
 liquid (~307 K), so the timed steps see production list lengths.
+The timed region is max(--steps, 60) steps rounded up to windows of 20, each window between a
+barrier + stream drain on both sides; `ms_per_step` and `value` come from the MEDIAN window
+(`window_ms` lists them all).  At N=1 the line also carries `also`: the other single-GPU configs of
+BASELINE.json (1 M-bead water, the 2 M-bead lipid bilayer) and one rank's brick of the 8-GPU run
+through the RCCL loopback, each timed the same way.
 Prints ONE JSON line (rank 0).  `roofline` prices the nonbonded kernel with the
 ALGORITHMIC bytes of SURVEY 8(d): (36 + 24 + 4*L) B per atom-step, L = stored
 full-list entries per atom, over the HIP-event time of that kernel measured on
@@ -28,7 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-DT_FS = 20.0
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64: half of the guide's 157.3 TFLOP/s FP32 vector peak (AMD's MI355X figure)
+WINDOW = 20                    # timed steps come in windows of 20: one list rebuild each for water (two for the lipid deck's 10-step period)
+MIN_TIMED_STEPS = 60           # at least three windows whatever --steps says (a 20-step region is one rebuild's luck)
 
 
 def cpu_baseline(n_lattice, seconds_budget=18.0):
@@ -104,14 +111,176 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
+def build_setup(workload, n, reps):
+    import ddcmd_amd
+    if workload == "water":
+        s = ddcmd_amd.make_water_setup(n)
+        return s, "martini_water_%dk_beads" % (s.natoms // 1000), "fcc", n
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import replicate_setup
+    r3 = tuple(int(x) for x in reps.split(","))
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+    # 310 K restart relaxed by tests/golden/make_lipid_relaxed.py, Berendsen group (Teq 310 K, tau 1 ps)
+    s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), r3)
+    return s, "martini_lipid_bilayer_%dk_beads" % (s.natoms // 1000), "deck tiled %s" % reps, None
+
+
+def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank, rdzv, transport, loopback):
+    """one workload on this launch's ranks: equilibration, warm-up, then the timed windows.  Returns the pieces of the JSON line."""
+    import numpy as np
+    import ddcmd_amd
+    from ddcmd_amd.martini import MartiniHIP, MartiniRank, domain_of
+    s, wname, lattice, lattice_n = build_setup(workload, n, reps)
+    dt_fs = float(ddcmd_amd.units_convert(s.dt, None, "fs"))
+    grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+    if grid is None:
+        raise SystemExit("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)")
+    if world == 1 and loopback:
+        os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
+        m = MartiniRank(s, np.arange(s.natoms), device=local_rank)
+        buf = ctypes.create_string_buffer(128)
+        assert m.lib.ddcmi_comm_unique_id(buf) == 0
+        m.comm_init(0, 1, buf.raw, (1, 1, 1))
+        m.upload_local()
+    elif world == 1:
+        os.environ.pop("DDCMI_RCCL_LOOPBACK", None)
+        m = MartiniHIP(s, device=local_rank)
+    else:
+        # spatial decomposition: this rank uploads the beads of its brick; halo exchange
+        # and migration run inside libddcmi over RCCL point-to-point (include/ddcmi.h)
+        owner = domain_of(s, grid)
+        m = MartiniRank(s, np.flatnonzero(owner == rank), device=local_rank)
+        if transport == "host":
+            m.comm_init_host(rdzv, grid)
+        else:
+            buf = ctypes.create_string_buffer(128)
+            if rank == 0:
+                assert m.lib.ddcmi_comm_unique_id(buf) == 0
+            m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)      # MPI_Bcast of the id in ddcMD
+        m.upload_local()
+    m.eval_forces()                       # firstEnergyCall (masters.c:579)
+    # RCCL prints a version banner through C stdio at communicator creation; flush it now so that the JSON
+    # line below is the last line of stdout
+    ctypes.CDLL(None).fflush(None)
+    thermostat = any(int(t) == 1 for t in np.asarray(s.group_type).ravel())
+    if thermostat:
+        m.group_temperatures()            # the temperature Berendsen scales with (published by eval_energyInfo in the reference)
+    if equil < 0:
+        equil = 200 if workload == "water" else 0
+    done = 0
+    while done < equil:                   # (in rebuild periods, so that a Berendsen group sees its temperature as in a production run)
+        k = min(20, equil - done)
+        m.step(k)
+        done += k
+        if thermostat:
+            m.group_temperatures()
+    m.step(warmup)
+    if thermostat:
+        m.group_temperatures()
+    m.sync()
+
+    def barrier():
+        m.sync()                          # this rank's stream is drained ...
+        if rdzv is not None:
+            rdzv.barrier()                # ... and so is everybody else's
+
+    nwin = max(1, -(-max(steps, MIN_TIMED_STEPS) // WINDOW))
+    m.timing(True)
+    reb0 = m.list_stats()["rebuilds"]
+    wins = []
+    for _ in range(nwin):
+        barrier()
+        t0 = time.perf_counter()
+        m.step(WINDOW)
+        barrier()
+        el = time.perf_counter() - t0
+        if rdzv is not None:
+            el = float(rdzv.allreduce([el], "max")[0])       # the slowest rank's time
+        wins.append(el)
+    launches, kernel_ms = m.timing_read()
+    m.timing(False)
+    e, vir, rk, tion = m.energies()
+    st = m.list_stats()
+    nlocal = int(m.lib.ddcmi_nlocal(m.ctx))
+    epot, ekin = e["total"], rk
+    comm = None
+    if rdzv is not None or loopback:
+        cs = m.comm_stats()
+        comm = {"transport": cs["transport"], "rccl_version": cs["rccl_version"], "halo_beads_sent_per_step_rank0": cs["send_beads"],
+                "halo_messages_per_step_rank0": cs["send_msgs"]}
+    if rdzv is not None:
+        tot = m.allreduce([epot, ekin, float(nlocal), float(cs["send_beads"])])      # energyInfo.c allreduce()
+        epot, ekin = float(tot[0]), float(tot[1])
+        assert int(round(tot[2])) == s.natoms, "beads lost in migration"
+        per_rank = rdzv.allgather(np.array([nlocal, cs["send_beads"], cs["send_msgs"]], dtype=np.int64))
+        comm.update({"ranks_met": int(rdzv.allreduce([1.0])[0]), "beads_per_rank": [int(x) for x in per_rank[:, 0]],
+                     "halo_beads_sent_per_step": [int(x) for x in per_rank[:, 1]], "peers_per_rank": [int(x) for x in per_rank[:, 2]],
+                     "halo_bytes_per_step_all_ranks": int(round(tot[3])) * 24})
+    med = sorted(wins)[len(wins) // 2]
+    ms_per_step = med * 1e3 / WINDOW
+    L = st["entries"] / float(max(nlocal, 1))
+    bytes_per_atom = 36.0 + 24.0 + 4.0 * L
+    t_kernel = kernel_ms * 1e-3 / max(1, launches)
+    achieved = bytes_per_atom * nlocal / t_kernel / 1e9
+    # the second, honest bound (SURVEY 8d): FP64 vector work of the pair kernel, ~45 flop per in-cutoff pair visit + ~10 per list entry
+    # that fails the distance test; in-cutoff visits per bead from the density (4/3 pi rcut^3 rho: the full list visits a pair from both sides)
+    rho = s.natoms / float(s.volume)
+    n_in = 4.0 / 3.0 * 3.141592653589793 * float(s.rmax) ** 3 * rho
+    flops = (45.0 * n_in + 10.0 * max(L - n_in, 0.0)) * nlocal
+    # HBM bytes of the nonbonded kernel from the PMC passes committed under profiles/: quoted only when the file
+    # was collected on this workload AND on these device sources (kernel_src_id), else null
+    traffic = None
+    try:
+        if world == 1 and not loopback:
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if not fn.endswith("traffic.json"):
+                    continue
+                t = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if t.get("workload") == wname and t.get("kernel_src_id") == kernel_source_id():
+                    traffic = float(t["traffic_bytes_per_launch"])
+                    break
+    except Exception:
+        traffic = None
+    res = {
+        "value": s.natoms / (med / WINDOW), "ms_per_step": ms_per_step, "ms_per_step_mean": sum(wins) * 1e3 / (len(wins) * WINDOW),
+        "steps_timed": nwin * WINDOW, "window_steps": WINDOW, "window_ms": [round(w * 1e3, 4) for w in wins],
+        "ns_per_day": (WINDOW / med) * dt_fs * 1e-6 * 86400.0,
+        "config": {"workload": wname, "beads_total": s.natoms, "beads_rank0": nlocal,
+                   "lattice": lattice, "lattice_n": lattice_n,
+                   "stands_for": ("BASELINE configs[3] '4M-bead Martini water' (SURVEY 8d: 4 096 000 on a simple-cubic start that explodes at 20 fs; "
+                                  "FCC 4 n^3 at the same density, n = 100)" if wname == "martini_water_4000k_beads" else None),
+                   "rcut_A": float(ddcmd_amd.units_convert(s.rmax, None, "Angstrom")), "skin_A": float(ddcmd_amd.units_convert(s.deltaR, None, "Angstrom")),
+                   "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
+                   "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
+                   "energy_virial_every_step": True, "equilibration_steps_untimed": equil,
+                   "parallelism": ("spatial decomposition %dx%dx%d, %s (control plane: libddcmi TCP rendezvous, no torch)"
+                                   % (grid + ("RCCL p2p halo" if transport != "host" else "host-staged TCP halo",))) if world > 1
+                                  else ("single GPU, images through RCCL loopback" if loopback else "single GPU"),
+                   "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
+        "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "hbm_frac_measured": (traffic / t_kernel / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "fp64_valu_frac": flops / t_kernel / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     "fp64_valu_note": "(45 flop x %.1f in-cutoff pair visits + 10 x %.1f rejected entries) per bead over %.1f TFLOP/s" % (n_in, max(L - n_in, 0.0), FP64_VALU_PEAK_TFLOPS),
+                     "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches,
+                     "note": "rank 0's kernel on its own beads" if world > 1 else "whole box"},
+        "check": {"epot": epot, "ekin": ekin},
+    }
+    if comm:
+        res["comm"] = comm
+    m.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--lattice", dest="n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 64 -> 1.05M, 25 -> 62.5k)")
+    ap.add_argument("--lattice", dest="n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 101 -> 4.12M >= SURVEY's 4.096M, 64 -> 1.05M, 25 -> 62.5k)")
     ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N=1: only the headline workload, not the other single-GPU configs")
     ap.add_argument("--workload", choices=("water", "lipid"), default="water",
                     help="water: the headline Martini water box; lipid: tests/golden/lipid_deck (DPPC-style bilayer patch in water, "
                          "all bonded term kinds, charges, Berendsen) tiled --reps times")
@@ -136,8 +305,13 @@ def main():
     # path (halo exchange, migration, count all-gathers, energy all-reduce) over libddcmi's RCCL communicator.
     rdzv = None
     if world > 1:
-        from ddcmd_amd.martini import Rendezvous
-        rdzv = Rendezvous.from_env()
+        from ddcmd_amd.martini import Rendezvous, DdcmiError
+        try:
+            # a rank that never arrives ends the launch with a message and a non-zero exit after two minutes: no hang, no re-exec
+            rdzv = Rendezvous.from_env(timeout=float(os.environ.get("DDCMI_RDZV_TIMEOUT", "120")))
+        except DdcmiError as ex:
+            sys.stderr.write("bench.py rank %d of %d: rendezvous failed: %s\n" % (rank, world, ex))
+            sys.exit(2)
     if args.check_runtime:
         # the launcher and the runtime binding, without touching a device
         import ddcmd_amd
@@ -151,137 +325,33 @@ def main():
             rdzv.close()
         return
 
-    import numpy as np
-    import ddcmd_amd
-    from ddcmd_amd.martini import MartiniHIP, MartiniRank, domain_of
-    if args.workload == "water":
-        s = ddcmd_amd.make_water_setup(args.n)
-        wname = "martini_water_%dk_beads" % (s.natoms // 1000)
-    else:
-        from ddcmd_amd.deck import load_deck
-        from ddcmd_amd.synth import replicate_setup
-        reps = tuple(int(x) for x in args.reps.split(","))
-        deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
-        # 310 K restart relaxed by tests/golden/make_lipid_relaxed.py, Berendsen group (Teq 310 K, tau 1 ps)
-        s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), reps)
-        wname = "martini_lipid_bilayer_%dk_beads" % (s.natoms // 1000)
-    dt_fs = float(ddcmd_amd.units_convert(s.dt, None, "fs"))
-    grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
-    if grid is None:
-        raise SystemExit("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)")
-    if world == 1 and args.rccl_loopback:
-        os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
-        m = MartiniRank(s, np.arange(s.natoms), device=local_rank)
-        buf = ctypes.create_string_buffer(128)
-        assert m.lib.ddcmi_comm_unique_id(buf) == 0
-        m.comm_init(0, 1, buf.raw, (1, 1, 1))
-        m.upload_local()
-    elif world == 1:
-        m = MartiniHIP(s, device=local_rank)
-    else:
-        # spatial decomposition: this rank uploads the beads of its brick; halo exchange
-        # and migration run inside libddcmi over RCCL point-to-point (include/ddcmi.h)
-        owner = domain_of(s, grid)
-        m = MartiniRank(s, np.flatnonzero(owner == rank), device=local_rank)
-        if transport == "host":
-            m.comm_init_host(rdzv, grid)
-        else:
-            buf = ctypes.create_string_buffer(128)
-            if rank == 0:
-                assert m.lib.ddcmi_comm_unique_id(buf) == 0
-            m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)      # MPI_Bcast of the id in ddcMD
-        m.upload_local()
-    nlocal0 = m.n
-    m.eval_forces()                       # firstEnergyCall (masters.c:579)
-    # RCCL prints a version banner through C stdio at communicator creation; flush it now so that the JSON
-    # line below is the last line of stdout
-    ctypes.CDLL(None).fflush(None)
-    thermostat = any(int(t) == 1 for t in np.asarray(s.group_type).ravel())
-    if thermostat:
-        m.group_temperatures()            # the temperature Berendsen scales with (published by eval_energyInfo in the reference)
-    equil = args.equil if args.equil >= 0 else (200 if args.workload == "water" else 0)
-    done = 0
-    while done < equil:                   # (in rebuild periods, so that a Berendsen group sees its temperature as in a production run)
-        k = min(20, equil - done)
-        m.step(k)
-        done += k
-        if thermostat:
-            m.group_temperatures()
-    m.step(args.warmup)
-    if thermostat:
-        m.group_temperatures()
-    m.sync()
-
-    def barrier():
-        m.sync()                          # this rank's stream is drained ...
-        if rdzv is not None:
-            rdzv.barrier()                # ... and so is everybody else's
-
-    m.timing(True)
-    barrier()
-    reb0 = m.list_stats()["rebuilds"]
-    t0 = time.perf_counter()
-    m.step(args.steps)
-    barrier()
-    el = time.perf_counter() - t0
-    launches, kernel_ms = m.timing_read()
-    m.timing(False)
-    e, vir, rk, tion = m.energies()
-    st = m.list_stats()
-    nlocal = int(m.lib.ddcmi_nlocal(m.ctx))
-    epot, ekin = e["total"], rk
-    if rdzv is not None:
-        el = float(rdzv.allreduce([el], "max")[0])           # the slowest rank's time
-        tot = m.allreduce([epot, ekin, float(nlocal)])      # energyInfo.c allreduce()
-        epot, ekin = float(tot[0]), float(tot[1])
-        assert int(round(tot[2])) == s.natoms, "beads lost in migration"
-
-    value = s.natoms * args.steps / el     # whole box, whole job
-    L = st["entries"] / float(max(nlocal, 1))
-    bytes_per_atom = 36.0 + 24.0 + 4.0 * L
-    t_kernel = kernel_ms * 1e-3 / max(1, launches)
-    achieved = bytes_per_atom * nlocal / t_kernel / 1e9
-    # HBM bytes of the nonbonded kernel from the PMC passes committed under profiles/: quoted only when the file
-    # was collected on this workload AND on these device sources (kernel_src_id), else null
-    traffic = None
-    try:
-        if world == 1 and not args.rccl_loopback:
-            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-                if not fn.endswith("traffic.json"):
-                    continue
-                t = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                if t.get("workload") == wname and t.get("kernel_src_id") == kernel_source_id():
-                    traffic = float(t["traffic_bytes_per_launch"])
-                    break
-    except Exception:
-        traffic = None
+    res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback)
     out = {
-        "metric": "atom_steps_per_sec", "value": value, "unit": "atom-steps/s",
+        "metric": "atom_steps_per_sec", "value": res.pop("value"), "unit": "atom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True,
+        "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "ns_per_day": (args.steps / el) * dt_fs * 1e-6 * 86400.0,
-        "config": {"workload": wname, "beads_total": s.natoms, "beads_rank0": nlocal,
-                   "lattice": "fcc" if args.workload == "water" else "deck tiled %s" % args.reps, "lattice_n": args.n if args.workload == "water" else None,
-                   "rcut_A": float(ddcmd_amd.units_convert(s.rmax, None, "Angstrom")), "skin_A": float(ddcmd_amd.units_convert(s.deltaR, None, "Angstrom")),
-                   "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
-                   "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
-                   "energy_virial_every_step": True, "equilibration_steps_untimed": equil,
-                   "parallelism": ("spatial decomposition %dx%dx%d, %s (control plane: libddcmi TCP rendezvous, no torch)"
-                                   % (grid + ("RCCL p2p halo" if transport != "host" else "host-staged TCP halo",))) if world > 1
-                                  else ("single GPU, images through RCCL loopback" if args.rccl_loopback else "single GPU"),
-                   "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
-        "roofline": {"bound": "hbm", "kernel": "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "hbm_frac_measured": (traffic / t_kernel / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "algorithmic_bytes_per_atom_step": bytes_per_atom, "kernel_ms_avg": t_kernel * 1e3, "launches": launches,
-                     "note": "rank 0's kernel on its own beads" if world > 1 else "whole box"},
-        "check": {"epot": epot, "ekin": ekin},
-        "runtime_libs": runtime_libs(),
     }
+    out.update(res)
+    out["runtime_libs"] = runtime_libs()
+    headline = world == 1 and args.workload == "water" and args.n == 100 and not args.rccl_loopback
+    if headline and not args.no_also:
+        # the other single-GPU configurations, each timed like the headline (>= 100 steps): BASELINE configs[2] (1 M-bead water),
+        # configs[4] (the ~2 M-bead lipid bilayer) and one rank's brick of the 8-GPU run of configs[3] through the RCCL loopback
+        out["also"] = []
+        for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps"),
+                   dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen"),
+                   dict(workload="water", n=50, loopback=True, tag="one rank's 500k-bead brick of the 8-GPU run, periodic images through the RCCL loopback")):
+            try:
+                r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"])
+                out["also"].append({"what": kw["tag"], "workload": r["config"]["workload"], "value": r["value"], "unit": "atom-steps/s", "ms_per_step": r["ms_per_step"],
+                                    "steps_timed": r["steps_timed"], "window_ms": r["window_ms"], "rebuilds_in_timed_region": r["config"]["rebuilds_in_timed_region"],
+                                    "list_entries_per_atom": r["config"]["list_entries_per_atom"], "parallelism": r["config"]["parallelism"],
+                                    "roofline": r["roofline"], "comm": r.get("comm")})
+            except Exception as ex:      # the headline stands on its own
+                out["also"].append({"what": kw["tag"], "error": str(ex)})
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)      # N=1 only (the contract): a bounded sample on one host core
-    m.close()
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()

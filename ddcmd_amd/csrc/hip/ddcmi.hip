@@ -3244,6 +3244,17 @@ extern "C" int ddcmi_list_stats(const ddcmi_ctx *ctx, int64_t stats[8])
    return DDCMI_OK;
 }
 
+extern "C" int ddcmi_comm_stats(const ddcmi_ctx *ctx, int64_t stats[8])
+{
+   if (!ctx || !stats) return DDCMI_EINVAL;
+   int v = 0;
+   (void)ncclGetVersion(&v);
+   stats[0] = ctx->nsend; stats[1] = ctx->nrecv; stats[2] = ctx->hmsg_s.n; stats[3] = ctx->hmsg_r.n;
+   stats[4] = v; stats[5] = ctx->comm ? (ctx->loopback ? 3 : 1) : ctx->hcomm ? 2 : 0;
+   stats[6] = ctx->nranks; stats[7] = ctx->rank;
+   return DDCMI_OK;
+}
+
 extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int64_t *nentries)
 {
    if (!ctx || !ctx->list_valid || which < 0 || which > 1) return DDCMI_EINVAL;

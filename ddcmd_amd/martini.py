@@ -492,6 +492,15 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_list_stats(self.ctx, st))
         return {"entries": st[0], "excluded": st[1], "ell_width": st[2], "images": st[3], "cells": st[4], "rebuilds": st[5], "npad": st[6]}
 
+    def comm_stats(self):
+        st = (ctypes.c_int64 * 8)()
+        self.lib.ddcmi_comm_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        self._chk(self.lib.ddcmi_comm_stats(self.ctx, st))
+        v = int(st[4])
+        return {"send_beads": int(st[0]), "recv_beads": int(st[1]), "send_msgs": int(st[2]), "recv_msgs": int(st[3]),
+                "rccl_version": "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v else None,
+                "transport": ("none", "rccl", "host", "rccl-loopback")[int(st[5])], "ranks": int(st[6]), "rank": int(st[7])}
+
     def get_list(self, which=0):
         n = self.n
         tot = ctypes.c_int64(0)

@@ -199,6 +199,10 @@ int ddcmi_sync(ddcmi_ctx *ctx);
  * [1]=excluded-list entries, [2]=ELL width, [3]=image (halo) atoms, [4]=cells,
  * [5]=rebuild count */
 int ddcmi_list_stats(const ddcmi_ctx *ctx, int64_t stats[8]);
+/* the per-step halo exchange of a decomposed run, as laid out at the last rebuild (ddcSendRecvTables, ddcSendRecv.c:41):
+ * stats[0]=beads this rank sends per step, [1]=beads it receives, [2]/[3]=messages sent/received (one per peer),
+ * [4]=RCCL version code (ncclGetVersion), [5]=transport (0 none, 1 RCCL, 2 host-staged TCP, 3 RCCL loopback), [6]=ranks, [7]=rank */
+int ddcmi_comm_stats(const ddcmi_ctx *ctx, int64_t stats[8]);
 /* Copy the full neighbour list out as CSR over caller-order indices (image atoms
  * are mapped back to their source atom). start[nlocal+1]; j may be NULL to query
  * the size (returned through *nentries).  which: 0 kept, 1 excluded. [sync] */

@@ -44,3 +44,20 @@ def test_bench_source_has_no_torch_import():
     assert not pat.search(src) and "torch.cuda" not in src
     for f in ("martini.py", "_lib.py", "deck.py", "synth.py", "__init__.py"):
         assert not pat.search(open(os.path.join(ROOT, "ddcmd_amd", f)).read())
+
+
+def test_bench_rank_that_never_arrives_ends_the_launch(built):
+    """a launch whose second rank never shows up: rank 0 gives up at the rendezvous deadline with a message and a non-zero exit
+    (no hang, no re-exec) -- the first contact with a real multi-GPU node must not be able to wedge the driver"""
+    import time
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ)
+        env.update({"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1",
+                    "DDCMI_RDZV_FILE": os.path.join(d, "port"), "DDCMI_TRANSPORT": "host", "DDCMI_RDZV_TIMEOUT": "3"})
+        t0 = time.time()
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--lattice", "10"], cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert p.returncode == 2 and time.time() - t0 < 60
+        assert "rendezvous failed" in p.stderr and "only 1 of 2 ranks arrived" in p.stderr, p.stderr[-800:]
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -182,6 +182,65 @@ def test_bench_decompositions_at_4M(water_4M_single, grid):
     g.close()
 
 
+def _copies_vs_oracle(reps, decomposed):
+    """The 62.5 k-bead water box (BASELINE configs[1], the size the oracle runs every step in seconds) tiled reps times is the same
+    periodic system at the size the bench times: EVERY copy of EVERY bead must feel the force the oracle computes for the small
+    box, energies and virial scale with the copy count, and after 25 steps -- across the rebuild at step 20 -- every copy sits
+    where the oracle's bead sits, with its velocity."""
+    import pyoracle
+    from ddcmd_amd.synth import replicate_setup
+    from ddcmd_amd.martini import MartiniHIP, MartiniGroup
+    s0 = make_water_setup(25)
+    o = pyoracle.Oracle(s0)
+    e0, v0 = o.forces()
+    ref = np.stack([o.fx, o.fy, o.fz])[:, None, :].copy()
+    ncopy = reps[0] * reps[1] * reps[2]
+    s = replicate_setup(s0, reps)
+    assert s.natoms == s0.natoms * ncopy
+    m = MartiniGroup(s, (2, 2, 2)) if decomposed else MartiniHIP(s)
+    e, vir = m.eval_forces()
+    d = m.gather() if decomposed else m.download()
+    f = np.stack(d["f"]).reshape(3, ncopy, s0.natoms)
+    assert np.abs(f - ref).max() < 1e-10 * np.abs(ref).max()          # per bead, per copy
+    assert abs(e["lj"] - ncopy * e0["lj"]) < 1e-10 * ncopy * abs(e0["lj"])
+    assert abs(e["total"] - ncopy * e0["total"]) < 1e-10 * ncopy * abs(e0["total"])
+    assert np.abs(vir - ncopy * v0).max() < 1e-10 * ncopy * np.abs(v0).max()
+    eo, vo, rko, _ = o.step(25)
+    m.step(25)
+    e2, vir2, rk, _ = m.energies()
+    assert abs(rk - ncopy * rko) < 1e-9 * ncopy * rko
+    assert abs(e2["total"] - ncopy * eo["total"]) < 1e-9 * ncopy * abs(eo["total"])
+    assert np.abs(vir2 - ncopy * vo).max() < 1e-9 * ncopy * np.abs(vo).max()
+    d = m.gather() if decomposed else m.download()
+    v = np.stack(d["v"]).reshape(3, ncopy, s0.natoms)
+    vref = np.stack([o.vx, o.vy, o.vz])[:, None, :]
+    assert np.abs(v - vref).max() < 1e-8 * np.abs(vref).max()
+    f = np.stack(d["f"]).reshape(3, ncopy, s0.natoms)
+    fref = np.stack([o.fx, o.fy, o.fz])[:, None, :]
+    assert np.abs(f - fref).max() < 1e-7 * np.abs(fref).max()
+    # positions: copy (ix, iy, iz) is the oracle's bead shifted by whole small boxes
+    L0 = np.array([s0.h[0], s0.h[4], s0.h[8]])
+    r = np.stack(d["r"]).reshape(3, ncopy, s0.natoms)
+    for c, oref in enumerate((o.rx, o.ry, o.rz)):
+        dr = r[c] - oref[None, :] - L0[c] * (0.5 - 0.5 * reps[c])      # (replicate_setup centres the tiled box on 0 again)
+        dr -= L0[c] * np.rint(dr / L0[c])
+        assert np.abs(dr).max() < 1e-9 * L0[c]
+    if not decomposed:
+        assert m.list_stats()["rebuilds"] == 2
+    m.close()
+
+
+@pytest.mark.parametrize("reps", [(4, 4, 4), (4, 2, 2)])
+def test_water_at_bench_sizes_per_bead_against_the_oracle(reps):
+    """4.0 M beads (the headline config) and 1.0 M beads (configs[2]) on one domain"""
+    _copies_vs_oracle(reps, False)
+
+
+def test_water_4M_on_eight_domains_per_bead_against_the_oracle():
+    """the same at 4.0 M beads on the 2x2x2 bricks of bench.py --gpus 8 (emulated domains on one GPU)"""
+    _copies_vs_oracle((4, 4, 4), True)
+
+
 def test_lipid_bilayer_2M_beads_periodic_copies():
     """BASELINE config 5 size: the lipid deck tiled 12x12x6 (2.04M beads, ~0.9M bonded terms).
     A periodic box repeated is the same system: every copy of a bead must feel the force the

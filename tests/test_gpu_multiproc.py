@@ -159,8 +159,13 @@ def test_bench_world2_as_the_driver_launches_it():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 40 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["config"]["beads_total"] == 4 * 14 ** 3 and 0 < out["config"]["beads_rank0"] < out["config"]["beads_total"]
-    assert out["config"]["rebuilds_in_timed_region"] == 2
-    assert "cpu_baseline" not in out               # rank 0 at N = 1 only
+    # at least 60 timed steps whatever --steps says, in windows of 20 (one rebuild each); the median window is the figure
+    assert out["steps_timed"] == 60 and len(out["window_ms"]) == 3 and out["config"]["rebuilds_in_timed_region"] == 3
+    assert abs(out["ms_per_step"] - sorted(out["window_ms"])[1] / 20.0) < 1e-9 * out["ms_per_step"] + 1e-4
+    c = out["comm"]
+    assert c["ranks_met"] == 2 and sum(c["beads_per_rank"]) == 4 * 14 ** 3 and len(c["halo_beads_sent_per_step"]) == 2
+    assert c["transport"] == "host" and c["rccl_version"] and c["halo_bytes_per_step_all_ranks"] == 24 * sum(c["halo_beads_sent_per_step"]) > 0
+    assert "cpu_baseline" not in out and "also" not in out               # rank 0 at N = 1 only
     for l in out["runtime_libs"]:
         assert os.path.realpath(l).startswith(os.path.realpath("/opt/rocm") + os.sep), l
     # the same box on one rank gives the same energies (the decomposition changes no physics)
@@ -216,8 +221,13 @@ def test_bench_world8_on_one_device():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["config"]["beads_total"] == 4 * 16 ** 3 and out["config"]["rebuilds_in_timed_region"] == 2
+    assert out["n_gpus"] == 8 and out["config"]["beads_total"] == 4 * 16 ** 3 and out["config"]["rebuilds_in_timed_region"] == 3
     assert "2x2x2" in out["config"]["parallelism"]
+    # what the first contact with a real 8-GPU node should show at a glance: who met, who owns what, what travels per step, which RCCL
+    c = out["comm"]
+    assert c["ranks_met"] == 8 and len(c["beads_per_rank"]) == 8 and sum(c["beads_per_rank"]) == 4 * 16 ** 3
+    assert c["peers_per_rank"] == [7] * 8 and all(b > 0 for b in c["halo_beads_sent_per_step"])
+    assert c["halo_bytes_per_step_all_ranks"] == 24 * sum(c["halo_beads_sent_per_step"]) and c["rccl_version"].count(".") == 2
     p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "20", "--lattice", "16", "--no-cpu"],
                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p1.returncode == 0, p1.stderr[-3000:]
