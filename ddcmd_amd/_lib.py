@@ -94,6 +94,7 @@ class CSetup(ctypes.Structure):
         ("rest_gid", c_u64_p), ("rest_fc", c_int_p), ("rest_r0", c_double_p), ("rest_kb", c_double_p),
         ("cons_off", c_int_p), ("consI", c_int_p), ("consJ", c_int_p), ("cons_grp", c_int_p), ("cons_r0", c_double_p),
         ("npt_isotropic", ctypes.c_int),
+        ("printStress", ctypes.c_int), ("printHmatrix", ctypes.c_int), ("u_energyflux", ctypes.c_char_p),
     ]
 
 

@@ -1685,6 +1685,46 @@ __global__ void k_group_ke_sum(int ngroup, const double *__restrict__ partials, 
    out[q] = a;
 }
 
+/* The per-group and per-species copies of kinetic_terms (energy.c:104-147) and the thermal flux: for every class c (a
+ * group or a species) {rk, tion xx yy zz xy xz yz, mass, number, J x y z} with J_k = (K_k + U_k) v_k - 1/2 S_k v_k; on this
+ * path the per-atom potential energy U_k and stress S_k are zero (martiniNonBond and the bonded terms book e->eion and
+ * e->virial only, bioMartini.c:1111-1120), so J = sum K v and a class's eion stays 0.  Read at print steps only: one pass
+ * per class, fixed-order sums (bitwise reproducible) like k_group_ke. */
+#define KD_NV 12
+__global__ __launch_bounds__(DDCMI_BLOCK) void k_class_kinetic(int nloc, int nclass, int by_species, const double *__restrict__ massv, const int *__restrict__ species,
+                                                                const int *__restrict__ group,
+                                                                const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
+                                                                double *partials /* [GKE_BLOCKS][nclass][16] */)
+{
+   for (int c = 0; c < nclass; c++)
+   {
+      double acc[KD_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = blockIdx.x * DDCMI_BLOCK + threadIdx.x; i < nloc; i += GKE_BLOCKS * DDCMI_BLOCK)
+      {
+         const int sp = species[i];
+         if ((by_species ? sp : group[i]) != c) continue;
+         const double m = massv[sp], x = vx[i], y = vy[i], z = vz[i];
+         const double K = 0.5 * m * (x * x + y * y + z * z);
+         acc[0] += K;
+         acc[1] += m * (x * x); acc[2] += m * (y * y); acc[3] += m * (z * z);
+         acc[4] += m * (x * y); acc[5] += m * (x * z); acc[6] += m * (y * z);
+         acc[7] += m; acc[8] += 1.0;
+         acc[9] += K * x; acc[10] += K * y; acc[11] += K * z;
+      }
+      block_reduce_store<KD_NV>(acc, partials + ((size_t)blockIdx.x * nclass + c) * 16);
+      __syncthreads();      /* the reduction's scratch is reused by the next class */
+   }
+}
+__global__ void k_class_kinetic_sum(int nclass, const double *__restrict__ partials, double *out)
+{
+   const int q = blockIdx.x * blockDim.x + threadIdx.x;
+   if (q >= nclass * KD_NV) return;
+   const int c = q / KD_NV, k = q % KD_NV;
+   double a = 0.0;
+   for (int b = 0; b < GKE_BLOCKS; b++) a += partials[((size_t)b * nclass + c) * 16 + k];
+   out[q] = a;
+}
+
 /* download helpers: caller order + wrap */
 __global__ void k_export_pos(GridParams gp, int nloc, const double4 *pos, const int *orig, double *ox, double *oy, double *oz)
 {
@@ -3241,6 +3281,24 @@ extern "C" int ddcmi_list_stats(const ddcmi_ctx *ctx, int64_t stats[8])
    if (!ctx || !stats) return DDCMI_EINVAL;
    stats[0] = ctx->list_entries; stats[1] = ctx->excl_entries; stats[2] = ctx->maxnbr; stats[3] = ctx->nhalo;
    stats[4] = ctx->gp.ncell; stats[5] = ctx->nrebuild; stats[6] = ctx->npad; stats[7] = 0;
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_kinetic_detail(ddcmi_ctx *ctx, int by_species, int nclass, double *out)
+{
+   if (!ctx || !out || nclass <= 0) return DDCMI_EINVAL;
+   if (nclass != (by_species ? ctx->nspecies : ctx->ngroup))
+      SETERR(ctx, DDCMI_EINVAL, "ddcmi_kinetic_detail: %d classes asked, the context has %d %s", nclass, by_species ? ctx->nspecies : ctx->ngroup, by_species ? "species" : "groups");
+   (void)hipSetDevice(ctx->device);
+   hipStream_t st = ctx->stream;
+   dbuf<double> part, res;
+   if (part.ensure((size_t)GKE_BLOCKS * nclass * 16) || res.ensure((size_t)nclass * KD_NV)) SETERR(ctx, DDCMI_ENOMEM, "kinetic detail scratch");
+   hipLaunchKernelGGL(k_class_kinetic, dim3(GKE_BLOCKS), dim3(DDCMI_BLOCK), 0, st, ctx->nloc, nclass, by_species, ctx->d_mass.p, ctx->species.p, ctx->group.p,
+                      ctx->vx.p, ctx->vy.p, ctx->vz.p, part.p);
+   hipLaunchKernelGGL(k_class_kinetic_sum, dim3(cdiv(nclass * KD_NV, 64)), dim3(64), 0, st, nclass, part.p, res.p);
+   HIPCHK(ctx, hipMemcpyAsync(out, res.p, (size_t)nclass * KD_NV * sizeof(double), hipMemcpyDeviceToHost, st));
+   HIPCHK(ctx, hipStreamSynchronize(st));
+   part.release(); res.release();
    return DDCMI_OK;
 }
 

@@ -485,6 +485,9 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       OBJECT *po = object_find(pname, "PRINTINFO");
       s->u_pressure = get_string(po, "PRESSURE", "GPa");
       object_get(po, "printMolecularPressure", &s->printMolecularPressure, INT, 1, "0");
+      object_get(po, "printStress", &s->printStress, INT, 1, "0");
+      object_get(po, "printHmatrix", &s->printHmatrix, INT, 1, "0");
+      s->u_energyflux = get_string(po, "ENERGYFLUX", "ueV/Ang^2/fs");
       s->u_volume = get_string(po, "VOLUME", "Ang^3");
       s->u_temperature = get_string(po, "TEMPERATURE", "K");
       s->u_energy = get_string(po, "ENERGY", "eV");
@@ -917,6 +920,7 @@ void ddcmi_setup_free(ddcmi_setup *s)
    free(s->rest_gid); free(s->rest_fc); free(s->rest_r0); free(s->rest_kb);
    free(s->cons_off); free(s->consI); free(s->consJ); free(s->cons_grp); free(s->cons_r0);
    free(s->integrator_type); free(s->accelerator_type);
+   free(s->u_energyflux);
    free(s->u_pressure); free(s->u_volume); free(s->u_temperature); free(s->u_energy); free(s->u_time); free(s->u_length);
    free(s);
 }

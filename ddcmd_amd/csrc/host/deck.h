@@ -92,6 +92,9 @@ typedef struct ddcmi_setup
    double *cons_r0;
    /* INTEGRATOR type=NGLFGPULANGEVIN (nglfGPU.cu:422-507): isotropic barostat, every bead under group 0's Langevin thermostat */
    int npt_isotropic;
+   /* PRINTINFO printStress / printHmatrix (printinfo.c:52-53): stress.data (stress tensor + thermal flux) and hmatrix.data */
+   int printStress, printHmatrix;
+   char *u_energyflux;                /* PRINTINFO ENERGYFLUX (printinfo.c:35-36), default ueV/Ang^2/fs */
 } ddcmi_setup;
 
 /* Load a deck.  object_file is required; restart_file may be NULL (then

@@ -520,20 +520,33 @@ int ddcenergy(DDC *ddc, SYSTEM *sys, int e_eval_flag)
    return 0;
 }
 
-/* kinetic_terms (energy.c:48-163): rk, tion from the device reduction */
+/* kinetic_terms (energy.c:48-163): rk, tion, the thermal flux and the per-group / per-species copies (rk, tion, mass,
+ * number) from the device reductions.  The per-atom potentialEnergy and sion the reference reads for J are what the
+ * potentials left per atom: nothing on this path (bioMartini.c:1111-1120 books e->eion / e->virial only), so J = sum K v
+ * and the copies' eion stay 0. */
+static void etype_from_row(ETYPE *g, const double *r)
+{
+   g->rk = r[0];
+   g->tion.xx = r[1]; g->tion.yy = r[2]; g->tion.zz = r[3]; g->tion.xy = r[4]; g->tion.xz = r[5]; g->tion.yz = r[6];
+   g->mass = r[7]; g->number = r[8];
+   g->thermal_flux.x = r[9]; g->thermal_flux.y = r[10]; g->thermal_flux.z = r[11];
+   g->eion = 0.0;
+}
 void kinetic_terms(SYSTEM *sys, int flag)
 {
    (void)flag;
    ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
    ETYPE *e = &sys->energyInfo;
    double tion[6];
+   const int ncl = sys->ngroup + sys->nspecies;
+   double *rows = (double *)calloc((size_t)12 * (ncl > 0 ? ncl : 1), sizeof(double));      /* [groups..., species...][12] */
+   if (!rows) die("kinetic_terms", "out of memory");
    if (host_integrated(sys))
    {
-      /* energy.c:48-163 over STATE: rk = sum 1/2 m v^2, tion = sum m v (x) v; per-group kinetic energy and count */
+      /* energy.c:48-163 over STATE */
       STATE *st = sys->state;
       double rk = 0.0;
       memset(tion, 0, sizeof(tion));
-      for (int g = 0; g < sys->ngroup; g++) { sys->group[g]->energyInfo.rk = 0.0; sys->group[g]->energyInfo.number = 0.0; }
       for (int k = 0; k < st->nlocal; k++)
       {
          const double m = st->species[k]->mass, x = st->vx[k], y = st->vy[k], z = st->vz[k];
@@ -541,13 +554,33 @@ void kinetic_terms(SYSTEM *sys, int flag)
          rk += K;
          tion[DDCMI_XX] += m * x * x; tion[DDCMI_YY] += m * y * y; tion[DDCMI_ZZ] += m * z * z;
          tion[DDCMI_XY] += m * x * y; tion[DDCMI_XZ] += m * x * z; tion[DDCMI_YZ] += m * y * z;
-         st->group[k]->energyInfo.rk += K; st->group[k]->energyInfo.number += 1.0;
+         double *two[2] = {rows + 12 * st->group[k]->index, rows + 12 * (sys->ngroup + st->species[k]->index)};
+         for (int w = 0; w < 2; w++)
+         {
+            double *r = two[w];
+            r[0] += K; r[1] += m * x * x; r[2] += m * y * y; r[3] += m * z * z; r[4] += m * x * y; r[5] += m * x * z; r[6] += m * y * z;
+            r[7] += m; r[8] += 1.0; r[9] += K * x; r[10] += K * y; r[11] += K * z;
+         }
       }
       e->rk = rk;
    }
-   else if (ddcmi_kinetic(ctx, &e->rk, tion) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
+   else
+   {
+      if (ddcmi_kinetic(ctx, &e->rk, tion) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
+      if (sys->ngroup > 0 && ddcmi_kinetic_detail(ctx, 0, sys->ngroup, rows) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
+      if (sys->nspecies > 0 && ddcmi_kinetic_detail(ctx, 1, sys->nspecies, rows + 12 * sys->ngroup) != DDCMI_OK) die("kinetic_terms", ddcmi_last_error(ctx));
+   }
    e->tion.xx = tion[DDCMI_XX]; e->tion.yy = tion[DDCMI_YY]; e->tion.zz = tion[DDCMI_ZZ];
    e->tion.xy = tion[DDCMI_XY]; e->tion.xz = tion[DDCMI_XZ]; e->tion.yz = tion[DDCMI_YZ];
+   e->thermal_flux.x = e->thermal_flux.y = e->thermal_flux.z = 0.0; e->mass = 0.0;
+   for (int g = 0; g < sys->ngroup; g++) etype_from_row(&sys->group[g]->energyInfo, rows + 12 * g);
+   for (int q = 0; q < sys->nspecies; q++)
+   {
+      const double *r = rows + 12 * (sys->ngroup + q);
+      etype_from_row(&sys->species[q]->energyInfo, r);
+      e->thermal_flux.x += r[9]; e->thermal_flux.y += r[10]; e->thermal_flux.z += r[11]; e->mass += r[7];      /* every bead has one species */
+   }
+   free(rows);
    e->number = (par.world > 1) ? (double)ddcmi_nlocal(ctx) : (double)sys->nlocal;      /* this rank's beads (they migrate); eval_energyInfo sums the ranks */
    e->temperature = 2.0 * e->rk / (3.0 * (double)sys->nglobal);        /* energy.c:151 */
 }
@@ -559,12 +592,29 @@ void eval_energyInfo(SYSTEM *sys)
    if (par.world > 1)
    {
       /* allreduce(energyInfo), energyInfo.c:9-63: the members this path fills */
-      double b[15] = {e->rk, e->eion, e->virial.xx, e->virial.yy, e->virial.zz, e->virial.xy, e->virial.xz, e->virial.yz,
-                      e->number, e->tion.xx, e->tion.yy, e->tion.zz, e->tion.xy, e->tion.xz, e->tion.yz};
+      double b[19] = {e->rk, e->eion, e->virial.xx, e->virial.yy, e->virial.zz, e->virial.xy, e->virial.xz, e->virial.yz,
+                      e->number, e->tion.xx, e->tion.yy, e->tion.zz, e->tion.xy, e->tion.xz, e->tion.yz,
+                      e->thermal_flux.x, e->thermal_flux.y, e->thermal_flux.z, e->mass};
       ddcmi_ctx *c = accelerator_getAccelerator(NULL)->parms;
-      if (ddcmi_comm_allreduce_sum(c, b, 15) != DDCMI_OK) die("eval_energyInfo", ddcmi_last_error(c));
+      if (ddcmi_comm_allreduce_sum(c, b, 19) != DDCMI_OK) die("eval_energyInfo", ddcmi_last_error(c));
       e->rk = b[0]; e->eion = b[1]; e->virial.xx = b[2]; e->virial.yy = b[3]; e->virial.zz = b[4]; e->virial.xy = b[5]; e->virial.xz = b[6]; e->virial.yz = b[7];
       e->number = b[8]; e->tion.xx = b[9]; e->tion.yy = b[10]; e->tion.zz = b[11]; e->tion.xy = b[12]; e->tion.xz = b[13]; e->tion.yz = b[14];
+      e->thermal_flux.x = b[15]; e->thermal_flux.y = b[16]; e->thermal_flux.z = b[17]; e->mass = b[18];
+      /* the group and species copies (energyInfo.c:118-141 sums the groups' blocks the same way) */
+      const int ncl = sys->ngroup + sys->nspecies;
+      double *rows = (double *)malloc(sizeof(double) * 12 * (size_t)(ncl > 0 ? ncl : 1));
+      if (!rows) die("eval_energyInfo", "out of memory");
+      for (int q = 0; q < ncl; q++)
+      {
+         const ETYPE *g = q < sys->ngroup ? &sys->group[q]->energyInfo : &sys->species[q - sys->ngroup]->energyInfo;
+         double *r = rows + 12 * q;
+         r[0] = g->rk; r[1] = g->tion.xx; r[2] = g->tion.yy; r[3] = g->tion.zz; r[4] = g->tion.xy; r[5] = g->tion.xz; r[6] = g->tion.yz;
+         r[7] = g->mass; r[8] = g->number; r[9] = g->thermal_flux.x; r[10] = g->thermal_flux.y; r[11] = g->thermal_flux.z;
+      }
+      for (int q0 = 0; q0 < ncl; q0 += 5)      /* (the all-reduce takes up to 64 doubles a call) */
+         if (ddcmi_comm_allreduce_sum(c, rows + 12 * q0, 12 * (ncl - q0 < 5 ? ncl - q0 : 5)) != DDCMI_OK) die("eval_energyInfo", ddcmi_last_error(c));
+      for (int q = 0; q < ncl; q++) etype_from_row(q < sys->ngroup ? &sys->group[q]->energyInfo : &sys->species[q - sys->ngroup]->energyInfo, rows + 12 * q);
+      free(rows);
    }
    /* the barostat moves the box on the device */
    if (ddcmi_get_box(accelerator_getAccelerator(NULL)->parms, sys->box->h0) == DDCMI_OK)
@@ -962,6 +1012,42 @@ void printinfo(SIMULATE *simulate, ETYPE *e_in, int header)
               temperature, pressure, voln, cL * sys->box->h0[0], cL * sys->box->h0[4], cL * sys->box->h0[8]);
       fflush(f);
    }
+   /* print_stress (printinfo.c:282-318): the stress tensor sion and the thermal flux -- of the UNconverted energyInfo, as
+    * printinfoAll passes it (printinfo.c:255) -- and print_hmat (:320-350) */
+   if (simulate->stressfile)
+   {
+      FILE *f = simulate->stressfile;
+      const double cJ = units_convert(1.0, NULL, s->u_energyflux);
+      if (header)
+      {
+         char b[10][64];
+         const char *nm[9] = {"Sigma_xx", "Sigma_yy", "Sigma_zz", "Sigma_xy", "Sigma_xz", "Sigma_yz", "Jx", "Jy", "Jz"};
+         snprintf(b[0], 64, "time(%s)", s->u_time);
+         for (int k = 0; k < 9; k++) snprintf(b[1 + k], 64, "%s(%s)", nm[k], k < 6 ? s->u_pressure : s->u_energyflux);
+         fprintf(f, "%-12s %16s %16s %16s %16s %16s %16s %16s %16s %16s %16s\n", "#loop", b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9]);
+      }
+      const ETYPE *u = e_in;
+      fprintf(f, "%12" PRId64 " %16.6f %16.12f %16.12f %16.12f %16.12f %16.12f %16.12f %16.12f %16.12f %16.12f\n", simulate->loop, time,
+              cP * u->sion.xx, cP * u->sion.yy, cP * u->sion.zz, cP * u->sion.xy, cP * u->sion.xz, cP * u->sion.yz,
+              cJ * u->thermal_flux.x, cJ * u->thermal_flux.y, cJ * u->thermal_flux.z);
+      fflush(f);
+   }
+   if (simulate->hmatfile)
+   {
+      FILE *f = simulate->hmatfile;
+      if (header)
+      {
+         char b[10][64];
+         const char *nm[9] = {"h_xx", "h_xy", "h_xz", "h_yx", "h_yy", "h_yz", "h_zx", "h_zy", "h_zz"};
+         snprintf(b[0], 64, "time(%s)", s->u_time);
+         for (int k = 0; k < 9; k++) snprintf(b[1 + k], 64, "%s(%s)", nm[k], s->u_length);
+         fprintf(f, "%-12s %16s %16s %16s %16s %16s %16s %16s %16s %16s %16s\n", "#loop", b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9]);
+      }
+      const double *h = sys->box->h0;
+      fprintf(f, "%12" PRId64 " %16.6f %16.10f %16.10f %16.10f %16.10f %16.10f %16.10f %16.10f %16.10f %16.10f\n", simulate->loop, time,
+              cL * h[0], cL * h[1], cL * h[2], cL * h[3], cL * h[4], cL * h[5], cL * h[6], cL * h[7], cL * h[8]);
+      fflush(f);
+   }
 }
 
 /* simulateMaster, masters.c:369-559: firstEnergyCall, then batches of steps up to
@@ -971,6 +1057,17 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
    SYSTEM *sys = simulate->system;
    ddcmi_ctx *ctx = simulate->accelerator->parms;
    simulate->datafile = (datafile_path && par.rank == 0) ? fopen(datafile_path, "a") : NULL;
+   simulate->stressfile = simulate->hmatfile = NULL;
+   if (datafile_path && par.rank == 0 && (simulate->setup->printStress || simulate->setup->printHmatrix))
+   {
+      /* next to the data file, under the reference's names (printinfo.c:248-249) */
+      char path[1200], dir[1024];
+      snprintf(dir, sizeof(dir), "%s", datafile_path);
+      char *slash = strrchr(dir, '/');
+      if (slash) slash[1] = 0; else dir[0] = 0;
+      if (simulate->setup->printStress) { snprintf(path, sizeof(path), "%sstress.data", dir); simulate->stressfile = fopen(path, "a"); }
+      if (simulate->setup->printHmatrix) { snprintf(path, sizeof(path), "%shmatrix.data", dir); simulate->hmatfile = fopen(path, "a"); }
+   }
    simulate->ddc->update = 3;                                     /* firstEnergyCall :579-620 */
    ddcenergy(simulate->ddc, sys, 1);
    printinfo(simulate, &sys->energyInfo, 1);
@@ -1024,6 +1121,9 @@ int simulateMaster(SIMULATE *simulate, const char *datafile_path)
    sendHostState(sys);
    if (simulate->datafile) fclose(simulate->datafile);
    simulate->datafile = NULL;
+   if (simulate->stressfile) fclose(simulate->stressfile);
+   if (simulate->hmatfile) fclose(simulate->hmatfile);
+   simulate->stressfile = simulate->hmatfile = NULL;
    return 0;
 }
 

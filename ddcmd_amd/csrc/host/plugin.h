@@ -33,9 +33,10 @@ typedef struct etype_st
    double rk, eion, pion, temperature, number, mass, eBath;
    THREE_SMATRIX virial, tion, sion;
    double energy;                       /* sys->energy = eion + rk (energyInfo.c:116) */
+   THREE_VECTOR thermal_flux;           /* J = sum (K + U) v - S v / 2 (energy.c:112-114) */
 } ETYPE;
 
-typedef struct species_st { char *name; int index; double mass, charge; } SPECIES;
+typedef struct species_st { char *name; int index; double mass, charge; ETYPE energyInfo; /* the per-species copy kinetic_terms keeps (energy.c:136-147) */ } SPECIES;
 enum GROUP_CLASS { FREE, BERENDSEN, LANGEVIN_GROUP, OTHER_GROUP };
 typedef struct group_st { char *name; int index; int itype; double Teq, tau; int interval; ETYPE energyInfo;
                           double Tsum, lambda; int nT, doScaling;      /* BERENDSEN_PARMS' running state (berendsen.c:30-62), host integrator */
@@ -161,6 +162,7 @@ typedef struct simulate_st
    char snapshotdir[512];
    ddcmi_setup *setup;                  /* the parsed deck */
    FILE *datafile;
+   FILE *stressfile, *hmatfile;         /* stress.data / hmatrix.data next to the data file (printinfo.c:248-249) */
 } SIMULATE;
 
 /* accelerator.c:10-56 */

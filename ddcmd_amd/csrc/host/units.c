@@ -46,6 +46,7 @@ static const unit_symbol table[] = {
    {"e", e_MKS, {0, 0, 1, 1, 0}}, {"C", 1.0, {0, 0, 1, 1, 0}},
    {"K", 1.0, {0, 0, 0, 0, 1}},
    {"J", 1.0, {2, 1, -2, 0, 0}}, {"kJ", 1e3, {2, 1, -2, 0, 0}}, {"eV", e_MKS, {2, 1, -2, 0, 0}},
+   {"meV", 1e-3 * e_MKS, {2, 1, -2, 0, 0}}, {"ueV", 1e-6 * e_MKS, {2, 1, -2, 0, 0}},      /* printinfo.c:36: the ENERGYFLUX default is ueV/Ang^2/fs */
    {"keV", 1e3 * e_MKS, {2, 1, -2, 0, 0}}, {"Ry", Rinfhc_MKS, {2, 1, -2, 0, 0}}, {"Rydberg", Rinfhc_MKS, {2, 1, -2, 0, 0}},
    {"Hartree", 2 * Rinfhc_MKS, {2, 1, -2, 0, 0}}, {"kcal", 4184.0, {2, 1, -2, 0, 0}},
    {"Pa", 1.0, {-1, 1, -2, 0, 0}}, {"bar", 1e5, {-1, 1, -2, 0, 0}}, {"GPa", 1e9, {-1, 1, -2, 0, 0}},

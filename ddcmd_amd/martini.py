@@ -437,6 +437,14 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
         return rk.value, t
 
+    def kinetic_detail(self, by_species):
+        """per-group / per-species {rk, tion[6], mass, number, J[3]} (energy.c:104-147) of this rank's beads"""
+        ncl = int(self.s.nspecies if by_species else max(1, self.s.ngroup))
+        out = np.zeros((ncl, 12))
+        self.lib.ddcmi_kinetic_detail.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
+        self._chk(self.lib.ddcmi_kinetic_detail(self.ctx, int(bool(by_species)), ncl, _d(out)))
+        return out
+
     def set_barostat(self, T, P0, beta, tau, isotropic=False, by_gid=False):
         """nglfconstraint's Berendsen barostat (isotropic: NGLFGPULANGEVIN's); the molecule lists feed its molecular virial
         (by_gid: atoms named by gid + the molecules' masses, for decomposed runs)"""

@@ -187,6 +187,11 @@ int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps);
 int ddcmi_get_energies(ddcmi_ctx *ctx, double *energies, double *virial, double *rk, double *tion);
 /* kinetic_terms (energy.c:48-163) on the current velocities. [sync] */
 int ddcmi_kinetic(ddcmi_ctx *ctx, double *rk, double *tion);
+/* the per-group (by_species = 0) or per-species (1) copies of kinetic_terms and the thermal flux, energy.c:104-147:
+ * out[12 c + k] for class c = {rk, tion xx yy zz xy xz yz, mass, number, J x y z} over this rank's beads, J = sum (K + U) v - S v / 2
+ * with the per-atom U and S this path leaves at zero (ddcenergy.c:152-154, bioMartini.c:1111-1120); the classes' J add up to
+ * e->thermal_flux.  nclass must be the context's group / species count.  For print steps. [sync] */
+int ddcmi_kinetic_detail(ddcmi_ctx *ctx, int by_species, int nclass, double *out);
 /* eval_energyInfo group branch (energyInfo.c:118-141): refresh the per-group
  * temperatures Berendsen reads; returns them in Tgroup[ngroup] if not NULL.  With an
  * RCCL communicator the sums are all-reduced first (collective call). [sync] */

@@ -691,6 +691,33 @@ void orc_kinetic(const orc_params *p, int n, const double *vx, const double *vy,
    for (int c = 0; c < 6; c++) tion[c] = t[c];
 }
 
+/* kinetic_terms, energy.c:104-147: the per-group / per-species copies and the thermal flux.  out[12 c + ..] for class c =
+ * {rk, tion xx yy zz xy xz yz, mass, number, J x y z}.  U = potentialEnergy[k] and S = sion[k] are what the potentials
+ * left per atom: the Martini path books e->eion / e->virial only (bioMartini.c:1111-1120), so both are zero here and
+ * ge->eion / se->eion stay zero. */
+void orc_kinetic_detail(const orc_params *p, int n, const double *vx, const double *vy, const double *vz,
+                        const int *species, const int *group, int by_species, int nclass, double *out)
+{
+   for (int q = 0; q < 12 * nclass; q++) out[q] = 0.0;
+   for (int k = 0; k < n; k++)
+   {
+      double mass = p->mass[species[k]];
+      double vxx = vx[k] * vx[k], vyy = vy[k] * vy[k], vzz = vz[k] * vz[k];
+      double vxy = vx[k] * vy[k], vxz = vx[k] * vz[k], vyz = vy[k] * vz[k];
+      double K = 0.5 * mass * (vxx + vyy + vzz);
+      double U = 0.0, Sxx = 0.0, Syy = 0.0, Szz = 0.0, Sxy = 0.0, Sxz = 0.0, Syz = 0.0;
+      int c = by_species ? species[k] : group[k];
+      if (c < 0 || c >= nclass) continue;
+      double *e = out + 12 * c;
+      e[0] += K;
+      e[1] += mass * vxx; e[2] += mass * vyy; e[3] += mass * vzz; e[4] += mass * vxy; e[5] += mass * vxz; e[6] += mass * vyz;
+      e[7] += mass; e[8] += 1.0;
+      e[9] += (K + U) * vx[k] - 0.5 * (Sxx * vx[k] + Sxy * vy[k] + Sxz * vz[k]);
+      e[10] += (K + U) * vy[k] - 0.5 * (Sxy * vx[k] + Syy * vy[k] + Syz * vz[k]);
+      e[11] += (K + U) * vz[k] - 0.5 * (Sxz * vx[k] + Syz * vy[k] + Szz * vz[k]);
+   }
+}
+
 /* eval_energyInfo, energyInfo.c:75-116 (global branch, single rank) */
 void orc_energyinfo(const orc_params *p, double natoms, int nConstraints, double eion, double rk,
                     const double *virial, const double *tion, double *out)

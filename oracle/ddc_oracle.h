@@ -129,6 +129,9 @@ void orc_brute_force(const orc_params *p, int n,
                      double *fx, double *fy, double *fz, double *vLJ, double *vEle, double *virial,
                      long *npair_in_cut);
 
+/* kinetic_terms (energy.c:104-147): per-group (by_species 0) / per-species copies and the thermal flux, 12 doubles per class */
+void orc_kinetic_detail(const orc_params *p, int n, const double *vx, const double *vy, const double *vz,
+                        const int *species, const int *group, int by_species, int nclass, double *out);
 /* kinetic_terms (energy.c:48-163): rk and tion[6] */
 void orc_kinetic(const orc_params *p, int n, const double *vx, const double *vy, const double *vz,
                  const int *species, double *rk, double *tion);

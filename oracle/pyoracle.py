@@ -75,6 +75,8 @@ def lib(path=None):
     L.orc_brute_force.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp, up, ip, dp, dp, dp, dp, dp, dp,
                                   ctypes.POINTER(ctypes.c_long)]
     L.orc_kinetic.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp, ip, dp, dp]
+    L.orc_kinetic_detail.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp, ip, ip, ctypes.c_int, ctypes.c_int, dp]
+    L.orc_kinetic_detail.restype = None
     L.orc_energyinfo.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp, dp, dp]
     L.orc_nglf_step.argtypes = [ctypes.POINTER(OrcParams), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_double,
                                 ctypes.POINTER(ctypes.c_long), dp, ctypes.c_int,
@@ -213,6 +215,13 @@ class Oracle(object):
         self.L.orc_kinetic(ctypes.byref(self.p), self.n, _d(self.vx), _d(self.vy), _d(self.vz), _i(self.species),
                            ctypes.byref(rk), _d(tion))
         return rk.value, tion
+
+    def kinetic_detail(self, by_species):
+        ncl = int(self.s.nspecies if by_species else max(1, self.s.ngroup))
+        out = np.zeros((ncl, 12))
+        self.L.orc_kinetic_detail(ctypes.byref(self.p), self.n, _d(self.vx), _d(self.vy), _d(self.vz), _i(self.species), _i(self.group),
+                                  int(bool(by_species)), ncl, _d(out))
+        return out
 
     def energy_info(self, eion, rk, virial, tion):
         out = np.zeros(9)

@@ -43,6 +43,39 @@ def test_ddcmi_md_data_file(tmp_path):
             e, vir, rk, tion = o.step(s.printrate)
 
 
+def test_ddcmi_md_stress_and_hmatrix_files(tmp_path):
+    """PRINTINFO printStress / printHmatrix (printinfo.c:52-53,248-255): stress.data carries the stress tensor
+    sion = -(virial + tion)/V and the thermal flux J = sum K v of kinetic_terms (energy.c:112-114 with the per-atom U and S
+    this path leaves at zero), hmatrix.data the box -- every print step, against the oracle"""
+    data = str(tmp_path / "data")
+    x = "printinfo PRINTINFO { printStress = 1; printHmatrix = 1; PRESSURE = bar; ENERGYFLUX = ueV/Ang^2/fs; ENERGY = kJ/mol; TIME = ns; TEMPERATURE = K; }"
+    out = subprocess.run([EXE, "-o", DECK, "-d", data, "-x", x], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    s = load_deck(DECK)
+    o = pyoracle.Oracle(s)
+    e, vir = o.forces()
+    rk, tion = o.kinetic()
+    cP, cJ, cL = units_convert(1, None, "bar"), units_convert(1, None, "ueV/Ang^2/fs"), units_convert(1, None, "Ang")
+    st = [l for l in open(str(tmp_path / "stress.data")).read().splitlines() if l.strip()]
+    hm = [l for l in open(str(tmp_path / "hmatrix.data")).read().splitlines() if l.strip()]
+    assert st[0].startswith("#loop") and "Sigma_xx(bar)" in st[0] and "Jz(ueV/Ang^2/fs)" in st[0]
+    assert hm[0].startswith("#loop") and "h_zz(" in hm[0]
+    srows = np.array([[float(v) for v in l.split()] for l in st[1:]])
+    hrows = np.array([[float(v) for v in l.split()] for l in hm[1:]])
+    nrow = 1 + (s.maxloop - s.loop) // s.printrate
+    assert srows.shape == (nrow, 11) and hrows.shape == (nrow, 11)
+    for k in range(nrow):
+        info = o.energy_info(e["total"], rk, vir, tion)
+        assert int(srows[k][0]) == k * s.printrate and int(hrows[k][0]) == k * s.printrate
+        want = cP * info["sion"]
+        assert np.abs(srows[k][2:8] - want).max() < 1e-6 * np.abs(want).max() + 1e-9
+        J = o.kinetic_detail(1)[:, 9:12].sum(axis=0)
+        assert np.abs(srows[k][8:11] - cJ * J).max() < 1e-6 * np.abs(cJ * J).max() + 1e-11
+        assert np.abs(hrows[k][2:11] - cL * np.asarray(s.h)).max() < 1e-8 * cL * s.h[0]
+        if k + 1 < nrow:
+            e, vir, rk, tion = o.step(s.printrate)
+
+
 def test_ddcmi_md_rejects_unsupported_integrator(tmp_path):
     out = subprocess.run([EXE, "-o", DECK, "-d", str(tmp_path / "d"), "-x", "nglf INTEGRATOR {type = NGLFRATTLE;}"],
                          capture_output=True, text=True, timeout=120)

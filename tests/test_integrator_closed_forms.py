@@ -15,6 +15,7 @@ import closed_forms as cf
 from ddcmd_amd.deck import load_deck, units_convert
 from ddcmd_amd.synth import make_water_setup
 from test_closed_forms import tstm_molecules, LIPID_DECK
+LIPID_DECK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
 
 
 def force_free_water(n=5):
@@ -46,6 +47,9 @@ class OracleEngine(object):
     def kinetic(self):
         return self.o.kinetic()
 
+    def kinetic_detail(self, by_species):
+        return self.o.kinetic_detail(by_species)
+
     def state(self):
         return np.stack([self.o.rx, self.o.ry, self.o.rz]), np.stack([self.o.vx, self.o.vy, self.o.vz])
 
@@ -69,6 +73,9 @@ class DeviceEngine(object):
     def kinetic(self):
         return self.m.kinetic()
 
+    def kinetic_detail(self, by_species):
+        return self.m.kinetic_detail(by_species)
+
     def state(self):
         d = self.m.download()
         return np.stack(d["r"]), np.stack(d["v"])
@@ -87,6 +94,36 @@ def check_kinetic_terms(make):
     want = np.array([np.sum(m * v[0] * v[0]), np.sum(m * v[1] * v[1]), np.sum(m * v[2] * v[2]),
                      np.sum(m * v[0] * v[1]), np.sum(m * v[0] * v[2]), np.sum(m * v[1] * v[2])])
     assert np.abs(tion - want).max() < 1e-13 * np.abs(want).max()
+    eng.close()
+
+
+def check_kinetic_detail(make):
+    """the per-group and per-species copies of kinetic_terms and the thermal flux (energy.c:104-147) against numpy sums over the
+    lipid deck (15 species, its groups): rk, tion, mass, number per class; J = sum K v (per-atom U and S are zero on this path)"""
+    s = load_deck(os.path.join(LIPID_DECK_DIR, "object_nvt.data"), restart_file=os.path.join(LIPID_DECK_DIR, "relaxed", "restart"))
+    eng = make(s)
+    m = s.mass[s.species]
+    v = np.stack([s.vx, s.vy, s.vz])
+    K = 0.5 * m * (v ** 2).sum(axis=0)
+    tot = np.zeros(12)
+    for by_species, cls, ncl in ((1, np.asarray(s.species), s.nspecies), (0, np.asarray(s.group), max(1, s.ngroup))):
+        got = eng.kinetic_detail(by_species)
+        assert got.shape == (ncl, 12)
+        for c in range(ncl):
+            sel = cls == c
+            want = np.array([K[sel].sum(),
+                             np.sum(m[sel] * v[0][sel] ** 2), np.sum(m[sel] * v[1][sel] ** 2), np.sum(m[sel] * v[2][sel] ** 2),
+                             np.sum(m[sel] * v[0][sel] * v[1][sel]), np.sum(m[sel] * v[0][sel] * v[2][sel]), np.sum(m[sel] * v[1][sel] * v[2][sel]),
+                             m[sel].sum(), float(sel.sum()),
+                             np.sum(K[sel] * v[0][sel]), np.sum(K[sel] * v[1][sel]), np.sum(K[sel] * v[2][sel])])
+            scale = np.array([K.sum()] + [np.sum(m * (v ** 2).sum(axis=0))] * 6 + [m.sum(), 1.0] + [np.abs(K * np.abs(v).max()).sum()] * 3)
+            assert np.abs(got[c] - want).max() / 1.0 < 1e-12 * scale.max() and np.all(np.abs(got[c] - want) < 1e-12 * scale), (by_species, c)
+        if by_species:
+            tot = got.sum(axis=0)
+            assert np.count_nonzero(got[:, 8]) > 5          # the deck really has many species
+    rk, tion = eng.kinetic()
+    assert abs(tot[0] - rk) < 1e-12 * rk and np.abs(tot[1:7] - tion).max() < 1e-12 * np.abs(tion).max()      # the classes add up to the system's terms
+    assert int(round(tot[8])) == s.natoms
     eng.close()
 
 
@@ -148,6 +185,10 @@ def test_oracle_kinetic_terms():
     check_kinetic_terms(OracleEngine)
 
 
+def test_oracle_kinetic_detail():
+    check_kinetic_detail(OracleEngine)
+
+
 def test_oracle_berendsen_free_flight():
     check_berendsen_free_flight(OracleEngine)
 
@@ -159,6 +200,11 @@ def test_oracle_nglf_on_one_molecule():
 @pytest.mark.gpu
 def test_device_kinetic_terms():
     check_kinetic_terms(DeviceEngine)
+
+
+@pytest.mark.gpu
+def test_device_kinetic_detail():
+    check_kinetic_detail(DeviceEngine)
 
 
 @pytest.mark.gpu
