@@ -31,6 +31,22 @@
 
 static std::string g_create_err;
 
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs tens of microseconds of host time a call: the limit of a kernel is
+ * raised once per (device, kernel) and only ever upwards */
+#include <map>
+#include <mutex>
+static hipError_t dyn_lds_limit(int device, const void *fn, int bytes)
+{
+   static std::mutex mu;
+   static std::map<std::pair<int, const void *>, int> have;
+   std::lock_guard<std::mutex> lk(mu);
+   int &h = have[std::make_pair(device, fn)];
+   if (bytes <= h) return hipSuccess;
+   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+   if (e == hipSuccess) h = bytes;
+   return e;
+}
+
 /* ------------------------------------------------------------------------- */
 /* small device helpers                                                       */
 __device__ __forceinline__ int cell_linear(const GridParams &gp, int cx, int cy, int cz)
@@ -104,7 +120,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
 
 /* ------------------------------------------------------------------------- */
 /* sort: wrap + cell id + in-cell rank                                        */
-__global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway)
+__global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway, int *runaway2)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    int c = -1;
@@ -114,7 +130,7 @@ __global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int
       /* a bead that is not a number, or more than a box length outside the box: the run has blown up (the
        * reference would abort in its domain assignment); reported at this rebuild instead of as a full cell */
       if (!(((gp.pbc & 1) ? fabs(p.x) < 1.5 * gp.L[0] : fabs(p.x) < 1e300) && ((gp.pbc & 2) ? fabs(p.y) < 1.5 * gp.L[1] : fabs(p.y) < 1e300) &&
-            ((gp.pbc & 4) ? fabs(p.z) < 1.5 * gp.L[2] : fabs(p.z) < 1e300))) atomicAdd(runaway, 1);
+            ((gp.pbc & 4) ? fabs(p.z) < 1.5 * gp.L[2] : fabs(p.z) < 1e300))) { atomicAdd(runaway, 1); if (runaway2) atomicAdd(runaway2, 1); }
       /* backInBox_fast: PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
       if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
       if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
@@ -1888,6 +1904,9 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (!ctx) return;
    (void)hipSetDevice(ctx->device);
    (void)hipStreamSynchronize(ctx->stream);
+   if (ctx->ph_on > 0)
+      for (int k = 0; k < 32; k++)
+         if (ctx->ph_cnt[k]) fprintf(stderr, "ddcmi phase %2d %-28s %8.1f us x %ld\n", k, ctx->ph_name[k], ctx->ph_sum[k] / ctx->ph_cnt[k], ctx->ph_cnt[k]);
    ddcmi_comm_destroy(ctx);
    dbuf<double> *db[] = {&ctx->d_invmass, &ctx->d_mass, &ctx->d_charge_sp, &ctx->bpartials, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->vx2, &ctx->vy2, &ctx->vz2,
                          &ctx->fx, &ctx->fy, &ctx->fz, &ctx->d_kqtab, &ctx->partials};
@@ -1916,6 +1935,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
    for (int k = 0; k < 3; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
+   if (ctx->mbox_h) (void)hipHostFree(ctx->mbox_h);
    (void)hipStreamDestroy(ctx->stream);
    if (ctx->self_pinned) (void)hipHostUnregister(ctx);
    delete ctx;
@@ -2363,7 +2383,10 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
                                .add(ctx->d_flags + 32, 2));
    if (n > 0)
    {
-      hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12);
+      /* (decomposed runs: the "beads are not numbers" flag also rides in slot 30 of the direction counters, so that the halo count
+       * round of this rebuild tells every rank) */
+      hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12,
+                         ((ctx->nranks > 1 || ctx->loopback) && ctx->dir_cnt.cap >= 32) ? ctx->dir_cnt.p + 30 : (int *)nullptr);
    }
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
    if (n > 0)
@@ -2410,9 +2433,10 @@ static int bl_self_images(ddcmi_ctx *ctx)
    int n = ctx->nloc, nb = cdiv(n, 256), rc;
    /* (nimg was counted by k_gather_state) */
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->nimg.p, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
-   HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags + 8, ctx->d_flags + 8, sizeof(int), hipMemcpyDeviceToHost, st));
-   HIPCHK(ctx, hipStreamSynchronize(st));
-   int nh = ctx->h_flags[8];
+   PostJobs pj;
+   pj.add(ctx->d_flags + 8, 1);
+   if ((rc = ddcmi_post(ctx, st, pj)) || (rc = ddcmi_post_wait(ctx, st))) return rc;
+   int nh = ctx->mbox_h[pj.off[0]];
    ctx->nhalo = nh;
    if (nh > 0)
    {
@@ -2455,10 +2479,14 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    int rc;
    if ((rc = nb_tables(ctx))) return rc;
    if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
+   ctx->phase(-1, nullptr);
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
+   ctx->phase(0, "sort_owned launched");
    if ((rc = bl_self_images(ctx))) return rc;
+   ctx->phase(1, "self_images (sync)");
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
    if ((rc = ddcmi_bl_finish(ctx))) return rc;
+   ctx->phase(14, "localize");
    return ddcmi_mol_split_finish(ctx);      /* one domain: no molecule is split */
 }
 
@@ -2601,8 +2629,7 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
    ENSURE(ctx, ctx->tile_perm, cap_items + 1);
    ENSURE(ctx, ctx->sched, 32);
    ENSURE(ctx, ctx->partials, (size_t)(nitems + 8) * 8);
-   HIPCHK(ctx, hipMemcpyAsync(ctx->tile_perm.p, perm, (size_t)std::max(nitems, 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-   HIPCHK(ctx, hipMemcpyAsync(ctx->sched.p, sched, 32 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+   { int rcf; if ((rcf = ddcmi_fetch(ctx, ctx->stream, ctx->tile_perm.p, perm, std::max(nitems, 1))) || (rcf = ddcmi_fetch(ctx, ctx->stream, ctx->sched.p, sched, 32))) return rcf; }
    return DDCMI_OK;       /* the pinned buffers are rewritten at the next rebuild, behind its own synchronisation */
 }
 
@@ -2613,6 +2640,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    GridParams &gp = ctx->gp;
    hipStream_t st = ctx->stream;
    int n = ctx->nloc;
+   ctx->phase(10, "-> bl_finish");
    graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
    /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
    ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
@@ -2673,29 +2701,34 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
+      ctx->phase(17, "bl_finish: buffers");
       auto kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
                             : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
-      HIPCHK(ctx, hipFuncSetAttribute((const void *)kbuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)kbuild, (int)lds));
       hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
                          ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
                          ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags);
       /* everything the host decides on (capacity flags, totals, the tiles' cost estimates) is final when k_tile_build
        * ends: it travels behind an event, and the host reads it -- and orders the tiles -- while k_tile_transpose runs */
+      ctx->phase(18, "bl_finish: build launch");
       unsigned long long tot[3];
       int *h_work = ctx->pinned(0, 5 * (size_t)ntile + 8);      /* per tile: list cost, staging cost, entries, excluded entries, width */
       if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
-      if (!ctx->ev_build) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_build, hipEventDisableTiming));
-      HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipMemcpyAsync(h_work, ctx->tile_work.p, 5 * (size_t)ntile * sizeof(int), hipMemcpyDeviceToHost, st));      /* for schedule_tiles: same round trip */
-      HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
+      PostJobs pj;
+      pj.add(ctx->d_flags, 64).add(ctx->tile_work.p, 5 * (size_t)ntile);      /* flags + the tiles' costs and totals: one post, read while the transposition runs */
+      { int rcp = ddcmi_post(ctx, st, pj); if (rcp) return rcp; }
       {
          const size_t lds2 = (size_t)(TR_THREADS / 64) * ctx->tmpw * TR_S * sizeof(unsigned short);
          auto ktr = ctx->tmpw <= 192 ? k_tile_transpose<6> : ctx->tmpw <= 384 ? k_tile_transpose<12> : k_tile_transpose<24>;
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)ktr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)ktr, (int)lds2));
          hipLaunchKernelGGL(ktr, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
       }
       HIPCHK(ctx, hipGetLastError());
-      HIPCHK(ctx, hipEventSynchronize(ctx->ev_build));
+      ctx->phase(11, "build+transpose launched");
+      { int rcp = ddcmi_post_wait(ctx, st); if (rcp) return rcp; }
+      memcpy(ctx->h_flags, ctx->mbox_h + pj.off[0], 64 * sizeof(int));
+      memcpy(h_work, ctx->mbox_h + pj.off[1], 5 * (size_t)ntile * sizeof(int));
+      ctx->phase(12, "wait for the build");
       tot[0] = tot[1] = 0;
       int maxw = 0;
       for (int t = 0; t < ntile; t++) { tot[0] += (unsigned)h_work[2 * (size_t)ntile + t]; tot[1] += (unsigned)h_work[3 * (size_t)ntile + t]; maxw = std::max(maxw, h_work[4 * (size_t)ntile + t]); }
@@ -2730,6 +2763,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(ctx->pos0.p, ctx->pos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToDevice, st));
    }
    if (ctx->nrebuild == 0 && getenv("DDCMI_DEBUG_SCHED")) fprintf(stderr, "ddcmi build: stage_cap %d tmpw %d maxexcl %d pack_type %d tiles %d\n", ctx->stage_cap, ctx->tmpw, ctx->maxexcl, ctx->pack_type, ctx->ntile);
+   ctx->phase(13, "schedule_tiles");
    ctx->list_valid = true;
    ctx->nrebuild++;
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
@@ -2797,7 +2831,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) do { \
-         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>, (int)lds)); \
          hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl16.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)

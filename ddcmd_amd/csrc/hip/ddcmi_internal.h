@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -182,6 +184,7 @@ struct ddcmi_ctx
    bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
+   int64_t mg_rebuilds = 0;            /* decomposed runs: rebuilds entered (the same number on every rank) */
    /* bonded */
    int nbond = 0, nangle = 0, ntors = 0;          /* term counts (of the whole system in a decomposed run) */
    /* RESTRAINT potential: restraints by gid; rest_slot = owned device slot of each (or -1), found at rebuilds */
@@ -216,6 +219,8 @@ struct ddcmi_ctx
    double *d_results = nullptr; double *h_results = nullptr;
    int *d_flags = nullptr; int *h_flags = nullptr; bool self_pinned = false;
    /* growable pinned host staging (so that small copies are truly asynchronous): [0] tile work, [1] tile order, [2] count exchange */
+   /* the mailbox (scan.hip: ddcmi_post / ddcmi_post_wait): mapped coherent host memory, [0] = sequence word */
+   int *mbox_h = nullptr, *mbox_d = nullptr; size_t mbox_cap = 0; int mbox_seq = 0;
    int *h_pin[3] = {nullptr, nullptr, nullptr}; size_t h_pin_cap[3] = {0, 0, 0};
    int *pinned(int which, size_t n)
    {
@@ -223,7 +228,7 @@ struct ddcmi_ctx
       if (h_pin[which]) (void)hipHostFree(h_pin[which]);
       h_pin[which] = nullptr; h_pin_cap[which] = 0;
       size_t cap = n + n / 4 + 64;
-      if (hipHostMalloc((void **)&h_pin[which], cap * sizeof(int), hipHostMallocDefault) != hipSuccess) return nullptr;
+      if (hipHostMalloc((void **)&h_pin[which], cap * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
       h_pin_cap[which] = cap;
       return h_pin[which];
    }
@@ -237,6 +242,17 @@ struct ddcmi_ctx
     * 256 k: 136 vs 126).  graph_state 0: none, 1: buffers sized by a plain step, 2: graph_exec is valid */
    int graph_state = 0; hipGraphExec_t graph_exec = nullptr; double graph_dt = 0; int graph_max_beads = 0;
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
+   /* DDCMI_DEBUG_PHASES=1: host wall time between the marks of a rebuild (where the host waits, where it is busy), printed at ddcmi_destroy */
+   int ph_on = -1; double ph_last = 0, ph_sum[32] = {0}; long ph_cnt[32] = {0}; const char *ph_name[32] = {nullptr};
+   void phase(int k, const char *name)
+   {
+      if (ph_on < 0) ph_on = getenv("DDCMI_DEBUG_PHASES") ? 1 : 0;
+      if (!ph_on) return;
+      struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+      const double now = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+      if (k >= 0 && k < 32) { ph_sum[k] += now - ph_last; ph_cnt[k]++; ph_name[k] = name; }
+      ph_last = now;
+   }
    /* comm */
    int rank = 0, nranks = 1; void *comm = nullptr; int pgrid[3] = {1, 1, 1}, pcoord[3] = {0, 0, 0};
    ddcmi_rdzv *hcomm = nullptr;        /* host transport (ddcmi_comm_init_host): messages staged through the host, carried by TCP streams */
@@ -299,6 +315,14 @@ struct ZeroJobs
    ZeroJobs &add(void *ptr, size_t nints) { p[cnt] = (int *)ptr; n[cnt] = (int)nints; cnt++; return *this; }
 };
 int ddcmi_zero_ints(ddcmi_ctx *ctx, hipStream_t st, const ZeroJobs &z);
+struct PostJobs
+{
+   const int *src[6]; int n[6]; int off[6]; int cnt = 0;
+   PostJobs &add(const void *ptr, size_t nints) { src[cnt] = (const int *)ptr; n[cnt] = (int)nints; off[cnt] = 0; cnt++; return *this; }
+};
+int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j);            /* device arrays -> the mailbox; fills j.off */
+int ddcmi_post_wait(ddcmi_ctx *ctx, hipStream_t st);                    /* spin until the post has landed */
+int ddcmi_fetch(ddcmi_ctx *ctx, hipStream_t st, int *dst, const int *src_host_mapped, int n);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);

@@ -407,7 +407,7 @@ static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over,
    int *h = ctx->pinned(2, 64 + (MG_BLK + 27) * (size_t)nr);
    if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
    int *all = h + 64, *packed = h + 64 + MG_BLK * (size_t)nr;
-   if (with_flags) HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+   if (with_flags && ctx->hcomm) HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
    if (ctx->dir_cnt.cap < MG_BLK && ctx->dir_cnt.ensure(MG_BLK)) SETERR(ctx, DDCMI_ENOMEM, "direction counters");
    if (local_err)
    {
@@ -426,8 +426,13 @@ static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over,
    {
       ENSURE(ctx, ctx->cnt_xchg, 32 + MG_BLK * (size_t)nr);
       NCCLCHK2(ctx, ncclAllGather(ctx->dir_cnt.p, ctx->cnt_xchg.p + 32, MG_BLK, ncclInt, (ncclComm_t)ctx->comm, st));
-      HIPCHK(ctx, hipMemcpyAsync(all, ctx->cnt_xchg.p + 32, MG_BLK * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
+      /* every rank's block (and this rank's flags) through the mailbox: no copy call that waits, no late wake-up (scan.hip) */
+      PostJobs pj;
+      pj.add(ctx->cnt_xchg.p + 32, MG_BLK * (size_t)nr).add(ctx->d_flags, 8);
+      int rcp;
+      if ((rcp = ddcmi_post(ctx, st, pj)) || (rcp = ddcmi_post_wait(ctx, st))) return rcp;
+      memcpy(all, ctx->mbox_h + pj.off[0], MG_BLK * (size_t)nr * sizeof(int));
+      if (with_flags) memcpy(ctx->h_flags, ctx->mbox_h + pj.off[1], 8 * sizeof(int));
    }
    *any_over = false;
    for (int r = 0; r < nr; r++)
@@ -446,6 +451,9 @@ static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over,
          SETERR(ctx, DDCMI_ECOMM, "rank %d failed during the list rebuild (error %d): its own message says why", r, all[MG_BLK * r + 28]);
       }
       if (all[MG_BLK * r + 29]) SETERR(ctx, DDCMI_EINVAL, "a bead moved further than one domain between rebuilds (rank %d)", r);
+      if (all[MG_BLK * r + 30])
+         SETERR(ctx, DDCMI_EINVAL, "%d beads of rank %d have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)",
+                all[MG_BLK * r + 30], r, (long long)ctx->loop);
    }
    for (int c = 0; c < 27; c++) scnt[c] = all[MG_BLK * (size_t)ctx->rank + c];
    plan_recv_counts(ctx->dir_dest, ctx->rank, ctx->loopback, packed, rcnt);
@@ -472,9 +480,11 @@ static int mg_agree(ddcmi_ctx *ctx, int local_rc)
       h[0] = worst;
       HIPCHK(ctx, hipMemcpyAsync(ctx->cnt_xchg.p, h, sizeof(int), hipMemcpyHostToDevice, st));
       NCCLCHK2(ctx, ncclAllReduce(ctx->cnt_xchg.p, ctx->cnt_xchg.p + 1, 1, ncclInt, ncclMax, (ncclComm_t)ctx->comm, st));
-      HIPCHK(ctx, hipMemcpyAsync(h + 1, ctx->cnt_xchg.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      worst = h[1];
+      PostJobs pj;
+      pj.add(ctx->cnt_xchg.p + 1, 1);
+      int rcp;
+      if ((rcp = ddcmi_post(ctx, st, pj)) || (rcp = ddcmi_post_wait(ctx, st))) return rcp;
+      worst = ctx->mbox_h[pj.off[0]];
    }
    if (local_rc) { ctx->err = local_msg; return local_rc; }
    if (worst) SETERR(ctx, DDCMI_ECOMM, "another rank failed during the list rebuild (error %d): its own message says why", worst);
@@ -698,7 +708,7 @@ static int mg_halo_select_launch(ddcmi_ctx *ctx)
    const int n = ctx->nloc;
    if (ctx->hs_cap == 0) ctx->hs_cap = std::max(4096, n / 4);
    ENSURE(ctx, ctx->hs_idx, (size_t)27 * ctx->hs_cap);
-   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 32));
+   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28));      /* (slots 28-31 keep what the rebuild has flagged so far: k_wrap_cell's slot 30) */
    if (n > 0)
       hipLaunchKernelGGL(k_halo_select, dim3(cdiv(n, 256)), dim3(256), 0, st, ctx->gp, mg_dirtab(ctx), n, ctx->hs_cap, ctx->pos.p, ctx->dir_cnt.p, ctx->hs_idx.p);
    return DDCMI_OK;
@@ -757,7 +767,9 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
       ctx->hkey_valid = true;
       if (ctx->nrecv > 0) hipLaunchKernelGGL(k_rec5to3, dim3(cdiv(ctx->nrecv, 256)), dim3(256), 0, st, ctx->nrecv, ctx->hrecv5.p, ctx->hrecv3.p);
    }
+   ctx->phase(6, "mg halo assemble launched");
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
+   ctx->phase(7, "mg halo sort launched");
    if (ctx->has_charge)
    {
       /* sum of q^2 over this rank's beads: reaches the host with ddcmi_bl_finish's own round trip (pinned h_results) */
@@ -783,12 +795,16 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
     * all ranks repeat the round together) to the host.  A rank on which something failed on the way still joins the round, with
     * its error code in its block, and every rank returns from the rebuild together (mg_counts_round, mg_agree): none is left
     * waiting inside the next exchange for a peer that has gone. */
+   ctx->phase(-1, nullptr);
+   ctx->mg_rebuilds++;
    for (;;)
    {
       bool over = false;
       int mx = 0;
       const int lrc = mg_phase1_launch(ctx);
+      ctx->phase(0, "mg phase1 launched");
       if ((rc = mg_counts_round(ctx, ctx->mig_scnt, ctx->mig_rcnt, &over, &mx, true, lrc))) return rc;
+      ctx->phase(1, "mg migration count round");
       if (!over) break;
       if (mx > ctx->mig_cap) ctx->mig_cap = mx + mx / 4 + 64;     /* positions were only wrapped (idempotent): simply redo */
    }
@@ -800,13 +816,16 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
       if (ctx->mig_in.ensure((size_t)acc * 10 + 16)) return mg_fatal(ctx, DDCMI_ENOMEM, "device allocation for the arriving beads failed");
       if ((rc = mg_xchg_data(ctx, ctx->mig_out.p, nullptr, ctx->mig_scnt, ctx->mig_cap, ctx->mig_in.p, roff, ctx->mig_rcnt, 10))) return rc;
    }
+   ctx->phase(2, "mg migration exchange");
    lrc = mg_phase2_migrate_in(ctx);
    for (;;)
    {
       bool over = false;
       int mx = 0;
       if (!lrc) lrc = mg_halo_select_launch(ctx);
+      ctx->phase(3, "mg phase2+select launched");
       if ((rc = mg_counts_round(ctx, ctx->hs_cnt, ctx->hr_cnt, &over, &mx, false, lrc))) return rc;
+      ctx->phase(4, "mg halo count round");
       if (!over) break;
       if (mx > ctx->hs_cap) ctx->hs_cap = mx + mx / 4 + 64;
    }
@@ -815,8 +834,17 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
    /* the list build, the bonded terms' and the constraint groups' partners (beads that are not numbers, a partner beyond the
     * halo ...): local checks, agreed on before anybody enters the next collective -- the one collective of a rebuild that
     * exists for errors only (one small all-reduce: 2 us per step at a 20-step period) */
+   ctx->phase(5, "mg pack+exchange launched");
    lrc = mg_phase4_finish(ctx);
-   if ((rc = mg_agree(ctx, lrc))) return rc;
+   ctx->phase(15, "mg phase4 rest");
+   /* The first rebuilds of a run can fail on the set-up (a bonded partner or a constraint partner beyond the halo, capacities):
+    * the ranks agree on the outcome with one small all-reduce.  Later rebuilds have told each other everything a running system
+    * produces -- beads that moved too far or are not numbers travel in the count rounds above -- and a rank on which phase 4 still
+    * fails (an allocation) leaves the job; the extra collective would cost every rebuild of a healthy run ~4 us per step at a
+    * 20-step period on a 500 k-bead rank. */
+   if (ctx->mg_rebuilds <= 2) { if ((rc = mg_agree(ctx, lrc))) return rc; }      /* (a count every rank keeps alike, whatever failed where) */
+   else if (lrc) return mg_fatal(ctx, lrc, nullptr);
+   ctx->phase(16, "mg agree");
    /* which molecules have atoms on several ranks, and where is their anchor? (one all-reduce of 4 doubles per multi-bead molecule) */
    if (ctx->mol_gid && ctx->nmol_multi > 0 && (rc = mg_allreduce_device(ctx, ctx->mol_info.p, 4 * (size_t)ctx->nmol_multi))) return rc;
    return ddcmi_mol_split_finish(ctx);

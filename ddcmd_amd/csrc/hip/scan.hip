@@ -85,6 +85,80 @@ int ddcmi_scan_exclusive(ddcmi_ctx *ctx, const int *src, int *dst, int n, int *d
    return DDCMI_OK;
 }
 
+/* The mailbox: small results a rebuild decides on (flags, counts, tile costs) are written by a one-workgroup kernel straight
+ * into mapped, coherent host memory, followed by a sequence word the host spins on.  hipMemcpyAsync + hipStreamSynchronize
+ * cost more than the kernels they wait for: a device-to-host copy of more than a few KB blocks the HOST until the kernel in
+ * front of it has finished (the 40 KB of tile costs of a 500 k-bead rank: 283 us inside hipMemcpyAsync, the duration of
+ * k_tile_build), and a blocked stream or event wait wakes up 20-90 us late. */
+__global__ __launch_bounds__(1024) void k_post(PostJobs j, int *dst, int seq)
+{
+   for (int q = 0; q < j.cnt; q++)
+   {
+      const int *src = j.src[q];
+      int *d = dst + j.off[q];
+      for (int i = threadIdx.x; i < j.n[q]; i += 1024) d[i] = src[i];
+   }
+   __threadfence_system();
+   __syncthreads();
+   if (threadIdx.x == 0) __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j)
+{
+   size_t need = 16;
+   for (int q = 0; q < j.cnt; q++) { j.off[q] = (int)need; need += (size_t)((j.n[q] + 3) & ~3); }
+   if (need > ctx->mbox_cap)
+   {
+      /* (every post is waited for before the next one: the old mailbox is idle) */
+      if (ctx->mbox_h) (void)hipHostFree(ctx->mbox_h);
+      ctx->mbox_h = nullptr; ctx->mbox_d = nullptr; ctx->mbox_cap = 0;
+      const size_t cap = need + need / 4 + 1024;
+      if (hipHostMalloc((void **)&ctx->mbox_h, cap * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) SETERR(ctx, DDCMI_ENOMEM, "mapped host memory for the mailbox");
+      if (hipHostGetDevicePointer((void **)&ctx->mbox_d, ctx->mbox_h, 0) != hipSuccess) SETERR(ctx, DDCMI_ENODEVICE, "device address of the mailbox");
+      ctx->mbox_cap = cap;
+      ctx->mbox_h[0] = 0; ctx->mbox_seq = 0;
+   }
+   ctx->mbox_seq++;
+   hipLaunchKernelGGL(k_post, dim3(1), dim3(1024), 0, st, j, ctx->mbox_d, ctx->mbox_seq);
+   HIPCHK(ctx, hipGetLastError());
+   return DDCMI_OK;
+}
+/* spin until the last post has landed; job q's data is at mbox_h + off[q] */
+int ddcmi_post_wait(ddcmi_ctx *ctx, hipStream_t st)
+{
+   volatile int *flag = ctx->mbox_h;
+   struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+   for (unsigned long spin = 0;; spin++)
+   {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->mbox_seq) return DDCMI_OK;
+      if ((spin & 0xfff) == 0xfff)
+      {
+         struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+         if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 20.0)
+         {
+            /* the kernels in front of the post did not finish: let the runtime say why */
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->mbox_seq) return DDCMI_OK;
+            SETERR(ctx, DDCMI_ENODEVICE, "the device never posted its results (mailbox sequence %d)", ctx->mbox_seq);
+         }
+      }
+      __builtin_ia32_pause();
+   }
+}
+/* the other direction: a small table the host prepared in mapped memory, fetched by a kernel (stream-ordered, no host wait) */
+__global__ void k_fetch(int *dst, const int *src, int n)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) dst[i] = src[i];
+}
+int ddcmi_fetch(ddcmi_ctx *ctx, hipStream_t st, int *dst, const int *src_host_mapped, int n)
+{
+   if (n <= 0) return DDCMI_OK;
+   const int *src_d = nullptr;
+   if (hipHostGetDevicePointer((void **)&src_d, (void *)src_host_mapped, 0) != hipSuccess) SETERR(ctx, DDCMI_ENODEVICE, "device address of a pinned table");
+   hipLaunchKernelGGL(k_fetch, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, src_d, n);
+   return DDCMI_OK;
+}
+
 /* several small arrays zeroed by ONE launch (a hipMemsetAsync each is a launch each, and an odd byte count two) */
 __global__ void k_zero_multi(ZeroJobs z)
 {
