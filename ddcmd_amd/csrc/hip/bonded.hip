@@ -730,6 +730,7 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    if (ctx->inc_nrow == 0) return DDCMI_OK;
    /* one lane per atom with terms; a decomposed run launches over the global atom lists and every rank
     * works on the atoms it owns */
+   if (!ctx->bonded_gid) { int rcs = ddcmi_ensure_slots(ctx); if (rcs) return rcs; }
    const int *slot = ctx->bonded_gid ? ctx->slot_of_atom.p : ctx->slot_of_orig.p;
    const int nblk = cdiv(ctx->inc_light, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
    ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
@@ -898,6 +899,7 @@ int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location)
    for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
    box.pbc = ctx->pbc;
    const size_t lds = (size_t)(4 * ctx->cons_maxA + 3 * ctx->cons_maxP) * CONS_T * sizeof(double);
+   if (!ctx->cons_gid) { int rcs = ddcmi_ensure_slots(ctx); if (rcs) return rcs; }
    auto kern = location == 0 ? k_constrain<0> : k_constrain<1>;
    hipLaunchKernelGGL(kern, dim3(cdiv(ctx->ncgroup, CONS_T)), dim3(CONS_T), lds, ctx->stream, ctx->ncgroup, ctx->cg_atom_off.p,
                       ctx->cons_gid ? (const int *)nullptr : ctx->cg_atoms.p, ctx->cg_pair_off.p,
@@ -1163,6 +1165,7 @@ int ddcmi_launch_mol_virial(ddcmi_ctx *ctx)
                          ctx->mol_info.p, ctx->mol_mtot.p, box, ctx->pos.p, ctx->d_mass.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->mol_red.p, ctx->d_results + R_SCR_MOLV);
       return DDCMI_OK;
    }
+   { int rcs = ddcmi_ensure_slots(ctx); if (rcs) return rcs; }
    hipLaunchKernelGGL(k_mol_virial, dim3(cdiv(ctx->nmol_multi, 256)), dim3(256), 0, ctx->stream, ctx->nmol_multi, ctx->mol_off.p, ctx->mol_atoms.p, ctx->slot_of_orig.p, box,
                       ctx->pos.p, ctx->species.p, ctx->d_mass.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_MOLV);
    return DDCMI_OK;

@@ -118,9 +118,16 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
    }
 }
 
+/* backInBox_fast: PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
+__device__ __forceinline__ void back_in_box(const GridParams &gp, double4 &p)
+{
+   if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
+   if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
+   if (gp.pbc & 4) { if (p.z > 0.5 * gp.L[2]) p.z -= gp.L[2]; if (p.z < -0.5 * gp.L[2]) p.z += gp.L[2]; }
+}
 /* ------------------------------------------------------------------------- */
 /* sort: wrap + cell id + in-cell rank                                        */
-__global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway, int *runaway2)
+__global__ void k_wrap_cell(GridParams gp, int nloc, const double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway, int *runaway2)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    int c = -1;
@@ -131,11 +138,9 @@ __global__ void k_wrap_cell(GridParams gp, int nloc, double4 *pos, int *cid, int
        * reference would abort in its domain assignment); reported at this rebuild instead of as a full cell */
       if (!(((gp.pbc & 1) ? fabs(p.x) < 1.5 * gp.L[0] : fabs(p.x) < 1e300) && ((gp.pbc & 2) ? fabs(p.y) < 1.5 * gp.L[1] : fabs(p.y) < 1e300) &&
             ((gp.pbc & 4) ? fabs(p.z) < 1.5 * gp.L[2] : fabs(p.z) < 1e300))) { atomicAdd(runaway, 1); if (runaway2) atomicAdd(runaway2, 1); }
-      /* backInBox_fast: PreduceOrthorhombicB7_OneLatticeReduction (preduce.c:147-160) */
-      if (gp.pbc & 1) { if (p.x > 0.5 * gp.L[0]) p.x -= gp.L[0]; if (p.x < -0.5 * gp.L[0]) p.x += gp.L[0]; }
-      if (gp.pbc & 2) { if (p.y > 0.5 * gp.L[1]) p.y -= gp.L[1]; if (p.y < -0.5 * gp.L[1]) p.y += gp.L[1]; }
-      if (gp.pbc & 4) { if (p.z > 0.5 * gp.L[2]) p.z -= gp.L[2]; if (p.z < -0.5 * gp.L[2]) p.z += gp.L[2]; }
-      pos[i] = p;
+      /* backInBox_fast (nglf.c:90).  The wrapped record is not written back here: k_gather_state, which moves every record
+       * anyway, wraps it again the same way (128 MB less to write at 4 M beads) */
+      back_in_box(gp, p);
       int cx, cy, cz;
       cell_coords(gp, p.x, p.y, p.z, true, cx, cy, cz);
       c = cell_linear(gp, cx, cy, cz);
@@ -205,25 +210,32 @@ __global__ void k_gather_state(int nloc, const int *order,
                                const double4 *pos, const double *vx, const double *vy, const double *vz,
                                const int *species, const int *group, const uint64_t *gid, const int *orig,
                                double4 *pos2, double *vx2, double *vy2, double *vz2,
-                               int *species2, int *group2, uint64_t *gid2, int *orig2, int *slot_of_orig, GridParams gp, int *nimg)
+                               int *species2, int *group2, uint64_t *gid2, int *orig2, int *slot_of_orig, GridParams gp, int *nimg, int wrap)
 {
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= nloc) return;
    int i = order[k];
+   double4 p = pos[i];
+   if (wrap) back_in_box(gp, p);      /* (k_wrap_cell sorted the beads by their wrapped positions) */
    if (nimg)
    {
       int d[3];
-      image_dirs(gp, pos[i], d);
+      image_dirs(gp, p, d);
       nimg[k] = (1 + (d[0] != 0)) * (1 + (d[1] != 0)) * (1 + (d[2] != 0)) - 1;
    }
-   pos2[k] = pos[i];
+   pos2[k] = p;
    vx2[k] = vx[i]; vy2[k] = vy[i]; vz2[k] = vz[i];
    species2[k] = species[i]; group2[k] = group[i]; gid2[k] = gid[i];
    int o = orig[i];
    orig2[k] = o;
-   slot_of_orig[o] = k;
+   if (slot_of_orig) slot_of_orig[o] = k;      /* (a scattered store per bead: only where something names beads by caller index) */
 }
 
+__global__ void k_slots_from_orig(int nloc, const int *__restrict__ orig, int *slot_of_orig)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k < nloc) slot_of_orig[orig[k]] = k;
+}
 /* ------------------------------------------------------------------------- */
 /* periodic image atoms                                                       */
 __device__ __forceinline__ void image_dirs(const GridParams &gp, const double4 &p, int d[3])
@@ -1289,6 +1301,15 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             }
 #undef NB_PAIR
          };
+         /* charged systems: the bead's excluded partners (a few 2-byte entries, one memory round trip each if asked for after the walk) */
+         int ecnt_pre = 0;
+         unsigned epre[4] = {0u, 0u, 0u, 0u};
+         if (HAS_Q)
+         {
+            ecnt_pre = (active && sub == 0) ? excl_cnt[a] : 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) epre[k] = (k < ecnt_pre) ? (unsigned)excl16[(size_t)k * npad + a] : 0u;
+         }
          uint4 qa = load_group(0), qb = load_group(1), qc;
          int gi = 0;
          for (; gi + 3 <= wmax; gi += 3)
@@ -1303,12 +1324,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          {
             /* excluded (same-molecule bonded) pairs: reaction-field correction only
              * (martiniIntraMoleReaction); few per bead, gathered from global memory */
-            int ecnt = (active && sub == 0) ? excl_cnt[a] : 0;
+            const int ecnt = ecnt_pre;
             for (int k = 0; k < ecnt; k++)
             {
                /* the partner out of LDS, like a list entry (a global gather per excluded pair at the end of every wave was a
-                * memory round trip nothing overlapped) */
-               const unsigned e16 = excl16[(size_t)k * npad + a];
+                * memory round trip nothing overlapped); the first four entries were requested before the list walk */
+               const unsigned e16 = k < 4 ? epre[k] : (unsigned)excl16[(size_t)k * npad + a];
                const unsigned oe = PACKED ? (e16 & 0xfff0u) : (e16 << 4);
                const xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + oe);
                const double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)((oe >> 1) + (unsigned)ZOFF);
@@ -2221,6 +2242,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    hipLaunchKernelGGL(k_init_state, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, n, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species.p,
                       ctx->d_ljtype_sp.p, ctx->gid.p, ctx->pos.p, ctx->orig.p, ctx->slot_of_orig.p);
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   ctx->slot_valid = true;
    if (vx && vy && vz)
    {
       HIPCHK(ctx, hipMemcpyAsync(ctx->vx.p, vx, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -2396,10 +2418,14 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
          hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p, ctx->gid.p, (const int *)nullptr);
       else
          hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
+      /* caller index -> slot: a scattered store per bead, kept up only where something reads it every step */
+      const bool slots = (!ctx->bonded_gid && ctx->inc_nrow > 0) || (!ctx->cons_gid && ctx->ncgroup > 0) || (!ctx->mol_gid && ctx->nmol_multi > 0);
       hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
                          ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
-                         ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p,
-                         gp, (ctx->nranks == 1 && !ctx->loopback && !ctx->group_) ? ctx->nimg.p : (int *)nullptr);
+                         ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p,
+                         slots ? ctx->slot_of_orig.p : (int *)nullptr,
+                         gp, (ctx->nranks == 1 && !ctx->loopback && !ctx->group_) ? ctx->nimg.p : (int *)nullptr, 1);
+      ctx->slot_valid = slots;
       std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
       std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
    }
@@ -2467,6 +2493,14 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
    }
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
+   return DDCMI_OK;
+}
+
+int ddcmi_ensure_slots(ddcmi_ctx *ctx)
+{
+   if (ctx->slot_valid || ctx->nloc <= 0) return DDCMI_OK;
+   hipLaunchKernelGGL(k_slots_from_orig, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, ctx->stream, ctx->nloc, ctx->orig.p, ctx->slot_of_orig.p);
+   ctx->slot_valid = true;
    return DDCMI_OK;
 }
 

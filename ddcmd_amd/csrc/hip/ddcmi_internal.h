@@ -181,6 +181,8 @@ struct ddcmi_ctx
    bool baro_iso = false;                                           /* one scale factor from the mean of the three pressures (changeVolumeGPUisotropic) */
    double pmol[3] = {0, 0, 0};                                      /* molecular pressure (xx, yy, zz) the barostat last acted on */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
+   bool slot_valid = false;            /* slot_of_orig (caller index -> device slot) belongs to the current order: refilled by the sort of a rebuild only when something
+                                          names beads by caller index (bonded terms, constraint groups, molecule lists), else on demand (ddcmi_ensure_slots) */
    bool drift_done = false;            /* the FRONT kick + drift of the coming step ran fused with the last step's BACK kick */
    bool list_valid = false;
    int64_t nrebuild = 0, list_entries = 0, excl_entries = 0;
@@ -324,6 +326,7 @@ int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j);            /* devic
 int ddcmi_post_wait(ddcmi_ctx *ctx, hipStream_t st);                    /* spin until the post has landed */
 int ddcmi_fetch(ddcmi_ctx *ctx, hipStream_t st, int *dst, const int *src_host_mapped, int n);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
+int ddcmi_ensure_slots(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */

@@ -686,7 +686,7 @@ static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
       {
          hipLaunchKernelGGL(k_gather_state, dim3(cdiv(nkeep, 256)), dim3(256), 0, st, nkeep, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
                             ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
-                            ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p, ctx->gp, (int *)nullptr);
+                            ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p, ctx->gp, (int *)nullptr, 0);
       }
       std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
       std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);

@@ -2,7 +2,7 @@
 # kernel-trace stats of the rebuild kernels for the tree's library and every tuning build, one box
 set -u
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-args="${1:---lattice 100 --steps 40 --warmup 0 --equil 0}"
+args="${1:---no-also --lattice 100 --steps 40 --warmup 0 --equil 0}"
 for so in tree tuning/libddcmi_*.so; do
    [ "$so" = tree ] || [ -e "$so" ] || continue
    if [ "$so" = tree ]; then unset DDCMI_LIB; else export DDCMI_LIB=$PWD/$so; fi
