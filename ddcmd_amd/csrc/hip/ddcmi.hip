@@ -380,7 +380,9 @@ struct TileArgs
    long long *tile_base; int *tile_width, *tile_rows, *tile_work;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt;
-   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead: entry | distance shell << 16 */
+   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead.  Packed entries (pack_type != 0): 16-bit words,
+                                           staged slot + 1 | distance shell << 12, and the slot's type nibble in tile_nib; bare entries: 32-bit words, entry | shell << 16 */
+   unsigned char *tile_nib;             /* [ntile][stage_stride] type nibble (+ shifted-copy bit) of every staged slot: k_tile_transpose finishes the entries with it */
    ShellCuts shc;
 };
 
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
             unsigned nib = lo & 0xfu;
             if (PACK == 2 && hs4[u] != 13) nib |= 8u;      /* a periodically shifted copy: bit 3 of the entry's type nibble */
             unsigned wv = PACK ? (((unsigned)(k + 1) << 4) | nib) : (unsigned)(k + 1);      /* the bead's list entry, finished */
+            if (PACK) ta.tile_nib[(size_t)t * ta.stage_stride + k] = (unsigned char)nib;
             if (HAS_MOL)
             {
                const unsigned mol = (unsigned)(w >> 32);
@@ -566,7 +569,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    int mymax = 0;
    /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go to the bead's own row of a
     * row-major scratch list tagged with their distance shell; k_tile_transpose lays them out slot-major in shell order */
-   unsigned *const trow = ta.tmp32 + (size_t)ts * ta.tmpw;      /* the tile's scratch rows (wave-uniform base, 32-bit lane offsets) */
+   constexpr unsigned SCRB = PACK ? 2u : 4u;      /* bytes of a scratch word */
+   char *const trow = (char *)ta.tmp32 + (size_t)ts * ta.tmpw * SCRB;      /* the tile's scratch rows (wave-uniform base, 32-bit lane offsets) */
    const int wlim = ta.tmpw - 4;                                /* a trip stores while its row has room for four more words */
    for (int al = threadIdx.x; al < nown; al += TB_THREADS)
    {
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       constexpr unsigned RING_STEP = TB_THREADS * 4u, RING_MASK = (TB_RING - 1u) * RING_STEP;
       static_assert(TB_RING == 8 && (RING_STEP & (RING_STEP - 1)) == 0, "ring of eight words per lane");
       const unsigned tid4 = threadIdx.x * 4u, lim11 = (unsigned)wlim * RING_STEP;
-      unsigned c11 = 0, f11 = 0, gofs = (unsigned)al * (unsigned)ta.tmpw * 4u;
+      unsigned c11 = 0, f11 = 0, gofs = (unsigned)al * (unsigned)ta.tmpw * SCRB;
       bool ovf = false;      /* an accepted candidate found its row full: the host grows the rows and builds again */
       /* one row of cells: candidates [s0, s1) of the LDS image.  SELF: the row holds the bead itself */
       auto scan_row = [&](const int s0, const int s1, auto self_row)
@@ -720,7 +724,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                unsigned sh;
                const float st = fmaf(r2[u], shA, shB);
                asm("v_cvt_u32_f32 %0, %1" : "=v"(sh) : "v"(st));      /* saturating: negative -> 0 (a C cast of a negative float is undefined) */
-               const unsigned word = (sh << 16) | (HAS_MOL ? (__float_as_uint(q4[u].w) & 0xffffu) : __float_as_uint(q4[u].w));
+               /* packed entries: the scratch word is 16 bits, staged slot + 1 | shell << 12 (the type nibble waits in tile_nib) */
+               const unsigned wq = __float_as_uint(q4[u].w);
+               const unsigned word = PACK ? ((sh << 12) | (HAS_MOL ? ((wq >> 4) & 0xfffu) : (wq >> 4))) : ((sh << 16) | (HAS_MOL ? (wq & 0xffffu) : wq));
                if (ok[u] & room)
                {
                   *(lds_uint *)(__UINTPTR_TYPE__)((c11 & RING_MASK) | tid4) = word;
@@ -736,8 +742,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
                o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
                o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
-               *(uint4 *)((char *)trow + gofs) = o;      /* wave-uniform base + 32-bit lane offset */
-               gofs += 16u; f11 += 4u * RING_STEP;
+               if (PACK) *(uint2 *)(trow + gofs) = make_uint2(o.x | (o.y << 16), o.z | (o.w << 16));
+               else *(uint4 *)(trow + gofs) = o;      /* wave-uniform base + 32-bit lane offset */
+               gofs += 4u * SCRB; f11 += 4u * RING_STEP;
             }
          }
       };
@@ -780,7 +787,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
          o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
          o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
          o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
-         *(uint4 *)((char *)trow + gofs) = o;
+         if (PACK) *(uint2 *)(trow + gofs) = make_uint2(o.x | (o.y << 16), o.z | (o.w << 16));
+         else *(uint4 *)(trow + gofs) = o;
       }
       const int cnt = (int)(c11 / RING_STEP);
       mymax = max(mymax, min(cnt, ta.tmpw));
@@ -858,12 +866,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
 #define TR_THREADS 256
 #define TR_WROWS 8                         /* rows a wave sorts together */
 #define TR_S 9                             /* row stride of the wave's image in 16-bit entries: [slot][TR_S] */
-template <int NQ>                          /* quads a lane may hold: rows of up to 32 NQ words */
+template <int NQ, bool SCR16>              /* quads a lane may hold: rows of up to 32 NQ (SCR16: 64 NQ) scratch words; SCR16: 16-bit words (packed entries) */
 __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
 {
    extern __shared__ unsigned int tr_smem[];
    __shared__ unsigned cur_s[NSHELL * TR_THREADS];   /* [shell][thread]: counts, then cursors */
    static_assert(NSHELL == 8, "two words of four 16-bit shell counters");
+   constexpr int EPQ = SCR16 ? 8 : 4;                /* scratch words in a 16-byte quad */
    const int t = blockIdx.x;
    const int ts = ta.cell_start_o[TCELLS * t];
    const int nown = ta.cell_start_o[TCELLS * t + TCELLS] - ts;
@@ -874,14 +883,23 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
    const int rl = lane >> 3, q = lane & 7;      /* row of the batch, lane of the row */
    unsigned short *img = (unsigned short *)tr_smem + (size_t)w * ta.tmpw * TR_S;      /* this wave's image: [width][TR_S] */
+   /* SCR16: the type nibble of every staged slot (slot + 1 indexes it; [0] = the sentinel's), behind the waves' images */
+   unsigned char *nib_s = (unsigned char *)((unsigned short *)tr_smem + (size_t)(TR_THREADS / 64) * ta.tmpw * TR_S);
+   if (SCR16)
+   {
+      const int ns = ta.tile_nstage[t];
+      const unsigned char *src = ta.tile_nib + (size_t)t * ta.stage_stride;
+      for (int i = threadIdx.x; i <= ns; i += TR_THREADS) nib_s[i] = i ? src[i - 1] : (unsigned char)0;
+      __syncthreads();      /* the one barrier of the kernel: from here on every wave works alone */
+   }
    unsigned *mycur = cur_s + threadIdx.x;
    const int ngrp = width >> 3;
    for (int r0 = w * TR_WROWS; r0 < rows; r0 += TR_WROWS * (TR_THREADS / 64))
    {
       const int row = r0 + rl;
       const int cnt = row < nown ? ta.nbr_cnt[ts + row] : 0;
-      const int nq = (cnt + 3) >> 2;
-      const uint4 *src = (const uint4 *)(ta.tmp32 + (size_t)(ts + min(row, nown - 1)) * ta.tmpw);      /* tmpw is a multiple of 8 */
+      const int nq = (cnt + EPQ - 1) / EPQ;
+      const uint4 *src = (const uint4 *)((const char *)ta.tmp32 + (size_t)(ts + min(row, nown - 1)) * ta.tmpw * (SCR16 ? 2 : 4));      /* tmpw is a multiple of 8 */
       uint4 wv[NQ];
 #pragma unroll
       for (int j = 0; j < NQ; j++) wv[j] = (q + 8 * j < nq) ? src[q + 8 * j] : make_uint4(0, 0, 0, 0);
@@ -889,15 +907,25 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
       for (int sh = 0; sh < NSHELL; sh++) mycur[sh * TR_THREADS] = 0u;
       /* padding of the row (entry 0 = the sentinel bead): slots cnt .. width-1 */
       for (int s = cnt + q; s < width; s += 8) img[s * TR_S + rl] = 0;
+      /* the scratch words of quad j as {shell, entry}: 32-bit words carry the finished entry, 16-bit ones the staged slot */
+      auto unpack = [&](const uint4 &v, int i, unsigned &sh, unsigned &ent)
+      {
+         const unsigned x[4] = {v.x, v.y, v.z, v.w};
+         if (SCR16) { const unsigned e = (i & 1) ? (x[i >> 1] >> 16) : (x[i >> 1] & 0xffffu); sh = e >> 12; ent = e & 0xfffu; }
+         else { sh = x[i] >> 16; ent = x[i] & 0xffffu; }
+      };
       /* counts per shell */
 #pragma unroll
       for (int j = 0; j < NQ; j++)
       {
-         const unsigned x[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
-         const int k = 4 * (q + 8 * j);
+         const int k = EPQ * (q + 8 * j);
 #pragma unroll
-         for (int i = 0; i < 4; i++)
-            if (k + i < cnt) atomicAdd(mycur + (x[i] >> 16) * TR_THREADS, 1u);      /* the shell, from k_tile_build */
+         for (int i = 0; i < EPQ; i++)
+         {
+            unsigned sh, ent;
+            unpack(wv[j], i, sh, ent);
+            if (k + i < cnt) atomicAdd(mycur + sh * TR_THREADS, 1u);      /* the shell, from k_tile_build */
+         }
       }
       /* offsets: shells in order, inside a shell the row's lanes in order -- on the eight counts packed as 16-bit
        * fields of two 64-bit words (a row holds < 65536 entries) */
@@ -927,17 +955,22 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
          mycur[sh * TR_THREADS] = (unsigned)((s0 >> (16 * sh)) & 0xffffull);
          mycur[(sh + 4) * TR_THREADS] = (unsigned)((s1 >> (16 * sh)) & 0xffffull);
       }
-      /* placement */
+      /* placement (16-bit scratch: the entry is finished here, staged slot << 4 | the slot's nibble) */
 #pragma unroll
       for (int j = 0; j < NQ; j++)
       {
-         const unsigned x[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
-         const int k = 4 * (q + 8 * j);
-         unsigned slot[4];
+         const int k = EPQ * (q + 8 * j);
+         unsigned slot[EPQ], ent[EPQ];
 #pragma unroll
-         for (int i = 0; i < 4; i++) slot[i] = (k + i < cnt) ? atomicAdd(mycur + (x[i] >> 16) * TR_THREADS, 1u) : 0u;
+         for (int i = 0; i < EPQ; i++)
+         {
+            unsigned sh;
+            unpack(wv[j], i, sh, ent[i]);
+            slot[i] = (k + i < cnt) ? atomicAdd(mycur + sh * TR_THREADS, 1u) : 0u;
+            if (SCR16) ent[i] = (ent[i] << 4) | nib_s[ent[i]];
+         }
 #pragma unroll
-         for (int i = 0; i < 4; i++) if (k + i < cnt) img[slot[i] * TR_S + rl] = (unsigned short)(x[i] & 0xffffu);
+         for (int i = 0; i < EPQ; i++) if (k + i < cnt) img[slot[i] * TR_S + rl] = (unsigned short)ent[i];
       }
       /* the wave's LDS operations complete in order: the image is whole when the reads below are issued */
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1944,6 +1977,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : {&ctx->cg_atom_off, &ctx->cg_atoms, &ctx->cg_pair_off, &ctx->cons_status, &ctx->mol_off, &ctx->mol_atoms}) b->release();
    ctx->cg_pa.release(); ctx->cg_pb.release();
    for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->slot_of_atom, &ctx->hvals}) b->release();
+   ctx->tile_nib.release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->excl16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
@@ -2735,6 +2769,8 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.nbr_cnt = ctx->nbr_cnt.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
+      if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
+      ta.tile_nib = ctx->tile_nib.p;
       ctx->phase(17, "bl_finish: buffers");
       auto kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
                             : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
@@ -2752,8 +2788,10 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       pj.add(ctx->d_flags, 64).add(ctx->tile_work.p, 5 * (size_t)ntile);      /* flags + the tiles' costs and totals: one post, read while the transposition runs */
       { int rcp = ddcmi_post(ctx, st, pj); if (rcp) return rcp; }
       {
-         const size_t lds2 = (size_t)(TR_THREADS / 64) * ctx->tmpw * TR_S * sizeof(unsigned short);
-         auto ktr = ctx->tmpw <= 192 ? k_tile_transpose<6> : ctx->tmpw <= 384 ? k_tile_transpose<12> : k_tile_transpose<24>;
+         const bool scr16 = ctx->pack_type != 0;
+         const size_t lds2 = (size_t)(TR_THREADS / 64) * ctx->tmpw * TR_S * sizeof(unsigned short) + (scr16 ? (size_t)ctx->stage_cap + 16 : 0);
+         auto ktr = scr16 ? (ctx->tmpw <= 192 ? k_tile_transpose<3, true> : ctx->tmpw <= 384 ? k_tile_transpose<6, true> : k_tile_transpose<12, true>)
+                          : (ctx->tmpw <= 192 ? k_tile_transpose<6, false> : ctx->tmpw <= 384 ? k_tile_transpose<12, false> : k_tile_transpose<24, false>);
          HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)ktr, (int)lds2));
          hipLaunchKernelGGL(ktr, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
       }

@@ -172,6 +172,7 @@ struct ddcmi_ctx
    int ntile = 0, stage_cap = 0; int pack_type = 0;      /* 0 bare slots, 1 slot<<4|type, 2 + shift bit (see TileArgs) */
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
    dbuf<long long> tile_base;
+   dbuf<unsigned char> tile_nib;       /* packed entries: type nibble of every staged slot of every tile (k_tile_build -> k_tile_transpose) */
    dbuf<unsigned short> nbr16, excl16; dbuf<unsigned int> tmp32; int tmpw = 0;      /* excl16: the excluded pairs as staged-slot entries (k_nonbond) */
    unsigned long long arena_cap = 0;
    dbuf<double> kpartials;             /* per-workgroup kinetic terms (k_kick_ke) */
