@@ -602,7 +602,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       constexpr unsigned RING_STEP = TB_THREADS * 4u, RING_MASK = (TB_RING - 1u) * RING_STEP;
       static_assert(TB_RING == 8 && (RING_STEP & (RING_STEP - 1)) == 0, "ring of eight words per lane");
       const unsigned tid4 = threadIdx.x * 4u, lim11 = (unsigned)wlim * RING_STEP;
-      unsigned c11 = 0, f11 = 0, gofs = (unsigned)al * (unsigned)ta.tmpw * SCRB;
+      const unsigned gofs0 = (unsigned)al * (unsigned)ta.tmpw * SCRB;
+      unsigned c11 = 0, f11 = 0, gofs = gofs0;
       bool ovf = false;      /* an accepted candidate found its row full: the host grows the rows and builds again */
       /* one row of cells: candidates [s0, s1) of the LDS image.  SELF: the row holds the bead itself */
       auto scan_row = [&](const int s0, const int s1, auto self_row)
@@ -717,7 +718,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
              * are waiting: 4-byte stores straight to the scratch row -- one per candidate slot, each lane its own cache
              * line -- ran into the rate at which L2 takes write requests (2.5 ms per build at 4 M beads against 2.3 for
              * paired 8-byte stores behind three times the vector instructions) */
-            const bool room = c11 <= lim11;
+            /* a row that cannot take four more words starts over (and says so: the host grows the rows and builds again) --
+             * one test per trip instead of a mask term per candidate */
+            if (c11 > lim11) { ovf = true; c11 = 0; f11 = 0; gofs = gofs0; }
 #pragma unroll
             for (int u = 0; u < 4; u++)
             {
@@ -727,12 +730,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                /* packed entries: the scratch word is 16 bits, staged slot + 1 | shell << 12 (the type nibble waits in tile_nib) */
                const unsigned wq = __float_as_uint(q4[u].w);
                const unsigned word = PACK ? ((sh << 12) | (HAS_MOL ? ((wq >> 4) & 0xfffu) : (wq >> 4))) : ((sh << 16) | (HAS_MOL ? (wq & 0xffffu) : wq));
-               if (ok[u] & room)
+               if (ok[u])
                {
                   *(lds_uint *)(__UINTPTR_TYPE__)((c11 & RING_MASK) | tid4) = word;
                   c11 += RING_STEP;
                }
-               ovf |= ok[u] & !room;
             }
             if (c11 - f11 >= 4u * RING_STEP)
             {

@@ -90,17 +90,29 @@ int ddcmi_scan_exclusive(ddcmi_ctx *ctx, const int *src, int *dst, int n, int *d
  * cost more than the kernels they wait for: a device-to-host copy of more than a few KB blocks the HOST until the kernel in
  * front of it has finished (the 40 KB of tile costs of a 500 k-bead rank: 283 us inside hipMemcpyAsync, the duration of
  * k_tile_build), and a blocked stream or event wait wakes up 20-90 us late. */
-__global__ __launch_bounds__(1024) void k_post(PostJobs j, int *dst, int seq)
+__global__ __launch_bounds__(1024) void k_post(PostJobs j, int *dst, int seq, unsigned *ticket)
 {
+   /* several workgroups share a large payload (235 KB of tile costs at 4 M beads took one workgroup 35 us, between the search
+    * and the transposition); the last one to finish -- a ticket -- writes the sequence word */
    for (int q = 0; q < j.cnt; q++)
    {
       const int *src = j.src[q];
       int *d = dst + j.off[q];
-      for (int i = threadIdx.x; i < j.n[q]; i += 1024) d[i] = src[i];
+      for (int i = blockIdx.x * 1024 + threadIdx.x; i < j.n[q]; i += gridDim.x * 1024) d[i] = src[i];
    }
    __threadfence_system();
    __syncthreads();
-   if (threadIdx.x == 0) __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   if (threadIdx.x == 0)
+   {
+      bool last = true;
+      if (gridDim.x > 1)
+      {
+         __threadfence();
+         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+         if (last) { *ticket = 0u; __threadfence_system(); }
+      }
+      if (last) __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
 }
 int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j)
 {
@@ -118,7 +130,8 @@ int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j)
       ctx->mbox_h[0] = 0; ctx->mbox_seq = 0;
    }
    ctx->mbox_seq++;
-   hipLaunchKernelGGL(k_post, dim3(1), dim3(1024), 0, st, j, ctx->mbox_d, ctx->mbox_seq);
+   unsigned *ticket = (unsigned *)((double *)ctx->red_tmp.p + 2 * 8 * 8 + 4);      /* a zeroed word behind k_reduce_jobs' own two tickets (left at zero by the last workgroup) */
+   hipLaunchKernelGGL(k_post, dim3((unsigned)std::min<size_t>(16, (need + 16383) / 16384)), dim3(1024), 0, st, j, ctx->mbox_d, ctx->mbox_seq, ticket);
    HIPCHK(ctx, hipGetLastError());
    return DDCMI_OK;
 }
