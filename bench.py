@@ -307,14 +307,15 @@ def main():
     if world > 1:
         # a launch that wedges (a peer that died inside a collective, a fabric that never answers) must end by itself: after
         # DDCMI_BENCH_DEADLINE seconds (default 900) every rank says so and exits 3 -- no hang for the driver to time out on
-        import signal
+        import threading
 
-        def _deadline(signum, frame):
+        def _deadline():
+            # (a thread, not SIGALRM: a Python signal handler cannot run while the main thread sits inside a library call)
+            time.sleep(float(os.environ.get("DDCMI_BENCH_DEADLINE", "900")))
             sys.stderr.write("bench.py rank %d of %d: no result after %s s, giving up\n" % (rank, world, os.environ.get("DDCMI_BENCH_DEADLINE", "900")))
             sys.stderr.flush()
             os._exit(3)
-        signal.signal(signal.SIGALRM, _deadline)
-        signal.alarm(int(os.environ.get("DDCMI_BENCH_DEADLINE", "900")))
+        threading.Thread(target=_deadline, daemon=True).start()
         from ddcmd_amd.martini import Rendezvous, DdcmiError
         try:
             # a rank that never arrives ends the launch with a message and a non-zero exit after two minutes: no hang, no re-exec
