@@ -2413,6 +2413,13 @@ static int setup_grid(ddcmi_ctx *ctx)
       double cmin = 0.5 * rlist;
       int n = (int)floor(W / cmin);
       if (n < 1) n = 1;
+      {
+         /* a last tile of the axis that would hold less than half of its cells is folded away when that costs at most 2 % of
+          * cell width (4 M-bead water: 101 -> 100 cells on the 4-cell axes: no layer of quarter-filled tiles, 7 % fewer workgroups) */
+         const int tdim0[3] = {TCX, TCY, TCZ};
+         const int r = n % tdim0[a];
+         if (r > 0 && 2 * r <= tdim0[a] && n - r >= tdim0[a] && (double)n / (double)(n - r) <= 1.02) n -= r;
+      }
       gp.n[a] = n;
       gp.cinv[a] = (double)n / W;
       const int tdim[3] = {TCX, TCY, TCZ};
