@@ -68,6 +68,52 @@ def test_waterbox_neighbor_list_matches_oracle(waterbox):
     m.close()
 
 
+def _list_pairs_device(m):
+    start, j = m.get_list(0)
+    di = np.repeat(np.arange(m.n), np.diff(start))
+    return set(zip(di.tolist(), j.tolist()))
+
+
+def _list_pairs_oracle(o, n):
+    import ctypes
+    cs, cj = ctypes.POINTER(ctypes.c_int)(), ctypes.POINTER(ctypes.c_int)()
+    o.L.orc_nbr_csr(o.nbr, 0, ctypes.byref(cs), ctypes.byref(cj))
+    ostart = np.ctypeslib.as_array(cs, shape=(n + 1,))
+    oj = np.ctypeslib.as_array(cj, shape=(ostart[-1],))
+    oi = np.repeat(np.arange(n), np.diff(ostart))
+    half = set(zip(oi.tolist(), oj.tolist()))
+    return half | set((b, a) for a, b in half)
+
+
+@pytest.mark.parametrize("rcut_A,skin_A,n", [(12.0, 4.0, 12), (14.0, 4.0, 12), (13.0, 4.0, 21)])
+def test_list_build_variants_by_list_radius(rcut_A, skin_A, n):
+    """The rebuild's code paths by list length and neighbourhood size, each against the oracle (list as a set of pairs, forces,
+    25 steps across a rebuild): 16 A in a small box (134 entries per bead: 16-bit scratch words, three quads per lane, packed
+    entries); 18 A in a small box (~190 entries, > 4095 staged beads per tile: bare 16-bit entries, 32-bit scratch words, twelve
+    quads per lane, k_nonbond's run-time LDS layout); 17 A in a 37 k-bead box (~154 entries with packed entries: 16-bit
+    scratch words, six quads per lane).  List radii from ~20 A on do not fit the LDS at water density."""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(n, rcut_A=rcut_A, skin_A=skin_A)
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    m = MartiniHIP(s)
+    e, vir = m.eval_forces()
+    o.build_list()
+    assert _list_pairs_device(m) == _list_pairs_oracle(o, s.natoms)
+    f = m.download(4)["f"]
+    assert rel_force_err(f, (o.fx, o.fy, o.fz)) < 1e-10
+    assert abs(e["total"] - e0["total"]) < 1e-11 * abs(e0["total"]) and np.abs(vir - v0).max() < 1e-10 * np.abs(v0).max()
+    st = m.list_stats()
+    dens = s.natoms / s.volume
+    assert abs(st["entries"] / s.natoms / (4.0 / 3.0 * np.pi * (s.rmax + s.deltaR) ** 3 * dens) - 1) < 0.1
+    eo, vo, rko, _ = o.step(25)
+    m.step(25)
+    e2, v2, rk, _ = m.energies()
+    assert abs(e2["total"] - eo["total"]) < 1e-8 * abs(eo["total"]) and abs(rk - rko) < 1e-8 * rko
+    assert m.list_stats()["rebuilds"] == 2
+    m.close()
+
+
 def test_waterbox_10_step_nve_trajectory(waterbox):
     """the deck's own run length (deltaloop=10, dt=20 fs): E_pot, E_kin, virial, r, v per golden trace"""
     from ddcmd_amd.martini import MartiniHIP
