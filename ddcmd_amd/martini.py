@@ -486,6 +486,12 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_download_state(self.ctx, int(mask), *[_d(a) for a in out]))
         return {"r": out[0:3], "v": out[3:6], "f": out[6:9]}
 
+    def upload_positions(self, r, v=None):
+        """new positions (and velocities) of the same beads in caller order: sendGPUState of the host-integrator mode"""
+        self.lib.ddcmi_upload_positions.argtypes = [ctypes.c_void_p] + [_dp] * 6
+        vv = v if v is not None else (None, None, None)
+        self._chk(self.lib.ddcmi_upload_positions(self.ctx, _d(r[0]), _d(r[1]), _d(r[2]), _d(vv[0]), _d(vv[1]), _d(vv[2])))
+
     def sync(self):
         self._chk(self.lib.ddcmi_sync(self.ctx))
 
