@@ -95,6 +95,8 @@ class CSetup(ctypes.Structure):
         ("cons_off", c_int_p), ("consI", c_int_p), ("consJ", c_int_p), ("cons_grp", c_int_p), ("cons_r0", c_double_p),
         ("npt_isotropic", ctypes.c_int),
         ("printStress", ctypes.c_int), ("printHmatrix", ctypes.c_int), ("u_energyflux", ctypes.c_char_p),
+        ("random_name", ctypes.c_char_p), ("random_lcg64", ctypes.c_int), ("lcg_from_file", ctypes.c_int),
+        ("lcg_state", c_u64_p), ("lcg_multID", ctypes.POINTER(ctypes.c_uint32)), ("lcg_prime", ctypes.POINTER(ctypes.c_uint32)),
     ]
 
 

@@ -1532,7 +1532,8 @@ __global__ void k_finish_energy(double *r, double self_ele)
  * counter-based stream keyed by (seed, gid, 2*loop + BACK): the same numbers whatever the domain
  * decomposition or launch shape -- statistical, not bitwise, parity with ddcMD. */
 struct GroupLambda { double v[32]; double a[32]; double dfac[32]; unsigned lang_mask; unsigned long long seed, counter_front, counter_back;
-                     double scale[3]; /* barostat: positions are scaled by this (adjustPosn) before the drift; 1 otherwise */ };
+                     double scale[3]; /* barostat: positions are scaled by this (adjustPosn) before the drift; 1 otherwise */
+                     ulonglong2 *lcg; const int *orig; /* RANDOM type LCG64 (ddcmi_set_random_lcg64): the reference's per-particle streams, by caller index */ };
 __device__ __forceinline__ unsigned long long smix64(unsigned long long z)
 {
    z += 0x9E3779B97F4A7C15ull;
@@ -1549,6 +1550,39 @@ __device__ __forceinline__ void gauss3(unsigned long long seed, unsigned long lo
    double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
    g0 = r * cos(t); g1 = r * sin(t);
    g2 = sqrt(-2.0 * log(u3)) * cos(6.283185307179586476925 * u4);
+}
+/* The reference's own noise: lcg64_2 (lcg64.c:137-146) under gasdev3d (random.c:135-160) -- two polar draws, x and y from the
+ * first accepted pair, z from the second.  A record is LCG64_PARM {state; multID, prime}; it lives at the bead's caller index
+ * and only its state moves.  The products and the sum of rsq are rounded one by one, as the accept test of the CPU code sees them. */
+__device__ __forceinline__ void lcg_pair(unsigned long long &st, unsigned long long mult, unsigned long long prime, double &x, double &y, double &rsq)
+{
+   do
+   {
+      st = mult * st + prime; x = __dmul_rn((double)st, 5.4210108624275222e-20);
+      st = mult * st + prime; y = __dmul_rn((double)st, 5.4210108624275222e-20);
+      x = __dadd_rn(__dmul_rn(2.0, x), -1.0); y = __dadd_rn(__dmul_rn(2.0, y), -1.0);
+      rsq = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+   } while (rsq >= 1.0 || rsq == 0.0);
+}
+__device__ __forceinline__ void lcg_gauss3(ulonglong2 *lcg, int o, double &g0, double &g1, double &g2)
+{
+   const ulonglong2 q = lcg[o];
+   const unsigned id = (unsigned)q.y;
+   const unsigned long long mult = id == 0 ? 0x27bb2ee687b0b0fdull : id == 1 ? 0x2c6fe96ee78b6955ull : 0x369dea0f31a53f85ull, prime = q.y >> 32;
+   unsigned long long st = q.x;
+   double x, y, rsq;
+   lcg_pair(st, mult, prime, x, y, rsq);
+   double fac = sqrt(-2.0 * log(rsq) / rsq);
+   g0 = x * fac; g1 = y * fac;
+   lcg_pair(st, mult, prime, x, y, rsq);
+   fac = sqrt(-2.0 * log(rsq) / rsq);
+   g2 = x * fac;
+   lcg[o].x = st;
+}
+__device__ __forceinline__ void group_gauss3(const GroupLambda &gl, int i, const uint64_t *gid, unsigned long long counter, double &g0, double &g1, double &g2)
+{
+   if (gl.lcg) lcg_gauss3(gl.lcg, gl.orig[i], g0, g1, g2);
+   else gauss3(gl.seed, gid[i], counter, g0, g1, g2);
 }
 __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ invmass, const int *__restrict__ species,
                              const int *__restrict__ group, GroupLambda glambda, const uint64_t *__restrict__ gid,
@@ -1574,7 +1608,7 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
    if (glambda.lang_mask >> gr & 1u)
    {
       double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
-      gauss3(glambda.seed, gid[i], glambda.counter_front, g0, g1, g2);
+      group_gauss3(glambda, i, gid, glambda.counter_front, g0, g1, g2);
       x = fma(d, g0, fma(a, fx[i], al * x)); y = fma(d, g1, fma(a, fy[i], al * y)); z = fma(d, g2, fma(a, fz[i], al * z));
    }
    else
@@ -1624,7 +1658,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
          if (glambda.lang_mask >> gr & 1u)
          {
             double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
-            gauss3(glambda.seed, gid[i], glambda.counter_back, g0, g1, g2);
+            group_gauss3(glambda, i, gid, glambda.counter_back, g0, g1, g2);
             x = al * fma(d, g0, fma(a, fx[i], x)); y = al * fma(d, g1, fma(a, fy[i], y)); z = al * fma(d, g2, fma(a, fz[i], z));
          }
          else { x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z); }
@@ -1663,7 +1697,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
       if (lang)
       {
          dl = glambda.dfac[gr] * sqrt(im); al = glambda.a[gr];
-         gauss3(glambda.seed, gid[i], glambda.counter_back, g0, g1, g2);
+         group_gauss3(glambda, i, gid, glambda.counter_back, g0, g1, g2);
          x = al * fma(dl, g0, fma(a, f0, vx[i])); y = al * fma(dl, g1, fma(a, f1, vy[i])); z = al * fma(dl, g2, fma(a, f2, vz[i]));
       }
       else { x = fma(a, f0, vx[i]); y = fma(a, f1, vy[i]); z = fma(a, f2, vz[i]); }
@@ -1674,7 +1708,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
       acc[4] += m * (x * y); acc[5] += m * (x * z); acc[6] += m * (y * z);
       if (lang)
       {
-         gauss3(glambda.seed, gid[i], glambda.counter_front, g0, g1, g2);
+         group_gauss3(glambda, i, gid, glambda.counter_front, g0, g1, g2);
          x = fma(dl, g0, fma(a, f0, al * x)); y = fma(dl, g1, fma(a, f1, al * y)); z = fma(dl, g2, fma(a, f2, al * z));
       }
       else
@@ -2209,6 +2243,46 @@ extern "C" int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed)
    return DDCMI_OK;
 }
 
+/* RANDOM type LCG64: the particles' own streams (LCG64_PARM records in the caller order of ddcmi_upload_state) */
+extern "C" int ddcmi_set_random_lcg64(ddcmi_ctx *ctx, int n, const uint64_t *state, const uint32_t *multID, const uint32_t *prime)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   if (n == 0 || !state) { ctx->lcg_n = 0; return DDCMI_OK; }      /* back to the counter-based stream */
+   if (!multID || !prime) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: multID and prime are needed with the states");
+   if (ctx->nranks > 1 || ctx->loopback || ctx->group_)
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "per-particle LCG64 streams are kept by caller index and do not migrate: one domain only (decomposed runs draw from the counter-based stream)");
+   if (n != ctx->nloc) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: %d records for %d uploaded beads", n, ctx->nloc);
+   std::vector<ulonglong2> h((size_t)n);
+   for (int i = 0; i < n; i++)
+   {
+      /* lcg64_checkValue (lcg64.c:111-120) */
+      if (multID[i] > 2 || state[i] == 0 || prime[i] % 2 == 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: record %d {%llx %u %x} is not a valid LCG64 state", i, (unsigned long long)state[i], multID[i], prime[i]);
+      h[i].x = state[i]; h[i].y = (unsigned long long)multID[i] | ((unsigned long long)prime[i] << 32);
+   }
+   ENSURE(ctx, ctx->lcg, (size_t)n);
+   HIPCHK(ctx, hipMemcpy(ctx->lcg.p, h.data(), (size_t)n * sizeof(ulonglong2), hipMemcpyHostToDevice));
+   ctx->lcg_n = n;
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_get_random_lcg64(ddcmi_ctx *ctx, int n, uint64_t *state, uint32_t *multID, uint32_t *prime)
+{
+   if (!ctx || !state) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   if (ctx->lcg_n == 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_get_random_lcg64: no LCG64 streams are set");
+   if (n != ctx->lcg_n) SETERR(ctx, DDCMI_EINVAL, "ddcmi_get_random_lcg64: %d records asked, %d held", n, ctx->lcg_n);
+   std::vector<ulonglong2> h((size_t)n);
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   HIPCHK(ctx, hipMemcpy(h.data(), ctx->lcg.p, (size_t)n * sizeof(ulonglong2), hipMemcpyDeviceToHost));
+   for (int i = 0; i < n; i++)
+   {
+      state[i] = h[i].x;
+      if (multID) multID[i] = (uint32_t)h[i].y;
+      if (prime) prime[i] = (uint32_t)(h[i].y >> 32);
+   }
+   return DDCMI_OK;
+}
+
 extern "C" int ddcmi_set_clock(ddcmi_ctx *ctx, int64_t loop, double time)
 {
    if (!ctx) return DDCMI_EINVAL;
@@ -2247,6 +2321,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
       for (int i = 0; i < nlocal; i++)
          if (group[i] < 0 || group[i] >= ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "particle %d has group %d outside [0,%d)", i, group[i], ctx->ngroup);
    int n = nlocal;
+   if (ctx->lcg_n != nlocal) ctx->lcg_n = 0;      /* the streams belong to the caller indices of the upload they followed */
    size_t cap = (size_t)n + n / 4 + 1024;     /* room for image atoms; grown on demand */
    ENSURE(ctx, ctx->pos, cap); ENSURE(ctx, ctx->pos2, cap);
    ENSURE(ctx, ctx->gid, cap); ENSURE(ctx, ctx->gid2, cap);
@@ -3041,6 +3116,7 @@ static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
 {
    GroupLambda lam;
    lam.lang_mask = 0; lam.seed = ctx->rng_seed;
+   lam.lcg = ctx->lcg_n > 0 ? ctx->lcg.p : nullptr; lam.orig = ctx->orig.p;
    lam.scale[0] = lam.scale[1] = lam.scale[2] = 1.0;
    /* the FRONT update of a step sees the loop count before its increment, the BACK update the one after */
    lam.counter_front = 2ull * (unsigned long long)ctx->loop;

@@ -1168,6 +1168,10 @@ static int mg_check_one_domain_features(ddcmi_ctx *ctx)
    if (ctx->nranks > 1 && ((ctx->baro_beta > 0.0 && !ctx->mol_gid) || (ctx->ncgroup > 0 && !ctx->cons_gid)))
       SETERR(ctx, DDCMI_EUNSUPPORTED, "%d domains: the barostat and the velocity constraints (NGLFCONSTRAINT) work on a single domain unless the molecules and the "
              "constraint groups are named by gid (ddcmi_set_molecule_lists_gid, ddcmi_set_constraints_gid)", ctx->nranks);
+   bool lang = false;
+   for (int g = 0; g < ctx->ngroup; g++) lang |= ctx->gtype[g] == DDCMI_LANGEVIN;
+   if (ctx->lcg_n > 0 && lang && (ctx->nranks > 1 || ctx->loopback))
+      SETERR(ctx, DDCMI_EUNSUPPORTED, "per-particle LCG64 streams (ddcmi_set_random_lcg64) do not migrate between domains: clear them for a decomposed run");
    return DDCMI_OK;
 }
 /* RCCL bootstrap (the 128-byte id is distributed by the caller: MPI_Bcast in

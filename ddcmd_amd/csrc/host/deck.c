@@ -265,6 +265,57 @@ static void validate_exclusions(resiparms *r)
    }
 }
 
+/* primes.c:35-63: the next odd prime of this task's blocks.  (The reference tests primality with Montgomery products of
+ * operands that are not in Montgomery form -- a strong-probable-prime test to odd bases; a prime passes it whatever the
+ * bases, so below 2^64 its accepted numbers are the primes unless a composite is a strong pseudoprime to all seven.  Here:
+ * Miller-Rabin to the bases 2..17, exact below 3.4e14; tests/test_oracle.py compares the two sequences.) */
+static uint64_t mulmod64(uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)((unsigned __int128)a * b % m); }
+static int is_prime64(uint64_t n)
+{
+   static const uint64_t base[7] = {2, 3, 5, 7, 11, 13, 17};
+   if (n < 2) return 0;
+   for (int i = 0; i < 7; i++) { if (n == base[i]) return 1; if (n % base[i] == 0) return 0; }
+   uint64_t d = n - 1; int r = 0;
+   while ((d & 1) == 0) { d >>= 1; r++; }
+   for (int i = 0; i < 7; i++)
+   {
+      uint64_t x = 1, b = base[i] % n, e = d;
+      while (e) { if (e & 1) x = mulmod64(x, b, n); b = mulmod64(b, b, n); e >>= 1; }
+      if (x == 1 || x == n - 1) continue;
+      int ok = 0;
+      for (int j = 1; j < r && !ok; j++) { x = mulmod64(x, x, n); ok = x == n - 1; }
+      if (!ok) return 0;
+   }
+   return 1;
+}
+void ddcmi_lcg64_default(int n, const uint64_t *label, unsigned task, unsigned ntasks, uint64_t *state, uint32_t *multID, uint32_t *prime)
+{
+   const uint64_t blockSize = 30000, smallest = (2ull << 30) + 1ull;
+   uint64_t cand = 1, upper = 0, iblock = 0, cur = 0;
+   for (int i = 0; i < n; i++)
+   {
+      if (i % 3 == 0)      /* multID cycles 0,1,2; a new prime with every multID 0 */
+      {
+         do
+         {
+            cand += 2;
+            if (cand >= upper)
+            {
+               upper = (iblock * ntasks + task) * blockSize + smallest;
+               cand = upper - blockSize;
+               if (upper % 2 == 0) upper -= 1;
+               if (cand % 2 == 0) cand += 1;
+               iblock++;
+            }
+         } while (!is_prime64(cand));
+         cur = cand;
+      }
+      state[i] = 0x2bc6ffff8cfe166dull ^ label[i];      /* INIT_SEED ^ label */
+      multID[i] = (uint32_t)(i % 3);
+      prime[i] = (uint32_t)cur;
+   }
+}
+
 /* atoms reader: pio FILEHEADER object + VARRECORDASCII records
  * (collection_read.c:86-200; header fields per SURVEY A.5) */
 static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, char *err, int errlen)
@@ -283,6 +334,9 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
     * "checksum" column of 8 hex digits over the rest of the fixed-length record; nrecord = records in all files */
    int col_crc = -1, crc_on = 0, lrec = 0;
    long nrecord_total = -1;
+   /* RANDOM type=LCG64: "state multID prime" (%llx %u %x, lcg64_parse lcg64.c:89-95) after vz; one record without it and every
+    * atom gets the default values (collection_read.c:165-166,194, collection.c:100-109) */
+   int rnd_field = s->random_lcg64, rnd_default = s->random_lcg64 ? 0 : 1;
    for (int f = 0; f < nfiles; f++)
    {
       char fname[4096];
@@ -315,6 +369,12 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
          object_get(h, "nrecord", &nrecord_here, INT, 1, "-1");
          nrecord_total = nrecord_here;
          object_get(h, "lrec", &lrec, INT, 1, "0");
+         {
+            /* collection_read.c:102-108: random = NONE -> no field in the records; absent -> try to parse one */
+            char *rk = get_string(h, "random", "NotSet");
+            if (strcmp(rk, "NONE") == 0) rnd_field = 0;
+            free(rk);
+         }
          {
             char *ck = get_string(h, "checksum", "NONE");
             crc_on = strcmp(ck, "CRC32") == 0;
@@ -363,6 +423,11 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
                s->vx = realloc(s->vx, sizeof(double) * cap); s->vy = realloc(s->vy, sizeof(double) * cap); s->vz = realloc(s->vz, sizeof(double) * cap);
                s->gid = realloc(s->gid, sizeof(uint64_t) * cap);
                s->species = realloc(s->species, sizeof(int) * cap); s->group = realloc(s->group, sizeof(int) * cap);
+               if (s->random_lcg64)
+               {
+                  s->lcg_state = realloc(s->lcg_state, sizeof(uint64_t) * cap);
+                  s->lcg_multID = realloc(s->lcg_multID, sizeof(uint32_t) * cap); s->lcg_prime = realloc(s->lcg_prime, sizeof(uint32_t) * cap);
+               }
             }
             /* split the record into whitespace-separated tokens (in place) */
             char *tok[32];
@@ -389,6 +454,20 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
             s->gid[n] = label; s->species[n] = sp; s->group[n] = gr;
             s->rx[n] = length_convert * v[0]; s->ry[n] = length_convert * v[1]; s->rz[n] = length_convert * v[2];
             s->vx[n] = velocity_convert * v[3]; s->vy[n] = velocity_convert * v[4]; s->vz[n] = velocity_convert * v[5];
+            if (s->random_lcg64)
+            {
+               int got = 0;
+               const int c0 = col_v + 3;
+               if (rnd_field && c0 + 2 < ntok)
+               {
+                  char *e0, *e1, *e2;
+                  unsigned long long st = strtoull(tok[c0], &e0, 16);
+                  unsigned long mu = strtoul(tok[c0 + 1], &e1, 10), pr = strtoul(tok[c0 + 2], &e2, 16);
+                  if (!*e0 && !*e1 && !*e2 && e0 != tok[c0] && e1 != tok[c0 + 1] && e2 != tok[c0 + 2] && pr != 0 && mu <= 2)
+                  { s->lcg_state[n] = st; s->lcg_multID[n] = (uint32_t)mu; s->lcg_prime[n] = (uint32_t)pr; got = 1; }
+               }
+               if (!got) rnd_default = 1;
+            }
             n++;
          }
          if (!eol) break;
@@ -399,6 +478,11 @@ static int read_atoms(ddcmi_setup *s, const char *basepath, int nfiles_hint, cha
    if (nrecord_total >= 0 && n != nrecord_total)
    { snprintf(err, errlen, "%s: header announces nrecord=%ld but %d records were read: truncated snapshot?", basepath, nrecord_total, n); return -1; }
    s->natoms = n;
+   if (s->random_lcg64 && n > 0)
+   {
+      s->lcg_from_file = !rnd_default;
+      if (rnd_default) ddcmi_lcg64_default(n, s->gid, 0, 1, s->lcg_state, s->lcg_multID, s->lcg_prime);
+   }
    return 0;
 }
 
@@ -558,12 +642,19 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
          free(type);
       }
    }
-   /* RANDOM (system.c, random.c:44-60): only the seed is used (Langevin noise) */
+   /* RANDOM (system.c:135, random.c:44-71): type LCG64 = the particles carry their own streams (read_atoms); the seed feeds the
+    * counter-based stream of decomposed runs */
    {
       char *rname = get_string(sys, "random", "NONE");
       OBJECT *ro = strcmp(rname, "NONE") != 0 ? object_find(rname, "RANDOM") : NULL;
       s->rng_seed = 0;
-      if (ro) object_get(ro, "seed", &s->rng_seed, U64, 1, "0");
+      if (ro)
+      {
+         object_get(ro, "seed", &s->rng_seed, U64, 1, "0");
+         char *rtype = get_string(ro, "type", "NONE");
+         if (strcmp(rtype, "LCG64") == 0) { s->random_lcg64 = 1; s->random_name = strdup(rname); }
+         free(rtype);
+      }
       free(rname);
    }
    /* species: via MOLECULECLASS (system.c:139-146, molecule.c:39-66,226-246) or "species" */
@@ -921,6 +1012,7 @@ void ddcmi_setup_free(ddcmi_setup *s)
    free(s->cons_off); free(s->consI); free(s->consJ); free(s->cons_grp); free(s->cons_r0);
    free(s->integrator_type); free(s->accelerator_type);
    free(s->u_energyflux);
+   free(s->random_name); free(s->lcg_state); free(s->lcg_multID); free(s->lcg_prime);
    free(s->u_pressure); free(s->u_volume); free(s->u_temperature); free(s->u_energy); free(s->u_time); free(s->u_length);
    free(s);
 }

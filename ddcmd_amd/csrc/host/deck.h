@@ -95,7 +95,17 @@ typedef struct ddcmi_setup
    /* PRINTINFO printStress / printHmatrix (printinfo.c:52-53): stress.data (stress tensor + thermal flux) and hmatrix.data */
    int printStress, printHmatrix;
    char *u_energyflux;                /* PRINTINFO ENERGYFLUX (printinfo.c:35-36), default ueV/Ang^2/fs */
+   /* RANDOM type=LCG64 (random.c:44-71, lcg64.c): the particles' own streams, LCG64_PARM {state, multID, prime} per atom in file
+    * order -- read from the random field of the atoms records (collection_read.c:160-166) or, when a record carries none,
+    * lcg64_default's values for every atom (collection.c:95-109).  random_lcg64 = 0: no such object, the arrays are NULL */
+   char *random_name;
+   int random_lcg64, lcg_from_file;
+   uint64_t *lcg_state;
+   uint32_t *lcg_multID, *lcg_prime;
 } ddcmi_setup;
+
+/* lcg64_default over n particles in order (lcg64.c:98-110, primes.c:35-63 with prime_init(30000, task, ntasks), ddcMD.c:70) */
+void ddcmi_lcg64_default(int n, const uint64_t *label, unsigned task, unsigned ntasks, uint64_t *state, uint32_t *multID, uint32_t *prime);
 
 /* Load a deck.  object_file is required; restart_file may be NULL (then
  * "restart" next to object_file is tried, as run_ddcMD_CPU.sh does).  Relative

@@ -751,6 +751,16 @@ static int writeRestart_rank0(SIMULATE *simulate, const char *dir, int restartLi
    char line[1024];
    int lrec = snprintf(line, sizeof(line), fmt, 0u, (uint64_t)0, "ATOM", " ", " ", -1.0e-100, -1.0e-100, -1.0e-100, -1.0e-100, -1.0e-100, -1.0e-100);
    lrec += (int)(maxsp - 1) + (int)(maxgr - 1) + 1;
+   /* the random field (collection_write.c:81-89,157-161): lcg64_write's "%16.16llx %1u %8.8x" behind the velocities */
+   ddcmi_setup *su = simulate->setup;
+   const int rnd = su->random_lcg64 && par.world == 1 && st->nlocal == su->natoms;
+   const int randomFieldSize = rnd ? 16 + 1 + 1 + 1 + 8 : 0;
+   if (rnd)
+   {
+      ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
+      if (ddcmi_get_random_lcg64(ctx, st->nlocal, su->lcg_state, su->lcg_multID, su->lcg_prime) != DDCMI_OK) { fclose(f); return -1; }
+      lrec += randomFieldSize + 1;
+   }
    lrec = 8 * ((lrec + 7) / 8);
    const double *h = sys->box->h0;
    time_t now = time(NULL);
@@ -769,7 +779,7 @@ static int writeRestart_rank0(SIMULATE *simulate, const char *dir, int restartLi
    fprintf(f, "reducedcorner=%21.14f %21.14f %21.14f;\n", -0.5, -0.5, -0.5);
    fprintf(f, "h=%21.14f %21.14f %21.14f\n  %21.14f %21.14f %21.14f\n  %21.14f %21.14f %21.14f Ang;\n",
            h[0] * cLen, h[1] * cLen, h[2] * cLen, h[3] * cLen, h[4] * cLen, h[5] * cLen, h[6] * cLen, h[7] * cLen, h[8] * cLen);
-   fprintf(f, "random = NONE;\nrandomFieldSize = 0;\ngroups =");
+   fprintf(f, "random = %s;\nrandomFieldSize = %d;\ngroups =", rnd ? su->random_name : "NONE", randomFieldSize);
    for (int g = 0; g < sys->ngroup; g++) fprintf(f, " %s", sys->group[g]->name);
    fprintf(f, ";\nspecies =");
    for (int i = 0; i < sys->nspecies; i++) fprintf(f, " %s", sys->species[i]->name);
@@ -779,6 +789,8 @@ static int writeRestart_rank0(SIMULATE *simulate, const char *dir, int restartLi
       /* positions come back wrapped into the box (ddcmi_download_state = backInBox) */
       int len = snprintf(line, sizeof(line), fmt, 0u, (uint64_t)st->label[i], "ATOM", st->species[i]->name, st->group[i]->name,
                          st->rx[i] * cLen, st->ry[i] * cLen, st->rz[i] * cLen, st->vx[i] * cVel, st->vy[i] * cVel, st->vz[i] * cVel);
+      if (rnd && len > 0 && len < (int)sizeof(line))
+         len += snprintf(line + len, sizeof(line) - (size_t)len, " %16.16llx %1u %8.8x", (unsigned long long)su->lcg_state[i], (unsigned)su->lcg_multID[i], (unsigned)su->lcg_prime[i]);
       if (len > lrec - 1) { fclose(f); return -1; }
       for (int l = len; l < lrec; l++) line[l] = ' ';
       line[lrec - 1] = '\n';
@@ -914,6 +926,9 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
       free(lab); free(sp); free(gr);
       if (rcu != DDCMI_OK) die("simulate_init", ddcmi_last_error(ctx));      /* (a rank that returned would leave the others in their collectives) */
       sys->nlocal = sys->nion = (unsigned)m;
+      if (s->random_lcg64 && par.rank == 0)
+         printf("RANDOM %s: the per-particle LCG64 streams stay with one domain; %d domains draw the Langevin noise from the counter-based stream (seed %" PRIu64 ") and write no random field\n",
+                s->random_name, par.world, s->rng_seed);
       if (par.rank == 0) printf("%d ranks on a %d x %d x %d grid of domains (%s transport); rank 0 owns %d of %d beads\n", par.world, par.grid[0], par.grid[1], par.grid[2],
                                 par.host_transport ? "host" : "RCCL", m, n);
       return sim;
@@ -922,6 +937,12 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
    {
       snprintf(err, errlen, "%s", ddcmi_last_error(ctx));
       return NULL;
+   }
+   if (s->random_lcg64 && n > 0)
+   {
+      /* RANDOM type LCG64: the particles' streams follow them onto the device (langevin.c:95-96 reads random_getParms(random, k)) */
+      if (ddcmi_set_random_lcg64(ctx, n, s->lcg_state, s->lcg_multID, s->lcg_prime) != DDCMI_OK) { snprintf(err, errlen, "%s", ddcmi_last_error(ctx)); return NULL; }
+      printf("RANDOM %s: LCG64 streams of %d particles %s\n", s->random_name, n, s->lcg_from_file ? "from the atoms file" : "at their default values (no random field in the atoms file)");
    }
    return sim;
 }

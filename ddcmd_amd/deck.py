@@ -69,6 +69,8 @@ class Setup(object):
         self.integrator_type = "NGLF"
         self.has_accelerator = 0
         self.rng_seed = 0
+        self.lcg64 = None             # RANDOM type=LCG64: records {state, multID, prime} per atom (file order), else None
+        self.lcg_from_file = 0
         self.npt_T = self.npt_P0 = self.npt_beta = self.npt_tau = 0.0
         self.npt_isotropic = 0
         self.nresicons = 0
@@ -112,6 +114,12 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
             setattr(s, f, getattr(c, f))
         s.h = np.array(list(c.h), dtype=np.float64)
         s.rng_seed = int(c.rng_seed)
+        if int(c.random_lcg64) and c.natoms > 0:
+            s.lcg64 = np.zeros(c.natoms, dtype=[("state", "<u8"), ("multID", "<u4"), ("prime", "<u4")])
+            s.lcg64["state"] = _arr(c.lcg_state, c.natoms, np.uint64)
+            s.lcg64["multID"] = _arr(c.lcg_multID, c.natoms, np.uint32)
+            s.lcg64["prime"] = _arr(c.lcg_prime, c.natoms, np.uint32)
+            s.lcg_from_file = int(c.lcg_from_file)
         s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = float(c.npt_T), float(c.npt_P0), float(c.npt_beta), float(c.npt_tau)
         s.npt_isotropic = int(c.npt_isotropic)
         s.nresicons = int(c.nresicons)

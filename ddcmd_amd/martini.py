@@ -412,6 +412,9 @@ class MartiniHIP(object):
         gr = np.ascontiguousarray(s.group, dtype=np.int32)
         self._chk(self.lib.ddcmi_upload_state(self.ctx, self.n, _d(a[0]), _d(a[1]), _d(a[2]), _d(v[0]), _d(v[1]), _d(v[2]),
                                               gid.ctypes.data_as(_up), _i(sp), _i(gr)))
+        lcg = getattr(s, "lcg64", None)
+        if lcg is not None and type(self) is MartiniHIP and len(lcg) == self.n and np.any(np.asarray(s.group_type) == 2):
+            self.set_random_lcg64(lcg)      # RANDOM type=LCG64 in the deck: the Langevin groups of a one-domain run draw from the particles' own streams
 
     def build_list(self):
         self._chk(self.lib.ddcmi_build_list(self.ctx))
@@ -436,6 +439,27 @@ class MartiniHIP(object):
         rk = ctypes.c_double(0)
         self._chk(self.lib.ddcmi_kinetic(self.ctx, ctypes.byref(rk), _d(t)))
         return rk.value, t
+
+    def set_random_lcg64(self, parms):
+        """RANDOM type LCG64: the particles' own streams, records {state, multID, prime} (lcg64.h:8-12) in upload order; None clears them"""
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        self.lib.ddcmi_set_random_lcg64.argtypes = [ctypes.c_void_p, ctypes.c_int, _up, u32p, u32p]
+        if parms is None:
+            return self._chk(self.lib.ddcmi_set_random_lcg64(self.ctx, 0, None, None, None))
+        st = np.ascontiguousarray(parms["state"], dtype=np.uint64)
+        mu = np.ascontiguousarray(parms["multID"], dtype=np.uint32)
+        pr = np.ascontiguousarray(parms["prime"], dtype=np.uint32)
+        self._chk(self.lib.ddcmi_set_random_lcg64(self.ctx, int(st.size), st.ctypes.data_as(_up), mu.ctypes.data_as(u32p), pr.ctypes.data_as(u32p)))
+
+    def get_random_lcg64(self):
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        self.lib.ddcmi_get_random_lcg64.argtypes = [ctypes.c_void_p, ctypes.c_int, _up, u32p, u32p]
+        n = self.n
+        out = np.zeros(n, dtype=[("state", "<u8"), ("multID", "<u4"), ("prime", "<u4")])
+        st, mu, pr = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        self._chk(self.lib.ddcmi_get_random_lcg64(self.ctx, n, st.ctypes.data_as(_up), mu.ctypes.data_as(u32p), pr.ctypes.data_as(u32p)))
+        out["state"], out["multID"], out["prime"] = st, mu, pr
+        return out
 
     def kinetic_detail(self, by_species):
         """per-group / per-species {rk, tion[6], mass, number, J[3]} (energy.c:104-147) of this rank's beads"""

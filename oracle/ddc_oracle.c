@@ -807,9 +807,10 @@ int orc_neighbor_check(const orc_params *p, const orc_nbr *nb, int n, const doub
 
 /* Langevin noise.  ddcMD draws three unit normals per particle and half step from a per-particle
  * LCG64 stream (lcg64.c, gasdev3d random.c:135-160) whose state travels with the particle.  The
- * device implementation replaces the stream by a counter-based one -- normals are a pure function
+ * device implementation's default replaces the stream by a counter-based one -- normals are a pure function
  * of (seed, gid, counter = 2*loop + {0 FRONT, 1 BACK}) -- and this restates exactly that function:
- * splitmix64 hashes, Box-Muller.  Parity with the reference is therefore statistical only. */
+ * splitmix64 hashes, Box-Muller (statistical parity with the reference; the same numbers under every
+ * decomposition).  The reference's own stream is below (orc_lcg64 ...): groups with `lcg` set draw from it. */
 static unsigned long long smix64(unsigned long long z)
 {
    z += 0x9E3779B97F4A7C15ull;
@@ -826,6 +827,111 @@ void orc_gauss3(unsigned long long seed, unsigned long long gid, unsigned long l
    double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
    g[0] = r * cos(t); g[1] = r * sin(t);
    g[2] = sqrt(-2.0 * log(u3)) * cos(6.283185307179586476925 * u4);
+}
+
+/* RANDOM type LCG64: the reference's own per-particle stream.
+ * lcg64_2 (lcg64.c:137-146): state = MULT[multID] * state + prime (mod 2^64), uniform = state * 2^-64, twice. */
+static const unsigned long long LCG64_MULT[3] = {0x27bb2ee687b0b0fdull, 0x2c6fe96ee78b6955ull, 0x369dea0f31a53f85ull};
+double orc_lcg64(orc_lcg64_parm *q)
+{
+   q->state = LCG64_MULT[q->multID] * q->state + q->prime;
+   return (double)q->state * 5.4210108624275222e-20;      /* TWO_M64 */
+}
+/* gasdev3d (random.c:135-160): two polar (Marsaglia) draws; x, y from the first accepted pair, z from the second */
+void orc_gasdev3d(orc_lcg64_parm *q, double g[3])
+{
+   double x, y, rsq, fac;
+   do { x = orc_lcg64(q); y = orc_lcg64(q); x = 2.0 * x - 1.0; y = 2.0 * y - 1.0; rsq = x * x + y * y; } while (rsq >= 1.0 || rsq == 0.0);
+   fac = sqrt(-2.0 * log(rsq) / rsq);
+   g[0] = x * fac; g[1] = y * fac;
+   do { x = orc_lcg64(q); y = orc_lcg64(q); x = 2.0 * x - 1.0; y = 2.0 * y - 1.0; rsq = x * x + y * y; } while (rsq >= 1.0 || rsq == 0.0);
+   fac = sqrt(-2.0 * log(rsq) / rsq);
+   g[2] = x * fac;
+}
+/* primes.c: nextPrime hands every task odd primes out of its own blocks of `blockSize` numbers above 2^31 + 1;
+ * isPrime1 (:120-155) is a strong-probable-prime test whose modular products are Montgomery products (MMUL :74-86)
+ * of operands that were never brought into Montgomery form -- i.e. a Miller-Rabin test to the bases
+ * {2,3,5,7,11,13,17} * 2^-n mod N.  Restated as it stands. */
+static unsigned long long pr_mmul(unsigned long long a, unsigned long long b, unsigned long long N, unsigned n)
+{
+   unsigned long long sum = 0;
+   for (unsigned i = 0; i < n; i++) { sum += (a & 1) * b; sum += (sum & 1) * N; sum >>= 1; a >>= 1; }
+   if (sum > N) sum -= N;
+   return sum;
+}
+static unsigned long long pr_two2n(unsigned n, unsigned long long N)
+{
+   unsigned long long q = 1ull << n;
+   if (q > N) q -= N;
+   for (unsigned s = 0; s < n; s++) { q = 2 * q; if (q > N) q -= N; }
+   return q;
+}
+static unsigned long long pr_ipow1(unsigned long long base, unsigned long long ex, unsigned long long N, unsigned n)
+{
+   unsigned long long result = 1;
+   while (ex) { if (ex & 1) result = pr_mmul(result, base, N, n); ex >>= 1; base = pr_mmul(base, base, N, n); }
+   return result;
+}
+int orc_is_prime1(unsigned long long N)
+{
+   static const unsigned long long small[7] = {2, 3, 5, 7, 11, 13, 17};
+   if (N % 3 == 0 || N % 5 == 0 || N % 7 == 0 || N % 11 == 0 || N % 13 == 0) return 0;
+   unsigned n = 0;
+   for (unsigned long long m = N; m; m >>= 1) n++;      /* 1 + llog2(N) */
+   unsigned long long s = N - 1, p2 = pr_two2n(n, N);
+   unsigned r = 0;
+   for (; s % 2 == 0; r++) s >>= 1;
+   for (unsigned i = 0; i < 7 && small[i] < N - 1; i++)
+   {
+      unsigned long long x = pr_ipow1(small[i], s, N, n);
+      if (x == 1 || x == N - 1) continue;
+      int ok = 0;
+      for (unsigned j = 1; j < r; j++)
+      {
+         x = pr_mmul(x, x, N, n); x = pr_mmul(x, p2, N, n);
+         if (x == 1) return 0;
+         if (x == N - 1) { ok = 1; break; }
+      }
+      if (!ok) return 0;
+   }
+   return 1;
+}
+void orc_prime_init(orc_primes *g, unsigned blockSize, unsigned taskId, unsigned nTasks)
+{
+   g->blockSize = blockSize; g->taskId = taskId; g->nTasks = nTasks;
+   g->upperBound = 0; g->prime = 1; g->iBlock = 0;
+}
+unsigned long long orc_next_prime(orc_primes *g)      /* primes.c:35-63 */
+{
+   do
+   {
+      g->prime += 2;
+      if (g->prime >= g->upperBound)
+      {
+         g->upperBound = (g->iBlock * g->nTasks + g->taskId) * g->blockSize + ((2ull << 30) + 1ull);
+         g->prime = g->upperBound - g->blockSize;
+         if (g->upperBound % 2 == 0) g->upperBound -= 1;
+         if (g->prime % 2 == 0) g->prime += 1;
+         g->iBlock++;
+      }
+   } while (!orc_is_prime1(g->prime));
+   return g->prime;
+}
+/* collection.c:95-109 + lcg64_default (lcg64.c:98-110): particles that come without a random field get, in the order they
+ * lie on the task, state = INIT_SEED ^ label, multID = 0,1,2,0,... and a fresh prime for every third particle
+ * (ddcMD.c:70: prime_init(30000, rank, size)) */
+void orc_lcg64_default(int n, const uint64_t *label, unsigned taskId, unsigned nTasks, orc_lcg64_parm *out)
+{
+   orc_primes g;
+   orc_prime_init(&g, 30000, taskId, nTasks);
+   unsigned long long prime = 0;
+   for (int i = 0; i < n; i++)
+   {
+      if (i % 3 == 0) prime = orc_next_prime(&g);
+      out[i].multID = (unsigned)(i % 3);
+      out[i].state = 0x2bc6ffff8cfe166dull ^ label[i];
+      out[i].prime = (unsigned)prime;
+   }
 }
 
 void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt,
@@ -845,6 +951,7 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
       {
          /* langevin_velocityUpdate FRONT_TIMESTEP (langevin.c:92-128), called with dt/2 */
          double dth = 0.5 * dt, al = exp(-dth / g->tau), c = dth / mass, d = sqrt(2.0 * dth * g->Teq / (mass * g->tau)), gg[3];
+         if (g->lcg) orc_gasdev3d(&g->lcg[k], gg); else
          orc_gauss3(g->seed, gid[k], 2ull * (unsigned long long)(*loop), gg);
          vx[k] = al * vx[k] + c * fx[k] + d * gg[0];
          vy[k] = al * vy[k] + c * fy[k] + d * gg[1];
@@ -880,6 +987,7 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
       {
          /* BACK_TIMESTEP: v = a (v + c f + d g), loop already advanced */
          double dth = 0.5 * dt, al = exp(-dth / g->tau), c = dth / mass, d = sqrt(2.0 * dth * g->Teq / (mass * g->tau)), gg[3];
+         if (g->lcg) orc_gasdev3d(&g->lcg[k], gg); else
          orc_gauss3(g->seed, gid[k], 2ull * (unsigned long long)(*loop) + 1ull, gg);
          vx[k] = al * (vx[k] + c * fx[k] + d * gg[0]);
          vy[k] = al * (vy[k] + c * fy[k] + d * gg[1]);

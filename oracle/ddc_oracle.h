@@ -141,6 +141,16 @@ void orc_kinetic(const orc_params *p, int n, const double *vx, const double *vy,
 void orc_energyinfo(const orc_params *p, double natoms, int nConstraints, double eion, double rk,
                     const double *virial, const double *tion, double *out);
 
+/* LCG64_PARM (lcg64.h:8-12): the random state a particle carries */
+typedef struct orc_lcg64_parm { unsigned long long state; unsigned int multID, prime; } orc_lcg64_parm;
+typedef struct orc_primes { unsigned long long blockSize, taskId, nTasks, upperBound, prime, iBlock; } orc_primes;
+double orc_lcg64(orc_lcg64_parm *q);                       /* lcg64.c:127-135 */
+void orc_gasdev3d(orc_lcg64_parm *q, double g[3]);         /* random.c:135-160 */
+int orc_is_prime1(unsigned long long N);                   /* primes.c:120-155 */
+void orc_prime_init(orc_primes *g, unsigned blockSize, unsigned taskId, unsigned nTasks);      /* primes.c:25-31 */
+unsigned long long orc_next_prime(orc_primes *g);          /* primes.c:35-63 */
+void orc_lcg64_default(int n, const uint64_t *label, unsigned taskId, unsigned nTasks, orc_lcg64_parm *out);   /* collection.c:95-109, lcg64.c:98-110 */
+
 /* thermostat description per group (group.c:48-90) */
 typedef struct orc_group
 {
@@ -151,6 +161,7 @@ typedef struct orc_group
    double lambda, Tsum; int nT, doScaling;
    double temperature; /* g->energyInfo.temperature, refreshed by orc_group_temperature */
    unsigned long long seed;   /* langevin: seed of the counter-based normal stream (see orc_gauss3) */
+   orc_lcg64_parm *lcg;       /* langevin: not NULL = the reference's per-particle LCG64 streams, [n] in particle order (advanced in place) */
 } orc_group;
 
 /* nglf (nglf.c:67-112): one velocity-Verlet step.  Rebuilds the list when

@@ -41,7 +41,11 @@ class OrcParams(ctypes.Structure):
 class OrcGroup(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int), ("Teq", ctypes.c_double), ("tau", ctypes.c_double), ("interval", ctypes.c_int),
                 ("lambda_", ctypes.c_double), ("Tsum", ctypes.c_double), ("nT", ctypes.c_int), ("doScaling", ctypes.c_int),
-                ("temperature", ctypes.c_double), ("seed", ctypes.c_ulonglong)]
+                ("temperature", ctypes.c_double), ("seed", ctypes.c_ulonglong), ("lcg", ctypes.c_void_p)]
+
+
+# LCG64_PARM (lcg64.h:8-12) as a numpy record
+LCG64 = np.dtype([("state", "<u8"), ("multID", "<u4"), ("prime", "<u4")])
 
 
 def build(native=False, out=None):
@@ -87,6 +91,11 @@ def lib(path=None):
     L.orc_velocity_constraint.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, ctypes.c_double, ctypes.c_int, dp, dp, dp, dp, dp, dp, up, ip]
     L.orc_velocity_constraint.restype = ctypes.c_int
     L.orc_barostat_mol.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, dp, dp, dp, dp, dp, dp, up, ip, dp] + [ctypes.c_double] * 5 + [dp]
+    L.orc_lcg64.restype = ctypes.c_double
+    L.orc_lcg64.argtypes = [ctypes.c_void_p]
+    L.orc_gasdev3d.argtypes = [ctypes.c_void_p, dp]
+    L.orc_is_prime1.argtypes = [ctypes.c_ulonglong]
+    L.orc_lcg64_default.argtypes = [ctypes.c_int, up, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
     _libs[path] = L
     return L
 
@@ -99,10 +108,25 @@ def _i(a):
     return a.ctypes.data_as(ip)
 
 
+def lcg64_default(labels, task=0, ntasks=1, libpath=None):
+    """the random state particles get when their file carries none (collection.c:95-109, lcg64.c:98-110, primes.c), in file order"""
+    labels = np.ascontiguousarray(labels, dtype=np.uint64)
+    out = np.zeros(len(labels), dtype=LCG64)
+    lib(libpath).orc_lcg64_default(len(labels), labels.ctypes.data_as(up), int(task), int(ntasks), out.ctypes.data)
+    return out
+
+
+def gasdev3d(parm, libpath=None):
+    """three unit normals from one particle's stream (random.c:135-160); parm: a 1-element LCG64 array, advanced in place"""
+    g = np.zeros(3)
+    lib(libpath).orc_gasdev3d(parm.ctypes.data, _d(g))
+    return g
+
+
 class Oracle(object):
     """The reference CPU path on one rank, driven from a ddcmd_amd.Setup."""
 
-    def __init__(self, setup, libpath=None, constraints=False):
+    def __init__(self, setup, libpath=None, constraints=False, lcg64="deck"):
         self.L = lib(libpath)
         s = self.s = setup
         self._keep = {}
@@ -162,6 +186,9 @@ class Oracle(object):
             self.groups[g].tau = s.group_tau[g]
             self.groups[g].interval = max(1, int(s.group_interval[g]))
             self.groups[g].lambda_ = 1.0
+        self.lcg = None
+        if getattr(s, "lcg64", None) is not None and lcg64 == "deck" and np.any(np.asarray(s.group_type) == 2):
+            self.set_lcg64(s.lcg64)       # RANDOM type=LCG64 in the deck (one task: system.c:135, langevin.c:95-96)
         self.nbr = None
         self.loop = ctypes.c_long(int(s.loop))
         self.time = ctypes.c_double(float(s.time))
@@ -259,6 +286,13 @@ class Oracle(object):
     @property
     def box(self):
         return np.array([self.p.hxx, self.p.hyy, self.p.hzz])
+
+    def set_lcg64(self, parms):
+        """LANGEVIN groups draw from the reference's per-particle LCG64 streams (parms: LCG64 records in particle order, advanced in place)"""
+        self.lcg = np.ascontiguousarray(parms, dtype=LCG64).copy()
+        assert len(self.lcg) == self.n
+        for g in range(self.s.ngroup):
+            self.groups[g].lcg = self.lcg.ctypes.data
 
     def step(self, nsteps=1, dt=None):
         """nglf steps; forces()/first energy call must have run once (firstEnergyCall, masters.c:579)."""

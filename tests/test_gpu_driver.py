@@ -120,6 +120,49 @@ def test_ddcmi_md_checkpoint_restart(tmp_path):
     assert np.abs(s2.vz - o.vz).max() < 1e-6 * np.abs(o.vz).max()
 
 
+def test_ddcmi_md_langevin_on_the_particles_lcg64_streams_across_a_restart(tmp_path):
+    """RANDOM type=LCG64 + a LANGEVIN group: the driver hands the particles' streams (default values: the deck's atoms file
+    has no random field) to the device, the run follows the oracle drawing from the same streams (langevin.c:92-128 over
+    gasdev3d), the snapshot carries the advanced states behind the velocities (collection_write.c:157-161), and a second run
+    from that snapshot continues the same noise: after 40 steps the streams are in the oracle's states bit for bit"""
+    cwd = str(tmp_path)
+    lang = "group GROUP { type = LANGEVIN; Teq = 310 K; tau = 0.5 ps; } "
+    x1 = lang + "simulate SIMULATE { maxloop = 20; checkpointrate = 20; printrate = 10; }"
+    out = subprocess.run([EXE, "-o", DECK, "-d", "data1", "-x", x1], capture_output=True, text=True, timeout=300, cwd=cwd)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "LCG64 streams of" in out.stdout and "at their default values" in out.stdout
+    s0 = load_deck(DECK, extra_objects=x1)
+    assert list(s0.group_type) == [2] and s0.lcg64 is not None
+    o = pyoracle.Oracle(s0)
+    assert o.lcg is not None
+    e, vir = o.forces()
+    rk, _ = o.kinetic()
+    rows = _rows(os.path.join(cwd, "data1"))
+    cE = units_convert(1, None, "kJ/mol")
+    for k in range(3):
+        assert abs(rows[k][3] - cE * rk / s0.natoms) < 1e-6 * abs(rows[k][3]) + 1e-9, k
+        assert abs(rows[k][4] - cE * e["total"] / s0.natoms) < 1e-6 * abs(rows[k][4]) + 1e-9, k
+        if k < 2:
+            e, vir, rk, _ = o.step(10)
+    snap = os.path.join(cwd, "snapshot.%012d" % 20)
+    head = open(os.path.join(snap, "atoms#000000")).read(1500)
+    assert "random = lcg64;" in head and "randomFieldSize = 27;" in head
+    s1 = load_deck(DECK, restart_file=os.path.join(cwd, "restart"), extra_objects=x1)
+    assert s1.loop == 20 and s1.lcg_from_file == 1
+    assert (s1.lcg64["state"] == o.lcg["state"]).all() and (s1.lcg64["prime"] == s0.lcg64["prime"]).all() and (s1.lcg64["multID"] == s0.lcg64["multID"]).all()
+    assert (s1.lcg64["state"] != s0.lcg64["state"]).all()
+    x2 = lang + "simulate SIMULATE { maxloop = 40; checkpointrate = 20; printrate = 10; }"
+    out = subprocess.run([EXE, "-o", DECK, "-r", "restart", "-d", "data2", "-x", x2], capture_output=True, text=True, timeout=300, cwd=cwd)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "from the atoms file" in out.stdout
+    o.step(20)
+    s2 = load_deck(DECK, restart_file=os.path.join(cwd, "snapshot.%012d" % 40, "restart"), extra_objects=x2)
+    assert s2.loop == 40 and (s2.lcg64["state"] == o.lcg["state"]).all()
+    assert np.abs(s2.vx - o.vx).max() < 1e-6 * np.abs(o.vx).max()
+    rows2 = _rows(os.path.join(cwd, "data2"))
+    assert abs(rows2[-1][3] - cE * o.rk.value / s0.natoms) < 1e-6 * abs(rows2[-1][3])
+
+
 def test_ddcmi_md_molecular_pressure(tmp_path):
     """PRINTINFO printMolecularPressure=1 (molecularPressure.c:22-67): the Press column becomes the molecular
     pressure = (atomic virial - sum_atoms (r - R_mol).f + N_mol kB T) / V"""

@@ -467,6 +467,50 @@ def test_langevin_group_matches_oracle_and_thermalises():
     m.close()
 
 
+def test_langevin_group_on_the_reference_lcg64_streams():
+    """RANDOM type LCG64 (lcg64.c:127-146, gasdev3d random.c:135-160): with the particles' own streams set, the device draws
+    the numbers the reference's CPU code draws -- the trajectory follows the oracle across a rebuild (fused and split kick
+    kernels alike), the streams end in the oracle's states bit for bit, and a different state array gives another trajectory"""
+    from ddcmd_amd.martini import MartiniHIP, DdcmiError
+    s = make_water_setup(10)
+    s.group_type = np.array([2], np.int32)
+    s.group_Teq = np.array([units_convert(310.0, "K")])
+    s.group_tau = np.array([units_convert(0.2, "ps")])
+    parms = pyoracle.lcg64_default(s.gid)
+    o = pyoracle.Oracle(s)
+    o.set_lcg64(parms)
+    o.forces()
+    m = MartiniHIP(s)
+    m.set_random_lcg64(parms)
+    assert (m.get_random_lcg64() == parms).all()
+    m.eval_forces()
+    for block in range(5):
+        eo, vo, rko, _ = o.step(5)
+        m.step(5 if block % 2 else 1)
+        if block % 2 == 0:
+            m.step(4)
+        e, vir, rk, _ = m.energies()
+        assert abs(rk - rko) < TOL * rko, block
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+    assert m.list_stats()["rebuilds"] >= 2
+    got = m.get_random_lcg64()
+    assert (got["state"] == o.lcg["state"]).all() and (got["multID"] == parms["multID"]).all() and (got["prime"] == parms["prime"]).all()
+    assert (got["state"] != parms["state"]).all()
+    d = m.download()
+    assert np.abs(d["v"][0] - o.vx).max() < 1e-6 * np.abs(o.vx).max()
+    # an invalid record (lcg64_checkValue: even prime) and a wrong count are refused
+    bad = parms.copy(); bad["prime"][7] = 4
+    with pytest.raises(DdcmiError, match="not a valid LCG64 state"):
+        m.set_random_lcg64(bad)
+    with pytest.raises(DdcmiError, match="records for"):
+        m.set_random_lcg64(parms[:-1])
+    # cleared: the counter-based stream again (another trajectory than the oracle's LCG64 one)
+    m.set_random_lcg64(None)
+    m.step(5); o.step(5)
+    assert abs(m.energies()[2] - o.rk.value) > 1e-6 * o.rk.value
+    m.close()
+
+
 RESTRAINT_X = ("system SYSTEM { potential = martini restraintPot; } "
                "restraintPot POTENTIAL { type = RESTRAINT; parmfile = restraint.data; }")
 

@@ -432,3 +432,135 @@ def test_crc32_known_answer_and_corrupted_snapshots(tmp_path):
     with pytest.raises(Exception) as ei:
         load_deck(os.path.join(deck, "object.data"), restart_file=short)
     assert "nrecord" in str(ei.value)
+
+
+def _is_prime(n):
+    if n < 2 or n % 2 == 0:
+        return n == 2
+    i = 3
+    while i * i <= n:
+        if n % i == 0:
+            return False
+        i += 2
+    return True
+
+
+def test_lcg64_streams_known_answers():
+    """RANDOM type LCG64 as the oracle restates it (lcg64.c:127-146, random.c:135-160, primes.c:35-155, collection.c:95-109),
+    against arithmetic done here with Python integers: the recurrence, the polar normals, the default states."""
+    L = pyoracle.lib()
+    MULT = [0x27bb2ee687b0b0fd, 0x2c6fe96ee78b6955, 0x369dea0f31a53f85]
+    for mult_id, prime, state in ((0, 2147453653, 0x2bc6ffff8cfe166d), (1, 2147483659, 1), (2, 4294967291, 0xffffffffffffffff)):
+        q = np.zeros(1, dtype=pyoracle.LCG64)
+        q["state"], q["multID"], q["prime"] = state, mult_id, prime
+        st = state
+        for _ in range(50):
+            u = L.orc_lcg64(q.ctypes.data)
+            st = (MULT[mult_id] * st + prime) % (1 << 64)
+            assert int(q["state"][0]) == st
+            assert u == float(st) * 2.0 ** -64 and 0.0 <= u <= 1.0
+        # gasdev3d: two polar draws over pairs of uniforms; x, y of the first accepted pair and x of the second
+        ref = []
+        for _ in range(200):
+            g = []
+            for draw in range(2):
+                while True:
+                    st = (MULT[mult_id] * st + prime) % (1 << 64); x = 2.0 * (float(st) * 2.0 ** -64) - 1.0
+                    st = (MULT[mult_id] * st + prime) % (1 << 64); y = 2.0 * (float(st) * 2.0 ** -64) - 1.0
+                    rsq = x * x + y * y
+                    if 0.0 < rsq < 1.0:
+                        break
+                fac = np.sqrt(-2.0 * np.log(rsq) / rsq)
+                g += [x * fac, y * fac] if draw == 0 else [x * fac]
+            ref.append(g)
+        got = np.array([pyoracle.gasdev3d(q) for _ in range(200)])
+        assert int(q["state"][0]) == st                      # the same number of uniforms was consumed
+        assert np.abs(got - np.array(ref)).max() < 1e-14
+    # unit normals: moments over 3 x 100 000 draws
+    q = np.zeros(1, dtype=pyoracle.LCG64)
+    q["state"], q["multID"], q["prime"] = 0x2bc6ffff8cfe166d ^ (77 << 32), 1, 2147453657
+    g = np.array([pyoracle.gasdev3d(q) for _ in range(100000)])
+    assert np.abs(g.mean(axis=0)).max() < 0.02 and np.abs(g.var(axis=0) - 1.0).max() < 0.02
+    assert abs(np.mean(g ** 4) - 3.0) < 0.1 and np.abs(np.corrcoef(g.T) - np.eye(3)).max() < 0.02
+    # default states (file order on one task): INIT_SEED ^ label, multID 0,1,2,..., one prime per three particles --
+    # the odd primes of the task's blocks of 30000 numbers, the first block ending at 2^31 + 1
+    labels = (np.arange(1, 601, dtype=np.uint64) << np.uint64(32)) | np.uint64(5)
+    for task, ntasks in ((0, 1), (3, 8)):
+        d = pyoracle.lcg64_default(labels, task, ntasks)
+        assert (d["state"] == (np.uint64(0x2bc6ffff8cfe166d) ^ labels)).all()
+        assert (d["multID"] == np.arange(600) % 3).all()
+        assert (d["prime"][0::3] == d["prime"][1::3]).all() and (d["prime"][0::3] == d["prime"][2::3]).all()
+        want, block = [], 0
+        while len(want) < 200:
+            hi = (block * ntasks + task) * 30000 + (1 << 31) + 1
+            lo = hi - 30000
+            hi -= (hi % 2 == 0)
+            lo += (lo % 2 == 0)
+            want += [x for x in range(lo, hi, 2) if _is_prime(x)]
+            block += 1
+        assert [int(x) for x in d["prime"][0::3]] == want[:200]
+    # isPrime1 itself on Carmichael numbers, strong pseudoprimes to base 2 and prime squares
+    for n, expect in ((561, 0), (2047, 0), (3215031751, 0), (4294967291, 1), (4294967297, 0), (2147483647, 1), (46349 * 46349, 0), (2147483659, 1)):
+        assert L.orc_is_prime1(n) == expect, n
+
+
+def test_atoms_random_field_and_default_streams(tmp_path):
+    """RANDOM type=LCG64 in the deck (system.c:135, random.c:44-71): the atoms reader takes "state multID prime" behind the
+    velocities of every record (collection_read.c:160-166, lcg64_parse lcg64.c:89-95); a file written with random = NONE, or a
+    single record without the field, puts every particle on lcg64_default's values (collection.c:95-109) -- which the
+    loader (Miller-Rabin) and the oracle (the reference's own primality test, restated) derive independently"""
+    import os
+    import ctypes
+    from ddcmd_amd.deck import load_deck, units_convert
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s0 = load_deck(os.path.join(deck, "object.data"))
+    assert s0.lcg64 is not None and s0.lcg_from_file == 0 and len(s0.lcg64) == s0.natoms
+    want = pyoracle.lcg64_default(s0.gid)
+    assert (s0.lcg64 == want).all()
+    # the 6173-bead water deck: 2058 primes further up the same sequence
+    sw = load_deck(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "water_deck", "object.data"))
+    assert (sw.lcg64 == pyoracle.lcg64_default(sw.gid)).all() and len(set(sw.lcg64["prime"].tolist())) == (sw.natoms + 2) // 3
+    # a deck without a RANDOM object carries no streams
+    s_none = load_deck(os.path.join(deck, "object.data"), extra_objects="system SYSTEM { random = NONE; }")
+    assert s_none.lcg64 is None
+    A = units_convert(1.0, None, "Angstrom")
+    lib = ddcmd_amd.load_library()
+    lib.ddcmi_crc32.restype = ctypes.c_uint32
+    lib.ddcmi_crc32.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    rng = np.random.default_rng(5)
+    mine = np.zeros(s0.natoms, dtype=pyoracle.LCG64)
+    mine["state"] = rng.integers(1, 2 ** 63, s0.natoms, dtype=np.uint64) * 2 + 1
+    mine["multID"] = rng.integers(0, 3, s0.natoms)
+    mine["prime"] = want["prime"][::-1]
+
+    def write(dirname, header_random, skip_record=None):
+        snap = tmp_path / dirname / "snapshot.000000000040"
+        snap.mkdir(parents=True)
+        with open(snap / "atoms#000000", "w") as f:
+            f.write("particle FILEHEADER {type=MULTILINE; datatype=FIXRECORDASCII; checksum=CRC32; create_time=x; run_id=0x00000000;\n"
+                    "loop=40; time=400.000000 fs;\nnfiles=1; nrecord=%d; lrec=264; nfields=11; endian_key=875770417;\n"
+                    "field_names=checksum id class type group rx ry rz vx vy vz;\nfield_types=u u s s s f f f f f f;\n"
+                    "field_units=1 1 1 1 1 Ang Ang Ang Ang/fs Ang/fs Ang/fs;\n"
+                    "h=%f 0 0\n  0 %f 0\n  0 0 %f Ang;\n%sgroups = group;\ntypes = ATOM;\n}\n\n"
+                    % (s0.natoms, s0.h[0] * A, s0.h[4] * A, s0.h[8] * A, header_random))
+            for i in range(s0.natoms):
+                body = " %12.12d ATOM %s group %21.13e %21.13e %21.13e %21.13e %21.13e %21.13e" % (
+                    int(s0.gid[i]), s0.species_name[int(s0.species[i])], s0.rx[i] * A, s0.ry[i] * A, s0.rz[i] * A,
+                    s0.vx[i] * A, s0.vy[i] * A, s0.vz[i] * A)
+                if i != skip_record:
+                    body += " %16.16x %1u %8.8x" % (int(mine["state"][i]), int(mine["multID"][i]), int(mine["prime"][i]))      # lcg64_write
+                body = body.ljust(255) + "\n"
+                f.write("%08x" % lib.ddcmi_crc32(body.encode(), len(body)) + body)
+        with open(tmp_path / dirname / "restart", "w") as f:
+            f.write("simulate SIMULATE { run_id=0x0; loop=40; time=400.000000 fs;}\nbox BOX {\n h  = %.14e 0 0\n 0 %.14e 0\n 0 0 %.14e;\n}\n"
+                    "collection COLLECTION { size=%d; files=%s/atoms#;}\n" % (s0.h[0] * A, s0.h[4] * A, s0.h[8] * A, s0.natoms, snap))
+        return load_deck(os.path.join(deck, "object.data"), restart_file=str(tmp_path / dirname / "restart"))
+
+    s1 = write("a", "random = lcg64;\nrandomFieldSize = 27;\n")
+    assert s1.lcg_from_file == 1 and (s1.lcg64 == mine).all()
+    s2 = write("b", "")                                      # no `random` key in the header: the records are tried (collection_read.c:102-104)
+    assert s2.lcg_from_file == 1 and (s2.lcg64 == mine).all()
+    s3 = write("c", "random = NONE;\nrandomFieldSize = 0;\n")      # the header says there is none: defaults, whatever follows vz
+    assert s3.lcg_from_file == 0 and (s3.lcg64 == want).all()
+    s4 = write("d", "random = lcg64;\nrandomFieldSize = 27;\n", skip_record=17)      # one record without the field: defaults for all
+    assert s4.lcg_from_file == 0 and (s4.lcg64 == want).all()
