@@ -210,7 +210,8 @@ __global__ void k_gather_state(int nloc, const int *order,
                                const double4 *pos, const double *vx, const double *vy, const double *vz,
                                const int *species, const int *group, const uint64_t *gid, const int *orig,
                                double4 *pos2, double *vx2, double *vy2, double *vz2,
-                               int *species2, int *group2, uint64_t *gid2, int *orig2, int *slot_of_orig, GridParams gp, int *nimg, int wrap)
+                               int *species2, int *group2, uint64_t *gid2, int *orig2, int *slot_of_orig, GridParams gp, int *nimg, int wrap,
+                               const ulonglong2 *lcg, ulonglong2 *lcg2 /* the beads' LCG64 records, nullptr without them */)
 {
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= nloc) return;
@@ -229,6 +230,7 @@ __global__ void k_gather_state(int nloc, const int *order,
    int o = orig[i];
    orig2[k] = o;
    if (slot_of_orig) slot_of_orig[o] = k;      /* (a scattered store per bead: only where something names beads by caller index) */
+   if (lcg) lcg2[k] = lcg[i];
 }
 
 __global__ void k_slots_from_orig(int nloc, const int *__restrict__ orig, int *slot_of_orig)
@@ -1533,7 +1535,7 @@ __global__ void k_finish_energy(double *r, double self_ele)
  * decomposition or launch shape -- statistical, not bitwise, parity with ddcMD. */
 struct GroupLambda { double v[32]; double a[32]; double dfac[32]; unsigned lang_mask; unsigned long long seed, counter_front, counter_back;
                      double scale[3]; /* barostat: positions are scaled by this (adjustPosn) before the drift; 1 otherwise */
-                     ulonglong2 *lcg; const int *orig; /* RANDOM type LCG64 (ddcmi_set_random_lcg64): the reference's per-particle streams, by caller index */ };
+                     ulonglong2 *lcg; /* RANDOM type LCG64 (ddcmi_set_random_lcg64): the beads' own streams (the reference's), in slot order; nullptr = the counter-based stream */ };
 __device__ __forceinline__ unsigned long long smix64(unsigned long long z)
 {
    z += 0x9E3779B97F4A7C15ull;
@@ -1552,8 +1554,8 @@ __device__ __forceinline__ void gauss3(unsigned long long seed, unsigned long lo
    g2 = sqrt(-2.0 * log(u3)) * cos(6.283185307179586476925 * u4);
 }
 /* The reference's own noise: lcg64_2 (lcg64.c:137-146) under gasdev3d (random.c:135-160) -- two polar draws, x and y from the
- * first accepted pair, z from the second.  A record is LCG64_PARM {state; multID, prime}; it lives at the bead's caller index
- * and only its state moves.  The products and the sum of rsq are rounded one by one, as the accept test of the CPU code sees them. */
+ * first accepted pair, z from the second.  A record is LCG64_PARM {state; multID, prime}; it travels with its bead (sorts,
+ * migration) and only its state changes.  The products and the sum of rsq are rounded one by one, as the accept test of the CPU code sees them. */
 __device__ __forceinline__ void lcg_pair(unsigned long long &st, unsigned long long mult, unsigned long long prime, double &x, double &y, double &rsq)
 {
    do
@@ -1581,7 +1583,7 @@ __device__ __forceinline__ void lcg_gauss3(ulonglong2 *lcg, int o, double &g0, d
 }
 __device__ __forceinline__ void group_gauss3(const GroupLambda &gl, int i, const uint64_t *gid, unsigned long long counter, double &g0, double &g1, double &g2)
 {
-   if (gl.lcg) lcg_gauss3(gl.lcg, gl.orig[i], g0, g1, g2);
+   if (gl.lcg) lcg_gauss3(gl.lcg, i, g0, g1, g2);
    else gauss3(gl.seed, gid[i], counter, g0, g1, g2);
 }
 __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ invmass, const int *__restrict__ species,
@@ -2243,42 +2245,54 @@ extern "C" int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed)
    return DDCMI_OK;
 }
 
-/* RANDOM type LCG64: the particles' own streams (LCG64_PARM records in the caller order of ddcmi_upload_state) */
+/* RANDOM type LCG64: the particles' own streams (LCG64_PARM records in the caller order of ddcmi_upload_state).  On the device
+ * they lie in slot order like every other per-bead array and move with the beads (k_gather_state, the migration records). */
+static inline bool lcg_decomposed(const ddcmi_ctx *ctx) { return ctx->nranks > 1 || ctx->loopback || ctx->group_ != nullptr; }
 extern "C" int ddcmi_set_random_lcg64(ddcmi_ctx *ctx, int n, const uint64_t *state, const uint32_t *multID, const uint32_t *prime)
 {
    if (!ctx) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
-   if (n == 0 || !state) { ctx->lcg_n = 0; return DDCMI_OK; }      /* back to the counter-based stream */
+   if (n == 0 || !state) { ctx->lcg_on = false; return DDCMI_OK; }      /* back to the counter-based stream */
    if (!multID || !prime) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: multID and prime are needed with the states");
-   if (ctx->nranks > 1 || ctx->loopback || ctx->group_)
-      SETERR(ctx, DDCMI_EUNSUPPORTED, "per-particle LCG64 streams are kept by caller index and do not migrate: one domain only (decomposed runs draw from the counter-based stream)");
    if (n != ctx->nloc) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: %d records for %d uploaded beads", n, ctx->nloc);
-   std::vector<ulonglong2> h((size_t)n);
-   for (int i = 0; i < n; i++)
-   {
-      /* lcg64_checkValue (lcg64.c:111-120) */
+   if (lcg_decomposed(ctx) && ctx->nrebuild > 0)
+      SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: the beads of a decomposed run leave their caller order at the first list build; set the streams after ddcmi_upload_state");
+   for (int i = 0; i < n; i++)      /* lcg64_checkValue (lcg64.c:111-120) */
       if (multID[i] > 2 || state[i] == 0 || prime[i] % 2 == 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: record %d {%llx %u %x} is not a valid LCG64 state", i, (unsigned long long)state[i], multID[i], prime[i]);
-      h[i].x = state[i]; h[i].y = (unsigned long long)multID[i] | ((unsigned long long)prime[i] << 32);
+   std::vector<int> orig((size_t)n);
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   HIPCHK(ctx, hipMemcpy(orig.data(), ctx->orig.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+   std::vector<ulonglong2> h((size_t)n);
+   for (int k = 0; k < n; k++)
+   {
+      const int i = orig[k];      /* slot k holds the bead of caller index i (identity until the first sort) */
+      if (i < 0 || i >= n) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_random_lcg64: slot %d names caller index %d", k, i);
+      h[k].x = state[i]; h[k].y = (unsigned long long)multID[i] | ((unsigned long long)prime[i] << 32);
    }
-   ENSURE(ctx, ctx->lcg, (size_t)n);
+   ENSURE(ctx, ctx->lcg, (size_t)n + 1); ENSURE(ctx, ctx->lcg2, (size_t)n + 1);
    HIPCHK(ctx, hipMemcpy(ctx->lcg.p, h.data(), (size_t)n * sizeof(ulonglong2), hipMemcpyHostToDevice));
-   ctx->lcg_n = n;
+   ctx->lcg_on = true;
    return DDCMI_OK;
 }
 extern "C" int ddcmi_get_random_lcg64(ddcmi_ctx *ctx, int n, uint64_t *state, uint32_t *multID, uint32_t *prime)
 {
    if (!ctx || !state) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
-   if (ctx->lcg_n == 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_get_random_lcg64: no LCG64 streams are set");
-   if (n != ctx->lcg_n) SETERR(ctx, DDCMI_EINVAL, "ddcmi_get_random_lcg64: %d records asked, %d held", n, ctx->lcg_n);
+   if (!ctx->lcg_on) SETERR(ctx, DDCMI_EINVAL, "ddcmi_get_random_lcg64: no LCG64 streams are set");
+   if (n != ctx->nloc) SETERR(ctx, DDCMI_EINVAL, "ddcmi_get_random_lcg64: %d records asked, %d beads held", n, ctx->nloc);
+   if (n == 0) return DDCMI_OK;
    std::vector<ulonglong2> h((size_t)n);
+   std::vector<int> orig((size_t)n);
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    HIPCHK(ctx, hipMemcpy(h.data(), ctx->lcg.p, (size_t)n * sizeof(ulonglong2), hipMemcpyDeviceToHost));
-   for (int i = 0; i < n; i++)
+   const bool by_slot = lcg_decomposed(ctx);      /* a decomposed run: the order of ddcmi_download_particles */
+   if (!by_slot) HIPCHK(ctx, hipMemcpy(orig.data(), ctx->orig.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+   for (int k = 0; k < n; k++)
    {
-      state[i] = h[i].x;
-      if (multID) multID[i] = (uint32_t)h[i].y;
-      if (prime) prime[i] = (uint32_t)(h[i].y >> 32);
+      const int i = by_slot ? k : orig[k];
+      state[i] = h[k].x;
+      if (multID) multID[i] = (uint32_t)h[k].y;
+      if (prime) prime[i] = (uint32_t)(h[k].y >> 32);
    }
    return DDCMI_OK;
 }
@@ -2321,7 +2335,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
       for (int i = 0; i < nlocal; i++)
          if (group[i] < 0 || group[i] >= ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "particle %d has group %d outside [0,%d)", i, group[i], ctx->ngroup);
    int n = nlocal;
-   if (ctx->lcg_n != nlocal) ctx->lcg_n = 0;      /* the streams belong to the caller indices of the upload they followed */
+   ctx->lcg_on = false;      /* the streams belong to the beads of the upload they followed: ddcmi_set_random_lcg64 again */
    size_t cap = (size_t)n + n / 4 + 1024;     /* room for image atoms; grown on demand */
    ENSURE(ctx, ctx->pos, cap); ENSURE(ctx, ctx->pos2, cap);
    ENSURE(ctx, ctx->gid, cap); ENSURE(ctx, ctx->gid2, cap);
@@ -2537,12 +2551,15 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
       else
          hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
       /* caller index -> slot: a scattered store per bead, kept up only where something reads it every step */
+      if (ctx->lcg_on) ENSURE(ctx, ctx->lcg2, (size_t)n + 1);
       const bool slots = (!ctx->bonded_gid && ctx->inc_nrow > 0) || (!ctx->cons_gid && ctx->ncgroup > 0) || (!ctx->mol_gid && ctx->nmol_multi > 0);
       hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
                          ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
                          ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p,
                          slots ? ctx->slot_of_orig.p : (int *)nullptr,
-                         gp, (ctx->nranks == 1 && !ctx->loopback && !ctx->group_) ? ctx->nimg.p : (int *)nullptr, 1);
+                         gp, (ctx->nranks == 1 && !ctx->loopback && !ctx->group_) ? ctx->nimg.p : (int *)nullptr, 1,
+                         ctx->lcg_on ? ctx->lcg.p : (const ulonglong2 *)nullptr, ctx->lcg2.p);
+      if (ctx->lcg_on) std::swap(ctx->lcg, ctx->lcg2);
       ctx->slot_valid = slots;
       std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
       std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
@@ -3116,7 +3133,7 @@ static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
 {
    GroupLambda lam;
    lam.lang_mask = 0; lam.seed = ctx->rng_seed;
-   lam.lcg = ctx->lcg_n > 0 ? ctx->lcg.p : nullptr; lam.orig = ctx->orig.p;
+   lam.lcg = ctx->lcg_on ? ctx->lcg.p : nullptr;
    lam.scale[0] = lam.scale[1] = lam.scale[2] = 1.0;
    /* the FRONT update of a step sees the loop count before its increment, the BACK update the one after */
    lam.counter_front = 2ull * (unsigned long long)ctx->loop;

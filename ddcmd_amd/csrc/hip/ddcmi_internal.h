@@ -181,7 +181,7 @@ struct ddcmi_ctx
    double baro_T = 0, baro_P0 = 0, baro_beta = 0, baro_tau = 0;      /* NGLFCONSTRAINT's Berendsen barostat; beta = 0: off */
    bool baro_iso = false;                                           /* one scale factor from the mean of the three pressures (changeVolumeGPUisotropic) */
    double pmol[3] = {0, 0, 0};                                      /* molecular pressure (xx, yy, zz) the barostat last acted on */
-   dbuf<ulonglong2> lcg; int lcg_n = 0; /* Langevin groups, RANDOM type LCG64: LCG64_PARM {state; multID | prime << 32} by caller index; 0 = the counter-based stream */
+   dbuf<ulonglong2> lcg, lcg2; bool lcg_on = false; /* Langevin groups, RANDOM type LCG64: LCG64_PARM {state; multID | prime << 32} of the owned beads in slot order; off = the counter-based stream */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool slot_valid = false;            /* slot_of_orig (caller index -> device slot) belongs to the current order: refilled by the sort of a rebuild only when something
                                           names beads by caller index (bonded terms, constraint groups, molecule lists), else on demand (ddcmi_ensure_slots) */

@@ -79,9 +79,9 @@ __global__ void k_iota(int n, int *a)
 struct MigGeom { double L[3], W[3]; int P[3], pc[3], pbc; };
 
 /* ownership (voronoiCalcParticleDestinations for a cubic lattice of centres =
- * brick index) + packing of the beads that leave: record = x y z tag vx vy vz gid group - */
+ * brick index) + packing of the beads that leave: record = x y z tag vx vy vz gid {group, LCG64 multID, prime} {LCG64 state} */
 __global__ void k_mig_classify(MigGeom mg, int nloc, int mig_cap, double4 *pos, const double *vx, const double *vy, const double *vz,
-                               const uint64_t *gid, const int *group, int *keep, int *dir_cnt, double *mig_out, int *flags)
+                               const uint64_t *gid, const int *group, int *keep, int *dir_cnt, double *mig_out, int *flags, const ulonglong2 *lcg)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i == 0) dir_cnt[27] = mig_cap;      /* travels with the counts: every rank sees whether any rank's segments overflowed */
@@ -115,7 +115,10 @@ __global__ void k_mig_classify(MigGeom mg, int nloc, int mig_cap, double4 *pos, 
          rec[0] = p.x; rec[1] = p.y; rec[2] = p.z; rec[3] = p.w;
          rec[4] = vx[i]; rec[5] = vy[i]; rec[6] = vz[i];
          rec[7] = __longlong_as_double((long long)gid[i]);
-         rec[8] = (double)group[i]; rec[9] = 0.0;
+         /* [8] group | multID << 8 | prime << 32, [9] the LCG64 state (bit patterns; both zero beyond the group without streams) */
+         const ulonglong2 q = lcg ? lcg[i] : make_ulonglong2(0ull, 0ull);
+         rec[8] = __longlong_as_double((long long)((unsigned long long)(group[i] & 0xff) | (q.y & 3ull) << 8 | (q.y >> 32) << 32));
+         rec[9] = __longlong_as_double((long long)q.x);
       }
    }
 }
@@ -125,7 +128,7 @@ __global__ void k_compact_order(int n, const int *keep, const int *scan, int *or
    if (i < n && keep[i]) order[scan[i]] = i;
 }
 __global__ void k_unpack_mig(int narr, int nkeep, const double *mig_in, double4 *pos, double *vx, double *vy, double *vz,
-                             uint64_t *gid, int *species, int *group, int *orig)
+                             uint64_t *gid, int *species, int *group, int *orig, ulonglong2 *lcg)
 {
    int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= narr) return;
@@ -135,7 +138,9 @@ __global__ void k_unpack_mig(int narr, int nkeep, const double *mig_in, double4 
    vx[i] = rec[4]; vy[i] = rec[5]; vz[i] = rec[6];
    gid[i] = (uint64_t)__double_as_longlong(rec[7]);
    species[i] = (int)((__double_as_longlong(rec[3]) >> 16) & 0xffff);
-   group[i] = (int)rec[8];
+   const unsigned long long w = (unsigned long long)__double_as_longlong(rec[8]);
+   group[i] = (int)(w & 0xffull);
+   if (lcg) lcg[i] = make_ulonglong2((unsigned long long)__double_as_longlong(rec[9]), (w >> 8 & 3ull) | (w >> 32) << 32);
    orig[i] = i;
 }
 
@@ -288,11 +293,13 @@ static int mg_ensure_owned(ddcmi_ctx *ctx, size_t need)
 {
    hipStream_t st = ctx->stream;
    size_t want = need + need / 4 + 4096;
-   if (ctx->vx.cap >= need && ctx->species.cap >= need + 1 && ctx->pos.cap >= need) return DDCMI_OK;
+   const bool lcg_fits = !ctx->lcg_on || (ctx->lcg.cap >= need + 1 && ctx->lcg2.cap >= need + 1);
+   if (ctx->vx.cap >= need && ctx->species.cap >= need + 1 && ctx->pos.cap >= need && lcg_fits) return DDCMI_OK;
    dbuf<double> *d3[] = {&ctx->vx, &ctx->vy, &ctx->vz, &ctx->fx, &ctx->fy, &ctx->fz};
    for (auto b : d3) if (b->ensure(want, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
    dbuf<double> *d3b[] = {&ctx->vx2, &ctx->vy2, &ctx->vz2};
    for (auto b : d3b) if (b->ensure(want)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   if (ctx->lcg_on && (ctx->lcg.ensure(want + 1, true, st) || ctx->lcg2.ensure(want + 1))) SETERR(ctx, DDCMI_ENOMEM, "growing the LCG64 records to %zu failed", want);
    dbuf<int> *i1[] = {&ctx->species, &ctx->group, &ctx->orig};
    for (auto b : i1) if (b->ensure(want + 1, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
    dbuf<int> *i2[] = {&ctx->species2, &ctx->group2, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->nimg, &ctx->img_off, &ctx->keep};
@@ -644,7 +651,7 @@ static int mg_phase1_launch(ddcmi_ctx *ctx)
    {
       hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
       hipLaunchKernelGGL(k_mig_classify, dim3(cdiv(n, 256)), dim3(256), 0, st, mg, n, ctx->mig_cap, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
-                         ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags);
+                         ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags, ctx->lcg_on ? ctx->lcg.p : (const ulonglong2 *)nullptr);
    }
    return DDCMI_OK;
 }
@@ -686,14 +693,16 @@ static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
       {
          hipLaunchKernelGGL(k_gather_state, dim3(cdiv(nkeep, 256)), dim3(256), 0, st, nkeep, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
                             ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
-                            ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p, ctx->gp, (int *)nullptr, 0);
+                            ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p, ctx->slot_of_orig.p, ctx->gp, (int *)nullptr, 0,
+                            ctx->lcg_on ? ctx->lcg.p : (const ulonglong2 *)nullptr, ctx->lcg2.p);
       }
+      if (ctx->lcg_on) std::swap(ctx->lcg, ctx->lcg2);
       std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
       std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
    }
    if (narr > 0)
       hipLaunchKernelGGL(k_unpack_mig, dim3(cdiv(narr, 256)), dim3(256), 0, st, narr, nkeep, ctx->mig_in.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
-                         ctx->gid.p, ctx->species.p, ctx->group.p, ctx->orig.p);
+                         ctx->gid.p, ctx->species.p, ctx->group.p, ctx->orig.p, ctx->lcg_on ? ctx->lcg.p : (ulonglong2 *)nullptr);
    ctx->nloc = nkeep + narr;
    n = ctx->nloc;
    if (n > 0) hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
@@ -1168,10 +1177,6 @@ static int mg_check_one_domain_features(ddcmi_ctx *ctx)
    if (ctx->nranks > 1 && ((ctx->baro_beta > 0.0 && !ctx->mol_gid) || (ctx->ncgroup > 0 && !ctx->cons_gid)))
       SETERR(ctx, DDCMI_EUNSUPPORTED, "%d domains: the barostat and the velocity constraints (NGLFCONSTRAINT) work on a single domain unless the molecules and the "
              "constraint groups are named by gid (ddcmi_set_molecule_lists_gid, ddcmi_set_constraints_gid)", ctx->nranks);
-   bool lang = false;
-   for (int g = 0; g < ctx->ngroup; g++) lang |= ctx->gtype[g] == DDCMI_LANGEVIN;
-   if (ctx->lcg_n > 0 && lang && (ctx->nranks > 1 || ctx->loopback))
-      SETERR(ctx, DDCMI_EUNSUPPORTED, "per-particle LCG64 streams (ddcmi_set_random_lcg64) do not migrate between domains: clear them for a decomposed run");
    return DDCMI_OK;
 }
 /* RCCL bootstrap (the 128-byte id is distributed by the caller: MPI_Bcast in

@@ -642,7 +642,7 @@ void eval_energyInfo(SYSTEM *sys)
 
 /* more than one rank: the beads every rank owns now (they migrate), identified by gid, gathered on rank 0 in rank order;
  * collective.  Species and group come back as the deck's objects (the group of a bead is looked up by its gid). */
-typedef struct { uint64_t gid; int species, pad; double r[3], v[3], f[3]; } PREC;
+typedef struct { uint64_t gid; int species, pad; double r[3], v[3], f[3]; uint64_t lcg_state; uint32_t lcg_multID, lcg_prime; } PREC;
 static const ddcmi_setup *gather_setup = NULL;
 static gid_order *gather_tab = NULL;
 static int gather_state(SYSTEM *sys)
@@ -670,6 +670,14 @@ static int gather_state(SYSTEM *sys)
       q->gid = gid[i]; q->species = sp[i]; q->pad = 0;
       for (int k = 0; k < 3; k++) { q->r[k] = a[(size_t)k * cap + i]; q->v[k] = a[(size_t)(3 + k) * cap + i]; q->f[k] = a[(size_t)(6 + k) * cap + i]; }
    }
+   if (s->random_lcg64 && n > 0)
+   {
+      /* the LCG64 records of the beads this rank owns now, in the order of ddcmi_download_particles */
+      uint64_t *ls = malloc(sizeof(uint64_t) * (size_t)n); uint32_t *lm = malloc(sizeof(uint32_t) * 2 * (size_t)n);
+      if (ddcmi_get_random_lcg64(ctx, n, ls, lm, lm + n) != DDCMI_OK) die("sendHostState", ddcmi_last_error(ctx));
+      for (int i = 0; i < n; i++) { rec[i].lcg_state = ls[i]; rec[i].lcg_multID = lm[i]; rec[i].lcg_prime = lm[n + i]; }
+      free(ls); free(lm);
+   }
    free(gid); free(sp); free(a);
    if (par.rank != 0)
    {
@@ -696,6 +704,7 @@ static int gather_state(SYSTEM *sys)
          st->label[i] = q->gid; st->species[i] = sys->species[q->species]; st->group[i] = sys->group[s->group[hit->id]]; st->q[i] = st->species[i]->charge;
          st->rx[i] = q->r[0]; st->ry[i] = q->r[1]; st->rz[i] = q->r[2]; st->vx[i] = q->v[0]; st->vy[i] = q->v[1]; st->vz[i] = q->v[2];
          st->fx[i] = q->f[0]; st->fy[i] = q->f[1]; st->fz[i] = q->f[2];
+         if (s->random_lcg64) { ((ddcmi_setup *)s)->lcg_state[i] = q->lcg_state; ((ddcmi_setup *)s)->lcg_multID[i] = q->lcg_multID; ((ddcmi_setup *)s)->lcg_prime[i] = q->lcg_prime; }      /* the writer's order */
       }
       st->nlocal = st->nion = (int)tot;
    }
@@ -753,12 +762,13 @@ static int writeRestart_rank0(SIMULATE *simulate, const char *dir, int restartLi
    lrec += (int)(maxsp - 1) + (int)(maxgr - 1) + 1;
    /* the random field (collection_write.c:81-89,157-161): lcg64_write's "%16.16llx %1u %8.8x" behind the velocities */
    ddcmi_setup *su = simulate->setup;
-   const int rnd = su->random_lcg64 && par.world == 1 && st->nlocal == su->natoms;
+   const int rnd = su->random_lcg64 && st->nlocal == su->natoms;
    const int randomFieldSize = rnd ? 16 + 1 + 1 + 1 + 8 : 0;
    if (rnd)
    {
+      /* one rank: the advanced states in caller = file order, like STATE; several: gather_state left them in STATE's order */
       ddcmi_ctx *ctx = accelerator_getAccelerator(NULL)->parms;
-      if (ddcmi_get_random_lcg64(ctx, st->nlocal, su->lcg_state, su->lcg_multID, su->lcg_prime) != DDCMI_OK) { fclose(f); return -1; }
+      if (par.world == 1 && ddcmi_get_random_lcg64(ctx, st->nlocal, su->lcg_state, su->lcg_multID, su->lcg_prime) != DDCMI_OK) { fclose(f); return -1; }
       lrec += randomFieldSize + 1;
    }
    lrec = 8 * ((lrec + 7) / 8);
@@ -922,13 +932,23 @@ SIMULATE *simulate_init(const char *object_file, const char *restart_file, const
             lab[m] = s->gid[i]; sp[m] = s->species[i]; gr[m] = s->group[i]; m++;
          }
       int rcu = ddcmi_upload_state(ctx, m, a[0], a[1], a[2], a[3], a[4], a[5], lab, sp, gr);
+      if (rcu == DDCMI_OK && s->random_lcg64 && m > 0)
+      {
+         /* the streams of the beads this rank starts with; from here on they migrate with them */
+         uint64_t *ls = malloc(sizeof(uint64_t) * (size_t)m); uint32_t *lm = malloc(sizeof(uint32_t) * 2 * (size_t)m);
+         int k = 0;
+         for (int i = 0; i < n; i++)
+            if (brick_of(s, s->rx[i], s->ry[i], s->rz[i]) == par.rank) { ls[k] = s->lcg_state[i]; lm[k] = s->lcg_multID[i]; lm[m + k] = s->lcg_prime[i]; k++; }
+         rcu = ddcmi_set_random_lcg64(ctx, m, ls, lm, lm + m);
+         free(ls); free(lm);
+      }
       for (int k = 0; k < 6; k++) free(a[k]);
       free(lab); free(sp); free(gr);
       if (rcu != DDCMI_OK) die("simulate_init", ddcmi_last_error(ctx));      /* (a rank that returned would leave the others in their collectives) */
       sys->nlocal = sys->nion = (unsigned)m;
       if (s->random_lcg64 && par.rank == 0)
-         printf("RANDOM %s: the per-particle LCG64 streams stay with one domain; %d domains draw the Langevin noise from the counter-based stream (seed %" PRIu64 ") and write no random field\n",
-                s->random_name, par.world, s->rng_seed);
+         printf("RANDOM %s: LCG64 streams of %d particles %s; they migrate with their beads\n", s->random_name, n,
+                s->lcg_from_file ? "from the atoms file" : "at their default values, as one task assigns them (no random field in the atoms file)");
       if (par.rank == 0) printf("%d ranks on a %d x %d x %d grid of domains (%s transport); rank 0 owns %d of %d beads\n", par.world, par.grid[0], par.grid[1], par.grid[2],
                                 par.host_transport ? "host" : "RCCL", m, n);
       return sim;

@@ -445,11 +445,13 @@ class MartiniHIP(object):
         u32p = ctypes.POINTER(ctypes.c_uint32)
         self.lib.ddcmi_set_random_lcg64.argtypes = [ctypes.c_void_p, ctypes.c_int, _up, u32p, u32p]
         if parms is None:
+            self._lcg_set = False
             return self._chk(self.lib.ddcmi_set_random_lcg64(self.ctx, 0, None, None, None))
         st = np.ascontiguousarray(parms["state"], dtype=np.uint64)
         mu = np.ascontiguousarray(parms["multID"], dtype=np.uint32)
         pr = np.ascontiguousarray(parms["prime"], dtype=np.uint32)
         self._chk(self.lib.ddcmi_set_random_lcg64(self.ctx, int(st.size), st.ctypes.data_as(_up), mu.ctypes.data_as(u32p), pr.ctypes.data_as(u32p)))
+        self._lcg_set = True
 
     def get_random_lcg64(self):
         u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -617,7 +619,11 @@ class DomainMixin(object):
         arr = [np.zeros(cap) for _ in range(9)]
         self._chk(self.lib.ddcmi_download_particles(self.ctx, cap, ctypes.byref(n), gid.ctypes.data_as(_up), _i(sp), *[_d(a) for a in arr]))
         k = n.value
-        return {"gid": gid[:k], "species": sp[:k], "r": [a[:k] for a in arr[0:3]], "v": [a[:k] for a in arr[3:6]], "f": [a[:k] for a in arr[6:9]]}
+        out = {"gid": gid[:k], "species": sp[:k], "r": [a[:k] for a in arr[0:3]], "v": [a[:k] for a in arr[3:6]], "f": [a[:k] for a in arr[6:9]]}
+        if getattr(self, "_lcg_set", False) and k > 0:
+            self.n = k
+            out["lcg64"] = self.get_random_lcg64()      # same order: the beads this rank owns now
+        return out
 
 
 class MartiniRank(MartiniHIP, DomainMixin):
@@ -637,6 +643,9 @@ class MartiniRank(MartiniHIP, DomainMixin):
         self.n = len(ix)
         self._chk(self.lib.ddcmi_upload_state(self.ctx, self.n, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(a[4]), _d(a[5]),
                                               gid.ctypes.data_as(_up), _i(sp), _i(gr)))
+        lcg = getattr(s, "lcg64", None)
+        if lcg is not None and self.n > 0 and np.any(np.asarray(s.group_type) == 2):
+            self.set_random_lcg64(lcg[ix])      # the records migrate with their beads from here on
 
     def comm_init(self, rank, nranks, uid, grid):
         self._chk(self.lib.ddcmi_comm_init(self.ctx, rank, nranks, uid, grid[0], grid[1], grid[2]))
@@ -712,6 +721,8 @@ class MartiniGroup(object):
         out = {"gid": gid[order], "nlocal": [len(p["gid"]) for p in parts]}
         for k in ("r", "v", "f"):
             out[k] = [np.concatenate([p[k][c] for p in parts])[order] for c in range(3)]
+        if all("lcg64" in p or len(p["gid"]) == 0 for p in parts) and any("lcg64" in p for p in parts):
+            out["lcg64"] = np.concatenate([p["lcg64"] for p in parts if "lcg64" in p])[order]
         return out
 
     def close(self):

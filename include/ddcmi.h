@@ -147,10 +147,12 @@ int ddcmi_constraint_stats(ddcmi_ctx *ctx, int *max_sweeps, int *unconverged, in
 int ddcmi_set_random(ddcmi_ctx *ctx, uint64_t seed);
 /* RANDOM type LCG64 (lcg64.c, random.c:135-160): Langevin groups draw from the reference's own per-particle streams -- three
  * unit normals per half kick by gasdev3d over lcg64_2 -- instead of the counter-based one.  n LCG64_PARM records
- * {state, multID, prime} (lcg64.h:8-12) in the caller order of the last ddcmi_upload_state, which they must follow; what a
- * particle without a random field gets is lcg64_default's business (deck.c restates it for the atoms reader).  The records
- * are kept by caller index and do not migrate: one domain only (EUNSUPPORTED with a decomposition).  n = 0: back to the
- * counter-based stream.  ddcmi_get_random_lcg64 returns the advanced states (collection_write.c:157-161). [sync] */
+ * {state, multID, prime} (lcg64.h:8-12) in the caller order of the last ddcmi_upload_state, which they must follow (and, in a
+ * decomposed run, precede the first list build); what a particle without a random field gets is lcg64_default's business
+ * (deck.c restates it for the atoms reader).  The records travel with their beads: through the sorts of a rebuild and, in a
+ * decomposed run, inside the migration records (particleRegisterinfo of random->parmsArray, random.c:72-76).  n = 0: back to
+ * the counter-based stream.  ddcmi_get_random_lcg64 returns the advanced states (collection_write.c:157-161) in caller
+ * order -- in the order of ddcmi_download_particles for a decomposed run, whose beads have no caller order left. [sync] */
 int ddcmi_set_random_lcg64(ddcmi_ctx *ctx, int n, const uint64_t *state, const uint32_t *multID, const uint32_t *prime);
 int ddcmi_get_random_lcg64(ddcmi_ctx *ctx, int n, uint64_t *state, uint32_t *multID, uint32_t *prime);
 /* SIMULATE loop/time (simulate.c:146,155) */

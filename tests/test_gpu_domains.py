@@ -62,6 +62,40 @@ def test_decomposed_trajectory_with_migration():
     g.close()
 
 
+def test_decomposed_langevin_on_migrating_lcg64_streams():
+    """RANDOM type LCG64 under a decomposition: the particles' stream records ride in the migration records (random.c:72-76
+    registers parmsArray with the particle exchange) and through every sort, so 8 domains draw what one domain draws --
+    45 steps across two rebuilds with beads changing owners follow the oracle, and every stream ends in the oracle's state"""
+    from ddcmd_amd.martini import MartiniGroup
+    from ddcmd_amd.deck import units_convert
+    s = make_water_setup(15)
+    s.group_type = np.array([2], np.int32)
+    s.group_Teq = np.array([units_convert(310.0, "K")])
+    s.group_tau = np.array([units_convert(0.3, "ps")])
+    s.lcg64 = pyoracle.lcg64_default(s.gid)
+    o = pyoracle.Oracle(s)
+    assert o.lcg is not None
+    o.forces()
+    g = MartiniGroup(s, (2, 2, 2))
+    g.eval_forces()
+    st0 = g.gather()
+    by_gid = np.argsort(s.gid, kind="stable")
+    assert (st0["lcg64"] == s.lcg64[by_gid]).all()
+    for block in range(3):
+        eo, vo, rko, _ = o.step(15)
+        g.step(15)
+        e, vir, rk, _ = g.energies()
+        assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+        assert abs(rk - rko) < TOL * rko, block
+    st = g.gather()
+    assert st["nlocal"] != st0["nlocal"]                     # ownership really changed
+    assert (st["lcg64"]["state"] == o.lcg["state"][by_gid]).all()
+    assert (st["lcg64"]["prime"] == s.lcg64["prime"][by_gid]).all() and (st["lcg64"]["multID"] == s.lcg64["multID"][by_gid]).all()
+    for c, ref in enumerate((o.vx, o.vy, o.vz)):
+        assert np.abs(st["v"][c] - ref[by_gid]).max() < 1e-8 * np.abs(ref).max()
+    g.close()
+
+
 def test_decomposed_charged_system():
     """charges: per-rank self term and reaction field across domain faces"""
     from ddcmd_amd.martini import MartiniGroup

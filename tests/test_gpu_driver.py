@@ -398,6 +398,33 @@ def test_ddcmi_md_on_several_ranks_matches_one_rank(tmp_path, world):
     assert np.abs(s1.vx[i1] - sn.vx[i2]).max() < 1e-7 * np.abs(s1.vx).max()
 
 
+def test_ddcmi_md_langevin_lcg64_on_two_ranks_matches_one_rank(tmp_path):
+    """a LANGEVIN group on the particles' LCG64 streams through the driver on two ranks: the streams migrate with their
+    beads, so the `data` file is the one-rank run's and the checkpoint carries the same stream states, particle by particle"""
+    x = ("group GROUP { type = LANGEVIN; Teq = 310 K; tau = 0.5 ps; } "
+         "simulate SIMULATE { deltaloop = 40; maxloop = 40; checkpointrate = 40; printrate = 10; }")
+    d1 = tmp_path / "one"; d1.mkdir()
+    out = subprocess.run([EXE, "-o", DECK, "-d", "data", "-x", x], capture_output=True, text=True, timeout=300, cwd=str(d1))
+    assert out.returncode == 0, out.stdout + out.stderr
+    dn = tmp_path / "two"; dn.mkdir()
+    outs = _run_ranks(2, ["-o", DECK, "-d", "data", "-x", x], str(dn))
+    for rc, o, er in outs:
+        assert rc == 0, o + er
+    assert "they migrate with their beads" in outs[0][1]
+    a, b = _rows(str(d1 / "data")), _rows(str(dn / "data"))
+    assert a.shape == b.shape and a.shape[0] == 5
+    assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
+    s1 = load_deck(DECK, restart_file=str(d1 / "restart"), extra_objects=x)
+    sn = load_deck(DECK, restart_file=str(dn / "restart"), extra_objects=x)
+    assert s1.lcg_from_file == 1 and sn.lcg_from_file == 1 and sn.loop == 40
+    i1, i2 = np.argsort(s1.gid), np.argsort(sn.gid)
+    assert np.array_equal(s1.gid[i1], sn.gid[i2])
+    assert (s1.lcg64[i1] == sn.lcg64[i2]).all()
+    s0 = load_deck(DECK, extra_objects=x)
+    assert (s1.lcg64["state"] != s0.lcg64["state"]).all()
+    assert np.abs(s1.vx[i1] - sn.vx[i2]).max() < 1e-7 * np.abs(s1.vx).max()
+
+
 def test_ddcmi_md_nglfconstraint_on_two_ranks(tmp_path):
     """NGLFCONSTRAINT (velocity constraints + molecular-pressure barostat) through the driver on two ranks: constraint groups
     and molecule lists go in by gid, the box and the molecular-pressure column follow the one-rank run"""
