@@ -402,6 +402,20 @@ struct NbTileArgs
    const int *tile_work;                /* bit 30: the tile stages image/halo beads */
    const int *halo_shift; int nloc;     /* halo_shift[j - nloc] != 13: bead j carries a periodic shift */
 };
+/* k_nonbond<..., FUSE>: the pair kernel's epilogue is the integrator's pass over the bead -- BACK half kick, kinetic terms, FRONT half
+ * kick, drift (k_kick_ke_drift, bit for bit) -- for systems whose forces are complete when the list walk ends (no bonded terms,
+ * restraints, constraints or barostat; FREE / BERENDSEN groups).  The force never goes to memory; the drifted positions go to the
+ * second position buffer (the neighbours still read the old one), which the host swaps in after the launch. */
+struct FuseArgs
+{
+   double dt;
+   double lam[32];                      /* Berendsen scale factor of the FRONT kick per group (1 otherwise) */
+   const double *invmass, *massv; const int *group;
+   double *vx, *vy, *vz;
+   double4 *pos_new;
+   double *kpartials;                   /* [item][8]: rk, tion[6] of the item's beads */
+   int ke_off;                          /* LDS byte offset of the [waves][8] rows of kinetic sums */
+};
 
 /* The neighbour search of one tile (first half of the list build).
  *
@@ -1026,14 +1040,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
  *      shifted copies and excluded pairs (see below).
  * Bound: FP64 issue and LDS gathers behind s_waitcnt at 4 waves per SIMD -- DESIGN.md section 4 has the
  * counters, the ablations and the per-CU timelines. */
-template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF>
+template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF, bool FUSE>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
                                                          const unsigned short *__restrict__ excl16, const int *__restrict__ excl_cnt,
                                                          const double4 *__restrict__ ljtab,
                                                          double rc2, double krf, double crf, double keR,
                                                          double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz,
-                                                         double *__restrict__ partials)
+                                                         double *__restrict__ partials, FuseArgs fa)
 {
    /* LDS: staged neighbourhood as {x,y} pairs + z (24 B per bead), LJ table, and --
     * only when needed -- per-bead LJ types (nlj > 16) and charges */
@@ -1210,6 +1224,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          }
       }
       }
+      if (FUSE && threadIdx.x < (NB_BLOCK / 64) * 8) ((double *)((char *)smem + fa.ke_off))[threadIdx.x] = 0.0;
       if (threadIdx.x == 0)
       {
          /* staged slot 0: a bead far outside every cutoff.  List padding (entry 0) points
@@ -1396,7 +1411,37 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          {
             fxi += __shfl_xor(fxi, off, 64); fyi += __shfl_xor(fyi, off, 64); fzi += __shfl_xor(fzi, off, 64);
          }
-         if (active && sub == 0) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; }
+         if (!FUSE) { if (active && sub == 0) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; } }
+         else
+         {
+            /* k_kick_ke_drift on the bead, with the force still in registers (the same operations in the same order) */
+            double ke[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (active && sub == 0)
+            {
+               /* (asked for here, not before the walk: held across it these twelve registers spill, and the reload costs what the load does) */
+               const int sp = (int)((__double_as_longlong(pi.w) >> 16) & 0xffffll);
+               const double hk = (0.5 * fa.dt) * fa.invmass[sp], m = fa.massv[sp], lam = fa.lam[fa.group[a] & 31];
+               double x = fma(hk, fxi, fa.vx[a]), y = fma(hk, fyi, fa.vy[a]), z = fma(hk, fzi, fa.vz[a]);
+               const double vxx = x * x, vyy = y * y, vzz = z * z;
+               ke[0] = 0.5 * m * (vxx + vyy + vzz);
+               ke[1] = m * vxx; ke[2] = m * vyy; ke[3] = m * vzz;
+               ke[4] = m * (x * y); ke[5] = m * (x * z); ke[6] = m * (y * z);
+               if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
+               x = fma(hk, fxi, x); y = fma(hk, fyi, y); z = fma(hk, fzi, z);
+               fa.vx[a] = x; fa.vy[a] = y; fa.vz[a] = z;
+               double4 p = pi;
+               p.x = fma(fa.dt, x, p.x); p.y = fma(fa.dt, y, p.y); p.z = fma(fa.dt, z, p.z);
+               fa.pos_new[a] = p;
+            }
+            /* the wave's row of kinetic sums (only this wave touches it; the rows are added in index order at the end) */
+            double *ke_row = (double *)((char *)smem + fa.ke_off) + (threadIdx.x >> 6) * 8;
+#pragma unroll
+            for (int k = 0; k < 7; k++)
+            {
+               const double sv = wave_sum(ke[k]);
+               if (lane == 0) ke_row[k] += sv;
+            }
+         }
       }
       }
    }
@@ -1420,6 +1465,14 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
 #pragma unroll
          for (int q = 1; q < NB_BLOCK / 64; q++) a += s_red[q * 8 + threadIdx.x];
          partials[(size_t)slot * 8 + threadIdx.x] = a;      /* one row per work item */
+      }
+      if (FUSE && threadIdx.x >= 64 && threadIdx.x < 64 + 8)
+      {
+         const int k = threadIdx.x - 64;
+         const double *ke_s = (const double *)((char *)smem + fa.ke_off);
+         double a = 0.0;
+         if (nown > 0 && k < 7) for (int q = 0; q < NB_BLOCK / 64; q++) a += ke_s[q * 8 + k];
+         fa.kpartials[(size_t)slot * 8 + k] = a;
       }
    }
 }
@@ -2945,7 +2998,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
 /* ------------------------------------------------------------------------- */
 /* defer_reduce: the caller (a time step) folds the nonbonded reduction and the final
  * energies into the launch that reduces the kinetic terms */
-static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
+static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
@@ -2995,6 +3048,24 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       const bool zfix = capl * 16 <= NB_ZOFF;
       size_t lds = (zfix ? NB_ZOFF + capl * 8 : capl * 24) + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
+      FuseArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      if (fuse)
+      {
+         /* the rows of kinetic sums ([waves][8] doubles): in the gap between the {x,y} array and z when there is one, else behind
+          * everything -- but never at the price of the second workgroup per CU */
+         const size_t rows = (NB_THREADS / 64) * 8 * sizeof(double);
+         const bool gap = zfix && capl * 16 + rows <= NB_ZOFF;
+         const size_t lds_f = gap ? lds : ((lds + 7) & ~(size_t)7) + rows;
+         const bool keeps_two = lds_f * 2 <= 160 * 1024 || lds * 2 > 160 * 1024;
+         if (zfix && !useq && keeps_two && lds_f <= 160 * 1024)
+         {
+            fa = *fuse;
+            fa.ke_off = gap ? (int)(NB_ZOFF - rows) : (int)((lds + 7) & ~(size_t)7);
+            lds = lds_f;
+         }
+         else { fuse->dt = 0.0; fuse = nullptr; }
+      }
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nnb;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
@@ -3003,11 +3074,12 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
-#define LAUNCH_NBZ(Q, P, S, NT, Z) do { \
-         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
+#define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
+#define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
+         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl16.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p); } while (0)
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p, fa); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
       /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
        * class 1: tiles that stage image/halo beads, after the halo exchange */
@@ -3027,9 +3099,14 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
                for (size_t k = old; k < ctx->ev.size(); k++) HIPCHK(ctx, hipEventCreate(&ctx->ev[k]));
             }
             e0 = ctx->ev[ctx->ev_used++]; e1 = ctx->ev[ctx->ev_used++];
+            ctx->ev_fused.resize(ctx->ev.size() / 2);
+            ctx->ev_fused[ctx->ev_used / 2 - 1] = fuse ? 1 : 0;
             HIPCHK(ctx, hipEventRecord(e0, st));
          }
-         if (useq && shbit) LAUNCH_NB2(true, true, true);
+         if (fuse && shbit) LAUNCH_NBF(false, true, true, NB_THREADS, NB_ZOFF, true);      /* (fuse: uncharged, fixed LDS layout) */
+         else if (fuse && packed) LAUNCH_NBF(false, true, false, NB_THREADS, NB_ZOFF, true);
+         else if (fuse) LAUNCH_NBF(false, false, false, NB_THREADS, NB_ZOFF, true);
+         else if (useq && shbit) LAUNCH_NB2(true, true, true);
          else if (useq && packed) LAUNCH_NB2(true, true, false);
          else if (useq) LAUNCH_NB2(true, false, false);
          else if (shbit) LAUNCH_NB2(false, true, true);
@@ -3040,7 +3117,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false)
 #undef LAUNCH_NB2
 #undef LAUNCH_NB
 #undef LAUNCH_NBZ
-      if (ctx->timing) ctx->t_launches++;          /* per force evaluation: the event pairs of both classes add up */
+#undef LAUNCH_NBF
+      if (ctx->timing) { ctx->t_launches++; if (fuse) ctx->t_launches_fused++; }          /* per force evaluation: the event pairs of both classes add up */
       /* without bonded terms the final energies are formed in the same launch */
       if (!defer_reduce)
       {
@@ -3269,6 +3347,17 @@ static bool graph_ok(const ddcmi_ctx *ctx, double dt)
    for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE) return false;
    return ctx->graph_state < 2 || ctx->graph_dt == dt;
 }
+/* may the integrator's pass ride in the pair kernel (k_nonbond<..., FUSE>)?  The force must be complete when the list walk ends
+ * and the step must need nothing between the force and the drift */
+static bool fuse_ok(const ddcmi_ctx *ctx)
+{
+   static const bool off = getenv("DDCMI_NO_FUSED_STEP") != nullptr;
+   if (off || ctx->nloc <= 0 || ctx->group_) return false;
+   if ((ctx->excludePotentialTerm & 128) != 0 || ctx->has_charge) return false;
+   if (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest > 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0) return false;
+   for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE && ctx->gtype[g] != DDCMI_BERENDSEN) return false;
+   return true;
+}
 static int step_post_cons_b(ddcmi_ctx *ctx, double dt)
 {
    int rc;
@@ -3302,6 +3391,41 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
          return DDCMI_OK;
       }
       if (ctx->graph_state == 0 && ctx->graph_max_beads > 0) ctx->graph_state = 1;      /* after the plain step below */
+   }
+   if (more_steps && fuse_ok(ctx))
+   {
+      /* forces, BACK kick, kinetic terms, FRONT kick and drift in ONE pass: the pair kernel's epilogue is k_kick_ke_drift */
+      berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
+      const GroupLambda lam = front_lambda(ctx, dt);
+      FuseArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.dt = dt;
+      for (int g = 0; g < 32; g++) fa.lam[g] = lam.v[g];
+      fa.invmass = ctx->d_invmass.p; fa.massv = ctx->d_mass.p; fa.group = ctx->group.p;
+      fa.vx = ctx->vx.p; fa.vy = ctx->vy.p; fa.vz = ctx->vz.p;
+      ENSURE(ctx, ctx->kpartials, (size_t)(std::max(ctx->nitems, cdiv(ctx->nloc, DDCMI_BLOCK * KE_PER)) + 8) * 8);
+      ENSURE(ctx, ctx->pos2, (size_t)ctx->nloc + ctx->nhalo);      /* (the size ddcmi_bl_reserve_halo gave both buffers: no reallocation here) */
+      if (ctx->nhalo > 0 && ctx->fuse_tags_of != ctx->nrebuild)
+      {
+         /* received halo beads keep their tag word where they lie (k_halo_update rewrites x y z only): both buffers need it */
+         HIPCHK(ctx, hipMemcpyAsync(ctx->pos2.p + ctx->nloc, ctx->pos.p + ctx->nloc, (size_t)ctx->nhalo * sizeof(double4), hipMemcpyDeviceToDevice, ctx->stream));
+         ctx->fuse_tags_of = ctx->nrebuild;
+      }
+      fa.pos_new = ctx->pos2.p; fa.kpartials = ctx->kpartials.p;
+      if ((rc = launch_forces(ctx, true, &fa))) return rc;
+      if (fa.dt != 0.0)
+      {
+         RedJob jf = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, 1};
+         RedJob jk = {ctx->kpartials.p, ctx->nitems, 7, ctx->d_results + R_RK, 0};
+         hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p);
+         std::swap(ctx->pos, ctx->pos2);
+         ctx->drift_done = true;
+         return DDCMI_OK;
+      }
+      /* (the launch kept the plain kernel: LDS layout; the kick follows as usual) */
+      if ((rc = launch_kinetic(ctx, dt, 1, true, &lam, true))) return rc;
+      ctx->drift_done = true;
+      return DDCMI_OK;
    }
    if ((rc = launch_forces(ctx, true))) return rc;
    berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
@@ -3578,11 +3702,22 @@ extern "C" int ddcmi_timing_read(ddcmi_ctx *ctx, int64_t *launches, double *tota
       float ms = 0;
       HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
       ctx->t_ms += ms;
+      if (k / 2 < ctx->ev_fused.size() && ctx->ev_fused[k / 2]) ctx->t_ms_fused += ms;
    }
    ctx->ev_used = 0;
    if (launches) *launches = ctx->t_launches;
    if (total_ms) *total_ms = ctx->t_ms;
-   if (reset) { ctx->t_launches = 0; ctx->t_ms = 0; }
+   ctx->t_last_fused[0] = (double)ctx->t_launches_fused; ctx->t_last_fused[1] = ctx->t_ms_fused;
+   if (reset) { ctx->t_launches = 0; ctx->t_ms = 0; ctx->t_launches_fused = 0; ctx->t_ms_fused = 0; }
+   return DDCMI_OK;
+}
+/* of the launches and milliseconds the last ddcmi_timing_read returned: the share of k_nonbond<..., FUSE> (the pair kernel
+ * whose epilogue is the integrator's pass, ddcmi_step_nglf's steps between print steps of systems without bonded terms) */
+extern "C" int ddcmi_timing_fused(ddcmi_ctx *ctx, int64_t *launches, double *total_ms)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   if (launches) *launches = (int64_t)ctx->t_last_fused[0];
+   if (total_ms) *total_ms = ctx->t_last_fused[1];
    return DDCMI_OK;
 }
 

@@ -182,6 +182,7 @@ struct ddcmi_ctx
    bool baro_iso = false;                                           /* one scale factor from the mean of the three pressures (changeVolumeGPUisotropic) */
    double pmol[3] = {0, 0, 0};                                      /* molecular pressure (xx, yy, zz) the barostat last acted on */
    dbuf<ulonglong2> lcg, lcg2; bool lcg_on = false; /* Langevin groups, RANDOM type LCG64: LCG64_PARM {state; multID | prime << 32} of the owned beads in slot order; off = the counter-based stream */
+   int64_t fuse_tags_of = -1;              /* the rebuild whose halo tag words the second position buffer holds (fused steps swap the buffers) */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool slot_valid = false;            /* slot_of_orig (caller index -> device slot) belongs to the current order: refilled by the sort of a rebuild only when something
                                           names beads by caller index (bonded terms, constraint groups, molecule lists), else on demand (ddcmi_ensure_slots) */
@@ -246,6 +247,7 @@ struct ddcmi_ctx
     * 256 k: 136 vs 126).  graph_state 0: none, 1: buffers sized by a plain step, 2: graph_exec is valid */
    int graph_state = 0; hipGraphExec_t graph_exec = nullptr; double graph_dt = 0; int graph_max_beads = 0;
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
+   std::vector<char> ev_fused; int64_t t_launches_fused = 0; double t_ms_fused = 0, t_last_fused[2] = {0, 0};      /* of those: launches whose epilogue was the integrator's pass */
    /* DDCMI_DEBUG_PHASES=1: host wall time between the marks of a rebuild (where the host waits, where it is busy), printed at ddcmi_destroy */
    int ph_on = -1; double ph_last = 0, ph_sum[32] = {0}; long ph_cnt[32] = {0}; const char *ph_name[32] = {nullptr};
    void phase(int k, const char *name)

@@ -553,6 +553,13 @@ class MartiniHIP(object):
     def timing(self, on=True):
         self._chk(self.lib.ddcmi_timing_enable(self.ctx, 1 if on else 0))
 
+    def timing_fused(self):
+        """of the last timing_read: (launches, ms) of the pair kernel with the integrator's pass as its epilogue"""
+        n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        self.lib.ddcmi_timing_fused.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), _dp]
+        self._chk(self.lib.ddcmi_timing_fused(self.ctx, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
     def timing_read(self, reset=True):
         n = ctypes.c_int64(0)
         ms = ctypes.c_double(0)

@@ -226,6 +226,10 @@ int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int64_t *nentr
  * enable, run, then read {launch count, total ms}.  [sync] on read */
 int ddcmi_timing_enable(ddcmi_ctx *ctx, int on);
 int ddcmi_timing_read(ddcmi_ctx *ctx, int64_t *launches, double *total_ms, int reset);
+/* of what the last ddcmi_timing_read returned: the launches (and their time) whose epilogue was the integrator's pass -- between
+ * print steps ddcmi_step_nglf runs BACK kick, kinetic_terms, FRONT kick and drift (nglf.c:74-104) inside the pair kernel when
+ * the force is complete at the end of the list walk (no bonded terms, restraints, constraints, barostat, charges) */
+int ddcmi_timing_fused(ddcmi_ctx *ctx, int64_t *launches, double *total_ms);
 /* census of the rarely taken branches of the dihedral code since the last reset (bioCharmmCovalentEnergiesSorted.c:649-683,
  * 793-810): [0] torsion series (|sin phi| <= 1e-8), of these [1] delta < 1 deg, [2] delta > 179 deg, [3] any other delta;
  * [4] improper series; [5] improper difference wrapped by 2 pi; [6] cos phi clamped.  Counted per evaluation (a term is

@@ -432,6 +432,43 @@ def test_displacement_triggered_rebuilds():
     m.close()
 
 
+@pytest.mark.parametrize("thermostat", ["free", "berendsen"])
+def test_step_with_the_integrator_inside_the_pair_kernel_equals_the_split_step(thermostat):
+    """between print steps a system without bonded terms takes BACK kick, kinetic terms, FRONT kick and drift (nglf.c:74-104) in the
+    epilogue of the pair kernel (k_nonbond<FUSE>: the force stays in registers, the drifted positions go to the second buffer);
+    the last step of every ddcmi_step_nglf call is the split one.  Batches of 25 steps against 25 single steps: the same
+    operations in the same order -- positions and velocities bit for bit across a rebuild, sums to rounding -- and the oracle"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(12)
+    if thermostat == "berendsen":
+        s.group_type = np.array([1], np.int32)
+        s.group_Teq = np.array([units_convert(330.0, "K")])
+        s.group_tau = np.array([units_convert(2.0, "ps")])      # (the box starts at 50 K and the group temperature is published once per block)
+        s.group_interval = np.array([1], np.int32)
+    a, b = MartiniHIP(s), MartiniHIP(s)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    a.eval_forces(); b.eval_forces()
+    for block in range(2):
+        if thermostat == "berendsen":
+            o.group_temperature(); a.group_temperatures(); b.group_temperatures()
+        a.step(25)
+        for _ in range(25):
+            b.step(1)
+        eo, vo, rko, _ = o.step(25)
+        da, db = a.download(), b.download()
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(da[k][c], db[k][c]), (block, k, c)
+        ea, va, rka, ta = a.energies()
+        eb, vb, rkb, tb = b.energies()
+        assert abs(rka - rkb) <= 1e-13 * rkb and abs(ea["total"] - eb["total"]) <= 1e-13 * abs(eb["total"])
+        assert np.abs(ta - tb).max() <= 1e-13 * np.abs(tb).max()
+        assert abs(rka - rko) < TOL * rko and abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"])
+    assert a.list_stats()["rebuilds"] >= 3
+    a.close(); b.close()
+
+
 def test_langevin_group_matches_oracle_and_thermalises():
     """LANGEVIN group (langevin.c:92-128): the device update equals the oracle's restatement with the same
     counter-based normal stream (trajectory parity), and drives a 50 K box to Teq (the statistical
