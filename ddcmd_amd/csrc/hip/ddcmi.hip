@@ -95,6 +95,46 @@ __device__ __forceinline__ double wave_sum(double v)
    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
    return v;
 }
+/* the same sum without the LDS crossbar (__shfl_* is ds_bpermute: two per step and double, in the pair kernel they queue behind
+ * the gathers of every other wave of the CU): butterflies inside the rows of 16 lanes by DPP -- quad_perm [1,0,3,2], [2,3,0,1],
+ * row_half_mirror, row_mirror: after the four every lane holds its row's sum -- then the four rows by v_readlane.  Fixed order. */
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+   v += dpp_move<0xB1>(v);
+   v += dpp_move<0x4E>(v);
+   v += dpp_move<0x141>(v);
+   v += dpp_move<0x140>(v);
+   double r[4];
+#pragma unroll
+   for (int q = 0; q < 4; q++)
+      r[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * q), __builtin_amdgcn_readlane(__double2loint(v), 16 * q));
+   return (r[0] + r[1]) + (r[2] + r[3]);
+}
+__device__ __forceinline__ int wave_max_dpp(int v)      /* every lane gets the maximum over the wave (v >= 0) */
+{
+   v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+   return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_scan_inclusive_dpp(int v)      /* prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows (a lane without a source adds 0), then the totals of the rows before */
+{
+   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+   const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+   const int row = (int)(threadIdx.x & 63) >> 4;
+   return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
 /* block (NW waves) reduction of NV values per thread into out[NV], fixed order */
 template <int NV, int NW = 4>
 __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *out)
@@ -1138,8 +1178,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          int inc = vsum;
          {
             const int ln = threadIdx.x & 63;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { int q = __shfl_up(inc, off, 64); if (ln >= off) inc += q; }
+            inc = wave_scan_inclusive_dpp(inc);
             if (ln == 63) s_w[threadIdx.x >> 6] = inc;
          }
          __syncthreads();
@@ -1276,9 +1315,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          /* wave-uniform trip count; the list is read two groups ahead (one 16-byte load per
           * lane and group, 1 KiB per wave) so the HBM/L2 latency of the list stream overlaps
           * the pair math; the 8 distance tests of a group are independent (ILP) */
-         int wmax = ngl;
-#pragma unroll
-         for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+         const int wmax = wave_max_dpp(ngl);
          /* The list stream: one 16-byte load per lane and group, kept two groups ahead of
           * the pair loop.  Three named buffers (the loop is unrolled by three) rather
           * than a rotating one, so each wait covers exactly the oldest load; the loads
@@ -1435,12 +1472,14 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             }
             /* the wave's row of kinetic sums (only this wave touches it; the rows are added in index order at the end) */
             double *ke_row = (double *)((char *)smem + fa.ke_off) + (threadIdx.x >> 6) * 8;
+            double mine = 0.0;
 #pragma unroll
             for (int k = 0; k < 7; k++)
             {
-               const double sv = wave_sum(ke[k]);
-               if (lane == 0) ke_row[k] += sv;
+               const double sv = wave_sum_dpp(ke[k]);      /* (uniform over the wave) */
+               if (lane == k) mine = sv;
             }
+            if (lane < 7) ke_row[lane] += mine;      /* one read-modify-write for the seven sums */
          }
       }
       }
@@ -1455,7 +1494,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
 #pragma unroll
       for (int k = 0; k < 8; k++)
       {
-         double sv = wave_sum(acc[k]);
+         double sv = wave_sum_dpp(acc[k]);
          if (lane == 0) s_red[w * 8 + k] = sv;
       }
       __syncthreads();
