@@ -1444,7 +1444,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             acc[2] += px * pi.x; acc[3] += py * pi.y; acc[4] += pz * pi.z;
             acc[5] += px * pi.y; acc[6] += px * pi.z; acc[7] += py * pi.z;
          }
-         for (int off = parts >> 1; off > 0; off >>= 1)
+         /* the bead's lanes add up their shares (parts is uniform over the wave): butterflies by DPP inside the rows of 16 lanes */
+         if (parts > 1) { fxi += dpp_move<0xB1>(fxi); fyi += dpp_move<0xB1>(fyi); fzi += dpp_move<0xB1>(fzi); }
+         if (parts > 2) { fxi += dpp_move<0x4E>(fxi); fyi += dpp_move<0x4E>(fyi); fzi += dpp_move<0x4E>(fzi); }
+         if (parts > 4) { fxi += dpp_move<0x141>(fxi); fyi += dpp_move<0x141>(fyi); fzi += dpp_move<0x141>(fzi); }
+         if (parts > 8) { fxi += dpp_move<0x140>(fxi); fyi += dpp_move<0x140>(fyi); fzi += dpp_move<0x140>(fzi); }
+         for (int off = 16; off < parts; off <<= 1)
          {
             fxi += __shfl_xor(fxi, off, 64); fyi += __shfl_xor(fyi, off, 64); fzi += __shfl_xor(fzi, off, 64);
          }
