@@ -449,8 +449,8 @@ struct NbTileArgs
 struct FuseArgs
 {
    double dt;
-   double lam[32];                      /* Berendsen scale factor of the FRONT kick per group (1 otherwise) */
-   const double *invmass, *massv; const int *group;
+   double lam;                          /* Berendsen scale factor of the FRONT kick (1 otherwise): one value -- steps whose groups differ take the split kernels */
+   const double *invmass, *massv;
    double *vx, *vy, *vz;
    double4 *pos_new;
    double *kpartials;                   /* [item][8]: rk, tion[6] of the item's beads */
@@ -1462,7 +1462,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             {
                /* (asked for here, not before the walk: held across it these twelve registers spill, and the reload costs what the load does) */
                const int sp = (int)((__double_as_longlong(pi.w) >> 16) & 0xffffll);
-               const double hk = (0.5 * fa.dt) * fa.invmass[sp], m = fa.massv[sp], lam = fa.lam[fa.group[a] & 31];
+               const double hk = (0.5 * fa.dt) * fa.invmass[sp], m = fa.massv[sp], lam = fa.lam;
                double x = fma(hk, fxi, fa.vx[a]), y = fma(hk, fyi, fa.vy[a]), z = fma(hk, fzi, fa.vz[a]);
                const double vxx = x * x, vyy = y * y, vzz = z * z;
                ke[0] = 0.5 * m * (vxx + vyy + vzz);
@@ -3436,22 +3436,38 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       }
       if (ctx->graph_state == 0 && ctx->graph_max_beads > 0) ctx->graph_state = 1;      /* after the plain step below */
    }
-   if (more_steps && fuse_ok(ctx))
+   bool fuse = more_steps && fuse_ok(ctx);
+   GroupLambda lam_f;
+   if (fuse)
+   {
+      berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
+      lam_f = front_lambda(ctx, dt);
+      for (int g = 1; g < ctx->ngroup; g++) fuse &= lam_f.v[g] == lam_f.v[0];      /* one scale factor for every bead */
+      if (!fuse)
+      {
+         /* (groups with different Berendsen factors this step: the split kernels, with the factors just formed) */
+         if ((rc = launch_forces(ctx, true))) return rc;
+         if ((rc = launch_kinetic(ctx, dt, 1, true, &lam_f, true))) return rc;
+         ctx->drift_done = true;
+         return DDCMI_OK;
+      }
+   }
+   if (fuse)
    {
       /* forces, BACK kick, kinetic terms, FRONT kick and drift in ONE pass: the pair kernel's epilogue is k_kick_ke_drift */
-      berendsen_update(ctx, 0.5 * dt);     /* host scalars only: nothing of this step's device results enters */
-      const GroupLambda lam = front_lambda(ctx, dt);
+      const GroupLambda &lam = lam_f;
       FuseArgs fa;
       memset(&fa, 0, sizeof(fa));
       fa.dt = dt;
-      for (int g = 0; g < 32; g++) fa.lam[g] = lam.v[g];
-      fa.invmass = ctx->d_invmass.p; fa.massv = ctx->d_mass.p; fa.group = ctx->group.p;
+      fa.lam = ctx->ngroup > 0 ? lam.v[0] : 1.0;
+      fa.invmass = ctx->d_invmass.p; fa.massv = ctx->d_mass.p;
       fa.vx = ctx->vx.p; fa.vy = ctx->vy.p; fa.vz = ctx->vz.p;
       ENSURE(ctx, ctx->kpartials, (size_t)(std::max(ctx->nitems, cdiv(ctx->nloc, DDCMI_BLOCK * KE_PER)) + 8) * 8);
       ENSURE(ctx, ctx->pos2, (size_t)ctx->nloc + ctx->nhalo);      /* (the size ddcmi_bl_reserve_halo gave both buffers: no reallocation here) */
-      if (ctx->nhalo > 0 && ctx->fuse_tags_of != ctx->nrebuild)
+      if (ctx->nhalo > 0 && (ctx->nranks > 1 || ctx->loopback) && ctx->fuse_tags_of != ctx->nrebuild)
       {
-         /* received halo beads keep their tag word where they lie (k_halo_update rewrites x y z only): both buffers need it */
+         /* received halo beads keep their tag word where they lie (k_halo_update rewrites x y z only): both buffers need it
+          * (the periodic images of a single domain are whole copies of their owners' records) */
          HIPCHK(ctx, hipMemcpyAsync(ctx->pos2.p + ctx->nloc, ctx->pos.p + ctx->nloc, (size_t)ctx->nhalo * sizeof(double4), hipMemcpyDeviceToDevice, ctx->stream));
          ctx->fuse_tags_of = ctx->nrebuild;
       }

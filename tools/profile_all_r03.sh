@@ -1,0 +1,20 @@
+#!/bin/bash
+# the round's evidence for the four workloads of the bench line + the rebuild timelines, one box:
+#   gpurun --timeout 2400 -- 'bash tools/profile_all_r03.sh'
+set -u
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+bash tools/profile_r03.sh 4m --no-also --steps 100 --warmup 20 > gpurun_out/prof_4m.txt 2>&1
+bash tools/profile_r03.sh 1m --no-also --lattice 64 --steps 100 --warmup 20 > gpurun_out/prof_1m.txt 2>&1
+bash tools/profile_r03.sh lipid --no-also --workload lipid --steps 100 --warmup 20 > gpurun_out/prof_lipid.txt 2>&1
+bash tools/profile_r03.sh brick --no-also --lattice 50 --rccl-loopback --steps 100 --warmup 20 > gpurun_out/prof_brick.txt 2>&1
+bash tools/timeline.sh 4m --steps 40 --warmup 20 > /dev/null 2>&1
+bash tools/timeline.sh lipid --workload lipid --steps 40 --warmup 20 > /dev/null 2>&1
+bash tools/timeline.sh brick --lattice 50 --rccl-loopback --steps 40 --warmup 20 > /dev/null 2>&1
+for t in 4m 1m lipid brick; do python3 - $t <<'PY'
+import json, sys
+t = sys.argv[1]
+d = json.load(open("gpurun_out/prof_%s/traffic.json" % t))
+print(t, d.get("bench_plain"), d.get("traffic_kernel"), d.get("traffic_bytes_per_launch"))
+PY
+done
+head -3 gpurun_out/timeline_*/timeline.txt

@@ -30,7 +30,7 @@ res = {"method": "tools/profile_r03.sh: rocprofv3 --kernel-trace --stats (one ru
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
     open(os.path.join(out, "kernel_stats.csv"), "w").write(open(f).read())
-    res["kernel_stats_avg_us"] = {r["Name"].split("(")[0][:48]: [int(r["Calls"]), round(float(r["AverageNs"]) / 1e3, 2)] for r in rows[:18]}
+    res["kernel_stats_avg_us"] = {r["Name"].split("(")[0][:72]: [int(r["Calls"]), round(float(r["AverageNs"]) / 1e3, 2)] for r in rows[:18]}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
