@@ -422,6 +422,7 @@ struct TileArgs
    long long *tile_base; int *tile_width, *tile_rows, *tile_work;
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt;
+   uint4 *nbr_cum;                      /* [bead] eight 16-bit counts: the bead's entries in shells 0..s (k_tile_transpose) -- what k_nonbond walks when later shells cannot matter yet */
    unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead.  Packed entries (pack_type != 0): 16-bit words,
                                            staged slot + 1 | distance shell << 12, and the slot's type nibble in tile_nib; bare entries: 32-bit words, entry | shell << 16 */
    unsigned char *tile_nib;             /* [ntile][stage_stride] type nibble (+ shifted-copy bit) of every staged slot: k_tile_transpose finishes the entries with it */
@@ -441,6 +442,11 @@ struct NbTileArgs
    const int *perm;                     /* work items in launch order: tile | part << 24 | (nparts - 1) << 27 (schedule_tiles) */
    const int *tile_work;                /* bit 30: the tile stages image/halo beads */
    const int *halo_shift; int nloc;     /* halo_shift[j - nloc] != 13: bead j carries a periodic shift */
+   /* Shells that cannot matter yet.  disp (not null) points at D = sum over the steps since the rebuild of max_i |dt v_i|: no bead has moved
+    * further than D, no pair distance has changed by more than 2 D, so an entry that lay in shell s or beyond at the rebuild -- at
+    * r^2 >= sh_r0sq + (s - 1) sh_step -- is outside the cut-off while sqrt(that) - 2 D > r_cut, and the walk of every row ends with shell s - 1
+    * (nbr_cum).  Entries of later shells inside the last group walked are simply tested: they are real neighbours. */
+   const double *disp; const uint4 *nbr_cum; double sh_r0sq, sh_step;
 };
 /* k_nonbond<..., FUSE>: the pair kernel's epilogue is the integrator's pass over the bead -- BACK half kick, kinetic terms, FRONT half
  * kick, drift (k_kick_ke_drift, bit for bit) -- for systems whose forces are complete when the list walk ends (no bonded terms,
@@ -1007,6 +1013,12 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
       const unsigned long long n03 = ((b0 + t0) >> 48) & 0xffffull;                  /* entries in shells 0..3 */
       const unsigned long long b1 = n03 * 0x0001000100010001ull + (t1 << 16) + (t1 << 32) + (t1 << 48);
       const unsigned long long s0 = b0 + i0 - c0w, s1 = b1 + i1 - c1w;
+      if (q == 0 && row < nown)
+      {
+         /* entries in shells 0..s, s = 0..7, as eight 16-bit fields */
+         const unsigned long long n0 = b0 + t0, n1 = b1 + t1;
+         ta.nbr_cum[ts + row] = make_uint4((unsigned)n0, (unsigned)(n0 >> 32), (unsigned)n1, (unsigned)(n1 >> 32));
+      }
 #pragma unroll
       for (int sh = 0; sh < 4; sh++)
       {
@@ -1124,6 +1136,13 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    const int item = mine ? ta.perm[slot] : 0;
    const int t = item & 0xffffff, part = (item >> 24) & 7, nparts = ((item >> 27) & 7) + 1;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* vLJ, vEle, xx,yy,zz,xy,xz,yz */
+   /* the last shell this launch walks (NbTileArgs::disp) */
+   int smax = NSHELL - 1;
+   if (ta.disp)
+   {
+      const double twoD = 2.0 * *ta.disp, rc = sqrt(rc2);
+      while (smax >= 1 && sqrt(ta.sh_r0sq + (double)(smax - 1) * ta.sh_step) * (1.0 - 1e-4) - twoD > rc) smax--;
+   }
    int nown = 0, ts = 0, r_lo = 0, r_hi = 0;
    if (mine)
    {
@@ -1304,6 +1323,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          double4 pi = pos[a];
          int ti = (int)(__double_as_longlong(pi.w) & 0xffll);
          int cnt_full = active ? ta.nbr_cnt[a] : 0;
+         if (smax < NSHELL - 1 && active)
+         {
+            const uint4 cq = ta.nbr_cum[a];
+            const unsigned cw = smax < 2 ? cq.x : smax < 4 ? cq.y : smax < 6 ? cq.z : cq.w;
+            cnt_full = (int)((smax & 1) ? (cw >> 16) : (cw & 0xffffu));
+         }
          /* this lane walks slot groups sub, sub+parts, ... (8 slots each) */
          int ng_full = (cnt_full + 7) >> 3;
          int ngl = (ng_full > sub) ? (ng_full - sub + parts - 1) / parts : 0;
@@ -1458,6 +1483,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          {
             /* k_kick_ke_drift on the bead, with the force still in registers (the same operations in the same order) */
             double ke[7] = {0, 0, 0, 0, 0, 0, 0};
+            float v2max = 0.0f;      /* |v|^2 of the velocity the bead drifts with, rounded up: feeds the displacement bound D (NbTileArgs::disp) */
             if (active && sub == 0)
             {
                /* (asked for here, not before the walk: held across it these twelve registers spill, and the reload costs what the load does) */
@@ -1471,6 +1497,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
                x = fma(hk, fxi, x); y = fma(hk, fyi, y); z = fma(hk, fzi, z);
                fa.vx[a] = x; fa.vy[a] = y; fa.vz[a] = z;
+               v2max = __double2float_ru(x * x + y * y + z * z);
                double4 p = pi;
                p.x = fma(fa.dt, x, p.x); p.y = fma(fa.dt, y, p.y); p.z = fma(fa.dt, z, p.z);
                fa.pos_new[a] = p;
@@ -1484,7 +1511,14 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                const double sv = wave_sum_dpp(ke[k]);      /* (uniform over the wave) */
                if (lane == k) mine = sv;
             }
+            {
+               /* the wave's largest |v|^2 (non-negative floats order like their bit patterns) */
+               int vb = __float_as_int(v2max);
+               vb = wave_max_dpp(vb);
+               if (lane == 7) mine = fmax(ke_row[7], (double)__int_as_float(vb));
+            }
             if (lane < 7) ke_row[lane] += mine;      /* one read-modify-write for the seven sums */
+            else if (lane == 7) ke_row[7] = mine;
          }
       }
       }
@@ -1516,6 +1550,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          const double *ke_s = (const double *)((char *)smem + fa.ke_off);
          double a = 0.0;
          if (nown > 0 && k < 7) for (int q = 0; q < NB_BLOCK / 64; q++) a += ke_s[q * 8 + k];
+         if (nown > 0 && k == 7) for (int q = 0; q < NB_BLOCK / 64; q++) a = fmax(a, ke_s[q * 8 + 7]);
          fa.kpartials[(size_t)slot * 8 + k] = a;
       }
    }
@@ -1533,7 +1568,8 @@ __global__ void k_zero3(int n, double *a, double *b, double *c)
  * 128 row groups finishes all columns at once.  Same order every run => bitwise
  * reproducible.  A step runs its two jobs -- the nonbonded sums (+ the final energies)
  * and the kinetic terms -- in one launch. */
-struct RedJob { const double *partials; int nblocks; int nv; double *out; int finish; };
+struct RedJob { const double *partials; int nblocks; int nv; double *out; int finish;
+                double disp_dt; double *disp; /* disp_dt > 0: column 7 holds max |v|^2 of the step's drift -- reduced by max, then *disp += disp_dt * sqrt(max) (NbTileArgs::disp) */ };
 __device__ void finish_energy(double *r, double self_ele);
 /* RED_SPLIT workgroups share a job (one workgroup reading the 0.5 MB of per-tile partials of
  * a 4 M-bead box took 21 us); each leaves its 8 sums in tmp, the last one to arrive (ticket)
@@ -1546,8 +1582,13 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    __shared__ double s[1024];
    __shared__ int s_last;
    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
+   const bool mx = k == 7 && j.disp_dt > 0.0;      /* this thread's column is a maximum (of non-negative numbers) */
    double a = 0.0;
-   if (k < j.nv)
+   if (mx)
+   {
+      for (int b = g + 128 * (int)blockIdx.x; b < j.nblocks; b += 128 * RED_SPLIT) a = fmax(a, j.partials[(size_t)b * 8 + 7]);
+   }
+   else if (k < j.nv)
    {
       /* independent partial sums: a single chain of dependent loads is latency-bound */
       double p[4] = {0, 0, 0, 0};
@@ -1565,7 +1606,7 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    __syncthreads();
    for (int off = 512; off >= 8; off >>= 1)
    {
-      if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+      if (threadIdx.x < off) s[threadIdx.x] = mx ? fmax(s[threadIdx.x], s[threadIdx.x + off]) : s[threadIdx.x] + s[threadIdx.x + off];
       __syncthreads();
    }
    double *mytmp = tmp + ((size_t)blockIdx.y * RED_SPLIT + blockIdx.x) * 8;
@@ -1580,6 +1621,15 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    }
    __syncthreads();
    if (!s_last) return;
+   if (threadIdx.x == 7 && j.disp_dt > 0.0)
+   {
+      const double *row = tmp + (size_t)blockIdx.y * RED_SPLIT * 8 + 7;
+      double t = 0.0;
+      __threadfence();
+#pragma unroll
+      for (int q = 0; q < RED_SPLIT; q++) t = fmax(t, row[q * 8]);
+      *j.disp += j.disp_dt * sqrt(t) * (1.0 + 1e-7);      /* (rounded up: |v|^2 came as a float rounded up) */
+   }
    if (threadIdx.x < (unsigned)j.nv)
    {
       const double *row = tmp + (size_t)blockIdx.y * RED_SPLIT * 8 + threadIdx.x;
@@ -1683,44 +1733,73 @@ __device__ __forceinline__ void group_gauss3(const GroupLambda &gl, int i, const
    if (gl.lcg) lcg_gauss3(gl.lcg, i, g0, g1, g2);
    else gauss3(gl.seed, gid[i], counter, g0, g1, g2);
 }
+/* the largest |v|^2 of a workgroup's drifting beads, rounded up, into column 7 of its row of partials: the displacement bound of the
+ * shell-limited walk (NbTileArgs::disp) adds dt * sqrt(max over the rows) per step (k_reduce_jobs) */
+template <int NW>
+__device__ __forceinline__ void block_vmax_store(float v2, double *row)
+{
+   __shared__ int s_vm[NW];
+   const int m = wave_max_dpp(__float_as_int(v2));      /* non-negative floats order like their bit patterns */
+   if ((threadIdx.x & 63) == 0) s_vm[threadIdx.x >> 6] = m;
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      int t = s_vm[0];
+#pragma unroll
+      for (int q = 1; q < NW; q++) t = max(t, s_vm[q]);
+      row[7] = (double)__int_as_float(t);
+   }
+}
 __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ invmass, const int *__restrict__ species,
                              const int *__restrict__ group, GroupLambda glambda, const uint64_t *__restrict__ gid,
                              const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
-                             double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz, double4 *__restrict__ pos, int mode)
+                             double *__restrict__ vx, double *__restrict__ vy, double *__restrict__ vz, double4 *__restrict__ pos, int mode,
+                             double *__restrict__ vpart /* mode 3, not null: [block][8], column 7 = the block's largest |v|^2 of the drift */)
 {
-   int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= nloc) return;
-   if (mode != 3)
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   float v2 = 0.0f;
+   if (i < nloc)
    {
-      /* nglfconstraint splits the pass around the FRONT constraint solve: mode 1 = barostat scaling of the
-       * positions (adjustPosn) + kick, mode 2 = drift with the constrained velocities */
-      double4 p = pos[i];
-      if (mode == 2) { p.x = fma(dt, vx[i], p.x); p.y = fma(dt, vy[i], p.y); p.z = fma(dt, vz[i], p.z); pos[i] = p; return; }
-      if (glambda.scale[0] != 1.0 || glambda.scale[1] != 1.0 || glambda.scale[2] != 1.0)
-      { p.x *= glambda.scale[0]; p.y *= glambda.scale[1]; p.z *= glambda.scale[2]; pos[i] = p; }
+      bool done = false;
+      if (mode != 3)
+      {
+         /* nglfconstraint splits the pass around the FRONT constraint solve: mode 1 = barostat scaling of the
+          * positions (adjustPosn) + kick, mode 2 = drift with the constrained velocities */
+         double4 p = pos[i];
+         if (mode == 2) { p.x = fma(dt, vx[i], p.x); p.y = fma(dt, vy[i], p.y); p.z = fma(dt, vz[i], p.z); pos[i] = p; done = true; }
+         else if (glambda.scale[0] != 1.0 || glambda.scale[1] != 1.0 || glambda.scale[2] != 1.0)
+         { p.x *= glambda.scale[0]; p.y *= glambda.scale[1]; p.z *= glambda.scale[2]; pos[i] = p; }
+      }
+      if (!done)
+      {
+         const double im = invmass[species[i]];
+         double a = (0.5 * dt) * im;
+         const int gr = group[i] & 31;
+         double lam = glambda.v[gr];
+         double x = vx[i], y = vy[i], z = vz[i];
+         if (glambda.lang_mask >> gr & 1u)
+         {
+            double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
+            group_gauss3(glambda, i, gid, glambda.counter_front, g0, g1, g2);
+            x = fma(d, g0, fma(a, fx[i], al * x)); y = fma(d, g1, fma(a, fy[i], al * y)); z = fma(d, g2, fma(a, fz[i], al * z));
+         }
+         else
+         {
+            if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
+            /* explicit fma: k_kick_ke_drift must produce the same bits as this kernel */
+            x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
+         }
+         vx[i] = x; vy[i] = y; vz[i] = z;
+         if (mode == 3)
+         {
+            double4 p = pos[i];
+            p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
+            pos[i] = p;
+            v2 = __double2float_ru(x * x + y * y + z * z);
+         }
+      }
    }
-   const double im = invmass[species[i]];
-   double a = (0.5 * dt) * im;
-   const int gr = group[i] & 31;
-   double lam = glambda.v[gr];
-   double x = vx[i], y = vy[i], z = vz[i];
-   if (glambda.lang_mask >> gr & 1u)
-   {
-      double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
-      group_gauss3(glambda, i, gid, glambda.counter_front, g0, g1, g2);
-      x = fma(d, g0, fma(a, fx[i], al * x)); y = fma(d, g1, fma(a, fy[i], al * y)); z = fma(d, g2, fma(a, fz[i], al * z));
-   }
-   else
-   {
-      if (lam != 1.0) { x *= lam; y *= lam; z *= lam; }
-      /* explicit fma: k_kick_ke_drift must produce the same bits as this kernel */
-      x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z);
-   }
-   vx[i] = x; vy[i] = y; vz[i] = z;
-   if (mode != 3) return;
-   double4 p = pos[i];
-   p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
-   pos[i] = p;
+   if (vpart) block_vmax_store<4>(v2, vpart + (size_t)blockIdx.x * 8);      /* (uniform: every thread of the block gets here) */
 }
 __global__ void k_scale_pos(int n, double s0, double s1, double s2, double4 *pos)
 {
@@ -1781,6 +1860,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
                                                                double4 *__restrict__ pos, double *__restrict__ partials, const uint64_t *__restrict__ gid)
 {
    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+   float v2 = 0.0f;
 #pragma unroll
    for (int u = 0; u < KE_PER; u++)
    {
@@ -1817,11 +1897,13 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
          x = fma(a, f0, x); y = fma(a, f1, y); z = fma(a, f2, z);
       }
       vx[i] = x; vy[i] = y; vz[i] = z;
+      v2 = fmaxf(v2, __double2float_ru(x * x + y * y + z * z));
       double4 p = pos[i];
       p.x = fma(dt, x, glambda.scale[0] * p.x); p.y = fma(dt, y, glambda.scale[1] * p.y); p.z = fma(dt, z, glambda.scale[2] * p.z);
       pos[i] = p;
    }
    block_reduce_store<7>(acc, partials + (size_t)blockIdx.x * 8);
+   block_vmax_store<DDCMI_BLOCK / 64>(v2, partials + (size_t)blockIdx.x * 8);      /* column 7: the displacement bound's share of this drift */
 }
 /* neighborCheck (neighbor.c:117-208), constant box: displacement of every owned bead since the
  * list was built, measured relative to the centroid of the domain's beads (positions are not
@@ -2060,6 +2142,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = hipGetErrorString(e); return DDCMI_ENODEVICE; }
    ddcmi_ctx *ctx = new ddcmi_ctx();
    ctx->device = device;
+   ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;      /* (read per context: a test sets it between two of them) */
    /* the small host-side count arrays inside the context (migration / halo counts) become DMA targets */
    ctx->self_pinned = hipHostRegister(ctx, sizeof(ddcmi_ctx), hipHostRegisterDefault) == hipSuccess;
    if (!ctx->self_pinned) (void)hipGetLastError();
@@ -2516,6 +2599,7 @@ __global__ void k_import3(int nloc, const int *orig, const double *a, const doub
 }
 extern "C" int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const double *ry, const double *rz, const double *vx, const double *vy, const double *vz)
 {
+   if (ctx) ctx->shell_skip = false;
    if (!ctx || !rx || !ry || !rz) return DDCMI_EINVAL;
    if (ctx->nloc <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_upload_positions needs an uploaded state (ddcmi_upload_state)");
    if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "ddcmi_upload_positions: caller-order arrays do not survive migration between domains");
@@ -2929,7 +3013,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->tmpw > 768) ctx->tmpw = 768;          /* k_tile_transpose keeps a row in the registers of eight lanes: at most 24 quads each */
       ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
    }
-   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad);
+   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad); ENSURE(ctx, ctx->nbr_cum, ctx->npad);
    ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
    ENSURE(ctx, ctx->tile_work, 5 * (size_t)ntile + 2);
    if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
@@ -2964,7 +3048,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
       ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_arena;
-      ta.nbr_cnt = ctx->nbr_cnt.p;
+      ta.nbr_cnt = ctx->nbr_cnt.p; ta.nbr_cum = ctx->nbr_cum.p;
       if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
       if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
@@ -3036,6 +3120,13 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    ctx->phase(13, "schedule_tiles");
    ctx->list_valid = true;
    ctx->nrebuild++;
+   {
+      /* the displacement bound of the shell-limited walk starts from this list's positions (NbTileArgs::disp).  One domain only: the
+       * halo beads of a decomposed run move by what other ranks' beads do */
+      ctx->sh_r0sq = (double)shc.r0sq; ctx->sh_step = ((double)gp.rlist * gp.rlist - (double)shc.r0sq) / (double)(NSHELL - 1.01);
+      ctx->shell_skip = !ctx->no_shell_skip && !shc.one && ctx->nranks == 1 && !ctx->loopback && !ctx->group_ && ctx->sh_step > 0.0;
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_DISP, 0, sizeof(double), st));
+   }
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }
 
@@ -3117,6 +3208,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.tile_base = ctx->tile_base.p; na.tile_width = ctx->tile_width.p; na.tile_rows = ctx->tile_rows.p;
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
+      na.disp = ctx->shell_skip ? ctx->d_results + R_DISP : nullptr; na.nbr_cum = ctx->nbr_cum.p; na.sh_r0sq = ctx->sh_r0sq; na.sh_step = ctx->sh_step;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
 #define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
@@ -3215,12 +3307,15 @@ static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forc
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK * KE_PER);
    ENSURE(ctx, ctx->kpartials, (size_t)(nblk + 8) * 8);
    if (then_drift)
+   {
+      if (gk->scale[0] != 1.0 || gk->scale[1] != 1.0 || gk->scale[2] != 1.0) ctx->shell_skip = false;      /* (scaled positions: not a plain drift) */
       hipLaunchKernelGGL(k_kick_ke_drift, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p, ctx->group.p, *gk,
                          ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, ctx->kpartials.p, ctx->gid.p);
+   }
    else
    hipLaunchKernelGGL(k_kick_ke, dim3(std::max(nblk, 1)), dim3(DDCMI_BLOCK), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->d_mass.p, ctx->species.p,
                       ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->kpartials.p, do_kick, ctx->group.p, *gk, ctx->gid.p);
-   RedJob jk = {ctx->kpartials.p, nblk, 7, ctx->d_results + R_RK, 0};
+   RedJob jk = {ctx->kpartials.p, nblk, 7, ctx->d_results + R_RK, 0, then_drift ? dt : 0.0, ctx->d_results + R_DISP};      /* (+ the drift's share of the displacement bound) */
    if (with_forces)
    {
       const bool nb_on = (ctx->excludePotentialTerm & 128) == 0;
@@ -3333,13 +3428,25 @@ static int step_pre_b(ddcmi_ctx *ctx, double dt)
       /* the FRONT solve reads the (scaled) positions of partners that are image / halo beads: adjustPosn for them too (an image
        * r + L goes to lambda r + lambda L, its place in the scaled box); the position halo after the drift replaces them */
       hipLaunchKernelGGL(k_scale_pos, dim3(cdiv(ctx->nhalo, 256)), dim3(256), 0, ctx->stream, ctx->nhalo, lam.scale[0], lam.scale[1], lam.scale[2], ctx->pos.p + n);
+   /* the displacement bound of the shell-limited walk follows a plain kick + drift only: the barostat's scaling and the drift behind a
+    * constraint solve move beads by more than dt |v| of this kernel */
+   if (ctx->ncgroup > 0 || lam.scale[0] != 1.0 || lam.scale[1] != 1.0 || lam.scale[2] != 1.0) ctx->shell_skip = false;
    if (n > 0 && ctx->ncgroup > 0)
       /* nglfconstraint.c:538-553: FRONT kick, velocityConstraintOld(FRONT) at the (scaled) positions, drift */
       hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 1);
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 1, (double *)nullptr);
    else if (n > 0)
+   {
+      double *vpart = nullptr;
+      if (ctx->shell_skip) { ENSURE(ctx, ctx->kpartials, (size_t)(nb + 8) * 8); vpart = ctx->kpartials.p; }
       hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
-                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 3);
+                         ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 3, vpart);
+      if (vpart)
+      {
+         RedJob jd = {vpart, nb, 0, nullptr, 0, dt, ctx->d_results + R_DISP};      /* D += dt max |v| */
+         hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, ctx->stream, jd, jd, ctx->d_results, 0.0, ctx->red_tmp.p);
+      }
+   }
    return DDCMI_OK;
 }
 static int step_pre_c(ddcmi_ctx *ctx, double dt)
@@ -3352,7 +3459,7 @@ static int step_pre_c(ddcmi_ctx *ctx, double dt)
       if ((rcc = ddcmi_launch_constraints(ctx, dt, 0))) return rcc;
       if (n > 0)
          hipLaunchKernelGGL(k_kick_drift, dim3(nb), dim3(256), 0, ctx->stream, n, dt, ctx->d_invmass.p, ctx->species.p, ctx->group.p, lam, ctx->gid.p,
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 2);
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->vx.p, ctx->vy.p, ctx->vz.p, ctx->pos.p, 2, (double *)nullptr);
    }
    ctx->drift_done = false;             /* else: the previous step's last kernel already did this kick + drift */
    ctx->time += dt;
@@ -3414,6 +3521,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
    int rc;
    if (more_steps && graph_ok(ctx, dt))
    {
+      ctx->shell_skip = false;      /* (a recorded launch keeps the arguments of the step it was recorded on) */
       GroupLambda lam = front_lambda(ctx, dt);
       if (ctx->graph_state == 1)
       {
@@ -3476,7 +3584,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       if (fa.dt != 0.0)
       {
          RedJob jf = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, 1};
-         RedJob jk = {ctx->kpartials.p, ctx->nitems, 7, ctx->d_results + R_RK, 0};
+         RedJob jk = {ctx->kpartials.p, ctx->nitems, 7, ctx->d_results + R_RK, 0, dt, ctx->d_results + R_DISP};      /* + this drift's share of the displacement bound */
          hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p);
          std::swap(ctx->pos, ctx->pos2);
          ctx->drift_done = true;

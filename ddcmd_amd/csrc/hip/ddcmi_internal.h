@@ -120,7 +120,7 @@ enum
    R_E = 64,                                       /* final energies[DDCMI_NE] */
    R_VIR = 72,                                     /* final virial[6] */
    R_GROUP = 80,                                   /* per-group rk, count pairs */
-   R_FLAGS = 150,                                  /* ELL overflow etc (as doubles) */
+   R_DISP = 152,                                   /* displacement bound of the shell-limited walk: sum over the steps since the rebuild of max_i |dt v_i| */
    R_SIZE = 160
 };
 
@@ -182,6 +182,8 @@ struct ddcmi_ctx
    bool baro_iso = false;                                           /* one scale factor from the mean of the three pressures (changeVolumeGPUisotropic) */
    double pmol[3] = {0, 0, 0};                                      /* molecular pressure (xx, yy, zz) the barostat last acted on */
    dbuf<ulonglong2> lcg, lcg2; bool lcg_on = false; /* Langevin groups, RANDOM type LCG64: LCG64_PARM {state; multID | prime << 32} of the owned beads in slot order; off = the counter-based stream */
+   dbuf<uint4> nbr_cum;                /* [bead] entries in shells 0..s as eight 16-bit counts (k_tile_transpose) */
+   bool shell_skip = false, no_shell_skip = false; double sh_r0sq = 0, sh_step = 0;      /* k_nonbond may end its rows at the last shell that can matter (NbTileArgs::disp); DDCMI_NO_SHELL_SKIP */
    int64_t fuse_tags_of = -1;              /* the rebuild whose halo tag words the second position buffer holds (fused steps swap the buffers) */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool slot_valid = false;            /* slot_of_orig (caller index -> device slot) belongs to the current order: refilled by the sort of a rebuild only when something

@@ -469,6 +469,39 @@ def test_step_with_the_integrator_inside_the_pair_kernel_equals_the_split_step(t
     a.close(); b.close()
 
 
+def test_rows_end_at_the_last_shell_that_can_matter(monkeypatch):
+    """the pair kernel ends every row at the last distance shell a pair could have left since the rebuild (the displacement
+    bound D = sum of the steps' max |dt v|, kept by the fused step): entries of later shells lay further than r_cut + 2 D from
+    their bead when the list was built, so leaving them out changes nothing -- forces, positions and velocities equal those of
+    a context that walks every entry (DDCMI_NO_SHELL_SKIP) bit for bit over two rebuild periods, at a start temperature
+    (hot beads: large D) and after cooling the velocities to a crawl (D ~ 0: half of every row is skipped)"""
+    from ddcmd_amd.martini import MartiniHIP
+    for vscale in (3.0, 0.02):
+        s = make_water_setup(12)
+        s.vx, s.vy, s.vz = (np.asarray(v) * vscale for v in (s.vx, s.vy, s.vz))
+        monkeypatch.delenv("DDCMI_NO_SHELL_SKIP", raising=False)
+        a = MartiniHIP(s)
+        monkeypatch.setenv("DDCMI_NO_SHELL_SKIP", "1")
+        b = MartiniHIP(s)
+        monkeypatch.delenv("DDCMI_NO_SHELL_SKIP", raising=False)
+        o = pyoracle.Oracle(s)
+        o.forces()
+        a.eval_forces(); b.eval_forces()
+        for block in range(3):
+            n = (17, 20, 8)[block]
+            a.step(n); b.step(n)
+            eo, vo, rko, _ = o.step(n)
+            da, db = a.download(), b.download()
+            for k in ("r", "v", "f"):
+                for c in range(3):
+                    assert np.array_equal(da[k][c], db[k][c]), (vscale, block, k, c)
+            ea, _, rka, _ = a.energies()
+            eb, _, rkb, _ = b.energies()
+            assert ea["total"] == eb["total"] and rka == rkb
+            assert abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rka - rko) < TOL * max(rko, 1e-300)
+        a.close(); b.close()
+
+
 def test_langevin_group_matches_oracle_and_thermalises():
     """LANGEVIN group (langevin.c:92-128): the device update equals the oracle's restatement with the same
     counter-based normal stream (trajectory parity), and drives a 50 K box to Teq (the statistical
