@@ -1367,8 +1367,8 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   int tjj = PACKED ? (SHBIT ? (nib_ & 7) : nib_) : (int)T_s[o[u] >> 4]; \
                   double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
                   double ir = 0.0, ir2; \
-                  if (HAS_Q) { ir = rsqrt_f64(r2[u]); ir2 = ir * ir; } \
-                  else ir2 = rcp_f64(r2[u]); \
+                  if (HAS_Q) { ir = rsqrt_f64_pair(r2[u]); ir2 = ir * ir; } \
+                  else ir2 = rcp_f64_pair(r2[u]); \
                   double s2 = lj.x * ir2; \
                   double s4 = s2 * s2; \
                   double s6 = s4 * s2; \

@@ -301,6 +301,23 @@ __device__ __forceinline__ double rsqrt_f64(double x)
    y = fma(y, e, y);
    return y;
 }
+/* the pair kernel's versions: the double-precision hardware seeds (v_rsq_f64 / v_rcp_f64: not full precision by themselves -- bare, they
+ * fail the force parity by 1e-8 -- but good for one Newton step instead of two, without the two conversions: k_nonbond -2 % at 4 M
+ * water, -3 % on the lipid box).  The bonded kernels keep the versions above: their branch census (tests/test_gpu_branches.py) is
+ * pinned to that rounding. */
+__device__ __forceinline__ double rsqrt_f64_pair(double x)
+{
+   double y = __builtin_amdgcn_rsq(x);
+   const double h = 0.5 * x;
+   const double e = fma(-(h * y), y, 0.5);
+   return fma(y, e, y);
+}
+__device__ __forceinline__ double rcp_f64_pair(double x)
+{
+   double y = __builtin_amdgcn_rcp(x);
+   const double e = fma(-x, y, 1.0);
+   return fma(y, e, y);
+}
 /* 1/x: v_rcp_f32 seed + two Newton steps y += y*(1 - x y): 2 FP64 ops each.  Used
  * when no bead carries a charge: Lennard-Jones needs 1/r^2 only, no square root. */
 __device__ __forceinline__ double rcp_f64(double x)

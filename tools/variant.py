@@ -2,7 +2,7 @@
 """Tuning builds that never touch the product: copy csrc/hip to a scratch directory, apply text substitutions,
 compile for gfx950 and link tuning/libddcmi_<name>.so (git-ignored; select it with DDCMI_LIB=...).
 
-   python3 tools/variant.py <name> [-D FLAG ...] [--sub 'old' 'new' ...] [--patch file.py]
+   python3 tools/variant.py <name> [-D FLAG ...] [--sub 'old' 'new' ...] [--hsub 'old' 'new' ...] [--patch file.py]      (--hsub: in ddcmi_internal.h)
 
 --patch file.py: a python file defining edit(src: str) -> str, applied to ddcmi.hip."""
 import os, shutil, subprocess, sys
@@ -12,12 +12,13 @@ CSRC = os.path.join(ROOT, "ddcmd_amd", "csrc")
 
 def main():
     name = sys.argv[1]
-    flags, subs, patch = [], [], None
+    flags, subs, patch, hsubs = [], [], None, []
     a = sys.argv[2:]
     while a:
         if a[0] == "-D": flags.append("-D" + a[1]); a = a[2:]
         elif a[0] == "--sub": subs.append((a[1], a[2])); a = a[3:]
         elif a[0] == "--patch": patch = a[1]; a = a[2:]
+        elif a[0] == "--hsub": hsubs.append((a[1], a[2])); a = a[3:]
         else: raise SystemExit("unknown argument " + a[0])
     work = os.path.join("/tmp", "ddcmi_variant_" + name)
     shutil.rmtree(work, ignore_errors=True)
@@ -32,6 +33,13 @@ def main():
         exec(open(patch).read(), g)
         src = g["edit"](src)
     open(fn, "w").write(src)
+    if hsubs:
+        hn = os.path.join(work, "hip", "ddcmi_internal.h")
+        h = open(hn).read()
+        for old, new in hsubs:
+            if old not in h: raise SystemExit("header substitution source not found: " + old[:60])
+            h = h.replace(old, new)
+        open(hn, "w").write(h)
     subprocess.check_call(["make", "-s", "-C", CSRC])      # host objects
     objs = []
     procs = []
