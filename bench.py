@@ -307,6 +307,13 @@ def main():
     ap.add_argument("--check-runtime", action="store_true", help="rendezvous + library load only: print which HIP/RCCL runtime is mapped, touch no device")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: RCCL prints its version banner to C stdout when a communicator comes up
+    # (the loopback brick of `also`, every multi-rank run), so file descriptor 1 points at stderr while the libraries work and the
+    # line goes out through a duplicate of the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -344,7 +351,7 @@ def main():
         tok = rdzv.bcast(b"ddcmi-runtime-check-%06d" % os.getpid() if rank == 0 else bytes(26), 0) if rdzv else b""
         n = rdzv.allreduce([1.0])[0] if rdzv else 1.0
         print(json.dumps({"rank": rank, "world": world, "ranks_met": int(n), "token": tok.decode(), "runtime_libs": runtime_libs(),
-                          "torch_loaded": "torch" in sys.modules}), flush=True)
+                          "torch_loaded": "torch" in sys.modules}), file=real_stdout, flush=True)
         if rdzv:
             rdzv.barrier()
             rdzv.close()
@@ -381,8 +388,8 @@ def main():
         rdzv.barrier()
         rdzv.close()
     if rank == 0:
-        ctypes.CDLL(None).fflush(None)                      # anything the libraries left in C stdio goes out first
-        print(json.dumps(out), flush=True)
+        ctypes.CDLL(None).fflush(None)                      # anything the libraries left in C stdio goes out first (to stderr)
+        print(json.dumps(out), file=real_stdout, flush=True)
 
 
 if __name__ == "__main__":
