@@ -201,9 +201,10 @@ __global__ void k_wrap_cell(GridParams gp, int nloc, const double4 *pos, int *ci
    base = __shfl(base, hl, 64);
    if (c >= 0) rank[i] = base + (lane - hl);
 }
-__global__ void k_scatter_order(int n, const int *cid, const int *rank, const int *cell_start, int *order)
+__global__ void k_scatter_order(int n, const int *cid, const int *rank, const int *cell_start, int *order, const int *n_dev = nullptr /* the count, where the host only knows a bound */)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n_dev) n = min(n, *n_dev);
    if (i >= n) return;
    order[cell_start[cid[i]] + rank[i]] = i;
 }
@@ -293,7 +294,7 @@ __device__ __forceinline__ void image_dirs(const GridParams &gp, const double4 &
    }
 }
 __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const int *img_off, const int *nimg,
-                              int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h)
+                              int *hsrc, int *hshift, int *hcid, int *hrank, int *cell_cnt_h, int cap /* images beyond it are dropped: the host sees the count and starts over */)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= nloc || nimg[i] == 0) return;      /* three beads in four have no image: their records are not read */
@@ -310,6 +311,7 @@ __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const
             double x = p.x + ix * gp.L[0], y = p.y + iy * gp.L[1], z = p.z + iz * gp.L[2];
             int side[3] = {ix, iy, iz};
             int c = halo_cell(gp, x, y, z, side);
+            if (k >= cap) return;
             hsrc[k] = i;
             hshift[k] = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
             hcid[k] = c;
@@ -317,9 +319,10 @@ __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const
             k++;
          }
 }
-__global__ void k_gather_halo(int nhalo, const int *horder, const int *hsrc_t, const int *hshift_t, int *halo_src, int *halo_shift)
+__global__ void k_gather_halo(int nhalo, const int *horder, const int *hsrc_t, const int *hshift_t, int *halo_src, int *halo_shift, const int *n_dev)
 {
    int h = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n_dev) nhalo = min(nhalo, *n_dev);
    if (h >= nhalo) return;
    int k = horder[h];
    halo_src[h] = hsrc_t[k];
@@ -330,9 +333,10 @@ __global__ void k_gather_halo(int nhalo, const int *horder, const int *hsrc_t, c
  * src < 0 -> bead -1-src of the buffer received from a neighbour domain (the sender
  * has already applied the periodic shift). */
 __global__ void k_halo_update(int nloc, int nhalo, const int *halo_src, const int *halo_shift, double L0, double L1, double L2,
-                              double4 *pos, uint64_t *gid, bool with_tags, const double *hrecv3, const double *hrecv5)
+                              double4 *pos, uint64_t *gid, bool with_tags, const double *hrecv3, const double *hrecv5, const int *n_dev = nullptr)
 {
    int h = blockIdx.x * blockDim.x + threadIdx.x;
+   if (n_dev) nhalo = min(nhalo, *n_dev);
    if (h >= nhalo) return;
    int s = halo_src[h];
    if (s >= 0)
@@ -2142,7 +2146,9 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = hipGetErrorString(e); return DDCMI_ENODEVICE; }
    ddcmi_ctx *ctx = new ddcmi_ctx();
    ctx->device = device;
-   ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;      /* (read per context: a test sets it between two of them) */
+   ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
+   ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
+   ctx->debug_image_bound = getenv("DDCMI_DEBUG_IMAGE_BOUND") ? atoi(getenv("DDCMI_DEBUG_IMAGE_BOUND")) : 0;      /* (read per context: a test sets it between two of them) */
    /* the small host-side count arrays inside the context (migration / halo counts) become DMA targets */
    ctx->self_pinned = hipHostRegister(ctx, sizeof(ddcmi_ctx), hipHostRegisterDefault) == hipSuccess;
    if (!ctx->self_pinned) (void)hipGetLastError();
@@ -2202,6 +2208,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
    if (ctx->ev_build) (void)hipEventDestroy(ctx->ev_build);
    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+   if (ctx->stream_post) { (void)hipStreamSynchronize(ctx->stream_post); (void)hipStreamDestroy(ctx->stream_post); }
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -2516,6 +2523,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
          if (group[i] < 0 || group[i] >= ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "particle %d has group %d outside [0,%d)", i, group[i], ctx->ngroup);
    int n = nlocal;
    ctx->lcg_on = false;      /* the streams belong to the beads of the upload they followed: ddcmi_set_random_lcg64 again */
+   ctx->nhalo_hint = 0;      /* (another system: the first rebuild waits for its image count) */
    size_t cap = (size_t)n + n / 4 + 1024;     /* room for image atoms; grown on demand */
    ENSURE(ctx, ctx->pos, cap); ENSURE(ctx, ctx->pos2, cap);
    ENSURE(ctx, ctx->gid, cap); ENSURE(ctx, ctx->gid2, cap);
@@ -2775,15 +2783,29 @@ static int bl_self_images(ddcmi_ctx *ctx)
    int n = ctx->nloc, nb = cdiv(n, 256), rc;
    /* (nimg was counted by k_gather_state) */
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->nimg.p, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
-   PostJobs pj;
-   pj.add(ctx->d_flags + 8, 1);
-   if ((rc = ddcmi_post(ctx, st, pj)) || (rc = ddcmi_post_wait(ctx, st))) return rc;
-   int nh = ctx->mbox_h[pj.off[0]];
+   ctx->nhalo_dev = nullptr;
+   int nh;
+   if (ctx->nhalo_hint > 0 && !ctx->no_image_hint)
+   {
+      /* The image count moves by a fraction of a per cent between rebuilds: the kernels that lay the images out are launched for a bound
+       * taken from the last rebuild and read the count on the device; the host learns it with the build's other results (ddcmi_bl_finish)
+       * instead of waiting for it here -- one host round trip less per rebuild.  A count beyond the bound starts the rebuild over. */
+      nh = ctx->nhalo_hint + ctx->nhalo_hint / 32 + 1024;
+      if (ctx->debug_image_bound > 0) nh = std::min(nh, ctx->debug_image_bound);      /* (tests: force the start-over path) */
+      ctx->nhalo_dev = ctx->d_flags + 8;
+   }
+   else
+   {
+      PostJobs pj;
+      pj.add(ctx->d_flags + 8, 1);
+      if ((rc = ddcmi_post(ctx, st, pj)) || (rc = ddcmi_post_wait(ctx, st))) return rc;
+      nh = ctx->mbox_h[pj.off[0]];
+   }
    ctx->nhalo = nh;
    if (nh > 0)
    {
       if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
-      hipLaunchKernelGGL(k_fill_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->img_off.p, ctx->nimg.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p);
+      hipLaunchKernelGGL(k_fill_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->img_off.p, ctx->nimg.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p, nh);
    }
    return DDCMI_OK;
 }
@@ -2798,14 +2820,14 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
    {
       int nhb = cdiv(nh, 256);
       if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ncell, nullptr))) return rc;
-      hipLaunchKernelGGL(k_scatter_order, dim3(nhb), dim3(256), 0, st, nh, ctx->hcid.p, ctx->hrank.p, ctx->cell_start_h.p, ctx->horder.p);
+      hipLaunchKernelGGL(k_scatter_order, dim3(nhb), dim3(256), 0, st, nh, ctx->hcid.p, ctx->hrank.p, ctx->cell_start_h.p, ctx->horder.p, (const int *)ctx->nhalo_dev);
       if (ctx->hkey_valid)      /* decomposed runs: halo descriptors arrive in the order atomics filled the send lists */
          hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p, ctx->hkey.p, ctx->hshift_t.p);
       else
          hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
-      hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p);
+      hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p, (const int *)ctx->nhalo_dev);
       hipLaunchKernelGGL(k_halo_update, dim3(nhb), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
-                         ctx->hrecv3.p, ctx->hrecv5.p);
+                         ctx->hrecv3.p, ctx->hrecv5.p, (const int *)ctx->nhalo_dev);
    }
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
@@ -2830,12 +2852,19 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    if ((rc = nb_tables(ctx))) return rc;
    if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
    ctx->phase(-1, nullptr);
-   if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
-   ctx->phase(0, "sort_owned launched");
-   if ((rc = bl_self_images(ctx))) return rc;
-   ctx->phase(1, "self_images (sync)");
-   if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
-   if ((rc = ddcmi_bl_finish(ctx))) return rc;
+   for (int pass = 0;; pass++)
+   {
+      if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;      /* (idempotent: a second pass sorts sorted beads) */
+      ctx->phase(0, "sort_owned launched");
+      if ((rc = bl_self_images(ctx))) return rc;
+      ctx->phase(1, "self_images (sync)");
+      if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
+      rc = ddcmi_bl_finish(ctx);
+      if (rc == DDCMI_RETRY_IMAGES && pass == 0) continue;      /* more periodic images than the last rebuild's count allowed for */
+      if (rc) return rc;
+      break;
+   }
+   ctx->nhalo_hint = ctx->nhalo;
    ctx->phase(14, "localize");
    return ddcmi_mol_split_finish(ctx);      /* one domain: no molecule is split */
 }
@@ -3068,7 +3097,12 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
       PostJobs pj;
       pj.add(ctx->d_flags, 64).add(ctx->tile_work.p, 5 * (size_t)ntile);      /* flags + the tiles' costs and totals: one post, read while the transposition runs */
-      { int rcp = ddcmi_post(ctx, st, pj); if (rcp) return rcp; }
+      /* (on a stream of its own behind the build: its trip over the host link no longer stands between the build and the transposition) */
+      if (!ctx->stream_post) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream_post, hipStreamNonBlocking));
+      if (!ctx->ev_build) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_build, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_post, ctx->ev_build, 0));
+      { int rcp = ddcmi_post(ctx, ctx->stream_post, pj); if (rcp) return rcp; }
       {
          const bool scr16 = ctx->pack_type != 0;
          const size_t lds2 = (size_t)(TR_THREADS / 64) * ctx->tmpw * TR_S * sizeof(unsigned short) + (scr16 ? (size_t)ctx->stage_cap + 16 : 0);
@@ -3079,8 +3113,21 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       }
       HIPCHK(ctx, hipGetLastError());
       ctx->phase(11, "build+transpose launched");
-      { int rcp = ddcmi_post_wait(ctx, st); if (rcp) return rcp; }
+      { int rcp = ddcmi_post_wait(ctx, ctx->stream_post); if (rcp) return rcp; }
       memcpy(ctx->h_flags, ctx->mbox_h + pj.off[0], 64 * sizeof(int));
+      if (ctx->nhalo_dev)
+      {
+         /* the image count the rebuild was launched without (bl_self_images) */
+         const int nh_true = ctx->h_flags[8], bound = ctx->nhalo;
+         ctx->nhalo_dev = nullptr;
+         if (nh_true > bound)
+         {
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            ctx->nhalo_hint = 0;
+            return DDCMI_RETRY_IMAGES;      /* (ddcmi_build_list starts over, waiting for the count this time) */
+         }
+         ctx->nhalo = nh_true;
+      }
       memcpy(h_work, ctx->mbox_h + pj.off[1], 5 * (size_t)ntile * sizeof(int));
       ctx->phase(12, "wait for the build");
       tot[0] = tot[1] = 0;
@@ -3167,9 +3214,10 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       HIPCHK(ctx, hipEventRecord(ctx->ev_halo, ctx->stream2));
       halo_pending = true;
    }
-   else if (nh > 0)
+   else if (nh > 0 && !ctx->images_fresh)      /* (the rebuild this step began with made the periodic images from these very positions) */
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
+   ctx->images_fresh = false;
    const bool has_bonded = (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) > 0;
    const double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
    if ((ctx->excludePotentialTerm & 128) == 0)
@@ -3289,7 +3337,7 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
    (void)hipSetDevice(ctx->device);
    int rc;
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group evaluate forces with ddcmi_group_eval_forces");
-   if (!ctx->list_valid && (rc = ddcmi_build_list(ctx))) return rc;
+   if (!ctx->list_valid) { if ((rc = ddcmi_build_list(ctx))) return rc; ctx->images_fresh = true; }
    if ((rc = launch_forces(ctx))) return rc;
    ctx->molv_valid = false;
    if ((rc = fetch_results(ctx))) return rc;
@@ -3711,7 +3759,7 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
       /* ddcUpdateAll.c:64-71: rebuild when loop % updateRate == 0, or (updateRate == 0) when neighborCheck asks */
       bool due = false;
       if ((rc = rebuild_due(ctx, &due))) return rc;
-      if (due && (rc = ddcmi_build_list(ctx))) return rc;
+      if (due) { if ((rc = ddcmi_build_list(ctx))) return rc; ctx->images_fresh = true; }      /* (nothing moves between here and this step's forces) */
       if ((rc = step_post(ctx, dt, s + 1 < nsteps))) return rc;
    }
    return DDCMI_OK;

@@ -12,6 +12,7 @@
 #include "ddcmi.h"
 
 #define DDCMI_BLOCK 256
+#define DDCMI_RETRY_IMAGES 1001        /* internal: ddcmi_bl_finish found more periodic images than the rebuild was launched for */
 
 /* tile = TCX x TCY x TCZ cells (8x4x4 of >= (rmax+deltaR)/2 wide cells: ~500 beads, a
  * 64 x 32 x 32 A slab); its neighbourhood = the tile plus two cells on every side */
@@ -165,6 +166,7 @@ struct ddcmi_ctx
    int nitems = 0;                     /* work items of k_nonbond: the tiles with owned beads, the last ones of each XCD's run cut into parts */
    int sched_cache[2][8][3] = {};      /* tail split of each class and XCD run: {tiles it was found for, tiles cut, parts} */
    int sched_longest[2] = {0, 0}, ntile_class[2] = {0, 0};      /* class 0: all-owned neighbourhoods (all tiles on one domain), class 1: the rest */
+   hipStream_t stream_post = nullptr;  /* the post of the build's results to the host, beside the transposition */
    hipStream_t stream2 = nullptr;      /* decomposed runs: halo exchange, concurrent with the class-0 tiles */
    hipEvent_t ev_drift = nullptr, ev_halo = nullptr, ev_build = nullptr;
    bool halo_overlap = false;          /* DDCMI_HALO_OVERLAP=1: exchange on stream2 under the all-owned tiles */
@@ -184,6 +186,8 @@ struct ddcmi_ctx
    dbuf<ulonglong2> lcg, lcg2; bool lcg_on = false; /* Langevin groups, RANDOM type LCG64: LCG64_PARM {state; multID | prime << 32} of the owned beads in slot order; off = the counter-based stream */
    dbuf<uint4> nbr_cum;                /* [bead] entries in shells 0..s as eight 16-bit counts (k_tile_transpose) */
    bool shell_skip = false, no_shell_skip = false; double sh_r0sq = 0, sh_step = 0;      /* k_nonbond may end its rows at the last shell that can matter (NbTileArgs::disp); DDCMI_NO_SHELL_SKIP */
+   int nhalo_hint = 0; const int *nhalo_dev = nullptr; bool no_image_hint = false; int debug_image_bound = 0;      /* single-domain rebuilds after the first: the image count stays on the device until the build's post (bl_self_images); DDCMI_NO_IMAGE_HINT */
+   bool images_fresh = false;          /* the list was rebuilt in front of this force evaluation: the periodic images of a single domain need no update */
    int64_t fuse_tags_of = -1;              /* the rebuild whose halo tag words the second position buffer holds (fused steps swap the buffers) */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
    bool slot_valid = false;            /* slot_of_orig (caller index -> device slot) belongs to the current order: refilled by the sort of a rebuild only when something

@@ -502,6 +502,30 @@ def test_rows_end_at_the_last_shell_that_can_matter(monkeypatch):
         a.close(); b.close()
 
 
+def test_rebuild_without_waiting_for_the_image_count(monkeypatch):
+    """single-domain rebuilds after the first launch the image layout for a bound taken from the last rebuild and learn the
+    count with the build's other results; a count beyond the bound starts the rebuild over (forced here through
+    DDCMI_DEBUG_IMAGE_BOUND): both paths and the waiting one (DDCMI_NO_IMAGE_HINT) give the same trajectory bit for bit"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(12)
+    out = []
+    for env in ({}, {"DDCMI_NO_IMAGE_HINT": "1"}, {"DDCMI_DEBUG_IMAGE_BOUND": "100"}):
+        for k in ("DDCMI_NO_IMAGE_HINT", "DDCMI_DEBUG_IMAGE_BOUND"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = MartiniHIP(s)
+        m.eval_forces()
+        m.step(65)
+        st = m.download()
+        e, vir, rk, _ = m.energies()
+        out.append((e["total"], rk, np.concatenate(st["r"] + st["v"] + st["f"]), m.list_stats()["rebuilds"], m.list_stats()["images"]))
+        m.close()
+    for o in out[1:]:
+        assert o[0] == out[0][0] and o[1] == out[0][1] and np.array_equal(o[2], out[0][2]) and o[3] == out[0][3] and o[4] == out[0][4]
+    assert out[0][3] >= 4 and out[0][4] > 100
+
+
 def test_langevin_group_matches_oracle_and_thermalises():
     """LANGEVIN group (langevin.c:92-128): the device update equals the oracle's restatement with the same
     counter-based normal stream (trajectory parity), and drives a 50 K box to Teq (the statistical
