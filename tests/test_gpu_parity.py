@@ -469,6 +469,34 @@ def test_step_with_the_integrator_inside_the_pair_kernel_equals_the_split_step(t
     a.close(); b.close()
 
 
+def test_two_berendsen_groups_with_different_factors_take_the_split_kernels():
+    """the fused epilogue carries ONE Berendsen factor; a step on which two groups scale differently falls back to the split
+    kernels with the factors just formed -- the trajectory follows the oracle through such steps and through steps where the
+    factors coincide (1.0: the interval skips them)"""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(10)
+    s.ngroup = 2
+    s.group_name = ["cold", "hot"]
+    s.group = (np.arange(s.natoms) % 2).astype(np.int32)
+    s.group_type = np.array([1, 1], np.int32)
+    s.group_Teq = np.array([units_convert(250.0, "K"), units_convert(400.0, "K")])
+    s.group_tau = np.array([units_convert(2.0, "ps"), units_convert(1.0, "ps")])
+    s.group_interval = np.array([3, 1], np.int32)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    m = MartiniHIP(s)
+    m.eval_forces()
+    for block in range(3):
+        o.group_temperature(); m.group_temperatures()
+        eo, vo, rko, _ = o.step(15)
+        m.step(15)
+        e, vir, rk, _ = m.energies()
+        assert abs(rk - rko) < TOL * rko and abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+    d = m.download()
+    assert np.abs(d["v"][1] - o.vy).max() < 1e-8 * np.abs(o.vy).max()
+    m.close()
+
+
 def test_rows_end_at_the_last_shell_that_can_matter(monkeypatch):
     """the pair kernel ends every row at the last distance shell a pair could have left since the rebuild (the displacement
     bound D = sum of the steps' max |dt v|, kept by the fused step): entries of later shells lay further than r_cut + 2 D from
