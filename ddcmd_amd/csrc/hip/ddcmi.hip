@@ -1580,9 +1580,8 @@ __device__ void finish_energy(double *r, double self_ele);
  * adds the RED_SPLIT rows in index order.  tmp: [2 jobs][RED_SPLIT][8] doubles, then 2 ticket
  * counters (left at zero). */
 #define RED_SPLIT 8
-__global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp)
+__device__ __forceinline__ void reduce_jobs_block(const RedJob &j, const int bx, const int by, double *results, double self_ele, double *tmp)
 {
-   const RedJob j = blockIdx.y ? j1 : j0;
    __shared__ double s[1024];
    __shared__ int s_last;
    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
@@ -1590,13 +1589,13 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    double a = 0.0;
    if (mx)
    {
-      for (int b = g + 128 * (int)blockIdx.x; b < j.nblocks; b += 128 * RED_SPLIT) a = fmax(a, j.partials[(size_t)b * 8 + 7]);
+      for (int b = g + 128 * bx; b < j.nblocks; b += 128 * RED_SPLIT) a = fmax(a, j.partials[(size_t)b * 8 + 7]);
    }
    else if (k < j.nv)
    {
       /* independent partial sums: a single chain of dependent loads is latency-bound */
       double p[4] = {0, 0, 0, 0};
-      int b = g + 128 * (int)blockIdx.x;
+      int b = g + 128 * bx;
       const int stride = 128 * RED_SPLIT;
       for (; b + 3 * stride < j.nblocks; b += 4 * stride)
       {
@@ -1613,8 +1612,8 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
       if (threadIdx.x < off) s[threadIdx.x] = mx ? fmax(s[threadIdx.x], s[threadIdx.x + off]) : s[threadIdx.x] + s[threadIdx.x + off];
       __syncthreads();
    }
-   double *mytmp = tmp + ((size_t)blockIdx.y * RED_SPLIT + blockIdx.x) * 8;
-   unsigned int *ticket = (unsigned int *)(tmp + 2 * RED_SPLIT * 8) + blockIdx.y;
+   double *mytmp = tmp + ((size_t)by * RED_SPLIT + bx) * 8;
+   unsigned int *ticket = (unsigned int *)(tmp + 2 * RED_SPLIT * 8) + by;
    if (threadIdx.x < 8) { mytmp[threadIdx.x] = s[threadIdx.x]; __threadfence(); }
    __syncthreads();
    if (threadIdx.x == 0)
@@ -1627,7 +1626,7 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    if (!s_last) return;
    if (threadIdx.x == 7 && j.disp_dt > 0.0)
    {
-      const double *row = tmp + (size_t)blockIdx.y * RED_SPLIT * 8 + 7;
+      const double *row = tmp + (size_t)by * RED_SPLIT * 8 + 7;
       double t = 0.0;
       __threadfence();
 #pragma unroll
@@ -1636,7 +1635,7 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    }
    if (threadIdx.x < (unsigned)j.nv)
    {
-      const double *row = tmp + (size_t)blockIdx.y * RED_SPLIT * 8 + threadIdx.x;
+      const double *row = tmp + (size_t)by * RED_SPLIT * 8 + threadIdx.x;
       double t = 0.0;
       __threadfence();          /* acquire: the other workgroups' rows, written on other XCDs */
 #pragma unroll
@@ -1649,6 +1648,27 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
       if (threadIdx.x == 0) finish_energy(results, self_ele);
    }
 }
+__global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp)
+{
+   reduce_jobs_block(blockIdx.y ? j1 : j0, (int)blockIdx.x, (int)blockIdx.y, results, self_ele, tmp);
+}
+/* the same two jobs and, in further workgroups of the same launch, the periodic images of a single domain brought up to the positions
+ * the fused pair kernel has just drifted to (k_halo_update's self-image arm): both only wait for that kernel, one launch instead of two */
+struct ImageJob { int nloc, nhalo; const int *halo_src, *halo_shift; double L0, L1, L2; double4 *pos; };
+__global__ __launch_bounds__(1024) void k_reduce_jobs_images(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp, ImageJob im)
+{
+   const int b = (int)blockIdx.x;
+   if (b < 2 * RED_SPLIT) { reduce_jobs_block(b < RED_SPLIT ? j0 : j1, b % RED_SPLIT, b / RED_SPLIT, results, self_ele, tmp); return; }
+   const int h = (b - 2 * RED_SPLIT) * 1024 + (int)threadIdx.x;
+   if (h >= im.nhalo) return;
+   const int src = im.halo_src[h], code = im.halo_shift[h];
+   double4 p = im.pos[src];
+   p.x += (double)(code % 3 - 1) * im.L0;
+   p.y += (double)((code / 3) % 3 - 1) * im.L1;
+   p.z += (double)(code / 9 - 1) * im.L2;
+   im.pos[im.nloc + h] = p;
+}
+
 /* final energies / virial: full list counts every pair twice */
 __device__ void finish_energy(double *r, double self_ele)
 {
@@ -2607,7 +2627,7 @@ __global__ void k_import3(int nloc, const int *orig, const double *a, const doub
 }
 extern "C" int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const double *ry, const double *rz, const double *vx, const double *vy, const double *vz)
 {
-   if (ctx) ctx->shell_skip = false;
+   if (ctx) { ctx->shell_skip = false; ctx->images_fresh = false; }
    if (!ctx || !rx || !ry || !rz) return DDCMI_EINVAL;
    if (ctx->nloc <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_upload_positions needs an uploaded state (ddcmi_upload_state)");
    if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "ddcmi_upload_positions: caller-order arrays do not survive migration between domains");
@@ -3570,6 +3590,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
    if (more_steps && graph_ok(ctx, dt))
    {
       ctx->shell_skip = false;      /* (a recorded launch keeps the arguments of the step it was recorded on) */
+      ctx->images_fresh = false;    /* (and its kernels: the recording must hold the image update) */
       GroupLambda lam = front_lambda(ctx, dt);
       if (ctx->graph_state == 1)
       {
@@ -3633,8 +3654,16 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       {
          RedJob jf = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, 1};
          RedJob jk = {ctx->kpartials.p, ctx->nitems, 7, ctx->d_results + R_RK, 0, dt, ctx->d_results + R_DISP};      /* + this drift's share of the displacement bound */
-         hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p);
          std::swap(ctx->pos, ctx->pos2);
+         if (ctx->nhalo > 0 && ctx->nranks == 1 && !ctx->loopback)
+         {
+            /* + the periodic images at the drifted positions, in the same launch: the next force evaluation finds them fresh */
+            ImageJob im = {ctx->nloc, ctx->nhalo, ctx->halo_src.p, ctx->halo_shift.p, ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p};
+            hipLaunchKernelGGL(k_reduce_jobs_images, dim3(2 * RED_SPLIT + cdiv(ctx->nhalo, 1024)), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p, im);
+            ctx->images_fresh = true;
+         }
+         else
+            hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p);
          ctx->drift_done = true;
          return DDCMI_OK;
       }
