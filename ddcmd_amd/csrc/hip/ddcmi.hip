@@ -1655,10 +1655,26 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
 /* the same two jobs and, in further workgroups of the same launch, the periodic images of a single domain brought up to the positions
  * the fused pair kernel has just drifted to (k_halo_update's self-image arm): both only wait for that kernel, one launch instead of two */
 struct ImageJob { int nloc, nhalo; const int *halo_src, *halo_shift; double L0, L1, L2; double4 *pos; };
-__global__ __launch_bounds__(1024) void k_reduce_jobs_images(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp, ImageJob im)
+/* ... or, in a decomposed run, the halo messages packed from the drifted positions (k_pack_halo, width 3) */
+struct PackJob { int nsend; const unsigned *send_map; int shift[27][3]; double L0, L1, L2; const double4 *pos; double *out; };
+__global__ __launch_bounds__(1024) void k_reduce_jobs_images(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp, ImageJob im, PackJob pk)
 {
    const int b = (int)blockIdx.x;
    if (b < 2 * RED_SPLIT) { reduce_jobs_block(b < RED_SPLIT ? j0 : j1, b % RED_SPLIT, b / RED_SPLIT, results, self_ele, tmp); return; }
+   const int nimb = (im.nhalo + 1023) / 1024;
+   if (b >= 2 * RED_SPLIT + nimb)
+   {
+      const int k = (b - 2 * RED_SPLIT - nimb) * 1024 + (int)threadIdx.x;
+      if (k >= pk.nsend) return;
+      const unsigned m = pk.send_map[k];
+      const int i = (int)(m & 0x7ffffffu), code = (int)(m >> 27);
+      const double4 p = pk.pos[i];
+      double *o = pk.out + (size_t)k * 3;
+      o[0] = p.x + pk.shift[code][0] * pk.L0;
+      o[1] = p.y + pk.shift[code][1] * pk.L1;
+      o[2] = p.z + pk.shift[code][2] * pk.L2;
+      return;
+   }
    const int h = (b - 2 * RED_SPLIT) * 1024 + (int)threadIdx.x;
    if (h >= im.nhalo) return;
    const int src = im.halo_src[h], code = im.halo_shift[h];
@@ -2627,7 +2643,7 @@ __global__ void k_import3(int nloc, const int *orig, const double *a, const doub
 }
 extern "C" int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const double *ry, const double *rz, const double *vx, const double *vy, const double *vz)
 {
-   if (ctx) { ctx->shell_skip = false; ctx->images_fresh = false; }
+   if (ctx) { ctx->shell_skip = false; ctx->images_fresh = false; ctx->pack_fresh = false; }
    if (!ctx || !rx || !ry || !rz) return DDCMI_EINVAL;
    if (ctx->nloc <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_upload_positions needs an uploaded state (ddcmi_upload_state)");
    if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "ddcmi_upload_positions: caller-order arrays do not survive migration between domains");
@@ -2869,6 +2885,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
    (void)hipSetDevice(ctx->device);
    int rc;
+   ctx->pack_fresh = false;      /* (the rebuild's own exchange reuses the send buffer) */
    if ((rc = nb_tables(ctx))) return rc;
    if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
    ctx->phase(-1, nullptr);
@@ -3447,6 +3464,8 @@ static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
  *                                                                            -> velocity halo (constraints only)
  *   c  constraints: FRONT solve, drift; clock */
 static int mg_allreduce_host_values(ddcmi_ctx *ctx, double *values, int n);
+struct PackJob;
+static bool ddcmi_mg_pack_job(ddcmi_ctx *ctx, PackJob *pk);
 static int mg_allreduce_device(ddcmi_ctx *ctx, double *d, size_t n);
 int ddcmi_mg_refresh_vel(ddcmi_ctx *ctx);
 static inline bool decomposed(const ddcmi_ctx *ctx) { return ctx->nranks > 1 || ctx->loopback || ctx->group_ != nullptr; }
@@ -3655,12 +3674,22 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
          RedJob jf = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, 1};
          RedJob jk = {ctx->kpartials.p, ctx->nitems, 7, ctx->d_results + R_RK, 0, dt, ctx->d_results + R_DISP};      /* + this drift's share of the displacement bound */
          std::swap(ctx->pos, ctx->pos2);
+         PackJob pk;
+         memset(&pk, 0, sizeof(pk));
          if (ctx->nhalo > 0 && ctx->nranks == 1 && !ctx->loopback)
          {
             /* + the periodic images at the drifted positions, in the same launch: the next force evaluation finds them fresh */
             ImageJob im = {ctx->nloc, ctx->nhalo, ctx->halo_src.p, ctx->halo_shift.p, ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p};
-            hipLaunchKernelGGL(k_reduce_jobs_images, dim3(2 * RED_SPLIT + cdiv(ctx->nhalo, 1024)), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p, im);
+            hipLaunchKernelGGL(k_reduce_jobs_images, dim3(2 * RED_SPLIT + cdiv(ctx->nhalo, 1024)), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p, im, pk);
             ctx->images_fresh = true;
+         }
+         else if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_overlap && ddcmi_mg_pack_job(ctx, &pk) && pk.nsend > 0)
+         {
+            /* + this rank's halo messages packed from the drifted positions: the next step's exchange starts with the sends */
+            ImageJob im;
+            memset(&im, 0, sizeof(im));
+            hipLaunchKernelGGL(k_reduce_jobs_images, dim3(2 * RED_SPLIT + cdiv(pk.nsend, 1024)), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p, im, pk);
+            ctx->pack_fresh = true;
          }
          else
             hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 2), dim3(1024), 0, ctx->stream, jf, jk, ctx->d_results, ctx->self_ele, ctx->red_tmp.p);

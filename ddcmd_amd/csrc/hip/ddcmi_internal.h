@@ -187,6 +187,7 @@ struct ddcmi_ctx
    dbuf<uint4> nbr_cum;                /* [bead] entries in shells 0..s as eight 16-bit counts (k_tile_transpose) */
    bool shell_skip = false, no_shell_skip = false; double sh_r0sq = 0, sh_step = 0;      /* k_nonbond may end its rows at the last shell that can matter (NbTileArgs::disp); DDCMI_NO_SHELL_SKIP */
    int nhalo_hint = 0; const int *nhalo_dev = nullptr; bool no_image_hint = false; int debug_image_bound = 0;      /* single-domain rebuilds after the first: the image count stays on the device until the build's post (bl_self_images); DDCMI_NO_IMAGE_HINT */
+   bool pack_fresh = false;            /* decomposed runs: the halo send buffer already holds the current positions (packed in the fused step's reduction launch) */
    bool images_fresh = false;          /* the list was rebuilt in front of this force evaluation: the periodic images of a single domain need no update */
    int64_t fuse_tags_of = -1;              /* the rebuild whose halo tag words the second position buffer holds (fused steps swap the buffers) */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */

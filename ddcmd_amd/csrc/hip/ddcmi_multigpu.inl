@@ -869,11 +869,24 @@ static int mg_pack3(ddcmi_ctx *ctx, hipStream_t st)
    }
    return DDCMI_OK;
 }
+/* the pack of the next halo refresh as a job of the fused step's reduction launch (k_reduce_jobs_images) */
+static bool ddcmi_mg_pack_job(ddcmi_ctx *ctx, PackJob *pk)
+{
+   if (ctx->group_ || !ctx->list_valid || ctx->nsend <= 0 || !ctx->send_map.p || !ctx->sendbuf.p) return false;
+   const DirTab dt = mg_dirtab(ctx);
+   pk->nsend = ctx->nsend; pk->send_map = ctx->send_map.p;
+   for (int c = 0; c < 27; c++) for (int a = 0; a < 3; a++) pk->shift[c][a] = dt.shift[c][a];
+   pk->L0 = ctx->gp.L[0]; pk->L1 = ctx->gp.L[1]; pk->L2 = ctx->gp.L[2];
+   pk->pos = ctx->pos.p; pk->out = ctx->sendbuf.p;
+   return true;
+}
 int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st)
 {
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "in-process group: halos are refreshed by ddcmi_group_step_nglf / ddcmi_group_eval_forces");
    int rc;
-   if ((rc = mg_pack3(ctx, st))) return rc;
+   const bool packed = ctx->pack_fresh;      /* (the fused step before this one left the messages packed) */
+   ctx->pack_fresh = false;
+   if (!packed && (rc = mg_pack3(ctx, st))) return rc;
    if ((rc = mg_xchg_halo(ctx, ctx->sendbuf.p, ctx->hrecv3.p, 3, st))) return rc;
    ctx->halo_fresh = true;
    return DDCMI_OK;
