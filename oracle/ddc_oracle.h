@@ -8,7 +8,9 @@
  * PARITY UNPINNED: the reference ships no golden outputs and no runnable test
  * for this path, and cannot be compiled here (its util/, recbis/, cub/
  * submodules are empty; every hot-path .c includes three_algebra.h/object.h/
- * units.h from them).  This file restates the reference algorithm function by
+ * units.h from them).  The exception: primes.c builds by itself (oracle/_ref,
+ * oracle/Makefile) and pins orc_next_prime / orc_lcg64_default's primes
+ * (tests/test_ref_pinned.py).  This file restates the reference algorithm function by
  * function (each block cites /root/reference/src file:line) and is
  * cross-validated by an independent O(N^2) evaluation, finite differences
  * (forcetest.c method), sum(F)=0 and NVE drift in tests/.
