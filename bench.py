@@ -286,6 +286,43 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves -- N fresh child processes of this
+    very command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as `python -m torch.distributed.run
+    --nproc-per-node N` would.  The parent has loaded no library and touched no device (and never execs): it relays the
+    children's output (rank 0 prints the JSON line), ends the others when one fails, and returns the first non-zero exit code."""
+    import subprocess
+    if n not in (2, 4, 8):
+        sys.stderr.write("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)\n")
+        return 2
+    import tempfile
+    rc = 0
+    # rank 0 listens on a port of its own choosing and publishes it through a file only this launch knows (host/rdzv.c) -- no port
+    # picked here that somebody else could take in between
+    with tempfile.TemporaryDirectory(prefix="ddcmi_bench_") as d:
+        procs = []
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "0",
+                        "DDCMI_RDZV_FILE": os.path.join(d, "port"), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+            env.pop("DDCMI_RDZV_PORT", None)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))      # stdout / stderr inherited: one JSON line from rank 0
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                alive.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    sys.stderr.write("bench.py: rank %d of %d exited with code %d; ending the other ranks\n" % (r, n, c))
+                    for q in alive:
+                        procs[q].terminate()      # (exactly the PIDs started above)
+            time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +343,14 @@ def main():
                          "liquid state (~307 K after 200 steps): default 200 for water, 0 for the lipid deck (a relaxed restart)")
     ap.add_argument("--check-runtime", action="store_true", help="rendezvous + library load only: print which HIP/RCCL runtime is mapped, touch no device")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a launcher that started W ranks of a bench asked for N GPUs: a flat scaling curve in the making -- refuse
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher's world and --gpus must agree\n" % (args.gpus, os.environ["WORLD_SIZE"]))
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))      # `python bench.py --gpus N` without a launcher: this process only starts and watches the N ranks
 
     # stdout carries the ONE JSON line and nothing else: RCCL prints its version banner to C stdout when a communicator comes up
     # (the loopback brick of `also`, every multi-rank run), so file descriptor 1 points at stderr while the libraries work and the
@@ -344,6 +389,8 @@ def main():
         except DdcmiError as ex:
             sys.stderr.write("bench.py rank %d of %d: rendezvous failed: %s\n" % (rank, world, ex))
             sys.exit(2)
+    if os.environ.get("DDCMI_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: this rank dies after the rendezvous
+        os._exit(7)
     if args.check_runtime:
         # the launcher and the runtime binding, without touching a device
         import ddcmd_amd

@@ -61,3 +61,46 @@ def test_bench_rank_that_never_arrives_ends_the_launch(built):
         assert p.returncode == 2 and time.time() - t0 < 60
         assert "rendezvous failed" in p.stderr and "only 1 of 2 ranks arrived" in p.stderr, p.stderr[-800:]
         assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def _no_launcher_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DDCMI_RDZV_FILE", "DDCMI_RDZV_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks(built):
+    """`python3 bench.py --gpus N` as the driver starts N = 1 -- no launcher, no WORLD_SIZE -- used to run ONE rank
+    and print n_gpus 1.  The command itself now starts its N ranks (fresh children, before any library is loaded)."""
+    for n in (2, 8):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--check-runtime"], cwd=ROOT, env=_no_launcher_env(),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+        assert sorted(r["rank"] for r in recs) == list(range(n))
+        assert all(r["world"] == n and r["ranks_met"] == n and r["torch_loaded"] is False for r in recs)
+        assert len({r["token"] for r in recs}) == 1
+
+
+def test_bench_gpus_must_agree_with_the_launchers_world(built):
+    env = _no_launcher_env()
+    env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--check-runtime"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 2 and "must agree" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_self_launch_ends_with_the_failing_ranks_code(built):
+    """one rank of a self-started launch fails (here: an unsupported GPU count is refused before any rank starts; a rank that dies
+    takes the launch down with its exit code)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--check-runtime"], cwd=ROOT, env=_no_launcher_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 2 and "1, 2, 4 or 8" in p.stderr
+    env = _no_launcher_env()
+    env["DDCMI_BENCH_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-runtime"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    # (rank 0 may notice its peer's death -- a reset connection -- and fail first: either way the launch ends non-zero, at once, and says who)
+    assert p.returncode in (1, 7) and "ending the other ranks" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -181,6 +181,23 @@ def test_bench_world2_as_the_driver_launches_it():
     assert abs(out["check"]["ekin"] - one["check"]["ekin"]) < 1e-7 * abs(one["check"]["ekin"])
 
 
+def test_bench_gpus2_with_no_launcher_runs_two_ranks():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver starts N = 1 (no launcher, no WORLD_SIZE): the command
+    starts its two ranks itself; n_gpus and the ranks that met say 2"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DDCMI_RDZV_FILE", "DDCMI_RDZV_PORT"):
+        env.pop(k, None)
+    env.update({"DDCMI_BENCH_SINGLE_DEVICE": "1", "DDCMI_TRANSPORT": "host"})      # (one GPU on the test box: both ranks on device 0, host-staged messages)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lattice", "14", "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm"]["ranks_met"] == 2 and sum(out["comm"]["beads_per_rank"]) == 4 * 14 ** 3
+    assert "2x1x1" in out["config"]["parallelism"] and out["value"] > 0
+
+
 def test_nglfconstraint_between_processes():
     """constraints + barostat with the ranks in separate processes: velocity halo and the barostat's all-reduce (incl. the
     split molecules' partial sums) travel over the transport; both processes arrive at the oracle's box and pressure"""
