@@ -1,35 +1,58 @@
-"""ctypes loader for libddcmi.so (the product).  Fails loudly when absent."""
+"""ctypes loader for the product: libddcmi.so -- the drop-in boundary, HIP device code behind the C-ABI of
+include/ddcmi.h and nothing else -- and libddcmi_host.so, the stand-alone host layer (object-file reader, units,
+deck loader, plugin glue under ddcMD's own names).  Fails loudly when absent."""
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DDCMI_LIB: kernel-tuning builds of the same library (tools/build_variants.sh)
+# DDCMI_LIB: kernel-tuning builds of the device library (tools/variant.py)
 LIB_PATH = os.environ.get("DDCMI_LIB") or os.path.join(_HERE, "lib", "libddcmi.so")
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libddcmi_host.so")
 
 
 class LibraryMissing(RuntimeError):
     pass
 
 
+class _Libs(object):
+    """one handle over both libraries: ddcmi_* of include/ddcmi.h from the device library, the rest from the host layer"""
+
+    def __init__(self, dev, host):
+        self.dev, self.host = dev, host
+
+    def __getattr__(self, name):
+        for lib in (self.dev, self.host):
+            try:
+                f = getattr(lib, name)
+            except AttributeError:
+                continue
+            setattr(self, name, f)
+            return f
+        raise AttributeError(name)
+
+
 _lib = None
 
 
 def load_library():
-    """Return the ctypes handle of libddcmi.so; raise LibraryMissing if it is not built.
+    """Return the handle of libddcmi.so + libddcmi_host.so; raise LibraryMissing if they are not built.
 
     There is deliberately no fallback: the HIP library *is* the implementation.
     """
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise LibraryMissing(
-            "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C ddcmd_amd/csrc`)" % LIB_PATH)
+    for path in (LIB_PATH, HOST_LIB_PATH):
+        if not os.path.exists(path):
+            raise LibraryMissing(
+                "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C ddcmd_amd/csrc`)" % path)
     # several processes sharing device memory (RCCL between the ranks of a node): this pool's host driver only supports
     # dmabuf IPC; the HIP runtime reads the switch when it initialises, i.e. after this line
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    dev = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)      # (first, and global: the host layer's libddcmi.so dependency resolves to THIS copy by soname)
+    host = ctypes.CDLL(HOST_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    _lib = _Libs(dev, host)
     _declare(_lib)
     return _lib
 

@@ -2081,8 +2081,8 @@ __global__ void k_init_state(int n, const double *rx, const double *ry, const do
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
    int sp = species[i];
-   unsigned code = (unsigned)(gid[i] & 0xffffull);
-   long long w = (long long)((gid[i] >> 32) << 32) | ((long long)(sp & 0xffff) << 16) | ((long long)min(code, 255u) << 8) | (long long)(ljtype_sp[sp] & 0xff);
+   unsigned code = (unsigned)(gid[i] & DDCMI_GID_ATMGRPMASK);
+   long long w = (long long)(gid[i] & DDCMI_GID_MOLMASK) | ((long long)(sp & 0xffff) << 16) | ((long long)min(code, 255u) << 8) | (long long)(ljtype_sp[sp] & 0xff);
    pos[i] = make_double4(rx[i], ry[i], rz[i], __longlong_as_double(w));
    orig[i] = i;
    slot[i] = i;

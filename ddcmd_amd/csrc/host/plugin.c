@@ -139,7 +139,7 @@ static int cmp_gid(const void *a, const void *b)
 }
 static int martiniBondHIPParms(ddcmi_ctx *ctx, const ddcmi_setup *s)
 {
-   const uint64_t molResMask = 0xffffffffffff0000ull;
+   const uint64_t molResMask = DDCMI_GID_MOLRESMASK;
    int n = s->natoms;
    int nb_tot = s->bond_off[s->nresi], na_tot = s->angle_off[s->nresi], nt_tot = s->tors_off[s->nresi];
    if (nb_tot + na_tot + nt_tot == 0)
@@ -302,7 +302,7 @@ void martiniHIP(SYSTEM *sys, void *parms_, ETYPE *e)
  * order) and the molecule lists the barostat's molecular virial runs over (molecularPressure.c:23-56) */
 static void nglfconstraintHIP_parms(ddcmi_ctx *ctx, const ddcmi_setup *s)
 {
-   const uint64_t molResMask = 0xffffffffffff0000ull, molMask = 0xffffffff00000000ull;
+   const uint64_t molResMask = DDCMI_GID_MOLRESMASK, molMask = DDCMI_GID_MOLMASK;
    int n = s->natoms;
    gid_order *ord = malloc(sizeof(gid_order) * (n > 0 ? n : 1));
    for (int i = 0; i < n; i++) { ord[i].id = i; ord[i].gid = s->gid[i]; }

@@ -43,6 +43,17 @@ enum { DDCMI_POS = 1, DDCMI_VEL = 2, DDCMI_FORCE = 4 };
 /* group (thermostat) kinds: free.c, berendsen.c */
 enum { DDCMI_FREE = 0, DDCMI_BERENDSEN = 1, DDCMI_LANGEVIN = 2 };
 
+/* particle labels (gid_type = uint64_t, gid.h:13): MOL 32 | RESID 16 | GROUP 8 | ATOM 8 (bioGid.h:13-22).  The molecule id
+ * (reOrgPairs, molecule lists), the residue runs of the bonded terms (charmmResidues) and the group:atom codes of the
+ * bonded-pair lists are read off a label with these masks; tests/test_abi.py holds them against the reference's own header */
+#define DDCMI_GID_MOLSHIFT   32
+#define DDCMI_GID_ATMMASK    0x00000000000000ffull
+#define DDCMI_GID_ATMGRPMASK 0x000000000000ffffull
+#define DDCMI_GID_GRPMASK    0x000000000000ff00ull
+#define DDCMI_GID_RESMASK    0x00000000ffff0000ull
+#define DDCMI_GID_MOLMASK    0xffffffff00000000ull
+#define DDCMI_GID_MOLRESMASK 0xffffffffffff0000ull
+
 /* ---- context -------------------------------------------------------------
  * replaces accelerator_init / accelerator_getAccelerator (accelerator.c:10-56)
  * and the allocation half of allocSendGPUState / allocGPUBoxInfo

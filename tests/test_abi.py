@@ -25,6 +25,59 @@ def test_library_exports_every_declared_symbol(built):
     assert not missing, missing
 
 
+def test_device_library_exports_nothing_but_the_declared_c_abi(built):
+    """libddcmi.so used to export ddcMD's OWN names (nglf, ddcenergy, object_get, units_convert ...) with different
+    signatures, plus every mangled internal: -lddcmi into ddcMD meant duplicate definitions / interposition.  Its dynamic symbol
+    table is now exactly the functions include/ddcmi.h declares (version script generated from the header); the stand-alone host
+    layer with the reference-named symbols lives in libddcmi_host.so."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == _declared_functions(os.path.join(ROOT, "include", "ddcmi.h")), [n for n in exported if not n.startswith("ddcmi_")][:10]
+    host = subprocess.check_output(["nm", "-D", "--defined-only", _lib.HOST_LIB_PATH], text=True)
+    host = {l.split()[-1] for l in host.splitlines() if l.strip()}
+    assert {"nglf", "ddcenergy", "object_get", "units_convert", "martiniHIP", "nglfHIP"} <= host and not (host & set(exported))
+    deps = subprocess.check_output(["readelf", "-d", _lib.HOST_LIB_PATH], text=True)
+    assert "libddcmi.so" in deps                      # the host layer reaches the device through the C-ABI like any other client
+
+
+def test_links_beside_definitions_of_ddcmds_own_names(built, tmp_path):
+    """a program that defines nglf, ddcenergy, kinetic_terms, object_get, units_convert ... with the reference's signatures links
+    with -lddcmi alone, reaches its own definitions, and the library never calls them (tests/abi/link_with_ddcmd_names.c; the
+    -m gpu twin runs forces and steps through it)"""
+    import subprocess
+    exe = str(tmp_path / "link_with_ddcmd_names")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "abi", "link_with_ddcmd_names.c"), "-L" + libdir, "-lddcmi",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    lib = ddcmd_amd.load_library()
+    lib.ddcmi_device_count.restype = ctypes.c_int
+    if lib.ddcmi_device_count() > 0:
+        return          # (with a device the program wants its input file: tests/test_gpu_abi_link.py)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("nodevice stubs_called_by_library 0"), (out.stdout, out.stderr)
+
+
+def test_integrator_struct_and_label_masks_against_the_references_own_headers(built, tmp_path):
+    """integrator.h, bioGid.h and gid.h compile by themselves: where /root/reference exists they are INCLUDED (tests/abi/ref_headers.c),
+    not transcribed; what they print is the committed fixture tests/golden/ref_headers.txt (made by that very program), and host/plugin.h +
+    include/ddcmi.h must print the same (integrator.h:5-17, bioGid.h:13-22, gid.h:13)"""
+    import subprocess
+    abi = os.path.join(ROOT, "tests", "abi")
+    want = open(os.path.join(ROOT, "tests", "golden", "ref_headers.txt")).read().splitlines()
+    exe = str(tmp_path / "our_headers")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-I" + os.path.join(ROOT, "ddcmd_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(abi, "our_headers.c")])
+    assert subprocess.check_output([exe], text=True).splitlines() == want
+    ref = "/root/reference/src"
+    if os.path.exists(os.path.join(ref, "bioGid.h")):
+        exe = str(tmp_path / "ref_headers")
+        subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-I" + ref, "-o", exe, os.path.join(abi, "ref_headers.c")])
+        assert subprocess.check_output([exe], text=True).splitlines() == want
+    assert len(want) > 20
+
+
 def test_host_layer_symbols(built):
     lib = ddcmd_amd.load_library()
     for n in ("object_compilefile", "object_get", "object_getv", "object_find", "units_convert", "units_internal", "units_external",

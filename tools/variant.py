@@ -52,8 +52,9 @@ def main():
     if any(p.wait() for p in procs): raise SystemExit("compile failed")
     out = os.path.join(ROOT, "tuning", "libddcmi_%s.so" % name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    host = [os.path.join(CSRC, "build", "host", f) for f in os.listdir(os.path.join(CSRC, "build", "host")) if f.endswith(".o")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + host + objs + ["-L/opt/rocm/lib", "-lrccl", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
+    host = [os.path.join(CSRC, "build", "host", "rdzv.o")]      # the device library = HIP objects + the rendezvous, same export map and soname as the tree's
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + host + objs +
+                          ["-Wl,--version-script=" + os.path.join(CSRC, "build", "ddcmi.map"), "-Wl,-soname,libddcmi.so", "-L/opt/rocm/lib", "-lrccl", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
     print("built", out)
 
 
