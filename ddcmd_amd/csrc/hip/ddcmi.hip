@@ -47,6 +47,27 @@ static hipError_t dyn_lds_limit(int device, const void *fn, int bytes)
    return e;
 }
 
+/* k_nonbond addresses its staged beads by raw LDS byte offsets from LDS address 0 (a list entry's slot bits ARE the gather's
+ * address): that holds while the kernel has no static LDS, so that its dynamic region starts at 0.  Asked of the runtime once per
+ * (device, kernel) -- a compiler or runtime update that adds static LDS makes every launch return an error with this message
+ * (the kernel used to check on the device and __builtin_trap(): a process abort with no message). */
+static bool lds_starts_at_zero(int device, const void *fn, size_t *static_bytes)
+{
+   static std::mutex mu;
+   static std::map<std::pair<int, const void *>, size_t> seen;
+   std::lock_guard<std::mutex> lk(mu);
+   auto it = seen.find(std::make_pair(device, fn));
+   if (it == seen.end())
+   {
+      hipFuncAttributes at;
+      memset(&at, 0, sizeof(at));
+      const size_t sb = hipFuncGetAttributes(&at, fn) == hipSuccess ? at.sharedSizeBytes : 0;
+      it = seen.emplace(std::make_pair(device, fn), sb).first;
+   }
+   *static_bytes = it->second;
+   return it->second == 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* small device helpers                                                       */
 __device__ __forceinline__ int cell_linear(const GridParams &gp, int cx, int cy, int cz)
@@ -1121,12 +1142,11 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    unsigned char *S_s = T_s + (PACKED ? 0 : ta.cap);      /* 1: the staged bead is a periodically shifted copy */
    /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
     * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
-    * starts at LDS address 0 and the z gather needs no base add.  Checked here, not assumed. */
+    * starts at LDS address 0 and the z gather needs no base add.  Checked by the host before the first launch, not assumed. */
    typedef __attribute__((address_space(3))) const double lds_cdouble;
    typedef double xy_t __attribute__((ext_vector_type(2)));
    typedef __attribute__((address_space(3))) const xy_t lds_cxy;
-   const unsigned xy_off = ZOFF ? 0u : (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)XY_s;
-   if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)smem != 0u) __builtin_trap();
+   const unsigned xy_off = ZOFF ? 0u : (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)XY_s;      /* (the dynamic region starts at LDS address 0: launch_forces asks the runtime, lds_starts_at_zero) */
    /* XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs, so
     * give XCD x one contiguous tile range (schedule_tiles: equal work per XCD):
     * neighbouring tiles, which stage overlapping neighbourhoods, then share one L2.
@@ -2184,14 +2204,15 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->device = device;
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
    ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
-   ctx->debug_image_bound = getenv("DDCMI_DEBUG_IMAGE_BOUND") ? atoi(getenv("DDCMI_DEBUG_IMAGE_BOUND")) : 0;      /* (read per context: a test sets it between two of them) */
+   /* test hook, armed only together with DDCMI_DEBUG_HOOKS=1 (a stray value alone does nothing; read per context: a test sets it between two of them) */
+   ctx->debug_image_bound = (getenv("DDCMI_DEBUG_HOOKS") && getenv("DDCMI_DEBUG_IMAGE_BOUND")) ? atoi(getenv("DDCMI_DEBUG_IMAGE_BOUND")) : 0;
    /* the small host-side count arrays inside the context (migration / halo counts) become DMA targets */
    ctx->self_pinned = hipHostRegister(ctx, sizeof(ddcmi_ctx), hipHostRegisterDefault) == hipSuccess;
    if (!ctx->self_pinned) (void)hipGetLastError();
    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
        hipMalloc((void **)&ctx->d_results, R_SIZE * sizeof(double)) != hipSuccess ||
        hipHostMalloc((void **)&ctx->h_results, R_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-       hipMalloc((void **)&ctx->d_flags, 64 * sizeof(int)) != hipSuccess ||
+       hipMalloc((void **)&ctx->d_flags, DDCMI_NFLAGS * sizeof(int)) != hipSuccess ||
        hipHostMalloc((void **)&ctx->h_flags, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess)
    {
       g_create_err = "context allocation failed";
@@ -2200,7 +2221,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
-   (void)hipMemset(ctx->d_flags, 0, 64 * sizeof(int));
+   (void)hipMemset(ctx->d_flags, 0, DDCMI_NFLAGS * sizeof(int));
    if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the context's non-blocking stream */
@@ -2252,6 +2273,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
    for (int k = 0; k < 3; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
    if (ctx->mbox_h) (void)hipHostFree(ctx->mbox_h);
+   if (ctx->agree_h) (void)hipHostFree(ctx->agree_h);
    (void)hipStreamDestroy(ctx->stream);
    if (ctx->self_pinned) (void)hipHostUnregister(ctx);
    delete ctx;
@@ -2538,6 +2560,7 @@ extern "C" void *ddcmi_stream(ddcmi_ctx *ctx) { return ctx ? (void *)ctx->stream
 extern "C" int ddcmi_sync(ddcmi_ctx *ctx)
 {
    if (!ctx) return DDCMI_EINVAL;
+   { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    return DDCMI_OK;
 }
@@ -2673,6 +2696,7 @@ extern "C" int ddcmi_download_state(ddcmi_ctx *ctx, int mask, double *rx, double
 {
    if (!ctx || ctx->nloc <= 0) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
+   { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }
    int n = ctx->nloc, nb = cdiv(n, 256);
    /* scratch: vx2,vy2,vz2 are free between rebuilds */
    if ((mask & DDCMI_POS) && rx && ry && rz)
@@ -2827,7 +2851,7 @@ static int bl_self_images(ddcmi_ctx *ctx)
        * taken from the last rebuild and read the count on the device; the host learns it with the build's other results (ddcmi_bl_finish)
        * instead of waiting for it here -- one host round trip less per rebuild.  A count beyond the bound starts the rebuild over. */
       nh = ctx->nhalo_hint + ctx->nhalo_hint / 32 + 1024;
-      if (ctx->debug_image_bound > 0) nh = std::min(nh, ctx->debug_image_bound);      /* (tests: force the start-over path) */
+      if (ctx->debug_image_bound > 0) nh = std::min(nh, ctx->debug_image_bound);      /* (tests, DDCMI_DEBUG_HOOKS=1 only: force the start-over path) */
       ctx->nhalo_dev = ctx->d_flags + 8;
    }
    else
@@ -3297,6 +3321,9 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
 #define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
+         size_t sb_ = 0; \
+         if (!lds_starts_at_zero(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>, &sb_)) \
+            SETERR(ctx, DDCMI_EUNSUPPORTED, "k_nonbond was built with %zu bytes of static LDS: its staged arrays no longer start at LDS address 0 (toolchain change) -- rebuild libddcmi.so with a compiler that gives it none", sb_); \
          HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>, (int)lds)); \
          hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl16.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
@@ -3363,6 +3390,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
 
 static int fetch_results(ddcmi_ctx *ctx)
 {
+   { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }      /* (a peer whose rebuild failed: say so instead of waiting behind an exchange it never joins) */
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, R_SIZE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    return DDCMI_OK;

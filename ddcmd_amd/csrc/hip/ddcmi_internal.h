@@ -12,6 +12,11 @@
 #include "ddcmi.h"
 
 #define DDCMI_BLOCK 256
+/* d_flags slots: [0,64) the rebuild's flags and the arena counter ([32,34), a cache line of its own), posted to the host as one block;
+ * [64] the ticket of the mailbox post (scan.hip: k_post), [96] / [97] the in / out word of the rebuild's error agreement */
+#define DDCMI_NFLAGS 128
+#define DDCMI_FLAG_TICKET 64
+#define DDCMI_FLAG_AGREE 96
 #define DDCMI_RETRY_IMAGES 1001        /* internal: ddcmi_bl_finish found more periodic images than the rebuild was launched for */
 
 /* tile = TCX x TCY x TCZ cells (8x4x4 of >= (rmax+deltaR)/2 wide cells: ~500 beads, a
@@ -229,7 +234,11 @@ struct ddcmi_ctx
    /* reductions */
    dbuf<double> partials, bpartials; int npartial_blocks = 0;
    double *d_results = nullptr; double *h_results = nullptr;
-   int *d_flags = nullptr; int *h_flags = nullptr; bool self_pinned = false;
+   int *d_flags = nullptr; int *h_flags = nullptr; bool self_pinned = false;      /* d_flags: DDCMI_NFLAGS ints, see the DDCMI_FLAG_* slots */
+   /* decomposed runs, RCCL transport: the outcome of a rebuild's local phase (mg_phase4_finish) is agreed on by an all-reduce that
+    * nobody waits for -- its result lands in agree_h (mapped host memory, [0] = sequence word, [1] = worst error code) and is
+    * looked at in front of the next host wait (ddcmi_agree_poll) */
+   int *agree_h = nullptr, *agree_d = nullptr; int agree_seq = 0; bool agree_pending = false; int64_t agree_loop = 0;
    /* growable pinned host staging (so that small copies are truly asynchronous): [0] tile work, [1] tile order, [2] count exchange */
    /* the mailbox (scan.hip: ddcmi_post / ddcmi_post_wait): mapped coherent host memory, [0] = sequence word */
    int *mbox_h = nullptr, *mbox_d = nullptr; size_t mbox_cap = 0; int mbox_seq = 0;
@@ -352,6 +361,7 @@ struct PostJobs
 };
 int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j);            /* device arrays -> the mailbox; fills j.off */
 int ddcmi_post_wait(ddcmi_ctx *ctx, hipStream_t st);                    /* spin until the post has landed */
+int ddcmi_agree_poll(ddcmi_ctx *ctx);                                   /* in front of a host wait: has a peer reported a failed rebuild? (ddcmi_multigpu.inl) */
 int ddcmi_fetch(ddcmi_ctx *ctx, hipStream_t st, int *dst, const int *src_host_mapped, int n);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
 int ddcmi_ensure_slots(ddcmi_ctx *ctx);

@@ -410,6 +410,7 @@ static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over,
 {
    hipStream_t st = ctx->stream;
    const int nr = std::max(ctx->nranks, 1);
+   { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }      /* the last rebuild's agreement, before this rank waits on a collective again */
    const std::string local_msg = ctx->err;
    int *h = ctx->pinned(2, 64 + (MG_BLK + 27) * (size_t)nr);
    if (!h) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the count exchange");
@@ -466,6 +467,7 @@ static int mg_counts_round(ddcmi_ctx *ctx, int *scnt, int *rcnt, bool *any_over,
    plan_recv_counts(ctx->dir_dest, ctx->rank, ctx->loopback, packed, rcnt);
    return DDCMI_OK;
 }
+static int mg_fatal(ddcmi_ctx *ctx, int code, const char *msg);
 /* the ranks agree on the outcome of a phase that has no count round behind it: max of the error codes (one small collective) */
 static int mg_agree(ddcmi_ctx *ctx, int local_rc)
 {
@@ -495,6 +497,83 @@ static int mg_agree(ddcmi_ctx *ctx, int local_rc)
    }
    if (local_rc) { ctx->err = local_msg; return local_rc; }
    if (worst) SETERR(ctx, DDCMI_ECOMM, "another rank failed during the list rebuild (error %d): its own message says why", worst);
+   return DDCMI_OK;
+}
+/* The same agreement without anybody waiting for it (RCCL transport, rebuilds after the first two).  ADVICE r3: from the third
+ * rebuild on a rank whose local phase failed (a bond stretched beyond the halo in a system going unstable, a capacity, an
+ * allocation) used to abort its communicator and return, and its peers sat in the next halo kernel until something outside
+ * killed the job.  Now every rank contributes its error code to an all-reduce (max) queued behind the phase's kernels, a post
+ * kernel leaves the result in mapped host memory, and nobody waits: the failing rank returns its own error once the
+ * collective has run; a healthy rank goes on queueing steps and looks at the word in front of its next host wait (ddcmi_agree_poll:
+ * the next rebuild's count round, a read of energies, a download, ddcmi_sync) -- the word lands BEFORE the exchange the failed
+ * peer never joins, so the look cannot hang, and a reported failure aborts the communicator (which releases the waiting
+ * kernels) and returns DDCMI_ECOMM naming the rebuild.  Cost: one small collective per rebuild on the stream, no host wait. */
+__global__ void k_agree_post(const int *src, int *dst, int seq)
+{
+   if (threadIdx.x == 0)
+   {
+      dst[1] = *src;
+      __threadfence_system();
+      __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
+}
+static int mg_agree_async(ddcmi_ctx *ctx, int local_rc, int pretend_peer_code = 0 /* tests: the code a failed peer would have contributed */)
+{
+   hipStream_t st = ctx->stream;
+   if (!ctx->agree_h)
+   {
+      if (hipHostMalloc((void **)&ctx->agree_h, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { ctx->agree_h = nullptr; return mg_agree(ctx, local_rc); }
+      if (hipHostGetDevicePointer((void **)&ctx->agree_d, ctx->agree_h, 0) != hipSuccess) { (void)hipHostFree(ctx->agree_h); ctx->agree_h = nullptr; return mg_agree(ctx, local_rc); }
+      memset(ctx->agree_h, 0, 16 * sizeof(int));
+   }
+   { int rcp = ddcmi_agree_poll(ctx); if (rcp && !local_rc) return rcp; }      /* (never two agreements in flight) */
+   const std::string local_msg = ctx->err;
+   int *h = ctx->pinned(2, 64);
+   if (!h) return mg_agree(ctx, local_rc);
+   h[0] = std::max(local_rc < 0 ? -local_rc : local_rc, pretend_peer_code);
+   int *d = ctx->d_flags + DDCMI_FLAG_AGREE;
+   HIPCHK(ctx, hipMemcpyAsync(d, h, sizeof(int), hipMemcpyHostToDevice, st));
+   NCCLCHK2(ctx, ncclAllReduce(d, d + 1, 1, ncclInt, ncclMax, (ncclComm_t)ctx->comm, st));
+   ctx->agree_seq++;
+   hipLaunchKernelGGL(k_agree_post, dim3(1), dim3(64), 0, st, d + 1, ctx->agree_d, ctx->agree_seq);
+   ctx->agree_pending = true; ctx->agree_loop = ctx->loop;
+   if (local_rc)
+   {
+      /* this rank's own failure: it has told the others; it returns once the collective has run (its peers all join it) */
+      (void)hipStreamSynchronize(st);
+      ctx->agree_pending = false;
+      ctx->err = local_msg;
+      return local_rc;
+   }
+   return DDCMI_OK;
+}
+int ddcmi_agree_poll(ddcmi_ctx *ctx)
+{
+   if (!ctx->agree_pending) return DDCMI_OK;
+   volatile int *flag = ctx->agree_h;
+   struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+   for (unsigned long spin = 0;; spin++)
+   {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->agree_seq) break;
+      if ((spin & 0xff) == 0xff)
+      {
+         struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+         if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 20.0)
+         {
+            ctx->agree_pending = false;
+            return mg_fatal(ctx, DDCMI_ECOMM, "the ranks' agreement on the last list rebuild did not arrive within 20 s: a peer rank is gone");
+         }
+         sched_yield();
+      }
+   }
+   ctx->agree_pending = false;
+   const int worst = ctx->agree_h[1];
+   if (worst)
+   {
+      char b[256];
+      snprintf(b, sizeof(b), "another rank failed during the list rebuild at loop %lld (error %d): its own message says why", (long long)ctx->agree_loop, worst);
+      return mg_fatal(ctx, DDCMI_ECOMM, b);      /* (aborting the communicator releases this rank's kernels that wait for the peer) */
+   }
    return DDCMI_OK;
 }
 /* a rank that cannot go on at a point where its peers already wait for its data leaves the job: the host transport's
@@ -846,13 +925,24 @@ int ddcmi_mg_rebuild(ddcmi_ctx *ctx)
    ctx->phase(5, "mg pack+exchange launched");
    lrc = mg_phase4_finish(ctx);
    ctx->phase(15, "mg phase4 rest");
+   int pretend = 0;
+   if (getenv("DDCMI_DEBUG_HOOKS"))
+   {
+      /* test hooks: DDCMI_DEBUG_FAIL_REBUILD="<rank>:<n>" fails this rank's local phase of its n-th rebuild;
+       * DDCMI_DEBUG_PEER_FAILS_REBUILD="<n>" contributes an error code to the n-th rebuild's agreement as a failed peer would */
+       int fr = -1, fn = -1;
+       const char *e1 = getenv("DDCMI_DEBUG_FAIL_REBUILD"), *e2 = getenv("DDCMI_DEBUG_PEER_FAILS_REBUILD");
+       if (e1 && sscanf(e1, "%d:%d", &fr, &fn) == 2 && fr == ctx->rank && fn == (int)ctx->mg_rebuilds && !lrc) { ctx->err = "injected failure of the rebuild's local phase (DDCMI_DEBUG_FAIL_REBUILD)"; lrc = DDCMI_ENOMEM; }
+       if (e2 && atoi(e2) == (int)ctx->mg_rebuilds) pretend = 3;
+   }
    /* The first rebuilds of a run can fail on the set-up (a bonded partner or a constraint partner beyond the halo, capacities):
-    * the ranks agree on the outcome with one small all-reduce.  Later rebuilds have told each other everything a running system
-    * produces -- beads that moved too far or are not numbers travel in the count rounds above -- and a rank on which phase 4 still
-    * fails (an allocation) leaves the job; the extra collective would cost every rebuild of a healthy run ~4 us per step at a
-    * 20-step period on a 500 k-bead rank. */
-   if (ctx->mg_rebuilds <= 2) { if ((rc = mg_agree(ctx, lrc))) return rc; }      /* (a count every rank keeps alike, whatever failed where) */
-   else if (lrc) return mg_fatal(ctx, lrc, nullptr);
+    * the ranks agree on the outcome with one small all-reduce and its host wait (mg_agree), so that a set-up error comes back at
+    * once from every rank.  Later rebuilds agree as well -- a bond that stretches beyond the halo in a system going unstable, a
+    * capacity or an allocation are found only locally and can appear mid-run -- but without the host wait (mg_agree_async: it
+    * cost a healthy run ~4 us per step at a 20-step period on a 500 k-bead rank): the result is looked at in front of the
+    * next host wait. */
+   if (ctx->mg_rebuilds <= 2 || ctx->hcomm) { if ((rc = mg_agree(ctx, lrc))) return rc; }      /* (a count every rank keeps alike, whatever failed where) */
+   else if ((rc = mg_agree_async(ctx, lrc, pretend))) return rc;
    ctx->phase(16, "mg agree");
    /* which molecules have atoms on several ranks, and where is their anchor? (one all-reduce of 4 doubles per multi-bead molecule) */
    if (ctx->mol_gid && ctx->nmol_multi > 0 && (rc = mg_allreduce_device(ctx, ctx->mol_info.p, 4 * (size_t)ctx->nmol_multi))) return rc;
@@ -1146,6 +1236,7 @@ extern "C" int ddcmi_download_particles(ddcmi_ctx *ctx, int cap, int *nout, uint
 {
    if (!ctx || !nout) return DDCMI_EINVAL;
    (void)hipSetDevice(ctx->device);
+   { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }
    hipStream_t st = ctx->stream;
    int n = ctx->nloc;
    *nout = n;
@@ -1237,6 +1328,7 @@ static int mg_allreduce_host_values(ddcmi_ctx *ctx, double *values, int n)
 {
    if ((ctx->nranks == 1 && !ctx->loopback) || !mg_transport(ctx)) return DDCMI_OK;
    if (ctx->hcomm) { HOSTCHK(ctx, ddcmi_rdzv_allreduce_f64(ctx->hcomm, values, n, 0)); return DDCMI_OK; }
+   { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }
    double *d = ctx->d_results + R_GROUP;   /* scratch */
    HIPCHK(ctx, hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
    NCCLCHK2(ctx, ncclAllReduce(d, d, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));

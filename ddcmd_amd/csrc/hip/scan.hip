@@ -10,6 +10,7 @@
  * launches: the earlier copy + three-kernel form cost four of them per scan.
  */
 #include "ddcmi_internal.h"
+#include <sched.h>
 #include <algorithm>
 
 #define SCAN_TILE 2048   /* 256 threads x 8 items */
@@ -130,31 +131,40 @@ int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j)
       ctx->mbox_h[0] = 0; ctx->mbox_seq = 0;
    }
    ctx->mbox_seq++;
-   unsigned *ticket = (unsigned *)((double *)ctx->red_tmp.p + 2 * 8 * 8 + 4);      /* a zeroed word behind k_reduce_jobs' own two tickets (left at zero by the last workgroup) */
+   unsigned *ticket = (unsigned *)(ctx->d_flags + DDCMI_FLAG_TICKET);      /* the mailbox's own zeroed word (left at zero by the last workgroup) */
    hipLaunchKernelGGL(k_post, dim3((unsigned)std::min<size_t>(16, (need + 16383) / 16384)), dim3(1024), 0, st, j, ctx->mbox_d, ctx->mbox_seq, ticket);
    HIPCHK(ctx, hipGetLastError());
    return DDCMI_OK;
 }
-/* spin until the last post has landed; job q's data is at mbox_h + off[q] */
+/* wait until the last post has landed; job q's data is at mbox_h + off[q].  The first ~100 us are a hot spin (the single-GPU
+ * case the mailbox was built for: the post is a few us away); after that the thread yields between looks -- in a decomposed run
+ * the wait covers a collective, i.e. the slowest peer, and this thread may share its cores with the transport's progress thread.
+ * A post that never lands is an error after 20 s: with a communicator attached it is reported as such (a peer that is gone),
+ * never turned into a blocking hipStreamSynchronize behind a collective that cannot finish. */
 int ddcmi_post_wait(ddcmi_ctx *ctx, hipStream_t st)
 {
    volatile int *flag = ctx->mbox_h;
    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+   bool hot = true;
    for (unsigned long spin = 0;; spin++)
    {
       if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->mbox_seq) return DDCMI_OK;
-      if ((spin & 0xfff) == 0xfff)
+      if (!hot || (spin & 0xff) == 0xff)
       {
          struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-         if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 20.0)
+         const double el = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+         if (el > 100e-6) hot = false;
+         if (el > 20.0)
          {
-            /* the kernels in front of the post did not finish: let the runtime say why */
+            if (ctx->comm || ctx->hcomm)
+               SETERR(ctx, DDCMI_ECOMM, "the device posted no results within 20 s (mailbox sequence %d): a collective in front of the post did not finish -- is a peer rank gone?", ctx->mbox_seq);
+            /* one rank: the kernels in front of the post did not finish -- let the runtime say why */
             HIPCHK(ctx, hipStreamSynchronize(st));
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->mbox_seq) return DDCMI_OK;
             SETERR(ctx, DDCMI_ENODEVICE, "the device never posted its results (mailbox sequence %d)", ctx->mbox_seq);
          }
       }
-      __builtin_ia32_pause();
+      if (hot) __builtin_ia32_pause(); else sched_yield();
    }
 }
 /* the other direction: a small table the host prepared in mapped memory, fetched by a kernel (stream-ordered, no host wait) */

@@ -537,8 +537,8 @@ def test_rebuild_without_waiting_for_the_image_count(monkeypatch):
     from ddcmd_amd.martini import MartiniHIP
     s = make_water_setup(12)
     out = []
-    for env in ({}, {"DDCMI_NO_IMAGE_HINT": "1"}, {"DDCMI_DEBUG_IMAGE_BOUND": "100"}):
-        for k in ("DDCMI_NO_IMAGE_HINT", "DDCMI_DEBUG_IMAGE_BOUND"):
+    for env in ({}, {"DDCMI_NO_IMAGE_HINT": "1"}, {"DDCMI_DEBUG_IMAGE_BOUND": "100", "DDCMI_DEBUG_HOOKS": "1"}):
+        for k in ("DDCMI_NO_IMAGE_HINT", "DDCMI_DEBUG_IMAGE_BOUND", "DDCMI_DEBUG_HOOKS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -552,6 +552,42 @@ def test_rebuild_without_waiting_for_the_image_count(monkeypatch):
     for o in out[1:]:
         assert o[0] == out[0][0] and o[1] == out[0][1] and np.array_equal(o[2], out[0][2]) and o[3] == out[0][3] and o[4] == out[0][4]
     assert out[0][3] >= 4 and out[0][4] > 100
+
+
+def test_rebuild_started_over_with_bonded_terms_and_lcg64_streams(monkeypatch):
+    """the start-over path of a rebuild (image count beyond the bound) sorts the owned beads a second time after the
+    position / velocity / gid / caller-index / LCG64 buffers were swapped.  Pinned here with everything that rides through the
+    sort active: caller-index bonded terms (slot_of_orig), a LANGEVIN group on the particles' own LCG64 streams.  The forced
+    retries and the plain run give the same trajectory and the same stream states, bit for bit; a stray
+    DDCMI_DEBUG_IMAGE_BOUND without DDCMI_DEBUG_HOOKS does nothing."""
+    from ddcmd_amd.martini import MartiniHIP
+    s = _relaxed_lipid()
+    s.group_type = np.array([2] * s.ngroup, np.int32)
+    s.group_Teq = np.array([units_convert(310.0, "K")] * s.ngroup)
+    s.group_tau = np.array([units_convert(0.5, "ps")] * s.ngroup)
+    parms = pyoracle.lcg64_default(s.gid)
+    out = []
+    for env in ({}, {"DDCMI_DEBUG_IMAGE_BOUND": "64", "DDCMI_DEBUG_HOOKS": "1"}, {"DDCMI_DEBUG_IMAGE_BOUND": "64"}):
+        for k in ("DDCMI_NO_IMAGE_HINT", "DDCMI_DEBUG_IMAGE_BOUND", "DDCMI_DEBUG_HOOKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = MartiniHIP(s)
+        m.set_random_lcg64(parms)
+        m.eval_forces()
+        m.step(35)
+        st = m.download()
+        e, vir, rk, _ = m.energies()
+        out.append((e["total"], e["bond"], e["angle"], rk, np.concatenate(st["r"] + st["v"] + st["f"]), m.get_random_lcg64()["state"].copy(), m.list_stats()["rebuilds"]))
+        m.close()
+    for o in out[1:]:
+        assert o[:4] == out[0][:4] and np.array_equal(o[4], out[0][4]) and np.array_equal(o[5], out[0][5]) and o[6] == out[0][6]
+    assert out[0][6] >= 3 and (out[0][5] != parms["state"]).all()
+    ora = pyoracle.Oracle(s)
+    ora.set_lcg64(parms)
+    ora.forces()
+    eo, _, rko, _ = ora.step(35)
+    assert abs(out[0][0] - eo["total"]) < 1e-6 * abs(eo["total"]) and abs(out[0][3] - rko) < 1e-6 * rko
 
 
 def test_langevin_group_matches_oracle_and_thermalises():

@@ -138,3 +138,39 @@ def test_loopback_run_repeats_bit_for_bit(monkeypatch):
         m.close()
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
+
+
+def test_a_rebuild_that_fails_mid_run_ends_every_rank_without_a_host_wait(monkeypatch):
+    """from the third rebuild on the ranks no longer waited for each other's verdict on a rebuild's local phase,
+    and a rank that failed there left its peers inside the next halo kernel.  Every rebuild now carries an agreement that nobody
+    waits for (one small all-reduce on the stream; the result is read in front of the next host wait).  Through the loopback: (a) a
+    healthy run takes that path at every later rebuild and stays on the oracle; (b) this rank's own failure at its 4th rebuild comes
+    back as its own error, after the collective; (c) a peer's failure -- its code injected into the 4th rebuild's all-reduce --
+    surfaces as DDCMI_ECOMM at the next host wait (here: the read of the energies), naming the rebuild, and nothing hangs"""
+    from ddcmd_amd.martini import DdcmiError
+    s = make_water_setup(10)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    m = _loopback_rank(s, monkeypatch)
+    m.eval_forces()
+    m.step(100)                                     # five more rebuilds, each with an agreement in flight until the next count round
+    eo, _, rko, _ = o.step(100)
+    e, _, rk, _ = m.energies()
+    assert m.list_stats()["rebuilds"] >= 6 and abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rk - rko) < TOL * rko
+    m.close()
+    monkeypatch.setenv("DDCMI_DEBUG_HOOKS", "1")
+    monkeypatch.setenv("DDCMI_DEBUG_FAIL_REBUILD", "0:4")
+    m = _loopback_rank(s, monkeypatch)
+    m.eval_forces()
+    with pytest.raises(DdcmiError, match="injected failure"):
+        m.step(100)
+    assert m.list_stats()["rebuilds"] <= 4
+    m.close()
+    monkeypatch.delenv("DDCMI_DEBUG_FAIL_REBUILD")
+    monkeypatch.setenv("DDCMI_DEBUG_PEER_FAILS_REBUILD", "4")
+    m = _loopback_rank(s, monkeypatch)
+    m.eval_forces()
+    m.step(70)                                      # rebuilds 2, 3, 4 (at loops 20, 40, 60): nothing waits for the 4th one's agreement
+    with pytest.raises(DdcmiError, match="another rank failed during the list rebuild at loop 60"):
+        m.energies()
+    m.close()
