@@ -353,34 +353,63 @@ __global__ void k_gather_halo(int nhalo, const int *horder, const int *hsrc_t, c
  * ddcUpdate.c:40-85): src >= 0 -> periodic self-image of owned bead src;
  * src < 0 -> bead -1-src of the buffer received from a neighbour domain (the sender
  * has already applied the periodic shift). */
-__global__ void k_halo_update(int nloc, int nhalo, const int *halo_src, const int *halo_shift, double L0, double L1, double L2,
-                              double4 *pos, uint64_t *gid, bool with_tags, const double *hrecv3, const double *hrecv5, const int *n_dev = nullptr)
+/* hmax (decomposed runs whose pair kernel ends its rows early, NbTileArgs::hdisp): the largest squared distance of a RECEIVED bead
+ * from where it lay when the list was built -- hrecv5 still holds the rebuild's records -- goes to hmax[par] (bit pattern of a
+ * non-negative double, atomic max: one per workgroup of HU_PER beads); the word of the other parity, which the next step uses, is
+ * zeroed here.  Self-images move with their owned source: the owned beads' bound covers them. */
+#define HU_THREADS 256
+#define HU_PER 1024
+__global__ __launch_bounds__(HU_THREADS) void k_halo_update(int nloc, int nhalo, const int *halo_src, const int *halo_shift, double L0, double L1, double L2,
+                              double4 *pos, uint64_t *gid, bool with_tags, const double *hrecv3, const double *hrecv5, const int *n_dev = nullptr,
+                              unsigned long long *hmax = nullptr, int par = 0)
 {
-   int h = blockIdx.x * blockDim.x + threadIdx.x;
    if (n_dev) nhalo = min(nhalo, *n_dev);
-   if (h >= nhalo) return;
-   int s = halo_src[h];
-   if (s >= 0)
+   double d2max = 0.0;
+   const int hend = min(nhalo, ((int)blockIdx.x + 1) * HU_PER);
+   for (int h = blockIdx.x * HU_PER + threadIdx.x; h < hend; h += HU_THREADS)
    {
-      int code = halo_shift[h];
-      double4 p = pos[s];
-      p.x += (double)(code % 3 - 1) * L0;
-      p.y += (double)((code / 3) % 3 - 1) * L1;
-      p.z += (double)(code / 9 - 1) * L2;
-      pos[nloc + h] = p;
-      if (with_tags) gid[nloc + h] = gid[s];
-   }
-   else
-   {
-      int k = -1 - s;
-      double4 p = pos[nloc + h];
-      p.x = hrecv3[3 * k]; p.y = hrecv3[3 * k + 1]; p.z = hrecv3[3 * k + 2];
-      if (with_tags)
+      int s = halo_src[h];
+      if (s >= 0)
       {
-         p.w = hrecv5[5 * k + 3];
-         gid[nloc + h] = (uint64_t)__double_as_longlong(hrecv5[5 * k + 4]);
+         int code = halo_shift[h];
+         double4 p = pos[s];
+         p.x += (double)(code % 3 - 1) * L0;
+         p.y += (double)((code / 3) % 3 - 1) * L1;
+         p.z += (double)(code / 9 - 1) * L2;
+         pos[nloc + h] = p;
+         if (with_tags) gid[nloc + h] = gid[s];
       }
-      pos[nloc + h] = p;
+      else
+      {
+         int k = -1 - s;
+         double4 p = pos[nloc + h];
+         p.x = hrecv3[3 * k]; p.y = hrecv3[3 * k + 1]; p.z = hrecv3[3 * k + 2];
+         if (with_tags)
+         {
+            p.w = hrecv5[5 * k + 3];
+            gid[nloc + h] = (uint64_t)__double_as_longlong(hrecv5[5 * k + 4]);
+         }
+         else if (hmax)
+         {
+            const double dx = p.x - hrecv5[5 * k], dy = p.y - hrecv5[5 * k + 1], dz = p.z - hrecv5[5 * k + 2];
+            d2max = fmax(d2max, dx * dx + dy * dy + dz * dz);
+         }
+         pos[nloc + h] = p;
+      }
+   }
+   if (hmax)
+   {
+      __shared__ double s_m[HU_THREADS / 64];
+      for (int off = 32; off > 0; off >>= 1) d2max = fmax(d2max, __shfl_down(d2max, off, 64));
+      if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = d2max;
+      __syncthreads();
+      if (threadIdx.x == 0)
+      {
+         double m = s_m[0];
+         for (int w = 1; w < HU_THREADS / 64; w++) m = fmax(m, s_m[w]);
+         if (m > 0.0) (void)atomicMax(hmax + par, (unsigned long long)__double_as_longlong(m));
+         if (blockIdx.x == 0) hmax[par ^ 1] = 0ull;
+      }
    }
 }
 __global__ void k_merge_cells(int ncell, int nloc, const int *cnt_o, const int *start_o, const int *cnt_h, const int *start_h, int *cell_start, int *cell_cnt)
@@ -426,8 +455,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int *tot, int *s_w)
 }
 
 #define TB_THREADS 512      /* k_tile_build workgroup: one lane per owned bead of the tile */
-#define TB_RING 8           /* accepted words a lane keeps in LDS before they leave as 16-byte stores: [TB_RING][TB_THREADS] */
-#define TB_RING_BYTES (TB_RING * TB_THREADS * 4)
+/* accepted words wait in a ring in LDS, [slot][lane], and leave as 16-byte pieces: packed entries (16-bit scratch words) a ring of
+ * sixteen 2-byte slots per lane, eight words a piece; bare entries (32-bit words) eight 4-byte slots, four words a piece */
+#define TB_RING_BYTES (8 * TB_THREADS * 4)
+#define TB_CHUNK 64         /* rows of a scratch chunk = the lanes of the wave that fills it */
 #ifndef NSHELL
 #define NSHELL 8            /* distance shells of the list order */
 #endif
@@ -448,8 +479,12 @@ struct TileArgs
    unsigned short *nbr16; unsigned long long arena_cap; unsigned long long *arena_used;
    int *nbr_cnt;
    uint4 *nbr_cum;                      /* [bead] eight 16-bit counts: the bead's entries in shells 0..s (k_tile_transpose) -- what k_nonbond walks when later shells cannot matter yet */
-   unsigned int *tmp32; int tmpw;       /* row-major scratch list, tmpw words per bead.  Packed entries (pack_type != 0): 16-bit words,
-                                           staged slot + 1 | distance shell << 12, and the slot's type nibble in tile_nib; bare entries: 32-bit words, entry | shell << 16 */
+   unsigned int *tmp32; int tmpw;       /* scratch list, tmpw words per bead.  Packed entries (pack_type != 0): 16-bit words,
+                                           staged slot + 1 | distance shell << 12, and the slot's type nibble in tile_nib; bare entries: 32-bit words, entry | shell << 16.
+                                           Layout: the rows of tile t start at row ts + TB_CHUNK t (every tile rounded up to whole chunks); inside a chunk of TB_CHUNK rows the
+                                           16-byte piece q of row l lies at (q TB_CHUNK + l) 16 B -- piece-major, so the wave that fills a chunk writes whole cache lines
+                                           (row-major rows took 8-byte stores into 64 cache lines per instruction: 3.1 x the bytes at the memory) and the
+                                           eight lanes-per-row of k_tile_transpose still read 128 contiguous bytes per 8 rows */
    unsigned char *tile_nib;             /* [ntile][stage_stride] type nibble (+ shifted-copy bit) of every staged slot: k_tile_transpose finishes the entries with it */
    ShellCuts shc;
 };
@@ -472,6 +507,9 @@ struct NbTileArgs
     * r^2 >= sh_r0sq + (s - 1) sh_step -- is outside the cut-off while sqrt(that) - 2 D > r_cut, and the walk of every row ends with shell s - 1
     * (nbr_cum).  Entries of later shells inside the last group walked are simply tested: they are real neighbours. */
    const double *disp; const uint4 *nbr_cum; double sh_r0sq, sh_step;
+   /* decomposed runs: D bounds the OWNED beads' moves only; hdisp (not null) points at the largest squared distance of a received
+    * halo bead from its place at the rebuild (k_halo_update), and a pair distance has changed by at most D + max(D, sqrt(*hdisp)) */
+   const double *hdisp;
 };
 /* k_nonbond<..., FUSE>: the pair kernel's epilogue is the integrator's pass over the bead -- BACK half kick, kinetic terms, FRONT half
  * kick, drift (k_kick_ke_drift, bit for bit) -- for systems whose forces are complete when the list walk ends (no bonded terms,
@@ -657,7 +695,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    /* phase 2: ONE scan of the 5x5x5 cells around each bead.  Accepted neighbours go to the bead's own row of a
     * row-major scratch list tagged with their distance shell; k_tile_transpose lays them out slot-major in shell order */
    constexpr unsigned SCRB = PACK ? 2u : 4u;      /* bytes of a scratch word */
-   char *const trow = (char *)ta.tmp32 + (size_t)ts * ta.tmpw * SCRB;      /* the tile's scratch rows (wave-uniform base, 32-bit lane offsets) */
+   char *const trow = (char *)ta.tmp32 + ((size_t)ts + (size_t)TB_CHUNK * t) * ta.tmpw * SCRB;      /* the tile's scratch chunks (wave-uniform base, 32-bit lane offsets) */
    const int wlim = ta.tmpw - 4;                                /* a trip stores while its row has room for four more words */
    for (int al = threadIdx.x; al < nown; al += TB_THREADS)
    {
@@ -686,12 +724,36 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
       /* c11 / f11: words accepted / flushed so far, in units of RING_STEP (the byte stride of a ring slot: the ring address of word c is
        * one and-or away); gofs: byte offset of the row's next 16-byte group in the tile's scratch */
       typedef __attribute__((address_space(3))) unsigned lds_uint;
-      constexpr unsigned RING_STEP = TB_THREADS * 4u, RING_MASK = (TB_RING - 1u) * RING_STEP;
-      static_assert(TB_RING == 8 && (RING_STEP & (RING_STEP - 1)) == 0, "ring of eight words per lane");
-      const unsigned tid4 = threadIdx.x * 4u, lim11 = (unsigned)wlim * RING_STEP;
-      const unsigned gofs0 = (unsigned)al * (unsigned)ta.tmpw * SCRB;
+      typedef __attribute__((address_space(3))) unsigned short lds_ushort;
+      /* PACK: sixteen 2-byte ring slots, a piece = eight words; else eight 4-byte slots, a piece = four words: 16 bytes either way */
+      constexpr unsigned RING_STEP = TB_THREADS * SCRB, RING_SLOTS = PACK ? 16u : 8u, RING_MASK = (RING_SLOTS - 1u) * RING_STEP, PIECE_W = PACK ? 8u : 4u;
+      static_assert((RING_STEP & (RING_STEP - 1)) == 0 && RING_SLOTS * RING_STEP <= TB_RING_BYTES, "the ring: a power-of-two stride, inside its LDS block");
+      const unsigned tid4 = threadIdx.x * SCRB, lim11 = (unsigned)wlim * RING_STEP;
+      /* the row's pieces inside its chunk: piece q at (q TB_CHUNK + lane) 16 bytes */
+      const unsigned gofs0 = (unsigned)(al & ~(TB_CHUNK - 1)) * (unsigned)ta.tmpw * SCRB + (unsigned)(al & (TB_CHUNK - 1)) * 16u;
       unsigned c11 = 0, f11 = 0, gofs = gofs0;
       bool ovf = false;      /* an accepted candidate found its row full: the host grows the rows and builds again */
+      /* the piece that starts at flushed count f: ring slots [0, half) or [half, all) of this lane, as one 16-byte value */
+      auto ring_piece = [&](const unsigned f) -> uint4
+      {
+         const unsigned ra = (f & (PIECE_W * RING_STEP)) | tid4;      /* f counts whole pieces: the first or the second half of the ring */
+         uint4 o;
+         if (PACK)
+         {
+            unsigned h[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) h[k] = *(lds_ushort *)(__UINTPTR_TYPE__)(ra + (unsigned)k * RING_STEP);
+            o = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+         }
+         else
+         {
+            o.x = *(lds_uint *)(__UINTPTR_TYPE__)(ra);
+            o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
+            o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
+            o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
+         }
+         return o;
+      };
       /* one row of cells: candidates [s0, s1) of the LDS image.  SELF: the row holds the bead itself */
       auto scan_row = [&](const int s0, const int s1, auto self_row)
       {
@@ -819,21 +881,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                const unsigned word = PACK ? ((sh << 12) | (HAS_MOL ? ((wq >> 4) & 0xfffu) : (wq >> 4))) : ((sh << 16) | (HAS_MOL ? (wq & 0xffffu) : wq));
                if (ok[u])
                {
-                  *(lds_uint *)(__UINTPTR_TYPE__)((c11 & RING_MASK) | tid4) = word;
+                  if (PACK) *(lds_ushort *)(__UINTPTR_TYPE__)((c11 & RING_MASK) | tid4) = (unsigned short)word;
+                  else *(lds_uint *)(__UINTPTR_TYPE__)((c11 & RING_MASK) | tid4) = word;
                   c11 += RING_STEP;
                }
             }
-            if (c11 - f11 >= 4u * RING_STEP)
+            if (c11 - f11 >= PIECE_W * RING_STEP)
             {
-               const unsigned ra = (f11 & (4u * RING_STEP)) | tid4;      /* f11 counts whole groups of four: ring slots 0-3 or 4-7 */
-               uint4 o;
-               o.x = *(lds_uint *)(__UINTPTR_TYPE__)(ra);
-               o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
-               o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
-               o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
-               if (PACK) *(uint2 *)(trow + gofs) = make_uint2(o.x | (o.y << 16), o.z | (o.w << 16));
-               else *(uint4 *)(trow + gofs) = o;      /* wave-uniform base + 32-bit lane offset */
-               gofs += 4u * SCRB; f11 += 4u * RING_STEP;
+               *(uint4 *)(trow + gofs) = ring_piece(f11);      /* wave-uniform base + 32-bit lane offset; the lanes of a wave fill the same few KB */
+               gofs += TB_CHUNK * 16u; f11 += PIECE_W * RING_STEP;
             }
          }
       };
@@ -867,18 +923,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
             if (dz == 2 && dy == 2) scan_row(s0, s1, std::true_type()); else scan_row(s0, s1, std::false_type());
          }
       }
-      if (c11 != f11)
-      {
-         /* the last one to three words (the group's tail is never read: the row's count says so) */
-         const unsigned ra = (f11 & (4u * RING_STEP)) | tid4;
-         uint4 o;
-         o.x = *(lds_uint *)(__UINTPTR_TYPE__)(ra);
-         o.y = *(lds_uint *)(__UINTPTR_TYPE__)(ra + RING_STEP);
-         o.z = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 2u * RING_STEP);
-         o.w = *(lds_uint *)(__UINTPTR_TYPE__)(ra + 3u * RING_STEP);
-         if (PACK) *(uint2 *)(trow + gofs) = make_uint2(o.x | (o.y << 16), o.z | (o.w << 16));
-         else *(uint4 *)(trow + gofs) = o;
-      }
+      if (c11 != f11) *(uint4 *)(trow + gofs) = ring_piece(f11);      /* the last words (the piece's tail is never read: the row's count says so) */
       const int cnt = (int)(c11 / RING_STEP);
       mymax = max(mymax, min(cnt, ta.tmpw));
       ta.nbr_cnt[a] = min(cnt, ta.tmpw);
@@ -988,10 +1033,13 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
       const int row = r0 + rl;
       const int cnt = row < nown ? ta.nbr_cnt[ts + row] : 0;
       const int nq = (cnt + EPQ - 1) / EPQ;
-      const uint4 *src = (const uint4 *)((const char *)ta.tmp32 + (size_t)(ts + min(row, nown - 1)) * ta.tmpw * (SCR16 ? 2 : 4));      /* tmpw is a multiple of 8 */
+      /* the row's 16-byte pieces: piece p of row l of a chunk at (p TB_CHUNK + l) 16 bytes (TileArgs::tmp32) -- eight rows side by side
+       * are 128 contiguous bytes per piece */
+      const int rowc = min(row, nown - 1);
+      const uint4 *src = (const uint4 *)((const char *)ta.tmp32 + ((size_t)ts + (size_t)TB_CHUNK * t + (size_t)(rowc & ~(TB_CHUNK - 1))) * ta.tmpw * (SCR16 ? 2 : 4)) + (rowc & (TB_CHUNK - 1));      /* tmpw is a multiple of 8 */
       uint4 wv[NQ];
 #pragma unroll
-      for (int j = 0; j < NQ; j++) wv[j] = (q + 8 * j < nq) ? src[q + 8 * j] : make_uint4(0, 0, 0, 0);
+      for (int j = 0; j < NQ; j++) wv[j] = (q + 8 * j < nq) ? src[(size_t)(q + 8 * j) * TB_CHUNK] : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int sh = 0; sh < NSHELL; sh++) mycur[sh * TR_THREADS] = 0u;
       /* padding of the row (entry 0 = the sentinel bead): slots cnt .. width-1 */
@@ -1164,7 +1212,8 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    int smax = NSHELL - 1;
    if (ta.disp)
    {
-      const double twoD = 2.0 * *ta.disp, rc = sqrt(rc2);
+      const double Down = *ta.disp, Dhalo = ta.hdisp ? sqrt(*ta.hdisp) : 0.0;
+      const double twoD = Down + fmax(Down, Dhalo), rc = sqrt(rc2);
       while (smax >= 1 && sqrt(ta.sh_r0sq + (double)(smax - 1) * ta.sh_step) * (1.0 - 1e-4) - twoD > rc) smax--;
    }
    int nown = 0, ts = 0, r_lo = 0, r_hi = 0;
@@ -2886,7 +2935,7 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
       else
          hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
       hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p, (const int *)ctx->nhalo_dev);
-      hipLaunchKernelGGL(k_halo_update, dim3(nhb), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
+      hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
                          ctx->hrecv3.p, ctx->hrecv5.p, (const int *)ctx->nhalo_dev);
    }
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
@@ -3139,7 +3188,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
       ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_arena;
       ta.nbr_cnt = ctx->nbr_cnt.p; ta.nbr_cum = ctx->nbr_cum.p;
-      if (ctx->tmp32.ensure((size_t)ctx->npad * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");
+      if (ctx->tmp32.ensure(((size_t)ctx->npad + (size_t)TB_CHUNK * (ntile + 1)) * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");      /* every tile rounded up to whole chunks */
       ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
       if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
       ta.tile_nib = ctx->tile_nib.p;
@@ -3229,11 +3278,12 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    ctx->list_valid = true;
    ctx->nrebuild++;
    {
-      /* the displacement bound of the shell-limited walk starts from this list's positions (NbTileArgs::disp).  One domain only: the
-       * halo beads of a decomposed run move by what other ranks' beads do */
+      /* the displacement bound of the shell-limited walk starts from this list's positions (NbTileArgs::disp).  D covers the owned beads
+       * (and their periodic self-images); the beads a decomposed run receives from its neighbours are measured where they arrive:
+       * k_halo_update keeps their largest distance from the rebuild's records (NbTileArgs::hdisp) */
       ctx->sh_r0sq = (double)shc.r0sq; ctx->sh_step = ((double)gp.rlist * gp.rlist - (double)shc.r0sq) / (double)(NSHELL - 1.01);
-      ctx->shell_skip = !ctx->no_shell_skip && !shc.one && ctx->nranks == 1 && !ctx->loopback && !ctx->group_ && ctx->sh_step > 0.0;
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_DISP, 0, sizeof(double), st));
+      ctx->shell_skip = !ctx->no_shell_skip && !shc.one && ctx->sh_step > 0.0;
+      HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_DISP, 0, 3 * sizeof(double), st));      /* D, and the received beads' two displacement words (k_halo_update) */
    }
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }
@@ -3249,13 +3299,18 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
     * unpack) runs on a second stream while this stream computes the tiles whose
     * neighbourhoods hold owned beads only; the other tiles wait for it. */
    bool halo_pending = false;
+   /* the received beads' displacement since the rebuild (NbTileArgs::hdisp): measured by the halo update of a decomposed run whose pair
+    * kernel may end its rows early; the word of this step's parity is the one this step's pair kernel reads */
+   const bool hdisp_on = ctx->shell_skip && nh > 0 && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
+   const int hpar = (int)(ctx->loop & 1);
+   unsigned long long *hmax = hdisp_on ? (unsigned long long *)(ctx->d_results + R_DISP + 1) : nullptr;
    if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh && !ctx->halo_overlap)
    {
       int rc0 = ddcmi_mg_refresh_halo(ctx, st);
       if (rc0) return rc0;
       if (nh > 0)
-         hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
-                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
+         hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
+                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
    }
    else if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh)
    {
@@ -3270,14 +3325,14 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       int rc0 = ddcmi_mg_refresh_halo(ctx, ctx->stream2);
       if (rc0) return rc0;
       if (nh > 0)
-         hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, ctx->stream2, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
-                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
+         hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, ctx->stream2, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
+                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
       HIPCHK(ctx, hipEventRecord(ctx->ev_halo, ctx->stream2));
       halo_pending = true;
    }
    else if (nh > 0 && !ctx->images_fresh)      /* (the rebuild this step began with made the periodic images from these very positions) */
-      hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, 256)), dim3(256), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
-                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p);
+      hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
+                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
    ctx->images_fresh = false;
    const bool has_bonded = (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) > 0;
    const double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
@@ -3318,6 +3373,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       na.disp = ctx->shell_skip ? ctx->d_results + R_DISP : nullptr; na.nbr_cum = ctx->nbr_cum.p; na.sh_r0sq = ctx->sh_r0sq; na.sh_step = ctx->sh_step;
+      na.hdisp = hdisp_on ? ctx->d_results + R_DISP + 1 + hpar : nullptr;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
 #define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
@@ -3335,6 +3391,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       {
          if (cls == 1 && halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }
          if (ctx->ntile_class[cls] <= 0) continue;
+         const double *hd_keep = na.hdisp;
+         if (cls == 0 && halo_pending) na.hdisp = nullptr;      /* (tiles that stage owned beads only, while the exchange still writes the word) */
          const int grid = 8 * std::max(ctx->sched_longest[cls], 1);
          na.sched = ctx->sched.p + 16 * cls;
          hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -3361,6 +3419,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
          else if (packed) LAUNCH_NB2(false, true, false);
          else LAUNCH_NB2(false, false, false);
          if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
+         na.hdisp = hd_keep;
       }
 #undef LAUNCH_NB2
 #undef LAUNCH_NB

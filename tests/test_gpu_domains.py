@@ -385,3 +385,36 @@ def test_decomposed_barostat_with_molecular_virial_and_constraints(grid):
         assert np.abs(vir - vo).max() < TOL * np.abs(vo).max()
     assert np.abs(g.ranks[0].box() - L0).max() > 1e-5 * L0.max()
     g.close()
+
+
+@pytest.mark.parametrize("vscale", [3.0, 0.02])
+def test_decomposed_rows_end_at_the_last_shell_that_can_matter(monkeypatch, vscale):
+    """the shell-limited walk of the pair kernel was a single-domain feature.  A decomposed rank now bounds its pair
+    distances by D_own + max(D_own, H): D_own = sum over the steps of max |dt v| of its OWNED beads, H = the largest distance of a
+    RECEIVED halo bead from its place at the rebuild, measured by the halo update where the bead arrives.  2x2x2 emulated domains
+    with the walk cut short and with the full walk (DDCMI_NO_SHELL_SKIP) agree bit for bit over two rebuild periods with migration,
+    hot (large D) and nearly frozen (half of every row skipped), and follow the oracle."""
+    from ddcmd_amd.martini import MartiniGroup
+    s = make_water_setup(15)
+    s.vx, s.vy, s.vz = (np.asarray(v) * vscale for v in (s.vx, s.vy, s.vz))
+    monkeypatch.delenv("DDCMI_NO_SHELL_SKIP", raising=False)
+    a = MartiniGroup(s, (2, 2, 2))
+    monkeypatch.setenv("DDCMI_NO_SHELL_SKIP", "1")
+    b = MartiniGroup(s, (2, 2, 2))
+    monkeypatch.delenv("DDCMI_NO_SHELL_SKIP", raising=False)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    a.eval_forces(); b.eval_forces()
+    for block, n in enumerate((17, 20, 8)):
+        a.step(n); b.step(n)
+        eo, vo, rko, _ = o.step(n)
+        sa, sb = a.gather(), b.gather()
+        assert np.array_equal(sa["gid"], sb["gid"])
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(sa[k][c], sb[k][c]), (block, k, c)
+        ea, _, rka, _ = a.energies()
+        eb, _, rkb, _ = b.energies()
+        assert ea["total"] == eb["total"] and rka == rkb
+        assert abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rka - rko) < TOL * max(rko, 1e-300)
+    a.close(); b.close()

@@ -174,3 +174,33 @@ def test_a_rebuild_that_fails_mid_run_ends_every_rank_without_a_host_wait(monkey
     with pytest.raises(DdcmiError, match="another rank failed during the list rebuild at loop 60"):
         m.energies()
     m.close()
+
+
+@pytest.mark.parametrize("vscale", [3.0, 0.02])
+def test_loopback_rows_end_at_the_last_shell_that_can_matter(monkeypatch, vscale):
+    """the same through the RCCL transport (every image bead is a received halo bead here, and the fused step -- pair kernel with the
+    integrator's pass, two position buffers, halo messages packed in the reduction launch -- is the path a production rank takes):
+    bit for bit the full walk"""
+    s = make_water_setup(12)
+    s.vx, s.vy, s.vz = (np.asarray(v) * vscale for v in (s.vx, s.vy, s.vz))
+    monkeypatch.delenv("DDCMI_NO_SHELL_SKIP", raising=False)
+    a = _loopback_rank(s, monkeypatch)
+    monkeypatch.setenv("DDCMI_NO_SHELL_SKIP", "1")
+    b = _loopback_rank(s, monkeypatch)
+    monkeypatch.delenv("DDCMI_NO_SHELL_SKIP", raising=False)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    a.eval_forces(); b.eval_forces()
+    for block, n in enumerate((17, 20, 8)):
+        a.step(n); b.step(n)
+        eo, vo, rko, _ = o.step(n)
+        pa, pb = a.download_particles(), b.download_particles()
+        assert np.array_equal(pa["gid"], pb["gid"])
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(pa[k][c], pb[k][c]), (block, k, c)
+        ea, _, rka, _ = a.energies()
+        eb, _, rkb, _ = b.energies()
+        assert ea["total"] == eb["total"] and rka == rkb
+        assert abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rka - rko) < TOL * max(rko, 1e-300)
+    a.close(); b.close()
