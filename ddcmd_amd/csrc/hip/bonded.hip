@@ -559,7 +559,7 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
    /* the per-kind sums are only written by kernels that run: clear stale ones */
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->forces_valid = false; ctx->list_valid = false;
+   ctx->forces_valid = false; ctx->f_zero = false; ctx->list_valid = false;
    return DDCMI_OK;
 }
 
@@ -668,7 +668,7 @@ extern "C" int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, 
    }
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_REST, 0, 8 * sizeof(double), ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->forces_valid = false; ctx->list_valid = false;
+   ctx->forces_valid = false; ctx->f_zero = false; ctx->list_valid = false;
    return DDCMI_OK;
 }
 

@@ -138,6 +138,15 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
       r[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * q), __builtin_amdgcn_readlane(__double2loint(v), 16 * q));
    return (r[0] + r[1]) + (r[2] + r[3]);
 }
+/* the first half of it: every lane gets the sum over its ROW of 16 lanes (four DPP butterflies, no readlane) */
+__device__ __forceinline__ double row_sum_dpp(double v)
+{
+   v += dpp_move<0xB1>(v);
+   v += dpp_move<0x4E>(v);
+   v += dpp_move<0x141>(v);
+   v += dpp_move<0x140>(v);
+   return v;
+}
 __device__ __forceinline__ int wave_max_dpp(int v)      /* every lane gets the maximum over the wave (v >= 0) */
 {
    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
@@ -510,6 +519,10 @@ struct NbTileArgs
    /* decomposed runs: D bounds the OWNED beads' moves only; hdisp (not null) points at the largest squared distance of a received
     * halo bead from its place at the rebuild (k_halo_update), and a pair distance has changed by at most D + max(D, sqrt(*hdisp)) */
    const double *hdisp;
+   /* bonded terms / restraints: their kernels ran first and left their force on every owned bead in fx, fy, fz (zero where a bead
+    * has none); the pair kernel adds the bead's pair force to it -- in memory (plain launch) or in registers, in front of the
+    * integrator's pass (FUSE; it hands the array back zeroed for the next step's bonded kernels) */
+   int addf;
 };
 /* k_nonbond<..., FUSE>: the pair kernel's epilogue is the integrator's pass over the bead -- BACK half kick, kinetic terms, FRONT half
  * kick, drift (k_kick_ke_drift, bit for bit) -- for systems whose forces are complete when the list walk ends (no bonded terms,
@@ -1551,7 +1564,14 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          {
             fxi += __shfl_xor(fxi, off, 64); fyi += __shfl_xor(fyi, off, 64); fzi += __shfl_xor(fzi, off, 64);
          }
-         if (!FUSE) { if (active && sub == 0) { fx[a] = fxi; fy[a] = fyi; fz[a] = fzi; } }
+         if (!FUSE)
+         {
+            if (active && sub == 0)
+            {
+               if (ta.addf) { fxi += fx[a]; fyi += fy[a]; fzi += fz[a]; }
+               fx[a] = fxi; fy[a] = fyi; fz[a] = fzi;
+            }
+         }
          else
          {
             /* k_kick_ke_drift on the bead, with the force still in registers (the same operations in the same order) */
@@ -1562,6 +1582,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                /* (asked for here, not before the walk: held across it these twelve registers spill, and the reload costs what the load does) */
                const int sp = (int)((__double_as_longlong(pi.w) >> 16) & 0xffffll);
                const double hk = (0.5 * fa.dt) * fa.invmass[sp], m = fa.massv[sp], lam = fa.lam;
+               if (ta.addf)
+               {
+                  /* + the bonded terms' force on the bead (the same sum the plain launch leaves in memory); the array goes back zeroed */
+                  fxi += fx[a]; fyi += fy[a]; fzi += fz[a];
+                  fx[a] = 0.0; fy[a] = 0.0; fz[a] = 0.0;
+               }
                double x = fma(hk, fxi, fa.vx[a]), y = fma(hk, fyi, fa.vy[a]), z = fma(hk, fzi, fa.vz[a]);
                const double vxx = x * x, vyy = y * y, vzz = z * z;
                ke[0] = 0.5 * m * (vxx + vyy + vzz);
@@ -2642,7 +2668,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    if (n == 0)
    {
       ctx->nloc = 0; ctx->nhalo = 0; ctx->npad = DDCMI_BLOCK; ctx->self_ele = 0.0;
-      ctx->list_valid = false; ctx->forces_valid = false;
+      ctx->list_valid = false; ctx->forces_valid = false; ctx->f_zero = false;
       return DDCMI_OK;
    }
    /* stage through vx2/vy2/vz2 as scratch for the positions */
@@ -2686,7 +2712,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    double q2 = 0.0;
    for (int i = 0; i < n; i++) { double q = ctx->charge[species[i]]; q2 += q * q; }
    ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;
-   ctx->list_valid = false; ctx->forces_valid = false;
+   ctx->list_valid = false; ctx->forces_valid = false; ctx->f_zero = false;
    return DDCMI_OK;
 }
 
@@ -2736,7 +2762,7 @@ extern "C" int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const do
       hipLaunchKernelGGL(k_import3, dim3(nb), dim3(256), 0, st, n, ctx->orig.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->vx.p, ctx->vy.p, ctx->vz.p);
    }
    HIPCHK(ctx, hipStreamSynchronize(st));
-   ctx->forces_valid = false; ctx->halo_fresh = false; ctx->drift_done = false;
+   ctx->forces_valid = false; ctx->f_zero = false; ctx->halo_fresh = false; ctx->drift_done = false;
    return DDCMI_OK;
 }
 
@@ -3131,6 +3157,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    int n = ctx->nloc;
    ctx->phase(10, "-> bl_finish");
    graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
+   ctx->f_zero = false;  /* (the beads have new slots, a decomposed rank a new number of them) */
    /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
    ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
    int ntile = gp.T[0] * gp.T[1] * gp.T[2];
@@ -3338,6 +3365,19 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    const double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
+      /* Bonded terms and restraints FIRST, into a zeroed force array: the pair kernel then finishes every bead's force in ONE place --
+       * in memory (plain launch: f = f_pair + f_bonded) or in registers in front of the integrator's pass (FUSE), so that systems
+       * with bonded terms take the fused step too (the lipid box paid a separate 54 us kick kernel and a force store +
+       * re-read).  Both kinds of launch form the same sum, so the fused and the split step stay bit for bit alike.  The fused
+       * launch hands the array back zeroed (f_zero): between print steps no launch is spent on clearing it. */
+      if (has_bonded && n > 0)
+      {
+         if (halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }      /* bonded partners may be halo beads */
+         if (!ctx->f_zero) hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
+         ctx->f_zero = false;
+         int rcb = ddcmi_launch_bonded(ctx);
+         if (rcb) return rcb;
+      }
       int ntile = ctx->ntile;
       bool useq = ctx->has_charge;
       bool packed = ctx->pack_type != 0;
@@ -3357,7 +3397,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
          const bool gap = zfix && capl * 16 + rows <= NB_ZOFF;
          const size_t lds_f = gap ? lds : ((lds + 7) & ~(size_t)7) + rows;
          const bool keeps_two = lds_f * 2 <= 160 * 1024 || lds * 2 > 160 * 1024;
-         if (zfix && !useq && keeps_two && lds_f <= 160 * 1024)
+         if (zfix && keeps_two && lds_f <= 160 * 1024)
          {
             fa = *fuse;
             fa.ke_off = gap ? (int)(NB_ZOFF - rows) : (int)((lds + 7) & ~(size_t)7);
@@ -3374,6 +3414,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       na.disp = ctx->shell_skip ? ctx->d_results + R_DISP : nullptr; na.nbr_cum = ctx->nbr_cum.p; na.sh_r0sq = ctx->sh_r0sq; na.sh_step = ctx->sh_step;
       na.hdisp = hdisp_on ? ctx->d_results + R_DISP + 1 + hpar : nullptr;
+      na.addf = (has_bonded && n > 0) ? 1 : 0;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
 #define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
@@ -3409,7 +3450,10 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
             ctx->ev_fused[ctx->ev_used / 2 - 1] = fuse ? 1 : 0;
             HIPCHK(ctx, hipEventRecord(e0, st));
          }
-         if (fuse && shbit) LAUNCH_NBF(false, true, true, NB_THREADS, NB_ZOFF, true);      /* (fuse: uncharged, fixed LDS layout) */
+         if (fuse && useq && shbit) LAUNCH_NBF(true, true, true, NB_THREADS, NB_ZOFF, true);      /* (fuse: fixed LDS layout) */
+         else if (fuse && useq && packed) LAUNCH_NBF(true, true, false, NB_THREADS, NB_ZOFF, true);
+         else if (fuse && useq) LAUNCH_NBF(true, false, false, NB_THREADS, NB_ZOFF, true);
+         else if (fuse && shbit) LAUNCH_NBF(false, true, true, NB_THREADS, NB_ZOFF, true);
          else if (fuse && packed) LAUNCH_NBF(false, true, false, NB_THREADS, NB_ZOFF, true);
          else if (fuse) LAUNCH_NBF(false, false, false, NB_THREADS, NB_ZOFF, true);
          else if (useq && shbit) LAUNCH_NB2(true, true, true);
@@ -3426,17 +3470,21 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
 #undef LAUNCH_NBZ
 #undef LAUNCH_NBF
       if (ctx->timing) { ctx->t_launches++; if (fuse) ctx->t_launches_fused++; }          /* per force evaluation: the event pairs of both classes add up */
-      /* without bonded terms the final energies are formed in the same launch */
+      if (fuse && na.addf) ctx->f_zero = true;      /* (the fused launch cleared what it consumed) */
+      /* the final energies are formed in the same launch (the bonded kernels' sums are complete: they ran first) */
       if (!defer_reduce)
       {
-         RedJob j0 = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, has_bonded ? 0 : 1};
+         RedJob j0 = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, 1};
          hipLaunchKernelGGL(k_reduce_jobs, dim3(RED_SPLIT, 1), dim3(1024), 0, st, j0, j0, ctx->d_results, self, ctx->red_tmp.p);
       }
+      ctx->forces_valid = true;
+      return DDCMI_OK;
    }
    else
    {
       if (!defer_reduce) HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, 8 * sizeof(double), st));
       hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
+      ctx->f_zero = false;
    }
    if (halo_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0));      /* bonded partners may be halo beads */
    int rc = ddcmi_launch_bonded(ctx);
@@ -3678,8 +3726,9 @@ static bool fuse_ok(const ddcmi_ctx *ctx)
 {
    static const bool off = getenv("DDCMI_NO_FUSED_STEP") != nullptr;
    if (off || ctx->nloc <= 0 || ctx->group_) return false;
-   if ((ctx->excludePotentialTerm & 128) != 0 || ctx->has_charge) return false;
-   if (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest > 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0) return false;
+   if ((ctx->excludePotentialTerm & 128) != 0) return false;
+   /* (bonded terms, restraints and charges are no obstacle: their kernels run in front of the pair kernel, the excluded-pair loop ends before the epilogue) */
+   if (ctx->ncgroup > 0 || ctx->baro_beta > 0.0) return false;
    for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE && ctx->gtype[g] != DDCMI_BERENDSEN) return false;
    return true;
 }

@@ -255,6 +255,7 @@ struct ddcmi_ctx
    }
    double self_ele = 0.0;
    bool forces_valid = false;
+   bool f_zero = false;                /* fx, fy, fz of the owned beads are all zero (left so by a fused launch that consumed the bonded forces): the next bonded launch needs no clearing */
    /* timing */
    /* hipGraph of one steady-state step (forces + fused BACK kick / kinetic terms / FRONT kick / drift): small
     * systems are launch-bound -- five short kernels per step -- and can replay the step as one graph launch

@@ -469,6 +469,44 @@ def test_step_with_the_integrator_inside_the_pair_kernel_equals_the_split_step(t
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("thermostat", ["free", "berendsen"])
+def test_fused_step_of_a_system_with_bonded_terms_and_charges_equals_the_split_step(thermostat):
+    """the lipid deck (bonds, three angle kinds, dihedrals, impropers, charges, excluded pairs) now takes the fused step
+    too -- its bonded kernels run FIRST into a zeroed force array and the pair kernel's epilogue adds that force in registers
+    (k_nonbond<HAS_Q, ..., FUSE>; the array goes back zeroed).  The plain launch forms the same sum f_pair + f_bonded in memory,
+    so batches of 12 steps (fused but the last) and single steps (all split) agree bit for bit in positions, velocities and
+    forces across rebuilds, the energies by kind to rounding, and both follow the oracle."""
+    from ddcmd_amd.martini import MartiniHIP
+    s = _relaxed_lipid()
+    if thermostat == "free":
+        s.group_type = np.zeros(s.ngroup, np.int32)
+    a, b = MartiniHIP(s), MartiniHIP(s)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    a.eval_forces(); b.eval_forces()
+    for block in range(3):
+        if thermostat == "berendsen":
+            o.group_temperature(); a.group_temperatures(); b.group_temperatures()
+        a.step(12)
+        for _ in range(12):
+            b.step(1)
+        eo, vo, rko, _ = o.step(12)
+        da, db = a.download(), b.download()
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(da[k][c], db[k][c]), (block, k, c)
+        ea, va, rka, ta = a.energies()
+        eb, vb, rkb, tb = b.energies()
+        assert abs(rka - rkb) <= 1e-13 * rkb
+        for kind in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
+            assert abs(ea[kind] - eb[kind]) <= 1e-12 * max(abs(eb[kind]), abs(eb["total"]) * 1e-3), kind
+            assert abs(ea[kind] - eo[kind]) < TOL * max(abs(eo[kind]), abs(eo["total"]) * 1e-3), kind
+        assert np.abs(va - vb).max() <= 1e-12 * np.abs(vb).max() and np.abs(va - vo).max() < TOL * np.abs(vo).max()
+        assert abs(rka - rko) < TOL * rko
+    assert a.list_stats()["rebuilds"] >= 3
+    a.close(); b.close()
+
+
 def test_two_berendsen_groups_with_different_factors_take_the_split_kernels():
     """the fused epilogue carries ONE Berendsen factor; a step on which two groups scale differently falls back to the split
     kernels with the factors just formed -- the trajectory follows the oracle through such steps and through steps where the
