@@ -197,12 +197,14 @@ __device__ __forceinline__ void back_in_box(const GridParams &gp, double4 &p)
 }
 /* ------------------------------------------------------------------------- */
 /* sort: wrap + cell id + in-cell rank                                        */
-__global__ void k_wrap_cell(GridParams gp, int nloc, const double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway, int *runaway2)
+__global__ void k_wrap_cell(GridParams gp, int nloc, const double4 *pos, int *cid, int *rank, int *cell_cnt, int *runaway, int *runaway2, int *renumber = nullptr, int *zero28 = nullptr)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    int c = -1;
+   if (zero28 && i < 28) zero28[i] = 0;      /* decomposed runs: the direction counters of the halo selection that follows the sort (the migration round has read them) */
    if (i < nloc)
    {
+      if (renumber) renumber[i] = i;      /* decomposed runs: orig = the bead's place in front of this sort */
       double4 p = pos[i];
       /* a bead that is not a number, or more than a box length outside the box: the run has blown up (the
        * reference would abort in its domain assignment); reported at this rebuild instead of as a full cell */
@@ -370,17 +372,21 @@ __global__ void k_gather_halo(int nhalo, const int *horder, const int *hsrc_t, c
 #define HU_PER 1024
 __global__ __launch_bounds__(HU_THREADS) void k_halo_update(int nloc, int nhalo, const int *halo_src, const int *halo_shift, double L0, double L1, double L2,
                               double4 *pos, uint64_t *gid, bool with_tags, const double *hrecv3, const double *hrecv5, const int *n_dev = nullptr,
-                              unsigned long long *hmax = nullptr, int par = 0)
+                              unsigned long long *hmax = nullptr, int par = 0,
+                              const int *horder = nullptr, const int *hsrc_t = nullptr, const int *hshift_t = nullptr, int *halo_src_w = nullptr, int *halo_shift_w = nullptr
+                              /* rebuild: the sorted descriptors are gathered here (horder: sorted place -> descriptor) and written for the steps to come */)
 {
    if (n_dev) nhalo = min(nhalo, *n_dev);
    double d2max = 0.0;
    const int hend = min(nhalo, ((int)blockIdx.x + 1) * HU_PER);
    for (int h = blockIdx.x * HU_PER + threadIdx.x; h < hend; h += HU_THREADS)
    {
-      int s = halo_src[h];
+      int s, code0 = 0;
+      if (horder) { const int kd = horder[h]; s = hsrc_t[kd]; code0 = hshift_t[kd]; halo_src_w[h] = s; halo_shift_w[h] = code0; }
+      else s = halo_src[h];
       if (s >= 0)
       {
-         int code = halo_shift[h];
+         int code = horder ? code0 : halo_shift[h];
          double4 p = pos[s];
          p.x += (double)(code % 3 - 1) * L0;
          p.y += (double)((code / 3) % 3 - 1) * L1;
@@ -392,16 +398,20 @@ __global__ __launch_bounds__(HU_THREADS) void k_halo_update(int nloc, int nhalo,
       {
          int k = -1 - s;
          double4 p = pos[nloc + h];
-         p.x = hrecv3[3 * k]; p.y = hrecv3[3 * k + 1]; p.z = hrecv3[3 * k + 2];
          if (with_tags)
          {
+            p.x = hrecv5[5 * k]; p.y = hrecv5[5 * k + 1]; p.z = hrecv5[5 * k + 2];
             p.w = hrecv5[5 * k + 3];
             gid[nloc + h] = (uint64_t)__double_as_longlong(hrecv5[5 * k + 4]);
          }
-         else if (hmax)
+         else
          {
-            const double dx = p.x - hrecv5[5 * k], dy = p.y - hrecv5[5 * k + 1], dz = p.z - hrecv5[5 * k + 2];
-            d2max = fmax(d2max, dx * dx + dy * dy + dz * dz);
+            p.x = hrecv3[3 * k]; p.y = hrecv3[3 * k + 1]; p.z = hrecv3[3 * k + 2];
+            if (hmax)
+            {
+               const double dx = p.x - hrecv5[5 * k], dy = p.y - hrecv5[5 * k + 1], dz = p.z - hrecv5[5 * k + 2];
+               d2max = fmax(d2max, dx * dx + dy * dy + dz * dz);
+            }
          }
          pos[nloc + h] = p;
       }
@@ -2856,16 +2866,25 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
    int n = ctx->nloc, nb = cdiv(n, 256), ncell = gp.ncell, ncb = cdiv(ncell, 256);
    dbuf<int> *cb[] = {&ctx->cell_cnt_o, &ctx->cell_start_o, &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt};
    for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
-   /* the counters of the whole rebuild in one launch: cell counts, the capacity flags and totals of k_tile_build */
-   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1)
-                               .add(ctx->d_flags + 32, 2));
+   /* the counters of the whole rebuild: cell counts, the capacity flags and totals of k_tile_build -- left zeroed by the last rebuild's
+    * tail launch (k_rebuild_tail) unless this is the first rebuild, the grid changed, or a rebuild is being started over */
+   {
+      const bool clean = ctx->counters_clean && ctx->clean_ncell == ncell && ctx->clean_po == ctx->cell_cnt_o.p && ctx->clean_ph == ctx->cell_cnt_h.p;
+      ctx->counters_clean = false;
+      if (!clean)
+         ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1)
+                                     .add(ctx->d_flags + 32, 2));
+   }
    if (n > 0)
    {
       /* (decomposed runs: the "beads are not numbers" flag also rides in slot 30 of the direction counters, so that the halo count
        * round of this rebuild tells every rank) */
       hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12,
-                         ((ctx->nranks > 1 || ctx->loopback) && ctx->dir_cnt.cap >= 32) ? ctx->dir_cnt.p + 30 : (int *)nullptr);
+                         ((ctx->nranks > 1 || ctx->loopback) && ctx->dir_cnt.cap >= 32) ? ctx->dir_cnt.p + 30 : (int *)nullptr,
+                         ctx->sort_renumbers ? ctx->orig.p : (int *)nullptr, ctx->sort_renumbers ? ctx->dir_cnt.p : (int *)nullptr);
+      ctx->dir28_clean = ctx->sort_renumbers;
    }
+   ctx->sort_renumbers = false;
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
    if (n > 0)
    {
@@ -2960,9 +2979,10 @@ int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
          hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p, ctx->hkey.p, ctx->hshift_t.p);
       else
          hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
-      hipLaunchKernelGGL(k_gather_halo, dim3(nhb), dim3(256), 0, st, nh, ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p, (const int *)ctx->nhalo_dev);
-      hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
-                         ctx->hrecv3.p, ctx->hrecv5.p, (const int *)ctx->nhalo_dev);
+      /* the sorted descriptors and the beads they place, in one launch (a gather launch and an update launch before) */
+      hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, (const int *)nullptr, (const int *)nullptr, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
+                         ctx->hrecv3.p, ctx->hrecv5.p, (const int *)ctx->nhalo_dev, (unsigned long long *)nullptr, 0,
+                         ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p);
    }
    else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
    hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
@@ -3144,7 +3164,22 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
    ENSURE(ctx, ctx->tile_perm, cap_items + 1);
    ENSURE(ctx, ctx->sched, 32);
    ENSURE(ctx, ctx->partials, (size_t)(nitems + 8) * 8);
-   { int rcf; if ((rcf = ddcmi_fetch(ctx, ctx->stream, ctx->tile_perm.p, perm, std::max(nitems, 1))) || (rcf = ddcmi_fetch(ctx, ctx->stream, ctx->sched.p, sched, 32))) return rcf; }
+   {
+      /* the tile order and the ranges, the displacement words of the shell-limited walk back to zero, and the NEXT rebuild's counters
+       * cleared while nothing reads them (ddcmi_bl_sort_owned, mg_phase1_launch): one launch */
+      TailJobs tj;
+      tj.fetch(ctx->tile_perm.p, perm, std::max(nitems, 1)).fetch(ctx->sched.p, sched, 32);
+      const int ncell = ctx->gp.ncell;
+      tj.zero.add(ctx->d_results + R_DISP, 6);      /* three doubles */
+      tj.zero.add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1).add(ctx->d_flags + 32, 2);
+      tj.zero.add(ctx->d_flags + DDCMI_FLAG_AGREE, 2);
+      const bool dirs = ctx->dir_cnt.p != nullptr && ctx->dir_cnt.cap >= 32;
+      if (dirs) tj.zero.add(ctx->dir_cnt.p, 32);
+      int rcf = ddcmi_rebuild_tail(ctx, ctx->stream, tj);
+      if (rcf) return rcf;
+      ctx->counters_clean = true; ctx->clean_ncell = ncell; ctx->clean_po = ctx->cell_cnt_o.p; ctx->clean_ph = ctx->cell_cnt_h.p;
+      ctx->dircnt_clean = dirs;
+   }
    return DDCMI_OK;       /* the pinned buffers are rewritten at the next rebuild, behind its own synchronisation */
 }
 
@@ -3310,7 +3345,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
        * k_halo_update keeps their largest distance from the rebuild's records (NbTileArgs::hdisp) */
       ctx->sh_r0sq = (double)shc.r0sq; ctx->sh_step = ((double)gp.rlist * gp.rlist - (double)shc.r0sq) / (double)(NSHELL - 1.01);
       ctx->shell_skip = !ctx->no_shell_skip && !shc.one && ctx->sh_step > 0.0;
-      HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_DISP, 0, 3 * sizeof(double), st));      /* D, and the received beads' two displacement words (k_halo_update) */
+      /* (D and the received beads' two displacement words were zeroed by the rebuild's tail launch, schedule_tiles) */
    }
    return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
 }

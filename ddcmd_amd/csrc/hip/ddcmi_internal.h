@@ -254,6 +254,10 @@ struct ddcmi_ctx
       return h_pin[which];
    }
    double self_ele = 0.0;
+   /* what the last rebuild's tail left zeroed for this one (k_rebuild_tail): the cell counters (for this cell count, in these buffers),
+    * the flags, the arena counter, the direction counters; a rebuild that cannot rely on it clears them itself */
+   bool counters_clean = false, dircnt_clean = false, dir28_clean = false; int clean_ncell = 0; const int *clean_po = nullptr, *clean_ph = nullptr;
+   bool sort_renumbers = false;        /* decomposed rebuild: the coming sort numbers the beads (orig = place in front of the sort) in its first kernel */
    bool forces_valid = false;
    bool f_zero = false;                /* fx, fy, fz of the owned beads are all zero (left so by a fused launch that consumed the bonded forces): the next bonded launch needs no clearing */
    /* timing */
@@ -351,7 +355,7 @@ __device__ __forceinline__ double rcp_f64(double x)
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, const int *src, int *dst, int n, int *d_total);
 struct ZeroJobs
 {
-   int *p[8]; int n[8]; int cnt = 0;
+   int *p[10]; int n[10]; int cnt = 0;
    ZeroJobs &add(void *ptr, size_t nints) { p[cnt] = (int *)ptr; n[cnt] = (int)nints; cnt++; return *this; }
 };
 int ddcmi_zero_ints(ddcmi_ctx *ctx, hipStream_t st, const ZeroJobs &z);
@@ -364,6 +368,13 @@ int ddcmi_post(ddcmi_ctx *ctx, hipStream_t st, PostJobs &j);            /* devic
 int ddcmi_post_wait(ddcmi_ctx *ctx, hipStream_t st);                    /* spin until the post has landed */
 int ddcmi_agree_poll(ddcmi_ctx *ctx);                                   /* in front of a host wait: has a peer reported a failed rebuild? (ddcmi_multigpu.inl) */
 int ddcmi_fetch(ddcmi_ctx *ctx, hipStream_t st, int *dst, const int *src_host_mapped, int n);
+struct TailJobs
+{
+   int *fdst[2]; const int *fsrc[2]; int fn[2]; int nfetch = 0;      /* fsrc: mapped host memory (host addresses in, device addresses at the launch) */
+   ZeroJobs zero;
+   TailJobs &fetch(int *dst, const int *src_host_mapped, size_t n) { fdst[nfetch] = dst; fsrc[nfetch] = src_host_mapped; fn[nfetch] = (int)n; nfetch++; return *this; }
+};
+int ddcmi_rebuild_tail(ddcmi_ctx *ctx, hipStream_t st, TailJobs &j);
 int ddcmi_bonded_localize(ddcmi_ctx *ctx);
 int ddcmi_ensure_slots(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);

@@ -81,11 +81,12 @@ struct MigGeom { double L[3], W[3]; int P[3], pc[3], pbc; };
 /* ownership (voronoiCalcParticleDestinations for a cubic lattice of centres =
  * brick index) + packing of the beads that leave: record = x y z tag vx vy vz gid {group, LCG64 multID, prime} {LCG64 state} */
 __global__ void k_mig_classify(MigGeom mg, int nloc, int mig_cap, double4 *pos, const double *vx, const double *vy, const double *vz,
-                               const uint64_t *gid, const int *group, int *keep, int *dir_cnt, double *mig_out, int *flags, const ulonglong2 *lcg)
+                               const uint64_t *gid, const int *group, int *keep, int *dir_cnt, double *mig_out, int *flags, const ulonglong2 *lcg, int *orig)
 {
    int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i == 0) dir_cnt[27] = mig_cap;      /* travels with the counts: every rank sees whether any rank's segments overflowed */
    if (i >= nloc) return;
+   orig[i] = i;      /* (the beads' numbers of this rebuild: was a launch of its own) */
    double4 p = pos[i];
    if (mg.pbc & 1) { if (p.x > 0.5 * mg.L[0]) p.x -= mg.L[0]; if (p.x < -0.5 * mg.L[0]) p.x += mg.L[0]; }
    if (mg.pbc & 2) { if (p.y > 0.5 * mg.L[1]) p.y -= mg.L[1]; if (p.y < -0.5 * mg.L[1]) p.y += mg.L[1]; }
@@ -202,6 +203,24 @@ __global__ void k_halo_select(GridParams gp, DirTab dt, int nloc, int hs_cap, co
 struct OffTab { int off[28]; };   /* exclusive offsets of the flattened per-direction segments */
 
 
+/* rebuild: the send map AND the 5-wide records of the beads it names, one launch (a map launch and a pack launch before) */
+__global__ void k_send_map_pack5(int nsend, SegTab so, DirTab dt, int hs_cap, const int *__restrict__ hs_idx, unsigned *__restrict__ send_map, double L0, double L1, double L2,
+                                 const double4 *__restrict__ pos, const uint64_t *__restrict__ gid, double *__restrict__ out)
+{
+   int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= nsend) return;
+   int q = 0;
+   while (k >= so.off[q + 1]) q++;
+   const int code = so.code[q];
+   const int i = hs_idx[(size_t)code * hs_cap + (k - so.off[q])];
+   send_map[k] = (unsigned)i | ((unsigned)code << 27);
+   const double4 p = pos[i];
+   double *o = out + (size_t)k * 5;
+   o[0] = p.x + dt.shift[code][0] * L0;
+   o[1] = p.y + dt.shift[code][1] * L1;
+   o[2] = p.z + dt.shift[code][2] * L2;
+   o[3] = p.w; o[4] = __longlong_as_double((long long)gid[i]);
+}
 /* pack the beads a remote neighbour needs, shift applied: width 3 (x y z, every
  * step) or 5 (+ tag, gid: at rebuilds) */
 /* rebuild: send slot k of the halo buffer <- owned bead and direction, flattened once so that the per-step pack is a plain
@@ -532,7 +551,8 @@ static int mg_agree_async(ddcmi_ctx *ctx, int local_rc, int pretend_peer_code = 
    if (!h) return mg_agree(ctx, local_rc);
    h[0] = std::max(local_rc < 0 ? -local_rc : local_rc, pretend_peer_code);
    int *d = ctx->d_flags + DDCMI_FLAG_AGREE;
-   HIPCHK(ctx, hipMemcpyAsync(d, h, sizeof(int), hipMemcpyHostToDevice, st));
+   /* (a rebuild that went well contributes the zero its tail launch left there: no copy) */
+   if (h[0] != 0 || !ctx->list_valid) HIPCHK(ctx, hipMemcpyAsync(d, h, sizeof(int), hipMemcpyHostToDevice, st));
    NCCLCHK2(ctx, ncclAllReduce(d, d + 1, 1, ncclInt, ncclMax, (ncclComm_t)ctx->comm, st));
    ctx->agree_seq++;
    hipLaunchKernelGGL(k_agree_post, dim3(1), dim3(64), 0, st, d + 1, ctx->agree_d, ctx->agree_seq);
@@ -722,15 +742,15 @@ static int mg_phase1_launch(ddcmi_ctx *ctx)
    ENSURE(ctx, ctx->mig_out, (size_t)27 * ctx->mig_cap * 10);
    ENSURE(ctx, ctx->dir_cnt, 32);
    ENSURE(ctx, ctx->keep, (size_t)n + 1);
-   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 32).add(ctx->d_flags, 8));
+   if (!ctx->dircnt_clean) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 32).add(ctx->d_flags, 8));      /* (else: the last rebuild's tail launch left them zeroed) */
+   ctx->dircnt_clean = false;
    MigGeom mg;
    for (int a = 0; a < 3; a++) { mg.L[a] = ctx->h[4 * a]; mg.P[a] = ctx->pgrid[a]; mg.W[a] = mg.L[a] / mg.P[a]; mg.pc[a] = ctx->pcoord[a]; }
    mg.pbc = ctx->pbc;
    if (n > 0)
    {
-      hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
       hipLaunchKernelGGL(k_mig_classify, dim3(cdiv(n, 256)), dim3(256), 0, st, mg, n, ctx->mig_cap, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
-                         ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags, ctx->lcg_on ? ctx->lcg.p : (const ulonglong2 *)nullptr);
+                         ctx->gid.p, ctx->group.p, ctx->keep.p, ctx->dir_cnt.p, ctx->mig_out.p, ctx->d_flags, ctx->lcg_on ? ctx->lcg.p : (const ulonglong2 *)nullptr, ctx->orig.p);
    }
    return DDCMI_OK;
 }
@@ -784,7 +804,7 @@ static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
                          ctx->gid.p, ctx->species.p, ctx->group.p, ctx->orig.p, ctx->lcg_on ? ctx->lcg.p : (ulonglong2 *)nullptr);
    ctx->nloc = nkeep + narr;
    n = ctx->nloc;
-   if (n > 0) hipLaunchKernelGGL(k_iota, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->orig.p);
+   ctx->sort_renumbers = true;      /* (the sort's first kernel numbers the beads: was a launch of its own) */
    /* sort the owned beads, then pick what each neighbour direction needs */
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
    return DDCMI_OK;
@@ -796,7 +816,8 @@ static int mg_halo_select_launch(ddcmi_ctx *ctx)
    const int n = ctx->nloc;
    if (ctx->hs_cap == 0) ctx->hs_cap = std::max(4096, n / 4);
    ENSURE(ctx, ctx->hs_idx, (size_t)27 * ctx->hs_cap);
-   ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28));      /* (slots 28-31 keep what the rebuild has flagged so far: k_wrap_cell's slot 30) */
+   if (!ctx->dir28_clean) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->dir_cnt.p, 28));      /* (slots 28-31 keep what the rebuild has flagged so far: k_wrap_cell's slot 30; else: the sort's first kernel zeroed them) */
+   ctx->dir28_clean = false;
    if (n > 0)
       hipLaunchKernelGGL(k_halo_select, dim3(cdiv(n, 256)), dim3(256), 0, st, ctx->gp, mg_dirtab(ctx), n, ctx->hs_cap, ctx->pos.p, ctx->dir_cnt.p, ctx->hs_idx.p);
    return DDCMI_OK;
@@ -829,9 +850,15 @@ static int mg_phase3_pack(ddcmi_ctx *ctx, int width)
    {
       if (ctx->nloc >= (1 << 27)) SETERR(ctx, DDCMI_EUNSUPPORTED, "%d beads on one rank: more than the halo send map's 27 bits name", ctx->nloc);
       ENSURE(ctx, ctx->send_map, (size_t)ns + 8);
-      hipLaunchKernelGGL(k_send_map, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, ctx->sseg, ctx->hs_cap, ctx->hs_idx.p, ctx->send_map.p);
-      hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, mg_dirtab(ctx), ctx->send_map.p,
-                         ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, width);
+      if (width == 5)
+         hipLaunchKernelGGL(k_send_map_pack5, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, ctx->sseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p, ctx->send_map.p,
+                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p);
+      else
+      {
+         hipLaunchKernelGGL(k_send_map, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, ctx->sseg, ctx->hs_cap, ctx->hs_idx.p, ctx->send_map.p);
+         hipLaunchKernelGGL(k_pack_halo, dim3(cdiv(ns, 256)), dim3(256), 0, st, ns, mg_dirtab(ctx), ctx->send_map.p,
+                            ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, ctx->sendbuf.p, width);
+      }
    }
    return DDCMI_OK;
 }
@@ -853,7 +880,7 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
       hipLaunchKernelGGL(k_halo_assemble, dim3(cdiv(nh, 256)), dim3(256), 0, st, ctx->gp, nself, ctx->nrecv, selfo, ctx->rseg, mg_dirtab(ctx), ctx->hs_cap, ctx->hs_idx.p,
                          ctx->pos.p, ctx->hrecv5.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p, ctx->gid.p, ctx->hkey.p);
       ctx->hkey_valid = true;
-      if (ctx->nrecv > 0) hipLaunchKernelGGL(k_rec5to3, dim3(cdiv(ctx->nrecv, 256)), dim3(256), 0, st, ctx->nrecv, ctx->hrecv5.p, ctx->hrecv3.p);
+      /* (no 5 -> 3 copy of the received records: the tagged halo update of the rebuild reads x y z out of the 5-wide ones) */
    }
    ctx->phase(6, "mg halo assemble launched");
    if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
@@ -1103,6 +1130,9 @@ static int group_rebuild(ddcmi_group *g)
       }
       for (ddcmi_ctx *c : g->ranks) if ((rc = ddcmi_mol_split_finish(c))) return rc;
    }
+   /* (the rebuild's tagged halo update placed every image and halo bead from these very positions: the force evaluation that follows
+    * needs no update -- and has no 3-wide records to take one from: only the steps' exchanges fill them) */
+   for (ddcmi_ctx *c : g->ranks) c->images_fresh = true;
    return DDCMI_OK;
 }
 static int group_refresh(ddcmi_group *g)

@@ -173,6 +173,27 @@ __global__ void k_fetch(int *dst, const int *src, int n)
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i < n) dst[i] = src[i];
 }
+/* the tail of a rebuild in ONE launch (two fetch launches, two memsets and -- decomposed runs -- a host-to-device copy before): the tile
+ * order and the XCD ranges come in from mapped host memory, and everything the NEXT rebuild expects to find zero is zeroed now
+ * (TailJobs::zero): its counters are dead from here on, and a rebuild that finds them clean starts without a clearing launch */
+__global__ void k_rebuild_tail(TailJobs j)
+{
+   const int stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+   for (int q = 0; q < j.nfetch; q++) for (int i = i0; i < j.fn[q]; i += stride) j.fdst[q][i] = j.fsrc[q][i];
+   for (int q = 0; q < j.zero.cnt; q++) { int *p = j.zero.p[q]; for (int i = i0; i < j.zero.n[q]; i += stride) p[i] = 0; }
+}
+int ddcmi_rebuild_tail(ddcmi_ctx *ctx, hipStream_t st, TailJobs &j)
+{
+   size_t mx = 1;
+   for (int q = 0; q < j.nfetch; q++)
+   {
+      if (hipHostGetDevicePointer((void **)&j.fsrc[q], (void *)j.fsrc[q], 0) != hipSuccess) SETERR(ctx, DDCMI_ENODEVICE, "device address of a pinned table");
+      mx = std::max(mx, (size_t)j.fn[q]);
+   }
+   for (int q = 0; q < j.zero.cnt; q++) mx = std::max(mx, (size_t)j.zero.n[q]);
+   hipLaunchKernelGGL(k_rebuild_tail, dim3((unsigned)std::min<size_t>(256, (mx + 255) / 256)), dim3(256), 0, st, j);
+   return DDCMI_OK;
+}
 int ddcmi_fetch(ddcmi_ctx *ctx, hipStream_t st, int *dst, const int *src_host_mapped, int n)
 {
    if (n <= 0) return DDCMI_OK;
