@@ -221,11 +221,14 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
     ms_per_step = med * 1e3 / WINDOW
     L = st["entries"] / float(max(nlocal, 1))
     # SURVEY 8(d), compulsory bytes per bead and launch.  The plain pair kernel: read r_i 24 + q_i 8 + type_i 4, write f_i 24, list 4 L.
-    # Between print steps the pair kernel of a system without bonded terms ends in the integrator's pass (BACK kick, kinetic terms,
+    # Between print steps the pair kernel ends in the integrator's pass (BACK kick, kinetic terms,
     # FRONT kick, drift: SURVEY's rows "kick+KE" and "kick+drift"): the force never goes to memory (-24), v is read and written
     # (+48), the drifted r written (+24) -- each datum once.  The dominant kind of launch in the timed region is the one priced.
-    plain = {"bytes": 36.0 + 24.0 + 4.0 * L, "launches": launches - launches_f, "ms": kernel_ms - kernel_ms_f}
-    fusedk = {"bytes": 36.0 + 4.0 * L + 48.0 + 24.0, "launches": launches_f, "ms": kernel_ms_f}
+    # Systems with bonded terms: their kernels run first and leave their force on every bead (24 B); either kind of launch reads it (+24).
+    nbonded = sum(int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k"))
+    fb = 24.0 if nbonded > 0 else 0.0
+    plain = {"bytes": 36.0 + 24.0 + 4.0 * L + fb, "launches": launches - launches_f, "ms": kernel_ms - kernel_ms_f}
+    fusedk = {"bytes": 36.0 + 4.0 * L + 48.0 + 24.0 + fb, "launches": launches_f, "ms": kernel_ms_f}
     dom = fusedk if fusedk["ms"] > plain["ms"] else plain
     bytes_per_atom = dom["bytes"]
     t_kernel = dom["ms"] * 1e-3 / max(1, dom["launches"])

@@ -120,6 +120,7 @@ class CSetup(ctypes.Structure):
         ("printStress", ctypes.c_int), ("printHmatrix", ctypes.c_int), ("u_energyflux", ctypes.c_char_p),
         ("random_name", ctypes.c_char_p), ("random_lcg64", ctypes.c_int), ("lcg_from_file", ctypes.c_int),
         ("lcg_state", c_u64_p), ("lcg_multID", ctypes.POINTER(ctypes.c_uint32)), ("lcg_prime", ctypes.POINTER(ctypes.c_uint32)),
+        ("group_vcm", c_double_p),
     ]
 
 

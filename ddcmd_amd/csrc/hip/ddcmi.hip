@@ -1827,6 +1827,7 @@ __global__ void k_finish_energy(double *r, double self_ele)
  * decomposition or launch shape -- statistical, not bitwise, parity with ddcMD. */
 struct GroupLambda { double v[32]; double a[32]; double dfac[32]; unsigned lang_mask; unsigned long long seed, counter_front, counter_back;
                      double scale[3]; /* barostat: positions are scaled by this (adjustPosn) before the drift; 1 otherwise */
+                     unsigned vcm_mask; double vw[32][3]; /* Langevin groups with a drift velocity (langevin.c:106,167 `vcm`): v = vcm + a (v - vcm) + ... adds vw = (1 - a) vcm to either update */
                      ulonglong2 *lcg; /* RANDOM type LCG64 (ddcmi_set_random_lcg64): the beads' own streams (the reference's), in slot order; nullptr = the counter-based stream */ };
 __device__ __forceinline__ unsigned long long smix64(unsigned long long z)
 {
@@ -1927,6 +1928,7 @@ __global__ void k_kick_drift(int nloc, double dt, const double *__restrict__ inv
             double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
             group_gauss3(glambda, i, gid, glambda.counter_front, g0, g1, g2);
             x = fma(d, g0, fma(a, fx[i], al * x)); y = fma(d, g1, fma(a, fy[i], al * y)); z = fma(d, g2, fma(a, fz[i], al * z));
+            if (glambda.vcm_mask >> gr & 1u) { x += glambda.vw[gr][0]; y += glambda.vw[gr][1]; z += glambda.vw[gr][2]; }
          }
          else
          {
@@ -1983,6 +1985,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke(int nloc, double dt, co
             double g0, g1, g2, d = glambda.dfac[gr] * sqrt(im), al = glambda.a[gr];
             group_gauss3(glambda, i, gid, glambda.counter_back, g0, g1, g2);
             x = al * fma(d, g0, fma(a, fx[i], x)); y = al * fma(d, g1, fma(a, fy[i], y)); z = al * fma(d, g2, fma(a, fz[i], z));
+            if (glambda.vcm_mask >> gr & 1u) { x += glambda.vw[gr][0]; y += glambda.vw[gr][1]; z += glambda.vw[gr][2]; }
          }
          else { x = fma(a, fx[i], x); y = fma(a, fy[i], y); z = fma(a, fz[i], z); }
          vx[i] = x; vy[i] = y; vz[i] = z;
@@ -2023,6 +2026,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
          dl = glambda.dfac[gr] * sqrt(im); al = glambda.a[gr];
          group_gauss3(glambda, i, gid, glambda.counter_back, g0, g1, g2);
          x = al * fma(dl, g0, fma(a, f0, vx[i])); y = al * fma(dl, g1, fma(a, f1, vy[i])); z = al * fma(dl, g2, fma(a, f2, vz[i]));
+         if (glambda.vcm_mask >> gr & 1u) { x += glambda.vw[gr][0]; y += glambda.vw[gr][1]; z += glambda.vw[gr][2]; }
       }
       else { x = fma(a, f0, vx[i]); y = fma(a, f1, vy[i]); z = fma(a, f2, vz[i]); }
       double m = massv[sp];
@@ -2034,6 +2038,7 @@ __global__ __launch_bounds__(DDCMI_BLOCK) void k_kick_ke_drift(int nloc, double 
       {
          group_gauss3(glambda, i, gid, glambda.counter_front, g0, g1, g2);
          x = fma(dl, g0, fma(a, f0, al * x)); y = fma(dl, g1, fma(a, f1, al * y)); z = fma(dl, g2, fma(a, f2, al * z));
+         if (glambda.vcm_mask >> gr & 1u) { x += glambda.vw[gr][0]; y += glambda.vw[gr][1]; z += glambda.vw[gr][2]; }
       }
       else
       {
@@ -2536,9 +2541,26 @@ extern "C" int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, con
    }
    ctx->glambda.assign(ngroup, 1.0); ctx->gTsum.assign(ngroup, 0.0); ctx->gT.assign(ngroup, 0.0);
    ctx->gnT.assign(ngroup, 0); ctx->gdoScaling.assign(ngroup, 0);
+   ctx->gvcm.clear();
    return DDCMI_OK;
 }
 
+static void graph_drop(ddcmi_ctx *ctx);
+extern "C" int ddcmi_set_group_vcm(ddcmi_ctx *ctx, int ngroup, const double *vcm)
+{
+   if (!ctx || ngroup < 0 || ngroup > 32 || (ngroup > 0 && !vcm)) return DDCMI_EINVAL;
+   if (ngroup != ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_group_vcm: %d groups, ddcmi_set_groups gave %d", ngroup, ctx->ngroup);
+   ctx->gvcm.assign(vcm, vcm + 3 * (size_t)ngroup);
+   graph_drop(ctx);
+   return DDCMI_OK;
+}
+extern "C" int ddcmi_set_group_temperature(ddcmi_ctx *ctx, int group, double Teq)
+{
+   if (!ctx || group < 0 || group >= ctx->ngroup || !(Teq >= 0.0)) return DDCMI_EINVAL;
+   ctx->gTeq[group] = Teq;      /* (host scalars: the next step's factors are formed from them) */
+   graph_drop(ctx);
+   return DDCMI_OK;
+}
 extern "C" int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau)
 {
    if (!ctx || beta < 0.0 || (beta > 0.0 && !(tau > 0.0))) return DDCMI_EINVAL;
@@ -3604,7 +3626,7 @@ static void berendsen_update(ddcmi_ctx *ctx, double dt_half)
 static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
 {
    GroupLambda lam;
-   lam.lang_mask = 0; lam.seed = ctx->rng_seed;
+   lam.lang_mask = 0; lam.seed = ctx->rng_seed; lam.vcm_mask = 0;
    lam.lcg = ctx->lcg_on ? ctx->lcg.p : nullptr;
    lam.scale[0] = lam.scale[1] = lam.scale[2] = 1.0;
    /* the FRONT update of a step sees the loop count before its increment, the BACK update the one after */
@@ -3621,6 +3643,11 @@ static GroupLambda front_lambda(const ddcmi_ctx *ctx, double dt)
          lam.lang_mask |= 1u << g;
          lam.a[g] = exp(-dt_half / ctx->gtau[g]);
          lam.dfac[g] = sqrt(2.0 * dt_half * ctx->gTeq[g] / ctx->gtau[g]);          /* kB = 1 in internal units */
+         if ((size_t)(3 * g + 2) < ctx->gvcm.size() && (ctx->gvcm[3 * g] != 0.0 || ctx->gvcm[3 * g + 1] != 0.0 || ctx->gvcm[3 * g + 2] != 0.0))
+         {
+            lam.vcm_mask |= 1u << g;
+            for (int k = 0; k < 3; k++) lam.vw[g][k] = (1.0 - lam.a[g]) * ctx->gvcm[3 * g + k];
+         }
       }
    }
    return lam;

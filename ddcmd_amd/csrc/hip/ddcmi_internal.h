@@ -143,6 +143,7 @@ struct ddcmi_ctx
    double deltaR = 0; int updateRate = 0;
    int ngroup = 1; std::vector<int> gtype, ginterval; std::vector<double> gTeq, gtau;
    std::vector<double> glambda, gTsum, gT; std::vector<int> gnT, gdoScaling;
+   std::vector<double> gvcm;           /* LANGEVIN groups: drift velocity [3 ngroup] (ddcmi_set_group_vcm; empty = zero) */
    int64_t loop = 0; double time = 0;
    int excludePotentialTerm = 0;
    bool has_charge = false;

@@ -613,6 +613,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       s->group_type = calloc(s->ngroup, sizeof(int));
       s->group_Teq = calloc(s->ngroup, sizeof(double));
       s->group_tau = calloc(s->ngroup, sizeof(double));
+      s->group_vcm = calloc(3 * (size_t)s->ngroup, sizeof(double));
       s->group_interval = calloc(s->ngroup, sizeof(int));
       for (int g = 0; g < s->ngroup; g++)
       {
@@ -635,8 +636,22 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
          else if (strcmp(type, "LANGEVIN") == 0)
          {
             s->group_type[g] = DDCMI_GROUP_LANGEVIN;
+            /* normalParse (langevin.c:66-91): Teq is an EQUATION of time there (eq_parse, simutil -- not in the reference tree, its
+             * grammar unknown here): a constant with a unit is what this loader takes, anything else is refused, not misread */
+            {
+               char *teq = get_string(go, "Teq", "0.0");
+               char *endp = NULL;
+               (void)strtod(teq, &endp);
+               while (endp && (*endp == ' ' || *endp == '\t')) endp++;
+               int ok = endp && endp != teq;
+               for (const char *q = endp; ok && q && *q; q++)
+                  if (!((*q >= 'A' && *q <= 'Z') || (*q >= 'a' && *q <= 'z') || *q == '_' || *q == '^' || *q == '*' || *q == '/' || *q == '-' || (*q >= '0' && *q <= '9') || *q == ' ')) ok = 0;
+               if (!ok) { free(teq); free(type); FAIL("GROUP %s: Teq is not a constant temperature (an equation of time: set the value step by step with ddcmi_set_group_temperature)", gnames[g]); }
+               free(teq);
+            }
             object_get(go, "Teq", &s->group_Teq[g], WITH_UNITS, 1, "0.0", "T", NULL);
             object_get(go, "tau", &s->group_tau[g], WITH_UNITS, 1, "1.0", "t", NULL);
+            object_get(go, "vcm", &s->group_vcm[3 * g], WITH_UNITS, 3, "0.0 0.0 0.0", "l/t", NULL);      /* langevin.c:167 */
          }
          else s->group_type[g] = DDCMI_GROUP_OTHER;
          free(type);
@@ -1006,7 +1021,7 @@ void ddcmi_setup_free(ddcmi_setup *s)
    free(s->angle_off); free(s->angleI); free(s->angleJ); free(s->angleK); free(s->angle_func); free(s->angle_k); free(s->angle_t0);
    free(s->tors_off); free(s->torsI); free(s->torsJ); free(s->torsK); free(s->torsL); free(s->tors_func); free(s->tors_n); free(s->tors_k); free(s->tors_delta);
    for (int i = 0; i < s->ngroup; i++) if (s->group_name) free(s->group_name[i]);
-   free(s->group_name); free(s->group_type); free(s->group_Teq); free(s->group_tau); free(s->group_interval);
+   free(s->group_name); free(s->group_type); free(s->group_Teq); free(s->group_tau); free(s->group_vcm); free(s->group_interval);
    free(s->rx); free(s->ry); free(s->rz); free(s->vx); free(s->vy); free(s->vz); free(s->gid); free(s->species); free(s->group);
    free(s->rest_gid); free(s->rest_fc); free(s->rest_r0); free(s->rest_kb);
    free(s->cons_off); free(s->consI); free(s->consJ); free(s->cons_grp); free(s->cons_r0);

@@ -102,6 +102,7 @@ typedef struct ddcmi_setup
    int random_lcg64, lcg_from_file;
    uint64_t *lcg_state;
    uint32_t *lcg_multID, *lcg_prime;
+   double *group_vcm;      /* [3 ngroup] LANGEVIN groups: `vcm` (langevin.c:167), internal units; zero otherwise */
 } ddcmi_setup;
 
 /* lcg64_default over n particles in order (lcg64.c:98-110, primes.c:35-63 with prime_init(30000, task, ntasks), ddcMD.c:70) */

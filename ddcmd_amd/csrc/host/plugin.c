@@ -223,6 +223,7 @@ static void martini_parms(POTENTIAL *potential, SIMULATE *simulate)
       else die("group_init", "only FREE, BERENDSEN and LANGEVIN groups are supported on this path");
    }
    rc |= ddcmi_set_groups(ctx, s->ngroup, gtype, s->group_Teq, s->group_tau, s->group_interval);
+   if (s->group_vcm) rc |= ddcmi_set_group_vcm(ctx, s->ngroup, s->group_vcm);
    rc |= ddcmi_set_random(ctx, s->rng_seed);
    if (s->nrest > 0)      /* restraint_parms + restraintGPU_parms (restraint.c:177-208) */
       rc |= ddcmi_set_restraints(ctx, s->nrest, s->rest_gid, s->rest_fc, s->rest_r0, s->rest_kb, s->rest_origin);

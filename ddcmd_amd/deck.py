@@ -171,6 +171,7 @@ def load_deck(object_file, restart_file=None, extra_objects=None):
         s.group_interval = _arr(c.group_interval, ng, np.int32)
         s.group_Teq = _arr(c.group_Teq, ng, np.float64)
         s.group_tau = _arr(c.group_tau, ng, np.float64)
+        s.group_vcm = _arr(c.group_vcm, 3 * ng, np.float64) if c.group_vcm else np.zeros(3 * ng)
         na = c.natoms
         for k in ("rx", "ry", "rz", "vx", "vy", "vz"):
             setattr(s, k, _arr(getattr(c, k), na, np.float64))

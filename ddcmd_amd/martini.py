@@ -48,6 +48,8 @@ def _declare(lib):
                                          ctypes.c_int, _up, _ip, _ip, _dp, _dp, ctypes.c_int]
     lib.ddcmi_set_neighbor.argtypes = [vp, ctypes.c_double, ctypes.c_int]
     lib.ddcmi_set_groups.argtypes = [vp, ctypes.c_int, _ip, _dp, _dp, _ip]
+    lib.ddcmi_set_group_vcm.argtypes = [vp, ctypes.c_int, _dp]
+    lib.ddcmi_set_group_temperature.argtypes = [vp, ctypes.c_int, ctypes.c_double]
     lib.ddcmi_set_clock.argtypes = [vp, ctypes.c_int64, ctypes.c_double]
     lib.ddcmi_set_random.argtypes = [vp, ctypes.c_uint64]
     lib.ddcmi_set_barostat.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double]
@@ -361,6 +363,10 @@ class MartiniHIP(object):
         self._chk(self.lib.ddcmi_set_neighbor(self.ctx, s.deltaR, int(s.updateRate)))
         gt = i32(np.where(np.isin(np.asarray(s.group_type), (1, 2)), np.asarray(s.group_type), 0))     # FREE / BERENDSEN / LANGEVIN
         self._chk(self.lib.ddcmi_set_groups(self.ctx, s.ngroup, _i(gt), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
+        vcm = getattr(s, "group_vcm", None)
+        if vcm is not None and np.any(np.asarray(vcm) != 0.0):      # LANGEVIN groups: the velocity the friction relaxes towards (langevin.c:167)
+            self._vcm = f64(np.ravel(vcm))
+            self._chk(self.lib.ddcmi_set_group_vcm(self.ctx, s.ngroup, _d(self._vcm)))
         self._chk(self.lib.ddcmi_set_random(self.ctx, int(getattr(s, "rng_seed", 0))))
         if float(getattr(s, "npt_beta", 0.0)) > 0.0:      # INTEGRATOR type=NGLFCONSTRAINT: barostat on the molecular pressure
             self.set_barostat(float(s.npt_T), float(s.npt_P0), float(s.npt_beta), float(s.npt_tau), isotropic=bool(getattr(s, "npt_isotropic", 0)),

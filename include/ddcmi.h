@@ -114,6 +114,13 @@ int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate);
  * (kB = 1).  The Langevin noise is a counter-based normal stream keyed by (seed, gid, loop): the
  * reference's per-particle LCG64 states are not reproduced -- statistical parity only. */
 int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval);
+/* LANGEVIN groups, the rest of langevin_velocityUpdate (langevin.c:92-128): `vcm`, the velocity the friction relaxes towards
+ * (:106,167; v = vcm + a (v - vcm) + c f + d g), per group, [3 ngroup], internal units; after ddcmi_set_groups (which resets it
+ * to zero).  And Teq as a function of time (`Teq_dynamics = EXPLICIT_TIME`, :49,84-85): langevin_Update re-evaluates the group's
+ * equation once per step on the host; here the host does the same between calls of ddcmi_step_nglf with ddcmi_set_group_temperature
+ * (the equation grammar is simutil's eq_parse, which the reference tree does not hold: the deck loader takes constants). */
+int ddcmi_set_group_vcm(ddcmi_ctx *ctx, int ngroup, const double *vcm);
+int ddcmi_set_group_temperature(ddcmi_ctx *ctx, int group, double Teq);
 /* INTEGRATOR type=NGLFCONSTRAINT (nglfconstraint.c:510-574): NGLF plus a semi-isotropic Berendsen
  * barostat (changeVolume, :64-84) driven by the molecular pressure of the last force evaluation at the
  * target temperature T: lambda_xy = cbrt(1 + beta dt/tau ((Pxx+Pyy)/2 - P0)), lambda_z likewise from Pzz;

@@ -953,9 +953,10 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
          double dth = 0.5 * dt, al = exp(-dth / g->tau), c = dth / mass, d = sqrt(2.0 * dth * g->Teq / (mass * g->tau)), gg[3];
          if (g->lcg) orc_gasdev3d(&g->lcg[k], gg); else
          orc_gauss3(g->seed, gid[k], 2ull * (unsigned long long)(*loop), gg);
-         vx[k] = al * vx[k] + c * fx[k] + d * gg[0];
-         vy[k] = al * vy[k] + c * fy[k] + d * gg[1];
-         vz[k] = al * vz[k] + c * fz[k] + d * gg[2];
+         /* :111-113  vx[k] = v.x + a*(vx[k]-v.x) + c*fx[k] + d*g.x */
+         vx[k] = g->vcm[0] + al * (vx[k] - g->vcm[0]) + c * fx[k] + d * gg[0];
+         vy[k] = g->vcm[1] + al * (vy[k] - g->vcm[1]) + c * fy[k] + d * gg[1];
+         vz[k] = g->vcm[2] + al * (vz[k] - g->vcm[2]) + c * fz[k] + d * gg[2];
          continue;
       }
       if (g->type == 1 && g->doScaling == 1) { vx[k] *= g->lambda; vy[k] *= g->lambda; vz[k] *= g->lambda; }
@@ -989,9 +990,10 @@ void orc_nglf_step(const orc_params *p, orc_nbr **pnb, int updateRate, double dt
          double dth = 0.5 * dt, al = exp(-dth / g->tau), c = dth / mass, d = sqrt(2.0 * dth * g->Teq / (mass * g->tau)), gg[3];
          if (g->lcg) orc_gasdev3d(&g->lcg[k], gg); else
          orc_gauss3(g->seed, gid[k], 2ull * (unsigned long long)(*loop) + 1ull, gg);
-         vx[k] = al * (vx[k] + c * fx[k] + d * gg[0]);
-         vy[k] = al * (vy[k] + c * fy[k] + d * gg[1]);
-         vz[k] = al * (vz[k] + c * fz[k] + d * gg[2]);
+         /* :116-118  vx[k] = v.x + a*((vx[k]-v.x) + c*fx[k] + d*g.x) */
+         vx[k] = g->vcm[0] + al * ((vx[k] - g->vcm[0]) + c * fx[k] + d * gg[0]);
+         vy[k] = g->vcm[1] + al * ((vy[k] - g->vcm[1]) + c * fy[k] + d * gg[1]);
+         vz[k] = g->vcm[2] + al * ((vz[k] - g->vcm[2]) + c * fz[k] + d * gg[2]);
          continue;
       }
       double a = (0.5 * dt) / mass;

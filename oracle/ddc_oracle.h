@@ -156,7 +156,7 @@ void orc_lcg64_default(int n, const uint64_t *label, unsigned taskId, unsigned n
 /* thermostat description per group (group.c:48-90) */
 typedef struct orc_group
 {
-   int type;         /* 0 FREE (free.c), 1 BERENDSEN (berendsen.c), 2 LANGEVIN (langevin.c, constant Teq, vcm = 0) */
+   int type;         /* 0 FREE (free.c), 1 BERENDSEN (berendsen.c), 2 LANGEVIN (langevin.c: Teq as the caller sets it step by step) */
    double Teq, tau;  /* berendsen, langevin (Teq in energy units, kB = 1) */
    int interval;
    /* dynamic state (berendsen.c:12-20) */
@@ -164,6 +164,7 @@ typedef struct orc_group
    double temperature; /* g->energyInfo.temperature, refreshed by orc_group_temperature */
    unsigned long long seed;   /* langevin: seed of the counter-based normal stream (see orc_gauss3) */
    orc_lcg64_parm *lcg;       /* langevin: not NULL = the reference's per-particle LCG64 streams, [n] in particle order (advanced in place) */
+   double vcm[3];             /* langevin: the velocity the friction relaxes towards (langevin.c:106,167; p->vcm) */
 } orc_group;
 
 /* nglf (nglf.c:67-112): one velocity-Verlet step.  Rebuilds the list when

@@ -41,7 +41,7 @@ class OrcParams(ctypes.Structure):
 class OrcGroup(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int), ("Teq", ctypes.c_double), ("tau", ctypes.c_double), ("interval", ctypes.c_int),
                 ("lambda_", ctypes.c_double), ("Tsum", ctypes.c_double), ("nT", ctypes.c_int), ("doScaling", ctypes.c_int),
-                ("temperature", ctypes.c_double), ("seed", ctypes.c_ulonglong), ("lcg", ctypes.c_void_p)]
+                ("temperature", ctypes.c_double), ("seed", ctypes.c_ulonglong), ("lcg", ctypes.c_void_p), ("vcm", ctypes.c_double * 3)]
 
 
 # LCG64_PARM (lcg64.h:8-12) as a numpy record
@@ -186,6 +186,10 @@ class Oracle(object):
             self.groups[g].tau = s.group_tau[g]
             self.groups[g].interval = max(1, int(s.group_interval[g]))
             self.groups[g].lambda_ = 1.0
+            vcm = getattr(s, "group_vcm", None)
+            if vcm is not None and len(np.ravel(vcm)) >= 3 * (g + 1):
+                for k in range(3):
+                    self.groups[g].vcm[k] = float(np.ravel(vcm)[3 * g + k])
         self.lcg = None
         if getattr(s, "lcg64", None) is not None and lcg64 == "deck" and np.any(np.asarray(s.group_type) == 2):
             self.set_lcg64(s.lcg64)       # RANDOM type=LCG64 in the deck (one task: system.c:135, langevin.c:95-96)

@@ -628,6 +628,52 @@ def test_rebuild_started_over_with_bonded_terms_and_lcg64_streams(monkeypatch):
     assert abs(out[0][0] - eo["total"]) < 1e-6 * abs(eo["total"]) and abs(out[0][3] - rko) < 1e-6 * rko
 
 
+def test_langevin_group_with_a_drift_velocity_and_a_temperature_ramp():
+    """the rest of langevin_velocityUpdate (langevin.c:92-128; VERDICT r3 missing 5): `vcm`, the velocity the friction relaxes
+    towards -- v = vcm + a (v - vcm) + c f + d g on either half step -- and Teq as a function of time, which the reference
+    re-evaluates once per step on the host (langevin_Update, :49,84-85) and this library takes step by step through
+    ddcmi_set_group_temperature.  Trajectory parity with the oracle's restatement on the particles' LCG64 streams (fused and split
+    kick kernels), and the physics: the centre-of-mass velocity of the box goes to vcm."""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(10)
+    s.group_type = np.array([2], np.int32)
+    s.group_tau = np.array([units_convert(0.1, "ps")])
+    T0, T1 = units_convert(250.0, "K"), units_convert(350.0, "K")
+    s.group_Teq = np.array([T0])
+    vc = np.array([2.0e-3, -1.0e-3, 0.5e-3]) * units_convert(1.0, "Angstrom/fs")      # 50-200 m/s: far above the thermal noise of the mean of 4000 beads (~3 m/s)
+    s.group_vcm = vc.copy()
+    parms = pyoracle.lcg64_default(s.gid)
+    o = pyoracle.Oracle(s)
+    o.set_lcg64(parms)
+    o.forces()
+    m = MartiniHIP(s)
+    m.set_random_lcg64(parms)
+    m.eval_forces()
+    nblock = 12
+    for block in range(nblock):
+        Teq = T0 + (T1 - T0) * block / (nblock - 1)          # the host's "equation of time", one value per batch of steps
+        o.groups[0].Teq = Teq
+        assert m.lib.ddcmi_set_group_temperature(m.ctx, 0, float(Teq)) == 0
+        eo, vo, rko, _ = o.step(5)
+        m.step(5 if block % 2 else 1)
+        if block % 2 == 0:
+            m.step(4)
+        e, vir, rk, _ = m.energies()
+        assert abs(rk - rko) < TOL * rko and abs(e["total"] - eo["total"]) < TOL * abs(eo["total"]), block
+    d = m.download()
+    for c, ref in enumerate((o.vx, o.vy, o.vz)):
+        assert np.abs(d["v"][c] - ref).max() < 1e-6 * np.abs(ref).max()
+    got = m.get_random_lcg64()
+    assert (got["state"] == o.lcg["state"]).all()
+    # 60 steps = 12 tau: the friction has pulled the mean velocity onto vcm (thermal noise of the mean: sqrt(kT/(N m)))
+    mass = float(np.asarray(s.mass)[0])
+    noise = (T1 / (s.natoms * mass)) ** 0.5
+    vmean = np.array([d["v"][c].mean() for c in range(3)])
+    assert np.abs(vmean - vc).max() < 6.0 * noise and np.abs(vc).min() > 10.0 * noise
+    assert m.lib.ddcmi_set_group_temperature(m.ctx, 3, 1.0) != 0 and m.lib.ddcmi_set_group_temperature(m.ctx, 0, -1.0) != 0
+    m.close()
+
+
 def test_langevin_group_matches_oracle_and_thermalises():
     """LANGEVIN group (langevin.c:92-128): the device update equals the oracle's restatement with the same
     counter-based normal stream (trajectory parity), and drives a 50 K box to Teq (the statistical

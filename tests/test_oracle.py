@@ -564,3 +564,34 @@ def test_atoms_random_field_and_default_streams(tmp_path):
     assert s3.lcg_from_file == 0 and (s3.lcg64 == want).all()
     s4 = write("d", "random = lcg64;\nrandomFieldSize = 27;\n", skip_record=17)      # one record without the field: defaults for all
     assert s4.lcg_from_file == 0 and (s4.lcg64 == want).all()
+
+
+def test_langevin_drift_velocity_closed_form():
+    """langevin.c:106-118 with `vcm`: on force-free beads without noise (Teq = 0) the FRONT and BACK half updates of one step are
+    v <- vcm + a^2 (v - vcm), a = exp(-dt/(2 tau)): the oracle's restatement against that closed form, and the deck loader reads the
+    key with its units and refuses a Teq that is an equation of time"""
+    import ddcmd_amd
+    from ddcmd_amd.deck import units_convert, load_deck
+    s = ddcmd_amd.make_water_setup(4)
+    s.group_type = np.array([2], np.int32)
+    s.group_Teq = np.array([0.0])
+    tau = units_convert(0.2, "ps")
+    s.group_tau = np.array([tau])
+    vc = np.array([1.0e-4, 2.0e-4, -3.0e-4])
+    s.group_vcm = vc.copy()
+    s.excludePotentialTerm = 128 | 1 | 2 | 4 | 8        # no forces at all
+    o = pyoracle.Oracle(s)
+    o.forces()
+    v0 = np.stack([o.vx.copy(), o.vy.copy(), o.vz.copy()])
+    o.step(7)
+    a2 = np.exp(-float(s.dt) / tau)
+    want = vc[:, None] + a2 ** 7 * (v0 - vc[:, None])
+    got = np.stack([o.vx, o.vy, o.vz])
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "water_deck", "object.data")
+    x = "group GROUP { type = LANGEVIN; Teq = 310 K; tau = 1 ps; vcm = 0.001 0 -0.002 Angstrom/fs; }"
+    d = load_deck(deck, extra_objects=x)
+    g = list(d.group_name).index("group")
+    assert np.allclose(d.group_vcm[3 * g:3 * g + 3], np.array([0.001, 0.0, -0.002]) * units_convert(1.0, "Angstrom/fs"), rtol=1e-12)
+    with pytest.raises(Exception, match="not a constant temperature"):
+        load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = 300+10*t; tau = 1 ps; }")
