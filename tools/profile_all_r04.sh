@@ -1,12 +1,12 @@
 #!/bin/bash
 # the round's evidence for the four workloads of the bench line + the rebuild timelines, one box:
-#   gpurun --timeout 2400 -- 'bash tools/profile_all_r03.sh'
+#   gpurun --timeout 2400 -- 'bash tools/profile_all_r04.sh'
 set -u
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-bash tools/profile_r03.sh 4m --no-also --steps 100 --warmup 20 > gpurun_out/prof_4m.txt 2>&1
-bash tools/profile_r03.sh 1m --no-also --lattice 64 --steps 100 --warmup 20 > gpurun_out/prof_1m.txt 2>&1
-bash tools/profile_r03.sh lipid --no-also --workload lipid --steps 100 --warmup 20 > gpurun_out/prof_lipid.txt 2>&1
-bash tools/profile_r03.sh brick --no-also --lattice 50 --rccl-loopback --steps 100 --warmup 20 > gpurun_out/prof_brick.txt 2>&1
+bash tools/profile_r04.sh 4m --no-also --steps 100 --warmup 20 > gpurun_out/prof_4m.txt 2>&1
+bash tools/profile_r04.sh 1m --no-also --lattice 64 --steps 100 --warmup 20 > gpurun_out/prof_1m.txt 2>&1
+bash tools/profile_r04.sh lipid --no-also --workload lipid --steps 100 --warmup 20 > gpurun_out/prof_lipid.txt 2>&1
+bash tools/profile_r04.sh brick --no-also --lattice 50 --rccl-loopback --steps 100 --warmup 20 > gpurun_out/prof_brick.txt 2>&1
 bash tools/timeline.sh 4m --steps 40 --warmup 20 > /dev/null 2>&1
 bash tools/timeline.sh lipid --workload lipid --steps 40 --warmup 20 > /dev/null 2>&1
 bash tools/timeline.sh brick --lattice 50 --rccl-loopback --steps 40 --warmup 20 > /dev/null 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's rocprofv3 evidence for ONE bench invocation, every capture a run of its own (kernel trace, then each --pmc set):
-#   gpurun --timeout 900 -- 'bash tools/profile_r03.sh <tag> <bench args...>'
-# -> gpurun_out/prof_<tag>/{kernel_stats.csv, bench.log, traffic.json}; copy what is to be judged into profiles/r03_<tag>_*.
+#   gpurun --timeout 900 -- 'bash tools/profile_r04.sh <tag> <bench args...>'
+# -> gpurun_out/prof_<tag>/{kernel_stats.csv, bench.log, traffic.json}; copy what is to be judged into profiles/r04_<tag>_*.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 tag=$1; shift
@@ -23,7 +23,7 @@ cd "$root"
 python3 - "$out" <<'PY'
 import csv, glob, json, os, sys, collections
 out = sys.argv[1]
-res = {"method": "tools/profile_r03.sh: rocprofv3 --kernel-trace --stats (one run), a plain run, then --pmc FETCH_SIZE, --pmc WRITE_SIZE and three SQ counter "
+res = {"method": "tools/profile_r04.sh: rocprofv3 --kernel-trace --stats (one run), a plain run, then --pmc FETCH_SIZE, --pmc WRITE_SIZE and three SQ counter "
                  "sets in separate 4-step runs; means over the launches of each kernel",
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
        "gfx950_correction": "MI355X_MICROARCH.md, HBM: FETCH_SIZE reports exactly 1/2 of the bytes of wide coalesced streaming reads on gfx950 -> doubled; WRITE_SIZE as is"}
