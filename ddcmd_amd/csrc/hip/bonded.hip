@@ -238,25 +238,40 @@ struct GatherRows
    int nlight; const int *latoms;        /* atoms with bonds or func 2/10 angles, caller order: a molecule's atoms are neighbouring lanes */
 };
 template <bool HEAVY>      /* false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers) */
-__global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, BoxArgs box, int excl_mask,
+__global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, int ntot, BoxArgs box, int excl_mask,
                                                        const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double *partials)
 {
    /* lane = entry of the list of atoms that have terms of this launch, in caller order: the lanes of a
     * molecule sit together, so their rows are read with unit stride and the partners' bead records are the
-    * neighbouring lanes' own */
+    * neighbouring lanes' own -- taken from there (round 4): every lane leaves its own record in LDS, and a partner that is one of
+    * the workgroup's atoms (for a molecule in the middle of the block: all of them) is read from LDS instead of through a slot
+    * look-up and a scattered 32-byte gather each (five record gathers per bead became one: the light launch of the 2 M-bead
+    * bilayer moved 0.35 GB in 32-byte pieces) */
+   __shared__ double4 s_rec[256];
+   __shared__ int s_atom[256];
    const int j = blockIdx.x * 256 + threadIdx.x;
    double acc[GB_NV];
 #pragma unroll
    for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
-   int i = j, o = gr.nrow;
+   int i = 0x7fffffff, o = gr.nrow;
    if (j < (HEAVY ? gr.nheavy : gr.nlight)) { o = HEAVY ? gr.hatoms[j] : gr.latoms[j]; i = slot[o]; }
-   if (o < gr.nrow && i < nown)
+   const bool here = o < gr.nrow && (unsigned)i < (unsigned)ntot;      /* owned, or a halo copy on this rank */
+   const double4 me = here ? pos[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+   s_atom[threadIdx.x] = here ? o : -1;
+   s_rec[threadIdx.x] = me;
+   __syncthreads();
+   auto rec = [&](const int pa) -> double4
+   {
+      const int t = (int)threadIdx.x + (pa - o);
+      if ((unsigned)t < 256u && s_atom[t] == pa) return s_rec[t];
+      return pos[slot[pa]];
+   };
+   if (here && i < nown)
    {
       const int b0 = HEAVY ? 0 : gr.boff[o], b1 = HEAVY ? 0 : gr.boff[o + 1], a0 = HEAVY ? gr.haoff[o] : gr.aoff[o], a1 = HEAVY ? gr.haoff[o + 1] : gr.aoff[o + 1];
       const int t0 = HEAVY ? gr.toff[o] : 0, t1 = HEAVY ? gr.toff[o + 1] : 0;
       if (b1 + a1 + t1 > b0 + a0 + t0)
       {
-         const double4 me = pos[i];
          double fxi = 0, fyi = 0, fzi = 0;
          /* three loops, each of one kind: the lanes of a wave run the same code in every trip */
          /* the row and the partner's slot of the NEXT trip are fetched while this trip's bead record is in
@@ -264,12 +279,11 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          if (!HEAVY && b1 > b0)
          {
          int2 row_n = gr.brow[b0];
-         int s_n = slot[row_n.x];
          for (int r = b0; r < b1; r++)
          {
             const int2 row = row_n;
-            const double4 q = pos[s_n];
-            if (r + 1 < b1) { row_n = gr.brow[r + 1]; s_n = slot[row_n.x]; }
+            const double4 q = rec(row.x);
+            if (r + 1 < b1) row_n = gr.brow[r + 1];
             const int role = row.y & 3;
             const double2 par = gr.bpar[row.y >> 2];
             double e, fD[3], vir[6];
@@ -288,12 +302,11 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          {
          const int4 *arows = HEAVY ? gr.harow : gr.arow;
          int4 arow_n = arows[a0];
-         int s1_n = slot[arow_n.x], s2_n = slot[arow_n.y];
          for (int r = a0; r < a1; r++)
          {
             const int4 row = arow_n;
-            const double4 q1 = pos[s1_n], q2 = pos[s2_n];
-            if (r + 1 < a1) { arow_n = arows[r + 1]; s1_n = slot[arow_n.x]; s2_n = slot[arow_n.y]; }
+            const double4 q1 = rec(row.x), q2 = rec(row.y);
+            if (r + 1 < a1) arow_n = arows[r + 1];
             const int role = row.z & 3;
             const double4 par = gr.apar[row.z >> 2];
             double e, fI[3], fK[3], vir[6];
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
             const int4 row = gr.trow[r];
             const int role = row.w & 3;
             const double4 par = gr.tpar[row.w >> 2];
-            const double4 q1 = pos[slot[row.x]], q2 = pos[slot[row.y]], q3 = pos[slot[row.z]];
+            const double4 q1 = rec(row.x), q2 = rec(row.y), q3 = rec(row.z);
             double et, ei, fI[3], fJ[3], fK[3], fL[3], vir[6];
             if (tors_eval(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role <= 1 ? q2 : (role == 2 ? me : q3), role == 3 ? me : q3,
                           (int)par.z, (int)par.w, par.x, par.y, excl_mask, et, ei, fI, fJ, fK, fL, vir))
@@ -737,10 +750,10 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    GatherRows gr = gather_rows(ctx);
    double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
    if (nblk > 0)
-      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, box, ctx->excludePotentialTerm,
+      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->bpartials.p);
    if (nblk2 > 0)
-      hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, box, ctx->excludePotentialTerm,
+      hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, p2);
    hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
    return DDCMI_OK;
