@@ -106,8 +106,10 @@ def kernel_source_id():
     """short hash of the device sources: a PMC file under profiles/ is quoted only for the kernels it measured"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ddcmi.hip", "ddcmi_internal.h", "ddcmi_multigpu.inl"):
-        h.update(open(os.path.join(ROOT, "ddcmd_amd", "csrc", "hip", f), "rb").read())
+    d = os.path.join(ROOT, "ddcmd_amd", "csrc", "hip")
+    for f in sorted(os.listdir(d)):      # ddcmi.hip and the .inl parts it includes, the shared header, scan.hip, bonded.hip
+        if f.endswith((".hip", ".inl", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -1,0 +1,539 @@
+/* ddcmi_rebuild.inl -- host side of a list rebuild: grid, sort, periodic images, tile schedule, ddcmi_bl_finish.
+ * Part of the ONE translation unit ddcmi.hip (kernels, templates and the static helpers they share), included there in this order. */
+/* ------------------------------------------------------------------------- */
+static int setup_grid(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   double rlist = ctx->rmax + ctx->deltaR;
+   gp.rlist = rlist;
+   gp.pbc = ctx->pbc;
+   double L[3] = {ctx->h[0], ctx->h[4], ctx->h[8]};
+   long ncell = 1;
+   for (int a = 0; a < 3; a++)
+   {
+      gp.L[a] = L[a];
+      bool periodic = (ctx->pbc >> a) & 1;
+      int P = ctx->pgrid[a];
+      double W = L[a] / P;                       /* brick width of this rank */
+      if (periodic && L[a] < 2.0 * rlist)
+         SETERR(ctx, DDCMI_EUNSUPPORTED, "box length %g on axis %d is shorter than 2*(rmax+deltaR)=%g: the nearest-image convention the reference relies on breaks down", L[a], a, 2.0 * rlist);
+      if (P > 1 && W < rlist)
+         SETERR(ctx, DDCMI_EUNSUPPORTED, "domain width %g on axis %d is smaller than rmax+deltaR=%g: halo would reach beyond nearest-neighbour domains", W, a, rlist);
+      gp.lo[a] = -0.5 * L[a] + ctx->pcoord[a] * W;
+      double cmin = 0.5 * rlist;
+      int n = (int)floor(W / cmin);
+      if (n < 1) n = 1;
+      {
+         /* a last tile of the axis that would hold less than half of its cells is folded away when that costs at most 2 % of
+          * cell width (4 M-bead water: 101 -> 100 cells on the 4-cell axes: no layer of quarter-filled tiles, 7 % fewer workgroups) */
+         const int tdim0[3] = {TCX, TCY, TCZ};
+         const int r = n % tdim0[a];
+         if (r > 0 && 2 * r <= tdim0[a] && n - r >= tdim0[a] && (double)n / (double)(n - r) <= 1.02) n -= r;
+      }
+      gp.n[a] = n;
+      gp.cinv[a] = (double)n / W;
+      const int tdim[3] = {TCX, TCY, TCZ};
+      gp.m[a] = (periodic || P > 1) ? tdim[a] : 0;      /* one whole tile of margin: interior tiles hold owned beads only */
+      gp.g[a] = n + 2 * gp.m[a];
+      gp.T[a] = (gp.g[a] + tdim[a] - 1) / tdim[a];
+      ncell *= gp.T[a] * tdim[a];
+   }
+   if (ncell > 2000000000L) SETERR(ctx, DDCMI_EUNSUPPORTED, "cell grid too large");
+   gp.ncell = (int)ncell;
+   return DDCMI_OK;
+}
+
+/* rebuild phase 1: wrap into the box, cell ids, counting sort of the owned beads */
+int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
+{
+   int rc = setup_grid(ctx);
+   if (rc) return rc;
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, nb = cdiv(n, 256), ncell = gp.ncell, ncb = cdiv(ncell, 256);
+   dbuf<int> *cb[] = {&ctx->cell_cnt_o, &ctx->cell_start_o, &ctx->cell_cnt_h, &ctx->cell_start_h, &ctx->cell_start, &ctx->cell_cnt};
+   for (auto b : cb) ENSURE(ctx, *b, ncell + 2);
+   /* the counters of the whole rebuild: cell counts, the capacity flags and totals of k_tile_build -- left zeroed by the last rebuild's
+    * tail launch (k_rebuild_tail) unless this is the first rebuild, the grid changed, or a rebuild is being started over */
+   {
+      const bool clean = ctx->counters_clean && ctx->clean_ncell == ncell && ctx->clean_po == ctx->cell_cnt_o.p && ctx->clean_ph == ctx->cell_cnt_h.p;
+      ctx->counters_clean = false;
+      if (!clean)
+         ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1)
+                                     .add(ctx->d_flags + 32, 2));
+   }
+   if (n > 0)
+   {
+      /* (decomposed runs: the "beads are not numbers" flag also rides in slot 30 of the direction counters, so that the halo count
+       * round of this rebuild tells every rank) */
+      hipLaunchKernelGGL(k_wrap_cell, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->cid.p, ctx->crank.p, ctx->cell_cnt_o.p, ctx->d_flags + 12,
+                         ((ctx->nranks > 1 || ctx->loopback) && ctx->dir_cnt.cap >= 32) ? ctx->dir_cnt.p + 30 : (int *)nullptr,
+                         ctx->sort_renumbers ? ctx->orig.p : (int *)nullptr, ctx->sort_renumbers ? ctx->dir_cnt.p : (int *)nullptr);
+      ctx->dir28_clean = ctx->sort_renumbers;
+   }
+   ctx->sort_renumbers = false;
+   if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ncell + 1, nullptr))) return rc;     /* [ncell] = nloc */
+   if (n > 0)
+   {
+      hipLaunchKernelGGL(k_scatter_order, dim3(nb), dim3(256), 0, st, n, ctx->cid.p, ctx->crank.p, ctx->cell_start_o.p, ctx->order.p);
+      if (ctx->nranks > 1 || ctx->loopback || ctx->group_)      /* migrants arrive in message order: sort by gid, so that a run repeats bit for bit */
+         hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p, ctx->gid.p, (const int *)nullptr);
+      else
+         hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_o.p, ctx->cell_cnt_o.p, ctx->order.p);
+      /* caller index -> slot: a scattered store per bead, kept up only where something reads it every step */
+      if (ctx->lcg_on) ENSURE(ctx, ctx->lcg2, (size_t)n + 1);
+      const bool slots = (!ctx->bonded_gid && ctx->inc_nrow > 0) || (!ctx->cons_gid && ctx->ncgroup > 0) || (!ctx->mol_gid && ctx->nmol_multi > 0);
+      hipLaunchKernelGGL(k_gather_state, dim3(nb), dim3(256), 0, st, n, ctx->order.p, ctx->pos.p, ctx->vx.p, ctx->vy.p, ctx->vz.p,
+                         ctx->species.p, ctx->group.p, ctx->gid.p, ctx->orig.p,
+                         ctx->pos2.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->species2.p, ctx->group2.p, ctx->gid2.p, ctx->orig2.p,
+                         slots ? ctx->slot_of_orig.p : (int *)nullptr,
+                         gp, (ctx->nranks == 1 && !ctx->loopback && !ctx->group_) ? ctx->nimg.p : (int *)nullptr, 1,
+                         ctx->lcg_on ? ctx->lcg.p : (const ulonglong2 *)nullptr, ctx->lcg2.p);
+      if (ctx->lcg_on) std::swap(ctx->lcg, ctx->lcg2);
+      ctx->slot_valid = slots;
+      std::swap(ctx->pos, ctx->pos2); std::swap(ctx->vx, ctx->vx2); std::swap(ctx->vy, ctx->vy2); std::swap(ctx->vz, ctx->vz2);
+      std::swap(ctx->species, ctx->species2); std::swap(ctx->group, ctx->group2); std::swap(ctx->gid, ctx->gid2); std::swap(ctx->orig, ctx->orig2);
+   }
+   return DDCMI_OK;
+}
+
+/* make room for nh image/halo beads behind the owned ones */
+int ddcmi_bl_reserve_halo(ddcmi_ctx *ctx, int nh)
+{
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc;
+   dbuf<int> *hb[] = {&ctx->hsrc_t, &ctx->hshift_t, &ctx->hcid, &ctx->hrank, &ctx->horder, &ctx->halo_src, &ctx->halo_shift};
+   for (auto b : hb) ENSURE(ctx, *b, nh + 1);
+   if (ctx->cons_gid && ctx->ncgroup > 0 && (size_t)(n + nh) > ctx->vx.cap)      /* the velocity halo of the constraint solves */
+      if (ctx->vx.ensure(n + nh, true, st) || ctx->vy.ensure(n + nh, true, st) || ctx->vz.ensure(n + nh, true, st))
+         SETERR(ctx, DDCMI_ENOMEM, "growing velocity arrays for %d halo beads failed", nh);
+   if ((size_t)(n + nh) > ctx->pos.cap)
+   {
+      if (ctx->pos.ensure(n + nh, true, st) || ctx->pos2.ensure(n + nh) || ctx->gid.ensure(n + nh, true, st) || ctx->gid2.ensure(n + nh))
+         SETERR(ctx, DDCMI_ENOMEM, "growing particle arrays for %d image atoms failed", nh);
+   }
+   return DDCMI_OK;
+}
+
+/* rebuild phase 2 (single domain): periodic self-images */
+static int bl_self_images(ddcmi_ctx *ctx)
+{
+   ctx->hkey_valid = false;      /* self-images are laid out by a scan over the owned beads: already independent of timing */
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, nb = cdiv(n, 256), rc;
+   /* (nimg was counted by k_gather_state) */
+   if ((rc = ddcmi_scan_exclusive(ctx, ctx->nimg.p, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
+   ctx->nhalo_dev = nullptr;
+   int nh;
+   if (ctx->nhalo_hint > 0 && !ctx->no_image_hint)
+   {
+      /* The image count moves by a fraction of a per cent between rebuilds: the kernels that lay the images out are launched for a bound
+       * taken from the last rebuild and read the count on the device; the host learns it with the build's other results (ddcmi_bl_finish)
+       * instead of waiting for it here -- one host round trip less per rebuild.  A count beyond the bound starts the rebuild over. */
+      nh = ctx->nhalo_hint + ctx->nhalo_hint / 32 + 1024;
+      if (ctx->debug_image_bound > 0) nh = std::min(nh, ctx->debug_image_bound);      /* (tests, DDCMI_DEBUG_HOOKS=1 only: force the start-over path) */
+      ctx->nhalo_dev = ctx->d_flags + 8;
+   }
+   else
+   {
+      PostJobs pj;
+      pj.add(ctx->d_flags + 8, 1);
+      if ((rc = ddcmi_post(ctx, st, pj)) || (rc = ddcmi_post_wait(ctx, st))) return rc;
+      nh = ctx->mbox_h[pj.off[0]];
+   }
+   ctx->nhalo = nh;
+   if (nh > 0)
+   {
+      if ((rc = ddcmi_bl_reserve_halo(ctx, nh))) return rc;
+      hipLaunchKernelGGL(k_fill_images, dim3(nb), dim3(256), 0, st, gp, n, ctx->pos.p, ctx->img_off.p, ctx->nimg.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->hcid.p, ctx->hrank.p, ctx->cell_cnt_h.p, nh);
+   }
+   return DDCMI_OK;
+}
+
+/* rebuild phase 3: sort the halo descriptors by cell, place the halo beads */
+int ddcmi_bl_halo_sort(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc, nh = ctx->nhalo, ncell = gp.ncell, ncb = cdiv(ncell, 256), rc;
+   if (nh > 0)
+   {
+      int nhb = cdiv(nh, 256);
+      if ((rc = ddcmi_scan_exclusive(ctx, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ncell, nullptr))) return rc;
+      hipLaunchKernelGGL(k_scatter_order, dim3(nhb), dim3(256), 0, st, nh, ctx->hcid.p, ctx->hrank.p, ctx->cell_start_h.p, ctx->horder.p, (const int *)ctx->nhalo_dev);
+      if (ctx->hkey_valid)      /* decomposed runs: halo descriptors arrive in the order atomics filled the send lists */
+         hipLaunchKernelGGL(k_sort_cells_key, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p, ctx->hkey.p, ctx->hshift_t.p);
+      else
+         hipLaunchKernelGGL(k_sort_cells, dim3(ncb), dim3(256), 0, st, ncell, ctx->cell_start_h.p, ctx->cell_cnt_h.p, ctx->horder.p);
+      /* the sorted descriptors and the beads they place, in one launch (a gather launch and an update launch before) */
+      hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, (const int *)nullptr, (const int *)nullptr, gp.L[0], gp.L[1], gp.L[2], ctx->pos.p, ctx->gid.p, true,
+                         ctx->hrecv3.p, ctx->hrecv5.p, (const int *)ctx->nhalo_dev, (unsigned long long *)nullptr, 0,
+                         ctx->horder.p, ctx->hsrc_t.p, ctx->hshift_t.p, ctx->halo_src.p, ctx->halo_shift.p);
+   }
+   else HIPCHK(ctx, hipMemsetAsync(ctx->cell_start_h.p, 0, ncell * sizeof(int), st));
+   hipLaunchKernelGGL(k_merge_cells, dim3(ncb), dim3(256), 0, st, ncell, n, ctx->cell_cnt_o.p, ctx->cell_start_o.p, ctx->cell_cnt_h.p, ctx->cell_start_h.p, ctx->cell_start.p, ctx->cell_cnt.p);
+   return DDCMI_OK;
+}
+
+int ddcmi_ensure_slots(ddcmi_ctx *ctx)
+{
+   if (ctx->slot_valid || ctx->nloc <= 0) return DDCMI_OK;
+   hipLaunchKernelGGL(k_slots_from_orig, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, ctx->stream, ctx->nloc, ctx->orig.p, ctx->slot_of_orig.p);
+   ctx->slot_valid = true;
+   return DDCMI_OK;
+}
+
+extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
+{
+   if (!ctx) return DDCMI_EINVAL;
+   if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate < 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
+      SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
+   (void)hipSetDevice(ctx->device);
+   int rc;
+   ctx->pack_fresh = false;      /* (the rebuild's own exchange reuses the send buffer) */
+   if ((rc = nb_tables(ctx))) return rc;
+   if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
+   ctx->phase(-1, nullptr);
+   for (int pass = 0;; pass++)
+   {
+      if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;      /* (idempotent: a second pass sorts sorted beads) */
+      ctx->phase(0, "sort_owned launched");
+      if ((rc = bl_self_images(ctx))) return rc;
+      ctx->phase(1, "self_images (sync)");
+      if ((rc = ddcmi_bl_halo_sort(ctx))) return rc;
+      rc = ddcmi_bl_finish(ctx);
+      if (rc == DDCMI_RETRY_IMAGES && pass == 0) continue;      /* more periodic images than the last rebuild's count allowed for */
+      if (rc) return rc;
+      break;
+   }
+   ctx->nhalo_hint = ctx->nhalo;
+   ctx->phase(14, "localize");
+   return ddcmi_mol_split_finish(ctx);      /* one domain: no molecule is split */
+}
+
+/* Tile order and XCD ranges of k_nonbond, on the host from the per-tile cost estimates
+ * (ntile ints read back with the rebuild's other flags).  The hardware deals workgroups
+ * round-robin over the 8 XCDs; workgroup b takes the (b>>3)-th tile of range b&7, a
+ * contiguous run of perm[] with 1/8 of the class's estimated work -- equal COUNTS would
+ * leave the XCDs that own the thin edge tiles idle at the end of a launch.  Decomposed runs
+ * can order the tiles in two classes, each with its own ranges: tiles whose neighbourhood is
+ * all owned beads run while the halo exchange is in flight, the others after it
+ * (DDCMI_HALO_OVERLAP=1; off by default: on one GPU through the RCCL loopback the split costs
+ * more -- two launch tails, the exchange competing for the CUs -- than the 40 us it hides). */
+static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
+{
+   /* the tile costs came to the host with the build's flags (ddcmi_bl_finish), in pinned memory; the order
+    * and the ranges leave from pinned memory too, so this function costs no host round trip of its own */
+   const int ntile = ctx->ntile;
+   const int *work = ctx->h_pin[0], *stage = work ? work + ntile : nullptr;
+   const size_t cap_items = (size_t)ntile + 16 * 1024 + 64;      /* every tile once + the parts the tails may add: 8 XCD runs x 2 classes, at most 1024 items each */
+   int *perm = ctx->pinned(1, cap_items + 64), *sched = perm ? perm + cap_items : nullptr;
+   if (!work || !perm) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile schedule");
+   for (int k = 0; k < 32; k++) sched[k] = 0;
+   const bool two = ctx->halo_overlap && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
+   /* tiles without owned beads (the margin tiles, empty space) get no workgroup at all: a workgroup that finds
+    * nothing to do still has to be dispatched with its 72 KB of LDS and eight waves, and at 4 M beads 45 % of the
+    * grid were such workgroups -- the per-CU timeline showed one of the two slots of a CU empty a quarter of the
+    * time. */
+   std::vector<int> live;
+   live.reserve(ntile);
+   int n0 = 0;
+   if (two)
+   {
+      for (int t = 0; t < ntile; t++) if ((work[t] & 0x3fffffff) > 0 && !(work[t] >> 30)) live.push_back(t);
+      n0 = (int)live.size();
+      for (int t = 0; t < ntile; t++) if ((work[t] & 0x3fffffff) > 0 && (work[t] >> 30)) live.push_back(t);
+   }
+   else { for (int t = 0; t < ntile; t++) if ((work[t] & 0x3fffffff) > 0) live.push_back(t); n0 = (int)live.size(); }
+   const int nlive = (int)live.size();
+   auto cost_list = [&](int t) { return (double)(work[t] & 0x3fffffff); };
+   auto cost_stage = [&](int t) { return (double)stage[t]; };
+   /* greedy list scheduling of a range's items on the S workgroup slots of one XCD: the makespan */
+   const int S = std::max(1, wg_per_cu) * 32;
+   static const bool no_split = getenv("DDCMI_NO_TAIL_SPLIT") != nullptr;
+   std::vector<double> heap((size_t)S);
+   auto makespan = [&](const int *tl, int n, int m, int k) -> double
+   {
+      /* the last m tiles are cut into k parts each */
+      std::fill(heap.begin(), heap.end(), 0.0);      /* min-heap of slot finish times */
+      auto push_item = [&](double c)
+      {
+         std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
+         heap.back() += c;
+         std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+      };
+      for (int q = 0; q < n; q++)
+      {
+         const int t = tl[q];
+         if (q < n - m || k == 1) push_item(cost_stage(t) + cost_list(t));
+         else for (int p = 0; p < k; p++) push_item(cost_stage(t) + 1.08 * cost_list(t) / k + 2000.0);
+      }
+      double mx = 0.0;
+      for (double f : heap) mx = std::max(mx, f);
+      return mx;
+   };
+   int nitems = 0;
+   auto split = [&](int lo, int hi, int *out, int *longest)
+   {
+      /* 8 contiguous runs of equal estimated work, one per XCD (equal COUNTS would leave the XCDs that own the
+       * thin edge tiles idle at the end of a launch) */
+      double W = 0, run = 0;
+      for (int q = lo; q < hi; q++) W += cost_list(live[q]) + cost_stage(live[q]);
+      int cut[9];
+      for (int x = 0; x < 9; x++) cut[x] = (x == 8) ? hi : lo;
+      for (int q = lo; q < hi; q++)
+      {
+         double nxt = run + cost_list(live[q]) + cost_stage(live[q]);
+         for (int x = 1; x < 8; x++)
+         {
+            double target = W * x / 8.0;
+            if (run < target && nxt >= target) cut[x] = q + 1;
+         }
+         run = nxt;
+      }
+      for (int x = 1; x < 9; x++) cut[x] = std::max(cut[x], cut[x - 1]);
+      *longest = 0;
+      for (int x = 0; x < 8; x++)
+      {
+         int *tl = live.data() + cut[x];
+         const int n = cut[x + 1] - cut[x];
+         /* few rounds of workgroups per slot: the expensive tiles first, the thin edge tiles fill the end of the launch
+          * (at many rounds the raster order wins: neighbouring tiles share their neighbourhoods in L2) */
+         static const bool no_lpt = getenv("DDCMI_NO_LPT") != nullptr;
+         static const int lpt_rounds = getenv("DDCMI_LPT_ROUNDS") ? atoi(getenv("DDCMI_LPT_ROUNDS")) : 8;
+         if (!no_lpt && n < lpt_rounds * S)
+            std::stable_sort(tl, tl + n, [&](int ta_, int tb_) { return cost_list(ta_) + cost_stage(ta_) > cost_list(tb_) + cost_stage(tb_); });
+         /* the tail: how many of the run's last tiles to cut, and into how many parts, by simulated makespan */
+         int best_m = 0, best_k = 1;
+         /* (only where the last round weighs: with R rounds of workgroups per slot it is worth at most 1/(2R)).
+          * The search simulates a dozen schedules per XCD; tile counts barely move between rebuilds, so its answer
+          * is kept while the run's tile count stays within 3 % of the count it was found for and re-derived every
+          * 64th rebuild. */
+         int *cache = ctx->sched_cache[lo == 0 ? 0 : 1][x];
+         const bool cached = cache[0] > 0 && abs(cache[0] - n) <= 2 + n / 32 && (ctx->nrebuild & 63) != 0;
+         if (cached) { best_m = std::min(cache[1], n); best_k = cache[2]; }
+         else if (!no_split && n > 0 && n < 8 * S)
+         {
+            double best = makespan(tl, n, 0, 1);
+            const int r = n % S;
+            const int cand[] = {r, r + S / 2, r + S, r + 2 * S, n};
+            const int parts[] = {2, 3, 4, 6, 8};
+            for (int m : cand)
+            {
+               if (m <= 0 || m > n) continue;
+               for (int k : parts)
+               {
+                  if ((size_t)m * k > 64 * 8 * 2) continue;
+                  double ms = makespan(tl, n, m, k);
+                  if (ms < 0.985 * best) { best = ms; best_m = m; best_k = k; }
+               }
+            }
+         }
+         if (!cached) { cache[0] = n; cache[1] = best_m; cache[2] = best_k; }
+         if (getenv("DDCMI_DEBUG_SCHED")) fprintf(stderr, "ddcmi sched: xcd %d tiles %d tail %d tiles x %d parts\n", x, n, best_m, best_k);
+         if ((size_t)nitems + (size_t)n + (size_t)best_m * (best_k - 1) > cap_items) { best_m = 0; best_k = 1; }      /* (cannot happen: m k <= 1024 per run) */
+         out[x] = nitems;
+         for (int q = 0; q < n; q++)
+         {
+            if (q < n - best_m) perm[nitems++] = tl[q];
+            else for (int p = 0; p < best_k; p++) perm[nitems++] = tl[q] | (p << 24) | ((best_k - 1) << 27);
+         }
+         *longest = std::max(*longest, nitems - out[x]);
+      }
+      out[8] = nitems;
+   };
+   if (ntile >= (1 << 24)) SETERR(ctx, DDCMI_EUNSUPPORTED, "%d tiles: more than a work item's 24 bits name", ntile);
+   split(0, n0, &sched[0], &ctx->sched_longest[0]);
+   split(n0, nlive, &sched[16], &ctx->sched_longest[1]);
+   ctx->ntile_class[0] = sched[8] - sched[0]; ctx->ntile_class[1] = sched[24] - sched[16];
+   ctx->nitems = nitems;
+   ENSURE(ctx, ctx->tile_perm, cap_items + 1);
+   ENSURE(ctx, ctx->sched, 32);
+   ENSURE(ctx, ctx->partials, (size_t)(nitems + 8) * 8);
+   {
+      /* the tile order and the ranges, the displacement words of the shell-limited walk back to zero, and the NEXT rebuild's counters
+       * cleared while nothing reads them (ddcmi_bl_sort_owned, mg_phase1_launch): one launch */
+      TailJobs tj;
+      tj.fetch(ctx->tile_perm.p, perm, std::max(nitems, 1)).fetch(ctx->sched.p, sched, 32);
+      const int ncell = ctx->gp.ncell;
+      tj.zero.add(ctx->d_results + R_DISP, 6);      /* three doubles */
+      tj.zero.add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1).add(ctx->d_flags + 32, 2);
+      tj.zero.add(ctx->d_flags + DDCMI_FLAG_AGREE, 2);
+      const bool dirs = ctx->dir_cnt.p != nullptr && ctx->dir_cnt.cap >= 32;
+      if (dirs) tj.zero.add(ctx->dir_cnt.p, 32);
+      int rcf = ddcmi_rebuild_tail(ctx, ctx->stream, tj);
+      if (rcf) return rcf;
+      ctx->counters_clean = true; ctx->clean_ncell = ncell; ctx->clean_po = ctx->cell_cnt_o.p; ctx->clean_ph = ctx->cell_cnt_h.p;
+      ctx->dircnt_clean = dirs;
+   }
+   return DDCMI_OK;       /* the pinned buffers are rewritten at the next rebuild, behind its own synchronisation */
+}
+
+/* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
+static void graph_drop(ddcmi_ctx *ctx);
+int ddcmi_bl_finish(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc;
+   ctx->phase(10, "-> bl_finish");
+   graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
+   ctx->f_zero = false;  /* (the beads have new slots, a decomposed rank a new number of them) */
+   /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
+   ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
+   int ntile = gp.T[0] * gp.T[1] * gp.T[2];
+   ctx->ntile = ntile;
+   double vol = gp.L[0] * gp.L[1] * gp.L[2] / (double)ctx->nranks;
+   double dens = (double)std::max(n, 1) / vol;
+   if (ctx->stage_cap == 0)
+   {
+      double per_cell = dens / (gp.cinv[0] * gp.cinv[1] * gp.cinv[2]);
+      ctx->stage_cap = (((int)((double)NRC * per_cell * 1.05) + 48) + 63) & ~63;
+      if (ctx->stage_cap < 384) ctx->stage_cap = 384;      /* k_nonbond's cell tables alias the 24 B per bead position arrays */
+      ctx->maxexcl = 1;
+      for (int m = 0; m < ctx->nmoltype; m++) if (ctx->mol_nspecies[m] > 1) ctx->maxexcl = 16;
+   }
+   if (ctx->arena_cap == 0)
+   {
+      double expect = 4.0 / 3.0 * M_PI * gp.rlist * gp.rlist * gp.rlist * dens;
+      ctx->tmpw = ((int)(expect * 1.25) + 24 + 7) & ~7;
+      if (ctx->tmpw > 768) ctx->tmpw = 768;          /* k_tile_transpose keeps a row in the registers of eight lanes: at most 24 quads each */
+      ctx->arena_cap = (unsigned long long)((double)n * (expect * 1.45 + 32.0)) + 65536ull;
+   }
+   ENSURE(ctx, ctx->nbr_cnt, ctx->npad); ENSURE(ctx, ctx->excl_cnt, ctx->npad); ENSURE(ctx, ctx->nbr_cum, ctx->npad);
+   ENSURE(ctx, ctx->tile_nstage, ntile + 1); ENSURE(ctx, ctx->tile_width, ntile + 1); ENSURE(ctx, ctx->tile_rows, ntile + 1);
+   ENSURE(ctx, ctx->tile_work, 5 * (size_t)ntile + 2);
+   if (ctx->tile_base.ensure(ntile + 1)) SETERR(ctx, DDCMI_ENOMEM, "tile table allocation failed");
+   double rcut = ctx->rmax, dR = ctx->deltaR;
+   /* distance shells of the list order: entries a wave rejects as a whole come last.  Shell 0: r < rcut - dR/4; shells
+    * 1..NSHELL-1: equal steps of r^2 from there to the list radius (0.7 A wide at the cut-off for the Martini numbers; the
+    * last one, beyond rcut + 0.85 dR, holds what no drift brings inside the cut-off) */
+   ShellCuts shc;
+   {
+      const double r0 = rcut - 0.25 * dR;
+      shc.r0sq = (float)(r0 * r0); shc.one = !(dR > 1e-9 * rcut);      /* no skin: one shell */
+   }
+   unsigned long long *d_arena = (unsigned long long *)(ctx->d_flags + 32);    /* arena entries handed out: the one device-wide counter of the build, on a cache line of its own */
+   for (int attempt = 0;; attempt++)
+   {
+      if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
+      bool has_mol = false;
+      for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
+      /* LDS image: 16 B per staged bead (+ 4 B molecule id when pairs can be excluded) + the region cell tables */
+      /* LDS image: the ring of accepted words (16 KB), 16 B per staged bead (+ 2 B of molecule id when pairs can be excluded), the region cell tables */
+      size_t lds = TB_RING_BYTES + (size_t)ctx->stage_cap * (has_mol ? 18 : 16) + (2 * NRC + 16 + 2 * (TB_THREADS / 64) + 8) * sizeof(int) + 16;
+      if ((size_t)ctx->stage_cap * sizeof(unsigned short) > TB_RING_BYTES) lds += (size_t)ctx->stage_cap * sizeof(unsigned short);      /* (bare 16-bit entries: the slot -> cell map outgrows the ring) */
+      if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
+      ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
+      if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
+      if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
+      if (attempt > 0) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_arena, 2));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
+      ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
+      TileArgs ta;
+      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
+      ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
+      ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
+      ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
+      ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_arena;
+      ta.nbr_cnt = ctx->nbr_cnt.p; ta.nbr_cum = ctx->nbr_cum.p;
+      if (ctx->tmp32.ensure(((size_t)ctx->npad + (size_t)TB_CHUNK * (ntile + 1)) * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");      /* every tile rounded up to whole chunks */
+      ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
+      if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
+      ta.tile_nib = ctx->tile_nib.p;
+      ctx->phase(17, "bl_finish: buffers");
+      auto kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
+                            : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
+      HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)kbuild, (int)lds));
+      hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
+                         ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
+                         ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags);
+      /* everything the host decides on (capacity flags, totals, the tiles' cost estimates) is final when k_tile_build
+       * ends: it travels behind an event, and the host reads it -- and orders the tiles -- while k_tile_transpose runs */
+      ctx->phase(18, "bl_finish: build launch");
+      unsigned long long tot[3];
+      int *h_work = ctx->pinned(0, 5 * (size_t)ntile + 8);      /* per tile: list cost, staging cost, entries, excluded entries, width */
+      if (!h_work) SETERR(ctx, DDCMI_ENOMEM, "pinned staging for the tile costs");
+      PostJobs pj;
+      pj.add(ctx->d_flags, 64).add(ctx->tile_work.p, 5 * (size_t)ntile);      /* flags + the tiles' costs and totals: one post, read while the transposition runs */
+      /* (on a stream of its own behind the build: its trip over the host link no longer stands between the build and the transposition) */
+      if (!ctx->stream_post) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream_post, hipStreamNonBlocking));
+      if (!ctx->ev_build) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_build, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_build, st));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_post, ctx->ev_build, 0));
+      { int rcp = ddcmi_post(ctx, ctx->stream_post, pj); if (rcp) return rcp; }
+      {
+         const bool scr16 = ctx->pack_type != 0;
+         const size_t lds2 = (size_t)(TR_THREADS / 64) * ctx->tmpw * TR_S * sizeof(unsigned short) + (scr16 ? (size_t)ctx->stage_cap + 16 : 0);
+         auto ktr = scr16 ? (ctx->tmpw <= 192 ? k_tile_transpose<3, true> : ctx->tmpw <= 384 ? k_tile_transpose<6, true> : k_tile_transpose<12, true>)
+                          : (ctx->tmpw <= 192 ? k_tile_transpose<6, false> : ctx->tmpw <= 384 ? k_tile_transpose<12, false> : k_tile_transpose<24, false>);
+         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)ktr, (int)lds2));
+         hipLaunchKernelGGL(ktr, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
+      }
+      HIPCHK(ctx, hipGetLastError());
+      ctx->phase(11, "build+transpose launched");
+      { int rcp = ddcmi_post_wait(ctx, ctx->stream_post); if (rcp) return rcp; }
+      memcpy(ctx->h_flags, ctx->mbox_h + pj.off[0], 64 * sizeof(int));
+      if (ctx->nhalo_dev)
+      {
+         /* the image count the rebuild was launched without (bl_self_images) */
+         const int nh_true = ctx->h_flags[8], bound = ctx->nhalo;
+         ctx->nhalo_dev = nullptr;
+         if (nh_true > bound)
+         {
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            ctx->nhalo_hint = 0;
+            return DDCMI_RETRY_IMAGES;      /* (ddcmi_build_list starts over, waiting for the count this time) */
+         }
+         ctx->nhalo = nh_true;
+      }
+      memcpy(h_work, ctx->mbox_h + pj.off[1], 5 * (size_t)ntile * sizeof(int));
+      ctx->phase(12, "wait for the build");
+      tot[0] = tot[1] = 0;
+      int maxw = 0;
+      for (int t = 0; t < ntile; t++) { tot[0] += (unsigned)h_work[2 * (size_t)ntile + t]; tot[1] += (unsigned)h_work[3 * (size_t)ntile + t]; maxw = std::max(maxw, h_work[4 * (size_t)ntile + t]); }
+      memcpy(&tot[2], ctx->h_flags + 32, sizeof(unsigned long long));
+      if (ctx->h_flags[12] > 0)
+         SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)", ctx->h_flags[12], (long long)ctx->loop);
+      bool again = false;
+      if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.05) + 32) + 63) & ~63; again = true; }
+      if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }
+      if (ctx->h_flags[1] > 0) { ctx->maxexcl = ctx->h_flags[1] + 4; again = true; }
+      if (ctx->h_flags[5] > 0) { ctx->tmpw = ((int)(ctx->h_flags[5] * 1.1) + 8 + 7) & ~7; again = true; }
+      if (ctx->tmpw > 768) SETERR(ctx, DDCMI_EUNSUPPORTED, "neighbour lists of more than 768 entries per bead (list radius %g) are not supported", gp.rlist);
+      if (again) HIPCHK(ctx, hipStreamSynchronize(st));      /* the transposition still runs on buffers the next attempt may grow */
+      if (!again)
+      {
+         ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
+         ctx->maxnbr = maxw;
+         break;
+      }
+   }
+   {
+      /* workgroups of k_nonbond a CU holds: its LDS image of a neighbourhood (launch_forces), at most two by registers */
+      const size_t capl = (size_t)ctx->stage_cap + 2;
+      const size_t lds_nb = (capl * 16 <= NB_ZOFF ? NB_ZOFF + capl * 8 : capl * 24) + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
+      int rcs = schedule_tiles(ctx, (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_nb, 1))));
+      if (rcs) return rcs;
+   }
+   if (ctx->updateRate == 0)
+   {
+      /* neighborRef (neighbor.c:209-246): remember where every owned bead was */
+      if (ctx->pos0.ensure((size_t)std::max(n, 1))) SETERR(ctx, DDCMI_ENOMEM, "reference positions");
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pos0.p, ctx->pos.p, (size_t)n * sizeof(double4), hipMemcpyDeviceToDevice, st));
+   }
+   if (ctx->nrebuild == 0 && getenv("DDCMI_DEBUG_SCHED")) fprintf(stderr, "ddcmi build: stage_cap %d tmpw %d maxexcl %d pack_type %d tiles %d\n", ctx->stage_cap, ctx->tmpw, ctx->maxexcl, ctx->pack_type, ctx->ntile);
+   ctx->phase(13, "schedule_tiles");
+   ctx->list_valid = true;
+   ctx->nrebuild++;
+   {
+      /* the displacement bound of the shell-limited walk starts from this list's positions (NbTileArgs::disp).  D covers the owned beads
+       * (and their periodic self-images); the beads a decomposed run receives from its neighbours are measured where they arrive:
+       * k_halo_update keeps their largest distance from the rebuild's records (NbTileArgs::hdisp) */
+      ctx->sh_r0sq = (double)shc.r0sq; ctx->sh_step = ((double)gp.rlist * gp.rlist - (double)shc.r0sq) / (double)(NSHELL - 1.01);
+      ctx->shell_skip = !ctx->no_shell_skip && !shc.one && ctx->sh_step > 0.0;
+      /* (D and the received beads' two displacement words were zeroed by the rebuild's tail launch, schedule_tiles) */
+   }
+   return ddcmi_bonded_localize(ctx);      /* terms given by gid: located among the owned + halo beads */
+}
+

@@ -60,8 +60,10 @@ for name in ("bench_plain.log", "bench_profiled.log"):
                 open(os.path.join(out, "bench.log"), "w").write(line)
 import hashlib
 h = hashlib.sha256()
-for f in ("ddcmi.hip", "ddcmi_internal.h", "ddcmi_multigpu.inl"):
-    h.update(open(os.path.join("ddcmd_amd", "csrc", "hip", f), "rb").read())
+d = os.path.join("ddcmd_amd", "csrc", "hip")
+for f in sorted(os.listdir(d)):
+    if f.endswith((".hip", ".inl", ".h")):
+        h.update(open(os.path.join(d, f), "rb").read())
 res["kernel_src_id"] = h.hexdigest()[:16]
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps({k: res[k] for k in res if k not in ("counters_mean_per_launch", "method", "units", "gfx950_correction")}, indent=1)[:3000])

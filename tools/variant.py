@@ -23,16 +23,22 @@ def main():
     work = os.path.join("/tmp", "ddcmi_variant_" + name)
     shutil.rmtree(work, ignore_errors=True)
     shutil.copytree(os.path.join(CSRC, "hip"), os.path.join(work, "hip"))
-    fn = os.path.join(work, "hip", "ddcmi.hip")
-    src = open(fn).read()
+    # --sub applies to whichever device source holds the text (ddcmi.hip or one of the .inl parts it includes); --patch to ddcmi.hip
+    parts = sorted(f for f in os.listdir(os.path.join(work, "hip")) if f.endswith((".hip", ".inl")))
     for old, new in subs:
-        if old not in src: raise SystemExit("substitution source not found: " + old[:60])
-        src = src.replace(old, new)
+        for f in parts:
+            fnp = os.path.join(work, "hip", f)
+            src = open(fnp).read()
+            if old in src:
+                open(fnp, "w").write(src.replace(old, new))
+                break
+        else:
+            raise SystemExit("substitution source not found: " + old[:60])
+    fn = os.path.join(work, "hip", "ddcmi.hip")
     if patch:
         g = {}
         exec(open(patch).read(), g)
-        src = g["edit"](src)
-    open(fn, "w").write(src)
+        open(fn, "w").write(g["edit"](open(fn).read()))
     if hsubs:
         hn = os.path.join(work, "hip", "ddcmi_internal.h")
         h = open(hn).read()
