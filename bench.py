@@ -18,7 +18,9 @@ through the RCCL loopback, each timed the same way.
 Prints ONE JSON line (rank 0).  `roofline` prices the nonbonded kernel with the
 ALGORITHMIC bytes of SURVEY 8(d): (36 + 24 + 4*L) B per atom-step, L = stored
 full-list entries per atom, over the HIP-event time of that kernel measured on
-the library's own stream.  `cpu_baseline` times the CPU oracle (a port of the
+the library's own stream; `roofline.traffic` = that kernel's HBM bytes per launch MEASURED IN THIS RUN (N=1 headline: two short
+child runs under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, see live_traffic; the committed profiles/*traffic.json of the
+same device sources only if the profiler is not there).  `cpu_baseline` times the CPU oracle (a port of the
 reference's serial per-rank path; the reference itself cannot be built) on one
 host core on a bounded sample of the same workload.
 """
@@ -86,6 +88,47 @@ def cpu_baseline(n_lattice, seconds_budget=18.0):
     except OSError:
         pass
     return out
+
+
+def live_traffic(extra_args, fused, timeout_s=150.0):
+    """HBM bytes per launch of the pair kernel, MEASURED IN THIS RUN (the figure used to come from a committed file):
+    two short child runs of this very bench (4 steps, no equilibration) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    -- separate passes, as MI355X_MICROARCH.md prescribes; counters are KiB; FETCH_SIZE reports half the bytes of wide coalesced
+    streaming reads on gfx950 and is doubled.  Fresh child processes (never an exec of this one); None if the profiler is not
+    there or a pass fails.  fused: price the launches whose epilogue is the integrator's pass (kernel name ends `true>`)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    vals = {}
+    with tempfile.TemporaryDirectory(prefix="ddcmi_pmc_") as d:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu", "--no-also", "--no-pmc", "--steps", "4", "--warmup", "2", "--equil", "0"] + list(extra_args)
+            env = dict(os.environ)
+            env["TMPDIR"] = "/tmp"
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except Exception:
+                return None
+            if r.returncode != 0:
+                return None
+            acc = []
+            for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    k = row["Kernel_Name"].split("(")[0]
+                    if "k_nonbond" in k and row["Counter_Name"] == ctr and (k.rstrip().endswith("true>") == bool(fused)):
+                        acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None
+            vals[ctr] = sum(acc) / len(acc)
+    return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over child runs of this bench, 4 steps each; FETCH_SIZE doubled (gfx950), KiB counters"}
 
 
 def runtime_libs():
@@ -260,6 +303,7 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
                     break
     except Exception:
         traffic = None
+    traffic_source = "committed: profiles/*traffic.json of these device sources (tools/profile_r04.sh)" if traffic else None
     res = {
         "value": s.natoms / (med / WINDOW), "ms_per_step": ms_per_step, "ms_per_step_mean": sum(wins) * 1e3 / (len(wins) * WINDOW),
         "steps_timed": nwin * WINDOW, "window_steps": WINDOW, "window_ms": [round(w * 1e3, 4) for w in wins],
@@ -277,7 +321,7 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
                                   else ("single GPU, images through RCCL loopback" if loopback else "single GPU"),
                    "list_entries_per_atom": L, "image_or_halo_beads_rank0": st["images"], "rebuilds_in_timed_region": st["rebuilds"] - reb0},
         "roofline": {"bound": "hbm", "kernel": "k_nonbond<FUSE> (pair kernel + the integrator's pass as its epilogue)" if dom is fusedk else "k_nonbond", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "dominant_is_fused": dom is fusedk,
                      "hbm_frac_measured": (traffic / t_kernel / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "fp64_valu_frac": flops / t_kernel / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      "fp64_valu_note": "(45 flop x %.1f in-cutoff pair visits + 10 x %.1f rejected entries) per bead over %.1f TFLOP/s" % (n_in, max(L - n_in, 0.0), FP64_VALU_PEAK_TFLOPS),
@@ -337,6 +381,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="N=1: only the headline workload, not the other single-GPU configs")
+    ap.add_argument("--no-pmc", action="store_true", help="N=1 headline: do not measure the pair kernel's HBM bytes live (two short child runs under rocprofv3 --pmc)")
     ap.add_argument("--workload", choices=("water", "lipid"), default="water",
                     help="water: the headline Martini water box; lipid: tests/golden/lipid_deck (DPPC-style bilayer patch in water, "
                          "all bonded term kinds, charges, Berendsen) tiled --reps times")
@@ -434,6 +479,13 @@ def main():
                                     "roofline": r["roofline"], "comm": r.get("comm")})
             except Exception as ex:      # the headline stands on its own
                 out["also"].append({"what": kw["tag"], "error": str(ex)})
+    if headline and not args.no_pmc:
+        # roofline.traffic measured in THIS run (this process has finished its GPU work; the passes are fresh child processes)
+        lt = live_traffic(["--lattice", str(args.n)], out["roofline"].get("dominant_is_fused", False))
+        if lt:
+            t_k = out["roofline"]["kernel_ms_avg"] * 1e-3
+            out["roofline"].update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"], "traffic_FETCH_SIZE_KiB": lt["FETCH_SIZE_KiB"],
+                                    "traffic_WRITE_SIZE_KiB": lt["WRITE_SIZE_KiB"], "hbm_frac_measured": lt["bytes_per_launch"] / t_k / 1e9 / HBM_PEAK_GBS})
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)      # N=1 only (the contract): a bounded sample on one host core
     if rdzv is not None:
