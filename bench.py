@@ -479,7 +479,8 @@ def main():
                                     "roofline": r["roofline"], "comm": r.get("comm")})
             except Exception as ex:      # the headline stands on its own
                 out["also"].append({"what": kw["tag"], "error": str(ex)})
-    if headline and not args.no_pmc:
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
+    if headline and not args.no_pmc and not under_profiler:      # (a run that is itself being profiled starts no profiler of its own)
         # roofline.traffic measured in THIS run (this process has finished its GPU work; the passes are fresh child processes)
         lt = live_traffic(["--lattice", str(args.n)], out["roofline"].get("dominant_is_fused", False))
         if lt:

@@ -193,7 +193,9 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    int rc;
    ctx->pack_fresh = false;      /* (the rebuild's own exchange reuses the send buffer) */
    if ((rc = nb_tables(ctx))) return rc;
-   if (ctx->nranks > 1 || ctx->loopback) return ddcmi_mg_rebuild(ctx);
+   /* (a rebuild places every image and halo bead from the positions it sorts: the force evaluation that follows needs no update of
+    * them -- and a decomposed rank has no 3-wide records to take one from until its first per-step exchange) */
+   if (ctx->nranks > 1 || ctx->loopback) { rc = ddcmi_mg_rebuild(ctx); if (!rc) ctx->images_fresh = true; return rc; }
    ctx->phase(-1, nullptr);
    for (int pass = 0;; pass++)
    {
@@ -209,6 +211,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    }
    ctx->nhalo_hint = ctx->nhalo;
    ctx->phase(14, "localize");
+   ctx->images_fresh = true;
    return ddcmi_mol_split_finish(ctx);      /* one domain: no molecule is split */
 }
 

@@ -42,7 +42,9 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       HIPCHK(ctx, hipEventRecord(ctx->ev_halo, ctx->stream2));
       halo_pending = true;
    }
-   else if (nh > 0 && !ctx->images_fresh)      /* (the rebuild this step began with made the periodic images from these very positions) */
+   /* (not after a rebuild: it made the images from these very positions; and never on a rank of a transport whose halo is marked fresh --
+    * its last exchange or its rebuild placed every image and halo bead, and the receive buffer may hold velocities or nothing by now) */
+   else if (nh > 0 && !ctx->images_fresh && !((ctx->nranks > 1 || ctx->loopback) && !ctx->group_))
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
    ctx->images_fresh = false;

@@ -204,3 +204,30 @@ def test_loopback_rows_end_at_the_last_shell_that_can_matter(monkeypatch, vscale
         assert ea["total"] == eb["total"] and rka == rkb
         assert abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rka - rko) < TOL * max(rko, 1e-300)
     a.close(); b.close()
+
+
+def test_explicit_rebuild_then_forces_through_the_loopback(monkeypatch):
+    """constructList called by hand (ddcmi_build_list, the neighbour hook of ddcUpdateAll.c:136-139) followed by a force evaluation
+    on a decomposed rank: the rebuild itself has placed the halo beads -- the evaluation must not refresh them from the per-step
+    receive buffer, which no exchange has filled yet (round 4 dropped the rebuild's 5 -> 3 copy of the received records)"""
+    s = make_water_setup(10)
+    o = pyoracle.Oracle(s)
+    e0, v0 = o.forces()
+    m = _loopback_rank(s, monkeypatch)
+    e, _ = m.eval_forces()
+    for _ in range(2):
+        m.build_list()
+        e, _ = m.eval_forces()
+        assert abs(e["lj"] - e0["lj"]) < 1e-10 * abs(e0["lj"])
+    e2, _ = m.eval_forces()                      # twice in a row, no step and no exchange in between: the halo stays where the rebuild put it
+    assert e2["lj"] == e["lj"]
+    m.step(3)
+    m.build_list()
+    e, _ = m.eval_forces()
+    eo, _, _, _ = o.step(3)
+    assert abs(e["total"] - eo["total"]) < TOL * abs(eo["total"])
+    m.step(2)
+    e, _ = m.eval_forces(); e2, _ = m.eval_forces()      # and after steps (the receive buffer holds the last exchange)
+    eo, _ = o.step(2)[0], None
+    assert e2["total"] == e["total"] and abs(e["total"] - eo["total"]) < TOL * abs(eo["total"])
+    m.close()
