@@ -611,7 +611,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_tile_transpose(TileArgs ta)
    }
    unsigned *mycur = cur_s + threadIdx.x;
    const int ngrp = width >> 3;
-   for (int r0 = w * TR_WROWS; r0 < rows; r0 += TR_WROWS * (TR_THREADS / 64))
+   /* (few tiles -- a small system: the rows of a tile are shared by gridDim.y workgroups, every wave still works alone) */
+   for (int r0 = (w + (TR_THREADS / 64) * (int)blockIdx.y) * TR_WROWS; r0 < rows; r0 += TR_WROWS * (TR_THREADS / 64) * (int)gridDim.y)
    {
       const int row = r0 + rl;
       const int cnt = row < nown ? ta.nbr_cnt[ts + row] : 0;

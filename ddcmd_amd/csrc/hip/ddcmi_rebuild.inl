@@ -471,7 +471,9 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
          auto ktr = scr16 ? (ctx->tmpw <= 192 ? k_tile_transpose<3, true> : ctx->tmpw <= 384 ? k_tile_transpose<6, true> : k_tile_transpose<12, true>)
                           : (ctx->tmpw <= 192 ? k_tile_transpose<6, false> : ctx->tmpw <= 384 ? k_tile_transpose<12, false> : k_tile_transpose<24, false>);
          HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)ktr, (int)lds2));
-         hipLaunchKernelGGL(ktr, dim3(ntile), dim3(TR_THREADS), lds2, st, ta);
+         /* a box of fewer tiles than the chip has CUs: up to eight workgroups per tile (the 16 tiles of a 6.9 k-bead box took 61 us as 16 workgroups) */
+         const int ny = ntile < 256 ? std::max(1, std::min(8, 1024 / std::max(ntile, 1))) : 1;
+         hipLaunchKernelGGL(ktr, dim3(ntile, ny), dim3(TR_THREADS), lds2, st, ta);
       }
       HIPCHK(ctx, hipGetLastError());
       ctx->phase(11, "build+transpose launched");
