@@ -414,6 +414,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("DDCMI_BENCH_SINGLE_DEVICE"):      # all ranks on device 0 (tests on a one-GPU box; needs DDCMI_TRANSPORT=host: RCCL refuses two ranks on a device)
         local_rank = 0
+    else:
+        # a launcher that gives every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per process): ordinal 0 there, not LOCAL_RANK
+        try:
+            import ddcmd_amd
+            lib0 = ddcmd_amd.load_library()
+            lib0.ddcmi_device_count.restype = ctypes.c_int
+            ndev = int(lib0.ddcmi_device_count())
+            if 0 < ndev <= local_rank:
+                local_rank %= ndev
+        except Exception:
+            pass
     transport = os.environ.get("DDCMI_TRANSPORT", "rccl")
     # No torch in this process: libddcmi.so is built and validated against /opt/rocm's HIP and RCCL, and
     # `import torch` would map torch's bundled copies of the same sonames first.  The control plane (the 128-byte
