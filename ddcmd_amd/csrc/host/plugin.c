@@ -119,6 +119,7 @@ ACCELERATOR *accelerator_init(void *parent, const char *name, const char *type)
    ddcmi_ctx *ctx = NULL;
    /* one GPU per rank (LOCAL_RANK) unless the ranks are told to share one (tests on a one-GPU box) */
    int dev = (par.world > 1 && !env_int("DDCMI_SINGLE_DEVICE", 0)) ? par.local_rank : 0;
+   { const int ndev = ddcmi_device_count(); if (ndev > 0 && dev >= ndev) dev %= ndev; }      /* (a launcher that shows every rank ONE device: ordinal 0 there) */
    const char *env = getenv("DDCMI_DEVICE");
    if (env) dev = atoi(env);
    if (ddcmi_create(&ctx, dev) != DDCMI_OK) die("accelerator_init", ddcmi_last_error(NULL));
