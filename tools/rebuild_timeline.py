@@ -1,6 +1,7 @@
 """Timeline of ONE list rebuild out of a rocprofv3 --kernel-trace (+ --memory-copy-trace) capture: the kernels and copies
 between the last k_nonbond before a rebuild and the first one after it, with the idle gaps between them.
-   python3 tools/rebuild_timeline.py <dir with *_kernel_trace.csv> [which rebuild, default: the last]"""
+   python3 tools/rebuild_timeline.py <dir with *_kernel_trace.csv> [which rebuild, default: the last]
+A steady step as well: the launches between the two k_nonbond launches five steps before that rebuild."""
 import csv, glob, sys
 d = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
@@ -29,3 +30,13 @@ for s, e, n in ev[lo + 1:hi + 1]:
     print("  +%8.1f us  gap %7.1f  dur %8.1f  %s" % ((s - t0) / 1e3, gap, (e - s) / 1e3, n))
     last = max(last, e)
 print("busy %.1f us, idle %.1f us" % (busy, gaps))
+
+# one steady-state step: from the start of the fifth pair kernel before the rebuild to the start of the next one
+nb = [k for k in range(lo + 1) if "k_nonbond" in ev[k][2]]
+if len(nb) > 6:
+    a, b = nb[-6], nb[-5]
+    print("steady step: %.1f us from the start of one pair kernel to the start of the next" % ((ev[b][0] - ev[a][0]) / 1e3))
+    last = ev[a][0]
+    for s_, e_, n in ev[a:b + 1]:
+        print("  +%8.1f us  gap %7.1f  dur %8.1f  %s" % ((s_ - ev[a][0]) / 1e3, (s_ - last) / 1e3, (e_ - s_) / 1e3, n))
+        last = max(last, e_)
