@@ -239,7 +239,7 @@ struct GatherRows
 };
 template <bool HEAVY>      /* false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers) */
 __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, int ntot, BoxArgs box, int excl_mask,
-                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double *partials)
+                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double4 *fb, double *partials)
 {
    /* lane = entry of the list of atoms that have terms of this launch, in caller order: the lanes of a
     * molecule sit together, so their rows are read with unit stride and the partners' bead records are the
@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
                else { fxi += fL[0]; fyi += fL[1]; fzi += fL[2]; }
             }
          }
-         fx[i] += fxi; fy[i] += fyi; fz[i] += fzi;
+         /* fb: the record array is all zero when the bonded kernels start and the light launch comes first: it stores (0 + f = f), the
+          * heavy launch adds to the record of its few beads */
+         if (fb) { if (HEAVY) { double4 b = fb[i]; b.x += fxi; b.y += fyi; b.z += fzi; fb[i] = b; } else fb[i] = make_double4(fxi, fyi, fzi, 0.0); }
+         else { fx[i] += fxi; fy[i] += fyi; fz[i] += fzi; }
       }
    }
    /* block sums, GB_NV values per block at stride 16 */
@@ -366,10 +369,17 @@ __global__ __launch_bounds__(256) void k_reduce_gather(const double *__restrict_
 {
    __shared__ double s[256];
    const int k = blockIdx.x;
-   double a = 0.0;
-   for (int b = threadIdx.x; b < nblocks; b += 256) a += partials[(size_t)b * 16 + k];
-   for (int b = threadIdx.x; b < nblocks2; b += 256) a += partials2[(size_t)b * 16 + k];
-   s[threadIdx.x] = a;
+   /* independent partial sums (a single chain of dependent loads is latency-bound: 9.5 us for the 5000 rows of the 2 M-bead bilayer) */
+   double p[4] = {0.0, 0.0, 0.0, 0.0};
+   int b = threadIdx.x;
+   for (; b + 3 * 256 < nblocks; b += 4 * 256)
+   {
+#pragma unroll
+      for (int u = 0; u < 4; u++) p[u] += partials[(size_t)(b + u * 256) * 16 + k];
+   }
+   for (int u = 0; b < nblocks; b += 256, u++) p[u] += partials[(size_t)b * 16 + k];
+   for (b = threadIdx.x; b < nblocks2; b += 256) p[0] += partials2[(size_t)b * 16 + k];
+   s[threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
    __syncthreads();
    for (int off = 128; off > 0; off >>= 1)
    {
@@ -572,7 +582,7 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
    /* the per-kind sums are only written by kernels that run: clear stale ones */
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_RK - R_SCR_BOND) * sizeof(double), ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->forces_valid = false; ctx->f_zero = false; ctx->list_valid = false;
+   ctx->forces_valid = false; ctx->list_valid = false;
    return DDCMI_OK;
 }
 
@@ -641,7 +651,7 @@ __global__ void k_rest_locate(int nrest, const uint64_t *__restrict__ rgid, int 
  * box: the same thing).  One workgroup, fixed summation order. */
 __global__ __launch_bounds__(256) void k_restraint(int nrest, BoxArgs box, int origin, const int *__restrict__ slot, const int *__restrict__ fc,
                                                    const double *__restrict__ r0, const double *__restrict__ kb_, const double4 *__restrict__ pos,
-                                                   double *fx, double *fy, double *fz, double *out)
+                                                   double *fx, double *fy, double *fz, double4 *fb, double *out)
 {
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
    for (int r = threadIdx.x; r < nrest; r += 256)
@@ -660,7 +670,8 @@ __global__ __launch_bounds__(256) void k_restraint(int nrest, BoxArgs box, int o
       }
       double kb = kb_[r], kforce = -2 * kb;
       double f0 = kforce * c[0], f1 = kforce * c[1], f2 = kforce * c[2];
-      atomicAdd(&fx[i], f0); atomicAdd(&fy[i], f1); atomicAdd(&fz[i], f2);
+      if (fb) { atomicAdd(&fb[i].x, f0); atomicAdd(&fb[i].y, f1); atomicAdd(&fb[i].z, f2); }
+      else { atomicAdd(&fx[i], f0); atomicAdd(&fy[i], f1); atomicAdd(&fz[i], f2); }
       acc[0] += kb * (c[0] * d[0] + c[1] * d[1] + c[2] * d[2]);
       acc[1] += f0 * c[0]; acc[2] += f1 * c[1]; acc[3] += f2 * c[2];
       acc[4] += f0 * c[1]; acc[5] += f0 * c[2]; acc[6] += f1 * c[2];
@@ -681,7 +692,7 @@ extern "C" int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, 
    }
    HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_REST, 0, 8 * sizeof(double), ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->forces_valid = false; ctx->f_zero = false; ctx->list_valid = false;
+   ctx->forces_valid = false; ctx->list_valid = false;
    return DDCMI_OK;
 }
 
@@ -729,7 +740,7 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
    return DDCMI_OK;
 }
 
-int ddcmi_launch_bonded(ddcmi_ctx *ctx)
+int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb)
 {
    if (ctx->inc_nrow == 0 && ctx->nrest == 0) return DDCMI_OK;
    hipStream_t st = ctx->stream;
@@ -737,9 +748,14 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];
    for (int a = 0; a < 3; a++) box.Linv[a] = 1.0 / box.L[a];
    box.pbc = ctx->pbc;
-   if (ctx->nrest > 0)
-      hipLaunchKernelGGL(k_restraint, dim3(1), dim3(256), 0, st, ctx->nrest, box, ctx->rest_origin, ctx->rest_slot.p, ctx->rest_fc.p, ctx->rest_r0.p, ctx->rest_kb.p,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->d_results + R_SCR_REST);
+   /* (restraints behind the bonded terms when the force goes to the record array: the light launch STORES its beads' records) */
+   auto restraints = [&]()
+   {
+      if (ctx->nrest > 0)
+         hipLaunchKernelGGL(k_restraint, dim3(1), dim3(256), 0, st, ctx->nrest, box, ctx->rest_origin, ctx->rest_slot.p, ctx->rest_fc.p, ctx->rest_r0.p, ctx->rest_kb.p,
+                            ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->d_results + R_SCR_REST);
+   };
+   if (!fb || ctx->inc_nrow == 0) restraints();
    if (ctx->inc_nrow == 0) return DDCMI_OK;
    /* one lane per atom with terms; a decomposed run launches over the global atom lists and every rank
     * works on the atoms it owns */
@@ -751,10 +767,11 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx)
    double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
    if (nblk > 0)
       hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->bpartials.p);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->bpartials.p);
    if (nblk2 > 0)
       hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, p2);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2);
+   if (fb) restraints();
    hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
    return DDCMI_OK;
 }

@@ -528,7 +528,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    ctx->cg_pa.release(); ctx->cg_pb.release();
    for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->slot_of_atom, &ctx->hvals}) b->release();
    ctx->tile_nib.release();
-   ctx->tile_base.release(); ctx->nbr16.release(); ctx->excl16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->tmp32.release();
+   ctx->tile_base.release(); ctx->nbr16.release(); ctx->excl16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->fb.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
@@ -879,7 +879,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    if (n == 0)
    {
       ctx->nloc = 0; ctx->nhalo = 0; ctx->npad = DDCMI_BLOCK; ctx->self_ele = 0.0;
-      ctx->list_valid = false; ctx->forces_valid = false; ctx->f_zero = false;
+      ctx->list_valid = false; ctx->forces_valid = false;
       return DDCMI_OK;
    }
    /* stage through vx2/vy2/vz2 as scratch for the positions */
@@ -923,7 +923,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    double q2 = 0.0;
    for (int i = 0; i < n; i++) { double q = ctx->charge[species[i]]; q2 += q * q; }
    ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;
-   ctx->list_valid = false; ctx->forces_valid = false; ctx->f_zero = false;
+   ctx->list_valid = false; ctx->forces_valid = false;
    return DDCMI_OK;
 }
 
@@ -973,7 +973,7 @@ extern "C" int ddcmi_upload_positions(ddcmi_ctx *ctx, const double *rx, const do
       hipLaunchKernelGGL(k_import3, dim3(nb), dim3(256), 0, st, n, ctx->orig.p, ctx->vx2.p, ctx->vy2.p, ctx->vz2.p, ctx->vx.p, ctx->vy.p, ctx->vz.p);
    }
    HIPCHK(ctx, hipStreamSynchronize(st));
-   ctx->forces_valid = false; ctx->f_zero = false; ctx->halo_fresh = false; ctx->drift_done = false;
+   ctx->forces_valid = false; ctx->halo_fresh = false; ctx->drift_done = false;
    return DDCMI_OK;
 }
 

@@ -260,7 +260,10 @@ struct ddcmi_ctx
    bool counters_clean = false, dircnt_clean = false, dir28_clean = false; int clean_ncell = 0; const int *clean_po = nullptr, *clean_ph = nullptr;
    bool sort_renumbers = false;        /* decomposed rebuild: the coming sort numbers the beads (orig = place in front of the sort) in its first kernel */
    bool forces_valid = false;
-   bool f_zero = false;                /* fx, fy, fz of the owned beads are all zero (left so by a fused launch that consumed the bonded forces): the next bonded launch needs no clearing */
+   /* the bonded kernels' (and restraints') force on every owned bead, ONE 32-byte record per bead: the bead-parallel kernels touch a
+    * scattered bead once (a store) instead of six times (read-modify-write of three arrays), the pair kernel reads it with one load
+    * and hands it back zeroed -- every pair launch does, so the array is all zero whenever the bonded kernels start */
+   dbuf<double4> fb; size_t fb_zeroed = 0;      /* fb_zeroed: elements known to be zero (a grown buffer is cleared once) */
    /* timing */
    /* hipGraph of one steady-state step (forces + fused BACK kick / kinetic terms / FRONT kick / drift): small
     * systems are launch-bound -- five short kernels per step -- and can replay the step as one graph launch
@@ -381,7 +384,7 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */
-int ddcmi_launch_bonded(ddcmi_ctx *ctx);
+int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb = nullptr);      /* fb: the force goes to the (zeroed) record array instead of being added to fx, fy, fz */
 int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location);   /* 0 FRONT, 1 BACK */
 int ddcmi_launch_mol_virial(ddcmi_ctx *ctx);
 int ddcmi_groups_localize(ddcmi_ctx *ctx);      /* rebuild: constraint groups / molecules named by gid -> device slots */

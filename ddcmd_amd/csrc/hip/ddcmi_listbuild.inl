@@ -89,10 +89,10 @@ struct NbTileArgs
    /* decomposed runs: D bounds the OWNED beads' moves only; hdisp (not null) points at the largest squared distance of a received
     * halo bead from its place at the rebuild (k_halo_update), and a pair distance has changed by at most D + max(D, sqrt(*hdisp)) */
    const double *hdisp;
-   /* bonded terms / restraints: their kernels ran first and left their force on every owned bead in fx, fy, fz (zero where a bead
-    * has none); the pair kernel adds the bead's pair force to it -- in memory (plain launch) or in registers, in front of the
-    * integrator's pass (FUSE; it hands the array back zeroed for the next step's bonded kernels) */
-   int addf;
+   /* bonded terms / restraints: their kernels ran first and left their force on every owned bead in fb (one 32-byte record per bead,
+    * zero where a bead has none); the pair kernel adds the bead's pair force to it -- into fx, fy, fz (plain launch) or in registers,
+    * in front of the integrator's pass (FUSE) -- and hands the record back zeroed for the next evaluation's bonded kernels */
+   double4 *fb;
 };
 /* k_nonbond<..., FUSE>: the pair kernel's epilogue is the integrator's pass over the bead -- BACK half kick, kinetic terms, FRONT half
  * kick, drift (k_kick_ke_drift, bit for bit) -- for systems whose forces are complete when the list walk ends (no bonded terms,

@@ -14,7 +14,7 @@
  *      give each bead 64/R lanes that split its list).  List entries are 16 bits, (staged slot + 1) << 4 | type
  *      [| shifted-copy bit], stored per tile as [group of 8 slots][row][8]: one 16-byte load per lane and group,
  *      kept two groups ahead.  Per slot: two LDS gathers by raw byte offset, the distance test, and under it
- *        ir2  = 1/r2   (v_rcp_f32 seed + 2 Newton steps; with charges ir = 1/sqrt(r2) from v_rsq_f32)
+ *        ir2  = 1/r2   (v_rcp_f64 seed + one Newton step; with charges ir = 1/sqrt(r2) from v_rsq_f64 the same way)
  *        s2   = sigma^2 ir2 ; s6 = s2^3 ; s12 = s6^2
  *        vLJ += 4eps(s12-s6)+shift ; dvdr = 24eps(s6-2s12) ir2
  *        vEle+= kqij(ir + krf r2 - crf) ; dvdr += kqij(2krf - ir^3)       (kqij from the type-pair table)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          {
             if (active && sub == 0)
             {
-               if (ta.addf) { fxi += fx[a]; fyi += fy[a]; fzi += fz[a]; }
+               if (ta.fb) { const double4 b = ta.fb[a]; fxi += b.x; fyi += b.y; fzi += b.z; ta.fb[a] = make_double4(0.0, 0.0, 0.0, 0.0); }
                fx[a] = fxi; fy[a] = fyi; fz[a] = fzi;
             }
          }
@@ -430,11 +430,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                /* (asked for here, not before the walk: held across it these twelve registers spill, and the reload costs what the load does) */
                const int sp = (int)((__double_as_longlong(pi.w) >> 16) & 0xffffll);
                const double hk = (0.5 * fa.dt) * fa.invmass[sp], m = fa.massv[sp], lam = fa.lam;
-               if (ta.addf)
+               if (ta.fb)
                {
-                  /* + the bonded terms' force on the bead (the same sum the plain launch leaves in memory); the array goes back zeroed */
-                  fxi += fx[a]; fyi += fy[a]; fzi += fz[a];
-                  fx[a] = 0.0; fy[a] = 0.0; fz[a] = 0.0;
+                  /* + the bonded terms' force on the bead (the same sum the plain launch leaves in memory); the record goes back zeroed */
+                  const double4 b = ta.fb[a];
+                  fxi += b.x; fyi += b.y; fzi += b.z;
+                  ta.fb[a] = make_double4(0.0, 0.0, 0.0, 0.0);
                }
                double x = fma(hk, fxi, fa.vx[a]), y = fma(hk, fyi, fa.vy[a]), z = fma(hk, fzi, fa.vz[a]);
                const double vxx = x * x, vyy = y * y, vzz = z * z;

@@ -382,7 +382,6 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    int n = ctx->nloc;
    ctx->phase(10, "-> bl_finish");
    graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
-   ctx->f_zero = false;  /* (the beads have new slots, a decomposed rank a new number of them) */
    /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
    ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
    int ntile = gp.T[0] * gp.T[1] * gp.T[2];

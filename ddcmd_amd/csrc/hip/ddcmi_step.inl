@@ -52,17 +52,19 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    const double self = ((ctx->excludePotentialTerm & 128) == 0) ? ctx->self_ele : 0.0;
    if ((ctx->excludePotentialTerm & 128) == 0)
    {
-      /* Bonded terms and restraints FIRST, into a zeroed force array: the pair kernel then finishes every bead's force in ONE place --
-       * in memory (plain launch: f = f_pair + f_bonded) or in registers in front of the integrator's pass (FUSE), so that systems
-       * with bonded terms take the fused step too (the lipid box paid a separate 54 us kick kernel and a force store +
-       * re-read).  Both kinds of launch form the same sum, so the fused and the split step stay bit for bit alike.  The fused
-       * launch hands the array back zeroed (f_zero): between print steps no launch is spent on clearing it. */
+      /* Bonded terms and restraints FIRST, into a zeroed array of force records (ddcmi_ctx::fb): the pair kernel then finishes every bead's
+       * force in ONE place -- in memory (plain launch: f = f_pair + f_bonded) or in registers in front of the integrator's pass (FUSE), so
+       * that systems with bonded terms take the fused step too (the lipid box paid a separate 54 us kick kernel and a force
+       * store + re-read).  Both kinds of launch form the same sum, so the fused and the split step stay bit for bit alike, and both hand
+       * the records back zeroed: no launch is ever spent on clearing them. */
       if (has_bonded && n > 0)
       {
          if (halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }      /* bonded partners may be halo beads */
-         if (!ctx->f_zero) hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
-         ctx->f_zero = false;
-         int rcb = ddcmi_launch_bonded(ctx);
+         /* (the record array: all zero -- every pair launch hands back zeroed what it consumed; a grown array is cleared once) */
+         if (ctx->fb.cap < (size_t)ctx->npad) { if (ctx->fb.ensure(ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "bonded force records"); ctx->fb_zeroed = 0; }
+         if (ctx->fb_zeroed < ctx->fb.cap) { HIPCHK(ctx, hipMemsetAsync(ctx->fb.p, 0, ctx->fb.cap * sizeof(double4), st)); ctx->fb_zeroed = ctx->fb.cap; }
+         ctx->fb_zeroed = 0;      /* (until the pair launches below have consumed the records) */
+         int rcb = ddcmi_launch_bonded(ctx, ctx->fb.p);
          if (rcb) return rcb;
       }
       int ntile = ctx->ntile;
@@ -101,7 +103,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       na.disp = ctx->shell_skip ? ctx->d_results + R_DISP : nullptr; na.nbr_cum = ctx->nbr_cum.p; na.sh_r0sq = ctx->sh_r0sq; na.sh_step = ctx->sh_step;
       na.hdisp = hdisp_on ? ctx->d_results + R_DISP + 1 + hpar : nullptr;
-      na.addf = (has_bonded && n > 0) ? 1 : 0;
+      na.fb = (has_bonded && n > 0) ? ctx->fb.p : nullptr;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
 #define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
@@ -156,8 +158,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
 #undef LAUNCH_NB
 #undef LAUNCH_NBZ
 #undef LAUNCH_NBF
+      if (na.fb) ctx->fb_zeroed = ctx->fb.cap;
       if (ctx->timing) { ctx->t_launches++; if (fuse) ctx->t_launches_fused++; }          /* per force evaluation: the event pairs of both classes add up */
-      if (fuse && na.addf) ctx->f_zero = true;      /* (the fused launch cleared what it consumed) */
       /* the final energies are formed in the same launch (the bonded kernels' sums are complete: they ran first) */
       if (!defer_reduce)
       {
@@ -171,7 +173,6 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    {
       if (!defer_reduce) HIPCHK(ctx, hipMemsetAsync(ctx->d_results, 0, 8 * sizeof(double), st));
       hipLaunchKernelGGL(k_zero3, dim3(cdiv(n, 256)), dim3(256), 0, st, n, ctx->fx.p, ctx->fy.p, ctx->fz.p);
-      ctx->f_zero = false;
    }
    if (halo_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0));      /* bonded partners may be halo beads */
    int rc = ddcmi_launch_bonded(ctx);
