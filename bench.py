@@ -6,8 +6,9 @@
 One "step" is one NGLF velocity-Verlet step of the whole box (half kick, drift,
 image refresh, nonbonded + bonded forces with energy and virial, half kick +
 kinetic terms; neighbour-list rebuild every 20 steps inside the timed region).
-Workload at N=1: BASELINE.json's headline config, the 4.0M-bead Martini water
-box (FCC n=100 lattice, rcut 12 A, skin 4 A, dt 20 fs), state resident in HBM;
+Workload at N=1: BASELINE.json's headline config, the 4M-bead Martini water
+box (FCC n=102 lattice = 4 244 832 beads >= SURVEY 8d's 4 096 000, even under a 2x2x2 split; rcut 12 A, skin 4 A, dt 20 fs),
+state resident in HBM;
 200 untimed steps in front of the warm-up melt the lattice start (50 K) into the
 liquid (~307 K), so the timed steps see production list lengths.
 The timed region is max(--steps, 60) steps rounded up to windows of 20, each window between a
@@ -34,6 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HEADLINE_N = 102               # FCC edge of the headline box: 4 n^3 = 4 244 832 beads (n = 100 was 2.3 % under SURVEY 8d's 4 096 000)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64: half of the guide's 157.3 TFLOP/s FP32 vector peak (AMD's MI355X figure)
 WINDOW = 20                    # timed steps come in windows of 20: one list rebuild each for water (two for the lipid deck's 10-step period)
@@ -90,12 +92,15 @@ def cpu_baseline(n_lattice, seconds_budget=18.0):
     return out
 
 
-def live_traffic(extra_args, fused, timeout_s=150.0):
-    """HBM bytes per launch of the pair kernel, MEASURED IN THIS RUN (the figure used to come from a committed file):
-    two short child runs of this very bench (4 steps, no equilibration) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
-    -- separate passes, as MI355X_MICROARCH.md prescribes; counters are KiB; FETCH_SIZE reports half the bytes of wide coalesced
-    streaming reads on gfx950 and is doubled.  Fresh child processes (never an exec of this one); None if the profiler is not
-    there or a pass fails.  fused: price the launches whose epilogue is the integrator's pass (kernel name ends `true>`)."""
+def live_traffic(extra_args, fused, timeout_s=240.0):
+    """HBM bytes per launch of the pair kernel, MEASURED IN THIS RUN and IN THE STATE OF THE TIMED RUN (the passes used to
+    sample a lattice start within six steps of a rebuild, where the shell-limited walk reads the fewest list bytes): two child runs of
+    this very bench with the SAME equilibration and warm-up as the timed run and MIN_TIMED_STEPS timed steps, under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md prescribes; counters are KiB;
+    FETCH_SIZE reports half the bytes of wide coalesced streaming reads on gfx950 and is doubled.  Only the launches of the child's
+    timed windows are averaged (the last MIN_TIMED_STEPS steps' launches by dispatch order: whole rebuild periods, every age of the
+    list).  Fresh child processes (never an exec of this one); None if the profiler is not there or a pass fails.
+    fused: price the launches whose epilogue is the integrator's pass (kernel name ends `true>`)."""
     import csv
     import glob
     import shutil
@@ -105,11 +110,12 @@ def live_traffic(extra_args, fused, timeout_s=150.0):
     if not os.path.exists(prof):
         return None
     vals = {}
+    nlaunch = 0
     with tempfile.TemporaryDirectory(prefix="ddcmi_pmc_") as d:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(d, ctr)
             cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--no-cpu", "--no-also", "--no-pmc", "--steps", "4", "--warmup", "2", "--equil", "0"] + list(extra_args)
+                   "--no-cpu", "--no-also", "--no-pmc", "--steps", str(MIN_TIMED_STEPS), "--warmup", "20"] + list(extra_args)
             env = dict(os.environ)
             env["TMPDIR"] = "/tmp"
             try:
@@ -118,17 +124,23 @@ def live_traffic(extra_args, fused, timeout_s=150.0):
                 return None
             if r.returncode != 0:
                 return None
-            acc = []
+            rows = []
             for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(fn)):
-                    k = row["Kernel_Name"].split("(")[0]
-                    if "k_nonbond" in k and row["Counter_Name"] == ctr and (k.rstrip().endswith("true>") == bool(fused)):
-                        acc.append(float(row["Counter_Value"]))
+                    if "k_nonbond" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"].split("(")[0].rstrip().endswith("true>"), float(row["Counter_Value"])))
+            rows.sort()
+            # the timed windows are the child's last MIN_TIMED_STEPS force evaluations (one pair launch each on a single domain)
+            rows = rows[-MIN_TIMED_STEPS:]
+            acc = [v for _, f, v in rows if f == bool(fused)]
             if not acc:
                 return None
             vals[ctr] = sum(acc) / len(acc)
+            nlaunch = len(acc)
     return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
-            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over child runs of this bench, 4 steps each; FETCH_SIZE doubled (gfx950), KiB counters"}
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over child runs of this bench in the timed run's own state "
+                      "(same equilibration and warm-up; the %d %s launches of the child's last %d steps: whole rebuild periods); FETCH_SIZE doubled (gfx950), KiB counters"
+                      % (nlaunch, "fused" if fused else "plain", MIN_TIMED_STEPS)}
 
 
 def runtime_libs():
@@ -311,7 +323,8 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
         "config": {"workload": wname, "beads_total": s.natoms, "beads_rank0": nlocal,
                    "lattice": lattice, "lattice_n": lattice_n,
                    "stands_for": ("BASELINE configs[3] '4M-bead Martini water' (SURVEY 8d: 4 096 000 on a simple-cubic start that explodes at 20 fs; "
-                                  "FCC 4 n^3 at the same density, n = 100)" if wname == "martini_water_4000k_beads" else None),
+                                  "FCC 4 n^3 at the same density with n = %d: the smallest even n with 4 n^3 >= 4 096 000)" % HEADLINE_N
+                                  if (workload == "water" and n == HEADLINE_N) else None),
                    "rcut_A": float(ddcmd_amd.units_convert(s.rmax, None, "Angstrom")), "skin_A": float(ddcmd_amd.units_convert(s.deltaR, None, "Angstrom")),
                    "dt_fs": dt_fs, "list_rebuild_every": int(s.updateRate),
                    "bonded_terms": {k: int(m.terms[k].size) for k in ("bond_kb", "angle_k", "tors_k")},
@@ -377,7 +390,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--lattice", dest="n", type=int, default=100, help="FCC lattice edge: 4*n^3 beads (100 -> 4.0M, 101 -> 4.12M >= SURVEY's 4.096M, 64 -> 1.05M, 25 -> 62.5k)")
+    ap.add_argument("--lattice", dest="n", type=int, default=HEADLINE_N, help="FCC lattice edge: 4*n^3 beads (102 -> 4.24M: the headline; 100 -> 4.0M: rounds 1-4; 64 -> 1.05M, 25 -> 62.5k)")
     ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="N=1: only the headline workload, not the other single-GPU configs")
@@ -414,17 +427,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("DDCMI_BENCH_SINGLE_DEVICE"):      # all ranks on device 0 (tests on a one-GPU box; needs DDCMI_TRANSPORT=host: RCCL refuses two ranks on a device)
         local_rank = 0
-    else:
-        # a launcher that gives every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per process): ordinal 0 there, not LOCAL_RANK
-        try:
-            import ddcmd_amd
-            lib0 = ddcmd_amd.load_library()
-            lib0.ddcmi_device_count.restype = ctypes.c_int
-            ndev = int(lib0.ddcmi_device_count())
-            if 0 < ndev <= local_rank:
-                local_rank %= ndev
-        except Exception:
-            pass
+    elif not args.check_runtime:      # (--check-runtime touches no device: not even the count)
+        # a launcher that gives every rank exactly ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per process): ordinal 0
+        # there, not LOCAL_RANK.  Fewer devices than ranks in any other way is refused: two ranks folded onto one GPU would print a
+        # scaling number that means nothing
+        import ddcmd_amd
+        lib0 = ddcmd_amd.load_library()
+        lib0.ddcmi_device_count.restype = ctypes.c_int
+        ndev = int(lib0.ddcmi_device_count())
+        if ndev == 1:
+            local_rank = 0
+        elif 0 < ndev <= local_rank:
+            sys.stderr.write("bench.py: LOCAL_RANK %d but only %d devices are visible: one rank per GPU (DDCMI_BENCH_SINGLE_DEVICE=1 + DDCMI_TRANSPORT=host "
+                             "shares one device on purpose)\n" % (local_rank, ndev))
+            sys.exit(2)
     transport = os.environ.get("DDCMI_TRANSPORT", "rccl")
     # No torch in this process: libddcmi.so is built and validated against /opt/rocm's HIP and RCCL, and
     # `import torch` would map torch's bundled copies of the same sonames first.  The control plane (the 128-byte
@@ -474,19 +490,29 @@ def main():
     }
     out.update(res)
     out["runtime_libs"] = runtime_libs()
-    headline = world == 1 and args.workload == "water" and args.n == 100 and not args.rccl_loopback
+    headline = world == 1 and args.workload == "water" and args.n == HEADLINE_N and not args.rccl_loopback
     if headline and not args.no_also:
         # the other single-GPU configurations, each timed like the headline (>= 100 steps): BASELINE configs[2] (1 M-bead water),
         # configs[4] (the ~2 M-bead lipid bilayer) and one rank's brick of the 8-GPU run of configs[3] through the RCCL loopback
         out["also"] = []
-        for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps"),
-                   dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen"),
-                   dict(workload="water", n=50, loopback=True, tag="one rank's 500k-bead brick of the 8-GPU run, periodic images through the RCCL loopback")):
+        under_prof = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
+        for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps", pmc=["--lattice", "64"]),
+                   dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen", pmc=["--workload", "lipid", "--reps", args.reps]),
+                   dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=None),
+                   dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
             try:
                 r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"])
+                if kw["pmc"] and not args.no_pmc and not under_prof:
+                    # the row's own HBM bytes, measured live like the headline's
+                    lt = live_traffic(kw["pmc"], r["roofline"].get("dominant_is_fused", False))
+                    if lt:
+                        t_k = r["roofline"]["kernel_ms_avg"] * 1e-3
+                        r["roofline"].update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"], "traffic_FETCH_SIZE_KiB": lt["FETCH_SIZE_KiB"],
+                                              "traffic_WRITE_SIZE_KiB": lt["WRITE_SIZE_KiB"], "hbm_frac_measured": lt["bytes_per_launch"] / t_k / 1e9 / HBM_PEAK_GBS})
                 out["also"].append({"what": kw["tag"], "workload": r["config"]["workload"], "value": r["value"], "unit": "atom-steps/s", "ms_per_step": r["ms_per_step"],
                                     "steps_timed": r["steps_timed"], "window_ms": r["window_ms"], "rebuilds_in_timed_region": r["config"]["rebuilds_in_timed_region"],
                                     "list_entries_per_atom": r["config"]["list_entries_per_atom"], "parallelism": r["config"]["parallelism"],
+                                    "dt_fs": r["config"]["dt_fs"], "list_rebuild_every": r["config"]["list_rebuild_every"],
                                     "roofline": r["roofline"], "comm": r.get("comm")})
             except Exception as ex:      # the headline stands on its own
                 out["also"].append({"what": kw["tag"], "error": str(ex)})

@@ -8,6 +8,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DDCMI_LIB: kernel-tuning builds of the device library (tools/variant.py)
 LIB_PATH = os.environ.get("DDCMI_LIB") or os.path.join(_HERE, "lib", "libddcmi.so")
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libddcmi_host.so")
+# the second link of the same objects that also exports include/ddcmi_test.h (in-process domain groups, the halo planner's host
+# logic, the branch census): tests/ and tools/ only.  A tuning build (DDCMI_LIB) carries both tables.
+TEST_LIB_PATH = os.environ.get("DDCMI_LIB") or os.path.join(_HERE, "lib", "libddcmi_test.so")
 
 
 class LibraryMissing(RuntimeError):
@@ -32,6 +35,22 @@ class _Libs(object):
 
 
 _lib = None
+_test_lib = None
+
+
+def load_test_library():
+    """libddcmi_test.so (+ the host layer): the product's objects with the test-only entry points of include/ddcmi_test.h exported
+    as well.  A context belongs to the library that created it: drive it through this handle only."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    base = load_library()
+    if not os.path.exists(TEST_LIB_PATH):
+        raise LibraryMissing("%s not found -- build it with `make -C ddcmd_amd/csrc`" % TEST_LIB_PATH)
+    dev = base.dev if os.path.realpath(TEST_LIB_PATH) == os.path.realpath(LIB_PATH) else ctypes.CDLL(TEST_LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    _test_lib = _Libs(dev, base.host)
+    _declare(_test_lib)
+    return _test_lib
 
 
 def load_library():

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "ddcmi.h"
+#include "ddcmi_test.h"      /* the test-only entry points: compiled into the objects, exported by libddcmi_test.so only */
 
 #define DDCMI_BLOCK 256
 /* d_flags slots: [0,64) the rebuild's flags and the arena counter ([32,34), a cache line of its own), posted to the host as one block;

@@ -570,6 +570,7 @@ int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need)
    hipStream_t st = ctx->stream;
    const int n = ctx->nloc, nblk = cdiv(std::max(n, 1), DDCMI_BLOCK);
    *need = 1;
+   if (ctx->comm) { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }      /* (this path waits on the host every step: a peer whose rebuild failed is reported here, not after the mailbox's timeout) */
    if (!ctx->list_valid || ctx->pos0.cap < (size_t)n) return DDCMI_OK;
    *need = 0;
    if (n == 0)

@@ -639,19 +639,37 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
             /* normalParse (langevin.c:66-91): Teq is an EQUATION of time there (eq_parse, simutil -- not in the reference tree, its
              * grammar unknown here): a constant with a unit is what this loader takes, anything else is refused, not misread */
             {
-               char *teq = get_string(go, "Teq", "0.0");
+               char *teq = NULL;
+               object_get(go, "Teq", &teq, LITERAL, 1, "0.0");      /* (the whole text of the value, not its first token: `300 t` is two) */
                char *endp = NULL;
                (void)strtod(teq, &endp);
                while (endp && (*endp == ' ' || *endp == '\t')) endp++;
+               /* <number>[ <unit of temperature>]: whatever follows the number must convert as a temperature unit by itself
+                * (a character-class check let `300-2*t` and `300*t` through as "a number with a unit") */
                int ok = endp && endp != teq;
-               for (const char *q = endp; ok && q && *q; q++)
-                  if (!((*q >= 'A' && *q <= 'Z') || (*q >= 'a' && *q <= 'z') || *q == '_' || *q == '^' || *q == '*' || *q == '/' || *q == '-' || (*q >= '0' && *q <= '9') || *q == ' ')) ok = 0;
+               if (ok && *endp)
+               {
+                  size_t L = strlen(endp);
+                  while (L > 0 && (endp[L - 1] == ' ' || endp[L - 1] == '\t' || endp[L - 1] == ';')) endp[--L] = 0;
+                  if (L > 0)
+                  {
+                     const double one = units_convert(1.0, endp, "T");
+                     ok = (one == one) && one > 0.0 && (*endp != '-' && *endp != '+' && *endp != '*' && *endp != '/' && *endp != '^');
+                  }
+               }
                if (!ok) { free(teq); free(type); FAIL("GROUP %s: Teq is not a constant temperature (an equation of time: set the value step by step with ddcmi_set_group_temperature)", gnames[g]); }
                free(teq);
             }
             object_get(go, "Teq", &s->group_Teq[g], WITH_UNITS, 1, "0.0", "T", NULL);
             object_get(go, "tau", &s->group_tau[g], WITH_UNITS, 1, "1.0", "t", NULL);
             object_get(go, "vcm", &s->group_vcm[3 * g], WITH_UNITS, 3, "0.0 0.0 0.0", "l/t", NULL);      /* langevin.c:167 */
+            {
+               /* langevin.c:71-79: GLOBAL_ENERGY steers Teq from the system's energy every step -- not a constant temperature either */
+               char *dyn = get_string(go, "Teq_dynamics", "EXPLICIT_TIME");
+               const int explicit_time = strcmp(dyn, "EXPLICIT_TIME") == 0;
+               free(dyn);
+               if (!explicit_time) { free(type); FAIL("GROUP %s: Teq_dynamics other than EXPLICIT_TIME is not supported (langevin.c:74-79 steers the temperature from the global energy)", gnames[g]); }
+            }
          }
          else s->group_type[g] = DDCMI_GROUP_OTHER;
          free(type);

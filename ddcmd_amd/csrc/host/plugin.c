@@ -119,7 +119,13 @@ ACCELERATOR *accelerator_init(void *parent, const char *name, const char *type)
    ddcmi_ctx *ctx = NULL;
    /* one GPU per rank (LOCAL_RANK) unless the ranks are told to share one (tests on a one-GPU box) */
    int dev = (par.world > 1 && !env_int("DDCMI_SINGLE_DEVICE", 0)) ? par.local_rank : 0;
-   { const int ndev = ddcmi_device_count(); if (ndev > 0 && dev >= ndev) dev %= ndev; }      /* (a launcher that shows every rank ONE device: ordinal 0 there) */
+   {
+      /* a launcher that shows every rank exactly ONE device: ordinal 0 there.  Fewer devices than ranks otherwise is an error, not a
+       * reason to put two ranks on one GPU silently (a bogus scaling number in the making) */
+      const int ndev = ddcmi_device_count();
+      if (ndev == 1) dev = 0;
+      else if (ndev > 1 && dev >= ndev && !getenv("DDCMI_DEVICE")) die("accelerator_init", "LOCAL_RANK is beyond the visible devices: start one rank per GPU (or set DDCMI_SINGLE_DEVICE=1 / DDCMI_DEVICE for tests that share one)");
+   }
    const char *env = getenv("DDCMI_DEVICE");
    if (env) dev = atoi(env);
    if (ddcmi_create(&ctx, dev) != DDCMI_OK) die("accelerator_init", ddcmi_last_error(NULL));

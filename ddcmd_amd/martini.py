@@ -97,8 +97,8 @@ def _declare(lib):
     lib.ddcmi_rdzv_allreduce_f64.argtypes = [vp, _dp, ctypes.c_int, ctypes.c_int]
     lib.ddcmi_rdzv_allgather.argtypes = [vp, vp, vp, szt]
     lib.ddcmi_rdzv_exchange.argtypes = [vp, ctypes.c_int, _ip, ctypes.POINTER(vp), ctypes.POINTER(szt), ctypes.c_int, _ip, ctypes.POINTER(vp), ctypes.POINTER(szt)]
-    lib.ddcmi_plan_recv_counts.argtypes = [ctypes.c_int] * 6 + [_ip, _ip]
-    lib.ddcmi_plan_halo_layout.argtypes = [ctypes.c_int] * 6 + [_ip, _ip, _ip, _ip, _ip, _ip]
+    lib.ddcmi_domain_bounds.argtypes = [vp, _dp, _dp]
+    lib.ddcmi_download_particles.argtypes = [vp, ctypes.c_int, _ip, _up, _ip] + [_dp] * 9
     lib._ddcmi_declared = True
 
 
@@ -182,9 +182,10 @@ class Rendezvous(object):
 
 
 def plan_recv_counts(grid, rank, pbc, all_counts, loopback=False):
-    """recv_cnt[27] from the all-gathered send counts [nranks, 27] (host logic of libddcmi)"""
-    lib = _lib.load_library()
+    """recv_cnt[27] from the all-gathered send counts [nranks, 27] (host logic of libddcmi; test API: libddcmi_test.so)"""
+    lib = _lib.load_test_library()
     _declare(lib)
+    _declare_domains(lib)
     ac = np.ascontiguousarray(all_counts, dtype=np.int32)
     out = np.zeros(27, np.int32)
     rc = lib.ddcmi_plan_recv_counts(grid[0], grid[1], grid[2], int(rank), int(pbc), int(loopback), _i(ac), _i(out))
@@ -195,9 +196,10 @@ def plan_recv_counts(grid, rank, pbc, all_counts, loopback=False):
 
 def plan_halo_layout(grid, rank, pbc, send_cnt, recv_cnt, loopback=False):
     """(send_off[28], recv_off[28], send messages [(peer, off, cnt)], receive messages) of the per-step halo
-    exchange: libddcmi's own peer-major layout (ddcmi_multigpu.inl plan_halo_layout)"""
-    lib = _lib.load_library()
+    exchange: libddcmi's own peer-major layout (ddcmi_multigpu.inl plan_halo_layout; test API: libddcmi_test.so)"""
+    lib = _lib.load_test_library()
     _declare(lib)
+    _declare_domains(lib)
     sc, rcn = np.ascontiguousarray(send_cnt, dtype=np.int32), np.ascontiguousarray(recv_cnt, dtype=np.int32)
     so, ro = np.zeros(28, np.int32), np.zeros(28, np.int32)
     ms, mr = np.zeros(1 + 3 * 27, np.int32), np.zeros(1 + 3 * 27, np.int32)
@@ -321,8 +323,9 @@ def molecule_lists(s):
 class MartiniHIP(object):
     """One device context running the Martini hot path for a Setup."""
 
-    def __init__(self, setup, device=0, upload=True, bonded_by_gid=False, constraints=False):
-        self.lib = _lib.load_library()
+    def __init__(self, setup, device=0, upload=True, bonded_by_gid=False, constraints=False, test_api=False):
+        # test_api: the context lives in libddcmi_test.so (same objects + the entry points of include/ddcmi_test.h)
+        self.lib = _lib.load_test_library() if test_api else _lib.load_library()
         _declare(self.lib)
         self.s = setup
         self.ctx = ctypes.c_void_p()
@@ -574,12 +577,13 @@ class MartiniHIP(object):
 
 
 def _declare_domains(lib):
+    """the test-only entry points (include/ddcmi_test.h): lib is the handle of libddcmi_test.so"""
     if getattr(lib, "_ddcmi_dom_declared", False):
         return
     vp = ctypes.c_void_p
     lib.ddcmi_plan_directions.argtypes = [ctypes.c_int] * 5 + [_ip, _ip]
-    lib.ddcmi_domain_bounds.argtypes = [vp, _dp, _dp]
-    lib.ddcmi_download_particles.argtypes = [vp, ctypes.c_int, _ip, _up, _ip] + [_dp] * 9
+    lib.ddcmi_plan_recv_counts.argtypes = [ctypes.c_int] * 6 + [_ip, _ip]
+    lib.ddcmi_plan_halo_layout.argtypes = [ctypes.c_int] * 6 + [_ip, _ip, _ip, _ip, _ip, _ip]
     lib.ddcmi_group_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.ddcmi_group_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.ddcmi_group_eval_forces.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
@@ -589,8 +593,8 @@ def _declare_domains(lib):
 
 
 def plan_directions(px, py, pz, rank, pbc=7):
-    """(dest[27], shift[27,3]) of the 26 neighbour directions (host logic, no GPU needed)."""
-    lib = _lib.load_library()
+    """(dest[27], shift[27,3]) of the 26 neighbour directions (host logic, no GPU needed; test API: libddcmi_test.so)."""
+    lib = _lib.load_test_library()
     _declare(lib)
     _declare_domains(lib)
     dest = np.zeros(27, np.int32)
@@ -624,7 +628,6 @@ class DomainMixin(object):
     """gid-addressed download for decomposed runs"""
 
     def download_particles(self):
-        _declare_domains(self.lib)
         cap = int(self.lib.ddcmi_nlocal(self.ctx)) + 16
         n = ctypes.c_int(0)
         gid = np.zeros(cap, np.uint64)
@@ -642,8 +645,8 @@ class DomainMixin(object):
 class MartiniRank(MartiniHIP, DomainMixin):
     """One rank of a decomposed run: uploads only the beads `index` selects."""
 
-    def __init__(self, setup, index, device=0, constraints=False):
-        MartiniHIP.__init__(self, setup, device=device, upload=False, bonded_by_gid=True, constraints=constraints)
+    def __init__(self, setup, index, device=0, constraints=False, test_api=False):
+        MartiniHIP.__init__(self, setup, device=device, upload=False, bonded_by_gid=True, constraints=constraints, test_api=test_api)
         self.index = np.asarray(index)
 
     def upload_local(self):
@@ -683,7 +686,7 @@ class MartiniGroup(object):
         self.grid = tuple(grid)
         self.n = grid[0] * grid[1] * grid[2]
         owner = domain_of(setup, grid)
-        self.ranks = [MartiniRank(setup, select_rank(setup, owner, r), device=device, constraints=constraints) for r in range(self.n)]
+        self.ranks = [MartiniRank(setup, select_rank(setup, owner, r), device=device, constraints=constraints, test_api=True) for r in range(self.n)]
         self.lib = self.ranks[0].lib
         _declare_domains(self.lib)
         self.arr = (ctypes.c_void_p * self.n)(*[r.ctx for r in self.ranks])

@@ -248,11 +248,6 @@ int ddcmi_timing_read(ddcmi_ctx *ctx, int64_t *launches, double *total_ms, int r
  * print steps ddcmi_step_nglf runs BACK kick, kinetic_terms, FRONT kick and drift (nglf.c:74-104) inside the pair kernel when
  * the force is complete at the end of the list walk (no bonded terms, restraints, constraints, barostat, charges) */
 int ddcmi_timing_fused(ddcmi_ctx *ctx, int64_t *launches, double *total_ms);
-/* census of the rarely taken branches of the dihedral code since the last reset (bioCharmmCovalentEnergiesSorted.c:649-683,
- * 793-810): [0] torsion series (|sin phi| <= 1e-8), of these [1] delta < 1 deg, [2] delta > 179 deg, [3] any other delta;
- * [4] improper series; [5] improper difference wrapped by 2 pi; [6] cos phi clamped.  Counted per evaluation (a term is
- * evaluated once per atom it has).  Test aid: shows that a test's geometry really drives those branches. [sync] */
-int ddcmi_debug_branch_census(unsigned long long out[8], int reset);
 /* native stream handle (hipStream_t) for callers that time with their own events */
 void *ddcmi_stream(ddcmi_ctx *ctx);
 
@@ -296,40 +291,15 @@ int ddcmi_rdzv_exchange(ddcmi_rdzv *h, int nsend, const int *send_peer, const vo
  * on a device: tests on a single-GPU box) and for nodes without working GPU peer access; rank and
  * size come from the rendezvous, which must outlive the context. */
 int ddcmi_comm_init_host(ddcmi_ctx *ctx, ddcmi_rdzv *rdzv, int px, int py, int pz);
-/* Host logic of the halo exchange (ddcSendRecvTables, ddcSendRecv.c:126-225), callable without a GPU.
- * ddcmi_plan_recv_counts: from the all-gathered per-direction send counts all_counts[nranks][27], what
- * this rank receives: recv_cnt[c] = what the rank in my direction opp(c) sends along ITS direction c.
- * ddcmi_plan_halo_layout: buffer layout (in beads) and message list of the per-step exchange -- remote
- * segments ordered by (peer rank, direction code) on both sides, so that each peer pair exchanges ONE
- * message: send_off/recv_off[28] = offset of direction c's segment (send: my direction; receive: the
- * SENDER's direction); msgs[0] = number of send messages, then {peer, offset, count} triples;
- * msgr likewise for the receives (room for 1 + 3*27 ints each).  loopback != 0: a single rank whose
- * periodic neighbours are itself exchanges with itself through the transport (test facility). */
-int ddcmi_plan_recv_counts(int px, int py, int pz, int rank, int pbc, int loopback, const int *all_counts, int *recv_cnt);
-int ddcmi_plan_halo_layout(int px, int py, int pz, int rank, int pbc, int loopback, const int send_cnt[27], const int recv_cnt[27],
-                           int send_off[28], int recv_off[28], int *msgs, int *msgr);
 /* Call order with decomposition: ddcmi_set_box -> ddcmi_comm_init -> set_* ->
  * ddcmi_upload_state with THIS rank's local beads (any beads inside the box are
  * accepted; the first rebuild migrates them to their owners, ddcAssignment.c) */
-/* host logic of the decomposition (domain.c:61-208 for a cubic lattice of domain
- * centres): destination rank and periodic shift of the 26 neighbour directions,
- * code = (dx+1)+3(dy+1)+9(dz+1); dest[27], shift[27*3]; dest = -1 where the box is open */
-int ddcmi_plan_directions(int px, int py, int pz, int rank, int pbc, int *dest, int *shift);
 int ddcmi_domain_bounds(const ddcmi_ctx *ctx, double lo[3], double hi[3]);
 /* current local beads in device order, identified by gid (beads migrate between
  * ranks; ddcMD identifies them by label).  Pointers may be NULL. [sync] */
 int ddcmi_download_particles(ddcmi_ctx *ctx, int cap, int *nout, uint64_t *gid, int *species,
                              double *rx, double *ry, double *rz, double *vx, double *vy, double *vz,
                              double *fx, double *fy, double *fz);
-/* in-process emulation of a px*py*pz decomposition (several contexts on one
- * device, halo/migration traffic by device copies): lets the whole multi-domain
- * path run on a single GPU.  Contexts of a group are driven only through these. */
-int ddcmi_group_create(ddcmi_ctx **ctxs, int n, int px, int py, int pz);
-int ddcmi_group_destroy(ddcmi_ctx **ctxs, int n);
-int ddcmi_group_eval_forces(ddcmi_ctx **ctxs, int n);
-int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nsteps);
-/* ddcmi_group_temperatures for an in-process group (sums over its domains) */
-int ddcmi_group_temperatures_all(ddcmi_ctx **ctxs, int n, double *Tgroup);
 
 #ifdef __cplusplus
 }

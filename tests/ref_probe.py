@@ -1,10 +1,12 @@
 """Child process of tests/test_ref_pinned.py: the ONLY process that maps oracle/_ref/libddcmd_ref_small.so (the reference's own
-crc32.c / primes.c / format.c, compiled where they lie by oracle/Makefile).  The reference's code is untrusted content: it runs
+crc32.c / primes.c / format.c / solve.c, compiled where they lie by oracle/Makefile, target `ref`).  The reference's code is untrusted content: it runs
 here, in a short-lived child, and hands back plain numbers as one JSON line -- never inside the pytest process.
 
    python tests/ref_probe.py crc                 checksum_crc32_table / checksum_crc32 of the test's deterministic records
    python tests/ref_probe.py primes TASK NTASKS  prime_init(30000, task, ntasks), 700 x nextPrime()
-   python tests/ref_probe.py formats             loopFormatInit(12), gidFormatInit("decimal")"""
+   python tests/ref_probe.py formats             loopFormatInit(12), gidFormatInit("decimal")
+   python tests/ref_probe.py solve < systems     solve(n, a, b, x) (solve.c:3-28: scaled partial pivoting, the linear solve of
+                                                 solveConstraintMatrix, nglfconstraint.c:161) for a JSON list of [n, a (row-major), b]"""
 import ctypes
 import json
 import os
@@ -35,6 +37,17 @@ def main():
         L.prime_init.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
         L.prime_init(30000, int(sys.argv[2]), int(sys.argv[3]))
         out = [int(L.nextPrime()) for _ in range(700)]
+    elif what == "solve":
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.solve.restype = None
+        L.solve.argtypes = [ctypes.c_int, dp, dp, dp]
+        out = []
+        for n, a, b in json.load(sys.stdin):
+            a = np.array(a, dtype=np.float64).reshape(n, n).copy()      # (solve overwrites a and b)
+            b = np.array(b, dtype=np.float64).copy()
+            x = np.zeros(n)
+            L.solve(int(n), a.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp))
+            out.append(x.tolist())
     else:
         L.loopFormat.restype = ctypes.c_char_p
         L.gidFormat.restype = ctypes.c_char_p

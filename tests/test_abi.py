@@ -41,6 +41,37 @@ def test_device_library_exports_nothing_but_the_declared_c_abi(built):
     assert "libddcmi.so" in deps                      # the host layer reaches the device through the C-ABI like any other client
 
 
+def test_test_only_entry_points_live_in_a_second_library(built):
+    """ddcmi_group_* (in-process domain groups), ddcmi_plan_* (the halo planner's host logic) and
+    ddcmi_debug_branch_census shipped in libddcmi.so's export table.  They are declared in include/ddcmi_test.h now and exported by
+    libddcmi_test.so only -- a second link of the SAME objects with a wider version script -- so the drop-in library exports the
+    plugin surface + comm and nothing else, while the tests that need the extra entry points still run the product's kernels."""
+    import subprocess
+    prod = _declared_functions(os.path.join(ROOT, "include", "ddcmi.h"))
+    extra = _declared_functions(os.path.join(ROOT, "include", "ddcmi_test.h"))
+    assert extra and not (set(prod) & set(extra))
+    assert all(n.startswith(("ddcmi_group_", "ddcmi_plan_", "ddcmi_debug_")) for n in extra), extra
+    assert not [n for n in prod if n.startswith(("ddcmi_plan_", "ddcmi_debug_")) or (n.startswith("ddcmi_group_") and n != "ddcmi_group_temperatures")]
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.TEST_LIB_PATH], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == sorted(prod + extra)
+    # the same device code: both libraries are links of the same objects (the gfx950 code objects are byte for byte alike)
+    def code_objects(path):
+        import hashlib
+        for line in subprocess.check_output(["readelf", "-S", "-W", path], text=True).splitlines():
+            f = line.replace("[", " ").replace("]", " ").split()
+            if len(f) > 5 and f[1] == ".hip_fatbin":
+                off, size = int(f[4], 16), int(f[5], 16)
+                with open(path, "rb") as fh:
+                    fh.seek(off)
+                    return size, hashlib.sha256(fh.read(size)).hexdigest()
+        return None
+    assert code_objects(_lib.LIB_PATH) is not None and code_objects(_lib.LIB_PATH)[0] > 100000
+    assert code_objects(_lib.LIB_PATH) == code_objects(_lib.TEST_LIB_PATH)
+    tl = _lib.load_test_library()
+    assert all(hasattr(tl, n) for n in extra)
+
+
 def test_links_beside_definitions_of_ddcmds_own_names(built, tmp_path):
     """a program that defines nglf, ddcenergy, kinetic_terms, object_get, units_convert ... with the reference's signatures links
     with -lddcmi alone, reaches its own definitions, and the library never calls them (tests/abi/link_with_ddcmd_names.c; the

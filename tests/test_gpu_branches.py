@@ -52,7 +52,7 @@ def test_dihedral_series_branches_are_driven_and_match():
         o.rx[m], o.ry[m], o.rz[m] = x[:, 0], x[:, 1], x[:, 2]
     s.rx, s.ry, s.rz = o.rx.copy(), o.ry.copy(), o.rz.copy()
     e0, v0 = o.forces()
-    dev = MartiniHIP(s)
+    dev = MartiniHIP(s, test_api=True)
     census(dev)
     e, vir = dev.eval_forces()
     c = census(dev)
@@ -80,7 +80,7 @@ def test_dihedral_series_branches_are_driven_and_match():
     o2 = pyoracle.Oracle(s)
     e0, v0 = o2.forces()
     dev.close()
-    dev = MartiniHIP(s)
+    dev = MartiniHIP(s, test_api=True)
     census(dev)
     e, vir = dev.eval_forces()
     c = census(dev)
@@ -93,7 +93,7 @@ def test_dihedral_series_branches_are_driven_and_match():
 
 
 def _fd_check(s, atoms, h, tol):
-    dev = MartiniHIP(s)
+    dev = MartiniHIP(s, test_api=True)
     dev.eval_forces()
     f0 = np.stack(dev.download()["f"])
     fmax = np.abs(f0).max()
@@ -130,7 +130,7 @@ def test_device_virial_is_the_volume_derivative_of_the_device_energy():
         if s is None:
             from ddcmd_amd.synth import make_water_setup
             s = make_water_setup(6)
-        dev = MartiniHIP(s)
+        dev = MartiniHIP(s, test_api=True)
         e, vir = dev.eval_forces()
         dev.close()
         tr = vir[0] + vir[1] + vir[2]
@@ -140,7 +140,7 @@ def test_device_virial_is_the_volume_derivative_of_the_device_energy():
             s2 = copy.copy(s)
             s2.h = np.asarray(s.h) * lam
             s2.rx, s2.ry, s2.rz = np.asarray(s.rx) * lam, np.asarray(s.ry) * lam, np.asarray(s.rz) * lam
-            d2 = MartiniHIP(s2)
+            d2 = MartiniHIP(s2, test_api=True)
             en = d2.eval_forces()[0]["total"]
             d2.close()
             return en
@@ -155,7 +155,7 @@ def test_device_against_closed_forms():
     s.excludePotentialTerm = 128
     mols, rt = tstm_molecules(s)
     rng = np.random.default_rng(11)
-    dev = MartiniHIP(s)
+    dev = MartiniHIP(s, test_api=True)
     e0, _ = dev.eval_forces()
     m = mols[3]
     x0 = np.stack([s.rx[m], s.ry[m], s.rz[m]], axis=1)
@@ -175,7 +175,7 @@ def test_device_against_closed_forms():
     dev.close()
     for r_A in (4.3, 5.2, 8.9, 9.5):
         s, r, d = charged_pair_setup(r_A)
-        dev = MartiniHIP(s)
+        dev = MartiniHIP(s, test_api=True)
         e, vir = dev.eval_forces()
         f = dev.download()["f"]
         dev.close()

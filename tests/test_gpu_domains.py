@@ -269,7 +269,7 @@ def test_index_based_npt_and_constraints_are_refused_on_several_domains(monkeypa
     from ddcmd_amd.martini import MartiniHIP, MartiniRank, _declare_domains
     s = make_water_setup(10)
     s.npt_T, s.npt_P0, s.npt_beta, s.npt_tau = 1e-3, 0.0, 1e-3, 1000.0
-    a, b = MartiniHIP(s, upload=False), MartiniHIP(s, upload=False)          # molecule lists by index
+    a, b = MartiniHIP(s, upload=False, test_api=True), MartiniHIP(s, upload=False, test_api=True)          # molecule lists by index (contexts of libddcmi_test.so: groups are test API)
     _declare_domains(a.lib)
     arr = (ctypes.c_void_p * 2)(a.ctx, b.ctx)
     assert a.lib.ddcmi_group_create(arr, 2, 2, 1, 1) == -4                   # DDCMI_EUNSUPPORTED
@@ -279,7 +279,6 @@ def test_index_based_npt_and_constraints_are_refused_on_several_domains(monkeypa
     # RCCL path, one rank in loopback mode is still ONE domain: accepted
     monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
     m = MartiniRank(s, np.arange(s.natoms))
-    _declare_domains(m.lib)
     buf = ctypes.create_string_buffer(128)
     assert m.lib.ddcmi_comm_unique_id(buf) == 0
     m.comm_init(0, 1, buf.raw, (1, 1, 1))

@@ -96,9 +96,9 @@ def test_single_bead_and_isolated_beads():
     m.close()
 
 
-@pytest.mark.parametrize("n,nsteps", [(64, 40), (100, 40)])
+@pytest.mark.parametrize("n,nsteps", [(64, 40), (102, 40)])
 def test_full_size_properties(n, nsteps):
-    """1.05 M and 4.0 M beads: Newton's third law, symmetric list, energy conservation over two
+    """1.05 M and 4.24 M beads (the headline box, bench.py HEADLINE_N): Newton's third law, symmetric list, energy conservation over two
     rebuilds, kinetic tensor trace = 2 rk -- properties that need no oracle run"""
     from ddcmd_amd.martini import MartiniHIP
     s = make_water_setup(n)
@@ -153,9 +153,9 @@ def test_decomposition_consistent_at_1M():
 
 @pytest.fixture(scope="module")
 def water_4M_single():
-    """the headline box after 45 steps on one domain: energies, kinetic energy, virial"""
+    """the headline box (FCC n = 102: 4 244 832 beads) after 45 steps on one domain: energies, kinetic energy, virial"""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(100)
+    s = make_water_setup(102)
     m = MartiniHIP(s)
     m.eval_forces()
     m.step(45)
@@ -166,7 +166,7 @@ def water_4M_single():
 
 @pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
 def test_bench_decompositions_at_4M(water_4M_single, grid):
-    """the bricks bench.py --gpus 2/4/8 uses, on the 4.0 M-bead box itself (emulated domains on one GPU):
+    """the bricks bench.py --gpus 2/4/8 uses, on the 4.24 M-bead headline box itself (emulated domains on one GPU):
     same energies, kinetic energy and virial as the single domain after 45 steps (3 rebuilds with migration),
     no bead lost -- the buffer sizes, halo tables and migration of the multi-GPU runs at their real sizes"""
     from ddcmd_amd.martini import MartiniGroup
@@ -182,15 +182,16 @@ def test_bench_decompositions_at_4M(water_4M_single, grid):
     g.close()
 
 
-def _copies_vs_oracle(reps, decomposed):
-    """The 62.5 k-bead water box (BASELINE configs[1], the size the oracle runs every step in seconds) tiled reps times is the same
+def _copies_vs_oracle(reps, decomposed, base=25):
+    """The 62.5 k-bead water box (BASELINE configs[1], the size the oracle runs every step in seconds; base = 17: 19.7 k beads, whose
+    6x6x6 tiling is the n = 102 headline box) tiled reps times is the same
     periodic system at the size the bench times: EVERY copy of EVERY bead must feel the force the oracle computes for the small
     box, energies and virial scale with the copy count, and after 25 steps -- across the rebuild at step 20 -- every copy sits
     where the oracle's bead sits, with its velocity."""
     import pyoracle
     from ddcmd_amd.synth import replicate_setup
     from ddcmd_amd.martini import MartiniHIP, MartiniGroup
-    s0 = make_water_setup(25)
+    s0 = make_water_setup(base)
     o = pyoracle.Oracle(s0)
     e0, v0 = o.forces()
     ref = np.stack([o.fx, o.fy, o.fz])[:, None, :].copy()
@@ -230,15 +231,15 @@ def _copies_vs_oracle(reps, decomposed):
     m.close()
 
 
-@pytest.mark.parametrize("reps", [(4, 4, 4), (4, 2, 2)])
-def test_water_at_bench_sizes_per_bead_against_the_oracle(reps):
-    """4.0 M beads (the headline config) and 1.0 M beads (configs[2]) on one domain"""
-    _copies_vs_oracle(reps, False)
+@pytest.mark.parametrize("reps,base", [((6, 6, 6), 17), ((4, 2, 2), 25)])
+def test_water_at_bench_sizes_per_bead_against_the_oracle(reps, base):
+    """4 244 832 beads (the headline config: the n = 17 box tiled 6x6x6 has exactly the n = 102 box's edge and bead count) and 1.0 M beads (configs[2]) on one domain"""
+    _copies_vs_oracle(reps, False, base)
 
 
 def test_water_4M_on_eight_domains_per_bead_against_the_oracle():
-    """the same at 4.0 M beads on the 2x2x2 bricks of bench.py --gpus 8 (emulated domains on one GPU)"""
-    _copies_vs_oracle((4, 4, 4), True)
+    """the same at the headline size on the 2x2x2 bricks of bench.py --gpus 8 (emulated domains on one GPU)"""
+    _copies_vs_oracle((6, 6, 6), True, 17)
 
 
 def test_lipid_bilayer_2M_beads_periodic_copies():

@@ -595,3 +595,14 @@ def test_langevin_drift_velocity_closed_form():
     assert np.allclose(d.group_vcm[3 * g:3 * g + 3], np.array([0.001, 0.0, -0.002]) * units_convert(1.0, "Angstrom/fs"), rtol=1e-12)
     with pytest.raises(Exception, match="not a constant temperature"):
         load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = 300+10*t; tau = 1 ps; }")
+    # tails made of unit characters only (`300-2*t`, `300*t`, `300 t`) passed as "a number with a unit"
+    for eq in ("300-2*t", "300*t", "300 t", "300 K*t", "2*K"):
+        with pytest.raises(Exception, match="not a constant temperature"):
+            load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = %s; tau = 1 ps; }" % eq)
+    for const in ("310 K", "310", "0.001 eV/kB" if False else "310.5 K"):
+        d2 = load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = %s; tau = 1 ps; }" % const)
+        assert d2.group_Teq[list(d2.group_name).index("group")] > 0.0
+    # langevin.c:71-79: Teq_dynamics = GLOBAL_ENERGY is not a constant temperature either
+    with pytest.raises(Exception, match="Teq_dynamics"):
+        load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = 310 K; tau = 1 ps; Teq_dynamics = GLOBAL_ENERGY; }")
+    load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = 310 K; tau = 1 ps; Teq_dynamics = EXPLICIT_TIME; }")

@@ -14,6 +14,6 @@ for args in "$@"; do
    echo "### $args"
    for r in 1 2; do
       echo " default"; run $args
-      echo " $var=1"; env $var=1 python3 -c "pass"; export $var=1; run $args; unset $var
+      echo " $var=1"; export $var=1; run $args; unset $var
    done
 done

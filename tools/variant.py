@@ -58,9 +58,9 @@ def main():
     if any(p.wait() for p in procs): raise SystemExit("compile failed")
     out = os.path.join(ROOT, "tuning", "libddcmi_%s.so" % name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    host = [os.path.join(CSRC, "build", "host", "rdzv.o")]      # the device library = HIP objects + the rendezvous, same export map and soname as the tree's
+    host = [os.path.join(CSRC, "build", "host", "rdzv.o")]      # the device library = HIP objects + the rendezvous; the soname of the tree's, the WIDER export map (include/ddcmi.h + ddcmi_test.h): a tuning build serves every test
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + host + objs +
-                          ["-Wl,--version-script=" + os.path.join(CSRC, "build", "ddcmi.map"), "-Wl,-soname,libddcmi.so", "-L/opt/rocm/lib", "-lrccl", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
+                          ["-Wl,--version-script=" + os.path.join(CSRC, "build", "ddcmi_test.map"), "-Wl,-soname,libddcmi.so", "-L/opt/rocm/lib", "-lrccl", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
     print("built", out)
 
 
