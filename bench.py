@@ -92,6 +92,15 @@ def cpu_baseline(n_lattice, seconds_budget=18.0):
     return out
 
 
+def nonbond_is_fused(kernel_name):
+    """k_nonbond<HAS_Q, PACKED, SHBIT, threads, waves, CH, ZOFF, FUSE, LVL>: is FUSE true?"""
+    k = kernel_name.split("(")[0]
+    if "<" not in k or ">" not in k:
+        return False
+    a = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+    return len(a) >= 2 and a[-2] == "true"
+
+
 def live_traffic(extra_args, fused, timeout_s=240.0):
     """HBM bytes per launch of the pair kernel, MEASURED IN THIS RUN and IN THE STATE OF THE TIMED RUN (the passes used to
     sample a lattice start within six steps of a rebuild, where the shell-limited walk reads the fewest list bytes): two child runs of
@@ -100,7 +109,7 @@ def live_traffic(extra_args, fused, timeout_s=240.0):
     FETCH_SIZE reports half the bytes of wide coalesced streaming reads on gfx950 and is doubled.  Only the launches of the child's
     timed windows are averaged (the last MIN_TIMED_STEPS steps' launches by dispatch order: whole rebuild periods, every age of the
     list).  Fresh child processes (never an exec of this one); None if the profiler is not there or a pass fails.
-    fused: price the launches whose epilogue is the integrator's pass (kernel name ends `true>`)."""
+    fused: price the launches whose epilogue is the integrator's pass (k_nonbond<..., FUSE, LVL>: the template's last argument but one)."""
     import csv
     import glob
     import shutil
@@ -128,7 +137,7 @@ def live_traffic(extra_args, fused, timeout_s=240.0):
             for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(fn)):
                     if "k_nonbond" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                        rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"].split("(")[0].rstrip().endswith("true>"), float(row["Counter_Value"])))
+                        rows.append((int(row["Dispatch_Id"]), nonbond_is_fused(row["Kernel_Name"]), float(row["Counter_Value"])))
             rows.sort()
             # the timed windows are the child's last MIN_TIMED_STEPS force evaluations (one pair launch each on a single domain)
             rows = rows[-MIN_TIMED_STEPS:]
@@ -168,10 +177,10 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
-def build_setup(workload, n, reps):
+def build_setup(workload, n, reps, types=0):
     import ddcmd_amd
     if workload == "water":
-        s = ddcmd_amd.make_water_setup(n)
+        s = ddcmd_amd.make_water_setup(n, density_scale=float(os.environ.get("DDCMI_BENCH_DENSITY_SCALE", "1.0")))      # (the variable: kernel-tuning experiments only)
         return s, "martini_water_%dk_beads" % (s.natoms // 1000), "fcc", n
     from ddcmd_amd.deck import load_deck
     from ddcmd_amd.synth import replicate_setup
@@ -179,15 +188,21 @@ def build_setup(workload, n, reps):
     deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
     # 310 K restart relaxed by tests/golden/make_lipid_relaxed.py, Berendsen group (Teq 310 K, tau 1 ps)
     s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), r3)
+    if types:
+        # the same physics under `types` LJ types (every type split into copies of itself, each bead's copy drawn at random): the size of
+        # the pair kernel's class table is what changes (bioMartini.c:868-950 builds nspecies^2 entries; a real Martini deck has ~40 types)
+        from ddcmd_amd.synth import relabel_types
+        s = relabel_types(s, types)
+        return s, "martini_lipid_bilayer_%dk_beads_%d_types" % (s.natoms // 1000, types), "deck tiled %s, %d LJ types" % (reps, types), None
     return s, "martini_lipid_bilayer_%dk_beads" % (s.natoms // 1000), "deck tiled %s" % reps, None
 
 
-def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank, rdzv, transport, loopback):
+def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank, rdzv, transport, loopback, types=0):
     """one workload on this launch's ranks: equilibration, warm-up, then the timed windows.  Returns the pieces of the JSON line."""
     import numpy as np
     import ddcmd_amd
     from ddcmd_amd.martini import MartiniHIP, MartiniRank, domain_of
-    s, wname, lattice, lattice_n = build_setup(workload, n, reps)
+    s, wname, lattice, lattice_n = build_setup(workload, n, reps, types)
     dt_fs = float(ddcmd_amd.units_convert(s.dt, None, "fs"))
     grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
     if grid is None:
@@ -400,6 +415,7 @@ def main():
                          "all bonded term kinds, charges, Berendsen) tiled --reps times")
     ap.add_argument("--rccl-loopback", action="store_true",
                     help="N=1 only: reach the periodic images through a 1-rank RCCL communicator (the multi-GPU transport on one GPU)")
+    ap.add_argument("--types", type=int, default=0, help="lipid workload: relabel the beads to this many LJ types (same physics, bigger class table; 0: the deck's own 6)")
     ap.add_argument("--reps", default="12,12,6", help="lipid workload: copies of the 2363-bead deck along x,y,z (12,12,6 -> 2.04M beads)")
     ap.add_argument("--equil", type=int, default=-1,
                     help="untimed steps in front of the warm-up that take the synthetic water box from its lattice start (50 K, FCC + jitter) to its "
@@ -481,7 +497,7 @@ def main():
             rdzv.close()
         return
 
-    res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback)
+    res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback, args.types)
     out = {
         "metric": "atom_steps_per_sec", "value": res.pop("value"), "unit": "atom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -498,10 +514,12 @@ def main():
         under_prof = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
         for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps", pmc=["--lattice", "64"]),
                    dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen", pmc=["--workload", "lipid", "--reps", args.reps]),
+                   dict(workload="lipid", n=None, loopback=False, types=20, tag="the same bilayer under 20 LJ types (every type split into copies of itself): the class table of a mid-size Martini deck", pmc=None),
+                   dict(workload="lipid", n=None, loopback=False, types=40, tag="the same bilayer under 40 LJ types / 48 (type, charge) classes: the pair table in two levels (k_nonbond<LVL>)", pmc=None),
                    dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=None),
                    dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
             try:
-                r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"])
+                r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0))
                 if kw["pmc"] and not args.no_pmc and not under_prof:
                     # the row's own HBM bytes, measured live like the headline's
                     lt = live_traffic(kw["pmc"], r["roofline"].get("dominant_is_fused", False))

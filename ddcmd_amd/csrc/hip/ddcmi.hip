@@ -473,6 +473,8 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->device = device;
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
    ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
+   ctx->no_direct_halo = getenv("DDCMI_NO_DIRECT_HALO") != nullptr;
+   ctx->force_lvl = getenv("DDCMI_FORCE_LEVEL_TABLE") != nullptr;
    /* test hook, armed only together with DDCMI_DEBUG_HOOKS=1 (a stray value alone does nothing; read per context: a test sets it between two of them) */
    ctx->debug_image_bound = (getenv("DDCMI_DEBUG_HOOKS") && getenv("DDCMI_DEBUG_IMAGE_BOUND")) ? atoi(getenv("DDCMI_DEBUG_IMAGE_BOUND")) : 0;
    /* the small host-side count arrays inside the context (migration / halo counts) become DMA targets */
@@ -508,6 +510,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (!ctx) return;
    (void)hipSetDevice(ctx->device);
    (void)hipStreamSynchronize(ctx->stream);
+   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);      /* (an interior search a failed rebuild left behind reads the buffers released below) */
    if (ctx->ph_on > 0)
       for (int k = 0; k < 32; k++)
          if (ctx->ph_cnt[k]) fprintf(stderr, "ddcmi phase %2d %-28s %8.1f us x %ld\n", k, ctx->ph_name[k], ctx->ph_sum[k] / ctx->ph_cnt[k], ctx->ph_cnt[k]);
@@ -521,6 +524,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->horder, &ctx->halo_src, &ctx->halo_shift, &ctx->scan_tmp, &ctx->nbr_cnt, &ctx->excl, &ctx->excl_cnt,
                       &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched, &ctx->tile_perm};
    for (auto b : ib) b->release();
+   ctx->d_lvltab.release(); ctx->d_lvlidx.release();
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->atom_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->cg_dist, &ctx->inc_bpar, &ctx->inc_apar, &ctx->inc_tpar}) b->release();
@@ -533,6 +537,8 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->ev_drift) (void)hipEventDestroy(ctx->ev_drift);
    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
    if (ctx->ev_build) (void)hipEventDestroy(ctx->ev_build);
+   if (ctx->ev_sorted) (void)hipEventDestroy(ctx->ev_sorted);
+   if (ctx->ev_interior) (void)hipEventDestroy(ctx->ev_interior);
    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
    if (ctx->stream_post) { (void)hipStreamSynchronize(ctx->stream_post); (void)hipStreamDestroy(ctx->stream_post); }
    if (ctx->d_results) (void)hipFree(ctx->d_results);
@@ -650,6 +656,29 @@ static int nb_tables(ddcmi_ctx *ctx)
          kq[(size_t)a * nnb + b] = ctx->keR * cls_q[a] * cls_q[b];
       }
    int rc;
+   {
+      /* the distinct entries (ddcmi_ctx::d_lvltab): compared bit for bit, in order of first appearance */
+      bool anyq = false;
+      for (double q : cls_q) anyq |= q != 0.0;
+      std::vector<double4> lv;
+      std::vector<unsigned char> idx((size_t)nnb * nnb);
+      ctx->nlvl = 0;
+      for (size_t k = 0; k < tab.size(); k++)
+      {
+         double4 e = tab[k];
+         if (anyq) e.w = kq[k];      /* (the charged kernel forms 24 eps = 6 x 4 eps itself: its fourth word is ke/eps_r q_a q_b) */
+         size_t f = 0;
+         for (; f < lv.size(); f++) if (memcmp(&lv[f], &e, sizeof(e)) == 0) break;
+         if (f == lv.size()) lv.push_back(e);
+         if (lv.size() > 256) break;
+         idx[k] = (unsigned char)f;
+      }
+      if (lv.size() <= 256)
+      {
+         if ((rc = upload_vec(ctx, ctx->d_lvltab, lv.data(), lv.size())) || (rc = upload_vec(ctx, ctx->d_lvlidx, idx.data(), idx.size()))) return rc;
+         ctx->nlvl = (int)lv.size();
+      }
+   }
    if ((rc = upload_vec(ctx, ctx->d_ljtab, tab.data(), tab.size())) || (rc = upload_vec(ctx, ctx->d_kqtab, kq.data(), kq.size())) ||
        (rc = upload_vec(ctx, ctx->d_ljtype_sp, nb.data(), nb.size()))) return rc;
    ctx->nnb = nnb;

@@ -89,6 +89,13 @@ struct NbTileArgs
    /* decomposed runs: D bounds the OWNED beads' moves only; hdisp (not null) points at the largest squared distance of a received
     * halo bead from its place at the rebuild (k_halo_update), and a pair distance has changed by at most D + max(D, sqrt(*hdisp)) */
    const double *hdisp;
+   /* decomposed runs, direct halo staging (ddcmi_ctx::halo_in_recv): received bead h = staged global index - nloc lies at
+    * hrecv3[3 k], k = -1 - halo_src[h] (the per-step exchange's receive buffer, sender's order); its record in pos[] carries the
+    * tag only.  Tiles that stage such beads walk their rows to the end (halo_full_walk): the displacement bound D covers this
+    * rank's beads, and nothing measures the neighbours' any more -- the shell-limited walk stays with the all-owned tiles. */
+   const double *hrecv3; const int *halo_src; int halo_full_walk;
+   /* k_nonbond<..., LVL>: the pair table in two levels (ddcmi_ctx::d_lvltab): lvlidx [nlj*nlj] = index of the class pair's entry among the nlvl distinct ones */
+   const unsigned char *lvlidx; int nlvl;
    /* bonded terms / restraints: their kernels ran first and left their force on every owned bead in fb (one 32-byte record per bead,
     * zero where a bead has none); the pair kernel adds the bead's pair force to it -- into fx, fy, fz (plain launch) or in registers,
     * in front of the integrator's pass (FUSE) -- and hands the record back zeroed for the next evaluation's bonded kernels */
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
                                                             const int *__restrict__ species,
                                                             int nmoltype, const int *moltype_sp, const int *mol_nspecies, const int *bpair_off,
                                                             const int *bpairI, const int *bpairJ, const unsigned long long *exmask,
-                                                            int maxexcl, unsigned short *excl16, int *excl_cnt, int *flags)
+                                                            int maxexcl, unsigned short *excl16, int *excl_cnt, int *flags, TileSel sel)
 {
    /* dynamic LDS only, so that the ring of accepted words starts at LDS address 0 (its address arithmetic is one and-or) */
    extern __shared__ float4 tb_smem[];
@@ -144,6 +151,16 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_build(GridParams gp, TileAr
    if ((unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)tb_smem != 0u) __builtin_trap();
 #define s_halo (*s_halo_p)
    int t = blockIdx.x;
+   if (sel.mode == 1)
+   {
+      const int b = (int)blockIdx.x, bx = b % sel.n[0], by = (b / sel.n[0]) % sel.n[1], bz = b / (sel.n[0] * sel.n[1]);
+      t = ((sel.lo[2] + bz) * gp.T[1] + (sel.lo[1] + by)) * gp.T[0] + (sel.lo[0] + bx);
+   }
+   else if (sel.mode == 2)
+   {
+      const int qx = t % gp.T[0] - sel.lo[0], qy = (t / gp.T[0]) % gp.T[1] - sel.lo[1], qz = t / (gp.T[0] * gp.T[1]) - sel.lo[2];
+      if (qx >= 0 && qx < sel.n[0] && qy >= 0 && qy < sel.n[1] && qz >= 0 && qz < sel.n[2]) return;      /* (searched by the interior launch) */
+   }
    int ts = ta.cell_start_o[TCELLS * t], te = ta.cell_start_o[TCELLS * t + TCELLS];
    int nown = te - ts;
    if (nown <= 0)

@@ -807,7 +807,7 @@ static int mg_phase2_migrate_in(ddcmi_ctx *ctx)
    ctx->sort_renumbers = true;      /* (the sort's first kernel numbers the beads: was a launch of its own) */
    /* sort the owned beads, then pick what each neighbour direction needs */
    if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;
-   return DDCMI_OK;
+   return bl_launch_interior(ctx);      /* the tiles that need nothing of the halo: searched while the halo is exchanged and sorted */
 }
 /* which owned beads does each neighbour direction need?  enqueue only */
 static int mg_halo_select_launch(ddcmi_ctx *ctx)
@@ -872,6 +872,8 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
    selfo.off[27] = nself;
    int nh = nself + ctx->nrecv;
    ctx->nhalo = nh;
+   ctx->nself_images = nself;
+   ctx->halo_in_recv = false;      /* (the rebuild places every halo bead in pos[] from the 5-wide records; the 3-wide receive buffer is stale) */
    ctx->hkey_valid = false;
    if (nh > 0)
    {

@@ -26,7 +26,7 @@
  *      shifted copies and excluded pairs (see below).
  * Bound: FP64 issue and LDS gathers behind s_waitcnt at 4 waves per SIMD -- DESIGN.md section 4 has the
  * counters, the ablations and the per-CU timelines. */
-template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF, bool FUSE>
+template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF, bool FUSE, bool LVL>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
                                                          const unsigned short *__restrict__ excl16, const int *__restrict__ excl_cnt,
@@ -47,7 +47,11 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    /* charges: a bead's "type" is its (LJ type, charge) class, so ke/eps_r q_i q_j is one more
     * per-type-pair table entry -- no per-bead charge array in LDS (it cost 8 B/bead: one
     * workgroup per CU instead of two) and no charge gather per pair */
-   unsigned char *T_s = (unsigned char *)(s_lj + ta.nlj * ta.nlj);
+   /* LVL: s_lj holds the DISTINCT entries of the pair table and L_s one byte per class pair (NbTileArgs::lvlidx) -- 40 Martini types are
+    * 1.6 KB + a few hundred bytes instead of 51 KB; one more (one-byte) LDS read per accepted pair */
+   const int ntab = LVL ? ta.nlvl : ta.nlj * ta.nlj;
+   unsigned char *L_s = (unsigned char *)(s_lj + ntab);
+   unsigned char *T_s = L_s + (LVL ? ((ta.nlj * ta.nlj + 15) & ~15) : 0);
    unsigned char *S_s = T_s + (PACKED ? 0 : ta.cap);      /* 1: the staged bead is a periodically shifted copy */
    /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
     * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
       while (smax >= 1 && sqrt(ta.sh_r0sq + (double)(smax - 1) * ta.sh_step) * (1.0 - 1e-4) - twoD > rc) smax--;
    }
    int nown = 0, ts = 0, r_lo = 0, r_hi = 0;
+   if (ta.halo_full_walk && mine && ((ta.tile_work[t] >> 30) & 1)) smax = NSHELL - 1;      /* (received beads nobody measures: NbTileArgs::hrecv3) */
    if (mine)
    {
       ts = ta.cell_start_o[TCELLS * t];
@@ -86,7 +91,8 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    }
    if (nown > 0)
    {
-      for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) { double4 e_ = ljtab[k]; if (HAS_Q) e_.w = kqtab[k]; s_lj[k] = e_; }
+      for (int k = threadIdx.x; k < ntab; k += NB_BLOCK) { double4 e_ = ljtab[k]; if (HAS_Q && !LVL) e_.w = kqtab[k]; s_lj[k] = e_; }      /* (LVL: the entries come with their fourth word) */
+      if (LVL) for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) L_s[k] = ta.lvlidx[k];
       int ns = ta.tile_nstage[t];
       /* Virial.  A pair of two unshifted beads contributes f_ij (x) (r_i - r_j) from i's side and
        * the mirror term from j's side; the two add up to 2 f_ij (x) r_i + 2 f_ji (x) r_j, so each
@@ -158,6 +164,15 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             gj[u] = ts;      /* rounds past the end re-read the tile's first bead (a cache hit) and drop it */
             if (k < ns) { const int c = cellof[k]; gj[u] = gst_s[c] + (k - ofs_s[c]); }
          }
+         /* direct halo staging: a received bead's position is in the exchange's receive buffer (NbTileArgs::hrecv3); its place there
+          * is asked for here, for all rounds at once, so the one dependent round trip is paid once per tile */
+         const bool from_recv = ta.hrecv3 != nullptr && tshift;
+         int hk[MAXR];
+         if (from_recv)
+         {
+#pragma unroll
+            for (int u = 0; u < MAXR; u++) hk[u] = (gj[u] >= ta.nloc) ? ta.halo_src[gj[u] - ta.nloc] : 0;
+         }
          __syncthreads();      /* the tables are dead: their bytes become staged positions */
 #pragma unroll
          for (int b = 0; b < MAXR; b += SU)
@@ -168,7 +183,13 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
 #pragma unroll
             for (int u = 0; u < SU; u++)
             {
-               pp[u] = pos[gj[b + u]];
+               if (from_recv && hk[b + u] < 0)
+               {
+                  const double *rr = ta.hrecv3 + 3 * (size_t)(-1 - hk[b + u]);
+                  pp[u].x = rr[0]; pp[u].y = rr[1]; pp[u].z = rr[2];
+                  pp[u].w = PACKED ? 0.0 : pos[gj[b + u]].w;      /* (packed entries carry the partner's type themselves) */
+               }
+               else pp[u] = pos[gj[b + u]];
                sh[u] = (!SHBIT && tshift && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
             }
 #pragma unroll
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
 #define NB_PAIR(u, WD_, HI_) do { \
                   const int nib_ = (int)(((WD_) >> ((HI_) ? 16 : 0)) & 0xfu); \
                   int tjj = PACKED ? (SHBIT ? (nib_ & 7) : nib_) : (int)T_s[o[u] >> 4]; \
-                  double4 lj = s_lj[ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
+                  double4 lj = s_lj[LVL ? (int)L_s[ti * nlj + tjj] : ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
                   double ir = 0.0, ir2; \
                   if (HAS_Q) { ir = rsqrt_f64_pair(r2[u]); ir2 = ir * ir; } \
                   else ir2 = rcp_f64_pair(r2[u]); \
@@ -386,7 +407,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                double r2 = x * x + y * y + z * z;
                if (r2 < rc2)
                {
-                  double kqij = s_lj[ti * nlj + tje].w;
+                  double kqij = s_lj[LVL ? (int)L_s[ti * nlj + tje] : ti * nlj + tje].w;
                   acc[1] += kqij * (krf * r2 - crf);
                   double dvdr = kqij * (2.0 * krf);
                   double fxij = -dvdr * x, fyij = -dvdr * y, fzij = -dvdr * z;

@@ -184,6 +184,8 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx)
    return DDCMI_OK;
 }
 
+static int bl_launch_interior(ddcmi_ctx *ctx);
+static size_t nb_lds_bytes(const ddcmi_ctx *ctx, int pack_type, bool *use_lvl);
 extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
 {
    if (!ctx) return DDCMI_EINVAL;
@@ -200,6 +202,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    for (int pass = 0;; pass++)
    {
       if ((rc = ddcmi_bl_sort_owned(ctx))) return rc;      /* (idempotent: a second pass sorts sorted beads) */
+      if ((rc = bl_launch_interior(ctx))) return rc;
       ctx->phase(0, "sort_owned launched");
       if ((rc = bl_self_images(ctx))) return rc;
       ctx->phase(1, "self_images (sync)");
@@ -375,14 +378,15 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
 
 /* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
 static void graph_drop(ddcmi_ctx *ctx);
-int ddcmi_bl_finish(ddcmi_ctx *ctx)
+/* sizes, buffers and kernel arguments of the search: everything k_tile_build needs, from the sorted owned beads alone (so that the
+ * interior tiles' search can start before the halo exists: bl_launch_interior).  Idempotent. */
+typedef void (*tile_build_fn)(GridParams, TileArgs, int, const double4 *, const uint64_t *, const int *, int, const int *, const int *, const int *,
+                              const int *, const int *, const unsigned long long *, int, unsigned short *, int *, int *, TileSel);
+struct BuildPlan { TileArgs ta; size_t lds; tile_build_fn kbuild; ShellCuts shc; };
+static int bl_plan(ddcmi_ctx *ctx, BuildPlan &bp)
 {
    GridParams &gp = ctx->gp;
-   hipStream_t st = ctx->stream;
-   int n = ctx->nloc;
-   ctx->phase(10, "-> bl_finish");
-   graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
-   /* 3. per-tile staging lists + full neighbour list (16-bit ELL per tile) */
+   const int n = ctx->nloc;
    ctx->npad = std::max(1, cdiv(n, DDCMI_BLOCK)) * DDCMI_BLOCK;
    int ntile = gp.T[0] * gp.T[1] * gp.T[2];
    ctx->ntile = ntile;
@@ -411,45 +415,134 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    /* distance shells of the list order: entries a wave rejects as a whole come last.  Shell 0: r < rcut - dR/4; shells
     * 1..NSHELL-1: equal steps of r^2 from there to the list radius (0.7 A wide at the cut-off for the Martini numbers; the
     * last one, beyond rcut + 0.85 dR, holds what no drift brings inside the cut-off) */
-   ShellCuts shc;
    {
       const double r0 = rcut - 0.25 * dR;
-      shc.r0sq = (float)(r0 * r0); shc.one = !(dR > 1e-9 * rcut);      /* no skin: one shell */
+      bp.shc.r0sq = (float)(r0 * r0); bp.shc.one = !(dR > 1e-9 * rcut);      /* no skin: one shell */
    }
    unsigned long long *d_arena = (unsigned long long *)(ctx->d_flags + 32);    /* arena entries handed out: the one device-wide counter of the build, on a cache line of its own */
+   bool has_mol = false;
+   for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
+   /* LDS image: the ring of accepted words (16 KB), 16 B per staged bead (+ 2 B of molecule id when pairs can be excluded), the region cell tables */
+   size_t lds = TB_RING_BYTES + (size_t)ctx->stage_cap * (has_mol ? 18 : 16) + (2 * NRC + 16 + 2 * (TB_THREADS / 64) + 8) * sizeof(int) + 16;
+   if ((size_t)ctx->stage_cap * sizeof(unsigned short) > TB_RING_BYTES) lds += (size_t)ctx->stage_cap * sizeof(unsigned short);      /* (bare 16-bit entries: the slot -> cell map outgrows the ring) */
+   if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
+   ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
+   if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
+   if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
+   ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
+   TileArgs &ta = bp.ta;
+   ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
+   ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
+   ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
+   ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
+   ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_arena;
+   ta.nbr_cnt = ctx->nbr_cnt.p; ta.nbr_cum = ctx->nbr_cum.p;
+   if (ctx->tmp32.ensure(((size_t)ctx->npad + (size_t)TB_CHUNK * (ntile + 1)) * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");      /* every tile rounded up to whole chunks */
+   ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = bp.shc;
+   if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
+   ta.tile_nib = ctx->tile_nib.p;
+   bp.kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
+                       : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
+   bp.lds = lds;
+   HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)bp.kbuild, (int)lds));
+   return DDCMI_OK;
+}
+static void bl_launch_tiles(ddcmi_ctx *ctx, const BuildPlan &bp, hipStream_t st, const TileSel &sel, int nblocks)
+{
+   hipLaunchKernelGGL(bp.kbuild, dim3(nblocks), dim3(TB_THREADS), bp.lds, st, ctx->gp, bp.ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
+                      ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
+                      ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags, sel);
+}
+/* The interior tiles' search, started as soon as the owned beads are sorted (round 5).  A tile whose neighbourhood -- the tile plus
+ * two cells on every side -- lies inside the owned cells stages owned beads only: nothing of the halo enters its search.  On a
+ * decomposed rank that is half the tiles, and between the owned sort and the halo's arrival the rebuild exchanges counts (two host
+ * round trips), packs, runs the RCCL kernel, assembles and sorts the halo: ~170 us of a 500 k-bead brick's 740 us window in which
+ * the chip ran a dozen latency-bound launches or nothing.  The interior launch goes to a second stream behind the sort and reads
+ * the owned cell tables; the boundary launch follows on the main stream when the halo is in place; the transposition waits for both.
+ * DDCMI_NO_INTERIOR_FIRST=1: one launch as before. */
+static void bl_drop_interior(ddcmi_ctx *ctx);
+static int bl_launch_interior(ddcmi_ctx *ctx)
+{
+   bl_drop_interior(ctx);      /* (a rebuild that ended early on an error may have left one behind) */
+   static const bool off = getenv("DDCMI_NO_INTERIOR_FIRST") != nullptr;
+   if (off || ctx->nloc <= 0) return DDCMI_OK;
+   const GridParams &gp = ctx->gp;
+   const int tdim[3] = {TCX, TCY, TCZ};
+   TileSel sel;
+   sel.mode = 1;
+   long nin = 1;
+   for (int a = 0; a < 3; a++)
+   {
+      int lo = 0, hi = gp.T[a] - 1;
+      if (gp.m[a] > 0)
+      {
+         /* region cells [tdim t - 2, tdim (t + 1) + 2) inside the owned cells [m, m + n) */
+         lo = gp.T[a]; hi = -1;
+         for (int t = 0; t < gp.T[a]; t++)
+            if (tdim[a] * t - 2 >= gp.m[a] && tdim[a] * (t + 1) + 2 <= gp.m[a] + gp.n[a]) { lo = std::min(lo, t); hi = std::max(hi, t); }
+      }
+      sel.lo[a] = lo; sel.n[a] = hi - lo + 1;
+      if (sel.n[a] <= 0) return DDCMI_OK;
+      nin *= sel.n[a];
+   }
+   const long ntile = (long)gp.T[0] * gp.T[1] * gp.T[2];
+   if (nin < 64 || 8 * nin < ntile) return DDCMI_OK;      /* (too few to be worth a launch of their own) */
+   BuildPlan bp;
+   int rc = bl_plan(ctx, bp);
+   if (rc) return rc;
+   if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+   if (!ctx->ev_sorted) { HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sorted, hipEventDisableTiming)); HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_interior, hipEventDisableTiming)); }
+   HIPCHK(ctx, hipEventRecord(ctx->ev_sorted, ctx->stream));
+   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_sorted, 0));
+   bp.ta.cell_start = ctx->cell_start_o.p; bp.ta.cell_cnt = ctx->cell_cnt_o.p;      /* (interior neighbourhoods: the merged tables, which do not exist yet, say the same) */
+   bl_launch_tiles(ctx, bp, ctx->stream2, sel, (int)nin);
+   HIPCHK(ctx, hipEventRecord(ctx->ev_interior, ctx->stream2));
+   ctx->interior_launched = true; ctx->interior_sel = sel;
+   ctx->interior_key[0] = ctx->stage_cap; ctx->interior_key[1] = ctx->tmpw; ctx->interior_key[2] = ctx->maxexcl; ctx->interior_key[3] = (long long)ctx->arena_cap;
+   return DDCMI_OK;
+}
+/* an early interior launch that cannot be used (the rebuild starts over): wait for it, forget it */
+static void bl_drop_interior(ddcmi_ctx *ctx)
+{
+   if (ctx->interior_launched && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+   ctx->interior_launched = false;
+}
+int ddcmi_bl_finish(ddcmi_ctx *ctx)
+{
+   GridParams &gp = ctx->gp;
+   hipStream_t st = ctx->stream;
+   int n = ctx->nloc;
+   ctx->phase(10, "-> bl_finish");
+   graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
+   int ntile = gp.T[0] * gp.T[1] * gp.T[2];
+   unsigned long long *d_arena = (unsigned long long *)(ctx->d_flags + 32);
+   ShellCuts shc;
    for (int attempt = 0;; attempt++)
    {
-      if (attempt == 8) SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled");
-      bool has_mol = false;
-      for (int m = 0; m < ctx->nmoltype; m++) has_mol |= ctx->mol_nspecies[m] > 1;
-      /* LDS image: 16 B per staged bead (+ 4 B molecule id when pairs can be excluded) + the region cell tables */
-      /* LDS image: the ring of accepted words (16 KB), 16 B per staged bead (+ 2 B of molecule id when pairs can be excluded), the region cell tables */
-      size_t lds = TB_RING_BYTES + (size_t)ctx->stage_cap * (has_mol ? 18 : 16) + (2 * NRC + 16 + 2 * (TB_THREADS / 64) + 8) * sizeof(int) + 16;
-      if ((size_t)ctx->stage_cap * sizeof(unsigned short) > TB_RING_BYTES) lds += (size_t)ctx->stage_cap * sizeof(unsigned short);      /* (bare 16-bit entries: the slot -> cell map outgrows the ring) */
-      if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "a tile neighbourhood of %d beads does not fit the 160 KiB LDS", ctx->stage_cap);
-      ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
-      if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
-      if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
-      if (attempt > 0) ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_arena, 2));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
-      ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
-      TileArgs ta;
-      ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
-      ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
-      ta.stage_idx = ctx->stage_idx.p; ta.tile_nstage = ctx->tile_nstage.p;
-      ta.tile_base = ctx->tile_base.p; ta.tile_width = ctx->tile_width.p; ta.tile_rows = ctx->tile_rows.p; ta.tile_work = ctx->tile_work.p;
-      ta.nbr16 = ctx->nbr16.p; ta.arena_cap = ctx->arena_cap; ta.arena_used = d_arena;
-      ta.nbr_cnt = ctx->nbr_cnt.p; ta.nbr_cum = ctx->nbr_cum.p;
-      if (ctx->tmp32.ensure(((size_t)ctx->npad + (size_t)TB_CHUNK * (ntile + 1)) * ctx->tmpw)) SETERR(ctx, DDCMI_ENOMEM, "scratch list allocation failed");      /* every tile rounded up to whole chunks */
-      ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = shc;
-      if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
-      ta.tile_nib = ctx->tile_nib.p;
+      if (attempt == 8) { bl_drop_interior(ctx); SETERR(ctx, DDCMI_ENOMEM, "neighbour list capacity could not be settled"); }
+      if (attempt > 0)
+      {
+         bl_drop_interior(ctx);
+         ddcmi_zero_ints(ctx, st, ZeroJobs().add(ctx->d_flags, 8).add(d_arena, 2));      /* first attempt: zeroed with the cell counters (ddcmi_bl_sort_owned) */
+      }
+      BuildPlan bp;
+      { int rcp = bl_plan(ctx, bp); if (rcp) { bl_drop_interior(ctx); return rcp; } }
+      shc = bp.shc;
+      TileArgs &ta = bp.ta;
       ctx->phase(17, "bl_finish: buffers");
-      auto kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
-                            : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
-      HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)kbuild, (int)lds));
-      hipLaunchKernelGGL(kbuild, dim3(ntile), dim3(TB_THREADS), lds, st, gp, ta, ctx->npad, ctx->pos.p, ctx->gid.p, ctx->species.p,
-                         ctx->nmoltype, ctx->d_moltype_sp.p, ctx->d_mol_nspecies.p, ctx->d_bpair_off.p, ctx->d_bpairI.p, ctx->d_bpairJ.p, ctx->d_exmask.p,
-                         ctx->maxexcl, ctx->excl16.p, ctx->excl_cnt.p, ctx->d_flags);
+      /* (an interior launch made for other capacities cannot be completed: cannot happen -- the capacities only change in this loop) */
+      const bool split = ctx->interior_launched && ctx->interior_key[0] == ctx->stage_cap && ctx->interior_key[1] == ctx->tmpw &&
+                         ctx->interior_key[2] == ctx->maxexcl && ctx->interior_key[3] == (long long)ctx->arena_cap;
+      if (ctx->interior_launched && !split) bl_drop_interior(ctx);
+      TileSel sel;
+      memset(&sel, 0, sizeof(sel));
+      if (split) { sel = ctx->interior_sel; sel.mode = 2; }
+      bl_launch_tiles(ctx, bp, st, sel, ntile);
+      if (split)
+      {
+         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_interior, 0));      /* the transposition and the post below need every tile */
+         ctx->interior_launched = false;
+      }
       /* everything the host decides on (capacity flags, totals, the tiles' cost estimates) is final when k_tile_build
        * ends: it travels behind an event, and the host reads it -- and orders the tiles -- while k_tile_transpose runs */
       ctx->phase(18, "bl_finish: build launch");
@@ -515,8 +608,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    }
    {
       /* workgroups of k_nonbond a CU holds: its LDS image of a neighbourhood (launch_forces), at most two by registers */
-      const size_t capl = (size_t)ctx->stage_cap + 2;
-      const size_t lds_nb = (capl * 16 <= NB_ZOFF ? NB_ZOFF + capl * 8 : capl * 24) + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (ctx->pack_type ? 0 : capl) + (ctx->pack_type == 2 ? 0 : capl);
+      const size_t lds_nb = nb_lds_bytes(ctx, ctx->pack_type, nullptr);
       int rcs = schedule_tiles(ctx, (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_nb, 1))));
       if (rcs) return rcs;
    }

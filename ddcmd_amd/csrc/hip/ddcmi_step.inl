@@ -3,6 +3,21 @@
 /* ------------------------------------------------------------------------- */
 /* defer_reduce: the caller (a time step) folds the nonbonded reduction and the final
  * energies into the launch that reduces the kinetic terms */
+/* LDS of one k_nonbond workgroup: the staged positions, the pair table -- direct (32 bytes per class pair) or in two levels (one byte per
+ * class pair + the distinct entries) -- and, unless the list entries carry them, the staged beads' types and shifted-copy flags.
+ * The level form is taken where the direct table would cost the second workgroup per CU (or fit no CU at all). */
+static size_t nb_lds_bytes(const ddcmi_ctx *ctx, int pack_type, bool *use_lvl)
+{
+   const size_t capl = (size_t)ctx->stage_cap + 2;
+   const size_t base = (capl * 16 <= NB_ZOFF ? NB_ZOFF + capl * 8 : capl * 24) + (pack_type ? 0 : capl) + (pack_type == 2 ? 0 : capl);
+   const size_t npair = (size_t)ctx->nnb * ctx->nnb;
+   const size_t direct = npair * sizeof(double4), level = (size_t)ctx->nlvl * sizeof(double4) + ((npair + 15) & ~(size_t)15);
+   /* (+ the fused step's rows of kinetic sums when they do not fit the gap in front of z: 512 bytes) */
+   auto wgs = [&](size_t table) { const size_t tot = base + table + 512; return tot > 160 * 1024 ? 0 : (int)std::min<size_t>(2, (160 * 1024) / tot); };
+   const bool lvl = ctx->nlvl > 0 && (ctx->force_lvl || wgs(level) > wgs(direct));
+   if (use_lvl) *use_lvl = lvl;
+   return base + (lvl ? level : direct);
+}
 static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */)
 {
    hipStream_t st = ctx->stream;
@@ -13,22 +28,34 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    bool halo_pending = false;
    /* the received beads' displacement since the rebuild (NbTileArgs::hdisp): measured by the halo update of a decomposed run whose pair
     * kernel may end its rows early; the word of this step's parity is the one this step's pair kernel reads */
-   const bool hdisp_on = ctx->shell_skip && nh > 0 && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
+   /* direct halo staging (ddcmi_ctx::halo_in_recv): the pair kernel takes the received beads out of the exchange's receive buffer, no
+    * update launch -- for halos of received beads only, needed by the pair kernel only */
+   const bool has_bonded0 = (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) > 0;
+   const bool direct = !ctx->no_direct_halo && (ctx->nranks > 1 || ctx->loopback) && (ctx->comm || ctx->hcomm) && !ctx->group_ && !ctx->halo_overlap && ctx->nself_images == 0 &&
+                       !has_bonded0 && ctx->ncgroup == 0 && !(ctx->baro_beta > 0.0) && ctx->stage_cap + 2 < 4096 && (ctx->excludePotentialTerm & 128) == 0 && ctx->updateRate > 0;
+   const bool hdisp_on = !direct && ctx->shell_skip && nh > 0 && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
    const int hpar = (int)(ctx->loop & 1);
    unsigned long long *hmax = hdisp_on ? (unsigned long long *)(ctx->d_results + R_DISP + 1) : nullptr;
-   if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh && !ctx->halo_overlap)
+   if (direct && !ctx->halo_fresh)
    {
       int rc0 = ddcmi_mg_refresh_halo(ctx, st);
       if (rc0) return rc0;
+      ctx->halo_in_recv = true;      /* (pos[nloc..] keeps the rebuild's records from here on) */
+   }
+   else if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh && !ctx->halo_overlap)
+   {
+      int rc0 = ddcmi_mg_refresh_halo(ctx, st);
+      if (rc0) return rc0;
+      ctx->halo_in_recv = false;      /* (the update below places every received bead in pos[]) */
       if (nh > 0)
          hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                             ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
    }
    else if ((ctx->nranks > 1 || ctx->loopback) && !ctx->halo_fresh)
    {
-      if (!ctx->stream2)
+      if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));      /* (the rebuild's interior search may have made it already) */
+      if (!ctx->ev_drift)
       {
-         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
          HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_drift, hipEventDisableTiming));
          HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
       }
@@ -74,7 +101,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
       /* fixed LDS layout ({x,y} at 0, z at NB_ZOFF) for neighbourhoods of up to NB_ZOFF/16 beads, which is every Martini system; else the run-time layout */
       const bool zfix = capl * 16 <= NB_ZOFF;
-      size_t lds = (zfix ? NB_ZOFF + capl * 8 : capl * 24) + (size_t)ctx->nnb * ctx->nnb * sizeof(double4) + (packed ? 0 : capl) + (shbit ? 0 : capl);      /* + shifted-copy flags unless the entries carry them */
+      bool lvl = false;
+      size_t lds = nb_lds_bytes(ctx, ctx->pack_type, &lvl);      /* positions + pair table (direct or in two levels) + types / shifted-copy flags unless the entries carry them */
       if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       FuseArgs fa;
       memset(&fa, 0, sizeof(fa));
@@ -103,16 +131,20 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       na.disp = ctx->shell_skip ? ctx->d_results + R_DISP : nullptr; na.nbr_cum = ctx->nbr_cum.p; na.sh_r0sq = ctx->sh_r0sq; na.sh_step = ctx->sh_step;
       na.hdisp = hdisp_on ? ctx->d_results + R_DISP + 1 + hpar : nullptr;
+      na.hrecv3 = ctx->halo_in_recv ? ctx->hrecv3.p : nullptr; na.halo_src = ctx->halo_src.p;
+      na.halo_full_walk = (direct && ctx->shell_skip) ? 1 : 0;
+      na.lvlidx = ctx->d_lvlidx.p; na.nlvl = ctx->nlvl;
       na.fb = (has_bonded && n > 0) ? ctx->fb.p : nullptr;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
-#define LAUNCH_NBF(Q, P, S, NT, Z, F) do { \
+#define LAUNCH_NBF(Q, P, S, NT, Z, F) do { if (lvl) LAUNCH_NBL(Q, P, S, NT, Z, F, true); else LAUNCH_NBL(Q, P, S, NT, Z, F, false); } while (0)
+#define LAUNCH_NBL(Q, P, S, NT, Z, F, L) do { \
          size_t sb_ = 0; \
-         if (!lds_starts_at_zero(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>, &sb_)) \
+         if (!lds_starts_at_zero(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F, L>, &sb_)) \
             SETERR(ctx, DDCMI_EUNSUPPORTED, "k_nonbond was built with %zu bytes of static LDS: its staged arrays no longer start at LDS address 0 (toolchain change) -- rebuild libddcmi.so with a compiler that gives it none", sb_); \
-         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>, (int)lds)); \
-         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
-                            ctx->excl16.p, ctx->excl_cnt.p, ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
+         HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F, L>, (int)lds)); \
+         hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F, L>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
+                            ctx->excl16.p, ctx->excl_cnt.p, (L) ? ctx->d_lvltab.p : ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
                             ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p, fa); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
       /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
@@ -158,6 +190,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
 #undef LAUNCH_NB
 #undef LAUNCH_NBZ
 #undef LAUNCH_NBF
+#undef LAUNCH_NBL
       if (na.fb) ctx->fb_zeroed = ctx->fb.cap;
       if (ctx->timing) { ctx->t_launches++; if (fuse) ctx->t_launches_fused++; }          /* per force evaluation: the event pairs of both classes add up */
       /* the final energies are formed in the same launch (the bonded kernels' sums are complete: they ran first) */

@@ -580,6 +580,8 @@ def _declare_domains(lib):
     """the test-only entry points (include/ddcmi_test.h): lib is the handle of libddcmi_test.so"""
     if getattr(lib, "_ddcmi_dom_declared", False):
         return
+    if not hasattr(lib, "ddcmi_group_create"):
+        return      # (a handle of the product library: it has none of them -- nothing to declare)
     vp = ctypes.c_void_p
     lib.ddcmi_plan_directions.argtypes = [ctypes.c_int] * 5 + [_ip, _ip]
     lib.ddcmi_plan_recv_counts.argtypes = [ctypes.c_int] * 6 + [_ip, _ip]

@@ -96,13 +96,13 @@ def water_forcefield(s, rcut_A=12.0, skin_A=4.0, dt_fs=20.0, update_rate=20):
 
 
 def make_water_setup(n, seed=SEED, temperature_K=50.0, rcut_A=12.0, skin_A=4.0, dt_fs=20.0,
-                     update_rate=20, thermostat=None, lattice="fcc", jitter_A=None):
+                     update_rate=20, thermostat=None, lattice="fcc", jitter_A=None, density_scale=1.0):
     """Martini water box: 4*n^3 beads on FCC (n=25: 62.5k, n=64: 1.05M, n=100: 4.0M);
     lattice="sc" gives SURVEY's n^3 simple-cubic start (unstable at 20 fs)."""
     s = Setup()
     water_forcefield(s, rcut_A, skin_A, dt_fs, update_rate)
     ang = units_convert(1.0, "Angstrom")
-    vol_per_bead_A3 = 93.858 ** 3 / 6173.0
+    vol_per_bead_A3 = 93.858 ** 3 / 6173.0 / float(density_scale)      # (density_scale != 1: kernel-tuning experiments only, tools/)
     if lattice == "fcc":
         N = 4 * n * n * n
         a_A = (4.0 * vol_per_bead_A3) ** (1.0 / 3.0)
@@ -199,4 +199,45 @@ def replicate_setup(s, reps):
     out.h = np.array(s.h, dtype=np.float64).copy()
     out.h[0], out.h[4], out.h[8] = Lnew
     out.natoms = n * ncopy
+    return out
+
+
+def relabel_types(s, ntypes, seed=SEED):
+    """The same system under MORE bead types: every LJ type of the Setup is split into copies with identical parameters until there
+    are `ntypes` of them (bioMartini.c:868-950 builds an nspecies^2 table: a real Martini deck has ~40 types where the decks of this
+    repository have 2-6), every species gets one copy per LJ-type copy, and every bead draws its copy at random (splitmix64 of
+    seed ^ bead index).  Physics -- forces, energies, trajectories -- is that of the original, bead for bead; what changes is
+    the size of the (type, charge) class table the pair kernel has to keep."""
+    import copy
+    out = copy.copy(s)
+    nlj0 = int(s.nlj)
+    if ntypes < nlj0:
+        raise ValueError("relabel_types: %d types asked for, the Setup has %d" % (ntypes, nlj0))
+    ncopy = np.full(nlj0, ntypes // nlj0, np.int64)
+    ncopy[: ntypes - int(ncopy.sum())] += 1
+    first = np.concatenate(([0], np.cumsum(ncopy)))            # new LJ type of copy 0 of each old type
+    base = np.repeat(np.arange(nlj0), ncopy)                    # old type of each new type
+    sig0, eps0, sh0 = (np.asarray(getattr(s, k), dtype=np.float64).reshape(nlj0, nlj0) for k in ("sigma", "eps", "shift"))
+    out.nlj = int(ntypes)
+    out.sigma, out.eps, out.shift = (np.ascontiguousarray(a[np.ix_(base, base)]).ravel() for a in (sig0, eps0, sh0))
+    # species: copy c of species sp has LJ type first[ljtype[sp]] + c
+    lj_sp = np.asarray(s.ljtype, dtype=np.int64)
+    kmax = int(ncopy.max())
+    nsp0 = int(s.nspecies)
+    sp_first = np.concatenate(([0], np.cumsum(ncopy[lj_sp])))   # first new species of each old species
+    old_of_new = np.repeat(np.arange(nsp0), ncopy[lj_sp])
+    copy_of_new = np.arange(int(sp_first[-1])) - sp_first[old_of_new]
+    out.nspecies = int(sp_first[-1])
+    for k in ("mass", "charge"):
+        setattr(out, k, np.asarray(getattr(s, k), dtype=np.float64)[old_of_new].copy())
+    for k in ("moltype", "resitype", "atomoffset"):
+        a = np.asarray(getattr(s, k))
+        if a.size == nsp0:
+            setattr(out, k, a[old_of_new].astype(np.int32))
+    out.ljtype = (first[lj_sp[old_of_new]] + copy_of_new).astype(np.int32)
+    out.species_name = ["%s" % s.species_name[o] for o in old_of_new] if len(getattr(s, "species_name", [])) == nsp0 else []
+    idx = np.arange(int(s.natoms), dtype=np.uint64)
+    sp_old = np.asarray(s.species, dtype=np.int64)
+    pick = (splitmix64(np.uint64(seed) ^ idx) % np.uint64(kmax)).astype(np.int64) % ncopy[lj_sp[sp_old]]
+    out.species = (sp_first[sp_old] + pick).astype(np.int32)
     return out

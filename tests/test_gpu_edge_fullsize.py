@@ -346,3 +346,87 @@ def test_many_lj_types(ntypes):
             assert abs(e[k] - e0[k]) < 1e-10 * abs(e0[k]), (ntypes, k)
         assert np.abs(vir - v0).max() < 1e-10 * np.abs(v0).max()
         m.close()
+
+
+def test_lipid_bilayer_2M_beads_with_forty_bead_types():
+    """VERDICT r4 #3, the type-count cliff: martiniLJ_parms builds an nspecies^2 table (bioMartini.c:868-950) and a real Martini
+    deck has ~40 bead types, where the decks here have 2-6.  The 2.04 M-bead bilayer tiling with every LJ type split into copies
+    of itself -- 40 LJ types, 48 (type, charge) classes, every bead's copy drawn at random (relabel_types) -- is the same physics
+    bead for bead: every copy of every bead must feel the force the oracle computes for the ORIGINAL 2363-bead deck.  The direct
+    class-pair table would be 74 KB of LDS (one workgroup per CU, or none beside a denser neighbourhood); the kernel keeps one byte
+    per class pair + the dozen distinct entries instead (k_nonbond<..., LVL>) and two workgroups per CU."""
+    import os
+    import pyoracle
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import replicate_setup, relabel_types
+    from ddcmd_amd.martini import MartiniHIP
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s0 = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    o = pyoracle.Oracle(s0)
+    e0, v0 = o.forces()
+    reps = (12, 12, 6)
+    ncopy = reps[0] * reps[1] * reps[2]
+    s = relabel_types(replicate_setup(s0, reps), 40)
+    assert s.nlj == 40 and s.natoms == 2363 * ncopy
+    classes = set(zip(s.ljtype[s.species].tolist(), s.charge[s.species].tolist()))
+    assert len(classes) >= 44
+    m = MartiniHIP(s)
+    e, vir = m.eval_forces()
+    d = m.download()
+    f = np.stack(d["f"]).reshape(3, ncopy, s0.natoms)
+    ref = np.stack([o.fx, o.fy, o.fz])[:, None, :]
+    assert np.abs(f - ref).max() < 1e-8 * np.abs(ref).max()
+    for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
+        assert abs(e[k] - ncopy * e0[k]) < 1e-9 * ncopy * max(abs(e0[k]), abs(e0["total"]) * 1e-6), k
+    assert np.abs(vir - ncopy * v0).max() < 1e-9 * ncopy * np.abs(v0).max()
+    o.group_temperature()
+    m.group_temperatures()
+    eo, vo, rko, _ = o.step(20)
+    m.step(20)
+    e2, _, rk, _ = m.energies()
+    assert abs(rk - ncopy * rko) < 1e-6 * ncopy * rko
+    assert abs(e2["total"] - ncopy * eo["total"]) < 1e-6 * ncopy * abs(eo["total"])
+    m.close()
+
+
+@pytest.mark.parametrize("workload", ["water", "lipid", "types12", "lipid40"])
+def test_pair_table_in_two_levels_equals_the_direct_table(monkeypatch, workload):
+    """k_nonbond<..., LVL> against the direct class-pair table on systems where both fit (DDCMI_FORCE_LEVEL_TABLE=1 takes the level
+    form regardless): the same entries reach the same arithmetic, so forces, energies and a 25-step trajectory agree in every bit --
+    packed entries with and without the shift bit, bare entries, charges, bonded terms, the fused step"""
+    import os
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import relabel_types
+    from ddcmd_amd.martini import MartiniHIP
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    if workload == "water":
+        s = make_water_setup(12)
+    elif workload == "lipid":
+        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    elif workload == "lipid40":
+        s = relabel_types(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), 40)
+    else:
+        s = relabel_types(make_water_setup(12), 12)
+    out = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("DDCMI_FORCE_LEVEL_TABLE", "1")
+        else:
+            monkeypatch.delenv("DDCMI_FORCE_LEVEL_TABLE", raising=False)
+        m = MartiniHIP(s)
+        e, vir = m.eval_forces()
+        f0 = np.stack(m.download()["f"])
+        m.group_temperatures()
+        m.step(25)
+        e2, vir2, rk, _ = m.energies()
+        d = m.download()
+        out.append((e["total"], e["lj"], e["ele"], vir.copy(), f0, e2["total"], rk, np.stack(d["r"]), np.stack(d["v"])))
+        m.close()
+    monkeypatch.delenv("DDCMI_FORCE_LEVEL_TABLE", raising=False)
+    a, b = out
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    if workload in ("lipid", "lipid40"):
+        o = pyoracle.Oracle(s)
+        eo, _ = o.forces()
+        assert abs(a[0] - eo["total"]) < 1e-10 * abs(eo["total"])

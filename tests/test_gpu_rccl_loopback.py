@@ -206,6 +206,38 @@ def test_loopback_rows_end_at_the_last_shell_that_can_matter(monkeypatch, vscale
     a.close(); b.close()
 
 
+def test_halo_staged_from_the_receive_buffer_equals_the_update_launch(monkeypatch):
+    """round 5: a rank whose halo holds received beads only stages them in k_nonbond straight from the exchange's receive buffer
+    (through halo_src) -- no k_halo_update launch between the exchange and the pair kernel.  Same run with DDCMI_NO_DIRECT_HALO=1
+    (the update launch, the measured halo displacement): every bit of positions, velocities, forces and energies agrees, across
+    rebuilds, single force evaluations, batches of fused steps and print steps"""
+    s = make_water_setup(12)
+    monkeypatch.delenv("DDCMI_NO_DIRECT_HALO", raising=False)
+    a = _loopback_rank(s, monkeypatch)
+    monkeypatch.setenv("DDCMI_NO_DIRECT_HALO", "1")
+    b = _loopback_rank(s, monkeypatch)
+    monkeypatch.delenv("DDCMI_NO_DIRECT_HALO", raising=False)
+    o = pyoracle.Oracle(s)
+    o.forces()
+    a.eval_forces(); b.eval_forces()
+    for block, n in enumerate((1, 1, 17, 23, 5)):
+        a.step(n); b.step(n)
+        eo, vo, rko, _ = o.step(n)
+        if block == 3:
+            ea1, _ = a.eval_forces(); eb1, _ = b.eval_forces()      # a force evaluation between batches: no exchange, no move
+            assert ea1["total"] == eb1["total"]
+        pa, pb = a.download_particles(), b.download_particles()
+        assert np.array_equal(pa["gid"], pb["gid"])
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(pa[k][c], pb[k][c]), (block, k, c)
+        ea, va, rka, _ = a.energies()
+        eb, vb, rkb, _ = b.energies()
+        assert ea["total"] == eb["total"] and rka == rkb and np.array_equal(va, vb)
+        assert abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rka - rko) < TOL * rko
+    a.close(); b.close()
+
+
 def test_explicit_rebuild_then_forces_through_the_loopback(monkeypatch):
     """constructList called by hand (ddcmi_build_list, the neighbour hook of ddcUpdateAll.c:136-139) followed by a force evaluation
     on a decomposed rank: the rebuild itself has placed the halo beads -- the evaluation must not refresh them from the per-step

@@ -38,7 +38,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         if k.startswith("void "): k = k[5:]
         if not (k.startswith("k_nonbond") or k.startswith("k_tile")): continue
         base = k.split("<")[0]
-        if base == "k_nonbond" and k.rstrip().endswith("true>"): base = "k_nonbond_fused"      # the pair kernel with the integrator's pass as its epilogue
+        if base == "k_nonbond" and [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")][-2] == "true": base = "k_nonbond_fused"      # the pair kernel with the integrator's pass as its epilogue
         acc[base][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res["counters_mean_per_launch"] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 plain = res["counters_mean_per_launch"].get("k_nonbond", {})
