@@ -177,7 +177,7 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
-def build_setup(workload, n, reps, types=0):
+def build_setup(workload, n, reps, types=0, cadence="reference"):
     import ddcmd_amd
     if workload == "water":
         s = ddcmd_amd.make_water_setup(n, density_scale=float(os.environ.get("DDCMI_BENCH_DENSITY_SCALE", "1.0")))      # (the variable: kernel-tuning experiments only)
@@ -188,6 +188,13 @@ def build_setup(workload, n, reps, types=0):
     deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
     # 310 K restart relaxed by tests/golden/make_lipid_relaxed.py, Berendsen group (Teq 310 K, tau 1 ps)
     s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), r3)
+    if cadence == "reference":
+        # the cadence of the reference's shipped decks (examples/waterbox/object.data:10,35; examples/object/object.data:13,41): dt = 20 fs, list
+        # rebuild every 20 steps.  The deck itself says 10 fs / 10 (a leftover of its relaxation); the 2.04 M-bead box holds 310 K, its bond
+        # lengths and its aged-list forces over 20 000 steps at 20 / 20 (tools/lipid_soak_r05.py, profiles/r05_lipid_soak.txt)
+        import ddcmd_amd
+        s.dt = ddcmd_amd.units_convert(20.0, "fs")
+        s.updateRate = 20
     if types:
         # the same physics under `types` LJ types (every type split into copies of itself, each bead's copy drawn at random): the size of
         # the pair kernel's class table is what changes (bioMartini.c:868-950 builds nspecies^2 entries; a real Martini deck has ~40 types)
@@ -197,12 +204,12 @@ def build_setup(workload, n, reps, types=0):
     return s, "martini_lipid_bilayer_%dk_beads" % (s.natoms // 1000), "deck tiled %s" % reps, None
 
 
-def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank, rdzv, transport, loopback, types=0):
+def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank, rdzv, transport, loopback, types=0, cadence="reference"):
     """one workload on this launch's ranks: equilibration, warm-up, then the timed windows.  Returns the pieces of the JSON line."""
     import numpy as np
     import ddcmd_amd
     from ddcmd_amd.martini import MartiniHIP, MartiniRank, domain_of
-    s, wname, lattice, lattice_n = build_setup(workload, n, reps, types)
+    s, wname, lattice, lattice_n = build_setup(workload, n, reps, types, cadence)
     dt_fs = float(ddcmd_amd.units_convert(s.dt, None, "fs"))
     grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
     if grid is None:
@@ -415,6 +422,8 @@ def main():
                          "all bonded term kinds, charges, Berendsen) tiled --reps times")
     ap.add_argument("--rccl-loopback", action="store_true",
                     help="N=1 only: reach the periodic images through a 1-rank RCCL communicator (the multi-GPU transport on one GPU)")
+    ap.add_argument("--cadence", choices=("reference", "deck"), default="reference",
+                    help="lipid workload: reference = dt 20 fs, rebuild every 20 steps (what the reference's shipped decks use); deck = the lipid deck's own 10 fs / 10")
     ap.add_argument("--types", type=int, default=0, help="lipid workload: relabel the beads to this many LJ types (same physics, bigger class table; 0: the deck's own 6)")
     ap.add_argument("--reps", default="12,12,6", help="lipid workload: copies of the 2363-bead deck along x,y,z (12,12,6 -> 2.04M beads)")
     ap.add_argument("--equil", type=int, default=-1,
@@ -497,7 +506,7 @@ def main():
             rdzv.close()
         return
 
-    res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback, args.types)
+    res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback, args.types, args.cadence)
     out = {
         "metric": "atom_steps_per_sec", "value": res.pop("value"), "unit": "atom-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -513,13 +522,14 @@ def main():
         out["also"] = []
         under_prof = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
         for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps", pmc=["--lattice", "64"]),
-                   dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen", pmc=["--workload", "lipid", "--reps", args.reps]),
+                   dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen, at the reference decks' cadence (dt 20 fs, rebuild every 20 steps)", pmc=["--workload", "lipid", "--reps", args.reps]),
+                   dict(workload="lipid", n=None, loopback=False, cadence="deck", tag="the same bilayer at the lipid deck's own cadence (dt 10 fs, rebuild every 10 steps): rounds 1-4's row", pmc=None),
                    dict(workload="lipid", n=None, loopback=False, types=20, tag="the same bilayer under 20 LJ types (every type split into copies of itself): the class table of a mid-size Martini deck", pmc=None),
                    dict(workload="lipid", n=None, loopback=False, types=40, tag="the same bilayer under 40 LJ types / 48 (type, charge) classes: the pair table in two levels (k_nonbond<LVL>)", pmc=None),
                    dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=None),
                    dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
             try:
-                r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0))
+                r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0), kw.get("cadence", "reference"))
                 if kw["pmc"] and not args.no_pmc and not under_prof:
                     # the row's own HBM bytes, measured live like the headline's
                     lt = live_traffic(kw["pmc"], r["roofline"].get("dominant_is_fused", False))

@@ -120,6 +120,9 @@ template <class T> struct dbuf
  * except that box (the workgroups of its tiles return at once). */
 struct TileSel { int mode; int lo[3], n[3]; };
 
+/* LDS layout of one k_nonbond workgroup (nb_lds_layout, ddcmi_step.inl) */
+struct NbLds { size_t total; int tab_off, ke_off; bool lvl, zfix; int wgs; };
+
 /* results block on the device / pinned host mirror */
 enum
 {
@@ -192,6 +195,7 @@ struct ddcmi_ctx
    hipEvent_t ev_sorted = nullptr, ev_interior = nullptr; bool interior_launched = false; TileSel interior_sel; long long interior_key[4] = {0, 0, 0, 0};
    bool halo_overlap = false;          /* DDCMI_HALO_OVERLAP=1: exchange on stream2 under the all-owned tiles */
    /* tiles (4x4x4 cells): staging lists + 16-bit ELL arena */
+   int stage_cap_want = 0;             /* the staging capacity the last build's largest neighbourhood asks for (+1.5 % + 40 beads): taken at the next rebuild if smaller -- every staged bead of slack is 24 B of k_nonbond's LDS */
    int ntile = 0, stage_cap = 0; int pack_type = 0;      /* 0 bare slots, 1 slot<<4|type, 2 + shift bit (see TileArgs) */
    dbuf<int> stage_idx, tile_nstage, tile_width, tile_rows;
    dbuf<long long> tile_base;

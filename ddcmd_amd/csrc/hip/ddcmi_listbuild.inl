@@ -96,6 +96,7 @@ struct NbTileArgs
    const double *hrecv3; const int *halo_src; int halo_full_walk;
    /* k_nonbond<..., LVL>: the pair table in two levels (ddcmi_ctx::d_lvltab): lvlidx [nlj*nlj] = index of the class pair's entry among the nlvl distinct ones */
    const unsigned char *lvlidx; int nlvl;
+   int tab_off;                         /* LDS byte offset of the pair table (nb_lds_layout: the gap between {x,y} and z when it fits, else behind z) */
    /* bonded terms / restraints: their kernels ran first and left their force on every owned bead in fb (one 32-byte record per bead,
     * zero where a bead has none); the pair kernel adds the bead's pair force to it -- into fx, fy, fz (plain launch) or in registers,
     * in front of the integrator's pass (FUSE) -- and hands the record back zeroed for the next evaluation's bonded kernels */

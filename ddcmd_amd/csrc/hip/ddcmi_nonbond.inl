@@ -26,6 +26,16 @@
  *      shifted copies and excluded pairs (see below).
  * Bound: FP64 issue and LDS gathers behind s_waitcnt at 4 waves per SIMD -- DESIGN.md section 4 has the
  * counters, the ablations and the per-CU timelines. */
+/* a staged z with the partner's tags in its lowest mantissa bits (see k_nonbond): bit 0 the shifted-copy flag; bare entries also
+ * bits 1-8 the (LJ type, charge) class from the record's tag word */
+template <bool PACKED>
+__device__ __forceinline__ double z_with_tags(double z, double tagword, bool shifted)
+{
+   unsigned lo = (unsigned)__double2loint(z);
+   if (PACKED) lo = (lo & ~1u) | (shifted ? 1u : 0u);
+   else lo = (lo & ~0x1ffu) | (shifted ? 1u : 0u) | (((unsigned)__double2loint(tagword) & 0xffu) << 1);
+   return __hiloint2double(__double2hiint(z), (int)lo);
+}
 template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF, bool FUSE, bool LVL>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
@@ -35,15 +45,14 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                                                          double *__restrict__ fx, double *__restrict__ fy, double *__restrict__ fz,
                                                          double *__restrict__ partials, FuseArgs fa)
 {
-   /* LDS: staged neighbourhood as {x,y} pairs + z (24 B per bead), LJ table, and --
-    * only when needed -- per-bead LJ types (nlj > 16) and charges */
+   /* LDS: staged neighbourhood as {x,y} pairs + z (24 B per bead), the pair table (and the fused step's rows of kinetic sums) */
    extern __shared__ double2 smem[];
    /* staged positions, 24 B per bead.  ZOFF > 0 (neighbourhoods of up to ZOFF/16 beads: every Martini system): {x,y} [cap] at LDS
     * address 0 and z [cap] at the compile-time byte offset ZOFF, so a gather's addresses are the entry's slot bits themselves
     * (slot * 16 for {x,y}; slot * 8 + the instruction's immediate offset for z).  ZOFF = 0: z [cap], then {x,y} [cap] at a run-time offset */
    double2 *XY_s = ZOFF ? (double2 *)smem : (double2 *)((double *)smem + ta.cap);
    double *Z_s = ZOFF ? (double *)((char *)smem + ZOFF) : (double *)smem;
-   double4 *s_lj = ZOFF ? (double4 *)(Z_s + ta.cap) : (double4 *)(XY_s + ta.cap);
+   double4 *s_lj = (double4 *)((char *)smem + ta.tab_off);      /* (the host places it: nb_lds_layout) */
    /* charges: a bead's "type" is its (LJ type, charge) class, so ke/eps_r q_i q_j is one more
     * per-type-pair table entry -- no per-bead charge array in LDS (it cost 8 B/bead: one
     * workgroup per CU instead of two) and no charge gather per pair */
@@ -51,8 +60,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
     * 1.6 KB + a few hundred bytes instead of 51 KB; one more (one-byte) LDS read per accepted pair */
    const int ntab = LVL ? ta.nlvl : ta.nlj * ta.nlj;
    unsigned char *L_s = (unsigned char *)(s_lj + ntab);
-   unsigned char *T_s = L_s + (LVL ? ((ta.nlj * ta.nlj + 15) & ~15) : 0);
-   unsigned char *S_s = T_s + (PACKED ? 0 : ta.cap);      /* 1: the staged bead is a periodically shifted copy */
+   /* What a list entry does not say about the partner rides in the LOWEST MANTISSA BITS of its staged z (round 5): bit 0 = the bead is a
+    * periodically shifted copy (entries without the shift bit: more than 8 classes), bits 1-8 = its (LJ type, charge) class (bare
+    * entries: more than 16 classes).  A per-bead byte array for each cost 1 B/bead of LDS -- beside a neighbourhood at the bilayer's
+    * density that was the second workgroup per CU (20 LJ types: 0.65 ms against 0.39 ms at 6) -- and one more LDS gather per entry.
+    * The price: z moves by < 2^-43 of itself (3e-11 A at 400 A from the origin: 1e-10 relative in a pair force at worst); systems of
+    * up to 8 classes carry everything in the entry and keep their z to the last bit. */
    /* The pair loop addresses the staged beads by raw LDS byte offsets (z at slot * 8,
     * {x,y} at xy_off + slot * 16): the kernel has no static LDS, so the dynamic region
     * starts at LDS address 0 and the z gather needs no base add.  Checked by the host before the first launch, not assumed. */
@@ -199,9 +212,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                if (k < ns)
                {
                   XY_s[k + 1] = make_double2(pp[u].x, pp[u].y);
-                  Z_s[k + 1] = pp[u].z;
-                  if (!PACKED) T_s[k + 1] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
-                  if (tshift && !SHBIT) S_s[k + 1] = (unsigned char)(sh[u] != 13);
+                  Z_s[k + 1] = SHBIT ? pp[u].z : z_with_tags<PACKED>(pp[u].z, pp[u].w, tshift && sh[u] != 13);
                }
             }
          }
@@ -230,9 +241,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             if (k < ns)
             {
                XY_s[k + 1] = make_double2(pp[u].x, pp[u].y);
-               Z_s[k + 1] = pp[u].z;
-               if (!PACKED) T_s[k + 1] = (unsigned char)(__double_as_longlong(pp[u].w) & 0xff);
-               if (tshift && !SHBIT) S_s[k + 1] = (unsigned char)(sh[u] != 13);
+               Z_s[k + 1] = SHBIT ? pp[u].z : z_with_tags<PACKED>(pp[u].z, pp[u].w, tshift && sh[u] != 13);
             }
          }
       }
@@ -242,9 +251,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
       {
          /* staged slot 0: a bead far outside every cutoff.  List padding (entry 0) points
           * at it, so the walk needs no per-slot validity masks. */
-         XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = 1e30;
-         if (!PACKED) T_s[0] = 0;
-         if (!SHBIT) S_s[0] = 0;
+         XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = SHBIT ? 1e30 : z_with_tags<PACKED>(1e30, 0.0, false);
       }
       __syncthreads();
       long long base = ta.tile_base[t];
@@ -276,6 +283,12 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          int al = row0 + chunk * R + (active ? ain : 0);
          int a = ts + al;
          double4 pi = pos[a];
+         /* entries without the shift bit: the bead meets its partners at the z its partners meet IT at -- its staged z, tag bits and
+          * all (z_with_tags) -- so that f_ij = -f_ji holds to the last bit, as it does for an exact z.  (With the exact z here the
+          * two sides of a pair differed by 1e-11 of the force, which the per-bead virial 2 F_i (x) r_i multiplies by the bead's
+          * distance from the origin: 1e-8 of the virial on the 2 M-bead bilayer.)  The drift starts from the exact value. */
+         const double zexact = pi.z;
+         if (!SHBIT) pi.z = z_with_tags<PACKED>(pi.z, pi.w, false);
          int ti = (int)(__double_as_longlong(pi.w) & 0xffll);
          int cnt_full = active ? ta.nbr_cnt[a] : 0;
          if (smax < NSHELL - 1 && active)
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             /* pair math for slot u of the part; WD_ = the dword holding its entry, HI_ = upper half */
 #define NB_PAIR(u, WD_, HI_) do { \
                   const int nib_ = (int)(((WD_) >> ((HI_) ? 16 : 0)) & 0xfu); \
-                  int tjj = PACKED ? (SHBIT ? (nib_ & 7) : nib_) : (int)T_s[o[u] >> 4]; \
+                  int tjj = PACKED ? (SHBIT ? (nib_ & 7) : nib_) : (int)((zb[u] >> 1) & 0xffu); \
                   double4 lj = s_lj[LVL ? (int)L_s[ti * nlj + tjj] : ti * nlj + tjj];            /* {sigma^2, 4eps, shift, 24eps} */ \
                   double ir = 0.0, ir2; \
                   if (HAS_Q) { ir = rsqrt_f64_pair(r2[u]); ir2 = ir * ir; } \
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   } \
                   double fxij = -dvdr * x[u], fyij = -dvdr * y[u], fzij = -dvdr * z[u]; \
                   fxi += fxij; fyi += fyij; fzi += fzij; \
-                  if (tshift && (SHBIT ? (nib_ & 8) : (int)S_s[o[u] >> 4])) \
+                  if (tshift && (SHBIT ? (nib_ & 8) : (int)(zb[u] & 1u))) \
                   { \
                      fsx += fxij; fsy += fyij; fsz += fzij; \
                      acc[2] += fxij * x[u]; acc[3] += fyij * y[u]; acc[4] += fzij * z[u]; \
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             for (int h = 0; h < 8 / CH; h++)
             {
                /* 16 x staged slot of the part's neighbours */
-               unsigned o[CH];
+               unsigned o[CH], zb[CH];      /* zb: the low word of the partner's staged z (its tag bits, z_with_tags) */
                double x[CH], y[CH], z[CH], r2[CH];
 #pragma unroll
                for (int u = 0; u < CH; u++)
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + o[u]);
                   double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)((o[u] >> 1) + (unsigned)ZOFF);
                   double px = pxy.x, py = pxy.y;
+                  zb[u] = (unsigned)__double2loint(pz);
                   x[u] = pi.x - px; y[u] = pi.y - py; z[u] = pi.z - pz;
                   r2[u] = x[u] * x[u] + y[u] * y[u] + z[u] * z[u];
                }
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                const unsigned oe = PACKED ? (e16 & 0xfff0u) : (e16 << 4);
                const xy_t pxy = *(lds_cxy *)(__UINTPTR_TYPE__)(xy_off + oe);
                const double pz = *(lds_cdouble *)(__UINTPTR_TYPE__)((oe >> 1) + (unsigned)ZOFF);
-               const int tje = PACKED ? (SHBIT ? (int)(e16 & 7u) : (int)(e16 & 0xfu)) : (int)T_s[oe >> 4];
+               const int tje = PACKED ? (SHBIT ? (int)(e16 & 7u) : (int)(e16 & 0xfu)) : (int)(((unsigned)__double2loint(pz) >> 1) & 0xffu);
                double x = pi.x - pxy.x, y = pi.y - pxy.y, z = pi.z - pz;
                double r2 = x * x + y * y + z * z;
                if (r2 < rc2)
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                fa.vx[a] = x; fa.vy[a] = y; fa.vz[a] = z;
                v2max = __double2float_ru(x * x + y * y + z * z);
                double4 p = pi;
+               if (!SHBIT) p.z = zexact;
                p.x = fma(fa.dt, x, p.x); p.y = fma(fa.dt, y, p.y); p.z = fma(fa.dt, z, p.z);
                fa.pos_new[a] = p;
             }

@@ -48,6 +48,8 @@ int ddcmi_bl_sort_owned(ddcmi_ctx *ctx)
 {
    int rc = setup_grid(ctx);
    if (rc) return rc;
+   if (ctx->stage_cap_want > 0 && ctx->stage_cap_want < ctx->stage_cap) ctx->stage_cap = ctx->stage_cap_want;      /* (the old list is dead from here on) */
+   ctx->stage_cap_want = 0;
    GridParams &gp = ctx->gp;
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nb = cdiv(n, 256), ncell = gp.ncell, ncb = cdiv(ncell, 256);
@@ -185,7 +187,7 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx)
 }
 
 static int bl_launch_interior(ddcmi_ctx *ctx);
-static size_t nb_lds_bytes(const ddcmi_ctx *ctx, int pack_type, bool *use_lvl);
+static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused);
 extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
 {
    if (!ctx) return DDCMI_EINVAL;
@@ -593,7 +595,7 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       if (ctx->h_flags[12] > 0)
          SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)", ctx->h_flags[12], (long long)ctx->loop);
       bool again = false;
-      if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.05) + 32) + 63) & ~63; again = true; }
+      if (ctx->h_flags[4] > 0) { ctx->stage_cap = (((int)(ctx->h_flags[4] * 1.02) + 40) + 63) & ~63; again = true; }
       if (ctx->h_flags[0] > 0) { ctx->arena_cap = (unsigned long long)((double)tot[2] * 1.10) + 65536ull; again = true; }
       if (ctx->h_flags[1] > 0) { ctx->maxexcl = ctx->h_flags[1] + 4; again = true; }
       if (ctx->h_flags[5] > 0) { ctx->tmpw = ((int)(ctx->h_flags[5] * 1.1) + 8 + 7) & ~7; again = true; }
@@ -603,13 +605,18 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
       {
          ctx->list_entries = (int64_t)tot[0]; ctx->excl_entries = (int64_t)tot[1];
          ctx->maxnbr = maxw;
+         {
+            /* the largest neighbourhood of this build (the tiles' staging costs are 7 x their bead counts): what the NEXT rebuild needs */
+            int mx = 0;
+            for (int t = 0; t < ntile; t++) mx = std::max(mx, h_work[(size_t)ntile + t] / 7);
+            ctx->stage_cap_want = std::max(384, (((int)(mx * 1.015) + 40) + 63) & ~63);
+         }
          break;
       }
    }
    {
       /* workgroups of k_nonbond a CU holds: its LDS image of a neighbourhood (launch_forces), at most two by registers */
-      const size_t lds_nb = nb_lds_bytes(ctx, ctx->pack_type, nullptr);
-      int rcs = schedule_tiles(ctx, (int)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds_nb, 1))));
+      int rcs = schedule_tiles(ctx, std::max(1, nb_lds_layout(ctx, true).wgs));
       if (rcs) return rcs;
    }
    if (ctx->updateRate == 0)

@@ -3,20 +3,42 @@
 /* ------------------------------------------------------------------------- */
 /* defer_reduce: the caller (a time step) folds the nonbonded reduction and the final
  * energies into the launch that reduces the kinetic terms */
-/* LDS of one k_nonbond workgroup: the staged positions, the pair table -- direct (32 bytes per class pair) or in two levels (one byte per
- * class pair + the distinct entries) -- and, unless the list entries carry them, the staged beads' types and shifted-copy flags.
- * The level form is taken where the direct table would cost the second workgroup per CU (or fit no CU at all). */
-static size_t nb_lds_bytes(const ddcmi_ctx *ctx, int pack_type, bool *use_lvl)
+/* LDS of one k_nonbond workgroup.  Fixed layout (neighbourhoods of up to NB_ZOFF/16 beads: every Martini system): {x,y} [capl] at
+ * address 0, z [capl] at NB_ZOFF -- and whatever else fits goes into the GAP between them, which used to be wasted (4 KB beside a
+ * water neighbourhood, 9 KB beside the bilayer's): the fused step's rows of kinetic sums at its top, the pair table at its bottom.
+ * The pair table is the direct one (32 bytes per class pair) or, where that would cost the second workgroup per CU (or fit no CU at
+ * all), the two-level one (one byte per class pair + the distinct entries).  Types and shifted-copy flags that the list entries do
+ * not carry ride in the staged z (k_nonbond): no per-bead byte arrays. */
+static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
 {
    const size_t capl = (size_t)ctx->stage_cap + 2;
-   const size_t base = (capl * 16 <= NB_ZOFF ? NB_ZOFF + capl * 8 : capl * 24) + (pack_type ? 0 : capl) + (pack_type == 2 ? 0 : capl);
+   const size_t rows = (NB_THREADS / 64) * 8 * sizeof(double);
    const size_t npair = (size_t)ctx->nnb * ctx->nnb;
    const size_t direct = npair * sizeof(double4), level = (size_t)ctx->nlvl * sizeof(double4) + ((npair + 15) & ~(size_t)15);
-   /* (+ the fused step's rows of kinetic sums when they do not fit the gap in front of z: 512 bytes) */
-   auto wgs = [&](size_t table) { const size_t tot = base + table + 512; return tot > 160 * 1024 ? 0 : (int)std::min<size_t>(2, (160 * 1024) / tot); };
-   const bool lvl = ctx->nlvl > 0 && (ctx->force_lvl || wgs(level) > wgs(direct));
-   if (use_lvl) *use_lvl = lvl;
-   return base + (lvl ? level : direct);
+   auto lay = [&](size_t table, bool lvl)
+   {
+      NbLds l;
+      l.lvl = lvl; l.zfix = capl * 16 <= NB_ZOFF;
+      /* (while it stages, the kernel keeps its cell tables and slot -> cell map where the positions will lie -- 2 (NRC + 8) + 16 ints and
+       * 2 bytes per staged bead from address 0: the table, loaded before the staging, must start behind them) */
+      const size_t scratch = ((2 * (NRC + 8) + 16) * sizeof(int) + 2 * capl + 15) & ~(size_t)15;
+      size_t gap_lo = std::max(capl * 16, scratch), gap_hi = l.zfix ? NB_ZOFF : 0, end = l.zfix ? NB_ZOFF + capl * 8 : capl * 24;
+      l.ke_off = 0;
+      if (fused)
+      {
+         if (l.zfix && gap_lo + rows <= gap_hi) { gap_hi -= rows; l.ke_off = (int)gap_hi; }
+         else { end = (end + 7) & ~(size_t)7; l.ke_off = (int)end; end += rows; }
+      }
+      if (l.zfix && gap_lo + table <= gap_hi) l.tab_off = (int)gap_lo;
+      else { end = (end + 15) & ~(size_t)15; l.tab_off = (int)end; end += table; }
+      l.total = end;
+      l.wgs = end > 160 * 1024 ? 0 : (int)std::min<size_t>(2, (160 * 1024) / end);
+      return l;
+   };
+   const NbLds d = lay(direct, false);
+   if (ctx->nlvl <= 0) return d;
+   const NbLds v = lay(level, true);
+   return (ctx->force_lvl || v.wgs > d.wgs) ? v : d;
 }
 static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */)
 {
@@ -99,29 +121,20 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       bool packed = ctx->pack_type != 0;
       const bool shbit = ctx->pack_type == 2;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
-      /* fixed LDS layout ({x,y} at 0, z at NB_ZOFF) for neighbourhoods of up to NB_ZOFF/16 beads, which is every Martini system; else the run-time layout */
-      const bool zfix = capl * 16 <= NB_ZOFF;
-      bool lvl = false;
-      size_t lds = nb_lds_bytes(ctx, ctx->pack_type, &lvl);      /* positions + pair table (direct or in two levels) + types / shifted-copy flags unless the entries carry them */
-      if (lds > 160 * 1024) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       FuseArgs fa;
       memset(&fa, 0, sizeof(fa));
+      NbLds lay = nb_lds_layout(ctx, fuse != nullptr);
       if (fuse)
       {
-         /* the rows of kinetic sums ([waves][8] doubles): in the gap between the {x,y} array and z when there is one, else behind
-          * everything -- but never at the price of the second workgroup per CU */
-         const size_t rows = (NB_THREADS / 64) * 8 * sizeof(double);
-         const bool gap = zfix && capl * 16 + rows <= NB_ZOFF;
-         const size_t lds_f = gap ? lds : ((lds + 7) & ~(size_t)7) + rows;
-         const bool keeps_two = lds_f * 2 <= 160 * 1024 || lds * 2 > 160 * 1024;
-         if (zfix && keeps_two && lds_f <= 160 * 1024)
-         {
-            fa = *fuse;
-            fa.ke_off = gap ? (int)(NB_ZOFF - rows) : (int)((lds + 7) & ~(size_t)7);
-            lds = lds_f;
-         }
-         else { fuse->dt = 0.0; fuse = nullptr; }
+         /* the integrator's pass rides in the pair kernel only with the fixed layout, and never at the price of the second workgroup per CU */
+         const NbLds plain = nb_lds_layout(ctx, false);
+         if (lay.zfix && lay.wgs >= plain.wgs && lay.wgs > 0) { fa = *fuse; fa.ke_off = lay.ke_off; }
+         else { fuse->dt = 0.0; fuse = nullptr; lay = plain; }
       }
+      /* fixed LDS layout ({x,y} at 0, z at NB_ZOFF) for neighbourhoods of up to NB_ZOFF/16 beads, which is every Martini system; else the run-time layout */
+      const bool zfix = lay.zfix, lvl = lay.lvl;
+      const size_t lds = lay.total;
+      if (lay.wgs <= 0) SETERR(ctx, DDCMI_EUNSUPPORTED, "nonbonded kernel needs %zu bytes of LDS (> 160 KiB)", lds);
       NbTileArgs na;
       na.ntile = ntile; na.stage_stride = ctx->stage_cap; na.cap = (int)capl; na.nlj = ctx->nnb;
       na.cell_start_o = ctx->cell_start_o.p; na.stage_idx = ctx->stage_idx.p; na.tile_nstage = ctx->tile_nstage.p;
@@ -133,7 +146,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.hdisp = hdisp_on ? ctx->d_results + R_DISP + 1 + hpar : nullptr;
       na.hrecv3 = ctx->halo_in_recv ? ctx->hrecv3.p : nullptr; na.halo_src = ctx->halo_src.p;
       na.halo_full_walk = (direct && ctx->shell_skip) ? 1 : 0;
-      na.lvlidx = ctx->d_lvlidx.p; na.nlvl = ctx->nlvl;
+      na.lvlidx = ctx->d_lvlidx.p; na.nlvl = ctx->nlvl; na.tab_off = lay.tab_off;
       na.fb = (has_bonded && n > 0) ? ctx->fb.p : nullptr;
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
