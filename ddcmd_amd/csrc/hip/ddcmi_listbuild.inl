@@ -86,6 +86,7 @@ struct NbTileArgs
     * r^2 >= sh_r0sq + (s - 1) sh_step -- is outside the cut-off while sqrt(that) - 2 D > r_cut, and the walk of every row ends with shell s - 1
     * (nbr_cum).  Entries of later shells inside the last group walked are simply tested: they are real neighbours. */
    const double *disp; const uint4 *nbr_cum; double sh_r0sq, sh_step;
+   double sh_reach[NSHELL];             /* [s], s >= 1: how far shell s begins beyond the cut-off, sqrt(sh_r0sq + (s - 1) sh_step) (1 - 1e-4) - r_cut: the walk ends with shell s - 1 while that exceeds the pairs' possible approach (formed once on the host: a square root per shell and wave was 6 % of the kernel's instructions) */
    /* decomposed runs: D bounds the OWNED beads' moves only; hdisp (not null) points at the largest squared distance of a received
     * halo bead from its place at the rebuild (k_halo_update), and a pair distance has changed by at most D + max(D, sqrt(*hdisp)) */
    const double *hdisp;

@@ -91,8 +91,9 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    if (ta.disp)
    {
       const double Down = *ta.disp, Dhalo = ta.hdisp ? sqrt(*ta.hdisp) : 0.0;
-      const double twoD = Down + fmax(Down, Dhalo), rc = sqrt(rc2);
-      while (smax >= 1 && sqrt(ta.sh_r0sq + (double)(smax - 1) * ta.sh_step) * (1.0 - 1e-4) - twoD > rc) smax--;
+      const double twoD = Down + fmax(Down, Dhalo);
+#pragma unroll
+      for (int s_ = NSHELL - 1; s_ >= 1; s_--) if (ta.sh_reach[s_] > twoD) smax = s_ - 1;      /* (sh_reach grows with s: the smallest such s decides) */
    }
    int nown = 0, ts = 0, r_lo = 0, r_hi = 0;
    if (ta.halo_full_walk && mine && ((ta.tile_work[t] >> 30) & 1)) smax = NSHELL - 1;      /* (received beads nobody measures: NbTileArgs::hrecv3) */
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    {
       for (int k = threadIdx.x; k < ntab; k += NB_BLOCK) { double4 e_ = ljtab[k]; if (HAS_Q && !LVL) e_.w = kqtab[k]; s_lj[k] = e_; }      /* (LVL: the entries come with their fourth word) */
       if (LVL) for (int k = threadIdx.x; k < ta.nlj * ta.nlj; k += NB_BLOCK) L_s[k] = ta.lvlidx[k];
+
       int ns = ta.tile_nstage[t];
       /* Virial.  A pair of two unshifted beads contributes f_ij (x) (r_i - r_j) from i's side and
        * the mirror term from j's side; the two add up to 2 f_ij (x) r_i + 2 f_ji (x) r_j, so each

@@ -143,6 +143,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.nbr16 = ctx->nbr16.p; na.nbr_cnt = ctx->nbr_cnt.p; na.perm = ctx->tile_perm.p;
       na.tile_work = ctx->tile_work.p; na.halo_shift = ctx->halo_shift.p; na.nloc = n;
       na.disp = ctx->shell_skip ? ctx->d_results + R_DISP : nullptr; na.nbr_cum = ctx->nbr_cum.p; na.sh_r0sq = ctx->sh_r0sq; na.sh_step = ctx->sh_step;
+      na.sh_reach[0] = -1e300;
+      for (int sq = 1; sq < NSHELL; sq++) na.sh_reach[sq] = sqrt(ctx->sh_r0sq + (double)(sq - 1) * ctx->sh_step) * (1.0 - 1e-4) - ctx->rmax;
       na.hdisp = hdisp_on ? ctx->d_results + R_DISP + 1 + hpar : nullptr;
       na.hrecv3 = ctx->halo_in_recv ? ctx->hrecv3.p : nullptr; na.halo_src = ctx->halo_src.p;
       na.halo_full_walk = (direct && ctx->shell_skip) ? 1 : 0;
