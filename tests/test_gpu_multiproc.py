@@ -81,9 +81,11 @@ def _merge(recs, key_gid, key):
     return gid[order], np.concatenate([r[key] for r in recs], axis=1)[:, order]
 
 
-@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 2)])
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
 def test_water_between_processes(grid):
-    """forces at step 0 and the state after 45 steps (two rebuilds with migration between the processes)"""
+    """forces at step 0 and the state after 45 steps (two rebuilds with migration between the processes).  2x2x2: eight ranks, seven
+    peers each, a halo of received beads only -- the bench's 8-GPU decomposition, and the configuration in which k_nonbond stages
+    the neighbours' beads straight from the exchange's receive buffer (no halo update launch; round 5)"""
     s = ddcmd_amd.make_water_setup(12)          # 6912 beads, box 97.5 A: bricks of 48.7 A
     o = pyoracle.Oracle(s)
     e0, v0 = o.forces()
