@@ -308,10 +308,12 @@ def test_tiled_bilayer_follows_the_oracle_for_a_thousand_steps():
     m.close()
 
 
-@pytest.mark.parametrize("ntypes", [12, 20])
+@pytest.mark.parametrize("ntypes", [12, 20, 26])
 def test_many_lj_types(ntypes):
-    """9..16 LJ types: packed entries without the shift bit (shifted partners flagged in LDS);
-    > 16 types: bare 16-bit slots with the type table in LDS.  Charged beads on top."""
+    """9..16 LJ types: packed entries without the shift bit (the shifted-copy flag rides in bit 0 of the partner's staged z);
+    > 16 types: bare 16-bit slots, the partner's class in bits 1-8 of its staged z.  Charged beads on top.  Every pair of types
+    has its own random sigma and eps here: 78 / 210 distinct table entries (two-level table where it saves a workgroup per CU) and,
+    at 26 types, 351 -- more than the level table's byte indexes: the direct table."""
     from ddcmd_amd.martini import MartiniHIP, MartiniGroup
     s = make_water_setup(10)
     rs = np.random.RandomState(7)
