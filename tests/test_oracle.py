@@ -606,3 +606,28 @@ def test_langevin_drift_velocity_closed_form():
     with pytest.raises(Exception, match="Teq_dynamics"):
         load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = 310 K; tau = 1 ps; Teq_dynamics = GLOBAL_ENERGY; }")
     load_deck(deck, extra_objects="group GROUP { type = LANGEVIN; Teq = 310 K; tau = 1 ps; Teq_dynamics = EXPLICIT_TIME; }")
+
+
+def test_relabelled_bead_types_leave_the_physics_alone():
+    """ddcmd_amd.synth.relabel_types (the workload of the type-count bench rows and of the 40-type GPU test): every LJ type split into
+    copies of itself, every species copied with it, every bead's copy drawn at random -- forces, energies, virial and a short
+    trajectory of the oracle are those of the original deck in every bit, while the (type, charge) class table grows from 6 to 48"""
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import relabel_types
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    s2 = relabel_types(s, 40)
+    assert s2.nlj == 40 and s2.natoms == s.natoms and s2.nspecies > s.nspecies
+    classes = lambda t: len(set(zip(t.ljtype[t.species].tolist(), t.charge[t.species].tolist())))
+    assert classes(s) <= 8 and classes(s2) >= 44
+    assert np.array_equal(s2.mass[s2.species], s.mass[s.species]) and np.array_equal(s2.charge[s2.species], s.charge[s.species])
+    assert np.array_equal(s2.resitype[s2.species], s.resitype[s.species]) and np.array_equal(s2.moltype[s2.species], s.moltype[s.species])
+    a, b = pyoracle.Oracle(s), pyoracle.Oracle(s2)
+    ea, va = a.forces(); eb, vb = b.forces()
+    assert ea == eb and np.array_equal(va, vb)
+    assert np.array_equal(a.fx, b.fx) and np.array_equal(a.fy, b.fy) and np.array_equal(a.fz, b.fz)
+    a.group_temperature(); b.group_temperature()
+    ra, rb = a.step(12), b.step(12)
+    assert ra[0] == rb[0] and ra[2] == rb[2] and np.array_equal(a.rx, b.rx) and np.array_equal(a.vz, b.vz)
+    with pytest.raises(ValueError):
+        relabel_types(s, 3)
