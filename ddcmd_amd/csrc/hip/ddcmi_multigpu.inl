@@ -685,7 +685,27 @@ static int mg_xchg_halo(ddcmi_ctx *ctx, const double *sbase, double *rbase, int 
       return mg_host_exchange(ctx, st, ms.n, ms.peer, sdev, sc, mr.n, mr.peer, rdev, rc_);
    }
    ncclComm_t comm = (ncclComm_t)ctx->comm;
+   /* DDCMI_DEBUG_SPLIT_MSGS=<k> (with DDCMI_DEBUG_HOOKS=1, loopback only): every message travels as k send/recv pairs -- what a rank with k peers hands
+    * RCCL per step (2x2x2: seven), on the one GPU there is to measure on: the same bytes, k times the operations of the group */
+   static const int split = (getenv("DDCMI_DEBUG_HOOKS") && getenv("DDCMI_DEBUG_SPLIT_MSGS")) ? std::max(1, atoi(getenv("DDCMI_DEBUG_SPLIT_MSGS"))) : 1;
    NCCLCHK2(ctx, ncclGroupStart());
+   if (split > 1 && ctx->loopback)
+   {
+      for (int k = 0; k < ms.n; k++)
+         for (int q = 0; q < split; q++)
+         {
+            const size_t a = (size_t)ms.cnt[k] * q / split, b = (size_t)ms.cnt[k] * (q + 1) / split;
+            if (b > a) NCCLCHK2(ctx, ncclSend(sbase + ((size_t)ms.off[k] + a) * width, (b - a) * width, ncclDouble, ms.peer[k], comm, st));
+         }
+      for (int k = 0; k < mr.n; k++)
+         for (int q = 0; q < split; q++)
+         {
+            const size_t a = (size_t)mr.cnt[k] * q / split, b = (size_t)mr.cnt[k] * (q + 1) / split;
+            if (b > a) NCCLCHK2(ctx, ncclRecv(rbase + ((size_t)mr.off[k] + a) * width, (b - a) * width, ncclDouble, mr.peer[k], comm, st));
+         }
+      NCCLCHK2(ctx, ncclGroupEnd());
+      return DDCMI_OK;
+   }
    for (int k = 0; k < ms.n; k++) NCCLCHK2(ctx, ncclSend(sbase + (size_t)ms.off[k] * width, (size_t)ms.cnt[k] * width, ncclDouble, ms.peer[k], comm, st));
    for (int k = 0; k < mr.n; k++) NCCLCHK2(ctx, ncclRecv(rbase + (size_t)mr.off[k] * width, (size_t)mr.cnt[k] * width, ncclDouble, mr.peer[k], comm, st));
    NCCLCHK2(ctx, ncclGroupEnd());
