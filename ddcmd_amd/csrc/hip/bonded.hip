@@ -16,6 +16,8 @@
 #include <math.h>
 #include <array>
 #include <map>
+#include <string>
+#include <unordered_map>
 
 #define FLOAT_EPS 1e-08
 #define NEAR_ZERO_ANGLE 0.017453292519943295
@@ -236,8 +238,21 @@ struct GatherRows
    const double4 *tpar;                  /* {k, delta, func, n} */
    int nheavy; const int *hatoms;        /* atoms with func-1 angles or dihedrals */
    int nlight; const int *latoms;        /* atoms with bonds or func 2/10 angles, caller order: a molecule's atoms are neighbouring lanes */
+   /* the light launch reads its rows as PATTERNS (round 5): a row names its partners by their distance in atom numbers, and atoms whose
+    * rows then read the same -- the n-th atom of every copy of a molecule -- share one copy of them.  A bilayer's 1.28 M lipid atoms
+    * have 12 patterns: the rows (55 B per atom, a third of the launch's traffic and 25 of its 72 us) come out of the L1 instead of the HBM.
+    * A system without repetition has as many patterns as atoms and reads what it read before. */
+   int nlanes; const int2 *ldesc;        /* [nlanes] {atom, pattern}: latoms[] with filler lanes {nrow, 0} in front of a molecule that would straddle two workgroups (its partners are then all in the workgroup's LDS: the trips read nothing from memory) */
+   const int4 *pat_hdr;                  /* [npat] {first bond row, bond rows, first angle row, angle rows} */
+   const int2 *pat_brow;                 /* {partner - atom, pid << 2 | role} */
+   const int4 *pat_arow;                 /* {other atoms - atom in term order, pid << 2 | role, 0} */
+   /* the four tables above and the bond / angle parameters as ONE block of 16-byte pieces (hdr | brow | arow | bpar | apar, the offsets in
+    * pieces): when it has at most GB_TAB_PIECES of them -- a force field's lipids: under 2 KB -- every workgroup of the light launch copies it
+    * to LDS and the trips of its lanes read nothing from memory but their partners' records (k_bonded_gather<false, true>) */
+   const int4 *tab; int tab_pieces, tab_brow, tab_arow, tab_bpar, tab_apar;
 };
-template <bool HEAVY>      /* false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers) */
+#define GB_TAB_PIECES 384      /* 6 KB */
+template <bool HEAVY, bool TABL = false>      /* HEAVY false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers).  TABL: row patterns and parameters in LDS */
 __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, int ntot, BoxArgs box, int excl_mask,
                                                        const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double4 *fb, double *partials)
 {
@@ -247,14 +262,28 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
     * the workgroup's atoms (for a molecule in the middle of the block: all of them) is read from LDS instead of through a slot
     * look-up and a scattered 32-byte gather each (five record gathers per bead became one: the light launch of the 2 M-bead
     * bilayer moved 0.35 GB in 32-byte pieces) */
-   __shared__ double4 s_rec[256];
+   /* the lanes' bead records; behind the terms the same bytes take the lanes' GB_NV sums, [value][lane] */
+   __shared__ double4 s_big[(GB_NV * 256 * sizeof(double)) / sizeof(double4)];
+   double4 *const s_rec = s_big;
    __shared__ int s_atom[256];
+   __shared__ int4 s_tab[TABL ? GB_TAB_PIECES : 1];
+   if (TABL) for (int k = threadIdx.x; k < gr.tab_pieces; k += 256) s_tab[k] = gr.tab[k];      /* (ordered by the barrier below) */
+   const int4 *const t_hdr = TABL ? s_tab : gr.pat_hdr;
+   const int2 *const t_brow = TABL ? (const int2 *)(s_tab + gr.tab_brow) : gr.pat_brow;
+   const int4 *const t_arow = TABL ? s_tab + gr.tab_arow : gr.pat_arow;
+   const double2 *const t_bpar = TABL ? (const double2 *)(s_tab + gr.tab_bpar) : gr.bpar;
+   const double4 *const t_apar = TABL ? (const double4 *)(s_tab + gr.tab_apar) : gr.apar;
    const int j = blockIdx.x * 256 + threadIdx.x;
    double acc[GB_NV];
 #pragma unroll
    for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
-   int i = 0x7fffffff, o = gr.nrow;
-   if (j < (HEAVY ? gr.nheavy : gr.nlight)) { o = HEAVY ? gr.hatoms[j] : gr.latoms[j]; i = slot[o]; }
+   int i = 0x7fffffff, o = gr.nrow, pat = 0;
+   if (j < (HEAVY ? gr.nheavy : gr.nlanes))
+   {
+      if (HEAVY) o = gr.hatoms[j];
+      else { const int2 d = gr.ldesc[j]; o = d.x; pat = d.y; }
+      if (o < gr.nrow) i = slot[o];
+   }
    const bool here = o < gr.nrow && (unsigned)i < (unsigned)ntot;      /* owned, or a halo copy on this rank */
    const double4 me = here ? pos[i] : make_double4(0.0, 0.0, 0.0, 0.0);
    s_atom[threadIdx.x] = here ? o : -1;
@@ -268,7 +297,9 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
    };
    if (here && i < nown)
    {
-      const int b0 = HEAVY ? 0 : gr.boff[o], b1 = HEAVY ? 0 : gr.boff[o + 1], a0 = HEAVY ? gr.haoff[o] : gr.aoff[o], a1 = HEAVY ? gr.haoff[o + 1] : gr.aoff[o + 1];
+      int b0 = 0, b1 = 0, a0, a1;
+      if (HEAVY) { a0 = gr.haoff[o]; a1 = gr.haoff[o + 1]; }
+      else { const int4 h = t_hdr[pat]; b0 = h.x; b1 = h.x + h.y; a0 = h.z; a1 = h.z + h.w; }
       const int t0 = HEAVY ? gr.toff[o] : 0, t1 = HEAVY ? gr.toff[o + 1] : 0;
       if (b1 + a1 + t1 > b0 + a0 + t0)
       {
@@ -278,14 +309,14 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
           * flight and its term is evaluated: one exposed memory latency per trip instead of three */
          if (!HEAVY && b1 > b0)
          {
-         int2 row_n = gr.brow[b0];
+         int2 row_n = t_brow[b0];
          for (int r = b0; r < b1; r++)
          {
             const int2 row = row_n;
-            const double4 q = rec(row.x);
-            if (r + 1 < b1) row_n = gr.brow[r + 1];
+            const double4 q = rec(o + row.x);
+            if (r + 1 < b1) row_n = t_brow[r + 1];
             const int role = row.y & 3;
-            const double2 par = gr.bpar[row.y >> 2];
+            const double2 par = t_bpar[row.y >> 2];
             double e, fD[3], vir[6];
             bond_eval(box, role == 0 ? me : q, role == 0 ? q : me, par.x, par.y, e, fD, vir);
             const double sg = role == 0 ? 1.0 : -1.0;
@@ -300,15 +331,16 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          }
          if (a1 > a0)
          {
-         const int4 *arows = HEAVY ? gr.harow : gr.arow;
+         const int4 *arows = HEAVY ? gr.harow : t_arow;
+         const int rel = HEAVY ? 0 : o;      /* (pattern rows name their atoms relative to the lane's) */
          int4 arow_n = arows[a0];
          for (int r = a0; r < a1; r++)
          {
             const int4 row = arow_n;
-            const double4 q1 = rec(row.x), q2 = rec(row.y);
+            const double4 q1 = rec(rel + row.x), q2 = rec(rel + row.y);
             if (r + 1 < a1) arow_n = arows[r + 1];
             const int role = row.z & 3;
-            const double4 par = gr.apar[row.z >> 2];
+            const double4 par = HEAVY ? gr.apar[row.z >> 2] : t_apar[row.z >> 2];
             double e, fI[3], fK[3], vir[6];
             if (angle_eval<HEAVY>(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role == 2 ? me : q2, (int)par.z, par.x, par.y, excl_mask, e, fI, fK, vir))
             {
@@ -351,17 +383,26 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          else { fx[i] += fxi; fy[i] += fyi; fz[i] += fzi; }
       }
    }
-   /* block sums, GB_NV values per block at stride 16 */
-   __shared__ double s_red[4][GB_NV];
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   /* block sums, GB_NV values per block at stride 16.  Every lane leaves its sums in LDS ([value][lane]: conflict-free), then wave w adds
+    * up values w, w + 4, w + 8: four columns per lane in a fixed order and ONE wave reduction per value (ten reductions per wave of ten
+    * lane values each were a sixth of the light launch's time) */
+   double *const s_acc = (double *)s_big;
+   __syncthreads();      /* (the last partner record has been read) */
 #pragma unroll
    for (int k = 0; k < GB_NV; k++)
-   {
-      double sv = wsum(acc[k]);
-      if (lane == 0) s_red[w][k] = sv;
-   }
+      if (HEAVY ? k != 0 : (k < 2 || k > 3)) s_acc[k * 256 + threadIdx.x] = acc[k];      /* the light launch has no dihedrals, the heavy one no bonds: those sums are zero */
    __syncthreads();
-   if (threadIdx.x < GB_NV) partials[(size_t)blockIdx.x * 16 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+   for (int kk = 0; kk < (GB_NV + 3) / 4; kk++)
+   {
+      const int k = w + 4 * kk;
+      if (k >= GB_NV) break;
+      double sv = 0.0;
+      if (HEAVY ? k != 0 : (k < 2 || k > 3))
+         sv = wsum((s_acc[k * 256 + lane] + s_acc[k * 256 + 64 + lane]) + (s_acc[k * 256 + 128 + lane] + s_acc[k * 256 + 192 + lane]));
+      if (lane == 0) partials[(size_t)blockIdx.x * 16 + k] = sv;
+   }
 }
 /* workgroup k sums column k of the gather kernel's partials in a fixed order and files it where
  * finish_energy expects the per-kind sums (the whole bonded virial goes to the bond block) */
@@ -478,7 +519,7 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
                       int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta)
 {
    int rc;
-   ctx->inc_nrow = 0; ctx->inc_light = 0; ctx->inc_heavy = 0;
+   ctx->inc_nrow = 0; ctx->inc_light = 0; ctx->inc_lanes = 0; ctx->inc_heavy = 0;
    ctx->nbond = nbond; ctx->nangle = nangle; ctx->ntors = ntors;
    if (nbond + nangle + ntors > 0)
    {
@@ -556,7 +597,58 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
       std::vector<int> latoms;
       for (int a = 0; a < nrow; a++) if (boff[a + 1] > boff[a] || aoff[a + 1] > aoff[a]) latoms.push_back(a);
       ctx->inc_light = (int)latoms.size();
+      /* row patterns of the light launch (GatherRows::ldesc): an atom's rows with the partners as differences of atom numbers */
+      std::vector<int> ldesc, pat_hdr, pat_brow, pat_arow;
+      {
+         std::unordered_map<std::string, int> seen;
+         std::string key;
+         ldesc.reserve(2 * latoms.size() + 2);
+         /* molecules = connected components of the terms' graph; a run of a molecule's atoms that fits one workgroup does not straddle two */
+         std::vector<int> root((size_t)nrow);
+         for (int a = 0; a < nrow; a++) root[a] = a;
+         auto find = [&](int a) { while (root[a] != a) { root[a] = root[root[a]]; a = root[a]; } return a; };
+         auto join = [&](int a, int b) { a = find(a); b = find(b); if (a != b) root[std::max(a, b)] = std::min(a, b); };
+         for (int t = 0; t < nbond; t++) join(bond_ij[2 * t], bond_ij[2 * t + 1]);
+         for (int t = 0; t < nangle; t++) { join(angle_ijk[3 * t], angle_ijk[3 * t + 1]); join(angle_ijk[3 * t], angle_ijk[3 * t + 2]); }
+         for (int t = 0; t < ntors; t++) for (int r = 1; r < 4; r++) join(tors_ijkl[4 * t], tors_ijkl[4 * t + r]);
+         size_t run_end = 0;      /* index in latoms behind the current run */
+         for (size_t la_i = 0; la_i < latoms.size(); la_i++)
+         {
+            const int a = latoms[la_i];
+            if (la_i == run_end)
+            {
+               const int r0 = find(a);
+               while (run_end < latoms.size() && find(latoms[run_end]) == r0) run_end++;
+               const size_t len = run_end - la_i, at = (ldesc.size() / 2) % 256;
+               if (len <= 256 && at + len > 256) for (size_t k = at; k < 256; k++) { ldesc.push_back(nrow); ldesc.push_back(0); }
+            }
+            const int nb = boff[a + 1] - boff[a], na = aoff[a + 1] - aoff[a];
+            std::vector<int> w;
+            w.reserve(2 + 2 * (size_t)nb + 3 * (size_t)na);
+            w.push_back(nb); w.push_back(na);
+            for (int r = boff[a]; r < boff[a + 1]; r++) { w.push_back(brow[2 * (size_t)r] - a); w.push_back(brow[2 * (size_t)r + 1]); }
+            for (int r = aoff[a]; r < aoff[a + 1]; r++) { w.push_back(arow[4 * (size_t)r] - a); w.push_back(arow[4 * (size_t)r + 1] - a); w.push_back(arow[4 * (size_t)r + 2]); }
+            key.assign((const char *)w.data(), w.size() * sizeof(int));
+            auto it = seen.find(key);
+            int p;
+            if (it != seen.end()) p = it->second;
+            else
+            {
+               p = (int)seen.size();
+               seen.emplace(key, p);
+               pat_hdr.push_back((int)(pat_brow.size() / 2)); pat_hdr.push_back(nb); pat_hdr.push_back((int)(pat_arow.size() / 4)); pat_hdr.push_back(na);
+               for (int k = 0; k < nb; k++) { pat_brow.push_back(w[2 + 2 * k]); pat_brow.push_back(w[3 + 2 * k]); }
+               for (int k = 0; k < na; k++) { const int *q = &w[2 + 2 * nb + 3 * k]; pat_arow.push_back(q[0]); pat_arow.push_back(q[1]); pat_arow.push_back(q[2]); pat_arow.push_back(0); }
+            }
+            ldesc.push_back(a); ldesc.push_back(p);
+         }
+         ctx->inc_npat = (int)seen.size();
+         ctx->inc_lanes = (int)(ldesc.size() / 2);
+         ldesc.push_back(nrow); ldesc.push_back(0);
+         pat_hdr.resize(pat_hdr.size() + 4, 0); pat_brow.resize(pat_brow.size() + 2, 0); pat_arow.resize(pat_arow.size() + 4, 0);      /* (the rows' read-ahead) */
+      }
       latoms.push_back(0);
+      std::vector<int> tab;      /* GatherRows::tab -- built below, when the parameter sets are complete */
       {
          std::vector<int> fill(toff.begin(), toff.end() - 1);
          for (int t = 0; t < ntors; t++)
@@ -573,9 +665,22 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
       }
       for (int k = 0; k < 3; k++) if (ids[k].size() >= (1u << 29)) SETERR(ctx, DDCMI_EINVAL, "too many distinct bonded parameter sets");
       for (int k = 0; k < 3; k++) par[k].resize(par[k].size() + 4, 0.0);
+      {
+         auto pieces = [](size_t bytes) { return (int)((bytes + 15) / 16); };
+         auto put = [&](const void *src, size_t bytes) { const int at = (int)(tab.size() / 4); tab.resize(tab.size() + 4 * (size_t)pieces(bytes), 0); memcpy(&tab[4 * (size_t)at], src, bytes); return at; };
+         put(pat_hdr.data(), pat_hdr.size() * sizeof(int));
+         ctx->inc_tab_off[0] = put(pat_brow.data(), pat_brow.size() * sizeof(int));
+         ctx->inc_tab_off[1] = put(pat_arow.data(), pat_arow.size() * sizeof(int));
+         ctx->inc_tab_off[2] = put(par[0].data(), par[0].size() * sizeof(double));
+         ctx->inc_tab_off[3] = put(par[1].data(), par[1].size() * sizeof(double));
+         ctx->inc_tab_pieces = (int)(tab.size() / 4);
+      }
       if ((rc = up(ctx, ctx->inc_boff, boff.data(), boff.size())) || (rc = up(ctx, ctx->inc_aoff, aoff.data(), aoff.size())) || (rc = up(ctx, ctx->inc_toff, toff.data(), toff.size())) ||
           (rc = up(ctx, ctx->inc_hatoms, hatoms.data(), hatoms.size())) || (rc = up(ctx, ctx->inc_latoms, latoms.data(), latoms.size())) || (rc = up(ctx, ctx->inc_haoff, haoff.data(), haoff.size())) || (rc = up(ctx, ctx->inc_harow, harow.data(), harow.size())) ||
           (rc = up(ctx, ctx->inc_brow, brow.data(), brow.size())) || (rc = up(ctx, ctx->inc_arow, arow.data(), arow.size())) || (rc = up(ctx, ctx->inc_trow, trow.data(), trow.size())) ||
+          (rc = up(ctx, ctx->inc_ldesc, ldesc.data(), ldesc.size())) || (rc = up(ctx, ctx->inc_pat_hdr, pat_hdr.data(), pat_hdr.size())) ||
+          (rc = up(ctx, ctx->inc_pat_brow, pat_brow.data(), pat_brow.size())) || (rc = up(ctx, ctx->inc_pat_arow, pat_arow.data(), pat_arow.size())) ||
+          (rc = up(ctx, ctx->inc_tab, tab.data(), tab.size())) ||
           (rc = up(ctx, ctx->inc_bpar, par[0].data(), par[0].size())) || (rc = up(ctx, ctx->inc_apar, par[1].data(), par[1].size())) || (rc = up(ctx, ctx->inc_tpar, par[2].data(), par[2].size()))) return rc;
       ctx->inc_nrow = nrow;
    }
@@ -700,7 +805,9 @@ static GatherRows gather_rows(const ddcmi_ctx *ctx)
 {
    GatherRows gr = {ctx->inc_nrow, ctx->inc_boff.p, ctx->inc_aoff.p, ctx->inc_haoff.p, ctx->inc_toff.p, (const int2 *)ctx->inc_brow.p, (const int4 *)ctx->inc_arow.p,
                     (const int4 *)ctx->inc_harow.p, (const int4 *)ctx->inc_trow.p,
-                    (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p, ctx->inc_light, ctx->inc_latoms.p};
+                    (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p, ctx->inc_light, ctx->inc_latoms.p,
+                    ctx->inc_lanes, (const int2 *)ctx->inc_ldesc.p, (const int4 *)ctx->inc_pat_hdr.p, (const int2 *)ctx->inc_pat_brow.p, (const int4 *)ctx->inc_pat_arow.p,
+                    (const int4 *)ctx->inc_tab.p, ctx->inc_tab_pieces, ctx->inc_tab_off[0], ctx->inc_tab_off[1], ctx->inc_tab_off[2], ctx->inc_tab_off[3]};
    return gr;
 }
 
@@ -761,13 +868,17 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb)
     * works on the atoms it owns */
    if (!ctx->bonded_gid) { int rcs = ddcmi_ensure_slots(ctx); if (rcs) return rcs; }
    const int *slot = ctx->bonded_gid ? ctx->slot_of_atom.p : ctx->slot_of_orig.p;
-   const int nblk = cdiv(ctx->inc_light, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
+   const int nblk = cdiv(ctx->inc_lanes, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
    ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
    GatherRows gr = gather_rows(ctx);
    double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
    if (nblk > 0)
-      hipLaunchKernelGGL(k_bonded_gather<false>, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
+   {
+      static const bool no_lds_tab = getenv("DDCMI_NO_BONDED_LDS_TABLES") != nullptr;
+      auto kl = (gr.tab_pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<false, true> : k_bonded_gather<false, false>;
+      hipLaunchKernelGGL(kl, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->bpartials.p);
+   }
    if (nblk2 > 0)
       hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2);
