@@ -254,7 +254,7 @@ struct GatherRows
 #define GB_TAB_PIECES 384      /* 6 KB */
 template <bool HEAVY, bool TABL = false>      /* HEAVY false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers).  TABL: row patterns and parameters in LDS */
 __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, int ntot, BoxArgs box, int excl_mask,
-                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double4 *fb, double *partials)
+                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double4 *fb, double *partials, int pstride)
 {
    /* lane = entry of the list of atoms that have terms of this launch, in caller order: the lanes of a
     * molecule sit together, so their rows are read with unit stride and the partners' bead records are the
@@ -401,28 +401,30 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
       double sv = 0.0;
       if (HEAVY ? k != 0 : (k < 2 || k > 3))
          sv = wsum((s_acc[k * 256 + lane] + s_acc[k * 256 + 64 + lane]) + (s_acc[k * 256 + 128 + lane] + s_acc[k * 256 + 192 + lane]));
-      if (lane == 0) partials[(size_t)blockIdx.x * 16 + k] = sv;
+      if (lane == 0) partials[(size_t)k * pstride + blockIdx.x] = sv;      /* [value][workgroup]: k_reduce_gather reads whole cache lines */
    }
 }
 /* workgroup k sums column k of the gather kernel's partials in a fixed order and files it where
  * finish_energy expects the per-kind sums (the whole bonded virial goes to the bond block) */
-__global__ __launch_bounds__(256) void k_reduce_gather(const double *__restrict__ partials, int nblocks, const double *__restrict__ partials2, int nblocks2, double *results)
+#define RG_T 1024
+__global__ __launch_bounds__(RG_T) void k_reduce_gather(const double *__restrict__ partials, int nblocks, int pstride, double *results)
 {
-   __shared__ double s[256];
+   __shared__ double s[RG_T];
    const int k = blockIdx.x;
-   /* independent partial sums (a single chain of dependent loads is latency-bound: 9.5 us for the 5000 rows of the 2 M-bead bilayer) */
+   /* row k of the [value][workgroup] sums of both launches (the light launch's workgroups, then the heavy one's): unit stride (rows of 16 values
+    * per workgroup made every load instruction touch 64 cache lines: 8 us for the 5000 workgroups of the 2 M-bead bilayer); independent partial sums */
+   const double *row = partials + (size_t)k * pstride;
    double p[4] = {0.0, 0.0, 0.0, 0.0};
    int b = threadIdx.x;
-   for (; b + 3 * 256 < nblocks; b += 4 * 256)
+   for (; b + 3 * RG_T < nblocks; b += 4 * RG_T)
    {
 #pragma unroll
-      for (int u = 0; u < 4; u++) p[u] += partials[(size_t)(b + u * 256) * 16 + k];
+      for (int u = 0; u < 4; u++) p[u] += row[b + u * RG_T];
    }
-   for (int u = 0; b < nblocks; b += 256, u++) p[u] += partials[(size_t)b * 16 + k];
-   for (b = threadIdx.x; b < nblocks2; b += 256) p[0] += partials2[(size_t)b * 16 + k];
+   for (int u = 0; b < nblocks; b += RG_T, u++) p[u] += row[b];
    s[threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
    __syncthreads();
-   for (int off = 128; off > 0; off >>= 1)
+   for (int off = RG_T / 2; off > 0; off >>= 1)
    {
       if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
       __syncthreads();
@@ -869,21 +871,22 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb)
    if (!ctx->bonded_gid) { int rcs = ddcmi_ensure_slots(ctx); if (rcs) return rcs; }
    const int *slot = ctx->bonded_gid ? ctx->slot_of_atom.p : ctx->slot_of_orig.p;
    const int nblk = cdiv(ctx->inc_lanes, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
-   ENSURE(ctx, ctx->bpartials, (size_t)(nblk + nblk2 + 1) * 16);
+   const int pstride = (nblk + nblk2 + 15) & ~15;
+   ENSURE(ctx, ctx->bpartials, (size_t)pstride * GB_NV + 16);
    GatherRows gr = gather_rows(ctx);
-   double *p2 = ctx->bpartials.p + (size_t)nblk * 16;
+   double *p2 = ctx->bpartials.p + nblk;      /* the heavy launch's workgroups follow the light one's in every row */
    if (nblk > 0)
    {
       static const bool no_lds_tab = getenv("DDCMI_NO_BONDED_LDS_TABLES") != nullptr;
       auto kl = (gr.tab_pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<false, true> : k_bonded_gather<false, false>;
       hipLaunchKernelGGL(kl, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->bpartials.p);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->bpartials.p, pstride);
    }
    if (nblk2 > 0)
       hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2, pstride);
    if (fb) restraints();
-   hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(256), 0, st, ctx->bpartials.p, nblk, p2, nblk2, ctx->d_results);
+   hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(RG_T), 0, st, ctx->bpartials.p, nblk + nblk2, pstride, ctx->d_results);
    return DDCMI_OK;
 }
 
