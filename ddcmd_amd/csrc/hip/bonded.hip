@@ -226,6 +226,15 @@ __device__ __forceinline__ bool tors_eval(const BoxArgs &box, const double4 &pI,
  * first, or INT_MAX.  A rank works on the atoms it owns (slot < nown): forces need no return traffic, and
  * every term's energy and virial are booked exactly once over all ranks, by the owner of its first atom. */
 #define GB_NV 10      /* e_bond, e_angle, e_tors, e_impr, virial xx yy zz xy xz yz */
+/* the lanes of one launch and their row patterns.  tab: ONE block of 16-byte pieces -- the patterns' headers {first A row, A rows, first B row,
+ * B rows}, the A rows, the B rows ({other atoms - atom in term order, pid << 2 | role}), the two parameter tables; the offsets in pieces.  When
+ * it has at most GB_TAB_PIECES of them (a force field's lipids: under 2 KB) every workgroup copies it to LDS and the trips of its lanes read
+ * nothing from memory but their partners' records (k_bonded_gather<., true>). */
+struct PatSet
+{
+   int nlanes; const int2 *desc;         /* [nlanes] {atom, pattern}: the launch's atoms in caller order, with filler lanes {nrow, 0} in front of a molecule that would straddle two workgroups (its partners are then all in the workgroup's LDS) */
+   const int4 *tab; int pieces, rowA, rowB, parA, parB;
+};
 struct GatherRows
 {
    int nrow;
@@ -238,18 +247,11 @@ struct GatherRows
    const double4 *tpar;                  /* {k, delta, func, n} */
    int nheavy; const int *hatoms;        /* atoms with func-1 angles or dihedrals */
    int nlight; const int *latoms;        /* atoms with bonds or func 2/10 angles, caller order: a molecule's atoms are neighbouring lanes */
-   /* the light launch reads its rows as PATTERNS (round 5): a row names its partners by their distance in atom numbers, and atoms whose
-    * rows then read the same -- the n-th atom of every copy of a molecule -- share one copy of them.  A bilayer's 1.28 M lipid atoms
-    * have 12 patterns: the rows (55 B per atom, a third of the launch's traffic and 25 of its 72 us) come out of the L1 instead of the HBM.
-    * A system without repetition has as many patterns as atoms and reads what it read before. */
-   int nlanes; const int2 *ldesc;        /* [nlanes] {atom, pattern}: latoms[] with filler lanes {nrow, 0} in front of a molecule that would straddle two workgroups (its partners are then all in the workgroup's LDS: the trips read nothing from memory) */
-   const int4 *pat_hdr;                  /* [npat] {first bond row, bond rows, first angle row, angle rows} */
-   const int2 *pat_brow;                 /* {partner - atom, pid << 2 | role} */
-   const int4 *pat_arow;                 /* {other atoms - atom in term order, pid << 2 | role, 0} */
-   /* the four tables above and the bond / angle parameters as ONE block of 16-byte pieces (hdr | brow | arow | bpar | apar, the offsets in
-    * pieces): when it has at most GB_TAB_PIECES of them -- a force field's lipids: under 2 KB -- every workgroup of the light launch copies it
-    * to LDS and the trips of its lanes read nothing from memory but their partners' records (k_bonded_gather<false, true>) */
-   const int4 *tab; int tab_pieces, tab_brow, tab_arow, tab_bpar, tab_apar;
+   /* both launches read their rows as PATTERNS (round 5): a row names its partners by their distance in atom numbers, and atoms whose rows
+    * then read the same -- the n-th atom of every copy of a molecule -- share one copy of them.  A bilayer's 1.28 M lipid atoms have 12
+    * patterns: the rows (55 B per atom, a third of the light launch's traffic and 25 of its 72 us) no longer come from the HBM.  A system
+    * without repetition has as many patterns as atoms and reads what it read before. */
+   PatSet lp, hp;                        /* light launch: A = bond rows (int2), B = func 2/10 angle rows, parameters bpar | apar; heavy: A = func-1 angle rows, B = dihedral rows, apar | tpar */
 };
 #define GB_TAB_PIECES 384      /* 6 KB */
 template <bool HEAVY, bool TABL = false>      /* HEAVY false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers).  TABL: row patterns and parameters in LDS */
@@ -267,21 +269,23 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
    double4 *const s_rec = s_big;
    __shared__ int s_atom[256];
    __shared__ int4 s_tab[TABL ? GB_TAB_PIECES : 1];
-   if (TABL) for (int k = threadIdx.x; k < gr.tab_pieces; k += 256) s_tab[k] = gr.tab[k];      /* (ordered by the barrier below) */
-   const int4 *const t_hdr = TABL ? s_tab : gr.pat_hdr;
-   const int2 *const t_brow = TABL ? (const int2 *)(s_tab + gr.tab_brow) : gr.pat_brow;
-   const int4 *const t_arow = TABL ? s_tab + gr.tab_arow : gr.pat_arow;
-   const double2 *const t_bpar = TABL ? (const double2 *)(s_tab + gr.tab_bpar) : gr.bpar;
-   const double4 *const t_apar = TABL ? (const double4 *)(s_tab + gr.tab_apar) : gr.apar;
+   const PatSet &ps = HEAVY ? gr.hp : gr.lp;
+   if (TABL) for (int k = threadIdx.x; k < ps.pieces; k += 256) s_tab[k] = ps.tab[k];      /* (ordered by the barrier below) */
+   const int4 *const t_hdr = TABL ? s_tab : ps.tab;
+   const int4 *const t_rowA = t_hdr + ps.rowA, *const t_rowB = t_hdr + ps.rowB;
+   const int4 *const t_parA = t_hdr + ps.parA, *const t_parB = t_hdr + ps.parB;
+   const int2 *const t_brow = (const int2 *)t_rowA;
+   const double2 *const t_bpar = (const double2 *)t_parA;
+   const double4 *const t_apar = (const double4 *)(HEAVY ? t_parA : t_parB), *const t_tpar = (const double4 *)t_parB;
    const int j = blockIdx.x * 256 + threadIdx.x;
    double acc[GB_NV];
 #pragma unroll
    for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
    int i = 0x7fffffff, o = gr.nrow, pat = 0;
-   if (j < (HEAVY ? gr.nheavy : gr.nlanes))
+   if (j < ps.nlanes)
    {
-      if (HEAVY) o = gr.hatoms[j];
-      else { const int2 d = gr.ldesc[j]; o = d.x; pat = d.y; }
+      const int2 d = ps.desc[j];
+      o = d.x; pat = d.y;
       if (o < gr.nrow) i = slot[o];
    }
    const bool here = o < gr.nrow && (unsigned)i < (unsigned)ntot;      /* owned, or a halo copy on this rank */
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
    };
    if (here && i < nown)
    {
-      int b0 = 0, b1 = 0, a0, a1;
-      if (HEAVY) { a0 = gr.haoff[o]; a1 = gr.haoff[o + 1]; }
-      else { const int4 h = t_hdr[pat]; b0 = h.x; b1 = h.x + h.y; a0 = h.z; a1 = h.z + h.w; }
-      const int t0 = HEAVY ? gr.toff[o] : 0, t1 = HEAVY ? gr.toff[o + 1] : 0;
+      const int4 h = t_hdr[pat];
+      /* light: bonds = the A rows, angles = the B rows; heavy: angles = the A rows, dihedrals = the B rows */
+      const int b0 = HEAVY ? 0 : h.x, b1 = HEAVY ? 0 : h.x + h.y, a0 = HEAVY ? h.x : h.z, a1 = HEAVY ? h.x + h.y : h.z + h.w;
+      const int t0 = HEAVY ? h.z : 0, t1 = HEAVY ? h.z + h.w : 0;
       if (b1 + a1 + t1 > b0 + a0 + t0)
       {
          double fxi = 0, fyi = 0, fzi = 0;
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          }
          if (a1 > a0)
          {
-         const int4 *arows = HEAVY ? gr.harow : t_arow;
-         const int rel = HEAVY ? 0 : o;      /* (pattern rows name their atoms relative to the lane's) */
+         const int4 *arows = HEAVY ? t_rowA : t_rowB;
+         const int rel = o;      /* (pattern rows name their atoms relative to the lane's) */
          int4 arow_n = arows[a0];
          for (int r = a0; r < a1; r++)
          {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
             const double4 q1 = rec(rel + row.x), q2 = rec(rel + row.y);
             if (r + 1 < a1) arow_n = arows[r + 1];
             const int role = row.z & 3;
-            const double4 par = HEAVY ? gr.apar[row.z >> 2] : t_apar[row.z >> 2];
+            const double4 par = t_apar[row.z >> 2];
             double e, fI[3], fK[3], vir[6];
             if (angle_eval<HEAVY>(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role == 2 ? me : q2, (int)par.z, par.x, par.y, excl_mask, e, fI, fK, vir))
             {
@@ -358,10 +362,10 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
          if (HEAVY)
          for (int r = t0; r < t1; r++)
          {
-            const int4 row = gr.trow[r];
+            const int4 row = t_rowB[r];
             const int role = row.w & 3;
-            const double4 par = gr.tpar[row.w >> 2];
-            const double4 q1 = rec(row.x), q2 = rec(row.y), q3 = rec(row.z);
+            const double4 par = t_tpar[row.w >> 2];
+            const double4 q1 = rec(o + row.x), q2 = rec(o + row.y), q3 = rec(o + row.z);
             double et, ei, fI[3], fJ[3], fK[3], fL[3], vir[6];
             if (tors_eval(box, role == 0 ? me : q1, role == 0 ? q1 : (role == 1 ? me : q2), role <= 1 ? q2 : (role == 2 ? me : q3), role == 3 ? me : q3,
                           (int)par.z, (int)par.w, par.x, par.y, excl_mask, et, ei, fI, fJ, fK, fL, vir))
@@ -521,7 +525,7 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
                       int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta)
 {
    int rc;
-   ctx->inc_nrow = 0; ctx->inc_light = 0; ctx->inc_lanes = 0; ctx->inc_heavy = 0;
+   ctx->inc_nrow = 0; ctx->inc_light = 0; ctx->inc_lanes = 0; ctx->inc_hlanes = 0; ctx->inc_heavy = 0;
    ctx->nbond = nbond; ctx->nangle = nangle; ctx->ntors = ntors;
    if (nbond + nangle + ntors > 0)
    {
@@ -599,37 +603,40 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
       std::vector<int> latoms;
       for (int a = 0; a < nrow; a++) if (boff[a + 1] > boff[a] || aoff[a + 1] > aoff[a]) latoms.push_back(a);
       ctx->inc_light = (int)latoms.size();
-      /* row patterns of the light launch (GatherRows::ldesc): an atom's rows with the partners as differences of atom numbers */
-      std::vector<int> ldesc, pat_hdr, pat_brow, pat_arow;
+      /* molecules = connected components of the terms' graph: a run of a molecule's atoms that fits one workgroup does not straddle two */
+      std::vector<int> root((size_t)nrow);
+      for (int a = 0; a < nrow; a++) root[a] = a;
+      auto find = [&](int a) { while (root[a] != a) { root[a] = root[root[a]]; a = root[a]; } return a; };
+      auto join = [&](int a, int b) { a = find(a); b = find(b); if (a != b) root[std::max(a, b)] = std::min(a, b); };
+      for (int t = 0; t < nbond; t++) join(bond_ij[2 * t], bond_ij[2 * t + 1]);
+      for (int t = 0; t < nangle; t++) { join(angle_ijk[3 * t], angle_ijk[3 * t + 1]); join(angle_ijk[3 * t], angle_ijk[3 * t + 2]); }
+      for (int t = 0; t < ntors; t++) for (int r = 1; r < 4; r++) join(tors_ijkl[4 * t], tors_ijkl[4 * t + r]);
+      /* the lanes and row patterns of one launch (PatSet): an atom's rows with the partners as differences of atom numbers.  Rows of kind A are
+       * wA ints wide with relA atom numbers in front, rows of kind B four ints with relB */
+      struct HostPat { std::vector<int> desc, hdr, rowA, rowB; int nlanes = 0; };
+      auto make_patterns = [&](const std::vector<int> &atoms, const std::vector<int> &offA, const std::vector<int> &rowsA, int wA, int relA,
+                               const std::vector<int> &offB, const std::vector<int> &rowsB, int relB)
       {
+         HostPat hp;
          std::unordered_map<std::string, int> seen;
          std::string key;
-         ldesc.reserve(2 * latoms.size() + 2);
-         /* molecules = connected components of the terms' graph; a run of a molecule's atoms that fits one workgroup does not straddle two */
-         std::vector<int> root((size_t)nrow);
-         for (int a = 0; a < nrow; a++) root[a] = a;
-         auto find = [&](int a) { while (root[a] != a) { root[a] = root[root[a]]; a = root[a]; } return a; };
-         auto join = [&](int a, int b) { a = find(a); b = find(b); if (a != b) root[std::max(a, b)] = std::min(a, b); };
-         for (int t = 0; t < nbond; t++) join(bond_ij[2 * t], bond_ij[2 * t + 1]);
-         for (int t = 0; t < nangle; t++) { join(angle_ijk[3 * t], angle_ijk[3 * t + 1]); join(angle_ijk[3 * t], angle_ijk[3 * t + 2]); }
-         for (int t = 0; t < ntors; t++) for (int r = 1; r < 4; r++) join(tors_ijkl[4 * t], tors_ijkl[4 * t + r]);
-         size_t run_end = 0;      /* index in latoms behind the current run */
-         for (size_t la_i = 0; la_i < latoms.size(); la_i++)
+         std::vector<int> w;
+         size_t run_end = 0;      /* index in atoms[] behind the current run of one molecule's atoms */
+         for (size_t ai = 0; ai < atoms.size(); ai++)
          {
-            const int a = latoms[la_i];
-            if (la_i == run_end)
+            const int a = atoms[ai];
+            if (ai == run_end)
             {
                const int r0 = find(a);
-               while (run_end < latoms.size() && find(latoms[run_end]) == r0) run_end++;
-               const size_t len = run_end - la_i, at = (ldesc.size() / 2) % 256;
-               if (len <= 256 && at + len > 256) for (size_t k = at; k < 256; k++) { ldesc.push_back(nrow); ldesc.push_back(0); }
+               while (run_end < atoms.size() && find(atoms[run_end]) == r0) run_end++;
+               const size_t len = run_end - ai, at = (hp.desc.size() / 2) % 256;
+               if (len <= 256 && at + len > 256) for (size_t k = at; k < 256; k++) { hp.desc.push_back(nrow); hp.desc.push_back(0); }
             }
-            const int nb = boff[a + 1] - boff[a], na = aoff[a + 1] - aoff[a];
-            std::vector<int> w;
-            w.reserve(2 + 2 * (size_t)nb + 3 * (size_t)na);
-            w.push_back(nb); w.push_back(na);
-            for (int r = boff[a]; r < boff[a + 1]; r++) { w.push_back(brow[2 * (size_t)r] - a); w.push_back(brow[2 * (size_t)r + 1]); }
-            for (int r = aoff[a]; r < aoff[a + 1]; r++) { w.push_back(arow[4 * (size_t)r] - a); w.push_back(arow[4 * (size_t)r + 1] - a); w.push_back(arow[4 * (size_t)r + 2]); }
+            const int nA = offA[a + 1] - offA[a], nB = offB[a + 1] - offB[a];
+            w.clear();
+            w.push_back(nA); w.push_back(nB);
+            for (int r = offA[a]; r < offA[a + 1]; r++) for (int c = 0; c < wA; c++) w.push_back(rowsA[(size_t)wA * r + c] - (c < relA ? a : 0));
+            for (int r = offB[a]; r < offB[a + 1]; r++) for (int c = 0; c < 4; c++) w.push_back(rowsB[4 * (size_t)r + c] - (c < relB ? a : 0));
             key.assign((const char *)w.data(), w.size() * sizeof(int));
             auto it = seen.find(key);
             int p;
@@ -638,19 +645,18 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
             {
                p = (int)seen.size();
                seen.emplace(key, p);
-               pat_hdr.push_back((int)(pat_brow.size() / 2)); pat_hdr.push_back(nb); pat_hdr.push_back((int)(pat_arow.size() / 4)); pat_hdr.push_back(na);
-               for (int k = 0; k < nb; k++) { pat_brow.push_back(w[2 + 2 * k]); pat_brow.push_back(w[3 + 2 * k]); }
-               for (int k = 0; k < na; k++) { const int *q = &w[2 + 2 * nb + 3 * k]; pat_arow.push_back(q[0]); pat_arow.push_back(q[1]); pat_arow.push_back(q[2]); pat_arow.push_back(0); }
+               hp.hdr.push_back((int)(hp.rowA.size() / wA)); hp.hdr.push_back(nA); hp.hdr.push_back((int)(hp.rowB.size() / 4)); hp.hdr.push_back(nB);
+               hp.rowA.insert(hp.rowA.end(), w.begin() + 2, w.begin() + 2 + (size_t)wA * nA);
+               hp.rowB.insert(hp.rowB.end(), w.begin() + 2 + (size_t)wA * nA, w.end());
             }
-            ldesc.push_back(a); ldesc.push_back(p);
+            hp.desc.push_back(a); hp.desc.push_back(p);
          }
-         ctx->inc_npat = (int)seen.size();
-         ctx->inc_lanes = (int)(ldesc.size() / 2);
-         ldesc.push_back(nrow); ldesc.push_back(0);
-         pat_hdr.resize(pat_hdr.size() + 4, 0); pat_brow.resize(pat_brow.size() + 2, 0); pat_arow.resize(pat_arow.size() + 4, 0);      /* (the rows' read-ahead) */
-      }
+         hp.nlanes = (int)(hp.desc.size() / 2);
+         hp.desc.push_back(nrow); hp.desc.push_back(0);
+         hp.hdr.resize(hp.hdr.size() + 4, 0); hp.rowA.resize(hp.rowA.size() + 4, 0); hp.rowB.resize(hp.rowB.size() + 4, 0);      /* (the rows' read-ahead) */
+         return hp;
+      };
       latoms.push_back(0);
-      std::vector<int> tab;      /* GatherRows::tab -- built below, when the parameter sets are complete */
       {
          std::vector<int> fill(toff.begin(), toff.end() - 1);
          for (int t = 0; t < ntors; t++)
@@ -667,22 +673,29 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
       }
       for (int k = 0; k < 3; k++) if (ids[k].size() >= (1u << 29)) SETERR(ctx, DDCMI_EINVAL, "too many distinct bonded parameter sets");
       for (int k = 0; k < 3; k++) par[k].resize(par[k].size() + 4, 0.0);
+      hatoms.pop_back(); latoms.pop_back();
+      HostPat lpat = make_patterns(latoms, boff, brow, 2, 1, aoff, arow, 2), hpat = make_patterns(hatoms, haoff, harow, 4, 2, toff, trow, 3);
+      hatoms.push_back(0); latoms.push_back(0);
+      ctx->inc_lanes = lpat.nlanes; ctx->inc_hlanes = hpat.nlanes;
+      std::vector<int> tabs[2];
+      for (int q = 0; q < 2; q++)
       {
-         auto pieces = [](size_t bytes) { return (int)((bytes + 15) / 16); };
-         auto put = [&](const void *src, size_t bytes) { const int at = (int)(tab.size() / 4); tab.resize(tab.size() + 4 * (size_t)pieces(bytes), 0); memcpy(&tab[4 * (size_t)at], src, bytes); return at; };
-         put(pat_hdr.data(), pat_hdr.size() * sizeof(int));
-         ctx->inc_tab_off[0] = put(pat_brow.data(), pat_brow.size() * sizeof(int));
-         ctx->inc_tab_off[1] = put(pat_arow.data(), pat_arow.size() * sizeof(int));
-         ctx->inc_tab_off[2] = put(par[0].data(), par[0].size() * sizeof(double));
-         ctx->inc_tab_off[3] = put(par[1].data(), par[1].size() * sizeof(double));
-         ctx->inc_tab_pieces = (int)(tab.size() / 4);
+         const HostPat &hp = q ? hpat : lpat;
+         std::vector<int> &tb = tabs[q];
+         auto put = [&](const void *src, size_t bytes) { const int at = (int)(tb.size() / 4); tb.resize(tb.size() + 4 * ((bytes + 15) / 16), 0); memcpy(&tb[4 * (size_t)at], src, bytes); return at; };
+         put(hp.hdr.data(), hp.hdr.size() * sizeof(int));
+         int *off = ctx->inc_tab_off[q];
+         off[0] = put(hp.rowA.data(), hp.rowA.size() * sizeof(int));
+         off[1] = put(hp.rowB.data(), hp.rowB.size() * sizeof(int));
+         off[2] = put(par[q ? 1 : 0].data(), par[q ? 1 : 0].size() * sizeof(double));
+         off[3] = put(par[q ? 2 : 1].data(), par[q ? 2 : 1].size() * sizeof(double));
+         ctx->inc_tab_pieces[q] = (int)(tb.size() / 4);
       }
       if ((rc = up(ctx, ctx->inc_boff, boff.data(), boff.size())) || (rc = up(ctx, ctx->inc_aoff, aoff.data(), aoff.size())) || (rc = up(ctx, ctx->inc_toff, toff.data(), toff.size())) ||
           (rc = up(ctx, ctx->inc_hatoms, hatoms.data(), hatoms.size())) || (rc = up(ctx, ctx->inc_latoms, latoms.data(), latoms.size())) || (rc = up(ctx, ctx->inc_haoff, haoff.data(), haoff.size())) || (rc = up(ctx, ctx->inc_harow, harow.data(), harow.size())) ||
           (rc = up(ctx, ctx->inc_brow, brow.data(), brow.size())) || (rc = up(ctx, ctx->inc_arow, arow.data(), arow.size())) || (rc = up(ctx, ctx->inc_trow, trow.data(), trow.size())) ||
-          (rc = up(ctx, ctx->inc_ldesc, ldesc.data(), ldesc.size())) || (rc = up(ctx, ctx->inc_pat_hdr, pat_hdr.data(), pat_hdr.size())) ||
-          (rc = up(ctx, ctx->inc_pat_brow, pat_brow.data(), pat_brow.size())) || (rc = up(ctx, ctx->inc_pat_arow, pat_arow.data(), pat_arow.size())) ||
-          (rc = up(ctx, ctx->inc_tab, tab.data(), tab.size())) ||
+          (rc = up(ctx, ctx->inc_ldesc, lpat.desc.data(), lpat.desc.size())) || (rc = up(ctx, ctx->inc_hdesc, hpat.desc.data(), hpat.desc.size())) ||
+          (rc = up(ctx, ctx->inc_tab, tabs[0].data(), tabs[0].size())) || (rc = up(ctx, ctx->inc_htab, tabs[1].data(), tabs[1].size())) ||
           (rc = up(ctx, ctx->inc_bpar, par[0].data(), par[0].size())) || (rc = up(ctx, ctx->inc_apar, par[1].data(), par[1].size())) || (rc = up(ctx, ctx->inc_tpar, par[2].data(), par[2].size()))) return rc;
       ctx->inc_nrow = nrow;
    }
@@ -808,8 +821,8 @@ static GatherRows gather_rows(const ddcmi_ctx *ctx)
    GatherRows gr = {ctx->inc_nrow, ctx->inc_boff.p, ctx->inc_aoff.p, ctx->inc_haoff.p, ctx->inc_toff.p, (const int2 *)ctx->inc_brow.p, (const int4 *)ctx->inc_arow.p,
                     (const int4 *)ctx->inc_harow.p, (const int4 *)ctx->inc_trow.p,
                     (const double2 *)ctx->inc_bpar.p, (const double4 *)ctx->inc_apar.p, (const double4 *)ctx->inc_tpar.p, ctx->inc_heavy, ctx->inc_hatoms.p, ctx->inc_light, ctx->inc_latoms.p,
-                    ctx->inc_lanes, (const int2 *)ctx->inc_ldesc.p, (const int4 *)ctx->inc_pat_hdr.p, (const int2 *)ctx->inc_pat_brow.p, (const int4 *)ctx->inc_pat_arow.p,
-                    (const int4 *)ctx->inc_tab.p, ctx->inc_tab_pieces, ctx->inc_tab_off[0], ctx->inc_tab_off[1], ctx->inc_tab_off[2], ctx->inc_tab_off[3]};
+                    {ctx->inc_lanes, (const int2 *)ctx->inc_ldesc.p, (const int4 *)ctx->inc_tab.p, ctx->inc_tab_pieces[0], ctx->inc_tab_off[0][0], ctx->inc_tab_off[0][1], ctx->inc_tab_off[0][2], ctx->inc_tab_off[0][3]},
+                    {ctx->inc_hlanes, (const int2 *)ctx->inc_hdesc.p, (const int4 *)ctx->inc_htab.p, ctx->inc_tab_pieces[1], ctx->inc_tab_off[1][0], ctx->inc_tab_off[1][1], ctx->inc_tab_off[1][2], ctx->inc_tab_off[1][3]}};
    return gr;
 }
 
@@ -870,20 +883,21 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb)
     * works on the atoms it owns */
    if (!ctx->bonded_gid) { int rcs = ddcmi_ensure_slots(ctx); if (rcs) return rcs; }
    const int *slot = ctx->bonded_gid ? ctx->slot_of_atom.p : ctx->slot_of_orig.p;
-   const int nblk = cdiv(ctx->inc_lanes, 256), nblk2 = cdiv(ctx->inc_heavy, 256);
+   const int nblk = cdiv(ctx->inc_lanes, 256), nblk2 = cdiv(ctx->inc_hlanes, 256);
    const int pstride = (nblk + nblk2 + 15) & ~15;
    ENSURE(ctx, ctx->bpartials, (size_t)pstride * GB_NV + 16);
    GatherRows gr = gather_rows(ctx);
    double *p2 = ctx->bpartials.p + nblk;      /* the heavy launch's workgroups follow the light one's in every row */
+   static const bool no_lds_tab = getenv("DDCMI_NO_BONDED_LDS_TABLES") != nullptr;
    if (nblk > 0)
    {
-      static const bool no_lds_tab = getenv("DDCMI_NO_BONDED_LDS_TABLES") != nullptr;
-      auto kl = (gr.tab_pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<false, true> : k_bonded_gather<false, false>;
+      auto kl = (gr.lp.pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<false, true> : k_bonded_gather<false, false>;
       hipLaunchKernelGGL(kl, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->bpartials.p, pstride);
    }
+   auto kh = (gr.hp.pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<true, true> : k_bonded_gather<true, false>;
    if (nblk2 > 0)
-      hipLaunchKernelGGL(k_bonded_gather<true>, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
+      hipLaunchKernelGGL(kh, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2, pstride);
    if (fb) restraints();
    hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(RG_T), 0, st, ctx->bpartials.p, nblk + nblk2, pstride, ctx->d_results);

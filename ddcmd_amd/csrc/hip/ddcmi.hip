@@ -530,7 +530,7 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    for (auto b : {&ctx->cg_dist, &ctx->inc_bpar, &ctx->inc_apar, &ctx->inc_tpar}) b->release();
    for (auto b : {&ctx->cg_atom_off, &ctx->cg_atoms, &ctx->cg_pair_off, &ctx->cons_status, &ctx->mol_off, &ctx->mol_atoms}) b->release();
    ctx->cg_pa.release(); ctx->cg_pb.release();
-   for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->inc_ldesc, &ctx->inc_pat_hdr, &ctx->inc_pat_brow, &ctx->inc_pat_arow, &ctx->inc_tab, &ctx->slot_of_atom, &ctx->hvals}) b->release();
+   for (auto b : {&ctx->inc_boff, &ctx->inc_aoff, &ctx->inc_toff, &ctx->inc_brow, &ctx->inc_arow, &ctx->inc_trow, &ctx->inc_haoff, &ctx->inc_harow, &ctx->inc_hatoms, &ctx->inc_latoms, &ctx->inc_ldesc, &ctx->inc_hdesc, &ctx->inc_tab, &ctx->inc_htab, &ctx->slot_of_atom, &ctx->hvals}) b->release();
    ctx->tile_nib.release();
    ctx->tile_base.release(); ctx->nbr16.release(); ctx->excl16.release(); ctx->kpartials.release(); ctx->red_tmp.release(); ctx->fb.release(); ctx->tmp32.release();
    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
