@@ -281,13 +281,16 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
    double acc[GB_NV];
 #pragma unroll
    for (int k = 0; k < GB_NV; k++) acc[k] = 0.0;
-   int i = 0x7fffffff, o = gr.nrow, pat = 0;
+   int i = 0x7fffffff, o = gr.nrow, pat = 0, near = 1;
    if (j < ps.nlanes)
    {
       const int2 d = ps.desc[j];
-      o = d.x; pat = d.y;
+      o = d.x; pat = d.y & 0x3fffffff; near = (d.y >> 30) & 1;
       if (o < gr.nrow) i = slot[o];
    }
+   /* every partner of every lane of this wave is a lane of this workgroup (the rule for a molecule's run that fits one: PatSet::desc): their
+    * records come out of LDS unasked (the look, compare and branch per partner were 6 of the light launch's 51 us) */
+   const bool all_near = __all(near) != 0;
    const bool here = o < gr.nrow && (unsigned)i < (unsigned)ntot;      /* owned, or a halo copy on this rank */
    const double4 me = here ? pos[i] : make_double4(0.0, 0.0, 0.0, 0.0);
    s_atom[threadIdx.x] = here ? o : -1;
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
    auto rec = [&](const int pa) -> double4
    {
       const int t = (int)threadIdx.x + (pa - o);
+      if (all_near) return s_rec[t];
       if ((unsigned)t < 256u && s_atom[t] == pa) return s_rec[t];
       return pos[slot[pa]];
    };
@@ -652,7 +656,22 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
             hp.desc.push_back(a); hp.desc.push_back(p);
          }
          hp.nlanes = (int)(hp.desc.size() / 2);
-         hp.desc.push_back(nrow); hp.desc.push_back(0);
+         {
+            /* bit 30 of a lane's pattern word: every partner of the atom is a lane of the same workgroup, at the distance of the atom numbers */
+            std::vector<int> lane_of((size_t)nrow + 1, -1);
+            for (int l = 0; l < hp.nlanes; l++) if (hp.desc[2 * (size_t)l] < nrow) lane_of[hp.desc[2 * (size_t)l]] = l;
+            for (int l = 0; l < hp.nlanes; l++)
+            {
+               const int a = hp.desc[2 * (size_t)l];
+               if (a >= nrow) { hp.desc[2 * (size_t)l + 1] |= 1 << 30; continue; }      /* (filler lanes walk no rows) */
+               bool near = true;
+               auto check = [&](int b) { const int lb = lane_of[b]; near = near && lb >= 0 && lb / 256 == l / 256 && lb - l == b - a; };
+               for (int r = offA[a]; r < offA[a + 1]; r++) for (int c = 0; c < relA; c++) check(rowsA[(size_t)wA * r + c]);
+               for (int r = offB[a]; r < offB[a + 1]; r++) for (int c = 0; c < relB; c++) check(rowsB[4 * (size_t)r + c]);
+               if (near) hp.desc[2 * (size_t)l + 1] |= 1 << 30;
+            }
+         }
+         hp.desc.push_back(nrow); hp.desc.push_back(1 << 30);
          hp.hdr.resize(hp.hdr.size() + 4, 0); hp.rowA.resize(hp.rowA.size() + 4, 0); hp.rowB.resize(hp.rowB.size() + 4, 0);      /* (the rows' read-ahead) */
          return hp;
       };
@@ -676,6 +695,7 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
       hatoms.pop_back(); latoms.pop_back();
       HostPat lpat = make_patterns(latoms, boff, brow, 2, 1, aoff, arow, 2), hpat = make_patterns(hatoms, haoff, harow, 4, 2, toff, trow, 3);
       hatoms.push_back(0); latoms.push_back(0);
+      if (lpat.hdr.size() / 4 >= (1u << 30) || hpat.hdr.size() / 4 >= (1u << 30)) SETERR(ctx, DDCMI_EUNSUPPORTED, "more than 2^30 distinct bonded row patterns");
       ctx->inc_lanes = lpat.nlanes; ctx->inc_hlanes = hpat.nlanes;
       std::vector<int> tabs[2];
       for (int q = 0; q < 2; q++)

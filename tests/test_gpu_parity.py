@@ -337,6 +337,38 @@ def test_lipid_deck_all_terms():
     m.close()
 
 
+def test_lipid_deck_in_shuffled_caller_order():
+    """The bonded launches take a partner's record from the lane (atom number difference) away -- wave-wide without asking when the molecule's
+    atoms are neighbouring lanes of one workgroup.  Here they are not: the beads are handed over in a random order (molecules are found by
+    gid, charmmResidues bioCharmmCovalent.c:48-93, so the system is the same one), every wave holds atoms whose partners lie anywhere, and
+    the general path -- look in LDS, else the slot table -- must give the oracle's forces; then the per-bead forces of the ordered and the
+    shuffled hand-over are compared bead by bead."""
+    import copy
+    from ddcmd_amd.martini import MartiniHIP
+    from ddcmd_amd.deck import load_deck
+    s0 = load_deck(LIPID_DECK)
+    perm = np.random.default_rng(20251003).permutation(s0.natoms)
+    s = copy.copy(s0)
+    for k in ("rx", "ry", "rz", "vx", "vy", "vz", "gid", "species", "group"):
+        setattr(s, k, np.ascontiguousarray(np.asarray(getattr(s0, k))[perm]))
+    o = pyoracle.Oracle(s)
+    o.build_list()
+    e0, v0 = o.forces()
+    m = MartiniHIP(s)
+    e, vir = m.eval_forces()
+    f = _forces(m)
+    assert rel_force_err(f, (o.fx, o.fy, o.fz)) < TIGHT
+    for k in ("lj", "ele", "bond", "angle", "tors", "impr", "total"):
+        assert abs(e[k] - e0[k]) < TIGHT * max(abs(e0[k]), 1e-12), k
+    assert np.abs(vir - v0).max() < TIGHT * np.abs(v0).max()
+    m.close()
+    m1 = MartiniHIP(s0)
+    m1.eval_forces()
+    f1 = _forces(m1)
+    m1.close()
+    assert rel_force_err(f, tuple(np.asarray(c)[perm] for c in f1)) < TIGHT
+
+
 def test_lipid_deck_20_steps():
     """NGLF on the lipid deck (dt 10 fs, rebuild every 10): per-step energies by kind, final state"""
     from ddcmd_amd.martini import MartiniHIP
