@@ -472,6 +472,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ddcmi_ctx *ctx = new ddcmi_ctx();
    ctx->device = device;
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
+   ctx->no_lean = getenv("DDCMI_NO_LEAN_STEP") != nullptr;
    ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
    ctx->no_direct_halo = getenv("DDCMI_NO_DIRECT_HALO") != nullptr;
    ctx->force_lvl = getenv("DDCMI_FORCE_LEVEL_TABLE") != nullptr;

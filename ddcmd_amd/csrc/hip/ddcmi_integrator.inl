@@ -20,7 +20,7 @@ __device__ void finish_energy(double *r, double self_ele);
  * adds the RED_SPLIT rows in index order.  tmp: [2 jobs][RED_SPLIT][8] doubles, then 2 ticket
  * counters (left at zero). */
 #define RED_SPLIT 8
-__device__ __forceinline__ void reduce_jobs_block(const RedJob &j, const int bx, const int by, double *results, double self_ele, double *tmp)
+__device__ __forceinline__ void reduce_jobs_block(const RedJob &j, const int bx, const int by, double *results, double self_ele, double *tmp, const int njobs = 2)
 {
    __shared__ double s[1024];
    __shared__ int s_last;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void reduce_jobs_block(const RedJob &j, const int bx,
       __syncthreads();
    }
    double *mytmp = tmp + ((size_t)by * RED_SPLIT + bx) * 8;
-   unsigned int *ticket = (unsigned int *)(tmp + 2 * RED_SPLIT * 8) + by;
+   unsigned int *ticket = (unsigned int *)(tmp + (size_t)njobs * RED_SPLIT * 8) + by;
    if (threadIdx.x < 8) { mytmp[threadIdx.x] = s[threadIdx.x]; __threadfence(); }
    __syncthreads();
    if (threadIdx.x == 0)
@@ -91,6 +91,18 @@ __device__ __forceinline__ void reduce_jobs_block(const RedJob &j, const int bx,
 __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, double *results, double self_ele, double *tmp)
 {
    reduce_jobs_block(blockIdx.y ? j1 : j0, (int)blockIdx.x, (int)blockIdx.y, results, self_ele, tmp);
+}
+/* the lean steps' sums, all pending steps in ONE launch (ddcmi_ctx::lean_pending): step q's rows lie q * stride doubles behind the first
+ * step's; its eight pair sums go to hist[16 q], its seven kinetic sums to hist[16 q + 8] -- the same workgroups, the same order of
+ * additions as the per-step launch (reduce_jobs_block), so the sums are bit for bit the ones that launch forms */
+__global__ __launch_bounds__(1024) void k_reduce_hist(RedJob jf, RedJob jk, size_t stride, int nsteps, double *hist, double *tmp)
+{
+   const int by = (int)blockIdx.y, q = by >> 1;
+   RedJob j = (by & 1) ? jk : jf;
+   j.partials += (size_t)q * stride;
+   j.out = hist + 16 * (size_t)q + ((by & 1) ? 8 : 0);
+   j.finish = 0; j.disp_dt = 0.0; j.disp = nullptr;
+   reduce_jobs_block(j, (int)blockIdx.x, by, nullptr, 0.0, tmp, 2 * nsteps);
 }
 /* the same two jobs and, in further workgroups of the same launch, the periodic images of a single domain brought up to the positions
  * the fused pair kernel has just drifted to (k_halo_update's self-image arm): both only wait for that kernel, one launch instead of two */

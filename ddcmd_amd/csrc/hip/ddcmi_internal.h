@@ -121,6 +121,8 @@ template <class T> struct dbuf
 struct TileSel { int mode; int lo[3], n[3]; };
 
 /* LDS layout of one k_nonbond workgroup (nb_lds_layout, ddcmi_step.inl) */
+#define LEAN_W 32
+#define LEAN_VSTRIDE 32      /* words: 128 B */
 struct NbLds { size_t total; int tab_off, ke_off; bool lvl, zfix; int wgs; };
 
 /* results block on the device / pinned host mirror */
@@ -213,6 +215,15 @@ struct ddcmi_ctx
    bool shell_skip = false, no_shell_skip = false; double sh_r0sq = 0, sh_step = 0;      /* k_nonbond may end its rows at the last shell that can matter (NbTileArgs::disp); DDCMI_NO_SHELL_SKIP */
    int nhalo_hint = 0; const int *nhalo_dev = nullptr; bool no_image_hint = false; int debug_image_bound = 0;      /* single-domain rebuilds after the first: the image count stays on the device until the build's post (bl_self_images); DDCMI_NO_IMAGE_HINT */
    bool pack_fresh = false;            /* decomposed runs: the halo send buffer already holds the current positions (packed in the fused step's reduction launch) */
+   /* the lean step (round 5, step_post): a single domain of FREE beads without bonded terms runs ONE launch per step between rebuilds --
+    * the pair kernel with the integrator's pass, which also stages the periodic images from their owners and keeps the displacement bound;
+    * the second stage of its energy / virial / kinetic sums waits in a ring of per-step rows (lean_part, lean_kpart: LEAN_W steps of
+    * lean_stride doubles) and is formed for all pending steps by one launch (lean_flush -> lean_hist: 16 sums per step) at the next rebuild,
+    * when the ring is full or when the host asks.  DDCMI_NO_LEAN_STEP=1: the reduction launch after every step, as before. */
+   int lean_pending = 0, lean_hist_n = 0, lean_since = 0 /* lean steps since the rebuild: the next one's word of the ring */; size_t lean_stride = 0; bool no_lean = false; double lean_dt = 0;
+   dbuf<double> lean_part, lean_kpart, lean_hist, lean_tmp;
+   dbuf<unsigned> d_vring;             /* largest |v|^2 (float bits) of each lean step since the rebuild, one word per step at a stride of LEAN_VSTRIDE words: the step that
+                                          is being written (atomic maxima of every workgroup) shares no cache line with the words the same launch reads */
    bool images_fresh = false;          /* the list was rebuilt in front of this force evaluation: the periodic images of a single domain need no update */
    int64_t fuse_tags_of = -1;              /* the rebuild whose halo tag words the second position buffer holds (fused steps swap the buffers) */
    uint64_t rng_seed = 0;              /* Langevin groups: seed of the counter-based normal stream (RANDOM seed) */
@@ -384,7 +395,7 @@ __device__ __forceinline__ double rcp_f64(double x)
 int ddcmi_scan_exclusive(ddcmi_ctx *ctx, const int *src, int *dst, int n, int *d_total);
 struct ZeroJobs
 {
-   int *p[10]; int n[10]; int cnt = 0;
+   int *p[12]; int n[12]; int cnt = 0;
    ZeroJobs &add(void *ptr, size_t nints) { p[cnt] = (int *)ptr; n[cnt] = (int)nints; cnt++; return *this; }
 };
 int ddcmi_zero_ints(ddcmi_ctx *ctx, hipStream_t st, const ZeroJobs &z);

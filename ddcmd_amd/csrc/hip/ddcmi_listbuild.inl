@@ -95,6 +95,11 @@ struct NbTileArgs
     * tag only.  Tiles that stage such beads walk their rows to the end (halo_full_walk): the displacement bound D covers this
     * rank's beads, and nothing measures the neighbours' any more -- the shell-limited walk stays with the all-owned tiles. */
    const double *hrecv3; const int *halo_src; int halo_full_walk;
+   /* the lean step of a single domain (launch_forces, ddcmi_ctx::lean_pending): nothing runs between two pair kernels.  self_img: the
+    * periodic images are staged from their OWNERS' records + the shift (halo_src >= 0, halo_shift) -- no image update launch.  The
+    * displacement bound: every workgroup of a lean step files its largest |v|^2 in the step's word vring_w of a ring of LEAN_W (atomic maximum
+    * of the float's bits), and every launch until the next rebuild adds vring_dt sqrt(word) over the ring to *disp (vring not null) */
+   int self_img; const unsigned *vring; int vring_n /* words in use */; unsigned *vring_w; double vring_dt;
    /* k_nonbond<..., LVL>: the pair table in two levels (ddcmi_ctx::d_lvltab): lvlidx [nlj*nlj] = index of the class pair's entry among the nlvl distinct ones */
    const unsigned char *lvlidx; int nlvl;
    int tab_off;                         /* LDS byte offset of the pair table (nb_lds_layout: the gap between {x,y} and z when it fits, else behind z) */

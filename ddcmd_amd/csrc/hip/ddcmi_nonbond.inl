@@ -36,6 +36,23 @@ __device__ __forceinline__ double z_with_tags(double z, double tagword, bool shi
    else lo = (lo & ~0x1ffu) | (shifted ? 1u : 0u) | (((unsigned)__double2loint(tagword) & 0xffu) << 1);
    return __hiloint2double(__double2hiint(z), (int)lo);
 }
+/* The lean steps' words of the displacement bound (NbTileArgs::vring): lane s holds W_s, the largest |v|^2 FILED for lean step s -- by the
+ * workgroups that lay above LEAN_C times the step before's effective value only (0.9 of its speed: half a percent of the workgroups; 8800 atomic
+ * maxima on one word per launch were 10 us of it).  Effective value E_s = max_j LEAN_C^(s-j) W_j >= the step's true maximum: a decaying maximum
+ * scan, the same arithmetic in the launch that files (its threshold LEAN_C E_(n-1)) and in every launch that reads. */
+#define LEAN_C 0.81f
+__device__ __forceinline__ float lean_effective(float w, const int lane)
+{
+   float e = w, c = LEAN_C;
+#pragma unroll
+   for (int i = 1; i < LEAN_W; i <<= 1)
+   {
+      const float t = __shfl_up(e, i, 64);
+      if (lane >= i) e = fmaxf(e, t * c);
+      c = c * c;
+   }
+   return e;
+}
 template <bool HAS_Q, bool PACKED, bool SHBIT, int NB_BLOCK, int WPE, int CH, int ZOFF, bool FUSE, bool LVL>
 __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTileArgs ta, int npad,
                                                          const double4 *__restrict__ pos, const double *__restrict__ kqtab,
@@ -86,11 +103,18 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
    const int item = mine ? ta.perm[slot] : 0;
    const int t = item & 0xffffff, part = (item >> 24) & 7, nparts = ((item >> 27) & 7) + 1;
    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* vLJ, vEle, xx,yy,zz,xy,xz,yz */
+   float wg_v2 = 0.0f;                        /* (lean step: the workgroup's largest |v|^2, thread 64 + 7) */
    /* the last shell this launch walks (NbTileArgs::disp) */
    int smax = NSHELL - 1;
-   if (ta.disp)
+   /* (the lean steps' words are asked for here and used behind the staging: a wait for them in front of it cost every workgroup a memory round trip) */
+   float ring_v2 = 0.0f;
+   const double disp_base = ta.disp ? *ta.disp : 0.0;      /* (asked for here as well: behind the staging's barrier it was a round trip of its own, 2 us per workgroup) */
+   if (FUSE && ta.disp && ta.vring && (int)threadIdx.x < ta.vring_n) ring_v2 = __uint_as_float(ta.vring[threadIdx.x * LEAN_VSTRIDE]);      /* (words of launches that have ended: an ordinary load, by the first wave only -- 70 000 waves asking for the same twenty cache lines were 7 us of the launch) */
+   if (!FUSE && ta.disp && ta.vring && (int)(threadIdx.x & 63) < ta.vring_n) ring_v2 = __uint_as_float(ta.vring[(threadIdx.x & 63) * LEAN_VSTRIDE]);
+   if (ta.disp && !ta.vring)
    {
-      const double Down = *ta.disp, Dhalo = ta.hdisp ? sqrt(*ta.hdisp) : 0.0;
+      const double Down = disp_base;
+      const double Dhalo = ta.hdisp ? sqrt(*ta.hdisp) : 0.0;
       const double twoD = Down + fmax(Down, Dhalo);
 #pragma unroll
       for (int s_ = NSHELL - 1; s_ >= 1; s_--) if (ta.sh_reach[s_] > twoD) smax = s_ - 1;      /* (sh_reach grows with s: the smallest such s decides) */
@@ -182,8 +206,9 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          /* direct halo staging: a received bead's position is in the exchange's receive buffer (NbTileArgs::hrecv3); its place there
           * is asked for here, for all rounds at once, so the one dependent round trip is paid once per tile */
          const bool from_recv = ta.hrecv3 != nullptr && tshift;
+         const bool from_owner = ta.self_img != 0 && tshift;      /* a single domain's images: the owner's record + the shift */
          int hk[MAXR];
-         if (from_recv)
+         if (from_recv || from_owner)
          {
 #pragma unroll
             for (int u = 0; u < MAXR; u++) hk[u] = (gj[u] >= ta.nloc) ? ta.halo_src[gj[u] - ta.nloc] : 0;
@@ -204,13 +229,20 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   pp[u].x = rr[0]; pp[u].y = rr[1]; pp[u].z = rr[2];
                   pp[u].w = PACKED ? 0.0 : pos[gj[b + u]].w;      /* (packed entries carry the partner's type themselves) */
                }
-               else pp[u] = pos[gj[b + u]];
-               sh[u] = (!SHBIT && tshift && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
+               else pp[u] = pos[(from_owner && gj[b + u] >= ta.nloc) ? hk[b + u] : gj[b + u]];
+               sh[u] = (((!SHBIT && tshift) || from_owner) && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
             }
 #pragma unroll
             for (int u = 0; u < SU; u++)
             {
                const int k = (int)threadIdx.x + (b + u) * NB_BLOCK;
+               if (from_owner && sh[u] != 13)
+               {
+                  /* (the image update's own arithmetic: k_reduce_jobs_images, k_halo_update) */
+                  pp[u].x += (double)(sh[u] % 3 - 1) * gp.L[0];
+                  pp[u].y += (double)((sh[u] / 3) % 3 - 1) * gp.L[1];
+                  pp[u].z += (double)(sh[u] / 9 - 1) * gp.L[2];
+               }
                if (k < ns)
                {
                   XY_s[k + 1] = make_double2(pp[u].x, pp[u].y);
@@ -249,6 +281,14 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
       }
       }
       if (FUSE && threadIdx.x < (NB_BLOCK / 64) * 8) ((double *)((char *)smem + fa.ke_off))[threadIdx.x] = 0.0;
+      if (FUSE && ta.disp && ta.vring && threadIdx.x < 64)
+      {
+         /* the lean steps' share of the displacement bound: their largest |v|^2, one word each, added up by the first wave for all */
+         const float eff = lean_effective(ring_v2, (int)threadIdx.x);      /* (lanes behind the last word hold decayed values: not steps) */
+         const double sum = wave_sum_dpp(((int)threadIdx.x < ta.vring_n ? ta.vring_dt * sqrt((double)eff) : 0.0) * (1.0 + 2e-6)) * (1.0 + 1e-6);      /* (every term and the sum rounded up, with room for the scan's roundings) */
+         const float thr = ta.vring_n > 0 ? __shfl(eff, ta.vring_n - 1, 64) * LEAN_C : 0.0f;      /* this step's workgroups file what lies above it */
+         if (threadIdx.x == 0) { double *h = (double *)((char *)smem + fa.ke_off) + (NB_BLOCK / 64) * 8; h[0] = sum; h[1] = (double)thr; }
+      }
       if (threadIdx.x == 0)
       {
          /* staged slot 0: a bead far outside every cutoff.  List padding (entry 0) points
@@ -256,6 +296,16 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = SHBIT ? 1e30 : z_with_tags<PACKED>(1e30, 0.0, false);
       }
       __syncthreads();
+      if (ta.disp && ta.vring)
+      {
+         /* the displacement bound + the lean steps since the rebuild: their largest |v|^2, one word each, added up in the same order by every wave
+          * (a single domain: no received beads, no hdisp) */
+         const double Down = disp_base + (FUSE ? ((const double *)((const char *)smem + fa.ke_off))[(NB_BLOCK / 64) * 8]
+                                                : wave_sum_dpp(((int)(threadIdx.x & 63) < ta.vring_n ? ta.vring_dt * sqrt((double)lean_effective(ring_v2, (int)(threadIdx.x & 63))) : 0.0) * (1.0 + 2e-6)) * (1.0 + 1e-6));
+         const double twoD = 2.0 * Down;
+#pragma unroll
+         for (int s_ = NSHELL - 1; s_ >= 1; s_--) if (ta.sh_reach[s_] > twoD) smax = s_ - 1;
+      }
       long long base = ta.tile_base[t];
       int rows = ta.tile_rows[t];
       const int nlj = ta.nlj;
@@ -538,7 +588,15 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          if (nown > 0 && k < 7) for (int q = 0; q < NB_BLOCK / 64; q++) a += ke_s[q * 8 + k];
          if (nown > 0 && k == 7) for (int q = 0; q < NB_BLOCK / 64; q++) a = fmax(a, ke_s[q * 8 + 7]);
          fa.kpartials[(size_t)slot * 8 + k] = a;
+         if (k == 7) wg_v2 = (float)a;      /* (a float's value held in a double: the conversion is exact) */
       }
    }
+   /* lean step: the workgroup's largest |v|^2 joins the step's word of the ring by an atomic maximum of the float's bits (non-negative
+    * floats order like their bits: exact and order-free; no return value, no fence -- a device-scope release here writes back an XCD's L2
+    * in the middle of the launch's 340 MB of stores: +40 % on the kernel) */
+   if (FUSE && ta.vring_w && threadIdx.x == 64 + 7)
+   {
+      const float thr = (ta.vring && nown > 0) ? (float)((const double *)((const char *)smem + fa.ke_off))[(NB_BLOCK / 64) * 8 + 1] : 0.0f;      /* (the first lean step after a rebuild: everyone files) */
+      if (wg_v2 > thr) atomicMax(ta.vring_w, __float_as_uint(wg_v2));
+   }
 }
-

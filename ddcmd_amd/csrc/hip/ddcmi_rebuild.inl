@@ -188,9 +188,11 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx)
 
 static int bl_launch_interior(ddcmi_ctx *ctx);
 static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused);
+int ddcmi_lean_flush(ddcmi_ctx *ctx);
 extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
 {
    if (!ctx) return DDCMI_EINVAL;
+   { int rcl = ddcmi_lean_flush(ctx); if (rcl) return rcl; }      /* (the pending steps' rows are as many as this list's work items) */
    if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate < 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
    (void)hipSetDevice(ctx->device);
@@ -359,6 +361,7 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
    ENSURE(ctx, ctx->tile_perm, cap_items + 1);
    ENSURE(ctx, ctx->sched, 32);
    ENSURE(ctx, ctx->partials, (size_t)(nitems + 8) * 8);
+   if (!ctx->no_lean && !ctx->d_vring.p) ENSURE(ctx, ctx->d_vring, (size_t)LEAN_W * LEAN_VSTRIDE);      /* (zeroed by the tail launch below, like the bound) */
    {
       /* the tile order and the ranges, the displacement words of the shell-limited walk back to zero, and the NEXT rebuild's counters
        * cleared while nothing reads them (ddcmi_bl_sort_owned, mg_phase1_launch): one launch */
@@ -366,6 +369,8 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
       tj.fetch(ctx->tile_perm.p, perm, std::max(nitems, 1)).fetch(ctx->sched.p, sched, 32);
       const int ncell = ctx->gp.ncell;
       tj.zero.add(ctx->d_results + R_DISP, 6);      /* three doubles */
+      if (ctx->d_vring.p) tj.zero.add(ctx->d_vring.p, LEAN_W * LEAN_VSTRIDE);      /* (and the lean steps' words of the bound) */
+      ctx->lean_since = 0;
       tj.zero.add(ctx->cell_cnt_o.p, ncell + 1).add(ctx->cell_cnt_h.p, ncell).add(ctx->d_flags, 8).add(ctx->d_flags + 12, 1).add(ctx->d_flags + 32, 2);
       tj.zero.add(ctx->d_flags + DDCMI_FLAG_AGREE, 2);
       const bool dirs = ctx->dir_cnt.p != nullptr && ctx->dir_cnt.cap >= 32;

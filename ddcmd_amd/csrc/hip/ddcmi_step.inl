@@ -12,7 +12,7 @@
 static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
 {
    const size_t capl = (size_t)ctx->stage_cap + 2;
-   const size_t rows = (NB_THREADS / 64) * 8 * sizeof(double);
+   const size_t rows = ((NB_THREADS / 64) * 8 + 2) * sizeof(double);      /* the waves' rows of kinetic sums + (lean step) the displacement bound handed from wave 0 to the others */
    const size_t npair = (size_t)ctx->nnb * ctx->nnb;
    const size_t direct = npair * sizeof(double4), level = (size_t)ctx->nlvl * sizeof(double4) + ((npair + 15) & ~(size_t)15);
    auto lay = [&](size_t table, bool lvl)
@@ -40,14 +40,15 @@ static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
    const NbLds v = lay(level, true);
    return (ctx->force_lvl || v.wgs > d.wgs) ? v : d;
 }
-static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */)
+static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */,
+                         bool *lean = nullptr /* in: the caller could run this step lean (ddcmi_ctx::lean_pending); out: this launch did */)
 {
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
    /* Decomposed runs, between rebuilds: the halo exchange (pack, one RCCL message per peer,
     * unpack) runs on a second stream while this stream computes the tiles whose
     * neighbourhoods hold owned beads only; the other tiles wait for it. */
-   bool halo_pending = false;
+   bool halo_pending = false, image_update_owed = false;
    /* the received beads' displacement since the rebuild (NbTileArgs::hdisp): measured by the halo update of a decomposed run whose pair
     * kernel may end its rows early; the word of this step's parity is the one this step's pair kernel reads */
    /* direct halo staging (ddcmi_ctx::halo_in_recv): the pair kernel takes the received beads out of the exchange's receive buffer, no
@@ -93,6 +94,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    }
    /* (not after a rebuild: it made the images from these very positions; and never on a rank of a transport whose halo is marked fresh --
     * its last exchange or its rebuild placed every image and halo bead, and the receive buffer may hold velocities or nothing by now) */
+   else if (lean && *lean && fuse) image_update_owed = nh > 0 && !ctx->images_fresh && !((ctx->nranks > 1 || ctx->loopback) && !ctx->group_);      /* (the pair kernel stages the images from their owners, NbTileArgs::self_img -- decided for good below) */
    else if (nh > 0 && !ctx->images_fresh && !((ctx->nranks > 1 || ctx->loopback) && !ctx->group_))
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
@@ -150,6 +152,30 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.halo_full_walk = (direct && ctx->shell_skip) ? 1 : 0;
       na.lvlidx = ctx->d_lvlidx.p; na.nlvl = ctx->nlvl; na.tab_off = lay.tab_off;
       na.fb = (has_bonded && n > 0) ? ctx->fb.p : nullptr;
+      na.self_img = 0; na.vring_w = nullptr; na.vring_dt = ctx->lean_dt;
+      na.vring = (na.disp && ctx->lean_since > 0) ? ctx->d_vring.p : nullptr; na.vring_n = ctx->lean_since;
+      double *partials_p = ctx->partials.p;
+      if (lean && *lean)
+      {
+         /* lean: the fused launch, every tile in ONE launch, neighbourhoods on the index-free staging path */
+         *lean = fuse != nullptr && ctx->ntile_class[1] <= 0 && ctx->stage_cap + 2 < 4096 && ctx->lean_pending < LEAN_W && ctx->lean_since < LEAN_W &&
+                 (ctx->lean_since == 0 || ctx->lean_dt == fuse->dt);
+         if (!*lean && image_update_owed)      /* (the image update skipped above) */
+            hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
+                               ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
+      }
+      if (lean && *lean)
+      {
+         const size_t stride = (size_t)(ctx->nitems + 8) * 8;
+         if (ctx->lean_pending > 0 && stride != ctx->lean_stride) SETERR(ctx, DDCMI_EINVAL, "internal: the lean steps' rows changed size without a flush");
+         ctx->lean_stride = stride;
+         ENSURE(ctx, ctx->lean_part, stride * LEAN_W); ENSURE(ctx, ctx->lean_kpart, stride * LEAN_W);
+         partials_p = ctx->lean_part.p + stride * ctx->lean_pending;
+         fa.kpartials = ctx->lean_kpart.p + stride * ctx->lean_pending;
+         na.self_img = nh > 0 ? 1 : 0;
+         if (na.disp) { na.vring_w = ctx->d_vring.p + (size_t)LEAN_VSTRIDE * ctx->lean_since; ctx->lean_dt = fa.dt; na.vring_dt = fa.dt; }
+         ctx->lean_since++;
+      }
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
 #define LAUNCH_NBZ(Q, P, S, NT, Z) LAUNCH_NBF(Q, P, S, NT, Z, false)
 #define LAUNCH_NBF(Q, P, S, NT, Z, F) do { if (lvl) LAUNCH_NBL(Q, P, S, NT, Z, F, true); else LAUNCH_NBL(Q, P, S, NT, Z, F, false); } while (0)
@@ -160,7 +186,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
          HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F, L>, (int)lds)); \
          hipLaunchKernelGGL((k_nonbond<Q, P, S, NT, NB_WPE, NB_CH, Z, F, L>), dim3(grid), dim3(NT), lds, st, ctx->gp, na, ctx->npad, ctx->pos.p, ctx->d_kqtab.p, \
                             ctx->excl16.p, ctx->excl_cnt.p, (L) ? ctx->d_lvltab.p : ctx->d_ljtab.p, ctx->rmax * ctx->rmax, ctx->krf, ctx->crf, ctx->keR, \
-                            ctx->fx.p, ctx->fy.p, ctx->fz.p, ctx->partials.p, fa); } while (0)
+                            ctx->fx.p, ctx->fy.p, ctx->fz.p, partials_p, fa); } while (0)
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
       /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
        * class 1: tiles that stage image/halo beads, after the halo exchange */
@@ -231,8 +257,57 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    return DDCMI_OK;
 }
 
+/* the lean steps' pending sums, all in one launch (k_reduce_hist) */
+int ddcmi_lean_flush(ddcmi_ctx *ctx)
+{
+   if (ctx->lean_pending <= 0) return DDCMI_OK;
+   const int np = ctx->lean_pending;
+   ctx->lean_pending = 0;
+   if (!ctx->lean_tmp.p)
+   {
+      const size_t nt = (size_t)2 * LEAN_W * RED_SPLIT * 8 + 2 * LEAN_W;      /* rows, then the jobs' tickets (left at zero by their last workgroup) */
+      ENSURE(ctx, ctx->lean_tmp, nt); ENSURE(ctx, ctx->lean_hist, (size_t)16 * LEAN_W);
+      HIPCHK(ctx, hipMemsetAsync(ctx->lean_tmp.p, 0, nt * sizeof(double), ctx->stream));
+   }
+   RedJob jf = {ctx->lean_part.p, ctx->nitems, 8, nullptr, 0, 0.0, nullptr};
+   RedJob jk = {ctx->lean_kpart.p, ctx->nitems, 7, nullptr, 0, 0.0, nullptr};
+   hipLaunchKernelGGL(k_reduce_hist, dim3(RED_SPLIT, 2 * np), dim3(1024), 0, ctx->stream, jf, jk, ctx->lean_stride, np, ctx->lean_hist.p, ctx->lean_tmp.p);
+   ctx->lean_hist_n = np;
+   return DDCMI_OK;
+}
+/* test entry point (ddcmi_test.h): the sums of the lean steps of the last flush, 16 per step: pair kernel {lj, ele, virial xx yy zz xy xz yz} as
+ * the full list counts them (x 2), then {rk, tion xx yy zz xy xz yz}, 0 */
+extern "C" int ddcmi_debug_lean_history(ddcmi_ctx *ctx, int *nsteps, double *sums)
+{
+   if (!ctx || !nsteps || !sums) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   int rc = ddcmi_lean_flush(ctx);
+   if (rc) return rc;
+   *nsteps = ctx->lean_hist_n;
+   if (ctx->lean_hist_n > 0)
+   {
+      HIPCHK(ctx, hipMemcpyAsync(sums, ctx->lean_hist.p, (size_t)16 * ctx->lean_hist_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   }
+   return DDCMI_OK;
+}
+/* test entry point: the displacement bound's base word and the lean steps' words (largest |v|^2 per step since the rebuild) */
+extern "C" int ddcmi_debug_disp(ddcmi_ctx *ctx, double *disp, float *ring, int *nring)
+{
+   if (!ctx || !disp || !ring || !nring) return DDCMI_EINVAL;
+   (void)hipSetDevice(ctx->device);
+   unsigned w[LEAN_W * LEAN_VSTRIDE];
+   memset(w, 0, sizeof(w));
+   HIPCHK(ctx, hipMemcpyAsync(disp, ctx->d_results + R_DISP, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+   if (ctx->d_vring.p) HIPCHK(ctx, hipMemcpyAsync(w, ctx->d_vring.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+   *nring = ctx->lean_since;
+   for (int q = 0; q < LEAN_W; q++) memcpy(ring + q, w + q * LEAN_VSTRIDE, sizeof(float));
+   return DDCMI_OK;
+}
 static int fetch_results(ddcmi_ctx *ctx)
 {
+   { int rcl = ddcmi_lean_flush(ctx); if (rcl) return rcl; }
    { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }      /* (a peer whose rebuild failed: say so instead of waiting behind an exchange it never joins) */
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, R_SIZE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -545,7 +620,19 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
          ctx->fuse_tags_of = ctx->nrebuild;
       }
       fa.pos_new = ctx->pos2.p; fa.kpartials = ctx->kpartials.p;
-      if ((rc = launch_forces(ctx, true, &fa))) return rc;
+      /* lean: a single domain of FREE beads with nothing but the pair kernel in its step */
+      bool lean = !ctx->no_lean && ctx->nranks == 1 && !ctx->loopback && !ctx->group_ && ctx->updateRate > 0 && ctx->nloc > 0 &&
+                  (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) == 0 && fa.lam == 1.0;
+      for (int g = 0; g < ctx->ngroup; g++) lean = lean && ctx->gtype[g] == DDCMI_FREE;
+      if ((rc = launch_forces(ctx, true, &fa, &lean))) return rc;
+      if (fa.dt != 0.0 && lean)
+      {
+         /* the kernel has left the step's rows of sums in the ring, moved the displacement bound on and will find the images at their owners */
+         std::swap(ctx->pos, ctx->pos2);
+         ctx->lean_pending++;
+         ctx->drift_done = true;
+         return ctx->lean_pending >= LEAN_W ? ddcmi_lean_flush(ctx) : DDCMI_OK;
+      }
       if (fa.dt != 0.0)
       {
          RedJob jf = {ctx->partials.p, ctx->nitems, 8, ctx->d_results + R_NB_LJ, 1};

@@ -567,6 +567,45 @@ def test_two_berendsen_groups_with_different_factors_take_the_split_kernels():
     m.close()
 
 
+def test_lean_steps_equal_steps_with_a_reduction_launch_each(monkeypatch):
+    """A single domain of FREE beads without bonded terms runs ONE launch per step between rebuilds (the pair kernel with the integrator's pass,
+    which stages the periodic images from their owners and keeps the displacement bound itself); the second stage of every step's energy /
+    virial / kinetic sums is formed later, all pending steps in one launch.  Against DDCMI_NO_LEAN_STEP=1 (a reduction + image launch after
+    every step): the state after 47 steps across two rebuilds bit for bit, and the sums of every lean step -- read back through the test
+    library -- equal to the energies, virial and kinetic terms the other run reports step by step."""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(14, temperature_K=310.0)
+    monkeypatch.setenv("DDCMI_NO_LEAN_STEP", "1")
+    a = MartiniHIP(s)
+    monkeypatch.delenv("DDCMI_NO_LEAN_STEP")
+    b = MartiniHIP(s, test_api=True)
+    a.eval_forces(); b.eval_forces()
+    per_step = []
+    for k in range(15):
+        a.step(1)
+        per_step.append(a.energies())
+    b.step(16)                                   # steps 1..15 fused (lean), step 16 split
+    h = b.lean_history()
+    assert len(h) == 15, len(h)
+    for k in range(15):
+        e, vir, rk, tion = per_step[k]
+        assert abs(0.5 * h[k, 0] - e["lj"]) <= 1e-12 * abs(e["lj"]), k
+        assert np.abs(0.5 * h[k, 2:8] - vir).max() <= 1e-12 * np.abs(vir).max(), k
+        assert abs(h[k, 8] - rk) <= 1e-12 * rk, k
+        assert np.abs(h[k, 9:15] - tion).max() <= 1e-12 * np.abs(tion).max(), k
+    a.step(1)
+    ea, eb = a.energies(), b.energies()
+    assert ea[0] == eb[0] and np.array_equal(ea[1], eb[1]) and ea[2] == eb[2]
+    a.step(31); b.step(31)                       # across the rebuilds at loops 20 and 40
+    da, db = a.download(), b.download()
+    for k in ("r", "v", "f"):
+        for c in range(3):
+            assert np.array_equal(np.asarray(da[k][c]), np.asarray(db[k][c])), (k, c)
+    ea, eb = a.energies(), b.energies()
+    assert ea[0] == eb[0] and np.array_equal(ea[1], eb[1]) and ea[2] == eb[2]
+    a.close(); b.close()
+
+
 def test_rows_end_at_the_last_shell_that_can_matter(monkeypatch):
     """the pair kernel ends every row at the last distance shell a pair could have left since the rebuild (the displacement
     bound D = sum of the steps' max |dt v|, kept by the fused step): entries of later shells lay further than r_cut + 2 D from
