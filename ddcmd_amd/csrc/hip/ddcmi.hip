@@ -473,6 +473,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->device = device;
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
    ctx->no_lean = getenv("DDCMI_NO_LEAN_STEP") != nullptr;
+   if (const char *e = getenv("DDCMI_LEAN_MAX_BEADS")) ctx->lean_max_beads = atoi(e);
    ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
    ctx->no_direct_halo = getenv("DDCMI_NO_DIRECT_HALO") != nullptr;
    ctx->force_lvl = getenv("DDCMI_FORCE_LEVEL_TABLE") != nullptr;

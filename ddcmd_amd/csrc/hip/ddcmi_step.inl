@@ -621,7 +621,8 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       }
       fa.pos_new = ctx->pos2.p; fa.kpartials = ctx->kpartials.p;
       /* lean: a single domain of FREE beads with nothing but the pair kernel in its step */
-      bool lean = !ctx->no_lean && ctx->nranks == 1 && !ctx->loopback && !ctx->group_ && ctx->updateRate > 0 && ctx->nloc > 0 &&
+      /* (up to lean_max_beads: at 4.24 M the images' extra round trip in the staging of a quarter of the tiles costs the pair kernel the 16 us the launch and its gap cost) */
+      bool lean = !ctx->no_lean && ctx->nranks == 1 && !ctx->loopback && !ctx->group_ && ctx->updateRate > 0 && ctx->nloc > 0 && ctx->nloc <= ctx->lean_max_beads &&
                   (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) == 0 && fa.lam == 1.0;
       for (int g = 0; g < ctx->ngroup; g++) lean = lean && ctx->gtype[g] == DDCMI_FREE;
       if ((rc = launch_forces(ctx, true, &fa, &lean))) return rc;
