@@ -313,6 +313,11 @@ __global__ void k_slots_from_orig(int nloc, const int *__restrict__ orig, int *s
 }
 /* ------------------------------------------------------------------------- */
 /* periodic image atoms                                                       */
+/* Which periodic images does an owned bead have?  By CELL (round 5): the beads of the two outermost layers of cells on a periodic axis -- cells are at
+ * least half a list radius wide, so that is everything within the list radius of the face and at most a few per cent more.  An image cell then holds
+ * exactly the beads of ONE owned cell, in the same order (k_fill_images places an image by its owner's cell, k_sort_cells orders a cell's images like
+ * their owners), so the pair kernel can stage a single domain's images from their owners by cell arithmetic alone (NbTileArgs::self_img). */
+#define IMG_LAYERS 2
 __device__ __forceinline__ void image_dirs(const GridParams &gp, const double4 &p, int d[3])
 {
    double r[3] = {p.x, p.y, p.z};
@@ -321,8 +326,9 @@ __device__ __forceinline__ void image_dirs(const GridParams &gp, const double4 &
    {
       d[a] = 0;
       if (gp.m[a] == 0) continue;               /* no image margin on this axis */
-      if (r[a] < gp.lo[a] + gp.rlist) d[a] = +1;                                /* image at r+L */
-      else if (r[a] >= gp.lo[a] + gp.n[a] / gp.cinv[a] - gp.rlist) d[a] = -1;   /* image at r-L */
+      const int ic = min(max((int)floor((r[a] - gp.lo[a]) * gp.cinv[a]), 0), gp.n[a] - 1);      /* (the bead's cell: cell_coords) */
+      if (ic < IMG_LAYERS) d[a] = +1;                                           /* image at r+L */
+      else if (ic >= gp.n[a] - IMG_LAYERS) d[a] = -1;                           /* image at r-L */
    }
 }
 __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const int *img_off, const int *nimg,
@@ -333,6 +339,8 @@ __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const
    double4 p = pos[i];
    int d[3];
    image_dirs(gp, p, d);
+   int ocx, ocy, ocz;
+   cell_coords(gp, p.x, p.y, p.z, true, ocx, ocy, ocz);
    int k = img_off[i];
    for (int sz = 0; sz <= (d[2] != 0); sz++)
       for (int sy = 0; sy <= (d[1] != 0); sy++)
@@ -340,9 +348,9 @@ __global__ void k_fill_images(GridParams gp, int nloc, const double4 *pos, const
          {
             if (!(sx | sy | sz)) continue;
             int ix = sx * d[0], iy = sy * d[1], iz = sz * d[2];
-            double x = p.x + ix * gp.L[0], y = p.y + iy * gp.L[1], z = p.z + iz * gp.L[2];
-            int side[3] = {ix, iy, iz};
-            int c = halo_cell(gp, x, y, z, side);
+            /* the image's cell: its owner's cell moved by whole boxes (from the shifted position a rounding could put it next door, and the image
+             * cell would no longer hold its owner cell's beads one for one) */
+            int c = cell_linear(gp, ocx + ix * gp.n[0], ocy + iy * gp.n[1], ocz + iz * gp.n[2]);
             if (k >= cap) return;
             hsrc[k] = i;
             hshift[k] = (ix + 1) + 3 * (iy + 1) + 9 * (iz + 1);
@@ -473,6 +481,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->device = device;
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
    ctx->no_lean = getenv("DDCMI_NO_LEAN_STEP") != nullptr;
+   ctx->no_self_img = getenv("DDCMI_NO_SELF_IMAGES") != nullptr;
    if (const char *e = getenv("DDCMI_LEAN_MAX_BEADS")) ctx->lean_max_beads = atoi(e);
    ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
    ctx->no_direct_halo = getenv("DDCMI_NO_DIRECT_HALO") != nullptr;

@@ -153,22 +153,40 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          int *ofs_s = (int *)smem;                                    /* [NRC]  staged offset of each region cell */
          int *gst_s = ofs_s + NRC + 8;                                /* [NRC]  global index of its first bead */
          int *s_w = gst_s + NRC + 8;                                  /* [NWV]  scan scratch */
-         unsigned short *cellof = (unsigned short *)(s_w + 16);       /* [ns]   region cell of each staged slot */
+         unsigned char *shc_s = (unsigned char *)(s_w + 16);          /* [NRC]  self_img: shift code of an image cell (13: none) */
+         unsigned short *cellof = (unsigned short *)(shc_s + ((NRC + 15) & ~15));      /* [ns]   region cell of each staged slot */
          constexpr int CPT = (NRC + NB_BLOCK - 1) / NB_BLOCK;
          const int tx = t % gp.T[0], ty = (t / gp.T[0]) % gp.T[1], tz = t / (gp.T[0] * gp.T[1]);
-         int v[CPT], g[CPT], vsum = 0;
+         int v[CPT], g[CPT], sc[CPT], vsum = 0;
+         const bool from_owner = ta.self_img != 0 && tshift;      /* a single domain's images: the owner's record + the shift, found by cell arithmetic (image_dirs) */
 #pragma unroll
          for (int h = 0; h < CPT; h++)
          {
             const int c = CPT * (int)threadIdx.x + h;
-            v[h] = 0; g[h] = 0;
+            v[h] = 0; g[h] = 0; sc[h] = 13;
             if (c < NRC)
             {
                const int cx = TCX * tx - 2 + (c % RGX), cy = TCY * ty - 2 + ((c / RGX) % RGY), cz = TCZ * tz - 2 + (c / (RGX * RGY));
                if (cx >= 0 && cy >= 0 && cz >= 0 && cx < gp.g[0] && cy < gp.g[1] && cz < gp.g[2])
                {
                   const int id = cell_linear(gp, cx, cy, cz);
-                  v[h] = ta.cell_cnt[id]; g[h] = ta.cell_start[id];
+                  v[h] = ta.cell_cnt[id];
+                  /* an image cell (known by its coordinates: no load to wait for) holds the beads of the owned cell a whole box away, one for
+                   * one and in their order: stage those */
+                  const int cc[3] = {cx, cy, cz};
+                  int oc[3], code = 0, w3 = 1;
+                  bool img = false;
+#pragma unroll
+                  for (int a = 0; a < 3; a++)
+                  {
+                     const bool lowside = cc[a] < gp.m[a], highside = cc[a] >= gp.m[a] + gp.n[a];
+                     oc[a] = cc[a] + (lowside ? gp.n[a] : highside ? -gp.n[a] : 0);
+                     code += w3 * (lowside ? 0 : highside ? 2 : 1);      /* the image lies at owner - L | owner + L */
+                     w3 *= 3;
+                     img |= lowside | highside;
+                  }
+                  if (from_owner && img) { g[h] = ta.cell_start_o[cell_linear(gp, oc[0], oc[1], oc[2])]; sc[h] = code; }
+                  else g[h] = ta.cell_start[id];
                }
             }
             vsum += v[h];
@@ -190,25 +208,33 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
             if (c < NRC)
             {
                ofs_s[c] = ex; gst_s[c] = g[h];
+               if (from_owner) shc_s[c] = (unsigned char)sc[h];
                for (int j = 0; j < v[h]; j++) cellof[ex + j] = (unsigned short)c;
             }
             ex += v[h];
          }
          __syncthreads();
          int gj[MAXR];
+         unsigned long long simg = 0ull;      /* self_img: the rounds' shift codes, 5 bits each (13: not an image) */
+         static_assert(MAXR * 5 <= 64, "shift codes of the staging rounds");
 #pragma unroll
          for (int u = 0; u < MAXR; u++)
          {
             const int k = (int)threadIdx.x + u * NB_BLOCK;
             gj[u] = ts;      /* rounds past the end re-read the tile's first bead (a cache hit) and drop it */
-            if (k < ns) { const int c = cellof[k]; gj[u] = gst_s[c] + (k - ofs_s[c]); }
+            if (k < ns)
+            {
+               const int c = cellof[k];
+               gj[u] = gst_s[c] + (k - ofs_s[c]);
+               if (from_owner) simg |= (unsigned long long)shc_s[c] << (5 * u);
+            }
+            else if (from_owner) simg |= 13ull << (5 * u);
          }
          /* direct halo staging: a received bead's position is in the exchange's receive buffer (NbTileArgs::hrecv3); its place there
           * is asked for here, for all rounds at once, so the one dependent round trip is paid once per tile */
          const bool from_recv = ta.hrecv3 != nullptr && tshift;
-         const bool from_owner = ta.self_img != 0 && tshift;      /* a single domain's images: the owner's record + the shift */
          int hk[MAXR];
-         if (from_recv || from_owner)
+         if (from_recv)
          {
 #pragma unroll
             for (int u = 0; u < MAXR; u++) hk[u] = (gj[u] >= ta.nloc) ? ta.halo_src[gj[u] - ta.nloc] : 0;
@@ -229,8 +255,9 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
                   pp[u].x = rr[0]; pp[u].y = rr[1]; pp[u].z = rr[2];
                   pp[u].w = PACKED ? 0.0 : pos[gj[b + u]].w;      /* (packed entries carry the partner's type themselves) */
                }
-               else pp[u] = pos[(from_owner && gj[b + u] >= ta.nloc) ? hk[b + u] : gj[b + u]];
-               sh[u] = (((!SHBIT && tshift) || from_owner) && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
+               else pp[u] = pos[gj[b + u]];
+               if (from_owner) sh[u] = (int)((simg >> (5 * (b + u))) & 31ull);
+               else sh[u] = (!SHBIT && tshift && gj[b + u] >= ta.nloc) ? ta.halo_shift[gj[b + u] - ta.nloc] : 13;
             }
 #pragma unroll
             for (int u = 0; u < SU; u++)

@@ -21,7 +21,7 @@ static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
       l.lvl = lvl; l.zfix = capl * 16 <= NB_ZOFF;
       /* (while it stages, the kernel keeps its cell tables and slot -> cell map where the positions will lie -- 2 (NRC + 8) + 16 ints and
        * 2 bytes per staged bead from address 0: the table, loaded before the staging, must start behind them) */
-      const size_t scratch = ((2 * (NRC + 8) + 16) * sizeof(int) + 2 * capl + 15) & ~(size_t)15;
+      const size_t scratch = ((2 * (NRC + 8) + 16) * sizeof(int) + ((NRC + 15) & ~15) + 2 * capl + 15) & ~(size_t)15;      /* cell tables, image cells' shift codes, the slot -> cell map */
       size_t gap_lo = std::max(capl * 16, scratch), gap_hi = l.zfix ? NB_ZOFF : 0, end = l.zfix ? NB_ZOFF + capl * 8 : capl * 24;
       l.ke_off = 0;
       if (fused)
@@ -40,6 +40,21 @@ static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
    const NbLds v = lay(level, true);
    return (ctx->force_lvl || v.wgs > d.wgs) ? v : d;
 }
+/* may this context run lean steps (ddcmi_ctx::lean_pending)?  A single domain of FREE beads whose force is the pair kernel's alone */
+static bool lean_capable(const ddcmi_ctx *ctx)
+{
+   if (ctx->no_lean || ctx->nranks != 1 || ctx->loopback || ctx->group_ || ctx->updateRate <= 0 || ctx->nloc <= 0 || ctx->nloc > ctx->lean_max_beads) return false;
+   if ((ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) != 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0 || (ctx->excludePotentialTerm & 128) != 0) return false;
+   for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE) return false;
+   return true;
+}
+/* a single domain's periodic images are staged by the pair kernel from their owners (NbTileArgs::self_img): nothing reads the image records
+ * between two rebuilds, and nothing refreshes them -- where the step can be lean; elsewhere the reduction launch of every step refreshes
+ * them on the side and the staging keeps its shorter path (the bilayer: 4 us per pair kernel).  DDCMI_NO_SELF_IMAGES=1: never. */
+static bool self_images(const ddcmi_ctx *ctx)
+{
+   return !ctx->no_self_img && lean_capable(ctx) && ctx->nhalo > 0 && ctx->stage_cap + 2 < 4096;
+}
 static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */,
                          bool *lean = nullptr /* in: the caller could run this step lean (ddcmi_ctx::lean_pending); out: this launch did */)
 {
@@ -48,7 +63,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    /* Decomposed runs, between rebuilds: the halo exchange (pack, one RCCL message per peer,
     * unpack) runs on a second stream while this stream computes the tiles whose
     * neighbourhoods hold owned beads only; the other tiles wait for it. */
-   bool halo_pending = false, image_update_owed = false;
+   bool halo_pending = false;
    /* the received beads' displacement since the rebuild (NbTileArgs::hdisp): measured by the halo update of a decomposed run whose pair
     * kernel may end its rows early; the word of this step's parity is the one this step's pair kernel reads */
    /* direct halo staging (ddcmi_ctx::halo_in_recv): the pair kernel takes the received beads out of the exchange's receive buffer, no
@@ -94,7 +109,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
    }
    /* (not after a rebuild: it made the images from these very positions; and never on a rank of a transport whose halo is marked fresh --
     * its last exchange or its rebuild placed every image and halo bead, and the receive buffer may hold velocities or nothing by now) */
-   else if (lean && *lean && fuse) image_update_owed = nh > 0 && !ctx->images_fresh && !((ctx->nranks > 1 || ctx->loopback) && !ctx->group_);      /* (the pair kernel stages the images from their owners, NbTileArgs::self_img -- decided for good below) */
+   else if (self_images(ctx)) { }      /* (the pair kernel finds the images at their owners) */
    else if (nh > 0 && !ctx->images_fresh && !((ctx->nranks > 1 || ctx->loopback) && !ctx->group_))
       hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
                          ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
@@ -152,17 +167,14 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.halo_full_walk = (direct && ctx->shell_skip) ? 1 : 0;
       na.lvlidx = ctx->d_lvlidx.p; na.nlvl = ctx->nlvl; na.tab_off = lay.tab_off;
       na.fb = (has_bonded && n > 0) ? ctx->fb.p : nullptr;
-      na.self_img = 0; na.vring_w = nullptr; na.vring_dt = ctx->lean_dt;
+      na.self_img = self_images(ctx) ? 1 : 0; na.vring_w = nullptr; na.vring_dt = ctx->lean_dt;
       na.vring = (na.disp && ctx->lean_since > 0) ? ctx->d_vring.p : nullptr; na.vring_n = ctx->lean_since;
       double *partials_p = ctx->partials.p;
       if (lean && *lean)
       {
          /* lean: the fused launch, every tile in ONE launch, neighbourhoods on the index-free staging path */
-         *lean = fuse != nullptr && ctx->ntile_class[1] <= 0 && ctx->stage_cap + 2 < 4096 && ctx->lean_pending < LEAN_W && ctx->lean_since < LEAN_W &&
+         *lean = fuse != nullptr && ctx->ntile_class[1] <= 0 && (nh == 0 || self_images(ctx)) && ctx->lean_pending < LEAN_W && ctx->lean_since < LEAN_W &&
                  (ctx->lean_since == 0 || ctx->lean_dt == fuse->dt);
-         if (!*lean && image_update_owed)      /* (the image update skipped above) */
-            hipLaunchKernelGGL(k_halo_update, dim3(cdiv(nh, HU_PER)), dim3(HU_THREADS), 0, st, n, nh, ctx->halo_src.p, ctx->halo_shift.p,
-                               ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p, ctx->gid.p, false, ctx->hrecv3.p, ctx->hrecv5.p, (const int *)nullptr, hmax, hpar);
       }
       if (lean && *lean)
       {
@@ -172,8 +184,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
          ENSURE(ctx, ctx->lean_part, stride * LEAN_W); ENSURE(ctx, ctx->lean_kpart, stride * LEAN_W);
          partials_p = ctx->lean_part.p + stride * ctx->lean_pending;
          fa.kpartials = ctx->lean_kpart.p + stride * ctx->lean_pending;
-         na.self_img = nh > 0 ? 1 : 0;
-         if (na.disp) { na.vring_w = ctx->d_vring.p + (size_t)LEAN_VSTRIDE * ctx->lean_since; ctx->lean_dt = fa.dt; na.vring_dt = fa.dt; }
+         ctx->lean_dt = fa.dt; na.vring_dt = fa.dt;
+         if (na.disp) na.vring_w = ctx->d_vring.p + (size_t)LEAN_VSTRIDE * ctx->lean_since;
          ctx->lean_since++;
       }
 #define LAUNCH_NB(Q, P, S, NT) do { if (zfix) LAUNCH_NBZ(Q, P, S, NT, NB_ZOFF); else LAUNCH_NBZ(Q, P, S, NT, 0); } while (0)
@@ -621,10 +633,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       }
       fa.pos_new = ctx->pos2.p; fa.kpartials = ctx->kpartials.p;
       /* lean: a single domain of FREE beads with nothing but the pair kernel in its step */
-      /* (up to lean_max_beads: at 4.24 M the images' extra round trip in the staging of a quarter of the tiles costs the pair kernel the 16 us the launch and its gap cost) */
-      bool lean = !ctx->no_lean && ctx->nranks == 1 && !ctx->loopback && !ctx->group_ && ctx->updateRate > 0 && ctx->nloc > 0 && ctx->nloc <= ctx->lean_max_beads &&
-                  (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) == 0 && fa.lam == 1.0;
-      for (int g = 0; g < ctx->ngroup; g++) lean = lean && ctx->gtype[g] == DDCMI_FREE;
+      bool lean = lean_capable(ctx) && fa.lam == 1.0;
       if ((rc = launch_forces(ctx, true, &fa, &lean))) return rc;
       if (fa.dt != 0.0 && lean)
       {
@@ -641,7 +650,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
          std::swap(ctx->pos, ctx->pos2);
          PackJob pk;
          memset(&pk, 0, sizeof(pk));
-         if (ctx->nhalo > 0 && ctx->nranks == 1 && !ctx->loopback)
+         if (ctx->nhalo > 0 && ctx->nranks == 1 && !ctx->loopback && !self_images(ctx))
          {
             /* + the periodic images at the drifted positions, in the same launch: the next force evaluation finds them fresh */
             ImageJob im = {ctx->nloc, ctx->nhalo, ctx->halo_src.p, ctx->halo_shift.p, ctx->gp.L[0], ctx->gp.L[1], ctx->gp.L[2], ctx->pos.p};

@@ -567,6 +567,35 @@ def test_two_berendsen_groups_with_different_factors_take_the_split_kernels():
     m.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["water", "water_open_z"])
+def test_images_staged_from_their_owners_equal_the_update_launch(case, monkeypatch):
+    """A single domain's periodic images are chosen by cell (the two outermost layers), so that an image cell holds one owned cell's beads one
+    for one and the pair kernel stages them from their owners by cell arithmetic -- no image update between rebuilds.  Against
+    DDCMI_NO_SELF_IMAGES=1 (the image records refreshed by a launch before every force evaluation): forces, energies, virial and the state
+    after 45 steps across two rebuilds, bit for bit; water and water with an open axis (where the step can be lean: elsewhere the
+    reduction launch of every step refreshes the images on the side and the staging keeps its shorter path)."""
+    from ddcmd_amd.martini import MartiniHIP
+    s = make_water_setup(13, temperature_K=310.0)
+    if case == "water_open_z":
+        s.pbc = 3
+    monkeypatch.setenv("DDCMI_NO_SELF_IMAGES", "1")
+    a = MartiniHIP(s)
+    monkeypatch.delenv("DDCMI_NO_SELF_IMAGES")
+    b = MartiniHIP(s)
+    ea, eb = a.eval_forces(), b.eval_forces()
+    assert ea[0] == eb[0] and np.array_equal(ea[1], eb[1])
+    for n in (7, 19, 19):
+        a.step(n); b.step(n)
+        da, db = a.download(), b.download()
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(np.asarray(da[k][c]), np.asarray(db[k][c])), (case, n, k, c)
+        ea, eb = a.energies(), b.energies()
+        assert ea[0] == eb[0] and np.array_equal(ea[1], eb[1]) and ea[2] == eb[2], (case, n)
+    a.close(); b.close()
+
+
 def test_lean_steps_equal_steps_with_a_reduction_launch_each(monkeypatch):
     """A single domain of FREE beads without bonded terms runs ONE launch per step between rebuilds (the pair kernel with the integrator's pass,
     which stages the periodic images from their owners and keeps the displacement bound itself); the second stage of every step's energy /
@@ -574,6 +603,9 @@ def test_lean_steps_equal_steps_with_a_reduction_launch_each(monkeypatch):
     every step): the state after 47 steps across two rebuilds bit for bit, and the sums of every lean step -- read back through the test
     library -- equal to the energies, virial and kinetic terms the other run reports step by step."""
     from ddcmd_amd.martini import MartiniHIP
+    import os
+    if any(os.environ.get(k) for k in ("DDCMI_NO_LEAN_STEP", "DDCMI_NO_SELF_IMAGES", "DDCMI_NO_FUSED_STEP", "DDCMI_GRAPH_MAX_BEADS")):
+        pytest.skip("the lean step is switched off in this environment")
     s = make_water_setup(14, temperature_K=310.0)
     monkeypatch.setenv("DDCMI_NO_LEAN_STEP", "1")
     a = MartiniHIP(s)
