@@ -415,13 +415,10 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
 /* workgroup k sums column k of the gather kernel's partials in a fixed order and files it where
  * finish_energy expects the per-kind sums (the whole bonded virial goes to the bond block) */
 #define RG_T 1024
-__global__ __launch_bounds__(RG_T) void k_reduce_gather(const double *__restrict__ partials, int nblocks, int pstride, double *results)
+/* row k of the [value][workgroup] sums of both launches (the light launch's workgroups, then the heavy one's): unit stride (rows of 16 values per
+ * workgroup made every load instruction touch 64 cache lines: 8 us for the 5000 workgroups of the 2 M-bead bilayer); independent partial sums */
+__device__ __forceinline__ double reduce_gather_row(const double *__restrict__ row, int nblocks, double *s)
 {
-   __shared__ double s[RG_T];
-   const int k = blockIdx.x;
-   /* row k of the [value][workgroup] sums of both launches (the light launch's workgroups, then the heavy one's): unit stride (rows of 16 values
-    * per workgroup made every load instruction touch 64 cache lines: 8 us for the 5000 workgroups of the 2 M-bead bilayer); independent partial sums */
-   const double *row = partials + (size_t)k * pstride;
    double p[4] = {0.0, 0.0, 0.0, 0.0};
    int b = threadIdx.x;
    for (; b + 3 * RG_T < nblocks; b += 4 * RG_T)
@@ -437,13 +434,36 @@ __global__ __launch_bounds__(RG_T) void k_reduce_gather(const double *__restrict
       if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
       __syncthreads();
    }
+   return s[0];
+}
+__global__ __launch_bounds__(RG_T) void k_reduce_gather(const double *__restrict__ partials, int nblocks, int pstride, double *results)
+{
+   __shared__ double s[RG_T];
+   const int k = blockIdx.x;
+   const double sum = reduce_gather_row(partials + (size_t)k * pstride, nblocks, s);
    if (threadIdx.x == 0)
    {
       const int dst = k == 0 ? R_SCR_BOND : k == 1 ? R_SCR_ANGLE : k == 2 ? R_SCR_TORS : k == 3 ? R_SCR_TORS + 1 : R_SCR_BOND + 1 + (k - 4);
-      results[dst] = s[0];
+      results[dst] = sum;
       if (k == 1) for (int q = 1; q < 7; q++) results[R_SCR_ANGLE + q] = 0.0;
       if (k == 2) for (int q = 2; q < 8; q++) results[R_SCR_TORS + q] = 0.0;
    }
+}
+/* the lean steps' bonded sums, every pending step in one launch (ddcmi_lean_flush): step q's rows lie q * bstride doubles behind the first step's;
+ * its GB_NV sums -- e_bond, e_angle, e_tors, e_impr, virial xx yy zz xy xz yz, the same additions in the same order as k_reduce_gather's --
+ * go to hist[LEAN_HW q + 16 ...] */
+__global__ __launch_bounds__(RG_T) void k_reduce_gather_hist(const double *__restrict__ partials, int nblocks, int pstride, size_t bstride, double *hist)
+{
+   __shared__ double s[RG_T];
+   const int k = blockIdx.x, q = blockIdx.y;
+   const double sum = reduce_gather_row(partials + (size_t)q * bstride + (size_t)k * pstride, nblocks, s);
+   if (threadIdx.x == 0) hist[(size_t)LEAN_HW * q + 16 + k] = sum;
+}
+int ddcmi_lean_flush_bonded(ddcmi_ctx *ctx, int np)
+{
+   if (ctx->lean_bnblk <= 0 || !ctx->lean_bpart.p) return DDCMI_OK;
+   hipLaunchKernelGGL(k_reduce_gather_hist, dim3(GB_NV, np), dim3(RG_T), 0, ctx->stream, ctx->lean_bpart.p, ctx->lean_bnblk, ctx->lean_bpstride, ctx->lean_bstride, ctx->lean_hist.p);
+   return DDCMI_OK;
 }
 
 /* ---- decomposed runs: atoms of terms are named by gid and located among the owned + halo beads - */
@@ -882,7 +902,7 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
    return DDCMI_OK;
 }
 
-int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb)
+int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb, int lean_slot)
 {
    if (ctx->inc_nrow == 0 && ctx->nrest == 0) return DDCMI_OK;
    hipStream_t st = ctx->stream;
@@ -907,20 +927,29 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb)
    const int pstride = (nblk + nblk2 + 15) & ~15;
    ENSURE(ctx, ctx->bpartials, (size_t)pstride * GB_NV + 16);
    GatherRows gr = gather_rows(ctx);
-   double *p2 = ctx->bpartials.p + nblk;      /* the heavy launch's workgroups follow the light one's in every row */
+   double *p1 = ctx->bpartials.p;
+   if (lean_slot >= 0)
+   {
+      /* a lean step (launch_forces): the kernels' sums wait in the step's slot of a ring; one launch adds up every pending step's (ddcmi_lean_flush_bonded) */
+      const size_t bstride = (size_t)pstride * GB_NV;
+      ENSURE(ctx, ctx->lean_bpart, bstride * LEAN_W + 16);
+      ctx->lean_bstride = bstride; ctx->lean_bpstride = pstride; ctx->lean_bnblk = nblk + nblk2;
+      p1 = ctx->lean_bpart.p + bstride * (size_t)lean_slot;
+   }
+   double *p2 = p1 + nblk;      /* the heavy launch's workgroups follow the light one's in every row */
    static const bool no_lds_tab = getenv("DDCMI_NO_BONDED_LDS_TABLES") != nullptr;
    if (nblk > 0)
    {
       auto kl = (gr.lp.pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<false, true> : k_bonded_gather<false, false>;
       hipLaunchKernelGGL(kl, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, ctx->bpartials.p, pstride);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p1, pstride);
    }
    auto kh = (gr.hp.pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<true, true> : k_bonded_gather<true, false>;
    if (nblk2 > 0)
       hipLaunchKernelGGL(kh, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
                          ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2, pstride);
    if (fb) restraints();
-   hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(RG_T), 0, st, ctx->bpartials.p, nblk + nblk2, pstride, ctx->d_results);
+   if (lean_slot < 0) hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(RG_T), 0, st, ctx->bpartials.p, nblk + nblk2, pstride, ctx->d_results);
    return DDCMI_OK;
 }
 

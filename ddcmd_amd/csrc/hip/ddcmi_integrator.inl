@@ -93,14 +93,14 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(RedJob j0, RedJob j1, doub
    reduce_jobs_block(blockIdx.y ? j1 : j0, (int)blockIdx.x, (int)blockIdx.y, results, self_ele, tmp);
 }
 /* the lean steps' sums, all pending steps in ONE launch (ddcmi_ctx::lean_pending): step q's rows lie q * stride doubles behind the first
- * step's; its eight pair sums go to hist[16 q], its seven kinetic sums to hist[16 q + 8] -- the same workgroups, the same order of
+ * step's; its eight pair sums go to hist[LEAN_HW q], its seven kinetic sums to hist[LEAN_HW q + 8] -- the same workgroups, the same order of
  * additions as the per-step launch (reduce_jobs_block), so the sums are bit for bit the ones that launch forms */
 __global__ __launch_bounds__(1024) void k_reduce_hist(RedJob jf, RedJob jk, size_t stride, int nsteps, double *hist, double *tmp)
 {
    const int by = (int)blockIdx.y, q = by >> 1;
    RedJob j = (by & 1) ? jk : jf;
    j.partials += (size_t)q * stride;
-   j.out = hist + 16 * (size_t)q + ((by & 1) ? 8 : 0);
+   j.out = hist + (size_t)LEAN_HW * q + ((by & 1) ? 8 : 0);
    j.finish = 0; j.disp_dt = 0.0; j.disp = nullptr;
    reduce_jobs_block(j, (int)blockIdx.x, by, nullptr, 0.0, tmp, 2 * nsteps);
 }

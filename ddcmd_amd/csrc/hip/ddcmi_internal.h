@@ -122,6 +122,7 @@ struct TileSel { int mode; int lo[3], n[3]; };
 
 /* LDS layout of one k_nonbond workgroup (nb_lds_layout, ddcmi_step.inl) */
 #define LEAN_W 32
+#define LEAN_HW 32             /* doubles of a lean step's row of sums: 8 pair sums, 7 kinetic sums, 0, the 10 bonded sums, 0 ... */
 #define LEAN_VSTRIDE 32      /* words: 128 B */
 struct NbLds { size_t total; int tab_off, ke_off; bool lvl, zfix; int wgs; };
 
@@ -221,7 +222,7 @@ struct ddcmi_ctx
     * lean_stride doubles) and is formed for all pending steps by one launch (lean_flush -> lean_hist: 16 sums per step) at the next rebuild,
     * when the ring is full or when the host asks.  DDCMI_NO_LEAN_STEP=1: the reduction launch after every step, as before. */
    int lean_pending = 0, lean_hist_n = 0, lean_since = 0 /* lean steps since the rebuild: the next one's word of the ring */; size_t lean_stride = 0; bool no_lean = false, no_self_img = false; double lean_dt = 0; int lean_max_beads = 2500000 /* DDCMI_LEAN_MAX_BEADS: beyond it the step's gain (-0.5 % at 4.24 M) is not worth 1 % of the pair kernel */;
-   dbuf<double> lean_part, lean_kpart, lean_hist, lean_tmp;
+   dbuf<double> lean_part, lean_kpart, lean_hist, lean_tmp, lean_bpart; size_t lean_bstride = 0; int lean_bpstride = 0, lean_bnblk = 0;
    dbuf<unsigned> d_vring;             /* largest |v|^2 (float bits) of each lean step since the rebuild, one word per step at a stride of LEAN_VSTRIDE words: the step that
                                           is being written (atomic maxima of every workgroup) shares no cache line with the words the same launch reads */
    bool images_fresh = false;          /* the list was rebuilt in front of this force evaluation: the periodic images of a single domain need no update */
@@ -420,7 +421,8 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx);
 int ddcmi_group_ke_sums(ddcmi_ctx *ctx);
 int ddcmi_displacement_check(ddcmi_ctx *ctx, int *need);
 /* bonded.hip */
-int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb = nullptr);      /* fb: the force goes to the (zeroed) record array instead of being added to fx, fy, fz */
+int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb = nullptr, int lean_slot = -1);
+int ddcmi_lean_flush_bonded(ddcmi_ctx *ctx, int np);      /* fb: the force goes to the (zeroed) record array instead of being added to fx, fy, fz */
 int ddcmi_launch_constraints(ddcmi_ctx *ctx, double dt, int location);   /* 0 FRONT, 1 BACK */
 int ddcmi_launch_mol_virial(ddcmi_ctx *ctx);
 int ddcmi_groups_localize(ddcmi_ctx *ctx);      /* rebuild: constraint groups / molecules named by gid -> device slots */

@@ -40,12 +40,12 @@ static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
    const NbLds v = lay(level, true);
    return (ctx->force_lvl || v.wgs > d.wgs) ? v : d;
 }
-/* may this context run lean steps (ddcmi_ctx::lean_pending)?  A single domain of FREE beads whose force is the pair kernel's alone */
+/* may this context run lean steps (ddcmi_ctx::lean_pending)?  A single domain whose step is the fused pair kernel (+ the bonded kernels in front of it) */
 static bool lean_capable(const ddcmi_ctx *ctx)
 {
    if (ctx->no_lean || ctx->nranks != 1 || ctx->loopback || ctx->group_ || ctx->updateRate <= 0 || ctx->nloc <= 0 || ctx->nloc > ctx->lean_max_beads) return false;
-   if ((ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) != 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0 || (ctx->excludePotentialTerm & 128) != 0) return false;
-   for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE) return false;
+   if (ctx->nrest != 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0 || (ctx->excludePotentialTerm & 128) != 0) return false;
+   for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE && ctx->gtype[g] != DDCMI_BERENDSEN) return false;      /* (Berendsen: host scalars from the temperature last published) */
    return true;
 }
 /* a single domain's periodic images are staged by the pair kernel from their owners (NbTileArgs::self_img): nothing reads the image records
@@ -123,16 +123,6 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
        * that systems with bonded terms take the fused step too (the lipid box paid a separate 54 us kick kernel and a force
        * store + re-read).  Both kinds of launch form the same sum, so the fused and the split step stay bit for bit alike, and both hand
        * the records back zeroed: no launch is ever spent on clearing them. */
-      if (has_bonded && n > 0)
-      {
-         if (halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }      /* bonded partners may be halo beads */
-         /* (the record array: all zero -- every pair launch hands back zeroed what it consumed; a grown array is cleared once) */
-         if (ctx->fb.cap < (size_t)ctx->npad) { if (ctx->fb.ensure(ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "bonded force records"); ctx->fb_zeroed = 0; }
-         if (ctx->fb_zeroed < ctx->fb.cap) { HIPCHK(ctx, hipMemsetAsync(ctx->fb.p, 0, ctx->fb.cap * sizeof(double4), st)); ctx->fb_zeroed = ctx->fb.cap; }
-         ctx->fb_zeroed = 0;      /* (until the pair launches below have consumed the records) */
-         int rcb = ddcmi_launch_bonded(ctx, ctx->fb.p);
-         if (rcb) return rcb;
-      }
       int ntile = ctx->ntile;
       bool useq = ctx->has_charge;
       bool packed = ctx->pack_type != 0;
@@ -147,6 +137,20 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
          const NbLds plain = nb_lds_layout(ctx, false);
          if (lay.zfix && lay.wgs >= plain.wgs && lay.wgs > 0) { fa = *fuse; fa.ke_off = lay.ke_off; }
          else { fuse->dt = 0.0; fuse = nullptr; lay = plain; }
+      }
+      /* lean (the caller could run this step lean): the fused launch, every tile in ONE launch, the images found at their owners */
+      const bool lean_now = lean && *lean && fuse != nullptr && ctx->ntile_class[1] <= 0 && (nh == 0 || self_images(ctx)) && ctx->lean_pending < LEAN_W &&
+                            ctx->lean_since < LEAN_W && (ctx->lean_since == 0 || ctx->lean_dt == fuse->dt);
+      if (lean) *lean = lean_now;
+      if (has_bonded && n > 0)
+      {
+         if (halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }      /* bonded partners may be halo beads */
+         /* (the record array: all zero -- every pair launch hands back zeroed what it consumed; a grown array is cleared once) */
+         if (ctx->fb.cap < (size_t)ctx->npad) { if (ctx->fb.ensure(ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "bonded force records"); ctx->fb_zeroed = 0; }
+         if (ctx->fb_zeroed < ctx->fb.cap) { HIPCHK(ctx, hipMemsetAsync(ctx->fb.p, 0, ctx->fb.cap * sizeof(double4), st)); ctx->fb_zeroed = ctx->fb.cap; }
+         ctx->fb_zeroed = 0;      /* (until the pair launches below have consumed the records) */
+         int rcb = ddcmi_launch_bonded(ctx, ctx->fb.p, lean_now ? ctx->lean_pending : -1);      /* (lean: the kernels' sums wait in the step's slot of the ring) */
+         if (rcb) return rcb;
       }
       /* fixed LDS layout ({x,y} at 0, z at NB_ZOFF) for neighbourhoods of up to NB_ZOFF/16 beads, which is every Martini system; else the run-time layout */
       const bool zfix = lay.zfix, lvl = lay.lvl;
@@ -170,12 +174,6 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       na.self_img = self_images(ctx) ? 1 : 0; na.vring_w = nullptr; na.vring_dt = ctx->lean_dt;
       na.vring = (na.disp && ctx->lean_since > 0) ? ctx->d_vring.p : nullptr; na.vring_n = ctx->lean_since;
       double *partials_p = ctx->partials.p;
-      if (lean && *lean)
-      {
-         /* lean: the fused launch, every tile in ONE launch, neighbourhoods on the index-free staging path */
-         *lean = fuse != nullptr && ctx->ntile_class[1] <= 0 && (nh == 0 || self_images(ctx)) && ctx->lean_pending < LEAN_W && ctx->lean_since < LEAN_W &&
-                 (ctx->lean_since == 0 || ctx->lean_dt == fuse->dt);
-      }
       if (lean && *lean)
       {
          const size_t stride = (size_t)(ctx->nitems + 8) * 8;
@@ -278,17 +276,19 @@ int ddcmi_lean_flush(ddcmi_ctx *ctx)
    if (!ctx->lean_tmp.p)
    {
       const size_t nt = (size_t)2 * LEAN_W * RED_SPLIT * 8 + 2 * LEAN_W;      /* rows, then the jobs' tickets (left at zero by their last workgroup) */
-      ENSURE(ctx, ctx->lean_tmp, nt); ENSURE(ctx, ctx->lean_hist, (size_t)16 * LEAN_W);
+      ENSURE(ctx, ctx->lean_tmp, nt); ENSURE(ctx, ctx->lean_hist, (size_t)LEAN_HW * LEAN_W);
+      HIPCHK(ctx, hipMemsetAsync(ctx->lean_hist.p, 0, (size_t)LEAN_HW * LEAN_W * sizeof(double), ctx->stream));
       HIPCHK(ctx, hipMemsetAsync(ctx->lean_tmp.p, 0, nt * sizeof(double), ctx->stream));
    }
    RedJob jf = {ctx->lean_part.p, ctx->nitems, 8, nullptr, 0, 0.0, nullptr};
    RedJob jk = {ctx->lean_kpart.p, ctx->nitems, 7, nullptr, 0, 0.0, nullptr};
    hipLaunchKernelGGL(k_reduce_hist, dim3(RED_SPLIT, 2 * np), dim3(1024), 0, ctx->stream, jf, jk, ctx->lean_stride, np, ctx->lean_hist.p, ctx->lean_tmp.p);
+   if ((ctx->nbond + ctx->nangle + ctx->ntors) > 0) { int rcb = ddcmi_lean_flush_bonded(ctx, np); if (rcb) return rcb; }
    ctx->lean_hist_n = np;
    return DDCMI_OK;
 }
-/* test entry point (ddcmi_test.h): the sums of the lean steps of the last flush, 16 per step: pair kernel {lj, ele, virial xx yy zz xy xz yz} as
- * the full list counts them (x 2), then {rk, tion xx yy zz xy xz yz}, 0 */
+/* test entry point (ddcmi_test.h): the sums of the lean steps of the last flush, LEAN_HW = 32 per step: pair kernel {lj, ele, virial xx yy zz xy xz yz} as
+ * the full list counts them (x 2), {rk, tion xx yy zz xy xz yz}, 0, the bonded kernels' {e_bond, e_angle, e_tors, e_impr, virial xx yy zz xy xz yz}, 0 ... */
 extern "C" int ddcmi_debug_lean_history(ddcmi_ctx *ctx, int *nsteps, double *sums)
 {
    if (!ctx || !nsteps || !sums) return DDCMI_EINVAL;
@@ -298,7 +298,7 @@ extern "C" int ddcmi_debug_lean_history(ddcmi_ctx *ctx, int *nsteps, double *sum
    *nsteps = ctx->lean_hist_n;
    if (ctx->lean_hist_n > 0)
    {
-      HIPCHK(ctx, hipMemcpyAsync(sums, ctx->lean_hist.p, (size_t)16 * ctx->lean_hist_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(sums, ctx->lean_hist.p, (size_t)LEAN_HW * ctx->lean_hist_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
    }
    return DDCMI_OK;
@@ -633,7 +633,7 @@ static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
       }
       fa.pos_new = ctx->pos2.p; fa.kpartials = ctx->kpartials.p;
       /* lean: a single domain of FREE beads with nothing but the pair kernel in its step */
-      bool lean = lean_capable(ctx) && fa.lam == 1.0;
+      bool lean = lean_capable(ctx);
       if ((rc = launch_forces(ctx, true, &fa, &lean))) return rc;
       if (fa.dt != 0.0 && lean)
       {

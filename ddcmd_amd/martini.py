@@ -444,9 +444,9 @@ class MartiniHIP(object):
         return dict(zip(E_NAMES, e.tolist())), v, rk.value, t
 
     def lean_history(self):
-        """(test_api) sums of the lean steps formed by the last batch launch: [nsteps, 16] = pair sums {lj, ele, vir6} as the full list counts
-        them (twice), kinetic sums {rk, tion6}, 0 -- include/ddcmi_test.h"""
-        out = np.zeros((32, 16))
+        """(test_api) sums of the lean steps formed by the last batch launch: [nsteps, 32] = pair sums {lj, ele, vir6} as the full list counts
+        them (twice), kinetic sums {rk, tion6}, 0, bonded sums {bond, angle, tors, impr, vir6}, zeros -- include/ddcmi_test.h"""
+        out = np.zeros((32, 32))
         nst = ctypes.c_int(0)
         self.lib.ddcmi_debug_lean_history.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), _dp]
         self._chk(self.lib.ddcmi_debug_lean_history(self.ctx, ctypes.byref(nst), _d(out)))

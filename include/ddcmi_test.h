@@ -42,9 +42,9 @@ int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nsteps);
 /* ddcmi_group_temperatures for an in-process group (sums over its domains) */
 int ddcmi_group_temperatures_all(ddcmi_ctx **ctxs, int n, double *Tgroup);
 /* the lean step (a single domain of FREE beads without bonded terms: one launch per step, the second stage of its energy / virial /
- * kinetic sums formed for all pending steps at once): the sums of the steps of the last such launch, 16 doubles per step --
- * {lj, ele, virial xx yy zz xy xz yz} as the full list counts them (twice), {rk, tion xx yy zz xy xz yz}, 0.  Forms what is pending first.
- * sums: room for 32 steps. */
+ * kinetic sums formed for all pending steps at once): the sums of the steps of the last such launch, 32 doubles per step --
+ * {lj, ele, virial xx yy zz xy xz yz} as the full list counts them (twice), {rk, tion xx yy zz xy xz yz}, 0, the bonded kernels'
+ * {e_bond, e_angle, e_tors, e_impr, virial xx yy zz xy xz yz}, zeros.  Forms what is pending first.  sums: room for 32 steps. */
 int ddcmi_debug_lean_history(ddcmi_ctx *ctx, int *nsteps, double *sums);
 /* the displacement bound of the shell-limited walk: the word the reduction launches add to, and the lean steps' words since the rebuild (largest |v|^2 of each; ring[32]) */
 int ddcmi_debug_disp(ddcmi_ctx *ctx, double *disp, float *ring, int *nring);

@@ -568,15 +568,15 @@ def test_two_berendsen_groups_with_different_factors_take_the_split_kernels():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["water", "water_open_z"])
+@pytest.mark.parametrize("case", ["water", "water_open_z", "lipid"])
 def test_images_staged_from_their_owners_equal_the_update_launch(case, monkeypatch):
     """A single domain's periodic images are chosen by cell (the two outermost layers), so that an image cell holds one owned cell's beads one
     for one and the pair kernel stages them from their owners by cell arithmetic -- no image update between rebuilds.  Against
     DDCMI_NO_SELF_IMAGES=1 (the image records refreshed by a launch before every force evaluation): forces, energies, virial and the state
-    after 45 steps across two rebuilds, bit for bit; water and water with an open axis (where the step can be lean: elsewhere the
-    reduction launch of every step refreshes the images on the side and the staging keeps its shorter path)."""
+    after 45 steps across two rebuilds, bit for bit; water, water with an open axis, the lipid deck (bonded terms, charges)."""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(13, temperature_K=310.0)
+    from ddcmd_amd.deck import load_deck
+    s = make_water_setup(13, temperature_K=310.0) if case != "lipid" else load_deck(LIPID_DECK)
     if case == "water_open_z":
         s.pbc = 3
     monkeypatch.setenv("DDCMI_NO_SELF_IMAGES", "1")
@@ -596,39 +596,46 @@ def test_images_staged_from_their_owners_equal_the_update_launch(case, monkeypat
     a.close(); b.close()
 
 
-def test_lean_steps_equal_steps_with_a_reduction_launch_each(monkeypatch):
-    """A single domain of FREE beads without bonded terms runs ONE launch per step between rebuilds (the pair kernel with the integrator's pass,
-    which stages the periodic images from their owners and keeps the displacement bound itself); the second stage of every step's energy /
-    virial / kinetic sums is formed later, all pending steps in one launch.  Against DDCMI_NO_LEAN_STEP=1 (a reduction + image launch after
-    every step): the state after 47 steps across two rebuilds bit for bit, and the sums of every lean step -- read back through the test
-    library -- equal to the energies, virial and kinetic terms the other run reports step by step."""
+@pytest.mark.parametrize("case", ["water", "lipid"])
+def test_lean_steps_equal_steps_with_a_reduction_launch_each(case, monkeypatch):
+    """A single domain whose step is the fused pair kernel (+ the bonded kernels in front of it) runs no other launch between rebuilds: the pair
+    kernel stages the periodic images from their owners and keeps the displacement bound itself; the second stage of every step's energy /
+    virial / kinetic sums -- and of the bonded kernels' sums -- is formed later, all pending steps in one launch each.  Against
+    DDCMI_NO_LEAN_STEP=1 (a reduction + image launch after every step): the state after 47 steps across rebuilds bit for bit, and the sums of
+    every lean step -- read back through the test library -- equal to the energies, virial and kinetic terms the other run reports step by
+    step.  Water, and the lipid deck (every bonded kind, charges, exclusions)."""
     from ddcmd_amd.martini import MartiniHIP
+    from ddcmd_amd.deck import load_deck
     import os
     if any(os.environ.get(k) for k in ("DDCMI_NO_LEAN_STEP", "DDCMI_NO_SELF_IMAGES", "DDCMI_NO_FUSED_STEP", "DDCMI_GRAPH_MAX_BEADS")):
         pytest.skip("the lean step is switched off in this environment")
-    s = make_water_setup(14, temperature_K=310.0)
+    s = make_water_setup(14, temperature_K=310.0) if case == "water" else load_deck(LIPID_DECK)
+    nlean = 15 if case == "water" else 7         # (the deck rebuilds every 10 steps: lean steps 1..7, the 8th of the call is split)
     monkeypatch.setenv("DDCMI_NO_LEAN_STEP", "1")
     a = MartiniHIP(s)
     monkeypatch.delenv("DDCMI_NO_LEAN_STEP")
     b = MartiniHIP(s, test_api=True)
     a.eval_forces(); b.eval_forces()
     per_step = []
-    for k in range(15):
+    for k in range(nlean):
         a.step(1)
         per_step.append(a.energies())
-    b.step(16)                                   # steps 1..15 fused (lean), step 16 split
+    b.step(nlean + 1)                            # steps 1..nlean fused (lean), the last one split
     h = b.lean_history()
-    assert len(h) == 15, len(h)
-    for k in range(15):
+    assert len(h) == nlean, len(h)
+    for k in range(nlean):
         e, vir, rk, tion = per_step[k]
         assert abs(0.5 * h[k, 0] - e["lj"]) <= 1e-12 * abs(e["lj"]), k
-        assert np.abs(0.5 * h[k, 2:8] - vir).max() <= 1e-12 * np.abs(vir).max(), k
+        assert np.abs(0.5 * h[k, 2:8] + h[k, 20:26] - vir).max() <= 1e-12 * np.abs(vir).max(), k
         assert abs(h[k, 8] - rk) <= 1e-12 * rk, k
         assert np.abs(h[k, 9:15] - tion).max() <= 1e-12 * np.abs(tion).max(), k
+        if case == "lipid":
+            for col, name in ((16, "bond"), (17, "angle"), (18, "tors"), (19, "impr")):
+                assert abs(h[k, col] - e[name]) <= 1e-12 * max(abs(e[name]), 1e-9), (k, name)
     a.step(1)
     ea, eb = a.energies(), b.energies()
     assert ea[0] == eb[0] and np.array_equal(ea[1], eb[1]) and ea[2] == eb[2]
-    a.step(31); b.step(31)                       # across the rebuilds at loops 20 and 40
+    a.step(31); b.step(31)                       # across the rebuilds
     da, db = a.download(), b.download()
     for k in ("r", "v", "f"):
         for c in range(3):
