@@ -482,6 +482,7 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
    ctx->no_lean = getenv("DDCMI_NO_LEAN_STEP") != nullptr;
    ctx->no_self_img = getenv("DDCMI_NO_SELF_IMAGES") != nullptr;
+   ctx->lean_bonded = getenv("DDCMI_LEAN_BONDED") != nullptr;
    if (const char *e = getenv("DDCMI_LEAN_MAX_BEADS")) ctx->lean_max_beads = atoi(e);
    ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
    ctx->no_direct_halo = getenv("DDCMI_NO_DIRECT_HALO") != nullptr;

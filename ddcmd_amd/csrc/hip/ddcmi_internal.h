@@ -221,7 +221,7 @@ struct ddcmi_ctx
     * the second stage of its energy / virial / kinetic sums waits in a ring of per-step rows (lean_part, lean_kpart: LEAN_W steps of
     * lean_stride doubles) and is formed for all pending steps by one launch (lean_flush -> lean_hist: 16 sums per step) at the next rebuild,
     * when the ring is full or when the host asks.  DDCMI_NO_LEAN_STEP=1: the reduction launch after every step, as before. */
-   int lean_pending = 0, lean_hist_n = 0, lean_since = 0 /* lean steps since the rebuild: the next one's word of the ring */; size_t lean_stride = 0; bool no_lean = false, no_self_img = false; double lean_dt = 0; int lean_max_beads = 2500000 /* DDCMI_LEAN_MAX_BEADS: beyond it the step's gain (-0.5 % at 4.24 M) is not worth 1 % of the pair kernel */;
+   int lean_pending = 0, lean_hist_n = 0, lean_since = 0 /* lean steps since the rebuild: the next one's word of the ring */; size_t lean_stride = 0; bool no_lean = false, no_self_img = false, lean_bonded = false; double lean_dt = 0; int lean_max_beads = 2500000 /* DDCMI_LEAN_MAX_BEADS: beyond it the step's gain (-0.5 % at 4.24 M) is not worth 1 % of the pair kernel */;
    dbuf<double> lean_part, lean_kpart, lean_hist, lean_tmp, lean_bpart; size_t lean_bstride = 0; int lean_bpstride = 0, lean_bnblk = 0;
    dbuf<unsigned> d_vring;             /* largest |v|^2 (float bits) of each lean step since the rebuild, one word per step at a stride of LEAN_VSTRIDE words: the step that
                                           is being written (atomic maxima of every workgroup) shares no cache line with the words the same launch reads */
