@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NB_BLOCK, WPE) void k_nonbond(GridParams gp, NbTile
          XY_s[0] = make_double2(1e30, 1e30); Z_s[0] = SHBIT ? 1e30 : z_with_tags<PACKED>(1e30, 0.0, false);
       }
       __syncthreads();
-      if (ta.disp && ta.vring)
+      if (ta.disp && ta.vring && !(ta.halo_full_walk && tshift))      /* (tiles that stage received beads walk their rows to the end) */
       {
          /* the displacement bound + the lean steps since the rebuild: their largest |v|^2, one word each, added up in the same order by every wave
           * (a single domain: no received beads, no hdisp) */

@@ -43,7 +43,7 @@ static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
 /* may this context run lean steps (ddcmi_ctx::lean_pending)?  A single domain whose step is the fused pair kernel (+ the bonded kernels in front of it) */
 static bool lean_capable(const ddcmi_ctx *ctx)
 {
-   if (ctx->no_lean || ctx->nranks != 1 || ctx->loopback || ctx->group_ || ctx->updateRate <= 0 || ctx->nloc <= 0 || ctx->nloc > ctx->lean_max_beads) return false;
+   if (ctx->no_lean || ctx->group_ || ctx->updateRate <= 0 || ctx->nloc <= 0 || ctx->nloc > ctx->lean_max_beads) return false;      /* (a decomposed rank: where its halo is staged from the receive buffer, launch_forces) */
    if (ctx->nrest != 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0 || (ctx->excludePotentialTerm & 128) != 0) return false;
    if ((ctx->nbond + ctx->nangle + ctx->ntors) > 0 && !ctx->lean_bonded) return false;      /* (the 2 M-bead bilayer: -0.9 % of the step for +2.3 % on its pair kernel: off unless DDCMI_LEAN_BONDED=1) */
    for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE && ctx->gtype[g] != DDCMI_BERENDSEN) return false;      /* (Berendsen: host scalars from the temperature last published) */
@@ -54,7 +54,7 @@ static bool lean_capable(const ddcmi_ctx *ctx)
  * them on the side and the staging keeps its shorter path (the bilayer: 4 us per pair kernel).  DDCMI_NO_SELF_IMAGES=1: never. */
 static bool self_images(const ddcmi_ctx *ctx)
 {
-   return !ctx->no_self_img && lean_capable(ctx) && ctx->nhalo > 0 && ctx->stage_cap + 2 < 4096;
+   return !ctx->no_self_img && ctx->nranks == 1 && !ctx->loopback && lean_capable(ctx) && ctx->nhalo > 0 && ctx->stage_cap + 2 < 4096;
 }
 static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */,
                          bool *lean = nullptr /* in: the caller could run this step lean (ddcmi_ctx::lean_pending); out: this launch did */)
@@ -140,7 +140,8 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
          else { fuse->dt = 0.0; fuse = nullptr; lay = plain; }
       }
       /* lean (the caller could run this step lean): the fused launch, every tile in ONE launch, the images found at their owners */
-      const bool lean_now = lean && *lean && fuse != nullptr && ctx->ntile_class[1] <= 0 && (nh == 0 || self_images(ctx)) && ctx->lean_pending < LEAN_W &&
+      /* (a decomposed rank: its next exchange packs its messages by a launch of its own, mg_pack3, instead of riding in the reduction launch) */
+      const bool lean_now = lean && *lean && fuse != nullptr && ctx->ntile_class[1] <= 0 && ((ctx->nranks > 1 || ctx->loopback) ? direct : (nh == 0 || self_images(ctx))) && ctx->lean_pending < LEAN_W &&
                             ctx->lean_since < LEAN_W && (ctx->lean_since == 0 || ctx->lean_dt == fuse->dt);
       if (lean) *lean = lean_now;
       if (has_bonded && n > 0)
