@@ -42,9 +42,10 @@ WINDOW = 20                    # timed steps come in windows of 20: one list reb
 MIN_TIMED_STEPS = 60           # at least three windows whatever --steps says (a 20-step region is one rebuild's luck)
 
 
-def cpu_baseline(n_lattice, seconds_budget=18.0):
+def cpu_baseline(n_lattice, seconds_budget=12.0, one_million=True):
     """Oracle (port of bioMartini.c/pairlist.c/nglf.c) on one core, bounded samples: the synthetic water
-    box at n_lattice (62.5k beads) and -- SURVEY 8(d) -- the reference's own 6173-bead examples/waterbox."""
+    box at n_lattice (26: 70 304 beads, BASELINE configs[1]), -- SURVEY 8(d) -- the reference's own 6173-bead examples/waterbox
+    and (one_million) one rebuild period of the 1.05 M-bead box of configs[2]."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     import ddcmd_amd
@@ -57,7 +58,7 @@ def cpu_baseline(n_lattice, seconds_budget=18.0):
     except Exception:
         libpath = None
 
-    def timed(s, budget):
+    def timed(s, budget, warm=True):
         period = max(int(s.updateRate), 1)
         o = pyoracle.Oracle(s, libpath)
         o.forces()
@@ -66,7 +67,10 @@ def cpu_baseline(n_lattice, seconds_budget=18.0):
         per = max(time.time() - t0, 1e-4)
         steps = int(max(period, min(10 * period, budget / per)))
         steps = (steps // period) * period   # whole rebuild periods
-        o.step(period)                       # warm-up incl. one rebuild
+        if warm:
+            o.step(period)                   # warm-up incl. one rebuild
+        else:
+            o.step(period - 1)               # (the big sample: up to the rebuild, so that the timed period holds exactly one)
         t0 = time.time()
         o.step(steps)
         return steps, time.time() - t0
@@ -85,6 +89,16 @@ def cpu_baseline(n_lattice, seconds_budget=18.0):
                         "sample": "the reference's examples/waterbox (%d beads, rcut 11 A, skin 4 A), %d NGLF steps" % (w.natoms, steps)}]
     except Exception as ex:      # the fixture is optional for the figure above
         out["also"] = [{"error": str(ex)}]
+    if one_million:
+        try:
+            big = ddcmd_amd.make_water_setup(64)
+            t0 = time.time()
+            steps, el = timed(big, 0.0, warm=False)      # exactly one rebuild period
+            out["also"].append({"value": big.natoms * steps / el, "unit": "atom-steps/s", "cores": 1,
+                                "sample": "%d-bead Martini water (n=64 lattice: BASELINE configs[2]), %d NGLF steps incl. 1 list rebuild, %.0f s of CPU work in all"
+                                          % (big.natoms, steps, time.time() - t0)})
+        except Exception as ex:
+            out["also"].append({"error": str(ex)})
     try:
         os.remove(native)
     except OSError:
@@ -212,6 +226,7 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
     s, wname, lattice, lattice_n = build_setup(workload, n, reps, types, cadence)
     dt_fs = float(ddcmd_amd.units_convert(s.dt, None, "fs"))
     grid = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+    preflight = None
     if grid is None:
         raise SystemExit("bench.py supports 1, 2, 4 or 8 GPUs (2x1x1, 2x2x1, 2x2x2 bricks)")
     if world == 1 and loopback:
@@ -220,6 +235,7 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
         buf = ctypes.create_string_buffer(128)
         assert m.lib.ddcmi_comm_unique_id(buf) == 0
         m.comm_init(0, 1, buf.raw, (1, 1, 1))
+        preflight = m.preflight(timeout=float(os.environ.get("DDCMI_PREFLIGHT_TIMEOUT", "60")))
         m.upload_local()
     elif world == 1:
         os.environ.pop("DDCMI_RCCL_LOOPBACK", None)
@@ -236,6 +252,17 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
             if rank == 0:
                 assert m.lib.ddcmi_comm_unique_id(buf) == 0
             m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)      # MPI_Bcast of the id in ddcMD
+        # the first real exchange of the launch is a CHECKED one, before any state goes up and before any timing: one grouped exchange
+        # of a known pattern with every peer of the brick plan, one 24-double all-reduce, one int all-gather (ddcmi_comm_preflight).
+        # A mismatch or the deadline ends the launch on every rank with the stage / peer / direction in the message (exit 4; a rerun
+        # over DDCMI_TRANSPORT=host is a NEW launch the caller starts: this process has touched the GPU and never re-execs)
+        from ddcmd_amd.martini import DdcmiError
+        try:
+            preflight = m.preflight(timeout=float(os.environ.get("DDCMI_PREFLIGHT_TIMEOUT", "60")))
+        except DdcmiError as ex:
+            sys.stderr.write("bench.py rank %d of %d: communicator preflight failed (%s transport): %s\n" % (rank, world, transport, ex))
+            sys.stderr.flush()
+            os._exit(4)
         m.upload_local()
     m.eval_forces()                       # firstEnergyCall (masters.c:579)
     # RCCL prints a version banner through C stdio at communicator creation; flush it now so that the JSON
@@ -287,7 +314,9 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
     if rdzv is not None or loopback:
         cs = m.comm_stats()
         comm = {"transport": cs["transport"], "rccl_version": cs["rccl_version"], "halo_beads_sent_per_step_rank0": cs["send_beads"],
-                "halo_messages_per_step_rank0": cs["send_msgs"]}
+                "halo_messages_per_step_rank0": cs["send_msgs"], "halo_bytes_per_step_rank0": cs["send_beads"] * 24,
+                "preflight_rank0": preflight,
+                "peers_rank0": [{"peer": pr, "send_bytes_per_step": 24 * sb, "recv_bytes_per_step": 24 * rb} for pr, sb, rb in m.comm_peers()]}
     if rdzv is not None:
         tot = m.allreduce([epot, ekin, float(nlocal), float(cs["send_beads"])])      # energyInfo.c allreduce()
         epot, ekin = float(tot[0]), float(tot[1])
@@ -413,7 +442,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lattice", dest="n", type=int, default=HEADLINE_N, help="FCC lattice edge: 4*n^3 beads (102 -> 4.24M: the headline; 100 -> 4.0M: rounds 1-4; 64 -> 1.05M, 25 -> 62.5k)")
-    ap.add_argument("--cpu-n", type=int, default=25, help="lattice edge of the CPU-baseline sample (25 -> 62.5k beads)")
+    ap.add_argument("--cpu-n", type=int, default=26, help="lattice edge of the CPU-baseline sample (26 -> 70 304 beads: BASELINE configs[1] '64k-bead water', the smallest FCC box with at least 64 000)")
+    ap.add_argument("--cpu-1m", type=int, default=1, help="1: also time the oracle on the 1.05 M-bead box of configs[2] for one rebuild period (SURVEY 8d: '1 M if time allows', ~20 s); 0: skip")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="N=1: only the headline workload, not the other single-GPU configs")
     ap.add_argument("--no-pmc", action="store_true", help="N=1 headline: do not measure the pair kernel's HBM bytes live (two short child runs under rocprofv3 --pmc)")
@@ -509,7 +539,7 @@ def main():
     res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback, args.types, args.cadence)
     out = {
         "metric": "atom_steps_per_sec", "value": res.pop("value"), "unit": "atom-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": res["steps_timed"], "steps_requested": args.steps, "warmup": args.warmup,
         "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
     }
@@ -520,16 +550,18 @@ def main():
         # the other single-GPU configurations, each timed like the headline (>= 100 steps): BASELINE configs[2] (1 M-bead water),
         # configs[4] (the ~2 M-bead lipid bilayer) and one rank's brick of the 8-GPU run of configs[3] through the RCCL loopback
         out["also"] = []
+        brick_reps = ",".join(str(max(1, int(x) // 2)) for x in args.reps.split(","))      # 12,12,6 -> 6,6,3: what one of 2x2x2 ranks owns
         under_prof = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
         for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps", pmc=["--lattice", "64"]),
                    dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen, at the reference decks' cadence (dt 20 fs, rebuild every 20 steps)", pmc=["--workload", "lipid", "--reps", args.reps]),
                    dict(workload="lipid", n=None, loopback=False, cadence="deck", tag="the same bilayer at the lipid deck's own cadence (dt 10 fs, rebuild every 10 steps): rounds 1-4's row", pmc=None),
-                   dict(workload="lipid", n=None, loopback=False, types=20, tag="the same bilayer under 20 LJ types (every type split into copies of itself): the class table of a mid-size Martini deck", pmc=None),
-                   dict(workload="lipid", n=None, loopback=False, types=40, tag="the same bilayer under 40 LJ types / 48 (type, charge) classes: the pair table in two levels (k_nonbond<LVL>)", pmc=None),
-                   dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=None),
+                   dict(workload="lipid", n=None, loopback=False, types=20, tag="the same bilayer under 20 LJ types (every type split into copies of itself): the class table of a mid-size Martini deck", pmc=["--workload", "lipid", "--reps", args.reps, "--types", "20"]),
+                   dict(workload="lipid", n=None, loopback=False, types=40, tag="the same bilayer under 40 LJ types / 48 (type, charge) classes: the pair table in two levels (k_nonbond<LVL>)", pmc=["--workload", "lipid", "--reps", args.reps, "--types", "40"]),
+                   dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=["--lattice", str(HEADLINE_N // 2), "--rccl-loopback"]),
+                   dict(workload="lipid", n=None, loopback=True, reps=brick_reps, tag="one rank's brick of the 8-GPU run of BASELINE configs[4] (the bilayer tiled %s: an eighth of %s), bonded terms by gid, Berendsen temperature all-reduced, periodic images through the RCCL loopback" % (brick_reps, args.reps), pmc=["--workload", "lipid", "--reps", brick_reps, "--rccl-loopback"]),
                    dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
             try:
-                r = run_config(kw["workload"], kw["n"], args.reps, 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0), kw.get("cadence", "reference"))
+                r = run_config(kw["workload"], kw["n"], kw.get("reps", args.reps), 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0), kw.get("cadence", "reference"))
                 if kw["pmc"] and not args.no_pmc and not under_prof:
                     # the row's own HBM bytes, measured live like the headline's
                     lt = live_traffic(kw["pmc"], r["roofline"].get("dominant_is_fused", False))
@@ -553,7 +585,7 @@ def main():
             out["roofline"].update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"], "traffic_FETCH_SIZE_KiB": lt["FETCH_SIZE_KiB"],
                                     "traffic_WRITE_SIZE_KiB": lt["WRITE_SIZE_KiB"], "hbm_frac_measured": lt["bytes_per_launch"] / t_k / 1e9 / HBM_PEAK_GBS})
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n)      # N=1 only (the contract): a bounded sample on one host core
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, one_million=bool(args.cpu_1m) and headline)      # N=1 only (the contract): bounded samples on one host core
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()

@@ -537,6 +537,11 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
                       &ctx->stage_idx, &ctx->tile_nstage, &ctx->tile_width, &ctx->tile_rows, &ctx->tile_work, &ctx->sched, &ctx->tile_perm};
    for (auto b : ib) b->release();
    ctx->d_lvltab.release(); ctx->d_lvlidx.release();
+   /* (audit of every dbuf member against this function, round 6: these were never released either) */
+   ctx->hkey.release(); ctx->lcg.release(); ctx->lcg2.release(); ctx->nbr_cum.release(); ctx->cg_atom_gid.release(); ctx->mol_atom_gid.release(); ctx->cg_slot.release(); ctx->mol_slot.release();
+   ctx->mol_mtot.release(); ctx->mol_info.release(); ctx->mol_red.release(); ctx->mol_split.release(); ctx->hs_idx.release(); ctx->dir_cnt.release(); ctx->send_map.release();
+   ctx->sendbuf.release(); ctx->hrecv3.release(); ctx->hrecv5.release(); ctx->mig_out.release(); ctx->mig_in.release(); ctx->keep.release(); ctx->cnt_xchg.release();
+   ctx->lean_part.release(); ctx->lean_kpart.release(); ctx->lean_hist.release(); ctx->lean_tmp.release(); ctx->lean_bpart.release(); ctx->d_vring.release();      /* (~80 MB per context at 1 M beads) */
    ctx->pos.release(); ctx->pos2.release(); ctx->d_ljtab.release(); ctx->gid.release(); ctx->gid2.release();
    ctx->d_exmask.release(); ctx->rest_gid.release(); ctx->rest_fc.release(); ctx->rest_slot.release(); ctx->rest_r0.release(); ctx->rest_kb.release(); ctx->pos0.release(); ctx->disp.release(); ctx->atom_gid.release(); ctx->hkeys.release();
    for (auto b : {&ctx->cg_dist, &ctx->inc_bpar, &ctx->inc_apar, &ctx->inc_tpar}) b->release();
@@ -1151,6 +1156,20 @@ extern "C" int ddcmi_comm_stats(const ddcmi_ctx *ctx, int64_t stats[8])
    stats[4] = v; stats[5] = ctx->comm ? (ctx->loopback ? 3 : 1) : ctx->hcomm ? 2 : 0;
    stats[6] = ctx->nranks; stats[7] = ctx->rank;
    return DDCMI_OK;
+}
+
+extern "C" int ddcmi_comm_peer_stats(const ddcmi_ctx *ctx, int cap, int *peer, int64_t *send_beads, int64_t *recv_beads)
+{
+   if (!ctx || cap < 0) return -1;
+   const HaloMsgs &ms = ctx->hmsg_s, &mr = ctx->hmsg_r;
+   if (!ctx->comm && !ctx->hcomm) return 0;
+   for (int k = 0; k < ms.n && k < cap; k++)
+   {
+      if (peer) peer[k] = ms.peer[k];
+      if (send_beads) send_beads[k] = ms.cnt[k];
+      if (recv_beads) { recv_beads[k] = 0; for (int q = 0; q < mr.n; q++) if (mr.peer[q] == ms.peer[k]) recv_beads[k] += mr.cnt[q]; }
+   }
+   return ms.n;
 }
 
 extern "C" int ddcmi_get_list(ddcmi_ctx *ctx, int which, int *start, int *j, int64_t *nentries)

@@ -777,6 +777,7 @@ static int mg_phase1_launch(ddcmi_ctx *ctx)
 /* in-process groups: the counts come to the host per context */
 static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
 {
+   bl_drop_interior(ctx);      /* (in-process groups enter the rebuild here: see ddcmi_build_list) */
    hipStream_t st = ctx->stream;
    int rc;
    for (;;)
@@ -1399,6 +1400,204 @@ extern "C" int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n)
       return DDCMI_OK;
    }
    return mg_allreduce_host_values(ctx, values, n);
+}
+/* ---- preflight: the first real multi-rank launch fails fast and legibly ------------------------------------
+ * ddcUpdate.c:56-85 / energyInfo.c:37 meet their peers for the first time inside the first step; a fabric that does not carry one
+ * of the seven links of a brick, a rank on the wrong device or a stale communicator id shows there as a hang.  This runs right
+ * behind ddcmi_comm_init, before any state is uploaded: (1) ONE grouped exchange of a known pattern along every direction the brick
+ * plan names -- the matching rule, peers and grouping of the per-step halo exchange and of the migration (mg_xchg_data), PF_N doubles
+ * per direction, verified element by element on the receiver --, (2) one 24-double sum all-reduce (energyInfo.c allreduce()) and
+ * (3) one all-gather of MG_BLK ints per rank (the rebuild's count round), each held against its closed form.  RCCL: everything is
+ * queued on the context's stream with an event behind each stage and the host polls under a deadline -- when it passes, the rank
+ * says which stage never finished and, for the exchange, from which peer ranks and directions nothing arrived (the receive buffer,
+ * pre-filled with a sentinel, is read back on a second stream), aborts its communicator and returns DDCMI_ECOMM.  Host transport:
+ * the rendezvous' own per-transfer timeouts name the peer.  The ranks then agree on the outcome (max of the error codes): a rank
+ * whose data was wrong reports what it saw, every other rank reports that a peer failed -- all return non-zero from the same call. */
+#define PF_N 512
+__global__ void k_pf_fill(int n, double *send, double *recv, int rank, int corrupt_code)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= 27 * n) return;
+   const int code = i / n, k = i % n;
+   send[i] = (double)(rank * 27 + code) * 4096.0 + (double)k + (code == corrupt_code && k == 7 ? 0.5 : 0.0);
+   recv[i] = -1.0;
+}
+static void pf_dir_name(int code, char *b, size_t nb) { snprintf(b, nb, "(%+d,%+d,%+d)", code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1); }
+extern "C" int ddcmi_comm_preflight(ddcmi_ctx *ctx, double timeout_s, int64_t report[16])
+{
+   if (!ctx) return DDCMI_EINVAL;
+   if (report) memset(report, 0, 16 * sizeof(int64_t));
+   if (!mg_transport(ctx)) SETERR(ctx, DDCMI_EINVAL, "ddcmi_comm_preflight: the context has no communicator (ddcmi_comm_init first)");
+   (void)hipSetDevice(ctx->device);
+   if (timeout_s <= 0.0) timeout_s = 60.0;
+   hipStream_t st = ctx->stream;
+   const int nr = std::max(ctx->nranks, 1);
+   const bool hooks = getenv("DDCMI_DEBUG_HOOKS") != nullptr;
+   const int corrupt = (hooks && getenv("DDCMI_DEBUG_PREFLIGHT_CORRUPT")) ? atoi(getenv("DDCMI_DEBUG_PREFLIGHT_CORRUPT")) : -1;      /* tests: this rank spoils its message along that direction */
+   const int corrupt_rank = (hooks && getenv("DDCMI_DEBUG_PREFLIGHT_CORRUPT_RANK")) ? atoi(getenv("DDCMI_DEBUG_PREFLIGHT_CORRUPT_RANK")) : 0;
+   const bool absent = hooks && getenv("DDCMI_DEBUG_PREFLIGHT_ABSENT") && atoi(getenv("DDCMI_DEBUG_PREFLIGHT_ABSENT")) == ctx->rank;      /* tests (host transport): this rank never joins the exchange */
+   struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+   auto elapsed = [&]() { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec); };
+   dbuf<double> buf;      /* [0, 27 PF_N) send, [27 PF_N, 54 PF_N) receive, then 24 + 24 doubles of the all-reduce */
+   dbuf<int> ibuf;        /* MG_BLK ints in, MG_BLK nr ints out */
+   int rc = DDCMI_OK;
+   std::string msg;
+   int soff[27], scnt[27], roff[27], rcnt[27], npeer = 0, peers[27], ndir = 0;
+   for (int c = 0; c < 27; c++)
+   {
+      soff[c] = roff[c] = c * PF_N;
+      scnt[c] = mg_remote(ctx, c) ? PF_N : 0;
+      rcnt[c] = mg_remote(ctx, mg_opp(c)) ? PF_N : 0;
+      if (scnt[c])
+      {
+         ndir++;
+         bool seen = false;
+         for (int k = 0; k < npeer; k++) seen |= peers[k] == ctx->dir_dest[c];
+         if (!seen) peers[npeer++] = ctx->dir_dest[c];
+      }
+   }
+   if (report) { report[0] = npeer; report[1] = ndir; report[2] = (int64_t)PF_N * sizeof(double); for (int k = 0; k < npeer && k < 8; k++) report[8 + k] = peers[k]; }
+   std::vector<double> h(27 * PF_N + 48);
+   std::vector<int> hi(MG_BLK * (size_t)nr + MG_BLK);
+   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+   hipStream_t side = nullptr;
+   int stage = 0;      /* stages verified */
+   do
+   {
+      if (buf.ensure(54 * PF_N + 64) || ibuf.ensure(MG_BLK * (size_t)(nr + 1) + 64)) { rc = DDCMI_ENOMEM; msg = "preflight buffers"; break; }
+      double *snd = buf.p, *rcv = buf.p + 27 * PF_N, *ar = buf.p + 54 * PF_N;
+      hipLaunchKernelGGL(k_pf_fill, dim3(cdiv(27 * PF_N, 256)), dim3(256), 0, st, PF_N, snd, rcv, ctx->rank, ctx->rank == corrupt_rank ? corrupt : -1);
+      for (int k = 0; k < 24; k++) h[k] = (double)(ctx->rank + 1) * (double)(k + 1);
+      for (int k = 0; k < MG_BLK; k++) hi[k] = ctx->rank * 1000 + k;
+      if (hipMemcpyAsync(ar, h.data(), 24 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(ibuf.p, hi.data(), MG_BLK * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { rc = DDCMI_ENODEVICE; msg = "preflight upload"; break; }
+      if (ctx->hcomm)
+      {
+         /* host transport: blocking transfers with the rendezvous' own deadlines and messages */
+         if (!absent && (rc = mg_xchg_data(ctx, snd, soff, scnt, 0, rcv, roff, rcnt, 1)) != DDCMI_OK) { msg = "preflight: the grouped exchange with the brick's peers failed: " + ctx->err; break; }
+         if (absent)
+         {
+            /* a rank that is stuck: its peers run into the rendezvous' deadline and name it; then it leaves for good */
+            struct timespec ts = {(time_t)timeout_s + 1, 0}; nanosleep(&ts, nullptr);
+            ctx->err = "preflight: this rank stayed away from the exchange (DDCMI_DEBUG_PREFLIGHT_ABSENT)";
+            buf.release(); ibuf.release();
+            return mg_fatal(ctx, DDCMI_ECOMM, nullptr);
+         }
+         if (hipMemcpyAsync(h.data(), ar, 24 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = DDCMI_ENODEVICE; msg = "preflight download"; break; }
+         if (ddcmi_rdzv_allreduce_f64(ctx->hcomm, h.data(), 24, 0) != DDCMI_OK) { rc = DDCMI_ECOMM; msg = std::string("preflight: the 24-double all-reduce failed: ") + ddcmi_rdzv_last_error(ctx->hcomm); break; }
+         memcpy(h.data() + 27 * PF_N, h.data(), 24 * sizeof(double));
+         if (ddcmi_rdzv_allgather(ctx->hcomm, hi.data(), hi.data() + MG_BLK, MG_BLK * sizeof(int)) != DDCMI_OK) { rc = DDCMI_ECOMM; msg = std::string("preflight: the count all-gather failed: ") + ddcmi_rdzv_last_error(ctx->hcomm); break; }
+         if (hipMemcpyAsync(h.data(), rcv, 27 * PF_N * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = DDCMI_ENODEVICE; msg = "preflight download"; break; }
+      }
+      else
+      {
+         ncclComm_t comm = (ncclComm_t)ctx->comm;
+         bool evok = true;
+         for (int k = 0; k < 3; k++) evok &= hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+         if (!evok || hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { rc = DDCMI_ENODEVICE; msg = "preflight events"; break; }
+         if ((rc = mg_xchg_data(ctx, snd, soff, scnt, 0, rcv, roff, rcnt, 1)) != DDCMI_OK) { msg = "preflight: queueing the grouped exchange failed: " + ctx->err; break; }
+         (void)hipEventRecord(ev[0], st);
+         if (ncclAllReduce(ar, ar + 24, 24, ncclDouble, ncclSum, comm, st) != ncclSuccess) { rc = DDCMI_ECOMM; msg = "preflight: ncclAllReduce could not be queued"; break; }
+         (void)hipEventRecord(ev[1], st);
+         if (ncclAllGather(ibuf.p, ibuf.p + MG_BLK, MG_BLK, ncclInt, comm, st) != ncclSuccess) { rc = DDCMI_ECOMM; msg = "preflight: ncclAllGather could not be queued"; break; }
+         (void)hipEventRecord(ev[2], st);
+         bool done = false;
+         while (!done)
+         {
+            const hipError_t q = hipEventQuery(ev[2]);
+            if (q == hipSuccess) { done = true; break; }
+            if (q != hipErrorNotReady) { rc = DDCMI_ENODEVICE; msg = std::string("preflight: the stream failed: ") + hipGetErrorString(q); break; }
+            if (elapsed() > timeout_s) break;
+            struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr);
+         }
+         if (rc) break;
+         if (!done)
+         {
+            /* which stage never finished; for the exchange, whose data never came (the receive buffer through a second stream: the first one is stuck) */
+            const int reached = hipEventQuery(ev[0]) != hipSuccess ? 0 : hipEventQuery(ev[1]) != hipSuccess ? 1 : 2;
+            char b[1024];
+            int o = snprintf(b, sizeof(b), "preflight: rank %d of %d: no completion within %.0f s, stuck in %s", ctx->rank, nr, timeout_s,
+                             reached == 0 ? "the grouped send/recv with the brick's peers" : reached == 1 ? "the 24-double all-reduce" : "the count all-gather");
+            if (reached == 0 && hipMemcpyAsync(h.data(), rcv, 27 * PF_N * sizeof(double), hipMemcpyDeviceToHost, side) == hipSuccess && hipStreamSynchronize(side) == hipSuccess)
+            {
+               o += snprintf(b + o, sizeof(b) - o, "; nothing arrived from");
+               for (int c = 0; c < 27 && o < (int)sizeof(b) - 64; c++)
+                  if (rcnt[c] && h[(size_t)c * PF_N + PF_N - 1] == -1.0)
+                  {
+                     char d[32]; pf_dir_name(mg_opp(c), d, sizeof(d));
+                     o += snprintf(b + o, sizeof(b) - o, " rank %d (my direction %s)", ctx->dir_dest[mg_opp(c)], d);
+                     if (report && report[3] == 0) { report[3] = 1; report[4] = ctx->dir_dest[mg_opp(c)]; report[5] = mg_opp(c); }
+                  }
+            }
+            msg = b;
+            rc = mg_fatal(ctx, DDCMI_ECOMM, nullptr);      /* (releases the kernels that wait for the peer) */
+            if (report) { report[6] = reached; report[7] = (int64_t)(elapsed() * 1e6); }
+            /* no agreement round: the fabric has just shown that it does not answer */
+            for (int k = 0; k < 3; k++) if (ev[k]) (void)hipEventDestroy(ev[k]);
+            if (side) (void)hipStreamDestroy(side);
+            ctx->err = msg;
+            return rc;
+         }
+         if (hipMemcpyAsync(h.data(), rcv, 27 * PF_N * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipMemcpyAsync(h.data() + 27 * PF_N, ar + 24, 24 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipMemcpyAsync(hi.data() + MG_BLK, ibuf.p + MG_BLK, MG_BLK * (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipStreamSynchronize(st) != hipSuccess) { rc = DDCMI_ENODEVICE; msg = "preflight download"; break; }
+      }
+      /* (1) every direction's message, element by element */
+      for (int c = 0; c < 27 && !rc; c++)
+      {
+         if (!rcnt[c]) continue;
+         const int src = ctx->dir_dest[mg_opp(c)];
+         for (int k = 0; k < PF_N; k++)
+         {
+            const double want = (double)(src * 27 + c) * 4096.0 + (double)k, got = h[(size_t)c * PF_N + k];
+            if (got != want)
+            {
+               char d[32], b[512]; pf_dir_name(mg_opp(c), d, sizeof(d));
+               snprintf(b, sizeof(b), "preflight: rank %d of %d: the message from rank %d (my direction %s, its direction code %d) is wrong at element %d of %d: got %.17g, expected %.17g",
+                        ctx->rank, nr, src, d, c, k, PF_N, got, want);
+               msg = b; rc = DDCMI_ECOMM;
+               if (report) { report[3] = 1; report[4] = src; report[5] = mg_opp(c); }
+               break;
+            }
+         }
+      }
+      if (rc) break;
+      stage = 1;
+      /* (2) sum over ranks of (r + 1)(k + 1) */
+      for (int k = 0; k < 24; k++)
+      {
+         const double want = 0.5 * (double)nr * (double)(nr + 1) * (double)(k + 1), got = h[27 * PF_N + k];
+         if (got != want)
+         {
+            char b[256]; snprintf(b, sizeof(b), "preflight: rank %d of %d: the 24-double all-reduce gave %.17g at element %d, expected %.17g", ctx->rank, nr, got, k, want);
+            msg = b; rc = DDCMI_ECOMM; break;
+         }
+      }
+      if (rc) break;
+      stage = 2;
+      /* (3) every rank's block of the all-gather */
+      for (int r = 0; r < nr && !rc; r++)
+         for (int k = 0; k < MG_BLK; k++)
+            if (hi[MG_BLK + (size_t)MG_BLK * r + k] != r * 1000 + k)
+            {
+               char b[256]; snprintf(b, sizeof(b), "preflight: rank %d of %d: the all-gather holds %d at word %d of rank %d's block, expected %d", ctx->rank, nr, hi[MG_BLK + (size_t)MG_BLK * r + k], k, r, r * 1000 + k);
+               msg = b; rc = DDCMI_ECOMM; break;
+            }
+      if (rc) break;
+      stage = 3;
+   } while (0);
+   for (int k = 0; k < 3; k++) if (ev[k]) (void)hipEventDestroy(ev[k]);
+   if (side) (void)hipStreamDestroy(side);
+   buf.release(); ibuf.release();
+   if (report) { report[6] = stage; report[7] = (int64_t)(elapsed() * 1e6); }
+   if (rc) ctx->err = msg;
+   /* every rank leaves with the same verdict (a transport error above has usually ended the agreement's transport too: then its own error stands) */
+   if (rc == DDCMI_ECOMM && ctx->hcomm && msg.find("failed:") != std::string::npos) return rc;
+   const int arc = mg_agree(ctx, rc);
+   if (rc) { ctx->err = msg; return rc; }
+   if (arc) { ctx->err = "preflight: another rank's check of the communicator failed (its own message says which peer and direction): " + ctx->err; return arc; }
+   return DDCMI_OK;
 }
 void ddcmi_comm_destroy(ddcmi_ctx *ctx)
 {

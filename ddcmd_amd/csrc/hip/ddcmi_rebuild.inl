@@ -189,9 +189,14 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx)
 static int bl_launch_interior(ddcmi_ctx *ctx);
 static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused);
 int ddcmi_lean_flush(ddcmi_ctx *ctx);
+static void bl_drop_interior(ddcmi_ctx *ctx);
 extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
 {
    if (!ctx) return DDCMI_EINVAL;
+   /* an interior search a failed rebuild left in flight on the second stream (an error between bl_launch_interior and ddcmi_bl_finish: the
+    * self-image count, the halo sort, a post, a phase of the decomposed path) must not meet this rebuild's sort, which rewrites the
+    * positions and cell tables it reads and zeroes the counters it adds to */
+   bl_drop_interior(ctx);
    { int rcl = ddcmi_lean_flush(ctx); if (rcl) return rcl; }      /* (the pending steps' rows are as many as this list's work items) */
    if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate < 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");

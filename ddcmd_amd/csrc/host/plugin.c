@@ -73,12 +73,23 @@ static void parallel_init(const ddcmi_setup *s)
    const char *tr = getenv("DDCMI_TRANSPORT");
    par.host_transport = tr && strcmp(tr, "host") == 0;
 }
+/* the first real exchange of a launch is a checked one (ddcmi_comm_preflight): a fabric that does not carry one of the brick's links, a
+ * rank on the wrong device or a stale id ends the launch here, on every rank, with the stage / peer / direction in the message --
+ * not as a hang inside the first step's ddcUpdate (ddcUpdate.c:56-85) */
+static void parallel_preflight(ddcmi_ctx *ctx)
+{
+   int64_t rep[16];
+   if (ddcmi_comm_preflight(ctx, (double)env_int("DDCMI_PREFLIGHT_TIMEOUT", 60), rep) != DDCMI_OK) die("ddcmi_comm_preflight", ddcmi_last_error(ctx));
+   if (par.rank == 0 && getenv("DDCMI_VERBOSE"))
+      fprintf(stderr, "ddcmi_md: communicator preflight ok: %d peers, %d directions x %d bytes, all-reduce, all-gather in %.1f ms\n", (int)rep[0], (int)rep[1], (int)rep[2], rep[7] * 1e-3);
+}
 static void parallel_comm_init(ddcmi_ctx *ctx)
 {
    if (par.world <= 1) return;
    if (par.host_transport)
    {
       if (ddcmi_comm_init_host(ctx, par.rdzv, par.grid[0], par.grid[1], par.grid[2]) != DDCMI_OK) die("ddcmi_comm_init_host", ddcmi_last_error(ctx));
+      parallel_preflight(ctx);
       return;
    }
    char id[128];
@@ -86,6 +97,7 @@ static void parallel_comm_init(ddcmi_ctx *ctx)
    if (par.rank == 0 && ddcmi_comm_unique_id(id) != DDCMI_OK) die("ddcmi_comm_unique_id", ddcmi_last_error(ctx));
    if (ddcmi_rdzv_bcast(par.rdzv, id, sizeof(id), 0) != DDCMI_OK) die("parallel_comm_init", ddcmi_rdzv_last_error(par.rdzv));      /* MPI_Bcast of the RCCL id */
    if (ddcmi_comm_init(ctx, par.rank, par.world, id, par.grid[0], par.grid[1], par.grid[2]) != DDCMI_OK) die("ddcmi_comm_init", ddcmi_last_error(ctx));
+   parallel_preflight(ctx);
 }
 /* owner of a bead in the px x py x pz brick decomposition of a box centred on the origin (domain.c:191-208 for a cubic
  * lattice of domain centres) */

@@ -559,6 +559,15 @@ class MartiniHIP(object):
                 "rccl_version": "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v else None,
                 "transport": ("none", "rccl", "host", "rccl-loopback")[int(st[5])], "ranks": int(st[6]), "rank": int(st[7])}
 
+    def comm_peers(self):
+        """[(peer rank, beads sent per step, beads received per step)] of the per-step halo exchange as laid out at the last rebuild"""
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        self.lib.ddcmi_comm_peer_stats.argtypes = [ctypes.c_void_p, ctypes.c_int, _ip, i64p, i64p]
+        peer = np.zeros(27, np.int32)
+        sb, rb = np.zeros(27, np.int64), np.zeros(27, np.int64)
+        n = int(self.lib.ddcmi_comm_peer_stats(self.ctx, 27, _i(peer), sb.ctypes.data_as(i64p), rb.ctypes.data_as(i64p)))
+        return [(int(peer[k]), int(sb[k]), int(rb[k])) for k in range(max(n, 0))]
+
     def get_list(self, which=0):
         n = self.n
         tot = ctypes.c_int64(0)
@@ -681,6 +690,21 @@ class MartiniRank(MartiniHIP, DomainMixin):
         """decomposition over the host transport (TCP streams of the rendezvous) instead of RCCL"""
         self._rdzv = rdzv      # must outlive the context
         self._chk(self.lib.ddcmi_comm_init_host(self.ctx, rdzv.h, grid[0], grid[1], grid[2]))
+
+    def preflight(self, timeout=60.0):
+        """ddcmi_comm_preflight: one grouped exchange of a known pattern with every peer of the brick plan, one 24-double all-reduce,
+        one int all-gather, verified; raises DdcmiError naming the stage / peer / direction.  Returns the report as a dict."""
+        self.lib.ddcmi_comm_preflight.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_int64)]
+        rep = (ctypes.c_int64 * 16)()
+        rc = self.lib.ddcmi_comm_preflight(self.ctx, float(timeout), rep)
+        out = {"peers": [int(rep[8 + k]) for k in range(min(int(rep[0]), 8))], "directions": int(rep[1]), "bytes_per_direction": int(rep[2]),
+               "stages_verified": int(rep[6]), "elapsed_us": int(rep[7])}
+        if rep[3]:
+            out.update(failed_peer=int(rep[4]), failed_direction_code=int(rep[5]))
+        self.preflight_report = out
+        if rc != 0:
+            raise DdcmiError("ddcmi error %d: %s" % (rc, self.lib.ddcmi_last_error(self.ctx).decode()))
+        return out
 
     def allreduce(self, values):
         v = np.ascontiguousarray(values, dtype=np.float64)

@@ -236,6 +236,9 @@ int ddcmi_list_stats(const ddcmi_ctx *ctx, int64_t stats[8]);
  * stats[0]=beads this rank sends per step, [1]=beads it receives, [2]/[3]=messages sent/received (one per peer),
  * [4]=RCCL version code (ncclGetVersion), [5]=transport (0 none, 1 RCCL, 2 host-staged TCP, 3 RCCL loopback), [6]=ranks, [7]=rank */
 int ddcmi_comm_stats(const ddcmi_ctx *ctx, int64_t stats[8]);
+/* the same exchange peer by peer: returns the number of peers (one message each way per step) and fills up to cap of them --
+ * peer rank, beads sent to it and received from it per step (x 24 B on the wire; 2x2x2 bricks: seven peers over seven xGMI links) */
+int ddcmi_comm_peer_stats(const ddcmi_ctx *ctx, int cap, int *peer, int64_t *send_beads, int64_t *recv_beads);
 /* Copy the full neighbour list out as CSR over caller-order indices (image atoms
  * are mapped back to their source atom). start[nlocal+1]; j may be NULL to query
  * the size (returned through *nentries).  which: 0 kept, 1 excluded. [sync] */
@@ -260,6 +263,15 @@ int ddcmi_comm_unique_id(char id[128]);
 int ddcmi_comm_init(ddcmi_ctx *ctx, int rank, int nranks, const char id[128], int px, int py, int pz);
 /* energyInfo.c:9-63 allreduce(): sum the 24-double ETYPE block across ranks */
 int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n);
+/* Preflight of a fresh communicator (RCCL or host transport), right behind ddcmi_comm_init[_host] and before any timing: ONE grouped
+ * exchange of a known pattern along every direction the brick plan names (the peers, matching and grouping of ddcUpdate's halo
+ * exchange, ddcUpdate.c:56-85 / ddcSendRecv.c:126-225), one 24-double sum all-reduce (energyInfo.c:37) and one int all-gather (the
+ * rebuild's count round), each verified on the receiver.  Collective.  On a mismatch, or when timeout_s (<= 0: 60 s) passes without
+ * completion, the call returns DDCMI_ECOMM on EVERY rank and ddcmi_last_error says which stage, peer rank and direction failed;
+ * after a timeout the RCCL communicator has been aborted (start a fresh process for another transport).
+ * report (may be NULL): [0] distinct peer ranks, [1] directions exchanged, [2] bytes per direction message, [3] 1 if a peer was
+ * named, [4] that peer, [5] its direction code, [6] stages verified (3 = all), [7] elapsed microseconds, [8..15] the peer ranks. [sync] */
+int ddcmi_comm_preflight(ddcmi_ctx *ctx, double timeout_s, int64_t report[16]);
 /* ---- process rendezvous without MPI (host/rdzv.c) ----------------------------
  * ddcMD takes rank, size, MPI_Bcast, MPI_Barrier and MPI_Allreduce from its MPI launcher
  * (ddcMD.c:93-139; energyInfo.c:9-63).  A one-process-per-GPU launch without MPI hands each

@@ -16,10 +16,10 @@ def main():
     grid = tuple(int(x) for x in gridtxt.split("x"))
     import ddcmd_amd
     from ddcmd_amd.martini import MartiniRank, Rendezvous, domain_of, _declare_domains
-    rdzv = Rendezvous.from_env(timeout=120.0)
+    rdzv = Rendezvous.from_env(timeout=float(os.environ.get("DDCMI_TEST_RDZV_TIMEOUT", "120")))
     rank, world = rdzv.rank, rdzv.world
     cons = False
-    if workload in ("water", "water_fault"):
+    if workload in ("water", "water_fault", "water_preflight"):
         s = ddcmd_amd.make_water_setup(12)
     else:
         from ddcmd_amd.deck import load_deck, units_convert
@@ -48,6 +48,16 @@ def main():
         if rank == 0:
             assert m.lib.ddcmi_comm_unique_id(buf) == 0
         m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)
+    if workload == "water_preflight":
+        # the communicator's preflight (ddcmi_comm_preflight) between real processes; fault hooks come in through the environment
+        from ddcmd_amd.martini import DdcmiError
+        try:
+            rep = m.preflight(timeout=float(os.environ.get("DDCMI_TEST_PREFLIGHT_TIMEOUT", "20")))
+        except DdcmiError as ex:
+            sys.stderr.write("PREFLIGHT rank %d: %s\n" % (rank, ex))
+            sys.exit(4)
+        sys.stderr.write("PREFLIGHT-OK rank %d: %r\n" % (rank, rep))
+        sys.exit(0)
     m.upload_local()
     n0 = m.n
     rec = {}

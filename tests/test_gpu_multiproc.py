@@ -75,6 +75,59 @@ def test_a_failing_rank_ends_the_rebuild_on_every_rank():
             assert len({re.search(r"beads of rank (\d)", e).group(1) for e in errs}) == 1      # and they name the same rank
 
 
+def _preflight_ranks(grid, extra_env, timeout=120):
+    world = grid[0] * grid[1] * grid[2]
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ)
+            env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1",
+                        "DDCMI_RDZV_FILE": os.path.join(d, "port"), "DDCMI_TRANSPORT": "host"})
+            env.pop("DDCMI_RCCL_LOOPBACK", None)
+            env.update(extra_env)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), "water_preflight", "%dx%dx%d" % grid, d, "0", "1"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=timeout) for p in procs]
+        return [p.returncode for p in procs], [o[1] for o in outs]
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 2)])
+def test_preflight_between_real_processes(grid):
+    """ddcmi_comm_preflight over the host transport between real processes -- one grouped exchange with every peer the
+    brick plan names (2x2x2: seven distinct peers, 26 directions), the 24-double all-reduce, the count all-gather, all verified"""
+    rcs, errs = _preflight_ranks(grid, {})
+    assert rcs == [0] * len(rcs), errs
+    world = len(rcs)
+    for e in errs:
+        assert "PREFLIGHT-OK" in e and "'stages_verified': 3" in e, e
+        if world == 2:          # only the directions with dx != 0 leave the rank: 18 of 26, all to the one neighbour
+            assert "'directions': 18" in e and ("'peers': [1]" in e or "'peers': [0]" in e), e
+        else:
+            import re
+            assert "'directions': 26" in e and len(re.search(r"'peers': \[([^\]]*)\]", e).group(1).split(",")) == 7, e
+
+
+def test_preflight_names_the_peer_and_direction_of_a_wrong_message():
+    """fault injection: rank 1 spoils the message it sends along its direction code 14 = (+1, 0, 0); its +x neighbour (rank 0 on the
+    periodic 2x1x1 grid) must say from whom and along which direction the data is wrong, and EVERY rank must leave non-zero"""
+    rcs, errs = _preflight_ranks((2, 1, 1), {"DDCMI_DEBUG_HOOKS": "1", "DDCMI_DEBUG_PREFLIGHT_CORRUPT": "14", "DDCMI_DEBUG_PREFLIGHT_CORRUPT_RANK": "1"})
+    assert rcs == [4, 4], (rcs, errs)
+    assert "the message from rank 1" in errs[0] and "my direction (-1,+0,+0)" in errs[0] and "wrong at element 7" in errs[0], errs[0]
+    assert "another rank's check of the communicator failed" in errs[1], errs[1]
+
+
+def test_preflight_ends_with_a_deadline_when_a_rank_stays_away():
+    """fault injection: rank 1 never joins the exchange; rank 0 must give up at the transport's deadline (3 s here) naming rank 1, not hang"""
+    import time
+    t0 = time.time()
+    rcs, errs = _preflight_ranks((2, 1, 1), {"DDCMI_DEBUG_HOOKS": "1", "DDCMI_DEBUG_PREFLIGHT_ABSENT": "1", "DDCMI_TEST_RDZV_TIMEOUT": "3",
+                                              "DDCMI_TEST_PREFLIGHT_TIMEOUT": "3"})
+    assert time.time() - t0 < 60
+    assert rcs == [4, 4], (rcs, errs)
+    assert "from rank 1 failed (timeout)" in errs[0] and "grouped exchange with the brick's peers failed" in errs[0], errs[0]
+    assert "stayed away" in errs[1], errs[1]
+
+
 def _merge(recs, key_gid, key):
     gid = np.concatenate([r[key_gid] for r in recs])
     order = np.argsort(gid, kind="stable")

@@ -185,10 +185,11 @@ def test_synthetic_water_25_steps_with_rebuild():
 
 
 def test_water_64k_forces_and_energies_every_step():
-    """BASELINE configs[1]: the 64k-bead class water box (62.5k beads, rcut 12 A, skin 4 A), forces, energies,
-    kinetic energy and virial diffed against the CPU oracle after EVERY step, across the rebuild at step 20"""
+    """BASELINE configs[1]: the 64k-bead water box (FCC n = 26: 70 304 beads, the smallest lattice with at least 64 000; rcut 12 A,
+    skin 4 A), forces, energies, kinetic energy and virial diffed against the CPU oracle after EVERY step, across the rebuild at step 20"""
     from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(25)
+    s = make_water_setup(26)
+    assert s.natoms >= 64000
     o = pyoracle.Oracle(s)
     o.forces()
     m = MartiniHIP(s)
@@ -1045,3 +1046,49 @@ def test_blown_up_run_is_reported_as_such():
     with pytest.raises(DdcmiError, match="unstable"):
         m.step(200, dt=400.0 * s.dt)
     m.close()
+
+
+def _free_device_bytes():
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+@pytest.mark.parametrize("kind", ["water", "lipid_loopback"])
+def test_create_step_destroy_returns_the_device_memory(kind, monkeypatch):
+    """ddcmi_destroy left the lean step's rings (two x (items + 8) x 8 x 32 doubles: ~40 MB per context at 1 M beads), the
+    displacement ring and -- found by an audit of every device buffer of the context against ddcmi_destroy -- 22 more (the decomposed
+    path's send / receive / migration buffers, LCG64 records, nbr_cum ...) allocated.  Create / 45 steps / destroy in a loop: the free
+    device memory after the sixth context is what it was after the second (the first ones warm the runtime's own pools)."""
+    import ctypes
+    import os
+    from ddcmd_amd.martini import MartiniHIP, MartiniRank
+    if kind == "water":
+        s = make_water_setup(40)          # 256 k beads: the lean step's rings alone are 10 MB
+        make = lambda: MartiniHIP(s)
+    else:
+        from ddcmd_amd.deck import load_deck
+        from ddcmd_amd.synth import replicate_setup
+        deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+        s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), (3, 3, 2))
+        monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
+
+        def make():
+            m = MartiniRank(s, np.arange(s.natoms))
+            buf = ctypes.create_string_buffer(128)
+            assert m.lib.ddcmi_comm_unique_id(buf) == 0
+            m.comm_init(0, 1, buf.raw, (1, 1, 1))
+            m.upload_local()
+            return m
+    free = []
+    for it in range(6):
+        m = make()
+        m.eval_forces()
+        m.group_temperatures()
+        m.step(45)
+        m.energies()
+        m.close()
+        free.append(_free_device_bytes())
+    assert abs(free[5] - free[1]) < (4 << 20), [f >> 20 for f in free]

@@ -30,6 +30,40 @@ def _loopback_rank(s, monkeypatch, overlap=False):
     return m
 
 
+def test_preflight_through_rccl_loopback(monkeypatch):
+    """ddcmi_comm_preflight over RCCL itself -- the grouped ncclSend/ncclRecv along all 26 directions (to the one rank
+    there is), ncclAllReduce of 24 doubles, ncclAllGather of the count block, queued with an event behind each stage and polled under
+    a deadline -- and its fault injection: a spoiled message is named with its sender and direction"""
+    from ddcmd_amd.martini import MartiniRank, DdcmiError
+    s = make_water_setup(8)
+    monkeypatch.setenv("DDCMI_RCCL_LOOPBACK", "1")
+    for corrupt in (None, 22):
+        if corrupt is not None:
+            monkeypatch.setenv("DDCMI_DEBUG_HOOKS", "1")
+            monkeypatch.setenv("DDCMI_DEBUG_PREFLIGHT_CORRUPT", str(corrupt))
+        m = MartiniRank(s, np.arange(s.natoms))
+        buf = ctypes.create_string_buffer(128)
+        assert m.lib.ddcmi_comm_unique_id(buf) == 0
+        m.comm_init(0, 1, buf.raw, (1, 1, 1))
+        if corrupt is None:
+            rep = m.preflight(timeout=30.0)
+            assert rep["stages_verified"] == 3 and rep["directions"] == 26 and rep["peers"] == [0] and rep["bytes_per_direction"] == 4096
+            assert m.comm_stats()["transport"] == "rccl-loopback"
+            # the communicator is as good as new: the run goes on
+            m.upload_local()
+            m.eval_forces()
+            m.step(3)
+        else:
+            with pytest.raises(DdcmiError) as ei:
+                m.preflight(timeout=30.0)
+            # code 22 = (0, 0, +1): received in slot 22 from the rank in my direction (0, 0, -1)
+            assert "the message from rank 0 (my direction (+0,+0,-1), its direction code 22) is wrong at element 7" in str(ei.value), str(ei.value)
+            assert m.preflight_report["failed_peer"] == 0 and m.preflight_report["failed_direction_code"] == 4
+        m.close()
+    monkeypatch.delenv("DDCMI_DEBUG_PREFLIGHT_CORRUPT", raising=False)
+    monkeypatch.delenv("DDCMI_DEBUG_HOOKS", raising=False)
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_water_through_rccl_loopback(monkeypatch, overlap):
     """overlap=True: the exchange runs on a second stream under the tiles with all-owned neighbourhoods"""
