@@ -202,6 +202,9 @@ def build_setup(workload, n, reps, types=0, cadence="reference"):
     deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
     # 310 K restart relaxed by tests/golden/make_lipid_relaxed.py, Berendsen group (Teq 310 K, tau 1 ps)
     s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), r3)
+    if os.environ.get("DDCMI_BENCH_NOCHARGE"):      # (kernel-tuning experiments only: what the charges cost the pair kernel)
+        import numpy as _np
+        s.charge = _np.zeros_like(_np.asarray(s.charge, dtype=float))
     if cadence == "reference":
         # the cadence of the reference's shipped decks (examples/waterbox/object.data:10,35; examples/object/object.data:13,41): dt = 20 fs, list
         # rebuild every 20 steps.  The deck itself says 10 fs / 10 (a leftover of its relaxation); the 2.04 M-bead box holds 310 K, its bond

@@ -442,7 +442,18 @@ int ddcmi_rdzv_exchange(ddcmi_rdzv *h, int nsend, const int *send_peer, const vo
       }
       if (npf == 0) break;
       double left = deadline - now_s();
-      if (left <= 0) { rc = fail(h, "rank %d: message exchange timed out", h->rank); break; }
+      if (left <= 0)
+      {
+         /* say WHOSE data never came (and who never took ours): the peers with a message still in progress */
+         char who[192];
+         int o = 0;
+         who[0] = 0;
+         for (int p = 0; p < W && o < (int)sizeof(who) - 40; p++)
+            if (scur[p] < nsend || rcur[p] < nrecv)
+               o += snprintf(who + o, sizeof(who) - (size_t)o, "%s rank %d (%s%s%s)", o ? "," : "", p, rcur[p] < nrecv ? "nothing received" : "", (rcur[p] < nrecv && scur[p] < nsend) ? ", " : "", scur[p] < nsend ? "send not taken" : "");
+         rc = fail(h, "rank %d: message exchange timed out after %.0f s waiting for%s", h->rank, h->timeout_s, who);
+         break;
+      }
       int pr = poll(pf, (nfds_t)npf, (int)(left * 1000.0) + 1);
       if (pr < 0) { if (errno == EINTR) continue; rc = fail(h, "poll: %s", strerror(errno)); break; }
       int q = 0;

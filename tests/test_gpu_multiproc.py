@@ -124,7 +124,7 @@ def test_preflight_ends_with_a_deadline_when_a_rank_stays_away():
                                               "DDCMI_TEST_PREFLIGHT_TIMEOUT": "3"})
     assert time.time() - t0 < 60
     assert rcs == [4, 4], (rcs, errs)
-    assert "from rank 1 failed (timeout)" in errs[0] and "grouped exchange with the brick's peers failed" in errs[0], errs[0]
+    assert "timed out after 3 s waiting for rank 1 (nothing received" in errs[0] and "grouped exchange with the brick's peers failed" in errs[0], errs[0]
     assert "stayed away" in errs[1], errs[1]
 
 
