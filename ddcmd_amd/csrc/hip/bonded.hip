@@ -905,6 +905,7 @@ int ddcmi_bonded_localize(ddcmi_ctx *ctx)
 int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb, int lean_slot)
 {
    if (ctx->inc_nrow == 0 && ctx->nrest == 0) return DDCMI_OK;
+   RoctxRange rng_cov("CHARMM_COVALENT");      /* charmmConvalent, bioCharmmCovalent.c:95-251 */
    hipStream_t st = ctx->stream;
    BoxArgs box;
    box.L[0] = ctx->h[0]; box.L[1] = ctx->h[4]; box.L[2] = ctx->h[8];

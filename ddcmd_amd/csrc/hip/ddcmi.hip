@@ -35,6 +35,7 @@ static std::string g_create_err;
  * raised once per (device, kernel) and only ever upwards */
 #include <map>
 #include <mutex>
+#include <atomic>
 static hipError_t dyn_lds_limit(int device, const void *fn, int bytes)
 {
    static std::mutex mu;
@@ -67,6 +68,13 @@ static bool lds_starts_at_zero(int device, const void *fn, size_t *static_bytes)
    *static_bytes = it->second;
    return it->second == 0;
 }
+
+/* roctx ranges on the regions ddcMD's own profile() calls mark (ptiming.h:10-37: MDSTEP, DDCENERGY, P_FORCE, CHARMM_NONBOND, CHARMM_COVALENT,
+ * KINETIC_TERMS, UPDATEALL, PAIRLIST, UPDATE, EVAL_ETYPE), named like them, so that a `rocprofv3 --marker-trace` timeline of a run reads like a
+ * ddcMD timing report.  Off unless DDCMI_ROCTX=1: the marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is looked up with
+ * dlopen the first time a range opens -- libddcmi.so does not link it -- and a run without the variable pays one predictable branch per range. */
+std::atomic<long> g_roctx_ranges{0};
+extern "C" long ddcmi_debug_roctx_ranges(void) { return g_roctx_ranges.load(); }
 
 /* ------------------------------------------------------------------------- */
 /* small device helpers                                                       */
@@ -482,9 +490,6 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->no_shell_skip = getenv("DDCMI_NO_SHELL_SKIP") != nullptr;
    ctx->no_lean = getenv("DDCMI_NO_LEAN_STEP") != nullptr;
    ctx->no_self_img = getenv("DDCMI_NO_SELF_IMAGES") != nullptr;
-   ctx->lean_bonded = getenv("DDCMI_LEAN_BONDED") != nullptr;
-   if (const char *e = getenv("DDCMI_LEAN_MAX_BEADS")) ctx->lean_max_beads = atoi(e);
-   ctx->no_image_hint = getenv("DDCMI_NO_IMAGE_HINT") != nullptr;
    ctx->no_direct_halo = getenv("DDCMI_NO_DIRECT_HALO") != nullptr;
    ctx->force_lvl = getenv("DDCMI_FORCE_LEVEL_TABLE") != nullptr;
    /* test hook, armed only together with DDCMI_DEBUG_HOOKS=1 (a stray value alone does nothing; read per context: a test sets it between two of them) */

@@ -214,14 +214,14 @@ struct ddcmi_ctx
    dbuf<ulonglong2> lcg, lcg2; bool lcg_on = false; /* Langevin groups, RANDOM type LCG64: LCG64_PARM {state; multID | prime << 32} of the owned beads in slot order; off = the counter-based stream */
    dbuf<uint4> nbr_cum;                /* [bead] entries in shells 0..s as eight 16-bit counts (k_tile_transpose) */
    bool shell_skip = false, no_shell_skip = false; double sh_r0sq = 0, sh_step = 0;      /* k_nonbond may end its rows at the last shell that can matter (NbTileArgs::disp); DDCMI_NO_SHELL_SKIP */
-   int nhalo_hint = 0; const int *nhalo_dev = nullptr; bool no_image_hint = false; int debug_image_bound = 0;      /* single-domain rebuilds after the first: the image count stays on the device until the build's post (bl_self_images); DDCMI_NO_IMAGE_HINT */
+   int nhalo_hint = 0; const int *nhalo_dev = nullptr; int debug_image_bound = 0;      /* single-domain rebuilds after the first: the image count stays on the device until the build's post (bl_self_images) */
    bool pack_fresh = false;            /* decomposed runs: the halo send buffer already holds the current positions (packed in the fused step's reduction launch) */
    /* the lean step (round 5, step_post): a single domain of FREE beads without bonded terms runs ONE launch per step between rebuilds --
     * the pair kernel with the integrator's pass, which also stages the periodic images from their owners and keeps the displacement bound;
     * the second stage of its energy / virial / kinetic sums waits in a ring of per-step rows (lean_part, lean_kpart: LEAN_W steps of
     * lean_stride doubles) and is formed for all pending steps by one launch (lean_flush -> lean_hist: 16 sums per step) at the next rebuild,
     * when the ring is full or when the host asks.  DDCMI_NO_LEAN_STEP=1: the reduction launch after every step, as before. */
-   int lean_pending = 0, lean_hist_n = 0, lean_since = 0 /* lean steps since the rebuild: the next one's word of the ring */; size_t lean_stride = 0; bool no_lean = false, no_self_img = false, lean_bonded = false; double lean_dt = 0; int lean_max_beads = 2500000 /* DDCMI_LEAN_MAX_BEADS: beyond it the step's gain (-0.5 % at 4.24 M) is not worth 1 % of the pair kernel */;
+   int lean_pending = 0, lean_hist_n = 0, lean_since = 0 /* lean steps since the rebuild: the next one's word of the ring */; size_t lean_stride = 0; bool no_lean = false, no_self_img = false; double lean_dt = 0;
    dbuf<double> lean_part, lean_kpart, lean_hist, lean_tmp, lean_bpart; size_t lean_bstride = 0; int lean_bpstride = 0, lean_bnblk = 0;
    dbuf<unsigned> d_vring;             /* largest |v|^2 (float bits) of each lean step since the rebuild, one word per step at a stride of LEAN_VSTRIDE words: the step that
                                           is being written (atomic maxima of every workgroup) shares no cache line with the words the same launch reads */
@@ -345,6 +345,45 @@ struct ddcmi_ctx
 #define ENSURE(ctx, buf, n) do { if ((buf).ensure((n)) != 0) SETERR(ctx, DDCMI_ENOMEM, "device allocation of %zu elements failed (%s:%d)", (size_t)(n), __FILE__, __LINE__); } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+/* roctx ranges (ddcmi.hip has the story): RoctxRange r("MDSTEP"); -- nothing unless DDCMI_ROCTX=1 */
+#include <dlfcn.h>
+#include <atomic>
+extern std::atomic<long> g_roctx_ranges;
+struct RoctxRange
+{
+   typedef int (*push_fn)(const char *);
+   typedef int (*pop_fn)(void);
+   static int state() { static int s = -1; if (s < 0) { const char *e = getenv("DDCMI_ROCTX"); s = (e && atoi(e) != 0) ? 1 : 0; } return s; }
+   static bool bind(push_fn *pu, pop_fn *po)
+   {
+      static push_fn push = nullptr; static pop_fn pop = nullptr; static bool tried = false;
+      if (!tried)
+      {
+         tried = true;
+         for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+         {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (push_fn)dlsym(h, "roctxRangePushA"); pop = (pop_fn)dlsym(h, "roctxRangePop");
+            if (push && pop) break;
+            push = nullptr; pop = nullptr;
+         }
+      }
+      *pu = push; *po = pop;
+      return push != nullptr;
+   }
+   bool on = false;
+   explicit RoctxRange(const char *name)
+   {
+      if (!state()) return;
+      push_fn pu; pop_fn po;
+      g_roctx_ranges++;      /* (counted whether or not a marker library is there: tests) */
+      if (bind(&pu, &po)) { pu(name); on = true; }
+   }
+   ~RoctxRange() { if (on) { push_fn pu; pop_fn po; bind(&pu, &po); po(); } }
+};
+
 
 #ifdef __HIPCC__
 /* double-precision 1/sqrt(x) and 1/x from the single-precision hardware seeds (shared by the pair and the bonded kernels) */

@@ -1022,6 +1022,7 @@ static bool ddcmi_mg_pack_job(ddcmi_ctx *ctx, PackJob *pk)
 }
 int ddcmi_mg_refresh_halo(ddcmi_ctx *ctx, hipStream_t st)
 {
+   RoctxRange rng_upd("UPDATE");      /* ddcUpdate.c:40-85 */
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "in-process group: halos are refreshed by ddcmi_group_step_nglf / ddcmi_group_eval_forces");
    int rc;
    const bool packed = ctx->pack_fresh;      /* (the fused step before this one left the messages packed) */

@@ -128,7 +128,7 @@ static int bl_self_images(ddcmi_ctx *ctx)
    if ((rc = ddcmi_scan_exclusive(ctx, ctx->nimg.p, ctx->img_off.p, n, ctx->d_flags + 8))) return rc;
    ctx->nhalo_dev = nullptr;
    int nh;
-   if (ctx->nhalo_hint > 0 && !ctx->no_image_hint)
+   if (ctx->nhalo_hint > 0)
    {
       /* The image count moves by a fraction of a per cent between rebuilds: the kernels that lay the images out are launched for a bound
        * taken from the last rebuild and read the count on the device; the host learns it with the build's other results (ddcmi_bl_finish)
@@ -266,7 +266,6 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
    auto cost_stage = [&](int t) { return (double)stage[t]; };
    /* greedy list scheduling of a range's items on the S workgroup slots of one XCD: the makespan */
    const int S = std::max(1, wg_per_cu) * 32;
-   static const bool no_split = getenv("DDCMI_NO_TAIL_SPLIT") != nullptr;
    std::vector<double> heap((size_t)S);
    auto makespan = [&](const int *tl, int n, int m, int k) -> double
    {
@@ -315,9 +314,8 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
          const int n = cut[x + 1] - cut[x];
          /* few rounds of workgroups per slot: the expensive tiles first, the thin edge tiles fill the end of the launch
           * (at many rounds the raster order wins: neighbouring tiles share their neighbourhoods in L2) */
-         static const bool no_lpt = getenv("DDCMI_NO_LPT") != nullptr;
-         static const int lpt_rounds = getenv("DDCMI_LPT_ROUNDS") ? atoi(getenv("DDCMI_LPT_ROUNDS")) : 8;
-         if (!no_lpt && n < lpt_rounds * S)
+         constexpr int lpt_rounds = 8;
+         if (n < lpt_rounds * S)
             std::stable_sort(tl, tl + n, [&](int ta_, int tb_) { return cost_list(ta_) + cost_stage(ta_) > cost_list(tb_) + cost_stage(tb_); });
          /* the tail: how many of the run's last tiles to cut, and into how many parts, by simulated makespan */
          int best_m = 0, best_k = 1;
@@ -328,7 +326,7 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
          int *cache = ctx->sched_cache[lo == 0 ? 0 : 1][x];
          const bool cached = cache[0] > 0 && abs(cache[0] - n) <= 2 + n / 32 && (ctx->nrebuild & 63) != 0;
          if (cached) { best_m = std::min(cache[1], n); best_k = cache[2]; }
-         else if (!no_split && n > 0 && n < 8 * S)
+         else if (n > 0 && n < 8 * S)
          {
             double best = makespan(tl, n, 0, 1);
             const int r = n % S;
@@ -441,7 +439,9 @@ static int bl_plan(ddcmi_ctx *ctx, BuildPlan &bp)
    ENSURE(ctx, ctx->stage_idx, (size_t)ntile * ctx->stage_cap);
    if (ctx->nbr16.ensure(ctx->arena_cap)) SETERR(ctx, DDCMI_ENOMEM, "neighbour arena of %llu entries failed", ctx->arena_cap);
    if (ctx->excl16.ensure((size_t)ctx->maxexcl * ctx->npad)) SETERR(ctx, DDCMI_ENOMEM, "excluded-pair entries");
-   ctx->pack_type = (ctx->stage_cap < 4096) ? (ctx->nnb <= 8 ? 2 : ctx->nnb <= 16 ? 1 : 0) : 0;
+   /* (round 6: the middle form of rounds 4-5 -- 9 to 16 classes, the class in the nibble and the shift flag in the staged z -- is gone: it was
+    * 4 % faster than bare entries for decks of exactly that size and a third of k_nonbond's instantiations; such decks take bare entries now) */
+   ctx->pack_type = (ctx->stage_cap < 4096 && ctx->nnb <= 8) ? 2 : 0;
    TileArgs &ta = bp.ta;
    ta.ntile = ntile; ta.stage_stride = ctx->stage_cap; ta.cap = ctx->stage_cap; ta.pack_type = ctx->pack_type; ta.nloc = n; ta.halo_shift = ctx->halo_shift.p;
    ta.cell_start_o = ctx->cell_start_o.p; ta.cell_start = ctx->cell_start.p; ta.cell_cnt = ctx->cell_cnt.p;
@@ -453,8 +453,8 @@ static int bl_plan(ddcmi_ctx *ctx, BuildPlan &bp)
    ta.tmp32 = ctx->tmp32.p; ta.tmpw = ctx->tmpw; ta.shc = bp.shc;
    if (ctx->pack_type && ctx->tile_nib.ensure((size_t)ntile * ctx->stage_cap + 16)) SETERR(ctx, DDCMI_ENOMEM, "nibble table allocation failed");
    ta.tile_nib = ctx->tile_nib.p;
-   bp.kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : ctx->pack_type == 1 ? k_tile_build<true, 1> : k_tile_build<true, 0>)
-                       : (ctx->pack_type == 2 ? k_tile_build<false, 2> : ctx->pack_type == 1 ? k_tile_build<false, 1> : k_tile_build<false, 0>);
+   bp.kbuild = has_mol ? (ctx->pack_type == 2 ? k_tile_build<true, 2> : k_tile_build<true, 0>)
+                       : (ctx->pack_type == 2 ? k_tile_build<false, 2> : k_tile_build<false, 0>);
    bp.lds = lds;
    HIPCHK(ctx, dyn_lds_limit(ctx->device, (const void *)bp.kbuild, (int)lds));
    return DDCMI_OK;
@@ -471,13 +471,12 @@ static void bl_launch_tiles(ddcmi_ctx *ctx, const BuildPlan &bp, hipStream_t st,
  * round trips), packs, runs the RCCL kernel, assembles and sorts the halo: ~170 us of a 500 k-bead brick's 740 us window in which
  * the chip ran a dozen latency-bound launches or nothing.  The interior launch goes to a second stream behind the sort and reads
  * the owned cell tables; the boundary launch follows on the main stream when the halo is in place; the transposition waits for both.
- * DDCMI_NO_INTERIOR_FIRST=1: one launch as before. */
+ * (Rounds 5's DDCMI_NO_INTERIOR_FIRST -- one launch -- was never faster and is gone.) */
 static void bl_drop_interior(ddcmi_ctx *ctx);
 static int bl_launch_interior(ddcmi_ctx *ctx)
 {
    bl_drop_interior(ctx);      /* (a rebuild that ended early on an error may have left one behind) */
-   static const bool off = getenv("DDCMI_NO_INTERIOR_FIRST") != nullptr;
-   if (off || ctx->nloc <= 0) return DDCMI_OK;
+   if (ctx->nloc <= 0) return DDCMI_OK;
    const GridParams &gp = ctx->gp;
    const int tdim[3] = {TCX, TCY, TCZ};
    TileSel sel;

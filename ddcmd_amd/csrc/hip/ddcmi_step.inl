@@ -43,9 +43,8 @@ static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused)
 /* may this context run lean steps (ddcmi_ctx::lean_pending)?  A single domain whose step is the fused pair kernel (+ the bonded kernels in front of it) */
 static bool lean_capable(const ddcmi_ctx *ctx)
 {
-   if (ctx->no_lean || ctx->group_ || ctx->updateRate <= 0 || ctx->nloc <= 0 || ctx->nloc > ctx->lean_max_beads) return false;      /* (a decomposed rank: where its halo is staged from the receive buffer, launch_forces) */
+   if (ctx->no_lean || ctx->group_ || ctx->updateRate <= 0 || ctx->nloc <= 0) return false;      /* (a decomposed rank: where its halo is staged from the receive buffer, launch_forces) */
    if (ctx->nrest != 0 || ctx->ncgroup > 0 || ctx->baro_beta > 0.0 || (ctx->excludePotentialTerm & 128) != 0) return false;
-   if ((ctx->nbond + ctx->nangle + ctx->ntors) > 0 && !ctx->lean_bonded) return false;      /* (the 2 M-bead bilayer: -0.9 % of the step for +2.3 % on its pair kernel: off unless DDCMI_LEAN_BONDED=1) */
    for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE && ctx->gtype[g] != DDCMI_BERENDSEN) return false;      /* (Berendsen: host scalars from the temperature last published) */
    return true;
 }
@@ -59,6 +58,7 @@ static bool self_images(const ddcmi_ctx *ctx)
 static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fuse = nullptr /* in: the integrator's pass rides in the pair kernel; out: ->dt = 0 if this launch could not take it */,
                          bool *lean = nullptr /* in: the caller could run this step lean (ddcmi_ctx::lean_pending); out: this launch did */)
 {
+   RoctxRange rng_force("DDCENERGY P_FORCE");      /* ddcenergy.c:160-238 */
    hipStream_t st = ctx->stream;
    int n = ctx->nloc, nh = ctx->nhalo;
    /* Decomposed runs, between rebuilds: the halo exchange (pack, one RCCL message per peer,
@@ -126,7 +126,6 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
        * the records back zeroed: no launch is ever spent on clearing them. */
       int ntile = ctx->ntile;
       bool useq = ctx->has_charge;
-      bool packed = ctx->pack_type != 0;
       const bool shbit = ctx->pack_type == 2;
       const size_t capl = (size_t)ctx->stage_cap + 2;      /* + sentinel slot 0, kept even so every LDS array stays 16-byte aligned */
       FuseArgs fa;
@@ -202,6 +201,7 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
 #define LAUNCH_NB2(Q, P, S) LAUNCH_NB(Q, P, S, NB_THREADS)
       /* class 0: tiles with all-owned neighbourhoods (every tile on a single domain);
        * class 1: tiles that stage image/halo beads, after the halo exchange */
+      RoctxRange rng_nb("CHARMM_NONBOND");      /* martiniNonBond, bioMartini.c:989-1122 */
       for (int cls = 0; cls < 2; cls++)
       {
          if (cls == 1 && halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }
@@ -225,16 +225,12 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
             HIPCHK(ctx, hipEventRecord(e0, st));
          }
          if (fuse && useq && shbit) LAUNCH_NBF(true, true, true, NB_THREADS, NB_ZOFF, true);      /* (fuse: fixed LDS layout) */
-         else if (fuse && useq && packed) LAUNCH_NBF(true, true, false, NB_THREADS, NB_ZOFF, true);
          else if (fuse && useq) LAUNCH_NBF(true, false, false, NB_THREADS, NB_ZOFF, true);
          else if (fuse && shbit) LAUNCH_NBF(false, true, true, NB_THREADS, NB_ZOFF, true);
-         else if (fuse && packed) LAUNCH_NBF(false, true, false, NB_THREADS, NB_ZOFF, true);
          else if (fuse) LAUNCH_NBF(false, false, false, NB_THREADS, NB_ZOFF, true);
          else if (useq && shbit) LAUNCH_NB2(true, true, true);
-         else if (useq && packed) LAUNCH_NB2(true, true, false);
          else if (useq) LAUNCH_NB2(true, false, false);
          else if (shbit) LAUNCH_NB2(false, true, true);
-         else if (packed) LAUNCH_NB2(false, true, false);
          else LAUNCH_NB2(false, false, false);
          if (ctx->timing) HIPCHK(ctx, hipEventRecord(e1, st));
          na.hdisp = hd_keep;
@@ -321,6 +317,7 @@ extern "C" int ddcmi_debug_disp(ddcmi_ctx *ctx, double *disp, float *ring, int *
 }
 static int fetch_results(ddcmi_ctx *ctx)
 {
+   RoctxRange rng_e("EVAL_ETYPE");      /* energyInfo.c:75-148 */
    { int rcl = ddcmi_lean_flush(ctx); if (rcl) return rcl; }
    { int rca = ddcmi_agree_poll(ctx); if (rca) return rca; }      /* (a peer whose rebuild failed: say so instead of waiting behind an exchange it never joins) */
    HIPCHK(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, R_SIZE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -347,6 +344,7 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
  * nonbonded partials of the force evaluation just queued and forms the final energies */
 static int launch_kinetic(ddcmi_ctx *ctx, double dt, int do_kick, bool with_forces = false, const GroupLambda *gk = nullptr, bool then_drift = false)
 {
+   RoctxRange rng_ke("KINETIC_TERMS");      /* energy.c:48-163 */
    GroupLambda plain;
    if (!gk) { memset(&plain, 0, sizeof(plain)); for (int g = 0; g < 32; g++) { plain.v[g] = 1.0; plain.a[g] = 1.0; } plain.scale[0] = plain.scale[1] = plain.scale[2] = 1.0; gk = &plain; }
    int n = ctx->nloc, nblk = cdiv(n, DDCMI_BLOCK * KE_PER);
@@ -790,11 +788,12 @@ extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
          if (ctx->mol_nspecies[m] > 1) SETERR(ctx, DDCMI_EINVAL, "the barostat acts on the molecular pressure: molecule type %d has %d beads, call ddcmi_set_molecule_lists first", m, ctx->mol_nspecies[m]);
    for (int s = 0; s < nsteps; s++)
    {
+      RoctxRange rng_step("MDSTEP");      /* nglf.c:67-112 */
       if ((rc = step_pre(ctx, dt))) return rc;
       /* ddcUpdateAll.c:64-71: rebuild when loop % updateRate == 0, or (updateRate == 0) when neighborCheck asks */
       bool due = false;
       if ((rc = rebuild_due(ctx, &due))) return rc;
-      if (due) { if ((rc = ddcmi_build_list(ctx))) return rc; ctx->images_fresh = true; }      /* (nothing moves between here and this step's forces) */
+      if (due) { RoctxRange rng_upd("UPDATEALL PAIRLIST"); if ((rc = ddcmi_build_list(ctx))) return rc; ctx->images_fresh = true; }      /* (nothing moves between here and this step's forces; ddcUpdateAll.c:120-156) */
       if ((rc = step_post(ctx, dt, s + 1 < nsteps))) return rc;
    }
    return DDCMI_OK;

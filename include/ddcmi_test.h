@@ -49,6 +49,9 @@ int ddcmi_debug_lean_history(ddcmi_ctx *ctx, int *nsteps, double *sums);
 /* the displacement bound of the shell-limited walk: the word the reduction launches add to, and the lean steps' words since the rebuild (largest |v|^2 of each; ring[32]) */
 int ddcmi_debug_disp(ddcmi_ctx *ctx, double *disp, float *ring, int *nring);
 
+/* roctx ranges opened so far (DDCMI_ROCTX=1: MDSTEP, DDCENERGY, CHARMM_NONBOND ... named like ptiming.h's regions; 0 without the variable) */
+long ddcmi_debug_roctx_ranges(void);
+
 #ifdef __cplusplus
 }
 #endif

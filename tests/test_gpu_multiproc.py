@@ -216,7 +216,11 @@ def test_bench_world2_as_the_driver_launches_it():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE JSON line"
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["value"] > 0 and out["scaling"] == "strong"
+    # "steps" says what was TIMED (at least MIN_TIMED_STEPS = 60, in windows of 20), "steps_requested" echoes --steps
+    assert out["n_gpus"] == 2 and out["steps"] == 60 and out["steps_requested"] == 40 and out["steps_timed"] == 60 and out["value"] > 0 and out["scaling"] == "strong"
+    pf = out["comm"]["preflight_rank0"]
+    assert pf["stages_verified"] == 3 and pf["directions"] == 18 and pf["peers"] == [1] and out["comm"]["ranks_met"] == 2
+    assert out["comm"]["peers_rank0"][0]["peer"] == 1 and out["comm"]["peers_rank0"][0]["send_bytes_per_step"] > 0
     assert out["config"]["beads_total"] == 4 * 14 ** 3 and 0 < out["config"]["beads_rank0"] < out["config"]["beads_total"]
     # at least 60 timed steps whatever --steps says, in windows of 20 (one rebuild each); the median window is the figure
     assert out["steps_timed"] == 60 and len(out["window_ms"]) == 3 and out["config"]["rebuilds_in_timed_region"] == 3

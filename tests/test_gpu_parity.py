@@ -583,7 +583,6 @@ def test_images_staged_from_their_owners_equal_the_update_launch(case, monkeypat
     monkeypatch.setenv("DDCMI_NO_SELF_IMAGES", "1")
     a = MartiniHIP(s)
     monkeypatch.delenv("DDCMI_NO_SELF_IMAGES")
-    monkeypatch.setenv("DDCMI_LEAN_BONDED", "1")
     b = MartiniHIP(s)
     ea, eb = a.eval_forces(), b.eval_forces()
     assert ea[0] == eb[0] and np.array_equal(ea[1], eb[1])
@@ -616,7 +615,6 @@ def test_lean_steps_equal_steps_with_a_reduction_launch_each(case, monkeypatch):
     monkeypatch.setenv("DDCMI_NO_LEAN_STEP", "1")
     a = MartiniHIP(s)
     monkeypatch.delenv("DDCMI_NO_LEAN_STEP")
-    monkeypatch.setenv("DDCMI_LEAN_BONDED", "1")      # (systems with bonded terms are lean on request only: the bilayer's pair kernel pays more than the step gains)
     b = MartiniHIP(s, test_api=True)
     a.eval_forces(); b.eval_forces()
     per_step = []
@@ -684,12 +682,13 @@ def test_rows_end_at_the_last_shell_that_can_matter(monkeypatch):
 def test_rebuild_without_waiting_for_the_image_count(monkeypatch):
     """single-domain rebuilds after the first launch the image layout for a bound taken from the last rebuild and learn the
     count with the build's other results; a count beyond the bound starts the rebuild over (forced here through
-    DDCMI_DEBUG_IMAGE_BOUND): both paths and the waiting one (DDCMI_NO_IMAGE_HINT) give the same trajectory bit for bit"""
+    DDCMI_DEBUG_IMAGE_BOUND): both paths give the same trajectory bit for bit (the waiting path of round 4, DDCMI_NO_IMAGE_HINT, is gone:
+    it remains as the first rebuild of every run)"""
     from ddcmd_amd.martini import MartiniHIP
     s = make_water_setup(12)
     out = []
-    for env in ({}, {"DDCMI_NO_IMAGE_HINT": "1"}, {"DDCMI_DEBUG_IMAGE_BOUND": "100", "DDCMI_DEBUG_HOOKS": "1"}):
-        for k in ("DDCMI_NO_IMAGE_HINT", "DDCMI_DEBUG_IMAGE_BOUND", "DDCMI_DEBUG_HOOKS"):
+    for env in ({}, {"DDCMI_DEBUG_IMAGE_BOUND": "100", "DDCMI_DEBUG_HOOKS": "1"}):
+        for k in ("DDCMI_DEBUG_IMAGE_BOUND", "DDCMI_DEBUG_HOOKS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -719,7 +718,7 @@ def test_rebuild_started_over_with_bonded_terms_and_lcg64_streams(monkeypatch):
     parms = pyoracle.lcg64_default(s.gid)
     out = []
     for env in ({}, {"DDCMI_DEBUG_IMAGE_BOUND": "64", "DDCMI_DEBUG_HOOKS": "1"}, {"DDCMI_DEBUG_IMAGE_BOUND": "64"}):
-        for k in ("DDCMI_NO_IMAGE_HINT", "DDCMI_DEBUG_IMAGE_BOUND", "DDCMI_DEBUG_HOOKS"):
+        for k in ("DDCMI_DEBUG_IMAGE_BOUND", "DDCMI_DEBUG_HOOKS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
