@@ -608,7 +608,7 @@ def test_lean_steps_equal_steps_with_a_reduction_launch_each(case, monkeypatch):
     from ddcmd_amd.martini import MartiniHIP
     from ddcmd_amd.deck import load_deck
     import os
-    if any(os.environ.get(k) for k in ("DDCMI_NO_LEAN_STEP", "DDCMI_NO_SELF_IMAGES", "DDCMI_NO_FUSED_STEP", "DDCMI_GRAPH_MAX_BEADS")):
+    if any(os.environ.get(k) for k in ("DDCMI_NO_LEAN_STEP", "DDCMI_NO_SELF_IMAGES", "DDCMI_NO_FUSED_STEP")):
         pytest.skip("the lean step is switched off in this environment")
     s = make_water_setup(14, temperature_K=310.0) if case == "water" else load_deck(LIPID_DECK)
     nlean = 15 if case == "water" else 7         # (the deck rebuilds every 10 steps: lean steps 1..7, the 8th of the call is split)
@@ -1013,26 +1013,6 @@ def test_barostat_with_molecular_virial_and_constraints():
     p_atomic = (vir[:3] + s.natoms * T) / vol
     assert np.abs(p_atomic - m.barostat_pressure()).max() > 0.05 * np.abs(m.barostat_pressure()).max()
     m.close()
-
-
-def test_step_graph_replay_is_bitwise_the_plain_step(monkeypatch):
-    """DDCMI_GRAPH_MAX_BEADS: between list rebuilds the steady-state step (forces + fused kick / kinetic terms /
-    drift) can be replayed as one hipGraph launch; the trajectory is bit for bit that of the plain launches
-    (off by default: slower than plain launches on this runtime)"""
-    from ddcmd_amd.martini import MartiniHIP
-    s = make_water_setup(10)
-    out = []
-    for graph in (0, 1000000):
-        monkeypatch.setenv("DDCMI_GRAPH_MAX_BEADS", str(graph))
-        m = MartiniHIP(s)
-        m.eval_forces()
-        m.step(47)                       # two rebuilds inside: the graph is dropped and recorded again
-        e, vir, rk, tion = m.energies()
-        st = m.download()
-        out.append((e["total"], rk, np.concatenate(st["r"] + st["v"])))
-        m.close()
-    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
-    assert np.array_equal(out[0][2], out[1][2])
 
 
 def test_blown_up_run_is_reported_as_such():
