@@ -515,7 +515,6 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the context's non-blocking stream */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
    { const char *ov = getenv("DDCMI_HALO_OVERLAP"); ctx->halo_overlap = (ov && atoi(ov) != 0); }
-   { const char *gv = getenv("DDCMI_GRAPH_MAX_BEADS"); if (gv) ctx->graph_max_beads = atoi(gv); }      /* 0 switches the step graph off */
    ctx->gtype.assign(1, DDCMI_FREE); ctx->ginterval.assign(1, 1); ctx->gTeq.assign(1, 0); ctx->gtau.assign(1, 0);
    ctx->glambda.assign(1, 1.0); ctx->gTsum.assign(1, 0); ctx->gT.assign(1, 0); ctx->gnT.assign(1, 0); ctx->gdoScaling.assign(1, 0);
    *out = ctx;
@@ -566,7 +565,6 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->d_results) (void)hipFree(ctx->d_results);
    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
    for (int k = 0; k < 3; k++) if (ctx->h_pin[k]) (void)hipHostFree(ctx->h_pin[k]);
    if (ctx->mbox_h) (void)hipHostFree(ctx->mbox_h);
@@ -775,20 +773,17 @@ extern "C" int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, con
    return DDCMI_OK;
 }
 
-static void graph_drop(ddcmi_ctx *ctx);
 extern "C" int ddcmi_set_group_vcm(ddcmi_ctx *ctx, int ngroup, const double *vcm)
 {
    if (!ctx || ngroup < 0 || ngroup > 32 || (ngroup > 0 && !vcm)) return DDCMI_EINVAL;
    if (ngroup != ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_group_vcm: %d groups, ddcmi_set_groups gave %d", ngroup, ctx->ngroup);
    ctx->gvcm.assign(vcm, vcm + 3 * (size_t)ngroup);
-   graph_drop(ctx);
    return DDCMI_OK;
 }
 extern "C" int ddcmi_set_group_temperature(ddcmi_ctx *ctx, int group, double Teq)
 {
    if (!ctx || group < 0 || group >= ctx->ngroup || !(Teq >= 0.0)) return DDCMI_EINVAL;
    ctx->gTeq[group] = Teq;      /* (host scalars: the next step's factors are formed from them) */
-   graph_drop(ctx);
    return DDCMI_OK;
 }
 extern "C" int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau)

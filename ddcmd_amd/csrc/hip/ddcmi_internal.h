@@ -296,12 +296,8 @@ struct ddcmi_ctx
     * and hands it back zeroed -- every pair launch does, so the array is all zero whenever the bonded kernels start */
    dbuf<double4> fb; size_t fb_zeroed = 0;      /* fb_zeroed: elements known to be zero (a grown buffer is cleared once) */
    /* timing */
-   /* hipGraph of one steady-state step (forces + fused BACK kick / kinetic terms / FRONT kick / drift): small
-    * systems are launch-bound -- five short kernels per step -- and can replay the step as one graph launch
-    * between list rebuilds.  OFF by default (DDCMI_GRAPH_MAX_BEADS=<n> enables it up to n beads): on ROCm 7.2 /
-    * MI355X the replay is slower than the five plain launches (6.9 k beads: 86 vs 74 us per step, 62 k: 105 vs 92,
-    * 256 k: 136 vs 126).  graph_state 0: none, 1: buffers sized by a plain step, 2: graph_exec is valid */
-   int graph_state = 0; hipGraphExec_t graph_exec = nullptr; double graph_dt = 0; int graph_max_beads = 0;
+   /* (rounds 3-5 could replay the steady step as a hipGraph, DDCMI_GRAPH_MAX_BEADS: slower than plain launches on ROCm 7.2 at every size measured
+    * -- 6.9 k beads 86 vs 74 us -- and since the lean step the steady step of such systems IS one launch: removed in round 6) */
    bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; int64_t t_launches = 0; double t_ms = 0;
    std::vector<char> ev_fused; int64_t t_launches_fused = 0; double t_ms_fused = 0, t_last_fused[2] = {0, 0};      /* of those: launches whose epilogue was the integrator's pass */
    /* DDCMI_DEBUG_PHASES=1: host wall time between the marks of a rebuild (where the host waits, where it is busy), printed at ddcmi_destroy */

@@ -387,7 +387,6 @@ static int schedule_tiles(ddcmi_ctx *ctx, int wg_per_cu)
 }
 
 /* rebuild phase 4: per-tile staging lists + full neighbour list (16-bit ELL per tile) */
-static void graph_drop(ddcmi_ctx *ctx);
 /* sizes, buffers and kernel arguments of the search: everything k_tile_build needs, from the sorted owned beads alone (so that the
  * interior tiles' search can start before the halo exists: bl_launch_interior).  Idempotent. */
 typedef void (*tile_build_fn)(GridParams, TileArgs, int, const double4 *, const uint64_t *, const int *, int, const int *, const int *, const int *,
@@ -524,7 +523,6 @@ int ddcmi_bl_finish(ddcmi_ctx *ctx)
    hipStream_t st = ctx->stream;
    int n = ctx->nloc;
    ctx->phase(10, "-> bl_finish");
-   graph_drop(ctx);      /* a recorded step names this list's buffers, tile schedule and grid sizes */
    int ntile = gp.T[0] * gp.T[1] * gp.T[2];
    unsigned long long *d_arena = (unsigned long long *)(ctx->d_flags + 32);
    ShellCuts shc;

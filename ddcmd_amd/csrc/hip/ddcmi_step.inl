@@ -534,20 +534,6 @@ static int step_pre(ddcmi_ctx *ctx, double dt)
    return step_pre_c(ctx, dt);
 }
 /* nglf.c:97-108: ddcenergy, BACK half kick, kinetic_terms, group Update */
-static void graph_drop(ddcmi_ctx *ctx)
-{
-   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
-   ctx->graph_exec = nullptr; ctx->graph_state = 0;
-}
-/* may the steady-state step be replayed as a graph?  Only when its kernel arguments are the same every
- * step: all groups FREE (no thermostat scalars), no barostat, no constraints, one domain, no event timing */
-static bool graph_ok(const ddcmi_ctx *ctx, double dt)
-{
-   if (ctx->graph_max_beads <= 0 || ctx->nloc > ctx->graph_max_beads || ctx->nloc <= 0) return false;
-   if (ctx->group_ || ctx->nranks > 1 || ctx->loopback || ctx->timing || ctx->baro_beta > 0.0 || ctx->ncgroup > 0) return false;
-   for (int g = 0; g < ctx->ngroup; g++) if (ctx->gtype[g] != DDCMI_FREE) return false;
-   return ctx->graph_state < 2 || ctx->graph_dt == dt;
-}
 /* may the integrator's pass ride in the pair kernel (k_nonbond<..., FUSE>)?  The force must be complete when the list walk ends
  * and the step must need nothing between the force and the drift */
 static bool fuse_ok(const ddcmi_ctx *ctx)
@@ -570,32 +556,6 @@ static int step_post_cons_b(ddcmi_ctx *ctx, double dt)
 static int step_post(ddcmi_ctx *ctx, double dt, bool more_steps)
 {
    int rc;
-   if (more_steps && graph_ok(ctx, dt))
-   {
-      ctx->shell_skip = false;      /* (a recorded launch keeps the arguments of the step it was recorded on) */
-      ctx->images_fresh = false;    /* (and its kernels: the recording must hold the image update) */
-      GroupLambda lam = front_lambda(ctx, dt);
-      if (ctx->graph_state == 1)
-      {
-         /* the previous plain step sized every buffer: record this one */
-         hipGraph_t graph = nullptr;
-         HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-         rc = launch_forces(ctx, true);
-         if (!rc) rc = launch_kinetic(ctx, dt, 1, true, &lam, true);
-         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-         if (e == hipSuccess && graph && hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) { ctx->graph_state = 2; ctx->graph_dt = dt; }
-         else { (void)hipGetLastError(); ctx->graph_exec = nullptr; ctx->graph_state = 0; ctx->graph_max_beads = 0; }      /* no graphs on this runtime: plain launches from now on */
-         if (graph) (void)hipGraphDestroy(graph);
-      }
-      if (ctx->graph_state == 2)
-      {
-         HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
-         ctx->drift_done = true;
-         return DDCMI_OK;
-      }
-      if (ctx->graph_state == 0 && ctx->graph_max_beads > 0) ctx->graph_state = 1;      /* after the plain step below */
-   }
    bool fuse = more_steps && fuse_ok(ctx);
    GroupLambda lam_f;
    if (fuse)
