@@ -256,8 +256,21 @@ struct GatherRows
 #define GB_TAB_PIECES 384      /* 6 KB */
 template <bool HEAVY, bool TABL = false>      /* HEAVY false: bonds and func 2/10 angles; true: func-1 angles and dihedrals (few terms, three times the registers).  TABL: row patterns and parameters in LDS */
 __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int *__restrict__ slot, int nown, int ntot, BoxArgs box, int excl_mask,
-                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double4 *fb, double *partials, int pstride)
+                                                       const double4 *__restrict__ pos, double *fx, double *fy, double *fz, double4 *fb, double *partials, int pstride,
+                                                       const double *__restrict__ hrecv3, const int *__restrict__ halo_src)
 {
+   /* a decomposed rank whose halo is staged straight from the exchange's receive buffer (ddcmi_ctx::halo_in_recv, round 6 for systems with
+    * bonded terms too): a received bead's current position lies at hrecv3[3 k], k = -1 - halo_src[slot - nown]; its record in pos[] is the
+    * rebuild's.  The terms read x y z only. */
+   auto bead = [&](const int idx) -> double4
+   {
+      if (hrecv3 && idx >= nown)
+      {
+         const int k = halo_src[idx - nown];
+         if (k < 0) { const double *r = hrecv3 + 3 * (size_t)(-1 - k); return make_double4(r[0], r[1], r[2], 0.0); }
+      }
+      return pos[idx];
+   };
    /* lane = entry of the list of atoms that have terms of this launch, in caller order: the lanes of a
     * molecule sit together, so their rows are read with unit stride and the partners' bead records are the
     * neighbouring lanes' own -- taken from there (round 4): every lane leaves its own record in LDS, and a partner that is one of
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
     * records come out of LDS unasked (the look, compare and branch per partner were 6 of the light launch's 51 us) */
    const bool all_near = __all(near) != 0;
    const bool here = o < gr.nrow && (unsigned)i < (unsigned)ntot;      /* owned, or a halo copy on this rank */
-   const double4 me = here ? pos[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+   const double4 me = here ? bead(i) : make_double4(0.0, 0.0, 0.0, 0.0);
    s_atom[threadIdx.x] = here ? o : -1;
    s_rec[threadIdx.x] = me;
    __syncthreads();
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bonded_gather(GatherRows gr, const int 
       const int t = (int)threadIdx.x + (pa - o);
       if (all_near) return s_rec[t];
       if ((unsigned)t < 256u && s_atom[t] == pa) return s_rec[t];
-      return pos[slot[pa]];
+      return bead(slot[pa]);
    };
    if (here && i < nown)
    {
@@ -938,17 +951,18 @@ int ddcmi_launch_bonded(ddcmi_ctx *ctx, double4 *fb, int lean_slot)
       p1 = ctx->lean_bpart.p + bstride * (size_t)lean_slot;
    }
    double *p2 = p1 + nblk;      /* the heavy launch's workgroups follow the light one's in every row */
+   const double *hrecv = ctx->halo_in_recv ? ctx->hrecv3.p : nullptr;      /* (received beads: their current positions are in the receive buffer) */
    static const bool no_lds_tab = getenv("DDCMI_NO_BONDED_LDS_TABLES") != nullptr;
    if (nblk > 0)
    {
       auto kl = (gr.lp.pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<false, true> : k_bonded_gather<false, false>;
       hipLaunchKernelGGL(kl, dim3(nblk), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p1, pstride);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p1, pstride, hrecv, ctx->halo_src.p);
    }
    auto kh = (gr.hp.pieces <= GB_TAB_PIECES && !no_lds_tab) ? k_bonded_gather<true, true> : k_bonded_gather<true, false>;
    if (nblk2 > 0)
       hipLaunchKernelGGL(kh, dim3(nblk2), dim3(256), 0, st, gr, slot, ctx->nloc, ctx->nloc + ctx->nhalo, box, ctx->excludePotentialTerm,
-                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2, pstride);
+                         ctx->pos.p, ctx->fx.p, ctx->fy.p, ctx->fz.p, fb, p2, pstride, hrecv, ctx->halo_src.p);
    if (fb) restraints();
    if (lean_slot < 0) hipLaunchKernelGGL(k_reduce_gather, dim3(GB_NV), dim3(RG_T), 0, st, ctx->bpartials.p, nblk + nblk2, pstride, ctx->d_results);
    return DDCMI_OK;

@@ -69,9 +69,10 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
     * kernel may end its rows early; the word of this step's parity is the one this step's pair kernel reads */
    /* direct halo staging (ddcmi_ctx::halo_in_recv): the pair kernel takes the received beads out of the exchange's receive buffer, no
     * update launch -- for halos of received beads only, needed by the pair kernel only */
-   const bool has_bonded0 = (ctx->nbond + ctx->nangle + ctx->ntors + ctx->nrest) > 0;
+   /* (round 6: bonded terms are no obstacle any more -- their kernels take a received partner out of the receive buffer too, k_bonded_gather's bead();
+    *  restraints, constraint groups and the barostat still want every halo bead in pos[]) */
    const bool direct = !ctx->no_direct_halo && (ctx->nranks > 1 || ctx->loopback) && (ctx->comm || ctx->hcomm) && !ctx->group_ && !ctx->halo_overlap && ctx->nself_images == 0 &&
-                       !has_bonded0 && ctx->ncgroup == 0 && !(ctx->baro_beta > 0.0) && ctx->stage_cap + 2 < 4096 && (ctx->excludePotentialTerm & 128) == 0 && ctx->updateRate > 0;
+                       ctx->nrest == 0 && ctx->ncgroup == 0 && !(ctx->baro_beta > 0.0) && ctx->stage_cap + 2 < 4096 && (ctx->excludePotentialTerm & 128) == 0 && ctx->updateRate > 0;
    const bool hdisp_on = !direct && ctx->shell_skip && nh > 0 && (ctx->nranks > 1 || ctx->loopback || ctx->group_);
    const int hpar = (int)(ctx->loop & 1);
    unsigned long long *hmax = hdisp_on ? (unsigned long long *)(ctx->d_results + R_DISP + 1) : nullptr;
