@@ -272,6 +272,52 @@ def test_halo_staged_from_the_receive_buffer_equals_the_update_launch(monkeypatc
     a.close(); b.close()
 
 
+def test_bonded_partners_out_of_the_receive_buffer_equal_the_update_launch(monkeypatch):
+    """round 6: a decomposed rank WITH bonded terms stages its halo from the receive buffer too -- the bonded kernels take a received
+    partner's position out of the exchange's receive buffer (k_bonded_gather's bead()) -- and so runs lean (bonded kernels, pair kernel with
+    the integrator inside, pack, exchange: nothing else between rebuilds).  The lipid deck tiled 2x2x1 through the RCCL loopback (lipids
+    across every face, Berendsen group) against the same run with DDCMI_NO_DIRECT_HALO=1 (halo update launch, reduction launch per step):
+    positions, velocities and forces agree to the last bit across rebuilds, single evaluations and batches; energies by kind agree with the
+    oracle's run of the deck."""
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import replicate_setup
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lipid_deck")
+    s0 = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    reps = (2, 2, 1)
+    ncopy = 4
+    s = replicate_setup(s0, reps)
+    monkeypatch.delenv("DDCMI_NO_DIRECT_HALO", raising=False)
+    a = _loopback_rank(s, monkeypatch)
+    monkeypatch.setenv("DDCMI_NO_DIRECT_HALO", "1")
+    b = _loopback_rank(s, monkeypatch)
+    monkeypatch.delenv("DDCMI_NO_DIRECT_HALO", raising=False)
+    o = pyoracle.Oracle(s0)
+    o.forces(); o.group_temperature()
+    a.eval_forces(); b.eval_forces()
+    a.group_temperatures(); b.group_temperatures()
+    for block, n in enumerate((1, 9, 10, 10, 7)):          # (the deck rebuilds every 10 steps; its Berendsen group reads the temperature published here)
+        a.step(n); b.step(n)
+        eo, vo, rko, _ = o.step(n)
+        if block == 2:
+            ea1, _ = a.eval_forces(); eb1, _ = b.eval_forces()      # a force evaluation between batches: no exchange, no move
+            assert ea1["total"] == eb1["total"]
+        pa, pb = a.download_particles(), b.download_particles()
+        assert np.array_equal(pa["gid"], pb["gid"])
+        for k in ("r", "v", "f"):
+            for c in range(3):
+                assert np.array_equal(pa[k][c], pb[k][c]), (block, k, c)
+        ea, va, rka, _ = a.energies()
+        eb, vb, rkb, _ = b.energies()
+        for k in ("lj", "ele", "bond", "angle", "tors", "impr"):
+            assert abs(ea[k] - eb[k]) <= 1e-12 * max(abs(eb[k]), 1.0), (block, k)          # (the lean steps' sums are formed in batches: the same additions)
+            assert abs(ea[k] - ncopy * eo[k]) < TOL * ncopy * max(abs(eo[k]), abs(eo["total"]) * 1e-3), (block, k)
+        assert abs(rka - rkb) <= 1e-12 * rkb and abs(rka - ncopy * rko) < TOL * ncopy * rko
+        o.group_temperature()
+        Ta, Tb = a.group_temperatures(), b.group_temperatures()
+        assert Ta[0] == Tb[0]
+    a.close(); b.close()
+
+
 def test_explicit_rebuild_then_forces_through_the_loopback(monkeypatch):
     """constructList called by hand (ddcmi_build_list, the neighbour hook of ddcUpdateAll.c:136-139) followed by a force evaluation
     on a decomposed rank: the rebuild itself has placed the halo beads -- the evaluation must not refresh them from the per-step
