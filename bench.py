@@ -14,8 +14,10 @@ liquid (~307 K), so the timed steps see production list lengths.
 The timed region is max(--steps, 60) steps rounded up to windows of 20, each window between a
 barrier + stream drain on both sides; `ms_per_step` and `value` come from the MEDIAN window
 (`window_ms` lists them all).  At N=1 the line also carries `also`: the other single-GPU configs of
-BASELINE.json (1 M-bead water, the 2 M-bead lipid bilayer) and one rank's brick of the 8-GPU run
-through the RCCL loopback, each timed the same way.
+BASELINE.json (1 M-bead water, the 2 M-bead lipid bilayer) and one rank's brick of the 8-GPU runs
+through the RCCL loopback, each timed the same way -- in ONE fresh child process started when the
+headline has finished its GPU work (a fault in a side workload never costs the headline's line),
+followed by the rocprofv3 --pmc child runs when nothing else of the launch uses the GPU any more.
 Prints ONE JSON line (rank 0).  `roofline` prices the nonbonded kernel with the
 ALGORITHMIC bytes of SURVEY 8(d): (36 + 24 + 4*L) B per atom-step, L = stored
 full-list entries per atom, over the HIP-event time of that kernel measured on
@@ -439,6 +441,34 @@ def spawn_ranks(n):
     return rc
 
 
+def also_rows(reps, local_rank, transport):
+    """the other single-GPU configurations, each timed like the headline (>= 100 steps): BASELINE configs[2] (1 M-bead water), configs[4] (the
+    ~2 M-bead lipid bilayer, also at the deck's own cadence and under 20 / 40 LJ types) and one rank's brick of the 8-GPU runs of configs[3] and
+    configs[4] through the RCCL loopback.  Returns (rows, the bench arguments of each row's PMC child runs or None)."""
+    brick_reps = ",".join(str(max(1, int(x) // 2)) for x in reps.split(","))      # 12,12,6 -> 6,6,3: what one of 2x2x2 ranks owns
+    rows, pmc = [], []
+    for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps", pmc=["--lattice", "64"]),
+               dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen, at the reference decks' cadence (dt 20 fs, rebuild every 20 steps)", pmc=["--workload", "lipid", "--reps", reps]),
+               dict(workload="lipid", n=None, loopback=False, cadence="deck", tag="the same bilayer at the lipid deck's own cadence (dt 10 fs, rebuild every 10 steps): rounds 1-4's row", pmc=None),
+               dict(workload="lipid", n=None, loopback=False, types=20, tag="the same bilayer under 20 LJ types (every type split into copies of itself): the class table of a mid-size Martini deck", pmc=["--workload", "lipid", "--reps", reps, "--types", "20"]),
+               dict(workload="lipid", n=None, loopback=False, types=40, tag="the same bilayer under 40 LJ types / 48 (type, charge) classes: the pair table in two levels (k_nonbond<LVL>)", pmc=["--workload", "lipid", "--reps", reps, "--types", "40"]),
+               dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=["--lattice", str(HEADLINE_N // 2), "--rccl-loopback"]),
+               dict(workload="lipid", n=None, loopback=True, reps=brick_reps, tag="one rank's brick of the 8-GPU run of BASELINE configs[4] (the bilayer tiled %s: an eighth of %s), bonded terms by gid, Berendsen temperature all-reduced, periodic images through the RCCL loopback" % (brick_reps, reps), pmc=["--workload", "lipid", "--reps", brick_reps, "--rccl-loopback"]),
+               dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
+        try:
+            r = run_config(kw["workload"], kw["n"], kw.get("reps", reps), 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0), kw.get("cadence", "reference"))
+            rows.append({"what": kw["tag"], "workload": r["config"]["workload"], "value": r["value"], "unit": "atom-steps/s", "ms_per_step": r["ms_per_step"],
+                         "steps_timed": r["steps_timed"], "window_ms": r["window_ms"], "rebuilds_in_timed_region": r["config"]["rebuilds_in_timed_region"],
+                         "list_entries_per_atom": r["config"]["list_entries_per_atom"], "parallelism": r["config"]["parallelism"],
+                         "dt_fs": r["config"]["dt_fs"], "list_rebuild_every": r["config"]["list_rebuild_every"],
+                         "roofline": r["roofline"], "comm": r.get("comm")})
+            pmc.append(kw["pmc"])
+        except Exception as ex:      # (the other rows stand on their own)
+            rows.append({"what": kw["tag"], "error": str(ex)})
+            pmc.append(None)
+    return rows, pmc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,6 +493,7 @@ def main():
                     help="untimed steps in front of the warm-up that take the synthetic water box from its lattice start (50 K, FCC + jitter) to its "
                          "liquid state (~307 K after 200 steps): default 200 for water, 0 for the lipid deck (a relaxed restart)")
     ap.add_argument("--check-runtime", action="store_true", help="rendezvous + library load only: print which HIP/RCCL runtime is mapped, touch no device")
+    ap.add_argument("--rows-only", action="store_true", help="(internal) run the `also` workloads and print them as one JSON object: what the N=1 headline run starts as a child process")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -539,6 +570,11 @@ def main():
             rdzv.close()
         return
 
+    if args.rows_only:
+        rows, pmc = also_rows(args.reps, local_rank, transport)
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps({"also": rows, "pmc": pmc}), file=real_stdout, flush=True)
+        return
     res = run_config(args.workload, args.n, args.reps, args.steps, args.warmup, args.equil, world, rank, local_rank, rdzv, transport, args.rccl_loopback, args.types, args.cadence)
     out = {
         "metric": "atom_steps_per_sec", "value": res.pop("value"), "unit": "atom-steps/s",
@@ -549,44 +585,37 @@ def main():
     out.update(res)
     out["runtime_libs"] = runtime_libs()
     headline = world == 1 and args.workload == "water" and args.n == HEADLINE_N and not args.rccl_loopback
+    pmc_jobs = []      # (row or None for the headline, bench arguments of the PMC child runs, dominant launch fused?)
     if headline and not args.no_also:
-        # the other single-GPU configurations, each timed like the headline (>= 100 steps): BASELINE configs[2] (1 M-bead water),
-        # configs[4] (the ~2 M-bead lipid bilayer) and one rank's brick of the 8-GPU run of configs[3] through the RCCL loopback
-        out["also"] = []
-        brick_reps = ",".join(str(max(1, int(x) // 2)) for x in args.reps.split(","))      # 12,12,6 -> 6,6,3: what one of 2x2x2 ranks owns
-        under_prof = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
-        for kw in (dict(workload="water", n=64, loopback=False, tag="BASELINE configs[2]: 1M-bead water, rebuild every 20 steps", pmc=["--lattice", "64"]),
-                   dict(workload="lipid", n=None, loopback=False, tag="BASELINE configs[4]: lipid bilayer in water, ~2M beads, bonded terms, Berendsen, at the reference decks' cadence (dt 20 fs, rebuild every 20 steps)", pmc=["--workload", "lipid", "--reps", args.reps]),
-                   dict(workload="lipid", n=None, loopback=False, cadence="deck", tag="the same bilayer at the lipid deck's own cadence (dt 10 fs, rebuild every 10 steps): rounds 1-4's row", pmc=None),
-                   dict(workload="lipid", n=None, loopback=False, types=20, tag="the same bilayer under 20 LJ types (every type split into copies of itself): the class table of a mid-size Martini deck", pmc=["--workload", "lipid", "--reps", args.reps, "--types", "20"]),
-                   dict(workload="lipid", n=None, loopback=False, types=40, tag="the same bilayer under 40 LJ types / 48 (type, charge) classes: the pair table in two levels (k_nonbond<LVL>)", pmc=["--workload", "lipid", "--reps", args.reps, "--types", "40"]),
-                   dict(workload="water", n=HEADLINE_N // 2, loopback=True, tag="one rank's brick of the 8-GPU run of the headline box (n/2 per axis), periodic images through the RCCL loopback", pmc=["--lattice", str(HEADLINE_N // 2), "--rccl-loopback"]),
-                   dict(workload="lipid", n=None, loopback=True, reps=brick_reps, tag="one rank's brick of the 8-GPU run of BASELINE configs[4] (the bilayer tiled %s: an eighth of %s), bonded terms by gid, Berendsen temperature all-reduced, periodic images through the RCCL loopback" % (brick_reps, args.reps), pmc=["--workload", "lipid", "--reps", brick_reps, "--rccl-loopback"]),
-                   dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
-            try:
-                r = run_config(kw["workload"], kw["n"], kw.get("reps", args.reps), 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0), kw.get("cadence", "reference"))
-                if kw["pmc"] and not args.no_pmc and not under_prof:
-                    # the row's own HBM bytes, measured live like the headline's
-                    lt = live_traffic(kw["pmc"], r["roofline"].get("dominant_is_fused", False))
-                    if lt:
-                        t_k = r["roofline"]["kernel_ms_avg"] * 1e-3
-                        r["roofline"].update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"], "traffic_FETCH_SIZE_KiB": lt["FETCH_SIZE_KiB"],
-                                              "traffic_WRITE_SIZE_KiB": lt["WRITE_SIZE_KiB"], "hbm_frac_measured": lt["bytes_per_launch"] / t_k / 1e9 / HBM_PEAK_GBS})
-                out["also"].append({"what": kw["tag"], "workload": r["config"]["workload"], "value": r["value"], "unit": "atom-steps/s", "ms_per_step": r["ms_per_step"],
-                                    "steps_timed": r["steps_timed"], "window_ms": r["window_ms"], "rebuilds_in_timed_region": r["config"]["rebuilds_in_timed_region"],
-                                    "list_entries_per_atom": r["config"]["list_entries_per_atom"], "parallelism": r["config"]["parallelism"],
-                                    "dt_fs": r["config"]["dt_fs"], "list_rebuild_every": r["config"]["list_rebuild_every"],
-                                    "roofline": r["roofline"], "comm": r.get("comm")})
-            except Exception as ex:      # the headline stands on its own
-                out["also"].append({"what": kw["tag"], "error": str(ex)})
+        # The other single-GPU configurations run in ONE fresh child process (this very file with --rows-only), started when this process
+        # has finished its own GPU work: a fault in one of them (round 6 saw "Memory access fault by GPU node" kill one default run in eight
+        # while rows and rocprofv3 --pmc child runs alternated in this process) costs the `also` block, never the headline's line.  The PMC
+        # passes of every row follow when NOTHING else of this launch uses the GPU any more.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--rows-only", "--reps", args.reps]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, timeout=float(os.environ.get("DDCMI_BENCH_ROWS_TIMEOUT", "900")))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out["also"] = [{"error": "the child process of the `also` workloads exited with code %d and %s" % (r.returncode, "no result" if not lines else "a partial result")}]
+            else:
+                rows = json.loads(lines[-1])
+                out["also"] = rows["also"]
+                for row, job in zip(rows["also"], rows["pmc"]):
+                    if job and "error" not in row:
+                        pmc_jobs.append((row, job, row["roofline"].get("dominant_is_fused", False)))
+        except Exception as ex:      # the headline stands on its own
+            out["also"] = [{"error": "the `also` workloads: %s" % ex}]
     under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
     if headline and not args.no_pmc and not under_profiler:      # (a run that is itself being profiled starts no profiler of its own)
-        # roofline.traffic measured in THIS run (this process has finished its GPU work; the passes are fresh child processes)
-        lt = live_traffic(["--lattice", str(args.n)], out["roofline"].get("dominant_is_fused", False))
-        if lt:
-            t_k = out["roofline"]["kernel_ms_avg"] * 1e-3
-            out["roofline"].update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"], "traffic_FETCH_SIZE_KiB": lt["FETCH_SIZE_KiB"],
-                                    "traffic_WRITE_SIZE_KiB": lt["WRITE_SIZE_KiB"], "hbm_frac_measured": lt["bytes_per_launch"] / t_k / 1e9 / HBM_PEAK_GBS})
+        # roofline.traffic measured in THIS run: this process and its rows child have finished their GPU work; every pass is a fresh child process
+        for row, job, fused in [(None, ["--lattice", str(args.n)], out["roofline"].get("dominant_is_fused", False))] + pmc_jobs:
+            lt = live_traffic(job, fused)
+            if lt:
+                rf = out["roofline"] if row is None else row["roofline"]
+                t_k = rf["kernel_ms_avg"] * 1e-3
+                rf.update({"traffic": lt["bytes_per_launch"], "traffic_source": lt["source"], "traffic_FETCH_SIZE_KiB": lt["FETCH_SIZE_KiB"],
+                           "traffic_WRITE_SIZE_KiB": lt["WRITE_SIZE_KiB"], "hbm_frac_measured": lt["bytes_per_launch"] / t_k / 1e9 / HBM_PEAK_GBS})
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, one_million=bool(args.cpu_1m) and headline)      # N=1 only (the contract): bounded samples on one host core
     if rdzv is not None:
