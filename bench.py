@@ -256,7 +256,16 @@ def run_config(workload, n, reps, steps, warmup, equil, world, rank, local_rank,
             buf = ctypes.create_string_buffer(128)
             if rank == 0:
                 assert m.lib.ddcmi_comm_unique_id(buf) == 0
-            m.comm_init(rank, world, rdzv.bcast(buf.raw, 0), grid)      # MPI_Bcast of the id in ddcMD
+            uid = rdzv.bcast(buf.raw, 0)                                 # MPI_Bcast of the id in ddcMD
+            try:
+                m.comm_init(rank, world, uid, grid)
+            except Exception as ex:
+                # (typically: several ranks of this launch see the SAME device -- RCCL refuses two ranks on one GPU; tests on a one-GPU box use
+                #  DDCMI_TRANSPORT=host + DDCMI_BENCH_SINGLE_DEVICE=1)
+                sys.stderr.write("bench.py rank %d of %d: the RCCL communicator could not be created on device %d: %s -- do several ranks of this launch see the same device?  "
+                                 "RCCL wants one GPU per rank (a one-GPU box: DDCMI_TRANSPORT=host DDCMI_BENCH_SINGLE_DEVICE=1, a new launch)\n" % (rank, world, local_rank, ex))
+                sys.stderr.flush()
+                os._exit(4)
         # the first real exchange of the launch is a CHECKED one, before any state goes up and before any timing: one grouped exchange
         # of a known pattern with every peer of the brick plan, one 24-double all-reduce, one int all-gather (ddcmi_comm_preflight).
         # A mismatch or the deadline ends the launch on every rank with the stage / peer / direction in the message (exit 4; a rerun
