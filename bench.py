@@ -465,6 +465,7 @@ def also_rows(reps, local_rank, transport):
                dict(workload="lipid", n=None, loopback=True, reps=brick_reps, tag="one rank's brick of the 8-GPU run of BASELINE configs[4] (the bilayer tiled %s: an eighth of %s), bonded terms by gid, Berendsen temperature all-reduced, periodic images through the RCCL loopback" % (brick_reps, reps), pmc=["--workload", "lipid", "--reps", brick_reps, "--rccl-loopback"]),
                dict(workload="water", n=50, loopback=True, tag="the 500k-bead brick of rounds 1-4 (n = 50: one eighth of the 4.0M box), same loopback -- kept for continuity with VERDICT r4's target", pmc=None)):
         try:
+            sys.stderr.write("bench.py rows: %s\n" % kw["tag"][:90]); sys.stderr.flush()
             r = run_config(kw["workload"], kw["n"], kw.get("reps", reps), 100, 20, -1, 1, 0, local_rank, None, transport, kw["loopback"], kw.get("types", 0), kw.get("cadence", "reference"))
             rows.append({"what": kw["tag"], "workload": r["config"]["workload"], "value": r["value"], "unit": "atom-steps/s", "ms_per_step": r["ms_per_step"],
                          "steps_timed": r["steps_timed"], "window_ms": r["window_ms"], "rebuilds_in_timed_region": r["config"]["rebuilds_in_timed_region"],

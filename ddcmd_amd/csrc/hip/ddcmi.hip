@@ -494,9 +494,11 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
    ctx->force_lvl = getenv("DDCMI_FORCE_LEVEL_TABLE") != nullptr;
    /* test hook, armed only together with DDCMI_DEBUG_HOOKS=1 (a stray value alone does nothing; read per context: a test sets it between two of them) */
    ctx->debug_image_bound = (getenv("DDCMI_DEBUG_HOOKS") && getenv("DDCMI_DEBUG_IMAGE_BOUND")) ? atoi(getenv("DDCMI_DEBUG_IMAGE_BOUND")) : 0;
-   /* the small host-side count arrays inside the context (migration / halo counts) become DMA targets */
-   ctx->self_pinned = hipHostRegister(ctx, sizeof(ddcmi_ctx), hipHostRegisterDefault) == hipSuccess;
-   if (!ctx->self_pinned) (void)hipGetLastError();
+   /* (Rounds 3-5 registered the context itself with hipHostRegister, so that the two small count arrays inside it -- mig_scnt, hs_cnt: host
+    * transport and in-process groups only -- were DMA targets.  A heap object registered, unregistered and freed, its address handed out again by
+    * the allocator: later copies from or to pageable memory in those pages ended with "Memory access fault by GPU node" -- 5 of 12 processes that ran
+    * eight workloads one after another died that way, in a different workload every time (tools/rowsloop.sh; 0 of 14 without the registration).
+    * The two copies are followed by a stream synchronisation anyway: pageable destinations cost them nothing.) */
    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
        hipMalloc((void **)&ctx->d_results, R_SIZE * sizeof(double)) != hipSuccess ||
        hipHostMalloc((void **)&ctx->h_results, R_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess ||
@@ -504,13 +506,12 @@ extern "C" int ddcmi_create(ddcmi_ctx **out, int device)
        hipHostMalloc((void **)&ctx->h_flags, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess)
    {
       g_create_err = "context allocation failed";
-      if (ctx->self_pinned) (void)hipHostUnregister(ctx);
       delete ctx;
       return DDCMI_ENOMEM;
    }
    (void)hipMemset(ctx->d_results, 0, R_SIZE * sizeof(double));
    (void)hipMemset(ctx->d_flags, 0, DDCMI_NFLAGS * sizeof(int));
-   if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; if (ctx->self_pinned) (void)hipHostUnregister(ctx); delete ctx; return DDCMI_ENOMEM; }
+   if (ctx->red_tmp.ensure(2 * RED_SPLIT * 8 + 8)) { g_create_err = "context allocation failed"; delete ctx; return DDCMI_ENOMEM; }
    (void)hipMemset(ctx->red_tmp.p, 0, (2 * RED_SPLIT * 8 + 8) * sizeof(double));      /* incl. the two ticket counters */
    (void)hipDeviceSynchronize();      /* null-stream memsets are not ordered with the context's non-blocking stream */
    memset(ctx->h_results, 0, R_SIZE * sizeof(double));
@@ -570,7 +571,6 @@ extern "C" void ddcmi_destroy(ddcmi_ctx *ctx)
    if (ctx->mbox_h) (void)hipHostFree(ctx->mbox_h);
    if (ctx->agree_h) (void)hipHostFree(ctx->agree_h);
    (void)hipStreamDestroy(ctx->stream);
-   if (ctx->self_pinned) (void)hipHostUnregister(ctx);
    delete ctx;
 }
 

@@ -266,7 +266,7 @@ struct ddcmi_ctx
    /* reductions */
    dbuf<double> partials, bpartials; int npartial_blocks = 0;
    double *d_results = nullptr; double *h_results = nullptr;
-   int *d_flags = nullptr; int *h_flags = nullptr; bool self_pinned = false;      /* d_flags: DDCMI_NFLAGS ints, see the DDCMI_FLAG_* slots */
+   int *d_flags = nullptr; int *h_flags = nullptr;      /* d_flags: DDCMI_NFLAGS ints, see the DDCMI_FLAG_* slots */
    /* decomposed runs, RCCL transport: the outcome of a rebuild's local phase (mg_phase4_finish) is agreed on by an all-reduce that
     * nobody waits for -- its result lands in agree_h (mapped host memory, [0] = sequence word, [1] = worst error code) and is
     * looked at in front of the next host wait (ddcmi_agree_poll) */

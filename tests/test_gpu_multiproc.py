@@ -343,3 +343,22 @@ def test_decomposed_runs_repeat_bit_for_bit():
     _, va = _merge(a, "gid", "v")
     for c in range(3):
         assert np.array_equal(out["v"][c], va[c])
+
+
+def test_bench_rows_child_runs_eight_workloads_in_one_process():
+    """bench.py --rows-only (what the N=1 headline run starts as a child process): eight workloads -- 1 M water, the 2 M bilayer four ways, three
+    loopback bricks -- one after another in ONE process, every row without an error.  Round 6: rounds 3-5 registered the context object itself
+    with hipHostRegister; contexts created and destroyed in one process at recycled heap addresses ended 5 of 12 such processes with a GPU
+    memory fault, in a different workload every time (tools/rowsloop.sh).  One run here is a net, not a proof."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DDCMI_TRANSPORT", "DDCMI_RCCL_LOOPBACK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows-only"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rows = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert len(rows["also"]) == 8 and len(rows["pmc"]) == 8
+    for r in rows["also"]:
+        assert "error" not in r, r
+        assert r["value"] > 0 and r["steps_timed"] >= 100 and r["roofline"]["frac"] > 0.1
+    bricks = [r for r in rows["also"] if r["comm"]]
+    assert len(bricks) == 3 and all(b["comm"]["preflight_rank0"]["stages_verified"] == 3 and b["comm"]["transport"] == "rccl-loopback" for b in bricks)
