@@ -598,9 +598,10 @@ def main():
     pmc_jobs = []      # (row or None for the headline, bench arguments of the PMC child runs, dominant launch fused?)
     if headline and not args.no_also:
         # The other single-GPU configurations run in ONE fresh child process (this very file with --rows-only), started when this process
-        # has finished its own GPU work: a fault in one of them (round 6 saw "Memory access fault by GPU node" kill one default run in eight
-        # while rows and rocprofv3 --pmc child runs alternated in this process) costs the `also` block, never the headline's line.  The PMC
-        # passes of every row follow when NOTHING else of this launch uses the GPU any more.
+        # has finished its own GPU work: a fault in one of them costs the `also` block, never the headline's line.  (Round 6 saw "Memory access
+        # fault by GPU node" end one default run in eight; the cause -- the context object registered with hipHostRegister at recycled heap
+        # addresses -- is gone from the library, the isolation stays.)  The PMC passes of every row follow when NOTHING else of this launch
+        # uses the GPU any more.
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--rows-only", "--reps", args.reps]
         try:
