@@ -34,6 +34,7 @@ static char *get_string(const OBJECT *o, const char *key, const char *dflt)
 {
    char *s = NULL;
    object_get(o, key, &s, STRING, 1, dflt);
+   if (!s) s = strdup("");      /* "key = ;": present and empty -- callers compare the result, none of them expects NULL */
    return s;
 }
 /* CRC-32 (IEEE 802.3, reflected 0xEDB88320, initial value and final xor 0xffffffff): the algorithm of the reference's
@@ -502,6 +503,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
    char **resiNames = NULL;
    if (errlen > 0) err[0] = 0;
    units_ddcmd_defaults();
+   units_clear_error();
    object_reset();
    if (object_compilefile(object_file) < 0) FAIL("cannot read object file %s", object_file);
    {
@@ -707,6 +709,7 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
             if (!mo) FAIL("MOLECULE %s not found", mnames[m]);
             char **snames = NULL;
             int ns = object_getv(mo, "species", (void **)&snames, STRING, IGNORE_IF_NOT_FOUND);
+            if (ns <= 0) FAIL("MOLECULE %s names no species", mnames[m]);      /* (its ownership species would be the next molecule's first) */
             char *ownership = get_string(mo, "ownershipSpecies", "$NONE$");
             s->mol_nspecies[m] = ns;
             own[m] = s->nspecies;       /* default: first species of the molecule */
@@ -956,6 +959,8 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       int total = 0;
       for (int m = 0; m < s->nmoltype; m++)
       {
+         if (own[m] < 0 || own[m] >= s->nspecies || s->resitype[own[m]] < 0 || s->resitype[own[m]] >= nresi)
+         { free(own); FAIL("molecule type %d: its ownership species has no residue in the parameter file", m); }
          resiparms *r = &resi[s->resitype[own[m]]];
          total += r->nbonds + r->nexcl + r->ncons;
          s->nresicons += r->ncons;
@@ -1014,6 +1019,8 @@ ddcmi_setup *ddcmi_deck_load_with(const char *object_file, const char *restart_f
       object_get(co, "size", &size, INT, 1, "-1");
       if (size >= 0 && size != s->natoms) FAIL("COLLECTION size=%d but %d records read", size, s->natoms);
    }
+   /* a value whose unit could not be read came back as NaN somewhere above: the deck is refused, not run with it (tools/fuzz_decks.py, round 6) */
+   if (units_error()[0]) FAIL("%s", units_error());
    for (int r = 0; r < nresi; r++) { free_resi(&resi[r]); free(resiNames[r]); }
    free(resi); free(resiNames);
    for (int i = 0; i < s->nlj; i++) free(typeNames[i]);

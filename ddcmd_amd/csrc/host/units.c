@@ -16,6 +16,7 @@ static int initialised = 0;
 static char errmsg[256] = "";
 
 const char *units_error(void) { return errmsg; }
+void units_clear_error(void) { errmsg[0] = 0; }
 
 void units_internal(double length, double mass, double time, double current, double temperature, double amount, double luminous)
 {
@@ -70,7 +71,10 @@ static int eval_expr(const char *s, double *factor, int dim[NDIM])
       double f = 1.0; int dm[NDIM] = {0, 0, 0, 0, 0};
       if (isdigit((unsigned char)*p) || *p == '.')
       {
-         char *end; f = strtod(p, &end); p = end;
+         char *end; f = strtod(p, &end);
+         /* a lone '.' ("kJ.mol^-1") is not a number: strtod consumes nothing */
+         if (end == p) { snprintf(errmsg, sizeof(errmsg), "units: cannot parse '%s'", s); return -1; }
+         p = end;
       }
       else if (isalpha((unsigned char)*p) || *p == '_')
       {

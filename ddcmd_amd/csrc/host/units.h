@@ -38,6 +38,7 @@ void units_ddcmd_defaults(void);     /* the two calls of ddcMD.c:71-72 */
  * and sets units_error() on an unknown symbol or dimension mismatch. */
 double units_convert(double value, const char *from, const char *to);
 const char *units_error(void);
+void units_clear_error(void);      /* units_error() is "" again (a loader clears it, reads its deck, and refuses the deck if it is set) */
 
 /* physical constants in internal units (codata.h: ke, kB) */
 double units_ke(void);   /* e^2/(4 pi eps0)  [energy*length/charge^2] */

@@ -33,6 +33,21 @@ def test_units_ddcmd_internal():
     assert abs(m * units_convert(1.0, "Angstrom") ** 2 / units_convert(1.0, "fs") ** 2 - units_convert(1.0, "amu*Angstrom^2*fs^-2")) < 1e-12
 
 
+def test_malformed_unit_expressions_return_nan_and_do_not_hang():
+    """found by tools/fuzz_decks.py (round 6): "kJ.mol^-1" -- a lone '.' where '*' was meant -- made the expression reader
+    spin forever because strtod consumed nothing.  Run in a child with a deadline so a regression is a failure, not a stuck suite."""
+    import subprocess, sys, os
+    code = ("import math; from ddcmd_amd.deck import units_convert\n"
+            "for u in ('kJ.mol^-1', '.', 'kJ*.', 'nm^', 'nm^x', '@', 'kJ*mol^-1*.nm', 'nosuchunit'):\n"
+            "    assert math.isnan(units_convert(1.0, u)), u\n"
+            "assert abs(units_convert(1.0, '0.5*nm') - 0.5*units_convert(1.0, 'nm')) < 1e-14\n"
+            "assert abs(units_convert(1.0, '.5*nm') - 0.5*units_convert(1.0, 'nm')) < 1e-14\n"
+            "print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_golden_waterbox_oracle(waterbox):
     """oracle reproduces the committed golden vectors bit-for-bit-ish (same code, same inputs)"""
     s, g = waterbox
@@ -432,6 +447,42 @@ def test_crc32_known_answer_and_corrupted_snapshots(tmp_path):
     with pytest.raises(Exception) as ei:
         load_deck(os.path.join(deck, "object.data"), restart_file=short)
     assert "nrecord" in str(ei.value)
+
+
+def test_decks_the_mutation_fuzz_broke_the_loader_with_are_refused_with_a_message(tmp_path):
+    """tools/fuzz_decks.py (round 6, host layer under ASan/UBSan) found three decks the loader did not survive: a key that is present and
+    empty ("type = ;": strcmp on NULL), a MOLECULE that names no species (its ownership species indexed past the species tables), and a unit
+    written with '.' for '*' (the expression reader never advanced).  Each is a message now; each runs in a child with a deadline."""
+    import shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    deck = os.path.join(root, "tests", "golden", "lipid_deck")
+    cases = {
+        "empty_type": ("object.data", "group GROUP { type = FREE; }", "group GROUP { type = ; }", None),      # loads: a group of no known type is GROUP_OTHER
+        "no_species": ("object.data", "Wx MOLECULE {ownershipSpecies = WxW; species = WxW;}", "Wx MOLECULE {ownershipSpecies = WxW; species = ;}", "names no species"),
+        "dot_unit": ("restart", None, None, "units: cannot parse"),      # (it used to spin; then it loaded with time = NaN; now the deck is refused)
+    }
+    for name, (victim, old, new, msg) in cases.items():
+        work = str(tmp_path / name)
+        shutil.copytree(deck, work)
+        path = os.path.join(work, victim)
+        text = open(path).read()
+        if name == "dot_unit":
+            text2 = text.replace("Angstrom", "kJ.mol^-1", 1) if "Angstrom" in text else text.replace(";", " kJ.mol^-1;", 2)
+        else:
+            assert old in text, name
+            text2 = text.replace(old, new, 1)
+        assert text2 != text
+        open(path, "w").write(text2)
+        code = ("from ddcmd_amd.deck import load_deck\n"
+                "try:\n    s = load_deck(%r); print('LOADED', s.natoms)\n"
+                "except RuntimeError as e:\n    print('REFUSED', e)\n" % os.path.join(work, "object.data"))
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (name, r.stdout, r.stderr)
+        out = r.stdout.strip()
+        if msg:
+            assert out.startswith("REFUSED") and msg in out, (name, out)
+        else:
+            assert out.startswith("REFUSED") or out.startswith("LOADED"), (name, out)
 
 
 def _is_prime(n):
