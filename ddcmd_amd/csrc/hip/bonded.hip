@@ -574,6 +574,16 @@ static int build_rows(ddcmi_ctx *ctx, int nbond, const int *bond_ij, const doubl
       for (int k = 0; k < 2 * nbond; k++) { if (bond_ij[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a bond"); amax = std::max(amax, bond_ij[k]); }
       for (int k = 0; k < 3 * nangle; k++) { if (angle_ijk[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in an angle"); amax = std::max(amax, angle_ijk[k]); }
       for (int k = 0; k < 4 * ntors; k++) { if (tors_ijkl[k] < 0) SETERR(ctx, DDCMI_EINVAL, "negative atom index in a dihedral"); amax = std::max(amax, tors_ijkl[k]); }
+      /* (indices are the caller's bead numbers of ddcmi_upload_state: checked against its count at the rebuild, when both are known; this bound keeps
+       *  a wild index from sizing the row tables -- and it is the device's own, whose slot numbers are 29 bits in the tables of the decomposed path) */
+      if (amax >= (1 << 29)) SETERR(ctx, DDCMI_EINVAL, "a bonded term names bead %d: more than 2^29 beads per device are not supported", amax);
+      if (ctx->nloc > 0 && amax >= ctx->nloc && !ctx->bonded_gid) SETERR(ctx, DDCMI_EINVAL, "a bonded term names bead %d, the uploaded state holds %d", amax, ctx->nloc);
+      for (int t = 0; t < nbond; t++)
+         if (!std::isfinite(bond_kb[t]) || !std::isfinite(bond_b0[t])) SETERR(ctx, DDCMI_EINVAL, "bond %d: kb = %g, b0 = %g must be finite", t, bond_kb[t], bond_b0[t]);
+      for (int t = 0; t < nangle; t++)
+         if (!std::isfinite(angle_k[t]) || !std::isfinite(angle_t0[t])) SETERR(ctx, DDCMI_EINVAL, "angle %d: k = %g, theta0 = %g must be finite", t, angle_k[t], angle_t0[t]);
+      for (int t = 0; t < ntors; t++)
+         if (!std::isfinite(tors_k[t]) || !std::isfinite(tors_delta[t])) SETERR(ctx, DDCMI_EINVAL, "dihedral %d: k = %g, delta = %g must be finite", t, tors_k[t], tors_delta[t]);
       const int nrow = amax + 1;
       /* distinct parameter sets per kind (a force field has a handful) */
       std::map<std::array<double, 4>, int> ids[3];
@@ -765,9 +775,9 @@ extern "C" int ddcmi_set_bonded(ddcmi_ctx *ctx,
                                 int ntors, const int *tors_ijkl, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
                                 int excludePotentialTerm)
 {
-   if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
-   if ((nbond > 0 && (!bond_ij || !bond_kb || !bond_b0)) || (nangle > 0 && (!angle_ijk || !angle_func || !angle_k || !angle_t0)) ||
-       (ntors > 0 && (!tors_ijkl || !tors_func || !tors_n || !tors_k || !tors_delta))) return DDCMI_EINVAL;
+   ARGCHK(ctx, nbond < 0 || nangle < 0 || ntors < 0, "ddcmi_set_bonded: negative term count (%d bonds, %d angles, %d dihedrals)", nbond, nangle, ntors);
+   ARGCHK(ctx, (nbond > 0 && (!bond_ij || !bond_kb || !bond_b0)) || (nangle > 0 && (!angle_ijk || !angle_func || !angle_k || !angle_t0)) ||
+          (ntors > 0 && (!tors_ijkl || !tors_func || !tors_n || !tors_k || !tors_delta)), "ddcmi_set_bonded: an array of a term kind with terms is NULL");
    (void)hipSetDevice(ctx->device);
    ctx->excludePotentialTerm = excludePotentialTerm;
    ctx->bonded_gid = false; ctx->natom_g = 0;
@@ -783,9 +793,9 @@ extern "C" int ddcmi_set_bonded_gid(ddcmi_ctx *ctx,
                                     int ntors, const uint64_t *tors_gid, const int *tors_func, const int *tors_n, const double *tors_k, const double *tors_delta,
                                     int excludePotentialTerm)
 {
-   if (!ctx || nbond < 0 || nangle < 0 || ntors < 0) return DDCMI_EINVAL;
-   if ((nbond > 0 && (!bond_gid || !bond_kb || !bond_b0)) || (nangle > 0 && (!angle_gid || !angle_func || !angle_k || !angle_t0)) ||
-       (ntors > 0 && (!tors_gid || !tors_func || !tors_n || !tors_k || !tors_delta))) return DDCMI_EINVAL;
+   ARGCHK(ctx, nbond < 0 || nangle < 0 || ntors < 0, "ddcmi_set_bonded_gid: negative term count (%d bonds, %d angles, %d dihedrals)", nbond, nangle, ntors);
+   ARGCHK(ctx, (nbond > 0 && (!bond_gid || !bond_kb || !bond_b0)) || (nangle > 0 && (!angle_gid || !angle_func || !angle_k || !angle_t0)) ||
+          (ntors > 0 && (!tors_gid || !tors_func || !tors_n || !tors_k || !tors_delta)), "ddcmi_set_bonded_gid: an array of a term kind with terms is NULL");
    (void)hipSetDevice(ctx->device);
    ctx->excludePotentialTerm = excludePotentialTerm;
    ctx->bonded_gid = true;

@@ -586,11 +586,12 @@ static int upload_vec(ddcmi_ctx *ctx, dbuf<T> &buf, const T *src, size_t n)
 
 extern "C" int ddcmi_set_box(ddcmi_ctx *ctx, const double h[9], int pbc)
 {
-   if (!ctx || !h) return DDCMI_EINVAL;
+   ARGCHK(ctx, !h, "ddcmi_set_box: h is NULL");
+   ARGCHK(ctx, pbc < 0 || pbc > 7, "ddcmi_set_box: pbc = %d is not a mask of the three axes (0..7)", pbc);
    const int off[6] = {1, 2, 3, 5, 6, 7};
    for (int k = 0; k < 6; k++)
       if (fabs(h[off[k]]) > 1e-10) SETERR(ctx, DDCMI_EUNSUPPORTED, "only orthorhombic boxes are supported (h[%d]=%g)", off[k], h[off[k]]);
-   if (!(h[0] > 0 && h[4] > 0 && h[8] > 0)) SETERR(ctx, DDCMI_EINVAL, "box lengths must be positive");
+   if (!(h[0] > 0 && h[4] > 0 && h[8] > 0) || !std::isfinite(h[0]) || !std::isfinite(h[4]) || !std::isfinite(h[8])) SETERR(ctx, DDCMI_EINVAL, "box lengths must be positive and finite (%g %g %g)", h[0], h[4], h[8]);
    memcpy(ctx->h, h, sizeof(double) * 9);
    ctx->pbc = pbc;
    ctx->have_box = true;
@@ -600,7 +601,12 @@ extern "C" int ddcmi_set_box(ddcmi_ctx *ctx, const double h[9], int pbc)
 
 extern "C" int ddcmi_set_species(ddcmi_ctx *ctx, int nspecies, const double *mass, const double *charge, const int *ljtype, const int *moltype)
 {
-   if (!ctx || nspecies <= 0 || !mass || !ljtype) return DDCMI_EINVAL;
+   ARGCHK(ctx, nspecies <= 0 || !mass || !ljtype, "ddcmi_set_species: %d species%s%s", nspecies, mass ? "" : ", mass is NULL", ljtype ? "" : ", ljtype is NULL");
+   for (int s = 0; s < nspecies; s++)
+   {
+      if (!(mass[s] > 0)) SETERR(ctx, DDCMI_EINVAL, "species %d has non-positive mass", s);      /* (before anything is kept: a refused call changes nothing) */
+      if (charge && !std::isfinite(charge[s])) SETERR(ctx, DDCMI_EINVAL, "species %d: charge %g is not finite", s, charge[s]);
+   }
    (void)hipSetDevice(ctx->device);
    ctx->nspecies = nspecies;
    ctx->mass.assign(mass, mass + nspecies);
@@ -629,7 +635,12 @@ extern "C" int ddcmi_set_species(ddcmi_ctx *ctx, int nspecies, const double *mas
 extern "C" int ddcmi_set_nonbonded(ddcmi_ctx *ctx, int nlj, const double *sigma, const double *eps, const double *shift,
                                    double rmax, double keR, double krf, double crf)
 {
-   if (!ctx || nlj <= 0 || !sigma || !eps || !shift || !(rmax > 0)) return DDCMI_EINVAL;
+   ARGCHK(ctx, nlj <= 0 || nlj > 4096 || !sigma || !eps || !shift, "ddcmi_set_nonbonded: %d LJ types%s", nlj, (sigma && eps && shift) ? "" : ", a table is NULL");
+   ARGCHK(ctx, !(rmax > 0) || !std::isfinite(rmax), "ddcmi_set_nonbonded: the cut-off rmax = %g must be positive and finite", rmax);
+   ARGCHK(ctx, !std::isfinite(keR) || !std::isfinite(krf) || !std::isfinite(crf), "ddcmi_set_nonbonded: the reaction-field constants keR = %g, krf = %g, crf = %g must be finite", keR, krf, crf);
+   for (int k = 0; k < nlj * nlj; k++)
+      if (!std::isfinite(sigma[k]) || !std::isfinite(eps[k]) || !std::isfinite(shift[k]))
+         SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_nonbonded: entry (%d,%d) of the LJ table is not finite (sigma %g, eps %g, shift %g)", k / nlj, k % nlj, sigma[k], eps[k], shift[k]);
    (void)hipSetDevice(ctx->device);
    ctx->nlj = nlj;
    ctx->sigma.assign(sigma, sigma + nlj * nlj); ctx->eps.assign(eps, eps + nlj * nlj); ctx->shift.assign(shift, shift + nlj * nlj);
@@ -711,12 +722,19 @@ static int nb_tables(ddcmi_ctx *ctx)
 
 extern "C" int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_nspecies, const int *bpair_off, const int *bpairI, const int *bpairJ)
 {
-   if (!ctx || nmoltype < 0) return DDCMI_EINVAL;
+   ARGCHK(ctx, nmoltype < 0, "ddcmi_set_molecules: %d molecule types", nmoltype);
+   ARGCHK(ctx, nmoltype > 0 && (!mol_nspecies || !bpair_off), "ddcmi_set_molecules: mol_nspecies or bpair_off is NULL");
+   for (int m = 0; m < nmoltype; m++)
+   {
+      if (mol_nspecies[m] < 1) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_molecules: molecule type %d has %d species", m, mol_nspecies[m]);
+      if (bpair_off[m] < 0 || bpair_off[m + 1] < bpair_off[m] || (m == 0 && bpair_off[0] != 0))
+         SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_molecules: bpair_off must start at 0 and never decrease (type %d: %d .. %d)", m, bpair_off[m], bpair_off[m + 1]);
+   }
+   ARGCHK(ctx, nmoltype > 0 && bpair_off[nmoltype] > 0 && (!bpairI || !bpairJ), "ddcmi_set_molecules: %d bonded pairs but bpairI or bpairJ is NULL", bpair_off[nmoltype]);
    (void)hipSetDevice(ctx->device);
    ctx->nmoltype = nmoltype;
    ctx->list_valid = false;
    if (nmoltype == 0) return DDCMI_OK;
-   if (!mol_nspecies || !bpair_off) return DDCMI_EINVAL;
    ctx->mol_nspecies.assign(mol_nspecies, mol_nspecies + nmoltype);
    ctx->bpair_off.assign(bpair_off, bpair_off + nmoltype + 1);
    int nb = bpair_off[nmoltype];
@@ -747,7 +765,7 @@ extern "C" int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_
 
 extern "C" int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate)
 {
-   if (!ctx || deltaR < 0) return DDCMI_EINVAL;
+   ARGCHK(ctx, !(deltaR >= 0) || !std::isfinite(deltaR), "ddcmi_set_neighbor: the skin deltaR = %g must be >= 0 and finite", deltaR);
    if (updateRate < 0) SETERR(ctx, DDCMI_EINVAL, "updateRate must be >= 0 (0 = rebuild when neighborCheck says so, ddcUpdateAll.c:64-71)");
    ctx->deltaR = deltaR; ctx->updateRate = updateRate; ctx->list_valid = false;
    return DDCMI_OK;
@@ -755,7 +773,15 @@ extern "C" int ddcmi_set_neighbor(ddcmi_ctx *ctx, double deltaR, int updateRate)
 
 extern "C" int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, const double *Teq, const double *tau, const int *interval)
 {
-   if (!ctx || ngroup <= 0 || ngroup > 32 || !type) return DDCMI_EINVAL;
+   ARGCHK(ctx, ngroup <= 0 || ngroup > 32 || !type, "ddcmi_set_groups: %d groups (1..32 are supported)%s", ngroup, type ? "" : ", type is NULL");
+   for (int g = 0; g < ngroup; g++)
+   {
+      /* berendsen.c:30-62 forms sqrt(1 + dt/tau (Teq/T - 1)), langevin.c sqrt(2 dt Teq / tau): a negative or NaN tau or Teq is a NaN in every velocity ten steps later */
+      if (type[g] == DDCMI_BERENDSEN && ((tau && !(tau[g] >= 0.0 && std::isfinite(tau[g]))) || (Teq && !(Teq[g] >= 0.0 && std::isfinite(Teq[g])))))
+         SETERR(ctx, DDCMI_EINVAL, "group %d: BERENDSEN needs Teq >= 0 and tau >= 0 (tau = 0: rescale to Teq every step), both finite", g);
+      if (type[g] == DDCMI_LANGEVIN && Teq && !(Teq[g] >= 0.0 && std::isfinite(Teq[g]))) SETERR(ctx, DDCMI_EINVAL, "group %d: LANGEVIN needs a finite Teq >= 0", g);
+      if (type[g] == DDCMI_LANGEVIN && tau && !std::isfinite(tau[g])) SETERR(ctx, DDCMI_EINVAL, "group %d: LANGEVIN needs a finite tau > 0", g);
+   }
    ctx->ngroup = ngroup;
    ctx->gtype.assign(type, type + ngroup);
    ctx->gTeq.assign(ngroup, 0.0); ctx->gtau.assign(ngroup, 0.0); ctx->ginterval.assign(ngroup, 1);
@@ -775,20 +801,21 @@ extern "C" int ddcmi_set_groups(ddcmi_ctx *ctx, int ngroup, const int *type, con
 
 extern "C" int ddcmi_set_group_vcm(ddcmi_ctx *ctx, int ngroup, const double *vcm)
 {
-   if (!ctx || ngroup < 0 || ngroup > 32 || (ngroup > 0 && !vcm)) return DDCMI_EINVAL;
+   ARGCHK(ctx, ngroup < 0 || ngroup > 32 || (ngroup > 0 && !vcm), "ddcmi_set_group_vcm: %d groups%s", ngroup, vcm ? "" : ", vcm is NULL");
    if (ngroup != ctx->ngroup) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_group_vcm: %d groups, ddcmi_set_groups gave %d", ngroup, ctx->ngroup);
    ctx->gvcm.assign(vcm, vcm + 3 * (size_t)ngroup);
    return DDCMI_OK;
 }
 extern "C" int ddcmi_set_group_temperature(ddcmi_ctx *ctx, int group, double Teq)
 {
-   if (!ctx || group < 0 || group >= ctx->ngroup || !(Teq >= 0.0)) return DDCMI_EINVAL;
+   ARGCHK(ctx, group < 0 || group >= ctx->ngroup || !(Teq >= 0.0) || !std::isfinite(Teq), "ddcmi_set_group_temperature: group %d of %d, Teq = %g (must be finite and >= 0)", group, ctx->ngroup, Teq);
    ctx->gTeq[group] = Teq;      /* (host scalars: the next step's factors are formed from them) */
    return DDCMI_OK;
 }
 extern "C" int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau)
 {
-   if (!ctx || beta < 0.0 || (beta > 0.0 && !(tau > 0.0))) return DDCMI_EINVAL;
+   ARGCHK(ctx, !(beta >= 0.0) || !std::isfinite(beta) || (beta > 0.0 && (!(tau > 0.0) || !std::isfinite(tau) || !std::isfinite(T) || !std::isfinite(P0))),
+          "ddcmi_set_barostat: beta = %g must be >= 0 (0 = off) and, when on, tau = %g > 0 with finite T = %g and P0 = %g", beta, tau, T, P0);
    if (beta > 0.0)
    {
       if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat is implemented for a single domain");
@@ -903,7 +930,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
                                   const uint64_t *gid, const int *species, const int *group)
 {
    /* nlocal == 0: a domain of a decomposed run that holds no bead yet (vacuum, a droplet elsewhere) */
-   if (!ctx || nlocal < 0 || (nlocal > 0 && (!rx || !ry || !rz || !species))) return DDCMI_EINVAL;
+   ARGCHK(ctx, nlocal < 0 || (nlocal > 0 && (!rx || !ry || !rz || !species)), "ddcmi_upload_state: %d beads%s", nlocal, nlocal < 0 ? "" : ", a coordinate array or species is NULL");
    if (ctx->nspecies <= 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_species must be called before ddcmi_upload_state");
    { int rct = nb_tables(ctx); if (rct) return rct; }
    (void)hipSetDevice(ctx->device);

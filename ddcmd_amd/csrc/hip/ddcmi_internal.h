@@ -337,6 +337,8 @@ struct ddcmi_ctx
 };
 
 #define SETERR(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
+/* an entry point's argument check: a NULL context has nowhere to leave a message; anything else says what was wrong (tools/fuzz_abi.py, round 6) */
+#define ARGCHK(ctx, bad, ...) do { if (!(ctx)) return DDCMI_EINVAL; if (bad) SETERR(ctx, DDCMI_EINVAL, __VA_ARGS__); } while (0)
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { SETERR(ctx, DDCMI_ENODEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
 #define ENSURE(ctx, buf, n) do { if ((buf).ensure((n)) != 0) SETERR(ctx, DDCMI_ENOMEM, "device allocation of %zu elements failed (%s:%d)", (size_t)(n), __FILE__, __LINE__); } while (0)
 

@@ -200,6 +200,14 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    { int rcl = ddcmi_lean_flush(ctx); if (rcl) return rcl; }      /* (the pending steps' rows are as many as this list's work items) */
    if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate < 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
+   /* what the setters could not check one by one (they may come in any order): every species' molecule type has its entry in the molecule
+    * tables, every index-named bonded term names a bead of the uploaded state -- the search and the bonded kernels index with them */
+   if (ctx->nmoltype > 0)
+      for (int sp = 0; sp < ctx->nspecies; sp++)
+         if (ctx->moltype[sp] < 0 || ctx->moltype[sp] >= ctx->nmoltype)
+            SETERR(ctx, DDCMI_EINVAL, "species %d: molecule type %d outside the %d types of ddcmi_set_molecules", sp, ctx->moltype[sp], ctx->nmoltype);
+   if (!ctx->bonded_gid && ctx->inc_nrow > ctx->nloc && ctx->nranks == 1 && !ctx->loopback && !ctx->group_)
+      SETERR(ctx, DDCMI_EINVAL, "a bonded term of ddcmi_set_bonded names bead %d, the uploaded state holds %d", ctx->inc_nrow - 1, ctx->nloc);
    (void)hipSetDevice(ctx->device);
    int rc;
    ctx->pack_fresh = false;      /* (the rebuild's own exchange reuses the send buffer) */

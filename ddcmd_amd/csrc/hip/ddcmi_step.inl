@@ -737,7 +737,8 @@ static int rebuild_due(ddcmi_ctx *ctx, bool *due)
 
 extern "C" int ddcmi_step_nglf(ddcmi_ctx *ctx, double dt, int nsteps)
 {
-   if (!ctx || nsteps < 0) return DDCMI_EINVAL;
+   ARGCHK(ctx, nsteps < 0, "ddcmi_step_nglf: %d steps", nsteps);
+   ARGCHK(ctx, !std::isfinite(dt), "ddcmi_step_nglf: the time step dt = %g is not finite", dt);
    if (!ctx->forces_valid) SETERR(ctx, DDCMI_EINVAL, "ddcmi_step_nglf needs forces: call ddcmi_eval_forces first (firstEnergyCall, masters.c:579)");
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group are stepped with ddcmi_group_step_nglf");
    (void)hipSetDevice(ctx->device);
