@@ -863,7 +863,10 @@ __global__ __launch_bounds__(256) void k_restraint(int nrest, BoxArgs box, int o
 }
 extern "C" int ddcmi_set_restraints(ddcmi_ctx *ctx, int n, const uint64_t *gid, const int *fc, const double *r0, const double *kb, int origin)
 {
-   if (!ctx || n < 0 || (n > 0 && (!gid || !fc || !r0 || !kb))) return DDCMI_EINVAL;
+   ARGCHK(ctx, n < 0 || (n > 0 && (!gid || !fc || !r0 || !kb)), "ddcmi_set_restraints: %d restraints%s", n, n < 0 ? "" : ", an array is NULL");
+   for (int k = 0; k < n; k++)
+      if (!std::isfinite(kb[k]) || !std::isfinite(r0[3 * k]) || !std::isfinite(r0[3 * k + 1]) || !std::isfinite(r0[3 * k + 2]))
+         SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_restraints: restraint %d has a constant or a reference position that is not finite", k);
    (void)hipSetDevice(ctx->device);
    int rc;
    ctx->nrest = n; ctx->rest_origin = origin;
@@ -1062,14 +1065,31 @@ __global__ __launch_bounds__(CONS_T) void k_constrain(int ngroups, const int *__
    if (it == maxit) atomicAdd(status + 1, 1);
 }
 
+/* an offsets array of a caller's table: starts at 0, never decreases (tools/fuzz_abi.py: a table out of order sized a vector with a negative count) */
+static int check_offsets(ddcmi_ctx *ctx, const char *who, const char *name, const int *off, int n)
+{
+   if (off[0] != 0) SETERR(ctx, DDCMI_EINVAL, "%s: %s[0] = %d, must be 0", who, name, off[0]);
+   for (int k = 0; k < n; k++)
+      if (off[k + 1] < off[k]) SETERR(ctx, DDCMI_EINVAL, "%s: %s decreases at %d (%d -> %d)", who, name, k, off[k], off[k + 1]);
+   return DDCMI_OK;
+}
 template <class KEY>
 static int set_constraints_impl(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const KEY *pairI, const KEY *pairJ, const double *dist, bool by_gid)
 {
-   if (!ctx || ngroups < 0 || (ngroups > 0 && (!pair_off || !pairI || !pairJ || !dist))) return DDCMI_EINVAL;
+   ARGCHK(ctx, ngroups < 0 || (ngroups > 0 && (!pair_off || !pairI || !pairJ || !dist)), "ddcmi_set_constraints: %d groups%s", ngroups, ngroups < 0 ? "" : ", an array is NULL");
+   if (ngroups > 0) { int rco = check_offsets(ctx, "ddcmi_set_constraints", "pair_off", pair_off, ngroups); if (rco) return rco; }
+   int amax = -1;
+   if (ngroups > 0 && !by_gid)
+      for (int k = 0; k < pair_off[ngroups]; k++)
+      {
+         if ((long long)pairI[k] < 0 || (long long)pairJ[k] < 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_constraints: pair %d names a negative bead index", k);
+         amax = std::max(amax, (int)std::max(pairI[k], pairJ[k]));
+      }
+   if (amax >= 0 && ctx->nloc > 0 && amax >= ctx->nloc) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_constraints: a pair names bead %d, the uploaded state holds %d", amax, ctx->nloc);
    if (ngroups > 0 && !by_gid && (ctx->group_ || ctx->nranks > 1))
       SETERR(ctx, DDCMI_EINVAL, "with several domains constraint groups must be given by gid (ddcmi_set_constraints_gid): caller-order indices do not survive migration");
    (void)hipSetDevice(ctx->device);
-   ctx->ncgroup = 0; ctx->ncpair = 0; ctx->cons_gid = false; ctx->cg_natom = 0;
+   ctx->ncgroup = 0; ctx->ncpair = 0; ctx->cons_gid = false; ctx->cg_natom = 0; ctx->idx_amax_cons = -1;
    if (ngroups == 0) return DDCMI_OK;
    /* group-local atom lists (CONSTRAINT.atomIDList, bioMartini.c:405-425): pairs name positions in them */
    std::vector<int> aoff(ngroups + 1, 0);
@@ -1082,7 +1102,7 @@ static int set_constraints_impl(ddcmi_ctx *ctx, int ngroups, const int *pair_off
       const int base = (int)alist.size();
       for (int k = pair_off[g]; k < pair_off[g + 1]; k++)
       {
-         if (pairI[k] == pairJ[k] || !(dist[k] > 0.0)) SETERR(ctx, DDCMI_EINVAL, "constraint %d of group %d: atoms %lld %lld, distance %g", k - pair_off[g], g, (long long)pairI[k], (long long)pairJ[k], dist[k]);
+         if (pairI[k] == pairJ[k] || !(dist[k] > 0.0) || !std::isfinite(dist[k])) SETERR(ctx, DDCMI_EINVAL, "constraint %d of group %d: atoms %lld %lld, distance %g", k - pair_off[g], g, (long long)pairI[k], (long long)pairJ[k], dist[k]);
          int loc[2];
          for (int e = 0; e < 2; e++)
          {
@@ -1111,7 +1131,7 @@ static int set_constraints_impl(ddcmi_ctx *ctx, int ngroups, const int *pair_off
    ENSURE(ctx, ctx->cons_status, 4);
    HIPCHK(ctx, hipMemsetAsync(ctx->cons_status.p, 0, 4 * sizeof(int), ctx->stream));
    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-   ctx->ncgroup = ngroups; ctx->ncpair = np_tot; ctx->cons_maxA = maxA; ctx->cons_maxP = maxP;
+   ctx->ncgroup = ngroups; ctx->ncpair = np_tot; ctx->cons_maxA = maxA; ctx->cons_maxP = maxP; ctx->idx_amax_cons = amax;
    return DDCMI_OK;
 }
 extern "C" int ddcmi_set_constraints(ddcmi_ctx *ctx, int ngroups, const int *pair_off, const int *pairI, const int *pairJ, const double *dist)
@@ -1304,7 +1324,10 @@ __global__ __launch_bounds__(256) void k_mol_split_term(int nmol, const int *__r
 
 extern "C" int ddcmi_set_molecule_lists_gid(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const uint64_t *mol_atom_gid, const double *mol_mass)
 {
-   if (!ctx || nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atom_gid || !mol_mass))) return DDCMI_EINVAL;
+   ARGCHK(ctx, nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atom_gid || !mol_mass)), "ddcmi_set_molecule_lists_gid: %ld molecules, %d of several beads%s", nmol_total, nmulti, (nmol_total < 0 || nmulti < 0) ? "" : ", an array is NULL");
+   if (nmulti > 0) { int rco = check_offsets(ctx, "ddcmi_set_molecule_lists_gid", "mol_off", mol_off, nmulti); if (rco) return rco; }
+   for (int m = 0; m < nmulti; m++)
+      if (!(mol_mass[m] > 0.0) || !std::isfinite(mol_mass[m])) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_molecule_lists_gid: molecule %d has mass %g", m, mol_mass[m]);
    (void)hipSetDevice(ctx->device);
    int rc;
    ctx->nmol_total = nmol_total; ctx->nmol_multi = 0; ctx->molv_valid = false; ctx->mol_gid = true; ctx->mol_natom = 0; ctx->nsplit = 0; ctx->list_valid = false;
@@ -1370,9 +1393,18 @@ int ddcmi_mol_split_term(ddcmi_ctx *ctx, double out[3])
 
 extern "C" int ddcmi_set_molecule_lists(ddcmi_ctx *ctx, long nmol_total, int nmulti, const int *mol_off, const int *mol_atoms)
 {
-   if (!ctx || nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atoms))) return DDCMI_EINVAL;
+   ARGCHK(ctx, nmol_total < 0 || nmulti < 0 || (nmulti > 0 && (!mol_off || !mol_atoms)), "ddcmi_set_molecule_lists: %ld molecules, %d of several beads%s", nmol_total, nmulti, (nmol_total < 0 || nmulti < 0) ? "" : ", an array is NULL");
+   if (nmulti > 0) { int rco = check_offsets(ctx, "ddcmi_set_molecule_lists", "mol_off", mol_off, nmulti); if (rco) return rco; }
+   int amax = -1;
+   for (int k = 0; nmulti > 0 && k < mol_off[nmulti]; k++)
+   {
+      if (mol_atoms[k] < 0) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_molecule_lists: entry %d names a negative bead index", k);
+      amax = std::max(amax, mol_atoms[k]);
+   }
+   if (amax >= 0 && ctx->nloc > 0 && amax >= ctx->nloc) SETERR(ctx, DDCMI_EINVAL, "ddcmi_set_molecule_lists: a molecule names bead %d, the uploaded state holds %d", amax, ctx->nloc);
    (void)hipSetDevice(ctx->device);
    int rc;
+   ctx->idx_amax_mol = amax;
    ctx->nmol_total = nmol_total; ctx->nmol_multi = 0; ctx->molv_valid = false; ctx->mol_gid = false; ctx->nsplit = 0;
    if (nmulti > 0)
    {

@@ -814,8 +814,8 @@ extern "C" int ddcmi_set_group_temperature(ddcmi_ctx *ctx, int group, double Teq
 }
 extern "C" int ddcmi_set_barostat(ddcmi_ctx *ctx, double T, double P0, double beta, double tau)
 {
-   ARGCHK(ctx, !(beta >= 0.0) || !std::isfinite(beta) || (beta > 0.0 && (!(tau > 0.0) || !std::isfinite(tau) || !std::isfinite(T) || !std::isfinite(P0))),
-          "ddcmi_set_barostat: beta = %g must be >= 0 (0 = off) and, when on, tau = %g > 0 with finite T = %g and P0 = %g", beta, tau, T, P0);
+   ARGCHK(ctx, !(beta >= 0.0) || !std::isfinite(beta) || (beta > 0.0 && (!(tau > 0.0) || !std::isfinite(tau) || !(T >= 0.0) || !std::isfinite(T) || !std::isfinite(P0))),
+          "ddcmi_set_barostat: beta = %g must be >= 0 (0 = off) and, when on, tau = %g > 0 with finite T = %g >= 0 and P0 = %g", beta, tau, T, P0);
    if (beta > 0.0)
    {
       if (ctx->nranks > 1 || ctx->group_) SETERR(ctx, DDCMI_EUNSUPPORTED, "the barostat is implemented for a single domain");

@@ -258,6 +258,7 @@ struct ddcmi_ctx
    dbuf<int> mol_off, mol_atoms;
    dbuf<uint64_t> rest_gid; dbuf<int> rest_fc, rest_slot; dbuf<double> rest_r0, rest_kb;
    /* rows of the bead-parallel bonded kernel (atom -> its terms), built once in ddcmi_set_bonded[_gid] */
+   int idx_amax_cons = -1, idx_amax_mol = -1;      /* largest caller index the index-named constraint groups / molecule lists use: checked against the bead count at the rebuild */
    int inc_nrow = 0, inc_heavy = 0, inc_light = 0, inc_lanes = 0, inc_hlanes = 0; dbuf<int> inc_boff, inc_aoff, inc_haoff, inc_toff, inc_brow, inc_arow, inc_harow, inc_trow, inc_hatoms, inc_latoms, inc_ldesc, inc_hdesc, inc_tab, inc_htab; int inc_tab_pieces[2] = {0, 0}, inc_tab_off[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; dbuf<double> inc_bpar, inc_apar, inc_tpar;
    bool bonded_gid = false;
    int natom_g = 0; dbuf<uint64_t> atom_gid;      /* sorted gids of the atoms that occur in terms: an atom's number is its place here */

@@ -208,6 +208,10 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
             SETERR(ctx, DDCMI_EINVAL, "species %d: molecule type %d outside the %d types of ddcmi_set_molecules", sp, ctx->moltype[sp], ctx->nmoltype);
    if (!ctx->bonded_gid && ctx->inc_nrow > ctx->nloc && ctx->nranks == 1 && !ctx->loopback && !ctx->group_)
       SETERR(ctx, DDCMI_EINVAL, "a bonded term of ddcmi_set_bonded names bead %d, the uploaded state holds %d", ctx->inc_nrow - 1, ctx->nloc);
+   if (!ctx->cons_gid && ctx->ncgroup > 0 && ctx->idx_amax_cons >= ctx->nloc)
+      SETERR(ctx, DDCMI_EINVAL, "a constraint pair of ddcmi_set_constraints names bead %d, the uploaded state holds %d", ctx->idx_amax_cons, ctx->nloc);
+   if (!ctx->mol_gid && ctx->nmol_multi > 0 && ctx->idx_amax_mol >= ctx->nloc)
+      SETERR(ctx, DDCMI_EINVAL, "a molecule of ddcmi_set_molecule_lists names bead %d, the uploaded state holds %d", ctx->idx_amax_mol, ctx->nloc);
    (void)hipSetDevice(ctx->device);
    int rc;
    ctx->pack_fresh = false;      /* (the rebuild's own exchange reuses the send buffer) */

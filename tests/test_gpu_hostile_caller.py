@@ -76,6 +76,30 @@ CASES = [
 ]
 
 
+def test_wrong_constraint_and_molecule_tables_are_refused(lipid):
+    """the index-named tables of the nglfconstraint path: offsets out of order, beads the state does not hold"""
+    md = martini.MartiniHIP(lipid)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    P, D = martini.ctypes.POINTER(martini.ctypes.c_int), martini.ctypes.POINTER(martini.ctypes.c_double)
+    ip = lambda a: a.ctypes.data_as(P)
+    try:
+        dist = np.array([7.0, 7.0, 7.0])
+        for off, pi, pj, msg in (([0, 2, 1], [0, 1, 2], [1, 2, 3], b"pair_off decreases"), ([1, 2, 3], [0, 1, 2], [1, 2, 3], b"pair_off[0]"),
+                                 ([0, 1, 3], [0, 1, lipid.natoms], [1, 2, 3], b"names bead"), ([0, 1, 3], [0, -1, 2], [1, 2, 3], b"negative bead")):
+            o, a, b = i32(off), i32(pi), i32(pj)
+            rc = md.lib.ddcmi_set_constraints(md.ctx, 2, ip(o), ip(a), ip(b), dist.ctypes.data_as(D))
+            assert rc != 0 and msg in md.lib.ddcmi_last_error(md.ctx), md.lib.ddcmi_last_error(md.ctx)
+        for off, at, msg in (([0, 3, 2], [0, 1, 2], b"mol_off decreases"), ([0, 2, 3], [0, 1, 1 << 30], b"names bead"), ([0, 2, 3], [0, -4, 2], b"negative bead")):
+            o, a = i32(off), i32(at)
+            rc = md.lib.ddcmi_set_molecule_lists(md.ctx, 100, 2, ip(o), ip(a))
+            assert rc != 0 and msg in md.lib.ddcmi_last_error(md.ctx), md.lib.ddcmi_last_error(md.ctx)
+        rc = md.lib.ddcmi_set_barostat(md.ctx, -1.0, 0.0, 1.0, 1000.0)
+        assert rc != 0 and b"ddcmi_set_barostat" in md.lib.ddcmi_last_error(md.ctx)
+        md.eval_forces()      # the context still runs
+    finally:
+        md.close()
+
+
 @pytest.mark.parametrize("what,f,msg", CASES, ids=[c[0].replace(" ", "_") for c in CASES])
 def test_wrong_argument_is_refused_with_a_message(lipid, what, f, msg):
     s, t = _mut(lipid, f)
@@ -106,9 +130,9 @@ def test_a_refused_call_leaves_the_context_usable(lipid):
 
 
 def test_one_pass_of_the_hostile_caller_fuzz():
-    """tools/fuzz_abi.py: 216 systems with one wrong argument each, set up, evaluated and stepped across a rebuild in child processes:
-    none of them may kill or hang its process"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_abi.py"), "216", "7"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    """tools/fuzz_abi.py: 283 systems with one wrong argument each (216 on the lipid deck / a water box, 67 on the relaxed deck with constraint
+    groups, the barostat and restraints), set up, evaluated and stepped across a rebuild in child processes: none of them may kill or hang its process"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_abi.py"), "283", "7"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(r.stdout.strip().splitlines()[-8:])
     assert r.returncode == 0 and "0 killed or hung" in tail, tail + r.stderr[-2000:]
     assert r.stdout.count(" -> REFUSED ") > 100 and r.stdout.count(" -> OK ") > 30, tail

@@ -129,6 +129,41 @@ def mutations():
     m("exclude_all_terms")(lambda s, rnd, t: setattr(s, "excludePotentialTerm", 255))
     m("exclude_garbage")(lambda s, rnd, t: setattr(s, "excludePotentialTerm", -1))
     m("control")(lambda s, rnd, t: None)
+    # ---- family "npt": the relaxed lipid deck with constraint groups, the barostat on the molecular pressure and restraints
+    # (t["cons"] = [pair_off, pairI, pairJ, dist] of martini.expand_constraints, t["mols"] = [nmol_total, mol_off, mol_atoms] of martini.molecule_lists)
+    m("npt_control")(lambda s, rnd, t: None)
+    m("npt_cons_pair_off_unsorted")(lambda s, rnd, t: t["cons"][0].__setitem__(rnd.randrange(1, t["cons"][0].size - 1), 1 << 20))
+    m("npt_cons_pair_off_neg")(lambda s, rnd, t: t["cons"][0].__setitem__(rnd.randrange(1, t["cons"][0].size), -5))
+    m("npt_cons_pair_off_first")(lambda s, rnd, t: t["cons"][0].__setitem__(0, 3))
+    for v, vt in ((None, "n"), (-1, "m1"), (1 << 30, "big")):
+        m("npt_cons_pairI_" + vt)(lambda s, rnd, t, v=v: t["cons"][1].__setitem__(rnd.randrange(t["cons"][1].size), s.natoms if v is None else v))
+        m("npt_cons_pairJ_" + vt)(lambda s, rnd, t, v=v: t["cons"][2].__setitem__(rnd.randrange(t["cons"][2].size), s.natoms if v is None else v))
+        m("npt_mol_atoms_" + vt)(lambda s, rnd, t, v=v: t["mols"][2].__setitem__(rnd.randrange(t["mols"][2].size), s.natoms if v is None else v))
+    m("npt_cons_pair_self")(lambda s, rnd, t: t["cons"][2].__setitem__(5, t["cons"][1][5]))
+    m("npt_cons_far_partner")(lambda s, rnd, t: t["cons"][2].__setitem__(0, int(np.argmax((s.rx - s.rx[t["cons"][1][0]]) ** 2))))
+    for v, vt in ((0.0, "zero"), (-1.0, "neg"), (float("nan"), "nan"), (float("inf"), "inf"), (1e4, "1e4"), (1e-9, "tiny")):
+        m("npt_cons_dist_" + vt)(lambda s, rnd, t, v=v: t["cons"][3].__setitem__(rnd.randrange(t["cons"][3].size), v))
+    m("npt_mol_off_unsorted")(lambda s, rnd, t: t["mols"][1].__setitem__(rnd.randrange(1, t["mols"][1].size - 1), 1 << 20))
+    m("npt_mol_off_neg")(lambda s, rnd, t: t["mols"][1].__setitem__(rnd.randrange(1, t["mols"][1].size), -2))
+    m("npt_mol_off_first")(lambda s, rnd, t: t["mols"][1].__setitem__(0, 2))
+    m("npt_nmol_neg")(lambda s, rnd, t: t["mols"].__setitem__(0, -3))
+    m("npt_nmol_zero")(lambda s, rnd, t: t["mols"].__setitem__(0, 0))
+    m("npt_mol_dup_atom")(lambda s, rnd, t: t["mols"][2].__setitem__(1, t["mols"][2][0]))
+    for fld in ("npt_T", "npt_P0", "npt_beta", "npt_tau"):
+        for v, vt in ((0.0, "zero"), (-1.0, "neg"), (float("nan"), "nan"), (float("inf"), "inf"), (1e30, "1e30")):
+            m("%s_%s" % (fld, vt))(lambda s, rnd, t, fld=fld, v=v: setattr(s, fld, v))
+    m("npt_rest_gid_unknown")(lambda s, rnd, t: s.rest_gid.__setitem__(rnd.randrange(s.nrest), np.uint64(0x7fffffff) << np.uint64(32)))
+    m("npt_rest_gid_dup")(lambda s, rnd, t: s.rest_gid.__setitem__(1, s.rest_gid[0]))
+    for v, vt in ((float("nan"), "nan"), (float("inf"), "inf"), (-1.0, "neg"), (1e30, "1e30")):
+        m("npt_rest_kb_" + vt)(lambda s, rnd, t, v=v: s.rest_kb.__setitem__(rnd.randrange(s.nrest), v))
+        m("npt_rest_r0_" + vt)(lambda s, rnd, t, v=v: s.rest_r0.reshape(-1).__setitem__(rnd.randrange(s.rest_r0.size), v))
+    for v in (-1, 2, 1 << 30):
+        m("npt_rest_fc_%d" % v)(lambda s, rnd, t, v=v: s.rest_fc.reshape(-1).__setitem__(rnd.randrange(s.rest_fc.size), v))
+        m("npt_rest_origin_%d" % v)(lambda s, rnd, t, v=v: setattr(s, "rest_origin", v))
+    m("npt_nrest_neg")(lambda s, rnd, t: setattr(s, "nrest", -1))
+    m("npt_pos_nan")(lambda s, rnd, t: s.rx.__setitem__(pick(s, rnd), float("nan")))
+    m("npt_vel_huge")(lambda s, rnd, t: s.vx.__setitem__(pick(s, rnd), 1.0e3))
+    m("npt_dt_1e6")(lambda s, rnd, t: setattr(s, "dt", 1e6))
     return M
 
 
@@ -138,6 +173,21 @@ def base_setup(which):
     from ddcmd_amd.synth import make_water_setup
     if which == "lipid":
         s = load_deck(os.path.join(ROOT, "tests", "golden", "lipid_deck", "object.data"))
+    elif which == "npt":
+        from ddcmd_amd.deck import units_convert
+        # the constraint lists tests/test_oracle.py adds to the deck's residues (a triangle and a pair in TSTM, the glycerol pair in DPPC)
+        CONSTRAINT_X = ("TSTM RESIPARMS { constraintList = TSTM_cl0 TSTM_cl1; } TSTM_cl0 CONSLISTPARMS { constraintSubList = TSTM_c0 TSTM_c1 TSTM_c2; } "
+                        "TSTM_cl1 CONSLISTPARMS { constraintSubList = TSTM_c3; } TSTM_c0 CONSPARMS { atomI=0; atomJ=1; func=1; r0=0.40 nm; } "
+                        "TSTM_c1 CONSPARMS { atomI=1; atomJ=2; func=1; r0=0.40 nm; } TSTM_c2 CONSPARMS { atomI=0; atomJ=2; func=1; r0=0.655 nm; } "
+                        "TSTM_c3 CONSPARMS { atomI=3; atomJ=4; func=1; r0=0.40 nm; } DPPC RESIPARMS { constraintList = DPPC_cl0; } "
+                        "DPPC_cl0 CONSLISTPARMS { constraintSubList = DPPC_c0; } DPPC_c0 CONSPARMS { atomI=2; atomJ=3; func=1; r0=0.37 nm; } ")
+        deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+        extra = CONSTRAINT_X + " system SYSTEM { potential = martini restraintPot; } restraintPot POTENTIAL { type = RESTRAINT; parmfile = restraint.data; }"
+        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=extra)
+        s.npt_T, s.npt_P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
+        s.npt_beta, s.npt_tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
+        s.rest_gid = np.array(s.rest_gid, dtype=np.uint64); s.rest_kb = np.array(s.rest_kb, dtype=np.float64)
+        s.rest_r0 = np.ascontiguousarray(s.rest_r0, dtype=np.float64); s.rest_fc = np.ascontiguousarray(s.rest_fc, dtype=np.int32)
     else:
         s = make_water_setup(7, temperature_K=300.0)
     for a in ("rx", "ry", "rz", "vx", "vy", "vz", "h", "mass", "charge", "sigma", "eps", "shift", "group_Teq", "group_tau"):
@@ -153,25 +203,34 @@ def child(seed, lo, hi):
     import numpy as np
     import ddcmd_amd.martini as martini
     M = mutations()
-    bases = {w: base_setup(w) for w in ("lipid", "water")}
+    bases = {w: base_setup(w) for w in ("lipid", "water", "npt")}
     for case in range(lo, hi):
         rnd = random.Random(seed * 1000003 + case)
         name, f = M[case % len(M)]
         which = rnd.choice(["lipid", "lipid", "water"])
-        if name.split("_")[0] in ("bond", "angle", "tors", "mol", "bpair", "bpairI", "bpairJ", "moltype", "charge", "krf", "crf", "keR"):
+        if name.startswith("npt_"):
+            which = "npt"
+        elif name.split("_")[0] in ("bond", "angle", "tors", "mol", "bpair", "bpairI", "bpairJ", "moltype", "charge", "krf", "crf", "keR"):
             which = "lipid"      # (the water box has no terms, no molecule tables and no charges: the mutation would change nothing)
         s = copy.deepcopy(bases[which])
         terms0 = {k: np.array(v) for k, v in martini.expand_bonded_terms(bases[which]).items()}
+        if which == "npt":
+            terms0["cons"] = [np.array(a) for a in martini.expand_constraints(bases[which])]
+            terms0["mols"] = list(martini.molecule_lists(bases[which]))
+            terms0["mols"][1:] = [np.array(a) for a in terms0["mols"][1:]]
         print("case %d %s %s ..." % (case, which, name), flush=True)
         out = "OK"
         try:
             f(s, rnd, terms0)
-            orig = martini.expand_bonded_terms
+            orig = (martini.expand_bonded_terms, martini.expand_constraints, martini.molecule_lists)
             martini.expand_bonded_terms = lambda _s, t=terms0: t
+            if which == "npt":
+                martini.expand_constraints = lambda _s, t=terms0: tuple(t["cons"])
+                martini.molecule_lists = lambda _s, t=terms0: tuple(t["mols"])
             try:
-                md = martini.MartiniHIP(s)
+                md = martini.MartiniHIP(s, constraints=(which == "npt"))
             finally:
-                martini.expand_bonded_terms = orig
+                martini.expand_bonded_terms, martini.expand_constraints, martini.molecule_lists = orig
             try:
                 e, _ = md.eval_forces()
                 md.step(STEPS)
