@@ -321,8 +321,12 @@ static int mg_ensure_owned(ddcmi_ctx *ctx, size_t need)
    if (ctx->lcg_on && (ctx->lcg.ensure(want + 1, true, st) || ctx->lcg2.ensure(want + 1))) SETERR(ctx, DDCMI_ENOMEM, "growing the LCG64 records to %zu failed", want);
    dbuf<int> *i1[] = {&ctx->species, &ctx->group, &ctx->orig};
    for (auto b : i1) if (b->ensure(want + 1, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
-   dbuf<int> *i2[] = {&ctx->species2, &ctx->group2, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->nimg, &ctx->img_off, &ctx->keep};
+   dbuf<int> *i2[] = {&ctx->species2, &ctx->group2, &ctx->orig2, &ctx->slot_of_orig, &ctx->cid, &ctx->crank, &ctx->order, &ctx->nimg, &ctx->img_off};
    for (auto b : i2) if (b->ensure(want + 1)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
+   /* keep[]: written by the migration's first phase, read by its second -- which is where a rank that receives more beads than it has room for grows
+    * its arrays.  Grown without its contents (rounds 2-6) the second phase compacted by whatever the new allocation held: a memory fault or lost beads
+    * on the first rank whose bead count outgrew its first rebuild's headroom (25 % + 4096) between two rebuilds (tools/fuzz_abi.py, round 6) */
+   if (ctx->keep.ensure(want + 1, true, st)) SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
    if (ctx->pos.ensure(want, true, st) || ctx->pos2.ensure(want) || ctx->gid.ensure(want, true, st) || ctx->gid2.ensure(want))
       SETERR(ctx, DDCMI_ENOMEM, "growing bead arrays to %zu failed", want);
    return DDCMI_OK;
@@ -780,6 +784,7 @@ static int mg_phase1_migrate_out(ddcmi_ctx *ctx)
    bl_drop_interior(ctx);      /* (in-process groups enter the rebuild here: see ddcmi_build_list) */
    hipStream_t st = ctx->stream;
    int rc;
+   if ((rc = bl_validate_tables(ctx))) return rc;
    for (;;)
    {
       if ((rc = mg_phase1_launch(ctx))) return rc;
@@ -851,8 +856,15 @@ static int mg_halo_select(ddcmi_ctx *ctx)
    for (;;)
    {
       if ((rc = mg_halo_select_launch(ctx))) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(ctx->hs_cnt, ctx->dir_cnt.p, 27 * sizeof(int), hipMemcpyDeviceToHost, st));
+      int h[32];
+      HIPCHK(ctx, hipMemcpyAsync(h, ctx->dir_cnt.p, 32 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(ctx, hipStreamSynchronize(st));
+      memcpy(ctx->hs_cnt, h, 27 * sizeof(int));
+      /* the sort's "these beads are not numbers" count (slot 30, k_wrap_cell): a transport's ranks learn of it in the halo count round; the domains of a
+       * group stop here too -- before a neighbour files such a bead into a halo cell (tools/fuzz_abi.py: an LJ table entry of 1e30 on 2x2x2 bricks) */
+      if (h[30] > 0)
+         SETERR(ctx, DDCMI_EINVAL, "%d beads have non-finite coordinates or lie more than a box length outside the box at loop %lld: the run is unstable (time step, overlapping start, singular bonded term?)",
+                h[30], (long long)ctx->loop);
       int mx = 0;
       for (int c = 0; c < 27; c++) mx = std::max(mx, ctx->hs_cnt[c]);
       if (mx <= ctx->hs_cap) break;

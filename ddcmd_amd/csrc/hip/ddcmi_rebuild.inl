@@ -189,6 +189,24 @@ int ddcmi_ensure_slots(ddcmi_ctx *ctx)
 static int bl_launch_interior(ddcmi_ctx *ctx);
 static NbLds nb_lds_layout(const ddcmi_ctx *ctx, bool fused);
 int ddcmi_lean_flush(ddcmi_ctx *ctx);
+/* what the setters could not check one by one (they may come in any order): every species' molecule type has its entry in the molecule
+ * tables, every index-named term, constraint pair and molecule names a bead of the uploaded state -- the search and the bonded kernels index
+ * with them.  Every rebuild starts here: ddcmi_build_list, and the first phase of a decomposed rank's or an in-process group's rebuild. */
+static int bl_validate_tables(ddcmi_ctx *ctx)
+{
+   if (ctx->nmoltype > 0)
+      for (int sp = 0; sp < ctx->nspecies; sp++)
+         if (ctx->moltype[sp] < 0 || ctx->moltype[sp] >= ctx->nmoltype)
+            SETERR(ctx, DDCMI_EINVAL, "species %d: molecule type %d outside the %d types of ddcmi_set_molecules", sp, ctx->moltype[sp], ctx->nmoltype);
+   const bool one = ctx->nranks == 1 && !ctx->loopback && !ctx->group_;      /* (several domains: index-named tables are refused where they are set) */
+   if (one && !ctx->bonded_gid && ctx->inc_nrow > ctx->nloc)
+      SETERR(ctx, DDCMI_EINVAL, "a bonded term of ddcmi_set_bonded names bead %d, the uploaded state holds %d", ctx->inc_nrow - 1, ctx->nloc);
+   if (one && !ctx->cons_gid && ctx->ncgroup > 0 && ctx->idx_amax_cons >= ctx->nloc)
+      SETERR(ctx, DDCMI_EINVAL, "a constraint pair of ddcmi_set_constraints names bead %d, the uploaded state holds %d", ctx->idx_amax_cons, ctx->nloc);
+   if (one && !ctx->mol_gid && ctx->nmol_multi > 0 && ctx->idx_amax_mol >= ctx->nloc)
+      SETERR(ctx, DDCMI_EINVAL, "a molecule of ddcmi_set_molecule_lists names bead %d, the uploaded state holds %d", ctx->idx_amax_mol, ctx->nloc);
+   return DDCMI_OK;
+}
 static void bl_drop_interior(ddcmi_ctx *ctx);
 extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
 {
@@ -200,18 +218,7 @@ extern "C" int ddcmi_build_list(ddcmi_ctx *ctx)
    { int rcl = ddcmi_lean_flush(ctx); if (rcl) return rcl; }      /* (the pending steps' rows are as many as this list's work items) */
    if (!ctx->have_box || ctx->nlj <= 0 || ctx->updateRate < 0 || (ctx->nloc <= 0 && ctx->nranks == 1))
       SETERR(ctx, DDCMI_EINVAL, "ddcmi_build_list needs box, nonbonded parameters, neighbor settings and an uploaded state");
-   /* what the setters could not check one by one (they may come in any order): every species' molecule type has its entry in the molecule
-    * tables, every index-named bonded term names a bead of the uploaded state -- the search and the bonded kernels index with them */
-   if (ctx->nmoltype > 0)
-      for (int sp = 0; sp < ctx->nspecies; sp++)
-         if (ctx->moltype[sp] < 0 || ctx->moltype[sp] >= ctx->nmoltype)
-            SETERR(ctx, DDCMI_EINVAL, "species %d: molecule type %d outside the %d types of ddcmi_set_molecules", sp, ctx->moltype[sp], ctx->nmoltype);
-   if (!ctx->bonded_gid && ctx->inc_nrow > ctx->nloc && ctx->nranks == 1 && !ctx->loopback && !ctx->group_)
-      SETERR(ctx, DDCMI_EINVAL, "a bonded term of ddcmi_set_bonded names bead %d, the uploaded state holds %d", ctx->inc_nrow - 1, ctx->nloc);
-   if (!ctx->cons_gid && ctx->ncgroup > 0 && ctx->idx_amax_cons >= ctx->nloc)
-      SETERR(ctx, DDCMI_EINVAL, "a constraint pair of ddcmi_set_constraints names bead %d, the uploaded state holds %d", ctx->idx_amax_cons, ctx->nloc);
-   if (!ctx->mol_gid && ctx->nmol_multi > 0 && ctx->idx_amax_mol >= ctx->nloc)
-      SETERR(ctx, DDCMI_EINVAL, "a molecule of ddcmi_set_molecule_lists names bead %d, the uploaded state holds %d", ctx->idx_amax_mol, ctx->nloc);
+   { int rcv = bl_validate_tables(ctx); if (rcv) return rcv; }
    (void)hipSetDevice(ctx->device);
    int rc;
    ctx->pack_fresh = false;      /* (the rebuild's own exchange reuses the send buffer) */

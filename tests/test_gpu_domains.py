@@ -417,3 +417,56 @@ def test_decomposed_rows_end_at_the_last_shell_that_can_matter(monkeypatch, vsca
         assert ea["total"] == eb["total"] and rka == rkb
         assert abs(ea["total"] - eo["total"]) < TOL * abs(eo["total"]) and abs(rka - rko) < TOL * max(rko, 1e-300)
     a.close(); b.close()
+
+
+def test_a_domain_grows_its_arrays_in_the_middle_of_a_migration():
+    """2x1x1 bricks, free faces in y.  Three groups of water beads more than a list radius apart in y: a slab (half the beads) that fills the LEFT brick and
+    drifts one brick to the right per rebuild period; a thin layer at the top of the RIGHT brick that drifts with it (so it LEAVES the right brick while
+    the slab arrives); a thin layer at the bottom of the right brick that stays.  At the first rebuild after the start the right domain -- sized for its
+    two thin layers plus headroom -- receives several times its bead count, loses some and keeps some: its arrays must grow between the phase that
+    decides who leaves (keep[]) and the phase that compacts by that decision.  Until round 6 keep[] was grown WITHOUT its contents (tools/fuzz_abi.py
+    met it as a GPU memory fault).  Uniform drifts change no pair distance inside a group, so the run equals the same system on one domain."""
+    from ddcmd_amd.martini import MartiniGroup, MartiniHIP
+    s = make_water_setup(16, temperature_K=300.0)
+    L = s.h[0]
+    y = np.asarray(s.ry)
+    slab, top, bottom = np.abs(y) < 0.25 * L, y > 0.44 * L, y < -0.44 * L
+    sel = np.flatnonzero(slab | top | bottom)
+    for a in ("rx", "ry", "rz", "vx", "vy", "vz", "species", "group", "gid"):
+        setattr(s, a, np.ascontiguousarray(np.asarray(getattr(s, a))[sel]))
+    s.natoms = int(sel.size)
+    slab, top, bottom = slab[sel], top[sel], bottom[sel]
+    assert (0.25 + 0.06) * L + (s.rmax + s.deltaR) < 0.44 * L          # the groups do not see each other
+    s.h = np.array(s.h, dtype=np.float64)
+    s.h[0] = 2.0 * L                                                   # bricks of the old box's width
+    s.pbc = 5                                                          # free faces in y
+    s.rx = np.asarray(s.rx) - 0.5 * L                                  # everything in the left brick [-L, 0) ...
+    s.rx[top | bottom] += L                                            # ... but for the two thin layers
+    period = int(s.updateRate)
+    s.vx = np.asarray(s.vx).copy()
+    s.vx[slab | top] += L / (period * s.dt)                            # one brick per rebuild period
+    one = MartiniHIP(s)
+    e1, _ = one.eval_forces()
+    g = MartiniGroup(s, (2, 1, 1))
+    e0, _ = g.eval_forces()
+    n0 = list(g.gather()["nlocal"])
+    assert n0 == [int(slab.sum()), int(top.sum() + bottom.sum())] and n0[0] + n0[1] // 2 > 1.3 * n0[1] + 5000, n0
+    assert abs(e0["lj"] - e1["lj"]) < TIGHT * abs(e1["lj"])
+    for block in range(2):
+        one.step(period + 2)
+        g.step(period + 2)                                # across the rebuild at which the slab and the top layer have changed bricks
+        st = g.gather()
+        assert sum(st["nlocal"]) == s.natoms and np.array_equal(st["gid"], np.sort(s.gid)), (block, st["nlocal"])
+        ea, va, rka, _ = one.energies()
+        eb, vb, rkb, _ = g.energies()
+        assert abs(eb["lj"] - ea["lj"]) < 1e-9 * abs(ea["lj"]) and abs(rkb - rka) < 1e-9 * rka, block
+        assert np.abs(vb - va).max() < 1e-8 * np.abs(va).max(), block
+        if block == 0:
+            assert abs(st["nlocal"][1] - (int(slab.sum()) + int(bottom.sum()))) < 0.02 * s.natoms, st["nlocal"]      # slab + the layer that stayed
+    d = one.download()
+    order = np.argsort(np.asarray(s.gid), kind="stable")
+    for c in range(3):
+        dv = st["v"][c] - d["v"][c][order]
+        assert np.abs(dv).max() < 1e-9 * np.abs(d["v"][c]).max()
+    one.close()
+    g.close()

@@ -6,7 +6,7 @@ a time step that blows the system up -- is set up, evaluated and stepped across 
 message or in a result; the process must not die (a GPU memory fault, SIGSEGV, SIGFPE) and must not hang.
 
 The parent runs the cases in child processes (a GPU fault takes the process with it) and prints one line per case:
-   python3 tools/fuzz_abi.py [ncases] [seed]          # parent; cases that killed or hung their child are listed at the end, exit 1 if any
+   python3 tools/fuzz_abi.py [ncases] [seed] [first]  # parent (cases first .. ncases-1); cases that killed or hung their child are listed at the end, exit 1 if any
 """
 import copy, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,7 +122,8 @@ def mutations():
             m("%s_%d" % (key, v))(lambda s, rnd, t, key=key, v=v: t[key].size and t[key].__setitem__(rnd.randrange(t[key].size), v))
     m("mol_nspecies_neg")(lambda s, rnd, t: s.nmoltype and s.mol_nspecies.__setitem__(rnd.randrange(s.nmoltype), -4))
     m("mol_nspecies_big")(lambda s, rnd, t: s.nmoltype and s.mol_nspecies.__setitem__(rnd.randrange(s.nmoltype), 1 << 20))
-    m("bpair_off_unsorted")(lambda s, rnd, t: s.nmoltype and s.bpair_off.__setitem__(rnd.randrange(s.nmoltype + 1), 1 << 20))
+    # (not the last offset: that one IS the length of bpairI / bpairJ the caller promises -- a count larger than the arrays is nothing a C-ABI can see)
+    m("bpair_off_unsorted")(lambda s, rnd, t: s.nmoltype and s.bpair_off.__setitem__(rnd.randrange(s.nmoltype), 1 << 20))
     m("bpair_off_neg")(lambda s, rnd, t: s.nmoltype and s.bpair_off.__setitem__(rnd.randrange(s.nmoltype + 1), -3))
     m("bpairI_big")(lambda s, rnd, t: s.bpairI.size and s.bpairI.__setitem__(rnd.randrange(s.bpairI.size), 1 << 20))
     m("bpairJ_neg")(lambda s, rnd, t: s.bpairJ.size and s.bpairJ.__setitem__(rnd.randrange(s.bpairJ.size), -9))
@@ -164,6 +165,23 @@ def mutations():
     m("npt_pos_nan")(lambda s, rnd, t: s.rx.__setitem__(pick(s, rnd), float("nan")))
     m("npt_vel_huge")(lambda s, rnd, t: s.vx.__setitem__(pick(s, rnd), 1.0e3))
     m("npt_dt_1e6")(lambda s, rnd, t: setattr(s, "dt", 1e6))
+    # ---- family "dec": the lipid deck on 2x2x2 bricks (an in-process group: migration, halo selection, terms named by gid, the gid -> slot tables)
+    by_name = dict(M)
+    for n in ("control", "pos_rx_nan", "pos_rz_inf", "pos_far", "pos_many_far", "pos_collapse_all", "pos_cluster_half", "pos_overlap_pair", "vel_huge", "vel_all_huge", "vel_nan",
+              "species_big", "group_big", "moltype_big", "ljtype_big", "gid_dup", "gid_all_equal", "gid_top_bit", "box_xx_huge", "box_zz_inf", "box_under_2rlist", "pbc_0", "pbc_3", "pbc_5",
+              "dt_1e6", "dt_nan", "charge_nan", "bond_ij_self", "tors_ijkl_self", "bond_kb_1e30", "bond_b0_1e30", "angle_t0_1e30", "rmax_tiny", "rmax_1e6", "deltaR_zero", "deltaR_1e6",
+              "updateRate_0_displacement", "updateRate_1", "berendsen_tau_0", "berendsen_interval_0", "langevin_interval_0", "langevin_Teq_neg", "eps_1e30", "sigma_1e30",
+              "mol_nspecies_big", "bpairI_big", "exclude_all_terms", "natoms_one"):
+        m("dec_" + n)(by_name[n])
+
+    @m("dec_bond_partner_across_the_box")
+    def _(s, rnd, t):
+        j = int(t["bond_ij"][1])
+        s.rz[j] += 0.45 * s.h[8]      # a bond longer than the halo is wide: its partner is on no rank that holds the other bead
+
+    @m("dec_everything_in_one_brick")
+    def _(s, rnd, t):
+        s.rx[:] = 0.25 * s.h[0] + 0.2 * (s.rx - s.rx.min()) / max(np.ptp(s.rx), 1e-9) * s.h[0]
     return M
 
 
@@ -210,6 +228,8 @@ def child(seed, lo, hi):
         which = rnd.choice(["lipid", "lipid", "water"])
         if name.startswith("npt_"):
             which = "npt"
+        elif name.startswith("dec_"):
+            which = "lipid"
         elif name.split("_")[0] in ("bond", "angle", "tors", "mol", "bpair", "bpairI", "bpairJ", "moltype", "charge", "krf", "crf", "keR"):
             which = "lipid"      # (the water box has no terms, no molecule tables and no charges: the mutation would change nothing)
         s = copy.deepcopy(bases[which])
@@ -228,14 +248,18 @@ def child(seed, lo, hi):
                 martini.expand_constraints = lambda _s, t=terms0: tuple(t["cons"])
                 martini.molecule_lists = lambda _s, t=terms0: tuple(t["mols"])
             try:
-                md = martini.MartiniHIP(s, constraints=(which == "npt"))
+                md = martini.MartiniGroup(s, (2, 2, 2)) if name.startswith("dec_") else martini.MartiniHIP(s, constraints=(which == "npt"))
             finally:
                 martini.expand_bonded_terms, martini.expand_constraints, martini.molecule_lists = orig
             try:
                 e, _ = md.eval_forces()
-                md.step(STEPS)
+                if os.environ.get("FUZZ_STEPWISE"):      # (reproducing a death: which step was it?  FUZZ_STEPWISE=1 python3 tools/fuzz_abi.py --child seed case case+1)
+                    for k in range(STEPS):
+                        md.step(1); md.energies(); print("   step %d done" % (k + 1), flush=True)
+                else:
+                    md.step(STEPS)
                 e2, _, rk, _ = md.energies()
-                md.download()
+                md.gather() if name.startswith("dec_") else md.download()
                 out = "OK e_lj %.6g -> %.6g, total %.6g -> %.6g, kinetic %.6g" % (e["lj"], e2["lj"], e["total"], e2["total"], rk)
             finally:
                 md.close()
@@ -246,9 +270,9 @@ def child(seed, lo, hi):
         print("case %d %s %s -> %s" % (case, which, name, out), flush=True)
 
 
-def parent(ncases, seed):
+def parent(ncases, seed, first=0):
     died = []
-    lo = 0
+    lo = first
     while lo < ncases:
         hi = min(lo + BATCH, ncases)
         try:
@@ -270,7 +294,7 @@ def parent(ncases, seed):
             lo = k + 1
         else:
             lo = hi
-    print("%d cases: %d ended in a result or a message, %d killed or hung their process" % (ncases, ncases - len(died), len(died)))
+    print("%d cases: %d ended in a result or a message, %d killed or hung their process" % (ncases - first, ncases - first - len(died), len(died)))
     for d in died:
         print("   " + d)
     return 1 if died else 0
@@ -284,4 +308,4 @@ if __name__ == "__main__":
             for k, (n, _) in enumerate(mutations()):
                 print(k, n)
             sys.exit(0)
-        sys.exit(parent(int(sys.argv[1]) if len(sys.argv) > 1 else len(mutations()), int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+        sys.exit(parent(int(sys.argv[1]) if len(sys.argv) > 1 else len(mutations()), int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else 0))
