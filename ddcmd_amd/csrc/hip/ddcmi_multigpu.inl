@@ -1219,6 +1219,7 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
    ddcmi_group *g = ctxs[0]->group_;
    int rc;
+   ARGCHK(ctxs[0], nsteps < 0 || !std::isfinite(dt), "ddcmi_group_step_nglf: %d steps of dt = %g", nsteps, dt);
    for (ddcmi_ctx *c : g->ranks) if ((rc = mg_check_one_domain_features(c))) return rc;
    for (int s = 0; s < nsteps; s++)
    {

@@ -174,6 +174,13 @@ def mutations():
               "mol_nspecies_big", "bpairI_big", "exclude_all_terms", "natoms_one"):
         m("dec_" + n)(by_name[n])
 
+    # ---- family "lb": the same through the RCCL loopback (one rank whose periodic neighbours are reached through a 1-rank RCCL communicator: the count
+    # rounds through the mailbox, grouped ncclSend / ncclRecv, the halo staged from the receive buffer, terms by gid)
+    for n in ("control", "pos_rx_nan", "pos_rz_inf", "pos_far", "pos_many_far", "pos_collapse_all", "pos_cluster_half", "vel_huge", "vel_all_huge", "vel_nan",
+              "moltype_big", "gid_dup", "gid_all_equal", "box_xx_huge", "box_under_2rlist", "pbc_0", "pbc_3", "dt_1e6", "dt_nan", "bond_ij_self", "bond_kb_1e30",
+              "rmax_tiny", "deltaR_zero", "updateRate_0_displacement", "updateRate_1", "berendsen_tau_0", "langevin_interval_0", "eps_1e30", "sigma_1e30", "exclude_all_terms"):
+        m("lb_" + n)(by_name[n])
+
     @m("dec_bond_partner_across_the_box")
     def _(s, rnd, t):
         j = int(t["bond_ij"][1])
@@ -216,6 +223,27 @@ def base_setup(which):
     return s
 
 
+def loopback_rank(martini, s):
+    import ctypes
+    import numpy as np
+    os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
+    try:
+        md = martini.MartiniRank(s, np.arange(s.natoms))
+        try:
+            martini._declare_domains(md.lib)
+            buf = ctypes.create_string_buffer(128)
+            if md.lib.ddcmi_comm_unique_id(buf) != 0:
+                raise martini.DdcmiError("ddcmi_comm_unique_id failed")
+            md.comm_init(0, 1, buf.raw, (1, 1, 1))
+            md.upload_local()
+        except Exception:
+            md.close()
+            raise
+    finally:
+        del os.environ["DDCMI_RCCL_LOOPBACK"]
+    return md
+
+
 def child(seed, lo, hi):
     import random
     import numpy as np
@@ -228,7 +256,7 @@ def child(seed, lo, hi):
         which = rnd.choice(["lipid", "lipid", "water"])
         if name.startswith("npt_"):
             which = "npt"
-        elif name.startswith("dec_"):
+        elif name.startswith("dec_") or name.startswith("lb_"):
             which = "lipid"
         elif name.split("_")[0] in ("bond", "angle", "tors", "mol", "bpair", "bpairI", "bpairJ", "moltype", "charge", "krf", "crf", "keR"):
             which = "lipid"      # (the water box has no terms, no molecule tables and no charges: the mutation would change nothing)
@@ -248,7 +276,10 @@ def child(seed, lo, hi):
                 martini.expand_constraints = lambda _s, t=terms0: tuple(t["cons"])
                 martini.molecule_lists = lambda _s, t=terms0: tuple(t["mols"])
             try:
-                md = martini.MartiniGroup(s, (2, 2, 2)) if name.startswith("dec_") else martini.MartiniHIP(s, constraints=(which == "npt"))
+                if name.startswith("lb_"):
+                    md = loopback_rank(martini, s)
+                else:
+                    md = martini.MartiniGroup(s, (2, 2, 2)) if name.startswith("dec_") else martini.MartiniHIP(s, constraints=(which == "npt"))
             finally:
                 martini.expand_bonded_terms, martini.expand_constraints, martini.molecule_lists = orig
             try:
@@ -259,7 +290,7 @@ def child(seed, lo, hi):
                 else:
                     md.step(STEPS)
                 e2, _, rk, _ = md.energies()
-                md.gather() if name.startswith("dec_") else md.download()
+                md.gather() if name.startswith("dec_") else md.download_particles() if name.startswith("lb_") else md.download()
                 out = "OK e_lj %.6g -> %.6g, total %.6g -> %.6g, kinetic %.6g" % (e["lj"], e2["lj"], e["total"], e2["total"], rk)
             finally:
                 md.close()
