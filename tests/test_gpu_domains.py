@@ -470,3 +470,12 @@ def test_a_domain_grows_its_arrays_in_the_middle_of_a_migration():
         assert np.abs(dv).max() < 1e-9 * np.abs(d["v"][c]).max()
     one.close()
     g.close()
+
+
+def test_a_drifting_cube_of_water_swings_every_domain_between_empty_and_full():
+    """tools/soak_migration_r06.py, short: a cube of liquid in a box three times its size drifts diagonally across 2x2x2 bricks; after every rebuild
+    period the bead set is whole and ONE domain evaluating the gathered state gives the same forces and sums (1e-10; measured 1e-15)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_migration_r06.py"), "16", "12", "2,2,2"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "16 periods of" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Soak of the decomposed rebuild under strong density changes (round 6, after the keep[] bug): a cube of liquid water in a box three times its size drifts
+diagonally, one brick of a 2x2x2 (or other) grid per few rebuild periods, so every domain's bead count swings between zero and most of the system and
+every array of the migration / halo path grows at some rebuild.  After every period: the bead set is whole, and ONE domain evaluating the gathered state gives the same forces and sums (1e-10).
+   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [transport: group | loopback]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ddcmd_amd.synth import make_water_setup
+from ddcmd_amd.martini import MartiniGroup, MartiniHIP
+
+periods = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+grid = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (2, 2, 2)
+s = make_water_setup(n, temperature_K=300.0)
+L = s.h[0]
+s.h = np.array(s.h, dtype=np.float64) * 3.0
+period = int(s.updateRate)
+# 0.37 / 0.23 / 0.31 of a brick (1.5 L) per rebuild period along x / y / z: incommensurate, so the cube meets the brick faces in ever new ways
+drift = np.array([0.37, 0.23, 0.31]) * 1.5 * L / (period * s.dt)
+s.vx = np.asarray(s.vx) + drift[0]; s.vy = np.asarray(s.vy) + drift[1]; s.vz = np.asarray(s.vz) + drift[2]
+one = MartiniHIP(s)
+one.eval_forces()
+g = MartiniGroup(s, grid)
+g.eval_forces()
+gid0 = np.sort(np.asarray(s.gid))
+assert np.array_equal(gid0, np.asarray(s.gid))      # (caller order = gid order: the gathered state uploads as it is)
+worst = worst_f = 0.0
+seen_min, seen_max = [10 ** 9] * g.n, [0] * g.n
+for p in range(periods):
+    g.step(period)
+    st = g.gather()
+    assert sum(st["nlocal"]) == s.natoms and np.array_equal(st["gid"], gid0), (p, st["nlocal"])
+    for r, c in enumerate(st["nlocal"]):
+        seen_min[r] = min(seen_min[r], c); seen_max[r] = max(seen_max[r], c)
+    # the decomposed run's state on ONE domain: the same forces and sums, exactly (no trajectory between the two to part)
+    one.upload(st["r"][0], st["r"][1], st["r"][2], st["v"][0], st["v"][1], st["v"][2])
+    ea, va = one.eval_forces()
+    d = one.download()
+    eb, vb, rkb, _ = g.energies()
+    fmax = max(np.abs(d["f"][c]).max() for c in range(3))
+    ferr = max(np.abs(st["f"][c] - d["f"][c]).max() for c in range(3)) / fmax
+    err = max(abs(eb["lj"] - ea["lj"]) / abs(ea["lj"]), np.abs(vb - va).max() / np.abs(va).max())
+    worst, worst_f = max(worst, err), max(worst_f, ferr)
+    print("period %3d  beads per domain %s  e_lj %.10g  against one domain: sums %.1e, forces %.1e" % (p + 1, st["nlocal"], eb["lj"], err, ferr), flush=True)
+    assert err < 1e-10 and ferr < 1e-10, (p, err, ferr)
+print("%d periods of %d steps, %d beads on %s bricks: every domain between %s and %s beads; against one domain evaluating the same state: sums %.1e, forces %.1e"
+      % (periods, period, s.natoms, "x".join(map(str, grid)), seen_min, seen_max, worst, worst_f))
