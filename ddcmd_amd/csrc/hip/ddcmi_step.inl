@@ -144,6 +144,10 @@ static int launch_forces(ddcmi_ctx *ctx, bool defer_reduce = false, FuseArgs *fu
       const bool lean_now = lean && *lean && fuse != nullptr && ctx->ntile_class[1] <= 0 && ((ctx->nranks > 1 || ctx->loopback) ? direct : (nh == 0 || self_images(ctx))) && ctx->lean_pending < LEAN_W &&
                             ctx->lean_since < LEAN_W && (ctx->lean_since == 0 || ctx->lean_dt == fuse->dt);
       if (lean) *lean = lean_now;
+      if (has_bonded && n == 0)
+         /* a domain that holds no bead at the moment: no bonded launch -- and the sums of the last one it ran must not be reported again (until round 6 an
+          * emptied domain kept adding its last bonded energies and virial to the run's; forces were never affected.  tools/soak_migration_r06.py lipid) */
+         HIPCHK(ctx, hipMemsetAsync(ctx->d_results + R_SCR_BOND, 0, (R_SCR_MOLV - R_SCR_BOND) * sizeof(double), st));
       if (has_bonded && n > 0)
       {
          if (halo_pending) { HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_halo, 0)); halo_pending = false; }      /* bonded partners may be halo beads */

@@ -2,7 +2,7 @@
 """Soak of the decomposed rebuild under strong density changes (round 6, after the keep[] bug): a cube of liquid water in a box three times its size drifts
 diagonally, one brick of a 2x2x2 (or other) grid per few rebuild periods, so every domain's bead count swings between zero and most of the system and
 every array of the migration / halo path grows at some rebuild.  After every period: the bead set is whole, and ONE domain evaluating the gathered state gives the same forces and sums (1e-10).
-   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [transport: group | loopback]"""
+   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [water | lipid]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,20 +13,36 @@ from ddcmd_amd.martini import MartiniGroup, MartiniHIP
 periods = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 grid = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (2, 2, 2)
-s = make_water_setup(n, temperature_K=300.0)
-L = s.h[0]
-s.h = np.array(s.h, dtype=np.float64) * 3.0
+workload = sys.argv[4] if len(sys.argv) > 4 else "water"
+if workload == "lipid":
+    # the relaxed bilayer patch tiled n x n x 1 (charges, bonds, angles, dihedrals by gid: the gid -> slot tables and the term localisation swing with the beads),
+    # vacuum above and below (box x 3 in z): the membrane drifts through the z bricks and slides along x and y
+    from ddcmd_amd.deck import load_deck
+    from ddcmd_amd.synth import replicate_setup
+    deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+    s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), (n, n, 1))
+    s.h = np.array(s.h, dtype=np.float64)
+    bricks = np.array([s.h[0], s.h[4], 3.0 * s.h[8]]) / np.array(grid)
+    s.h[8] *= 3.0
+    drift = np.array([0.37, 0.23, 0.31]) * bricks / (int(s.updateRate) * s.dt)
+else:
+    s = make_water_setup(n, temperature_K=300.0)
+    L = s.h[0]
+    s.h = np.array(s.h, dtype=np.float64) * 3.0
+    # 0.37 / 0.23 / 0.31 of a brick (1.5 L) per rebuild period along x / y / z: incommensurate, so the cube meets the brick faces in ever new ways
+    drift = np.array([0.37, 0.23, 0.31]) * 1.5 * L / (int(s.updateRate) * s.dt)
 period = int(s.updateRate)
-# 0.37 / 0.23 / 0.31 of a brick (1.5 L) per rebuild period along x / y / z: incommensurate, so the cube meets the brick faces in ever new ways
-drift = np.array([0.37, 0.23, 0.31]) * 1.5 * L / (period * s.dt)
 s.vx = np.asarray(s.vx) + drift[0]; s.vy = np.asarray(s.vy) + drift[1]; s.vz = np.asarray(s.vz) + drift[2]
 one = MartiniHIP(s)
 one.eval_forces()
+traj = MartiniHIP(s)      # the same run on one domain, stepped alongside for the first periods (thermostat and all): before the two trajectories part as any two do
+traj.eval_forces()
+TRAJ_PERIODS = 10
 g = MartiniGroup(s, grid)
 g.eval_forces()
 gid0 = np.sort(np.asarray(s.gid))
 assert np.array_equal(gid0, np.asarray(s.gid))      # (caller order = gid order: the gathered state uploads as it is)
-worst = worst_f = 0.0
+worst = worst_f = worst_t = 0.0
 seen_min, seen_max = [10 ** 9] * g.n, [0] * g.n
 for p in range(periods):
     g.step(period)
@@ -41,9 +57,21 @@ for p in range(periods):
     eb, vb, rkb, _ = g.energies()
     fmax = max(np.abs(d["f"][c]).max() for c in range(3))
     ferr = max(np.abs(st["f"][c] - d["f"][c]).max() for c in range(3)) / fmax
-    err = max(abs(eb["lj"] - ea["lj"]) / abs(ea["lj"]), np.abs(vb - va).max() / np.abs(va).max())
+    err = max(max(abs(eb[k] - ea[k]) / max(abs(ea[k]), 1e-3 * abs(ea["total"])) for k in ("lj", "ele", "bond", "angle", "tors", "impr")), np.abs(vb - va).max() / np.abs(va).max())
+    rk_np = 0.5 * float(np.sum(np.asarray(s.mass)[np.asarray(s.species)] * (st["v"][0] ** 2 + st["v"][1] ** 2 + st["v"][2] ** 2)))      # (caller order = gid order)
+    err = max(err, abs(rkb - rk_np) / rk_np)
+    terr = 0.0
+    if p < TRAJ_PERIODS:
+        traj.step(period)
+        et, vt, rkt, _ = traj.energies()
+        terr = max(abs(eb["total"] - et["total"]) / abs(et["total"]), abs(rkb - rkt) / rkt)
+        assert terr < 1e-6, (p, terr)
+        worst_t = max(worst_t, terr)
     worst, worst_f = max(worst, err), max(worst_f, ferr)
-    print("period %3d  beads per domain %s  e_lj %.10g  against one domain: sums %.1e, forces %.1e" % (p + 1, st["nlocal"], eb["lj"], err, ferr), flush=True)
+    print("period %3d  beads per domain %s  e_lj %.10g  against one domain: sums %.1e, forces %.1e%s" % (p + 1, st["nlocal"], eb["lj"], err, ferr, ", trajectory %.1e" % terr if p < TRAJ_PERIODS else ""), flush=True)
+    if not (err < 1e-10 and ferr < 1e-10):
+        print("   one domain:", {k: "%.12g" % v for k, v in ea.items()}, "virial", va)
+        print("   the bricks:", {k: "%.12g" % v for k, v in eb.items()}, "virial", vb)
     assert err < 1e-10 and ferr < 1e-10, (p, err, ferr)
-print("%d periods of %d steps, %d beads on %s bricks: every domain between %s and %s beads; against one domain evaluating the same state: sums %.1e, forces %.1e"
-      % (periods, period, s.natoms, "x".join(map(str, grid)), seen_min, seen_max, worst, worst_f))
+print("%d periods of %d steps, %d beads on %s bricks: every domain between %s and %s beads; against one domain evaluating the same state: sums %.1e, forces %.1e; against the one-domain run over the first %d periods: %.1e"
+      % (periods, period, s.natoms, "x".join(map(str, grid)), seen_min, seen_max, worst, worst_f, TRAJ_PERIODS, worst_t))
