@@ -38,7 +38,16 @@ one.eval_forces()
 traj = MartiniHIP(s)      # the same run on one domain, stepped alongside for the first periods (thermostat and all): before the two trajectories part as any two do
 traj.eval_forces()
 TRAJ_PERIODS = 10
-g = MartiniGroup(s, grid)
+class OneDomain(object):
+    """grid 1,1,1: the plain one-domain context under the same checks (the lean step, images staged from their owners, the shell-limited walk under a
+    large uniform drift) -- against a second context that evaluates the downloaded state afresh"""
+    def __init__(self, s):
+        self.m, self.n, self.s = MartiniHIP(s), 1, s
+        self.step, self.energies, self.eval_forces = self.m.step, self.m.energies, self.m.eval_forces
+    def gather(self):
+        d = self.m.download()
+        return {"gid": np.asarray(self.s.gid), "nlocal": [self.s.natoms], "r": d["r"], "v": d["v"], "f": d["f"]}
+g = OneDomain(s) if grid == (1, 1, 1) else MartiniGroup(s, grid)
 g.eval_forces()
 gid0 = np.sort(np.asarray(s.gid))
 assert np.array_equal(gid0, np.asarray(s.gid))      # (caller order = gid order: the gathered state uploads as it is)
