@@ -21,6 +21,10 @@ def main():
     cons = False
     if workload in ("water", "water_fault", "water_preflight"):
         s = ddcmd_amd.make_water_setup(12)
+    elif workload in ("water_drift", "lipid_drift"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from drift_setup import drifting_setup      # (the parent runs the same system on one domain)
+        s = drifting_setup(workload, grid)
     else:
         from ddcmd_amd.deck import load_deck, units_convert
         deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")

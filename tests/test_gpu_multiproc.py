@@ -362,3 +362,38 @@ def test_bench_rows_child_runs_eight_workloads_in_one_process():
         assert r["value"] > 0 and r["steps_timed"] >= 100 and r["roofline"]["frac"] > 0.1
     bricks = [r for r in rows["also"] if r["comm"]]
     assert len(bricks) == 3 and all(b["comm"]["preflight_rank0"]["stages_verified"] == 3 and b["comm"]["transport"] == "rccl-loopback" for b in bricks)
+
+
+@pytest.mark.parametrize("workload,grid", [("water_drift", (2, 1, 1)), ("lipid_drift", (1, 1, 2)), ("water_drift", (2, 2, 2))])
+def test_ranks_swing_between_empty_and_full_over_the_host_transport(workload, grid):
+    """the migration soak between REAL processes: the count rounds with a rank that holds nothing, arrays that grow in the middle of a migration (keep[], round
+    6), the bonded sums of a rank that has just been emptied (round 6).  Twelve rebuild periods, the all-reduced total energy and kinetic energy after every
+    period against the same system on one domain in this process (the two runs part like any two trajectories: 1e-9 here), and the final bead set whole"""
+    from ddcmd_amd.martini import MartiniHIP
+    from drift_setup import drifting_setup
+    s = drifting_setup(workload, grid)
+    period = int(s.updateRate)
+    nper = 12
+    recs = _run_ranks(workload, grid, nper * period, period)
+    one = MartiniHIP(s)
+    one.eval_forces()
+    thermo = any(int(t) == 1 for t in np.asarray(s.group_type).ravel())
+    if thermo:
+        one.group_temperatures()      # (the worker publishes the group temperature at the same points: tests/mp_worker.py)
+    ref = []
+    for _ in range(nper):
+        one.step(period)
+        e, vir, rk, _ = one.energies()
+        ref.append([e["total"], rk] + list(vir))
+        if thermo:
+            one.group_temperatures()
+    one.close()
+    ref = np.array(ref)
+    for r in recs:
+        assert r["traj"].shape == ref.shape
+        assert np.abs(r["traj"][:, :2] / ref[:, :2] - 1.0).max() < 1e-9, np.abs(r["traj"][:, :2] / ref[:, :2] - 1.0).max(axis=1)
+        assert np.abs(r["traj"][:, 2:] - ref[:, 2:]).max() < 1e-8 * np.abs(ref[:, 2:]).max()
+    gid = np.sort(np.concatenate([r["gid"] for r in recs]))
+    assert np.array_equal(gid, np.sort(np.asarray(s.gid)))
+    n_first, n_last = [int(r["nloc"][0]) for r in recs], [int(r["nloc"][1]) for r in recs]
+    assert sum(n_first) == s.natoms == sum(n_last) and n_first != n_last, (n_first, n_last)
