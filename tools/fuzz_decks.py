@@ -6,10 +6,17 @@ import os, shutil, signal, sys, tempfile, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ddcmd_amd.deck import load_deck
+RUN = "--run" in sys.argv      # on a GPU: every mutated deck also goes through the C driver (ddcmd_amd/bin/ddcmi_md: plugin.c's mirrors of ddcMD's objects, the
+if RUN:                        # integrator plugins, the data / restart writers): it must end with exit code 0 or with a message and a non-zero code -- no signal, no hang
+    sys.argv.remove("--run")
+    import subprocess
+    EXE = os.path.join(ROOT, "ddcmd_amd", "bin", "ddcmi_md")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 src = os.path.join(ROOT, "tests", "golden", "lipid_deck")
 ok = refused = 0
+run_ok = run_refused = 0
+run_bad = []
 with tempfile.TemporaryDirectory() as d:
     for case in range(n):
         work = os.path.join(d, "c%d" % case)
@@ -34,5 +41,22 @@ with tempfile.TemporaryDirectory() as d:
         except Exception as ex:
             refused += 1
         signal.alarm(0)
+        if RUN:
+            try:
+                r = subprocess.run([EXE, "-o", os.path.join(work, "object.data"), "-d", os.path.join(work, "data")], cwd=work, capture_output=True, text=True, timeout=120, errors="replace")
+                rc, tail = r.returncode, (r.stderr.strip().splitlines() or r.stdout.strip().splitlines() or [""])[-1][:160]
+            except subprocess.TimeoutExpired:
+                rc, tail = "HUNG", ""
+            run_ok += rc == 0
+            run_refused += (rc != 0 and rc != "HUNG" and rc > 0 and bool(tail))
+            if rc == "HUNG" or rc < 0 or (rc != 0 and not tail):
+                run_bad.append((case, victim, rc, tail))
+                shutil.copy(p, os.path.join(ROOT, "gpurun_out", "fuzz_deck_case%d_%s" % (case, os.path.basename(victim)))) if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
+            if os.environ.get("FUZZ_VERBOSE"): print("   driver rc", rc, tail, flush=True)
         shutil.rmtree(work)
 print("%d mutated decks: %d loaded, %d refused with a message, 0 crashes" % (n, ok, refused))
+if RUN:
+    print("through the C driver: %d ran to the end, %d ended with a message and a non-zero exit code, %d died on a signal / hung / left without a word" % (run_ok, run_refused, len(run_bad)))
+    for b in run_bad:
+        print("   case %d %s rc %s %s" % b)
+    sys.exit(1 if run_bad else 0)
