@@ -2,7 +2,7 @@
 """Soak of the decomposed rebuild under strong density changes (round 6, after the keep[] bug): a cube of liquid water in a box three times its size drifts
 diagonally, one brick of a 2x2x2 (or other) grid per few rebuild periods, so every domain's bead count swings between zero and most of the system and
 every array of the migration / halo path grows at some rebuild.  After every period: the bead set is whole, and ONE domain evaluating the gathered state gives the same forces and sums (1e-10).
-   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [water | lipid]"""
+   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [water | water_langevin | lipid]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +27,10 @@ if workload == "lipid":
     drift = np.array([0.37, 0.23, 0.31]) * bricks / (int(s.updateRate) * s.dt)
 else:
     s = make_water_setup(n, temperature_K=300.0)
+    if workload == "water_langevin":      # LANGEVIN on the counter-based stream keyed by gid: the same noise on any decomposition
+        from ddcmd_amd.deck import units_convert
+        s.group_type = np.array([2], np.int32); s.group_Teq = np.array([units_convert(300.0, "K")]); s.group_tau = np.array([units_convert(1.0, "ps")])
+        s.rng_seed = 20261003
     L = s.h[0]
     s.h = np.array(s.h, dtype=np.float64) * 3.0
     # 0.37 / 0.23 / 0.31 of a brick (1.5 L) per rebuild period along x / y / z: incommensurate, so the cube meets the brick faces in ever new ways
