@@ -616,7 +616,7 @@ extern "C" int ddcmi_set_species(ddcmi_ctx *ctx, int nspecies, const double *mas
    ctx->moltype.assign(nspecies, 0);
    if (moltype) ctx->moltype.assign(moltype, moltype + nspecies);
    ctx->has_charge = false;
-   ctx->tables_dirty = true;
+   ctx->tables_dirty = true; ctx->forces_valid = false;      /* (forces of the old charges: ddcmi_step_nglf asks for a new evaluation, which rebuilds the tables) */
    std::vector<double> inv(nspecies);
    for (int s = 0; s < nspecies; s++)
    {
@@ -645,7 +645,7 @@ extern "C" int ddcmi_set_nonbonded(ddcmi_ctx *ctx, int nlj, const double *sigma,
    ctx->nlj = nlj;
    ctx->sigma.assign(sigma, sigma + nlj * nlj); ctx->eps.assign(eps, eps + nlj * nlj); ctx->shift.assign(shift, shift + nlj * nlj);
    ctx->rmax = rmax; ctx->keR = keR; ctx->krf = krf; ctx->crf = crf;
-   ctx->list_valid = false;
+   ctx->list_valid = false; ctx->forces_valid = false;
    ctx->tables_dirty = true;
    return DDCMI_OK;
 }
@@ -660,6 +660,16 @@ __global__ void k_retag(int n, const int *species, const int *nb_of_sp, double4 
    if (i >= n) return;
    long long w = __double_as_longlong(pos[i].w);
    pos[i].w = __longlong_as_double((w & ~0xffll) | (long long)(nb_of_sp[species[i]] & 0xff));
+}
+/* self electrostatic term -1/2 sum q_i^2 keR crf over the local beads (bioMartini.c:1030-1035), one domain: from the species counts of the upload, so that new
+ * charges (ddcmi_set_species) or new reaction-field constants (ddcmi_set_nonbonded) under an uploaded state take effect -- until round 6 the term of the
+ * upload stayed (tools/fuzz_sequence.py).  Decomposed ranks sum it on the device at every rebuild (ddcmi_multigpu.inl). */
+static void update_self_ele(ddcmi_ctx *ctx)
+{
+   if (ctx->nranks > 1 || ctx->loopback || ctx->group_ || ctx->sp_count.empty()) return;
+   double q2 = 0.0;
+   for (size_t sp = 0; sp < ctx->sp_count.size() && sp < ctx->charge.size(); sp++) q2 += (double)ctx->sp_count[sp] * ctx->charge[sp] * ctx->charge[sp];
+   ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;
 }
 static int nb_tables(ddcmi_ctx *ctx)
 {
@@ -714,6 +724,7 @@ static int nb_tables(ddcmi_ctx *ctx)
        (rc = upload_vec(ctx, ctx->d_ljtype_sp, nb.data(), nb.size()))) return rc;
    ctx->nnb = nnb;
    ctx->tables_dirty = false;
+   update_self_ele(ctx);
    if (ctx->nloc > 0 && ctx->pos.p)      /* parameters changed under an uploaded state: refresh the tags */
       hipLaunchKernelGGL(k_retag, dim3(cdiv(ctx->nloc, 256)), dim3(256), 0, ctx->stream, ctx->nloc, ctx->species.p, ctx->d_ljtype_sp.p, ctx->pos.p);
    ctx->list_valid = false;
@@ -951,7 +962,7 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    for (auto b : i1) ENSURE(ctx, *b, n + 1);
    if (n == 0)
    {
-      ctx->nloc = 0; ctx->nhalo = 0; ctx->npad = DDCMI_BLOCK; ctx->self_ele = 0.0;
+      ctx->nloc = 0; ctx->nhalo = 0; ctx->npad = DDCMI_BLOCK; ctx->self_ele = 0.0; ctx->sp_count.assign(ctx->nspecies, 0);
       ctx->list_valid = false; ctx->forces_valid = false;
       return DDCMI_OK;
    }
@@ -993,9 +1004,13 @@ extern "C" int ddcmi_upload_state(ddcmi_ctx *ctx, int nlocal, const double *rx, 
    ctx->nloc = n; ctx->nhalo = 0;
    ctx->npad = cdiv(n, DDCMI_BLOCK) * DDCMI_BLOCK;
    /* self electrostatic term -1/2 sum q_i^2 keR crf over local atoms (bioMartini.c:1030-1035) */
-   double q2 = 0.0;
-   for (int i = 0; i < n; i++) { double q = ctx->charge[species[i]]; q2 += q * q; }
-   ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;
+   ctx->sp_count.assign(ctx->nspecies, 0);
+   for (int i = 0; i < n; i++) ctx->sp_count[species[i]]++;
+   {
+      double q2 = 0.0;      /* (in bead order, as every round summed it: decomposed ranks keep this value until their first rebuild) */
+      for (int i = 0; i < n; i++) { double q = ctx->charge[species[i]]; q2 += q * q; }
+      ctx->self_ele = -0.5 * q2 * ctx->keR * ctx->crf;
+   }
    ctx->list_valid = false; ctx->forces_valid = false;
    return DDCMI_OK;
 }

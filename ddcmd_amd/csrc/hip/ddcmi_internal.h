@@ -286,7 +286,7 @@ struct ddcmi_ctx
       h_pin_cap[which] = cap;
       return h_pin[which];
    }
-   double self_ele = 0.0;
+   double self_ele = 0.0; std::vector<long> sp_count;      /* sp_count: beads per species of the last ddcmi_upload_state (one domain: the self term follows new charges / constants without the beads) */
    /* what the last rebuild's tail left zeroed for this one (k_rebuild_tail): the cell counters (for this cell count, in these buffers),
     * the flags, the arena counter, the direction counters; a rebuild that cannot rely on it clears them itself */
    bool counters_clean = false, dircnt_clean = false, dir28_clean = false; int clean_ncell = 0; const int *clean_po = nullptr, *clean_ph = nullptr;

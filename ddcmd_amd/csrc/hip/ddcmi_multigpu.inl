@@ -929,7 +929,7 @@ static int mg_phase4_finish(ddcmi_ctx *ctx)
       HIPCHK(ctx, hipMemcpyAsync(ctx->h_results + R_GROUP, d, sizeof(double), hipMemcpyDeviceToHost, st));
    }
    if ((rc = ddcmi_bl_finish(ctx))) return rc;
-   if (ctx->has_charge) ctx->self_ele = -0.5 * ctx->h_results[R_GROUP] * ctx->keR * ctx->crf;     /* bioMartini.c:1030-1035 over this rank's local beads */
+   ctx->self_ele = ctx->has_charge ? -0.5 * ctx->h_results[R_GROUP] * ctx->keR * ctx->crf : 0.0;      /* (: 0 -- charges switched off under an uploaded state) */     /* bioMartini.c:1030-1035 over this rank's local beads */
    ctx->halo_fresh = true;
    return DDCMI_OK;
 }

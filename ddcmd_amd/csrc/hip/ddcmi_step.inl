@@ -336,6 +336,9 @@ extern "C" int ddcmi_eval_forces(ddcmi_ctx *ctx, double *energies, double *viria
    (void)hipSetDevice(ctx->device);
    int rc;
    if (ctx->group_) SETERR(ctx, DDCMI_EINVAL, "contexts of an in-process group evaluate forces with ddcmi_group_eval_forces");
+   /* new species or nonbonded parameters under an uploaded state (ddcmi_set_species / ddcmi_set_nonbonded without a new upload): the class tables, the
+    * beads' tags and with them the list are rebuilt before anything is evaluated with the old ones */
+   if (ctx->tables_dirty && ctx->nloc > 0 && (rc = nb_tables(ctx))) return rc;
    if (!ctx->list_valid) { if ((rc = ddcmi_build_list(ctx))) return rc; ctx->images_fresh = true; }
    if ((rc = launch_forces(ctx))) return rc;
    ctx->molv_valid = false;

@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Call-sequence fuzz of the C-ABI on a GPU: a long-lived context is driven through a random sequence of VALID calls -- steps, force evaluations,
+explicit rebuilds, new neighbour settings, a new cut-off, new charges and masses, terms dropped and restored, molecule tables switched off and on,
+thermostats switched, the state uploaded again (as it is, jittered, or a different system altogether), the box rescaled -- and after every few calls its
+force evaluation must equal that of a FRESH context created from the same parameters and the same state (forces and sums, 1e-10): what a setter
+invalidates (lists, tables, tags, slots, sums) must really be rebuilt, whatever came before.
+   python3 tools/fuzz_sequence.py [nsequences] [seed] [ops per sequence]"""
+import copy, ctypes, os, random, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ddcmd_amd.martini as martini
+from ddcmd_amd.martini import MartiniHIP, _d, _i
+from ddcmd_amd.deck import load_deck
+from ddcmd_amd.synth import make_water_setup
+
+f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))
+
+
+def base(which):
+    if which == "lipid":
+        deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    else:
+        s = make_water_setup(7, temperature_K=150.0)
+    for a in ("rx", "ry", "rz", "vx", "vy", "vz", "h", "mass", "charge", "sigma", "eps", "shift", "group_Teq", "group_tau"):
+        setattr(s, a, np.array(getattr(s, a), dtype=np.float64))
+    for a in ("group_type", "group_interval"):
+        setattr(s, a, np.array(getattr(s, a), dtype=np.int32))
+    return s
+
+
+class Live(object):
+    def __init__(self, s, rnd):
+        self.s, self.rnd = copy.deepcopy(s), rnd
+        self.terms = {k: np.array(v) for k, v in martini.expand_bonded_terms(s).items()}
+        self.molecules_on = s.nmoltype > 0
+        self.md = self.make(self.s, self.terms, self.molecules_on)
+        self.log = []
+
+    @staticmethod
+    def make(s, terms, molecules_on):
+        orig = martini.expand_bonded_terms
+        martini.expand_bonded_terms = lambda _s: terms
+        s2 = copy.copy(s)
+        if not molecules_on:
+            s2.nmoltype = 0
+        try:
+            return MartiniHIP(s2)
+        finally:
+            martini.expand_bonded_terms = orig
+
+    def chk(self, rc):
+        self.md._chk(rc)
+
+    def state(self):
+        d = self.md.download()
+        return [np.array(a) for a in d["r"]], [np.array(a) for a in d["v"]]
+
+    # ---- the calls ----
+    def op_step(self):
+        k = self.rnd.choice([1, 2, 3, 7, 20, 25])
+        self.md.step(k); return "step %d" % k
+
+    def op_eval(self):
+        self.md.eval_forces(); return "eval_forces"
+
+    def op_build(self):
+        self.md.build_list(); return "build_list"
+
+    def op_neighbor(self):
+        s = self.s
+        s.deltaR = float(s.deltaR * self.rnd.choice([0.5, 1.0, 1.25]))
+        s.deltaR = min(max(s.deltaR, 2.0), 0.45 * min(s.h[0], s.h[4], s.h[8]) - s.rmax)
+        s.updateRate = self.rnd.choice([0, 1, 5, 10, 20])
+        self.chk(self.md.lib.ddcmi_set_neighbor(self.md.ctx, s.deltaR, int(s.updateRate)))
+        return "set_neighbor deltaR %.3f updateRate %d" % (s.deltaR, s.updateRate)
+
+    def op_rmax(self):
+        s = self.s
+        s.rmax = float(min(s.rmax * self.rnd.choice([0.85, 1.0, 1.1]), 0.45 * min(s.h[0], s.h[4], s.h[8]) - s.deltaR))
+        self.chk(self.md.lib.ddcmi_set_nonbonded(self.md.ctx, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)), s.rmax, s.keR, s.krf, s.crf))
+        return "set_nonbonded rmax %.3f" % s.rmax
+
+    def op_table(self):
+        s = self.s
+        k = self.rnd.randrange(s.eps.size)
+        s.eps[k] *= self.rnd.choice([0.5, 1.0, 2.0])
+        s.eps = 0.5 * (s.eps.reshape(s.nlj, s.nlj) + s.eps.reshape(s.nlj, s.nlj).T).ravel()      # (the table is symmetric)
+        self.chk(self.md.lib.ddcmi_set_nonbonded(self.md.ctx, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)), s.rmax, s.keR, s.krf, s.crf))
+        return "set_nonbonded eps[%d]" % k
+
+    def op_species(self):
+        s = self.s
+        what = self.rnd.choice(["charges_off", "charges_half", "charges_back", "mass"])
+        if what == "charges_off": s.charge[:] = 0.0
+        elif what == "charges_half": s.charge[:] = 0.5 * self.charge0
+        elif what == "charges_back": s.charge[:] = self.charge0
+        else: s.mass[self.rnd.randrange(s.nspecies)] *= self.rnd.choice([0.5, 2.0])
+        self.chk(self.md.lib.ddcmi_set_species(self.md.ctx, s.nspecies, _d(f64(s.mass)), _d(f64(s.charge)), _i(i32(s.ljtype)), _i(i32(s.moltype))))
+        return "set_species " + what
+
+    def op_terms(self):
+        t0, t = self.terms0, {}
+        what = self.rnd.choice(["all", "half_bonds", "no_angles", "no_dihedrals", "none"])
+        for k, v in t0.items():
+            t[k] = np.array(v)
+        def cut(prefix, width, keep):
+            n = t[prefix + "_k" if prefix != "bond" else "bond_kb"].size
+            sel = np.arange(n)[:keep(n)]
+            for k in list(t):
+                if k.startswith(prefix + "_"):
+                    w = width if k.endswith(("_ij", "_ijk", "_ijkl")) else 1
+                    t[k] = np.ascontiguousarray(t[k].reshape(n, w)[sel].ravel()) if n else t[k]
+        if what == "half_bonds": cut("bond", 2, lambda n: n // 2)
+        if what == "no_angles": cut("angle", 3, lambda n: 0)
+        if what == "no_dihedrals": cut("tors", 4, lambda n: 0)
+        if what == "none":
+            cut("bond", 2, lambda n: 0); cut("angle", 3, lambda n: 0); cut("tors", 4, lambda n: 0)
+        self.terms = t
+        nb, na, nt = t["bond_kb"].size, t["angle_k"].size, t["tors_k"].size
+        z = np.zeros(4, np.int32)
+        self.chk(self.md.lib.ddcmi_set_bonded(self.md.ctx, nb, _i(t["bond_ij"] if nb else z), _d(t["bond_kb"]), _d(t["bond_b0"]),
+                                              na, _i(t["angle_ijk"] if na else z), _i(t["angle_func"] if na else z), _d(t["angle_k"]), _d(t["angle_t0"]),
+                                              nt, _i(t["tors_ijkl"] if nt else z), _i(t["tors_func"] if nt else z), _i(t["tors_n"] if nt else z), _d(t["tors_k"]), _d(t["tors_delta"]),
+                                              int(self.s.excludePotentialTerm)))
+        return "set_bonded " + what
+
+    def op_molecules(self):
+        s = self.s
+        self.molecules_on = not self.molecules_on if s.nmoltype > 0 else False
+        if self.molecules_on:
+            bi, bj = i32(s.bpairI), i32(s.bpairJ)
+            if bi.size == 0:
+                bi = bj = np.zeros(1, np.int32)
+            self.chk(self.md.lib.ddcmi_set_molecules(self.md.ctx, s.nmoltype, _i(i32(s.mol_nspecies)), _i(i32(s.bpair_off)), _i(bi), _i(bj)))
+        else:
+            self.chk(self.md.lib.ddcmi_set_molecules(self.md.ctx, 0, None, None, None, None))
+        return "set_molecules %s" % ("on" if self.molecules_on else "off")
+
+    def op_groups(self):
+        s = self.s
+        kind = self.rnd.choice([0, 1, 2])
+        s.group_type = np.full(s.ngroup, kind, np.int32)
+        s.group_Teq = np.full(s.ngroup, 1.0e-3); s.group_tau = np.full(s.ngroup, 500.0); s.group_interval = np.ones(s.ngroup, np.int32)
+        self.chk(self.md.lib.ddcmi_set_groups(self.md.ctx, s.ngroup, _i(i32(s.group_type)), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
+        return "set_groups %d" % kind
+
+    def op_reupload(self):
+        r, v = self.state()
+        how = self.rnd.choice(["same", "jitter", "shuffle_box"])
+        if how == "jitter":
+            r = [a + 0.05 * np.array([self.rnd.uniform(-1, 1) for _ in range(a.size)]) for a in r]
+        if how == "shuffle_box":      # every bead by a whole box length along some axis: the same system
+            r[0] = r[0] + self.s.h[0] * np.array([self.rnd.choice([-1, 0, 1]) for _ in range(r[0].size)])
+        self.md.upload(r[0], r[1], r[2], v[0], v[1], v[2])
+        return "upload_state " + how
+
+    def op_positions(self):
+        r, v = self.state()
+        r = [a + 0.02 * np.array([self.rnd.uniform(-1, 1) for _ in range(a.size)]) for a in r]
+        self.md.upload_positions(r, v)
+        return "upload_positions jitter"
+
+    def op_box(self):
+        s = self.s
+        f = self.rnd.choice([0.99, 1.01, 1.02])
+        r, v = self.state()
+        s.h = s.h * f
+        self.chk(self.md.lib.ddcmi_set_box(self.md.ctx, _d(f64(s.h)), int(s.pbc)))
+        self.md.upload(r[0] * f, r[1] * f, r[2] * f, v[0], v[1], v[2])
+        return "set_box x %.2f + upload_state" % f
+
+    def op_misc(self):
+        what = self.rnd.choice(["clock", "timing_on", "timing_off", "stats", "get_list", "kinetic"])
+        if what == "clock": self.chk(self.md.lib.ddcmi_set_clock(self.md.ctx, self.rnd.randrange(0, 1000), 0.0))
+        elif what == "timing_on": self.md.timing(True)
+        elif what == "timing_off": self.md.timing(False)
+        elif what == "stats": self.md.list_stats()
+        elif what == "get_list":
+            try: self.md.get_list(0)
+            except martini.DdcmiError: pass      # (no valid list at the moment: an answer)
+        else: self.md.energies()
+        return what
+
+    # ---- the check ----
+    def check(self, rebuild_first=False):
+        if rebuild_first:
+            self.md.build_list()
+        e1, v1 = self.md.eval_forces()
+        d = self.md.download()
+        s2 = copy.deepcopy(self.s)
+        s2.rx, s2.ry, s2.rz = [np.array(a) for a in d["r"]]
+        s2.vx, s2.vy, s2.vz = [np.array(a) for a in d["v"]]
+        fresh = self.make(s2, self.terms, self.molecules_on)
+        try:
+            e2, v2 = fresh.eval_forces()
+            d2 = fresh.download()
+        finally:
+            fresh.close()
+        fmax = max(np.abs(d2["f"][c]).max() for c in range(3)) + 1e-300
+        ferr = max(np.abs(d["f"][c] - d2["f"][c]).max() for c in range(3)) / fmax
+        scale = max(abs(e2["total"]), abs(e2["lj"]), 1e-12)
+        eerr = max(abs(e1[k] - e2[k]) for k in e2) / scale
+        verr = np.abs(v1 - v2).max() / max(np.abs(v2).max(), 1e-300)
+        return max(ferr, eerr, verr), (ferr, eerr, verr), (e1, e2)
+
+
+def main():
+    nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    nops = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+    bases = {w: base(w) for w in ("lipid", "water")}
+    bad = stale = 0
+    worst = 0.0
+    for q in range(nseq):
+        rnd = random.Random(seed * 7919 + q)
+        which = rnd.choice(["lipid", "lipid", "water"])
+        L = Live(bases[which], rnd)
+        L.charge0 = np.array(bases[which].charge); L.terms0 = {k: np.array(v) for k, v in L.terms.items()}
+        ops = [L.op_step, L.op_step, L.op_eval, L.op_build, L.op_neighbor, L.op_rmax, L.op_table, L.op_species, L.op_groups, L.op_reupload, L.op_positions, L.op_box, L.op_misc]
+        if which == "lipid":
+            ops += [L.op_terms, L.op_terms, L.op_molecules, L.op_species]
+        L.md.eval_forces()
+        try:
+            for k in range(nops):
+                op = rnd.choice(ops)
+                try:
+                    L.log.append(op())
+                except martini.DdcmiError as ex:
+                    L.log.append("%s -> REFUSED %s" % (op.__name__, str(ex)[:100]))
+                    if "unstable" in str(ex) or "non-finite" in str(ex):
+                        raise
+                    L.md.eval_forces() if "needs forces" in str(ex) else None
+                if VERBOSE: print("   ", L.log[-1], flush=True)
+                if k % 4 == 3 or k == nops - 1:
+                    err, parts, es = L.check()
+                    worst = max(worst, err) if err < 1e-9 else worst
+                    L.log.append("check %.1e" % err)
+                    if VERBOSE: print("   ", L.log[-1], flush=True)
+                    if not err < 1e-9:
+                        # a list on a fixed cadence (updateRate > 0) goes stale when beads outrun the skin between two rebuilds -- the reference's lists do too;
+                        # a context that agrees with the fresh one after an explicit rebuild had such a list, not a setter that forgot to invalidate something
+                        err2 = L.check(rebuild_first=True)[0]
+                        if err2 < 1e-9 and L.s.updateRate > 0:
+                            stale += 1
+                            print("sequence %d (%s): a list gone stale within its cadence (updateRate %d, deltaR %.2f): %.1e before, %.1e after an explicit rebuild; after: %s"
+                                  % (q, which, L.s.updateRate, L.s.deltaR, err, err2, " | ".join(L.log[-6:])), flush=True)
+                            continue
+                        bad += 1
+                        print("sequence %d (%s): the context and a fresh one differ by %.2e (forces %.1e, sums %.1e, virial %.1e) after:" % ((q, which, err) + parts))
+                        for l in L.log[-12:]: print("      " + l)
+                        print("      context:", {k: "%.10g" % v for k, v in es[0].items()})
+                        print("      fresh  :", {k: "%.10g" % v for k, v in es[1].items()})
+                        break
+            else:
+                print("sequence %d (%s): %d calls, %d checks, worst difference to a fresh context %.1e" % (q, which, nops, sum(l.startswith("check") for l in L.log), max(float(l.split()[1]) for l in L.log if l.startswith("check"))), flush=True)
+        except martini.DdcmiError as ex:
+            print("sequence %d (%s): ended by the library: %s   after: %s" % (q, which, str(ex)[:160], " | ".join(L.log[-5:])), flush=True)
+        finally:
+            L.md.close()
+    print("%d sequences of %d calls: %d differ from a fresh context (+ %d checks that met a list gone stale within its fixed cadence); worst difference of the others %.1e" % (nseq, nops, bad, stale, worst))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
