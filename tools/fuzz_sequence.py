@@ -23,6 +23,20 @@ def base(which):
     if which == "lipid":
         deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
         s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"))
+    elif which == "npt":      # the relaxed deck with constraint lists in its residues and six restrained beads: the nglfconstraint step's tables come and go
+        from ddcmd_amd.deck import units_convert
+        CONSTRAINT_X = ("TSTM RESIPARMS { constraintList = TSTM_cl0 TSTM_cl1; } TSTM_cl0 CONSLISTPARMS { constraintSubList = TSTM_c0 TSTM_c1 TSTM_c2; } "
+                        "TSTM_cl1 CONSLISTPARMS { constraintSubList = TSTM_c3; } TSTM_c0 CONSPARMS { atomI=0; atomJ=1; func=1; r0=0.40 nm; } "
+                        "TSTM_c1 CONSPARMS { atomI=1; atomJ=2; func=1; r0=0.40 nm; } TSTM_c2 CONSPARMS { atomI=0; atomJ=2; func=1; r0=0.655 nm; } "
+                        "TSTM_c3 CONSPARMS { atomI=3; atomJ=4; func=1; r0=0.40 nm; } DPPC RESIPARMS { constraintList = DPPC_cl0; } "
+                        "DPPC_cl0 CONSLISTPARMS { constraintSubList = DPPC_c0; } DPPC_c0 CONSPARMS { atomI=2; atomJ=3; func=1; r0=0.37 nm; } ")
+        deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
+        extra = CONSTRAINT_X + " system SYSTEM { potential = martini restraintPot; } restraintPot POTENTIAL { type = RESTRAINT; parmfile = restraint.data; }"
+        s = load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=extra)
+        s.baro = (units_convert(310.0, "K"), units_convert(1.0, "bar"), units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps"))
+        s.rest_gid = np.array(s.rest_gid, dtype=np.uint64); s.rest_kb = np.array(s.rest_kb, dtype=np.float64)
+        s.rest_r0 = np.ascontiguousarray(s.rest_r0, dtype=np.float64); s.rest_fc = np.ascontiguousarray(s.rest_fc, dtype=np.int32)
+        s.nrest_all = int(s.nrest)
     else:
         s = make_water_setup(7, temperature_K=150.0)
     for a in ("rx", "ry", "rz", "vx", "vy", "vz", "h", "mass", "charge", "sigma", "eps", "shift", "group_Teq", "group_tau"):
@@ -37,6 +51,8 @@ class Live(object):
         self.s, self.rnd = copy.deepcopy(s), rnd
         self.terms = {k: np.array(v) for k, v in martini.expand_bonded_terms(s).items()}
         self.molecules_on = s.nmoltype > 0
+        self.npt = hasattr(s, "baro")
+        self.cons_on = self.baro_on = False
         self.md = self.make(self.s, self.terms, self.molecules_on)
         self.log = []
 
@@ -62,7 +78,10 @@ class Live(object):
     # ---- the calls ----
     def op_step(self):
         k = self.rnd.choice([1, 2, 3, 7, 20, 25])
-        self.md.step(k); return "step %d" % k
+        self.md.step(k)
+        if self.baro_on:
+            b = self.md.box(); self.s.h[0], self.s.h[4], self.s.h[8] = b[0], b[1], b[2]      # (the barostat moves the box: the fresh context starts from the current one)
+        return "step %d" % k
 
     def op_eval(self):
         self.md.eval_forces(); return "eval_forces"
@@ -173,6 +192,46 @@ class Live(object):
         self.md.upload(r[0] * f, r[1] * f, r[2] * f, v[0], v[1], v[2])
         return "set_box x %.2f + upload_state" % f
 
+    def op_restraints(self):
+        s = self.s
+        s.nrest = 0 if s.nrest else s.nrest_all
+        up = ctypes.POINTER(ctypes.c_uint64)
+        self.chk(self.md.lib.ddcmi_set_restraints(self.md.ctx, int(s.nrest), s.rest_gid.ctypes.data_as(up), _i(i32(np.asarray(s.rest_fc).ravel())), _d(f64(np.asarray(s.rest_r0).ravel())),
+                                                   _d(f64(s.rest_kb)), int(getattr(s, "rest_origin", 0))))
+        return "set_restraints %d" % s.nrest
+
+    def op_constraints(self):
+        self.cons_on = not self.cons_on
+        if self.cons_on:
+            po, pi, pj, dd = self._cons = martini.expand_constraints(self.s)
+            self.chk(self.md.lib.ddcmi_set_constraints(self.md.ctx, int(po.size - 1), _i(po), _i(pi), _i(pj), _d(dd)))
+        else:
+            self.chk(self.md.lib.ddcmi_set_constraints(self.md.ctx, 0, None, None, None, None))
+        return "set_constraints %s" % ("on" if self.cons_on else "off")
+
+    def op_barostat(self):
+        self.baro_on = not self.baro_on
+        if self.baro_on:
+            self.md.set_barostat(*self.s.baro)
+        else:
+            self.chk(self.md.lib.ddcmi_set_barostat(self.md.ctx, 0.0, 0.0, 0.0, 1.0))
+        return "set_barostat %s" % ("on" if self.baro_on else "off")
+
+    def op_other_system(self):
+        """water: a box of another size into the same context (more or fewer beads, another box): every array sized by the bead count, the image count hint,
+        the rows of pending lean steps"""
+        n = self.rnd.choice([6, 7, 8])
+        new = copy.deepcopy(self.water_sizes[n])
+        for a in ("rmax", "deltaR", "updateRate", "eps", "sigma", "shift", "mass", "charge", "group_type", "group_Teq", "group_tau", "group_interval", "nlj", "keR", "krf", "crf"):
+            setattr(new, a, copy.deepcopy(getattr(self.s, a)))
+        if 0.45 * new.h[0] < new.rmax + new.deltaR:
+            return "another system: skipped (its box is under 2 (rmax + deltaR))"
+        self.s = new
+        self.md.s, self.md.n = new, new.natoms
+        self.chk(self.md.lib.ddcmi_set_box(self.md.ctx, _d(f64(new.h)), int(new.pbc)))
+        self.md.upload(new.rx, new.ry, new.rz, new.vx, new.vy, new.vz)
+        return "another system: %d beads" % new.natoms
+
     def op_misc(self):
         what = self.rnd.choice(["clock", "timing_on", "timing_off", "stats", "get_list", "kinetic"])
         if what == "clock": self.chk(self.md.lib.ddcmi_set_clock(self.md.ctx, self.rnd.randrange(0, 1000), 0.0))
@@ -212,17 +271,29 @@ def main():
     nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     nops = int(sys.argv[3]) if len(sys.argv) > 3 else 24
-    bases = {w: base(w) for w in ("lipid", "water")}
+    bases = {w: base(w) for w in ("lipid", "water", "npt")}
+    water_sizes = {}
+    for n in (6, 7, 8):
+        w = make_water_setup(n, temperature_K=150.0)
+        for a in ("rx", "ry", "rz", "vx", "vy", "vz", "h"):
+            setattr(w, a, np.array(getattr(w, a), dtype=np.float64))
+        water_sizes[n] = w
     bad = stale = 0
     worst = 0.0
     for q in range(nseq):
         rnd = random.Random(seed * 7919 + q)
-        which = rnd.choice(["lipid", "lipid", "water"])
+        which = rnd.choice(["lipid", "lipid", "water", "npt"])
         L = Live(bases[which], rnd)
         L.charge0 = np.array(bases[which].charge); L.terms0 = {k: np.array(v) for k, v in L.terms.items()}
         ops = [L.op_step, L.op_step, L.op_eval, L.op_build, L.op_neighbor, L.op_rmax, L.op_table, L.op_species, L.op_groups, L.op_reupload, L.op_positions, L.op_box, L.op_misc]
-        if which == "lipid":
+        if which in ("lipid", "npt"):
             ops += [L.op_terms, L.op_terms, L.op_molecules, L.op_species]
+        if which == "water":
+            L.water_sizes = water_sizes
+            ops += [L.op_other_system, L.op_other_system]
+        if which == "npt":
+            ops += [L.op_restraints, L.op_restraints, L.op_constraints, L.op_constraints, L.op_barostat, L.op_barostat]
+            ops.remove(L.op_box); ops.remove(L.op_molecules)      # (the barostat owns the box; it and the constraint groups need the molecule tables)
         L.md.eval_forces()
         try:
             for k in range(nops):
