@@ -2,8 +2,8 @@
 """Soak of the decomposed rebuild under strong density changes (round 6, after the keep[] bug): a cube of liquid water in a box three times its size drifts
 diagonally, one brick of a 2x2x2 (or other) grid per few rebuild periods, so every domain's bead count swings between zero and most of the system and
 every array of the migration / halo path grows at some rebuild.  After every period: the bead set is whole, and ONE domain evaluating the gathered state gives the same forces and sums (1e-10).
-   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [water | water_langevin | lipid]"""
-import os, sys
+   python3 tools/soak_migration_r06.py [periods] [n] [grid, e.g. 2,2,2] [water | water_langevin | lipid | lipid_npt]"""
+import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,13 +14,25 @@ periods = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 grid = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (2, 2, 2)
 workload = sys.argv[4] if len(sys.argv) > 4 else "water"
-if workload == "lipid":
+NPT = workload == "lipid_npt"      # the full nglfconstraint step: constraint groups across the bricks' faces, the barostat on the molecular pressure moving the box
+if workload in ("lipid", "lipid_npt"):
     # the relaxed bilayer patch tiled n x n x 1 (charges, bonds, angles, dihedrals by gid: the gid -> slot tables and the term localisation swing with the beads),
     # vacuum above and below (box x 3 in z): the membrane drifts through the z bricks and slides along x and y
     from ddcmd_amd.deck import load_deck
     from ddcmd_amd.synth import replicate_setup
     deck = os.path.join(ROOT, "tests", "golden", "lipid_deck")
-    s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart")), (n, n, 1))
+    extra = None
+    if NPT:
+        extra = ("TSTM RESIPARMS { constraintList = TSTM_cl0 TSTM_cl1; } TSTM_cl0 CONSLISTPARMS { constraintSubList = TSTM_c0 TSTM_c1 TSTM_c2; } "
+                 "TSTM_cl1 CONSLISTPARMS { constraintSubList = TSTM_c3; } TSTM_c0 CONSPARMS { atomI=0; atomJ=1; func=1; r0=0.40 nm; } "
+                 "TSTM_c1 CONSPARMS { atomI=1; atomJ=2; func=1; r0=0.40 nm; } TSTM_c2 CONSPARMS { atomI=0; atomJ=2; func=1; r0=0.655 nm; } "
+                 "TSTM_c3 CONSPARMS { atomI=3; atomJ=4; func=1; r0=0.40 nm; } DPPC RESIPARMS { constraintList = DPPC_cl0; } "
+                 "DPPC_cl0 CONSLISTPARMS { constraintSubList = DPPC_c0; } DPPC_c0 CONSPARMS { atomI=2; atomJ=3; func=1; r0=0.37 nm; } ")
+    s = replicate_setup(load_deck(os.path.join(deck, "object_nvt.data"), restart_file=os.path.join(deck, "relaxed", "restart"), extra_objects=extra), (n, n, 1))
+    if NPT:
+        from ddcmd_amd.deck import units_convert
+        s.npt_T, s.npt_P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
+        s.npt_beta, s.npt_tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
     s.h = np.array(s.h, dtype=np.float64)
     bricks = np.array([s.h[0], s.h[4], 3.0 * s.h[8]]) / np.array(grid)
     s.h[8] *= 3.0
@@ -37,9 +49,9 @@ else:
     drift = np.array([0.37, 0.23, 0.31]) * 1.5 * L / (int(s.updateRate) * s.dt)
 period = int(s.updateRate)
 s.vx = np.asarray(s.vx) + drift[0]; s.vy = np.asarray(s.vy) + drift[1]; s.vz = np.asarray(s.vz) + drift[2]
-one = MartiniHIP(s)
+one = MartiniHIP(s)      # (evaluates gathered states: forces and sums need neither the constraint groups nor the barostat)
 one.eval_forces()
-traj = MartiniHIP(s)      # the same run on one domain, stepped alongside for the first periods (thermostat and all): before the two trajectories part as any two do
+traj = MartiniHIP(s, constraints=NPT)      # the same run on one domain, stepped alongside for the first periods (thermostat and all): before the two trajectories part as any two do
 traj.eval_forces()
 TRAJ_PERIODS = 10
 class OneDomain(object):
@@ -51,7 +63,7 @@ class OneDomain(object):
     def gather(self):
         d = self.m.download()
         return {"gid": np.asarray(self.s.gid), "nlocal": [self.s.natoms], "r": d["r"], "v": d["v"], "f": d["f"]}
-g = OneDomain(s) if grid == (1, 1, 1) else MartiniGroup(s, grid)
+g = OneDomain(s) if grid == (1, 1, 1) else MartiniGroup(s, grid, constraints=NPT)
 g.eval_forces()
 gid0 = np.sort(np.asarray(s.gid))
 assert np.array_equal(gid0, np.asarray(s.gid))      # (caller order = gid order: the gathered state uploads as it is)
@@ -64,6 +76,9 @@ for p in range(periods):
     for r, c in enumerate(st["nlocal"]):
         seen_min[r] = min(seen_min[r], c); seen_max[r] = max(seen_max[r], c)
     # the decomposed run's state on ONE domain: the same forces and sums, exactly (no trajectory between the two to part)
+    if NPT:      # the barostat has moved the box: the evaluating context takes the bricks' current one
+        hb = np.array(s.h, dtype=np.float64); hb[[0, 4, 8]] = g.ranks[0].box()
+        one._chk(one.lib.ddcmi_set_box(one.ctx, hb.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(s.pbc)))
     one.upload(st["r"][0], st["r"][1], st["r"][2], st["v"][0], st["v"][1], st["v"][2])
     ea, va = one.eval_forces()
     d = one.download()
