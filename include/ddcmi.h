@@ -64,7 +64,12 @@ const char *ddcmi_last_error(const ddcmi_ctx *ctx);   /* ctx may be NULL: last c
 int ddcmi_device_count(void);                          /* hipGetDeviceCount; 0 without a GPU */
 const char *ddcmi_version(void);
 
-/* ---- parameters ------------------------------------------------------------ */
+/* ---- parameters ------------------------------------------------------------
+ * Every setter checks what it is handed -- counts, NULL arrays, offsets (start at 0, never decrease), indices (not negative), constants (finite; rmax > 0,
+ * deltaR >= 0, masses > 0, pbc in 0..7) -- and refuses with DDCMI_EINVAL and a message; a refused call changes nothing.  What only a rebuild can know is
+ * checked there (molecule types against ddcmi_set_molecules, index-named terms / constraint pairs / molecules against the bead count of the upload).  The
+ * caller's promise that an array is as long as its count says cannot be checked.  New species or nonbonded parameters under an uploaded state invalidate
+ * the forces on the device: the next ddcmi_eval_forces rebuilds the class tables, the beads' tags and the list (ddcmi_step_nglf asks for it). */
 /* BOX h (row-major 3x3, orthorhombic) and pbc bitmask: allocGPUBoxInfo */
 int ddcmi_set_box(ddcmi_ctx *ctx, const double h[9], int pbc);
 /* SPECIES tables: mass, charge (ddcenergy.c:210), LJ type (getCGLJindexbySpecie
