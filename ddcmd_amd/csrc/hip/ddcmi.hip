@@ -595,7 +595,7 @@ extern "C" int ddcmi_set_box(ddcmi_ctx *ctx, const double h[9], int pbc)
    memcpy(ctx->h, h, sizeof(double) * 9);
    ctx->pbc = pbc;
    ctx->have_box = true;
-   ctx->list_valid = false;
+   ctx->list_valid = false; ctx->forces_valid = false;      /* (the forces on the device are those of the old box) */
    return DDCMI_OK;
 }
 
@@ -744,7 +744,7 @@ extern "C" int ddcmi_set_molecules(ddcmi_ctx *ctx, int nmoltype, const int *mol_
    ARGCHK(ctx, nmoltype > 0 && bpair_off[nmoltype] > 0 && (!bpairI || !bpairJ), "ddcmi_set_molecules: %d bonded pairs but bpairI or bpairJ is NULL", bpair_off[nmoltype]);
    (void)hipSetDevice(ctx->device);
    ctx->nmoltype = nmoltype;
-   ctx->list_valid = false;
+   ctx->list_valid = false; ctx->forces_valid = false;      /* (... of the old exclusions) */
    if (nmoltype == 0) return DDCMI_OK;
    ctx->mol_nspecies.assign(mol_nspecies, mol_nspecies + nmoltype);
    ctx->bpair_off.assign(bpair_off, bpair_off + nmoltype + 1);

@@ -1206,6 +1206,9 @@ extern "C" int ddcmi_group_eval_forces(ddcmi_ctx **ctxs, int n)
    if (!ctxs || n < 1 || !ctxs[0] || !ctxs[0]->group_) return DDCMI_EINVAL;
    ddcmi_group *g = ctxs[0]->group_;
    int rc;
+   /* new species or nonbonded parameters under an uploaded state: class tables, tags and with them the lists first (as ddcmi_eval_forces does for one context;
+    * tools/fuzz_sequence.py's bricks: a group evaluated with the tables of the old parameters) */
+   for (ddcmi_ctx *c : g->ranks) if (c->tables_dirty && (rc = nb_tables(c))) return rc;
    bool valid = true;
    for (ddcmi_ctx *c : g->ranks) valid = valid && c->list_valid;
    if (!valid) { if ((rc = group_rebuild(g))) return rc; }
@@ -1220,6 +1223,8 @@ extern "C" int ddcmi_group_step_nglf(ddcmi_ctx **ctxs, int n, double dt, int nst
    ddcmi_group *g = ctxs[0]->group_;
    int rc;
    ARGCHK(ctxs[0], nsteps < 0 || !std::isfinite(dt), "ddcmi_group_step_nglf: %d steps of dt = %g", nsteps, dt);
+   for (ddcmi_ctx *c : g->ranks)
+      if (!c->forces_valid) SETERR(ctxs[0], DDCMI_EINVAL, "ddcmi_group_step_nglf needs forces: call ddcmi_group_eval_forces first (firstEnergyCall, masters.c:579)");
    for (ddcmi_ctx *c : g->ranks) if ((rc = mg_check_one_domain_features(c))) return rc;
    for (int s = 0; s < nsteps; s++)
    {

@@ -62,3 +62,14 @@ def test_a_pass_of_the_call_sequence_fuzz():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sequence.py"), "16", "1", "24"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.strip().splitlines()[-6:])
     assert r.returncode == 0 and " 0 differ from a fresh context" in tail, tail + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("family", ["bricks", "loopback"])
+def test_call_sequences_on_decomposed_contexts(family):
+    """the same on 2x2x2 bricks of an in-process group and on a rank of the RCCL loopback (the calls a decomposed run can take in mid-run: neighbour settings, cut-off,
+    LJ entries, charges, masses, thermostats, molecule tables).  The group used to evaluate with the class tables of the old parameters (its rebuild does not pass
+    through ddcmi_build_list); it refreshes them like ddcmi_eval_forces now, and its step asks for forces that are valid"""
+    env = dict(os.environ, FUZZ_ONLY=family)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sequence.py"), "8", "21", "24"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    tail = "\n".join(r.stdout.strip().splitlines()[-6:])
+    assert r.returncode == 0 and " 0 differ from a fresh context" in tail, tail + r.stderr[-2000:]

@@ -46,14 +46,59 @@ def base(which):
     return s
 
 
+class GroupMD(object):
+    """the lipid deck on 2x2x2 bricks of an in-process group behind the calls the sequences make (the state comes back gathered, in gid = caller order)"""
+    def __init__(self, s):
+        self.g = martini.MartiniGroup(s, (2, 2, 2))
+        self.lib, self.ctxs, self.s = self.g.lib, [r.ctx for r in self.g.ranks], s
+        self.step, self.eval_forces, self.energies, self.close = self.g.step, self.g.eval_forces, self.g.energies, self.g.close
+        assert np.array_equal(np.sort(np.asarray(s.gid)), np.asarray(s.gid))
+
+    def download(self):
+        st = self.g.gather()
+        return {"r": st["r"], "v": st["v"], "f": st["f"]}
+
+    def build_list(self):      # (a group rebuilds when a list is not valid: the neighbour settings again, unchanged, say so)
+        for r in self.g.ranks:
+            r._chk(self.lib.ddcmi_set_neighbor(r.ctx, r.s.deltaR, int(r.s.updateRate)))
+
+    def _chk(self, rc):
+        self.g._chk(rc)
+
+
+class LoopbackMD(object):
+    """the lipid deck on ONE rank whose periodic neighbours are reached through a 1-rank RCCL communicator (DDCMI_RCCL_LOOPBACK=1): the transport path --
+    count rounds, grouped ncclSend / ncclRecv, terms by gid, the halo staged from the receive buffer -- behind the same calls"""
+    def __init__(self, s):
+        os.environ["DDCMI_RCCL_LOOPBACK"] = "1"
+        try:
+            self.m = m = martini.MartiniRank(s, np.arange(s.natoms))
+            martini._declare_domains(m.lib)
+            buf = ctypes.create_string_buffer(128)
+            m._chk(m.lib.ddcmi_comm_unique_id(buf))
+            m.comm_init(0, 1, buf.raw, (1, 1, 1))
+            m.upload_local()
+        finally:
+            del os.environ["DDCMI_RCCL_LOOPBACK"]
+        self.lib, self.ctx, self.s = m.lib, m.ctx, s
+        self.step, self.eval_forces, self.energies, self.close, self._chk, self.build_list = m.step, m.eval_forces, m.energies, m.close, m._chk, m.build_list
+        assert np.array_equal(np.sort(np.asarray(s.gid)), np.asarray(s.gid))
+
+    def download(self):
+        p = self.m.download_particles()
+        o = np.argsort(p["gid"], kind="stable")
+        return {k: [a[o] for a in p[k]] for k in ("r", "v", "f")}
+
+
 class Live(object):
-    def __init__(self, s, rnd):
+    def __init__(self, s, rnd, group=False):
+        self.group = group
         self.s, self.rnd = copy.deepcopy(s), rnd
         self.terms = {k: np.array(v) for k, v in martini.expand_bonded_terms(s).items()}
         self.molecules_on = s.nmoltype > 0
         self.npt = hasattr(s, "baro")
         self.cons_on = self.baro_on = False
-        self.md = self.make(self.s, self.terms, self.molecules_on)
+        self.md = (LoopbackMD(self.s) if group == "loopback" else GroupMD(self.s)) if group else self.make(self.s, self.terms, self.molecules_on)
         self.log = []
 
     @staticmethod
@@ -70,6 +115,13 @@ class Live(object):
 
     def chk(self, rc):
         self.md._chk(rc)
+
+    def each(self, call):
+        """a setter on the context -- on every domain's context of an in-process group"""
+        for ctx in (self.md.ctxs if hasattr(self.md, "ctxs") else [self.md.ctx]):
+            rc = call(self.md.lib, ctx)
+            if rc != 0:
+                raise martini.DdcmiError("ddcmi error %d: %s" % (rc, self.md.lib.ddcmi_last_error(ctx).decode()))
 
     def state(self):
         d = self.md.download()
@@ -94,13 +146,15 @@ class Live(object):
         s.deltaR = float(s.deltaR * self.rnd.choice([0.5, 1.0, 1.25]))
         s.deltaR = min(max(s.deltaR, 2.0), 0.45 * min(s.h[0], s.h[4], s.h[8]) - s.rmax)
         s.updateRate = self.rnd.choice([0, 1, 5, 10, 20])
-        self.chk(self.md.lib.ddcmi_set_neighbor(self.md.ctx, s.deltaR, int(s.updateRate)))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_neighbor(ctx_, s.deltaR, int(s.updateRate)))
+        for r in getattr(getattr(self.md, "g", None), "ranks", []):
+            r.s.deltaR, r.s.updateRate = s.deltaR, s.updateRate
         return "set_neighbor deltaR %.3f updateRate %d" % (s.deltaR, s.updateRate)
 
     def op_rmax(self):
         s = self.s
         s.rmax = float(min(s.rmax * self.rnd.choice([0.85, 1.0, 1.1]), 0.45 * min(s.h[0], s.h[4], s.h[8]) - s.deltaR))
-        self.chk(self.md.lib.ddcmi_set_nonbonded(self.md.ctx, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)), s.rmax, s.keR, s.krf, s.crf))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_nonbonded(ctx_, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)), s.rmax, s.keR, s.krf, s.crf))
         return "set_nonbonded rmax %.3f" % s.rmax
 
     def op_table(self):
@@ -108,7 +162,7 @@ class Live(object):
         k = self.rnd.randrange(s.eps.size)
         s.eps[k] *= self.rnd.choice([0.5, 1.0, 2.0])
         s.eps = 0.5 * (s.eps.reshape(s.nlj, s.nlj) + s.eps.reshape(s.nlj, s.nlj).T).ravel()      # (the table is symmetric)
-        self.chk(self.md.lib.ddcmi_set_nonbonded(self.md.ctx, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)), s.rmax, s.keR, s.krf, s.crf))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_nonbonded(ctx_, s.nlj, _d(f64(s.sigma)), _d(f64(s.eps)), _d(f64(s.shift)), s.rmax, s.keR, s.krf, s.crf))
         return "set_nonbonded eps[%d]" % k
 
     def op_species(self):
@@ -118,7 +172,7 @@ class Live(object):
         elif what == "charges_half": s.charge[:] = 0.5 * self.charge0
         elif what == "charges_back": s.charge[:] = self.charge0
         else: s.mass[self.rnd.randrange(s.nspecies)] *= self.rnd.choice([0.5, 2.0])
-        self.chk(self.md.lib.ddcmi_set_species(self.md.ctx, s.nspecies, _d(f64(s.mass)), _d(f64(s.charge)), _i(i32(s.ljtype)), _i(i32(s.moltype))))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_species(ctx_, s.nspecies, _d(f64(s.mass)), _d(f64(s.charge)), _i(i32(s.ljtype)), _i(i32(s.moltype))))
         return "set_species " + what
 
     def op_terms(self):
@@ -141,7 +195,7 @@ class Live(object):
         self.terms = t
         nb, na, nt = t["bond_kb"].size, t["angle_k"].size, t["tors_k"].size
         z = np.zeros(4, np.int32)
-        self.chk(self.md.lib.ddcmi_set_bonded(self.md.ctx, nb, _i(t["bond_ij"] if nb else z), _d(t["bond_kb"]), _d(t["bond_b0"]),
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_bonded(ctx_, nb, _i(t["bond_ij"] if nb else z), _d(t["bond_kb"]), _d(t["bond_b0"]),
                                               na, _i(t["angle_ijk"] if na else z), _i(t["angle_func"] if na else z), _d(t["angle_k"]), _d(t["angle_t0"]),
                                               nt, _i(t["tors_ijkl"] if nt else z), _i(t["tors_func"] if nt else z), _i(t["tors_n"] if nt else z), _d(t["tors_k"]), _d(t["tors_delta"]),
                                               int(self.s.excludePotentialTerm)))
@@ -154,9 +208,9 @@ class Live(object):
             bi, bj = i32(s.bpairI), i32(s.bpairJ)
             if bi.size == 0:
                 bi = bj = np.zeros(1, np.int32)
-            self.chk(self.md.lib.ddcmi_set_molecules(self.md.ctx, s.nmoltype, _i(i32(s.mol_nspecies)), _i(i32(s.bpair_off)), _i(bi), _i(bj)))
+            self.each(lambda lib_, ctx_: lib_.ddcmi_set_molecules(ctx_, s.nmoltype, _i(i32(s.mol_nspecies)), _i(i32(s.bpair_off)), _i(bi), _i(bj)))
         else:
-            self.chk(self.md.lib.ddcmi_set_molecules(self.md.ctx, 0, None, None, None, None))
+            self.each(lambda lib_, ctx_: lib_.ddcmi_set_molecules(ctx_, 0, None, None, None, None))
         return "set_molecules %s" % ("on" if self.molecules_on else "off")
 
     def op_groups(self):
@@ -164,7 +218,7 @@ class Live(object):
         kind = self.rnd.choice([0, 1, 2])
         s.group_type = np.full(s.ngroup, kind, np.int32)
         s.group_Teq = np.full(s.ngroup, 1.0e-3); s.group_tau = np.full(s.ngroup, 500.0); s.group_interval = np.ones(s.ngroup, np.int32)
-        self.chk(self.md.lib.ddcmi_set_groups(self.md.ctx, s.ngroup, _i(i32(s.group_type)), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_groups(ctx_, s.ngroup, _i(i32(s.group_type)), _d(f64(s.group_Teq)), _d(f64(s.group_tau)), _i(i32(s.group_interval))))
         return "set_groups %d" % kind
 
     def op_reupload(self):
@@ -188,7 +242,7 @@ class Live(object):
         f = self.rnd.choice([0.99, 1.01, 1.02])
         r, v = self.state()
         s.h = s.h * f
-        self.chk(self.md.lib.ddcmi_set_box(self.md.ctx, _d(f64(s.h)), int(s.pbc)))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_box(ctx_, _d(f64(s.h)), int(s.pbc)))
         self.md.upload(r[0] * f, r[1] * f, r[2] * f, v[0], v[1], v[2])
         return "set_box x %.2f + upload_state" % f
 
@@ -196,7 +250,7 @@ class Live(object):
         s = self.s
         s.nrest = 0 if s.nrest else s.nrest_all
         up = ctypes.POINTER(ctypes.c_uint64)
-        self.chk(self.md.lib.ddcmi_set_restraints(self.md.ctx, int(s.nrest), s.rest_gid.ctypes.data_as(up), _i(i32(np.asarray(s.rest_fc).ravel())), _d(f64(np.asarray(s.rest_r0).ravel())),
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_restraints(ctx_, int(s.nrest), s.rest_gid.ctypes.data_as(up), _i(i32(np.asarray(s.rest_fc).ravel())), _d(f64(np.asarray(s.rest_r0).ravel())),
                                                    _d(f64(s.rest_kb)), int(getattr(s, "rest_origin", 0))))
         return "set_restraints %d" % s.nrest
 
@@ -204,9 +258,9 @@ class Live(object):
         self.cons_on = not self.cons_on
         if self.cons_on:
             po, pi, pj, dd = self._cons = martini.expand_constraints(self.s)
-            self.chk(self.md.lib.ddcmi_set_constraints(self.md.ctx, int(po.size - 1), _i(po), _i(pi), _i(pj), _d(dd)))
+            self.each(lambda lib_, ctx_: lib_.ddcmi_set_constraints(ctx_, int(po.size - 1), _i(po), _i(pi), _i(pj), _d(dd)))
         else:
-            self.chk(self.md.lib.ddcmi_set_constraints(self.md.ctx, 0, None, None, None, None))
+            self.each(lambda lib_, ctx_: lib_.ddcmi_set_constraints(ctx_, 0, None, None, None, None))
         return "set_constraints %s" % ("on" if self.cons_on else "off")
 
     def op_barostat(self):
@@ -214,7 +268,7 @@ class Live(object):
         if self.baro_on:
             self.md.set_barostat(*self.s.baro)
         else:
-            self.chk(self.md.lib.ddcmi_set_barostat(self.md.ctx, 0.0, 0.0, 0.0, 1.0))
+            self.each(lambda lib_, ctx_: lib_.ddcmi_set_barostat(ctx_, 0.0, 0.0, 0.0, 1.0))
         return "set_barostat %s" % ("on" if self.baro_on else "off")
 
     def op_other_system(self):
@@ -228,13 +282,13 @@ class Live(object):
             return "another system: skipped (its box is under 2 (rmax + deltaR))"
         self.s = new
         self.md.s, self.md.n = new, new.natoms
-        self.chk(self.md.lib.ddcmi_set_box(self.md.ctx, _d(f64(new.h)), int(new.pbc)))
+        self.each(lambda lib_, ctx_: lib_.ddcmi_set_box(ctx_, _d(f64(new.h)), int(new.pbc)))
         self.md.upload(new.rx, new.ry, new.rz, new.vx, new.vy, new.vz)
         return "another system: %d beads" % new.natoms
 
     def op_misc(self):
         what = self.rnd.choice(["clock", "timing_on", "timing_off", "stats", "get_list", "kinetic"])
-        if what == "clock": self.chk(self.md.lib.ddcmi_set_clock(self.md.ctx, self.rnd.randrange(0, 1000), 0.0))
+        if what == "clock": self.each(lambda lib_, ctx_: lib_.ddcmi_set_clock(ctx_, self.rnd.randrange(0, 1000), 0.0))
         elif what == "timing_on": self.md.timing(True)
         elif what == "timing_off": self.md.timing(False)
         elif what == "stats": self.md.list_stats()
@@ -282,10 +336,13 @@ def main():
     worst = 0.0
     for q in range(nseq):
         rnd = random.Random(seed * 7919 + q)
-        which = rnd.choice(["lipid", "lipid", "water", "npt"])
-        L = Live(bases[which], rnd)
-        L.charge0 = np.array(bases[which].charge); L.terms0 = {k: np.array(v) for k, v in L.terms.items()}
+        which = rnd.choice(["lipid", "lipid", "water", "npt", "bricks", "loopback"])
+        which = os.environ.get("FUZZ_ONLY", which)      # (FUZZ_ONLY=bricks: only that family)
+        L = Live(bases["lipid" if which in ("bricks", "loopback") else which], rnd, group=(which if which in ("bricks", "loopback") else False))
+        L.charge0 = np.array(L.s.charge); L.terms0 = {k: np.array(v) for k, v in L.terms.items()}
         ops = [L.op_step, L.op_step, L.op_eval, L.op_build, L.op_neighbor, L.op_rmax, L.op_table, L.op_species, L.op_groups, L.op_reupload, L.op_positions, L.op_box, L.op_misc]
+        if which in ("bricks", "loopback"):      # the calls a decomposed run can take in mid-run (terms by gid and the beads stay as they were given)
+            ops = [L.op_step, L.op_step, L.op_eval, L.op_neighbor, L.op_rmax, L.op_table, L.op_species, L.op_species, L.op_groups, L.op_molecules] + ([L.op_build] if which == "loopback" else [])
         if which in ("lipid", "npt"):
             ops += [L.op_terms, L.op_terms, L.op_molecules, L.op_species]
         if which == "water":
