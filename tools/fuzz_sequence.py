@@ -17,6 +17,7 @@ from ddcmd_amd.synth import make_water_setup
 f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
 i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
 VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))
+REPLAYS = []      # the trajectory replays of the checks (Live.check): their differences
 
 
 def base(which):
@@ -318,7 +319,37 @@ class Live(object):
         scale = max(abs(e2["total"]), abs(e2["lj"]), 1e-12)
         eerr = max(abs(e1[k] - e2[k]) for k in e2) / scale
         verr = np.abs(v1 - v2).max() / max(np.abs(v2).max(), 1e-300)
-        return max(ferr, eerr, verr), (ferr, eerr, verr), (e1, e2)
+        err = max(ferr, eerr, verr)
+        # ... and the next steps: a fresh context given the same state, clock and parameters must MOVE like the long-lived one (the integrator's side: drift and
+        # kick bookkeeping, lean steps and their rings, the Langevin noise keyed by gid and loop count).  Not for BERENDSEN groups -- their factor carries the
+        # temperatures published so far, which a fresh context has not seen -- nor while constraint groups or the barostat are on, nor on decomposed contexts.
+        kind = int(np.asarray(self.s.group_type).ravel()[0]) if np.asarray(self.s.group_type).size else 0
+        if err < 1e-9 and not rebuild_first and not self.group and not self.cons_on and not self.baro_on and kind in (0, 2):
+            k = self.rnd.choice([3, 11, 23])
+            s2.loop, s2.time = self.md.clock()
+            s2.lcg64 = None      # (the long-lived context draws from the counter-based stream: its groups were not LANGEVIN when the deck's LCG64 records could have been set)
+            fresh = self.make(s2, self.terms, self.molecules_on)
+            try:
+                fresh.eval_forces()
+                try:
+                    fresh.step(k); self.md.step(k)
+                except martini.DdcmiError as ex:
+                    if "unstable" in str(ex) or "non-finite" in str(ex):
+                        raise      # (both or either: the sequence ends as one the parameters made unstable)
+                    raise
+                da, db = self.md.download(), fresh.download()
+            finally:
+                fresh.close()
+            if self.baro_on is False:
+                Lbox = np.array([self.s.h[0], self.s.h[4], self.s.h[8]])
+                rerr = max(np.abs((da["r"][c] - db["r"][c]) - Lbox[c] * np.rint((da["r"][c] - db["r"][c]) / Lbox[c])).max() for c in range(3)) / Lbox.min()
+                vmax = max(np.abs(db["v"][c]).max() for c in range(3)) + 1e-300
+                terr = max(rerr, max(np.abs(da["v"][c] - db["v"][c]).max() for c in range(3)) / vmax)
+                self.log.append("   + %d steps beside a fresh context: %.1e" % (k, terr))
+                REPLAYS.append(terr)
+                if VERBOSE: print("   ", self.log[-1], flush=True)
+                err = max(err, terr * 1e-2)      # (1e-7 of the box / of the largest speed after up to 23 steps counts as a difference)
+        return err, (ferr, eerr, verr), (e1, e2)
 
 
 def main():
@@ -389,7 +420,8 @@ def main():
             print("sequence %d (%s): ended by the library: %s   after: %s" % (q, which, str(ex)[:160], " | ".join(L.log[-5:])), flush=True)
         finally:
             L.md.close()
-    print("%d sequences of %d calls: %d differ from a fresh context (+ %d checks that met a list gone stale within its fixed cadence); worst difference of the others %.1e" % (nseq, nops, bad, stale, worst))
+    print("%d sequences of %d calls: %d differ from a fresh context (+ %d checks that met a list gone stale within its fixed cadence); worst difference of the others %.1e; %d replays of 3-23 steps beside a fresh context, worst %.1e"
+          % (nseq, nops, bad, stale, worst, len(REPLAYS), max(REPLAYS) if REPLAYS else 0.0))
     sys.exit(1 if bad else 0)
 
 
