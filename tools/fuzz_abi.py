@@ -244,13 +244,29 @@ def loopback_rank(martini, s):
     return md
 
 
+def free_device_bytes():
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    return free.value if hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0 else 0
+
+
 def child(seed, lo, hi):
     import random
     import numpy as np
     import ddcmd_amd.martini as martini
     M = mutations()
     bases = {w: base_setup(w) for w in ("lipid", "water", "npt")}
+    free0 = None
     for case in range(lo, hi):
+        if case == lo + 2:
+            if any(M[c % len(M)][0].startswith("lb_") for c in range(lo, hi)):
+                try:      # (RCCL keeps ~360 MiB of its own for the life of the process from its first exchange on: not a context's)
+                    w = loopback_rank(martini, copy.deepcopy(bases["water"]))
+                    w.eval_forces(); w.step(2); w.close()
+                except Exception:
+                    pass
+            free0 = free_device_bytes()      # (the first cases warm the runtime's own pools)
         rnd = random.Random(seed * 1000003 + case)
         name, f = M[case % len(M)]
         which = rnd.choice(["lipid", "lipid", "water"])
@@ -299,10 +315,18 @@ def child(seed, lo, hi):
         except Exception as ex:      # the Python driver's own checks (shapes, index errors before the library is reached)
             out = "PYTHON %s %s" % (type(ex).__name__, str(ex)[:120].replace("\n", " "))
         print("case %d %s %s -> %s" % (case, which, name, out), flush=True)
+        if os.environ.get("FUZZ_MEM") and free0 is not None:
+            import gc
+            gc.collect()
+            print("      free device memory: %.1f MiB below the mark" % ((free0 - free_device_bytes()) / 1048576.0), flush=True)
+    if free0 is not None:
+        import gc
+        gc.collect()
+        print("device memory after the cases %d..%d: %.1f MiB less free than after the first two" % (lo, hi - 1, (free0 - free_device_bytes()) / 1048576.0), flush=True)
 
 
 def parent(ncases, seed, first=0):
-    died = []
+    died, leaked = [], []
     lo = first
     while lo < ncases:
         hi = min(lo + BATCH, ncases)
@@ -315,6 +339,12 @@ def parent(ncases, seed, first=0):
         done = [l for l in out.splitlines() if " -> " in l]
         for l in done:
             print(l, flush=True)
+        for l in out.splitlines():
+            if l.startswith("device memory after"):
+                mib = float(l.split(":")[1].split()[0])
+                leaked.append(mib)
+                if mib > 64.0:
+                    print(l + "   <-- a context's buffers did not come back", flush=True)
         started = [l for l in out.splitlines() if l.endswith(" ...")]
         if rc != 0 or hung:
             last = started[-1] if started else "case %d (before its first case)" % lo
@@ -325,10 +355,13 @@ def parent(ncases, seed, first=0):
             lo = k + 1
         else:
             lo = hi
-    print("%d cases: %d ended in a result or a message, %d killed or hung their process" % (ncases - first, ncases - first - len(died), len(died)))
+    print("%d cases: %d ended in a result or a message, %d killed or hung their process; device memory not returned by a batch of %d cases: %.1f MiB at worst"
+          % (ncases - first, ncases - first - len(died), len(died), BATCH, max(leaked) if leaked else 0.0))
     for d in died:
         print("   " + d)
-    return 1 if died else 0
+    if os.environ.get("FUZZ_MEM"):
+        print("   MiB not returned per batch:", " ".join("%.0f" % x for x in leaked))
+    return 1 if died or (leaked and max(leaked) > 64.0) else 0
 
 
 if __name__ == "__main__":
