@@ -1442,6 +1442,29 @@ __global__ void k_pf_fill(int n, double *send, double *recv, int rank, int corru
    recv[i] = -1.0;
 }
 static void pf_dir_name(int code, char *b, size_t nb) { snprintf(b, nb, "(%+d,%+d,%+d)", code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1); }
+/* what every rank of a run must have been given alike -- box, cut-offs, tables, species, molecule tables, term counts, groups, the process grid -- as one
+ * 64-bit number (FNV-1a over the values' bytes): the preflight's all-gather carries it, and ranks that read different decks say so before the first step
+ * instead of exchanging halos of different widths */
+static uint64_t mg_param_hash(const ddcmi_ctx *ctx)
+{
+   uint64_t h = 1469598103934665603ull;
+   auto eat = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 1099511628211ull; } };
+   auto vd = [&](const std::vector<double> &v) { const size_t n = v.size(); eat(&n, sizeof(n)); if (n) eat(v.data(), n * sizeof(double)); };
+   auto vi = [&](const std::vector<int> &v) { const size_t n = v.size(); eat(&n, sizeof(n)); if (n) eat(v.data(), n * sizeof(int)); };
+   eat(ctx->h, sizeof(ctx->h)); eat(&ctx->pbc, sizeof(int));
+   eat(&ctx->rmax, sizeof(double)); eat(&ctx->deltaR, sizeof(double)); eat(&ctx->updateRate, sizeof(int));
+   eat(&ctx->keR, sizeof(double)); eat(&ctx->krf, sizeof(double)); eat(&ctx->crf, sizeof(double));
+   eat(&ctx->nlj, sizeof(int)); vd(ctx->sigma); vd(ctx->eps); vd(ctx->shift);
+   eat(&ctx->nspecies, sizeof(int)); vd(ctx->mass); vd(ctx->charge); vi(ctx->ljtype); vi(ctx->moltype);
+   eat(&ctx->nmoltype, sizeof(int));
+   if (ctx->nmoltype > 0) { vi(ctx->mol_nspecies); vi(ctx->bpair_off); vi(ctx->bpairI); vi(ctx->bpairJ); }
+   eat(&ctx->nbond, sizeof(int)); eat(&ctx->nangle, sizeof(int)); eat(&ctx->ntors, sizeof(int)); eat(&ctx->nrest, sizeof(int)); eat(&ctx->ncgroup, sizeof(int));
+   eat(&ctx->excludePotentialTerm, sizeof(int));
+   eat(&ctx->ngroup, sizeof(int)); vi(ctx->gtype); vi(ctx->ginterval); vd(ctx->gTeq); vd(ctx->gtau);
+   eat(&ctx->baro_beta, sizeof(double)); eat(&ctx->baro_tau, sizeof(double));
+   eat(ctx->pgrid, sizeof(ctx->pgrid));
+   return h;
+}
 extern "C" int ddcmi_comm_preflight(ddcmi_ctx *ctx, double timeout_s, int64_t report[16])
 {
    if (!ctx) return DDCMI_EINVAL;
@@ -1488,6 +1511,7 @@ extern "C" int ddcmi_comm_preflight(ddcmi_ctx *ctx, double timeout_s, int64_t re
       hipLaunchKernelGGL(k_pf_fill, dim3(cdiv(27 * PF_N, 256)), dim3(256), 0, st, PF_N, snd, rcv, ctx->rank, ctx->rank == corrupt_rank ? corrupt : -1);
       for (int k = 0; k < 24; k++) h[k] = (double)(ctx->rank + 1) * (double)(k + 1);
       for (int k = 0; k < MG_BLK; k++) hi[k] = ctx->rank * 1000 + k;
+      { const uint64_t ph = mg_param_hash(ctx); hi[MG_BLK - 3] = (int)(unsigned)(ph & 0xffffffffull); hi[MG_BLK - 2] = (int)(unsigned)(ph >> 32); }      /* (words 29, 30: the parameters' hash instead of the pattern) */
       if (hipMemcpyAsync(ar, h.data(), 24 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
           hipMemcpyAsync(ibuf.p, hi.data(), MG_BLK * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { rc = DDCMI_ENODEVICE; msg = "preflight upload"; break; }
       if (ctx->hcomm)
@@ -1598,13 +1622,23 @@ extern "C" int ddcmi_comm_preflight(ddcmi_ctx *ctx, double timeout_s, int64_t re
       /* (3) every rank's block of the all-gather */
       for (int r = 0; r < nr && !rc; r++)
          for (int k = 0; k < MG_BLK; k++)
-            if (hi[MG_BLK + (size_t)MG_BLK * r + k] != r * 1000 + k)
+            if (k != MG_BLK - 3 && k != MG_BLK - 2 && hi[MG_BLK + (size_t)MG_BLK * r + k] != r * 1000 + k)
             {
                char b[256]; snprintf(b, sizeof(b), "preflight: rank %d of %d: the all-gather holds %d at word %d of rank %d's block, expected %d", ctx->rank, nr, hi[MG_BLK + (size_t)MG_BLK * r + k], k, r, r * 1000 + k);
                msg = b; rc = DDCMI_ECOMM; break;
             }
       if (rc) break;
       stage = 3;
+      /* ... and what the block carried: do the ranks run the same system? */
+      for (int r = 0; r < nr && !rc; r++)
+         if (hi[MG_BLK + (size_t)MG_BLK * r + MG_BLK - 3] != hi[MG_BLK - 3] || hi[MG_BLK + (size_t)MG_BLK * r + MG_BLK - 2] != hi[MG_BLK - 2])
+         {
+            char b[384];
+            snprintf(b, sizeof(b), "preflight: rank %d of %d: rank %d was given other parameters than this rank (box, cut-offs, neighbour settings, LJ table, species, molecule tables, "
+                     "term counts, groups, barostat or process grid differ): every rank of a run must be set up from the same deck", ctx->rank, nr, r);
+            msg = b; rc = DDCMI_EINVAL;
+            if (report) { report[3] = 1; report[4] = r; report[5] = -1; }
+         }
    } while (0);
    for (int k = 0; k < 3; k++) if (ev[k]) (void)hipEventDestroy(ev[k]);
    if (side) (void)hipStreamDestroy(side);

@@ -273,7 +273,10 @@ int ddcmi_comm_allreduce_sum(ddcmi_ctx *ctx, double *values, int n);
  * exchange, ddcUpdate.c:56-85 / ddcSendRecv.c:126-225), one 24-double sum all-reduce (energyInfo.c:37) and one int all-gather (the
  * rebuild's count round), each verified on the receiver.  Collective.  On a mismatch, or when timeout_s (<= 0: 60 s) passes without
  * completion, the call returns DDCMI_ECOMM on EVERY rank and ddcmi_last_error says which stage, peer rank and direction failed;
- * after a timeout the RCCL communicator has been aborted (start a fresh process for another transport).
+ * after a timeout the RCCL communicator has been aborted (start a fresh process for another transport).  The all-gather also carries a
+ * hash of what every rank must have been given alike (box, cut-offs, neighbour settings, LJ table, species, molecule tables, term counts,
+ * groups, barostat, process grid: set them BEFORE the preflight): a rank set up from another deck ends the launch with DDCMI_EINVAL on
+ * every rank, named ([4]; [5] = -1).
  * report (may be NULL): [0] distinct peer ranks, [1] directions exchanged, [2] bytes per direction message, [3] 1 if a peer was
  * named, [4] that peer, [5] its direction code, [6] stages verified (3 = all), [7] elapsed microseconds, [8..15] the peer ranks. [sync] */
 int ddcmi_comm_preflight(ddcmi_ctx *ctx, double timeout_s, int64_t report[16]);

@@ -38,6 +38,8 @@ def main():
             s.npt_T, s.npt_P0 = units_convert(310.0, "K"), units_convert(1.0, "bar")
             s.npt_beta, s.npt_tau = units_convert(3.0e-4, "1/bar") * 20.0, units_convert(1.0, "ps")
     owner = domain_of(s, grid)
+    if os.environ.get("DDCMI_TEST_DETUNE_RANK") == str(rank):
+        s.deltaR = s.deltaR * 1.01      # this rank "read another deck": the preflight's parameter check must name it on every rank
     if workload == "water_fault":
         # one bead of the LAST rank is not a number: that rank's list build refuses the state, and every rank must
         # come back from the rebuild with an error instead of waiting for the one that has gone

@@ -116,6 +116,18 @@ def test_preflight_names_the_peer_and_direction_of_a_wrong_message():
     assert "another rank's check of the communicator failed" in errs[1], errs[1]
 
 
+def test_preflight_names_the_rank_that_was_given_other_parameters():
+    """the all-gather of the preflight carries a hash of what every rank must have been given alike (box, cut-offs, neighbour settings, tables, species,
+    molecule tables, term counts, groups, grid): rank 2 of four runs with a skin 1 % wider -- every rank leaves non-zero, and says who differs from it"""
+    rcs, errs = _preflight_ranks((2, 2, 1), {"DDCMI_TEST_DETUNE_RANK": "2"})
+    assert rcs == [4, 4, 4, 4], (rcs, errs)
+    for r, e in enumerate(errs):
+        if r == 2:
+            assert "rank 0 was given other parameters than this rank" in e, e
+        else:
+            assert "rank 2 was given other parameters than this rank" in e and "same deck" in e, e
+
+
 def test_preflight_ends_with_a_deadline_when_a_rank_stays_away():
     """fault injection: rank 1 never joins the exchange; rank 0 must give up at the transport's deadline (3 s here) naming rank 1, not hang"""
     import time
